@@ -1,0 +1,136 @@
+"""ctypes binding of libunitex_hip.so (the C ABI declared in include/unitex_hip.h).
+
+This is the only place the Python host touches native code.  There is NO fallback: if the shared
+library is missing or the device is not gfx950, construction raises.  torch is used purely for device
+memory / streams (tensor.data_ptr(), torch.cuda.current_stream()).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libunitex_hip.so")
+
+c_void_p, c_long, c_int, c_float = C.c_void_p, C.c_long, C.c_int, C.c_float
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("A", c_void_p), ("lda", c_long), ("B", c_void_p), ("ldb", c_long),
+                ("A2", c_void_p), ("lda2", c_long), ("B2", c_void_p), ("ldb2", c_long),
+                ("M", c_int), ("N", c_int), ("K", c_int), ("K2", c_int),
+                ("lora_n_limit", c_int), ("lora_seg_n", c_int), ("alpha", c_float),
+                ("bias", c_void_p), ("gelu_from", c_int), ("gate", c_void_p),
+                ("res", c_void_p), ("ldres", c_long), ("C", c_void_p), ("ldc", c_long),
+                ("n_split", c_int), ("C1", c_void_p), ("ldc1", c_long), ("ntn", c_int)]
+
+
+class GemvDesc(C.Structure):
+    _fields_ = [("x", c_void_p), ("ldx", c_long), ("W", c_void_p), ("ldw", c_long),
+                ("bias", c_void_p), ("y", c_void_p), ("ldy", c_long),
+                ("M", c_int), ("N", c_int), ("K", c_int), ("silu_in", c_int), ("silu_out", c_int)]
+
+
+class QkvPostDesc(C.Structure):
+    _fields_ = [("qkv", c_void_p), ("ld", c_long), ("q_col", c_int), ("k_col", c_int), ("v_col", c_int),
+                ("wq", c_void_p), ("wk", c_void_p), ("cosb", c_void_p), ("sinb", c_void_p),
+                ("Qh", c_void_p), ("Kh", c_void_p), ("Vt", c_void_p),
+                ("hs_qk", c_long), ("hs_v", c_long), ("S_pad", c_long),
+                ("n_tok", c_int), ("tok_off", c_int), ("H", c_int), ("eps", c_float)]
+
+
+class LnModDesc(C.Structure):
+    _fields_ = [("x", c_void_p), ("ldx", c_long), ("shift", c_void_p), ("scale", c_void_p),
+                ("y", c_void_p), ("ldy", c_long), ("n_tok", c_int), ("D", c_int), ("eps", c_float)]
+
+
+class SchedDesc(C.Structure):
+    _fields_ = [("x", c_void_p), ("v", c_void_p), ("cond", c_void_p),
+                ("n_noise_elems", c_long), ("n_total_elems", c_long), ("dsigma", c_float)]
+
+
+ABI_STRUCTS = [GemmDesc, GemvDesc, QkvPostDesc, LnModDesc, SchedDesc]
+
+# every symbol include/unitex_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "utx_version": (c_int, []),
+    "utx_init": (c_int, [c_int, C.POINTER(c_void_p)]),
+    "utx_free": (None, [c_void_p]),
+    "utx_last_error": (C.c_char_p, [c_void_p]),
+    "utx_abi_sizes": (c_int, [C.POINTER(c_int), c_int]),
+    "utx_attn_fwd_bf16": (c_int, [c_void_p] * 5 + [c_long] * 7 + [c_int, c_int, c_float, c_void_p]),
+    "utx_gemm_bf16": (c_int, [c_void_p, C.POINTER(GemmDesc), c_void_p]),
+    "utx_gemv_bf16": (c_int, [c_void_p, C.POINTER(GemvDesc), c_void_p]),
+    "utx_qkv_post": (c_int, [c_void_p, C.POINTER(QkvPostDesc), c_void_p]),
+    "utx_ln_mod": (c_int, [c_void_p, C.POINTER(LnModDesc), c_void_p]),
+    "utx_sched_step": (c_int, [c_void_p, C.POINTER(SchedDesc), c_void_p]),
+}
+
+_lib = None
+
+
+def load_library():
+    """dlopen the C-ABI library and bind prototypes.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libunitex_hip.so not found at %s -- run `python unitex_amd/csrc/build.py` "
+            "(or __graft_entry__.build()). There is no CPU/PyTorch fallback by design." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check_abi():
+    """Compare ctypes struct sizes with the library's sizeof() -- runs without a GPU."""
+    lib = load_library()
+    n = len(ABI_STRUCTS)
+    out = (c_int * n)()
+    m = lib.utx_abi_sizes(out, n)
+    if m != n:
+        raise RuntimeError("ABI mismatch: library reports %d descriptor structs, binding has %d" % (m, n))
+    for i, st in enumerate(ABI_STRUCTS):
+        if C.sizeof(st) != out[i]:
+            raise RuntimeError("ABI mismatch for %s: ctypes %d vs C %d" % (st.__name__, C.sizeof(st), out[i]))
+    return True
+
+
+class Context:
+    """One utx_ctx per device.  All ops are stream-ordered on torch's current stream."""
+
+    def __init__(self, device=0):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("unitex_amd requires an MI355X (gfx950) GPU; no HIP device is visible")
+        self.lib = load_library()
+        check_abi()
+        self.device = int(device)
+        h = c_void_p()
+        rc = self.lib.utx_init(self.device, C.byref(h))
+        if rc != 0:
+            raise RuntimeError("utx_init(device=%d) failed with code %d (need a gfx950 device)" % (device, rc))
+        self.handle = h
+        self._torch = torch
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.utx_free(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def stream(self):
+        return c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)
+
+    def check(self, rc):
+        if rc != 0:
+            raise RuntimeError(self.lib.utx_last_error(self.handle).decode())
+
+
+def ptr(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)

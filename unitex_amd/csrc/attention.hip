@@ -1,0 +1,232 @@
+// bf16 MFMA flash-attention forward for the FLUX joint [text; image] sequence (gfx950).
+//
+// Replaces: torch SDPA call in NativeFluxAttnProcessor2_0.__call__
+//   (/root/reference/flux_piplines/texturing/attention_processor.py:89-91): non-causal, no mask,
+//   no dropout, head_dim 128, softmax scale 1/sqrt(128).
+//
+// Layout (chosen for this kernel, produced by qkv_post.hip):
+//   Q, K : [H][S_pad][128] bf16 (d contiguous)       -- strides passed explicitly
+//   Vt   : [H][128][S_pad] bf16 (keys contiguous)    -- V pre-transposed so that the PV product's
+//                                                       MFMA A-operand is a 16-byte LDS read
+//   O    : [S][H*128] bf16 (token-major; feeds the out-projection GEMM directly)
+//
+// Structure: 512-thread workgroup = 8 waves x 32 query rows = 256 queries; KV tile = 64 keys.
+//   S^T = K Q^T is computed "swapped" (MFMA A = K, B = Q) so each lane owns one query column and
+//   the softmax row reductions are in-register (+ one cross-half exchange).  The K rows inside each
+//   32-key block are read in a permuted order kappa() chosen so that the C-layout of the 32x32x16
+//   MFMA leaves, in each lane, exactly the 8 consecutive keys that the PV MFMA's B-operand wants:
+//   P is converted to bf16 in registers and fed straight to the second MFMA (no LDS round trip,
+//   no permlane).  O^T = Vt P^T accumulates in 4 x f32x16 per lane.
+//   K tile [64][128] and Vt tile [128][64] are staged global->regs->LDS (issue-early / write-late)
+//   into a 2-deep ring with XOR-swizzled 16-byte slots (conflict-free ds_read_b128 lane groups).
+//   One s_barrier per KV tile.
+//
+// Algorithmic FLOPs: 4 * S^2 * 128 per head (QK^T + PV, non-causal).
+#include "common.h"
+#include "kernels.h"
+
+#define ATT_QB 256
+#define ATT_KVB 64
+#define ATT_D 128
+#define ATT_LDS_BYTES (2 * 32768)
+
+
+__global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lq = lane & 31;   // query column owned by this lane (MFMA C column)
+    const int lh = lane >> 5;   // lane half
+
+    // XCD-aware work mapping: consecutive logical ids (= same head) stay on one XCD's L2.
+    const int w = xcd_remap(blockIdx.x, gridDim.x);
+    const int head = w / p.nqb;
+    const int qb = w - head * p.nqb;
+    const int S = p.S;
+
+    const bf16_t* kbase = p.k + (long)head * p.k_hs;
+    const bf16_t* vbase = p.vt + (long)head * p.vt_hs;
+
+    // ---- Q fragments (MFMA B operand): lane (q, h) holds Q[q][16kk + 8h .. +7], kk = 0..7
+    const int q0 = qb * ATT_QB + wave * 32;
+    bf16x8 qf[8];
+    {
+        int qrow = q0 + lq;
+        if (qrow > S - 1) qrow = S - 1;
+        const bf16_t* qp = p.q + (long)head * p.q_hs + (long)qrow * p.q_ss + lh * 8;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(qp + kk * 16);
+    }
+
+    // ---- staging registers (global -> regs -> LDS); named scalars so they stay in VGPRs
+    uint4 kreg0, kreg1, vreg0, vreg1;
+    const int k_row0 = tid >> 4, k_slot = tid & 15;  // + 32 rows on the 2nd pass
+    const int v_d0 = tid >> 3, v_slot = tid & 7;     // + 64 rows on the 2nd pass
+    const bf16_t* vsrc0 = vbase + (long)v_d0 * p.vt_ds + v_slot * 8;
+    const bf16_t* vsrc1 = vbase + (long)(v_d0 + 64) * p.vt_ds + v_slot * 8;
+    const int k_lds0 = k_row0 * 256 + ((k_slot ^ (k_row0 & 15)) << 4);
+    const int k_lds1 = (k_row0 + 32) * 256 + ((k_slot ^ ((k_row0 + 32) & 15)) << 4);
+    const int v_lds0 = v_d0 * 128 + ((v_slot ^ ((v_d0 >> 1) & 7)) << 4);
+    const int v_lds1 = (v_d0 + 64) * 128 + ((v_slot ^ (((v_d0 + 64) >> 1) & 7)) << 4);
+
+#define ATT_LOAD_TILE(t_)                                                                        \
+    do {                                                                                         \
+        const int kv0_ = (t_) * ATT_KVB;                                                         \
+        int r0_ = kv0_ + k_row0, r1_ = kv0_ + k_row0 + 32;                                       \
+        if (r0_ > S - 1) r0_ = S - 1; /* tail rows are masked to -inf later; stay in-bounds */   \
+        if (r1_ > S - 1) r1_ = S - 1;                                                            \
+        kreg0 = *reinterpret_cast<const uint4*>(kbase + (long)r0_ * p.k_ss + k_slot * 8);        \
+        kreg1 = *reinterpret_cast<const uint4*>(kbase + (long)r1_ * p.k_ss + k_slot * 8);        \
+        vreg0 = *reinterpret_cast<const uint4*>(vsrc0 + kv0_);                                   \
+        vreg1 = *reinterpret_cast<const uint4*>(vsrc1 + kv0_);                                   \
+    } while (0)
+#define ATT_STORE_TILE(buf_)                                                                     \
+    do {                                                                                         \
+        char* kb_ = smem + (buf_) * 32768;                                                       \
+        char* vb_ = kb_ + 16384;                                                                 \
+        *reinterpret_cast<uint4*>(kb_ + k_lds0) = kreg0;                                         \
+        *reinterpret_cast<uint4*>(kb_ + k_lds1) = kreg1;                                         \
+        *reinterpret_cast<uint4*>(vb_ + v_lds0) = vreg0;                                         \
+        *reinterpret_cast<uint4*>(vb_ + v_lds1) = vreg1;                                         \
+    } while (0)
+
+    // ---- per-lane LDS read offsets
+    // kappa: MFMA row i = 8a + 4h' + c  ->  key 16(a>>1) + 8h' + 4(a&1) + c   (within a 32-key block)
+    const int ka = lq >> 3, khp = (lq >> 2) & 1, kc = lq & 3;
+    const int krow = 16 * (ka >> 1) + 8 * khp + 4 * (ka & 1) + kc;
+    const int kswz = krow & 15;
+    const int k_off = krow * 256;        // + 32*256*b ; slot (2kk + lh) ^ kswz
+    const int vswz = (lq >> 1) & 7;
+    const int v_off = lq * 128;          // + 32*128*dblk ; slot (2s + lh) ^ vswz
+
+    f32x16 oacc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+    float m_run = -1e30f;  // running max (raw score units)
+    float l_run = 0.f;     // this lane-half's partial row sum
+    const float c2 = p.scale_log2;
+
+    const int nt = (S + ATT_KVB - 1) / ATT_KVB;
+    ATT_LOAD_TILE(0);
+    ATT_STORE_TILE(0);
+    __syncthreads();
+
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt) ATT_LOAD_TILE(t + 1);
+        const char* kb = smem + buf * 32768;
+        const char* vb = kb + 16384;
+
+        // ---- S^T = K Q^T  (2 blocks of 32 keys)
+        f32x16 sacc[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[b][r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(
+                    kb + b * 8192 + k_off + (((2 * kk + lh) ^ kswz) << 4));
+                sacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[kk], sacc[b], 0, 0, 0);
+            }
+        }
+        // lane (q, h): sacc[b][r] = score(key = kv0 + 32b + 16(r>>3) + 8h + (r&7), query q)
+
+        if (t == nt - 1 && (S & (ATT_KVB - 1))) {
+            const int kv0 = t * ATT_KVB;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kv0 + 32 * b + 16 * (r >> 3) + 8 * lh + (r & 7);
+                    if (key >= S) sacc[b][r] = -INFINITY;
+                }
+        }
+
+        // ---- online softmax (per query column; partner half = lane ^ 32)
+        float mx = sacc[0][0];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[b][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
+        const float mc = m_new * c2;
+        m_run = m_new;
+        float psum = 0.f;
+        bf16x8 pb[4];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(sacc[b][r] * c2 - mc);
+                psum += pv;
+                pb[2 * b + (r >> 3)][r & 7] = (__bf16)pv;
+            }
+        l_run = l_run * alpha + psum;
+        if (__any(alpha != 1.0f)) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+        }
+
+        // ---- O^T += Vt P^T   (4 blocks of 32 d, 4 k-steps of 16 keys)
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(
+                    vb + db * 4096 + v_off + (((2 * s + lh) ^ vswz) << 4));
+                oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb[s], oacc[db], 0, 0, 0);
+            }
+        }
+
+        if (t + 1 < nt) ATT_STORE_TILE(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: normalise, convert, store.  lane (q, h) holds O[q][32db + 8a + 4h + c], r = 4a + c
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int qrow = q0 + lq;
+    if (qrow < S) {
+        bf16_t* op = p.o + (long)qrow * p.o_ss + head * ATT_D + 4 * lh;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                uint2 v;
+                v.x = pack2bf(oacc[db][4 * a + 0] * inv, oacc[db][4 * a + 1] * inv);
+                v.y = pack2bf(oacc[db][4 * a + 2] * inv, oacc[db][4 * a + 3] * inv);
+                *reinterpret_cast<uint2*>(op + 32 * db + 8 * a) = v;
+            }
+    }
+}
+
+extern "C" int utx_launch_attn_fwd(const void* q, const void* k, const void* vt, void* o,
+                                   long q_hs, long q_ss, long k_hs, long k_ss, long vt_hs, long vt_ds,
+                                   long o_ss, int H, int S, float scale, hipStream_t stream) {
+    if (S <= 0 || H <= 0) return -1;
+    if ((vt_ds & 7) || (q_ss & 7) || (k_ss & 7) || (o_ss & 3)) return -2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES);
+        if (e != hipSuccess) return -3;
+        attr_set = true;
+    }
+    AttnParams p;
+    p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.vt = (const bf16_t*)vt; p.o = (bf16_t*)o;
+    p.q_hs = q_hs; p.q_ss = q_ss; p.k_hs = k_hs; p.k_ss = k_ss; p.vt_hs = vt_hs; p.vt_ds = vt_ds;
+    p.o_ss = o_ss; p.H = H; p.S = S;
+    p.nqb = (S + ATT_QB - 1) / ATT_QB;
+    p.scale_log2 = scale * 1.4426950408889634f;
+    dim3 grid(p.nqb * H), block(512);
+    hipLaunchKernelGGL(attn_fwd_kernel, grid, block, ATT_LDS_BYTES, stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}

@@ -1,0 +1,78 @@
+"""Build libunitex_hip.so (gfx950) in-tree:  python unitex_amd/csrc/build.py
+
+hipcc cross-compiles for gfx950 without a GPU.  Objects are cached under csrc/_obj keyed on source
+mtime, so a rebuild after touching one kernel takes seconds.  The .so lands in unitex_amd/lib/ (git-
+ignored, but it travels to the GPU box with the gpurun snapshot).
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIBDIR = os.path.normpath(os.path.join(HERE, "..", "lib"))
+OBJDIR = os.path.join(HERE, "_obj")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+
+# (source, extra flags)
+SOURCES = [
+    ("attention.hip", []),
+    ("gemm.hip", []),
+    ("dit_elementwise.hip", ["-ffp-contract=off"]),
+    ("capi.cpp", []),
+]
+GEOM = [
+    ("raster.hip", ["-ffp-contract=off"]),
+    ("bvh.hip", ["-ffp-contract=off"]),
+    ("backproject.hip", ["-ffp-contract=off"]),
+    ("texture_post.hip", ["-ffp-contract=off"]),
+]
+for s in GEOM:
+    if os.path.exists(os.path.join(HERE, s[0])):
+        SOURCES.append(s)
+
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + HERE,
+          "-I" + os.path.normpath(os.path.join(HERE, "..", "..", "include")), "-x", "hip"]
+
+
+def _newer(src, obj):
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    deps = [src] + [os.path.join(HERE, h) for h in os.listdir(HERE) if h.endswith(".h")]
+    deps.append(os.path.normpath(os.path.join(HERE, "..", "..", "include", "unitex_hip.h")))
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(item):
+    name, extra = item
+    src = os.path.join(HERE, name)
+    obj = os.path.join(OBJDIR, name + ".o")
+    if _newer(src, obj):
+        cmd = [HIPCC] + COMMON + extra + ["-c", src, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed for %s:\n%s" % (name, r.stderr[-4000:]))
+    return obj
+
+
+def build(verbose=True):
+    os.makedirs(OBJDIR, exist_ok=True)
+    os.makedirs(LIBDIR, exist_ok=True)
+    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+        objs = list(ex.map(_compile, SOURCES))
+    out = os.path.join(LIBDIR, "libunitex_hip.so")
+    if (not os.path.exists(out)) or any(os.path.getmtime(o) > os.path.getmtime(out) for o in objs):
+        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", out] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s" % r.stderr[-4000:])
+    if verbose:
+        print("built", out)
+    return out
+
+
+if __name__ == "__main__":
+    build()
+    sys.exit(0)

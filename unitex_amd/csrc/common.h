@@ -1,0 +1,53 @@
+// Shared device helpers for the gfx950 kernels of libunitex_hip.so.
+// CDNA4 only: wave = 64 lanes, MFMA 32x32x16 bf16, 160 KiB LDS / CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+#ifndef UTX_BF16_T
+#define UTX_BF16_T
+typedef uint16_t bf16_t;  // raw storage type used across the C ABI
+#endif
+
+#define UTX_WAVE 64
+
+// fp32 -> bf16 round-to-nearest-even on raw bits (NaN kept quiet). Matches torch's
+// float->bfloat16 conversion, which the oracle uses.
+__device__ __forceinline__ uint16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+// round an fp32 value through bf16 (used to mirror the reference's bf16 tensor boundaries)
+__device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Bijective XCD-aware remap (8 XCDs; block b is observed to land on XCD b % 8 -- speed only,
+// never correctness). Returns the logical work id for hardware block id `bid` so that each
+// XCD walks a contiguous chunk of the logical grid.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int nx = 8;
+    int xcd = bid % nx, j = bid / nx;
+    int q = nwg / nx, r = nwg % nx;
+    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + j;
+}

@@ -1,0 +1,202 @@
+// HBM-bound elementwise / normalisation kernels of the FLUX DiT step (gfx950).
+// Compiled with -ffp-contract=off so the fp32 arithmetic is the same sequence of roundings as the
+// CPU oracle (oracle/dit_ref.py), which restates the bf16 tensor boundaries of the reference's
+// diffusers modules [3p].
+#include "common.h"
+#include "kernels.h"
+
+// ---------------------------------------------------------------------------------------------
+// qkv_post: per-head RMSNorm(q), RMSNorm(k), RoPE(q), RoPE(k), head-major relayout, V transpose.
+// Mirrors NativeFluxAttnProcessor2_0.__call__ (/root/reference/flux_piplines/texturing/
+// attention_processor.py:42-87): view [B,S,H,128] -> norm_q/norm_k (RMSNorm eps 1e-6, weight) ->
+// cat(text, image) along S -> apply_rotary_emb (interleaved pairs, fp32 math, cast back).
+//   in : qkv [n_tok][ld] bf16, q at column q_col, k at k_col, v at v_col (each H*128 wide)
+//   out: Qh, Kh [H][S_pad][128];  Vt [H][128][S_pad]  (row = tok_off + token)
+// Block = 256 threads = 64 tokens x 1 head; each lane owns one rotation pair (2 channels).
+
+__global__ __launch_bounds__(256) void qkv_post_kernel(QkvPostParams p) {
+    __shared__ __attribute__((aligned(16))) uint16_t sv[64][130];  // V tile [token][d] (+2 pad)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int head = blockIdx.y;
+    const int t0 = blockIdx.x * 64;
+    const bf16_t* pwq = (const bf16_t*)p.wq; const bf16_t* pwk = (const bf16_t*)p.wk;
+    const float wq0 = bf2f(pwq[2 * lane]), wq1 = bf2f(pwq[2 * lane + 1]);
+    const float wk0 = bf2f(pwk[2 * lane]), wk1 = bf2f(pwk[2 * lane + 1]);
+
+    for (int i = 0; i < 16; ++i) {
+        const int tl = wave * 16 + i;
+        const int tok = t0 + tl;
+        if (tok >= p.n_tok) {  // keep the LDS tile defined for the transpose
+            sv[tl][2 * lane] = 0; sv[tl][2 * lane + 1] = 0;
+            continue;
+        }
+        const bf16_t* row = (const bf16_t*)p.qkv + (long)tok * p.ld + head * 128 + 2 * lane;
+        const long srow = (long)(p.tok_off + tok);
+        const float cs = p.cosb[srow * 64 + lane], sn = p.sinb[srow * 64 + lane];
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            const uint32_t raw = *reinterpret_cast<const uint32_t*>(row + (which ? p.k_col : p.q_col));
+            const float x0 = bf2f((uint16_t)(raw & 0xffff)), x1 = bf2f((uint16_t)(raw >> 16));
+            const float ss = wave_sum(x0 * x0 + x1 * x1);
+            const float rstd = 1.0f / sqrtf(ss / 128.0f + p.eps);
+            const float w0 = which ? wk0 : wq0, w1 = which ? wk1 : wq1;
+            const float a0 = rbf(rbf(x0 * rstd) * w0);
+            const float a1 = rbf(rbf(x1 * rstd) * w1);
+            const float r0 = a0 * cs + (-a1) * sn;
+            const float r1 = a1 * cs + a0 * sn;
+            bf16_t* dst = (bf16_t*)(which ? p.Kh : p.Qh) + (long)head * p.hs_qk + srow * 128 + 2 * lane;
+            *reinterpret_cast<uint32_t*>(dst) = pack2bf(r0, r1);
+        }
+        const uint32_t vraw = *reinterpret_cast<const uint32_t*>(row + p.v_col);
+        sv[tl][2 * lane] = (uint16_t)(vraw & 0xffff);
+        sv[tl][2 * lane + 1] = (uint16_t)(vraw >> 16);
+    }
+    __syncthreads();
+    // transpose-store: thread -> (d = tid>>1, 32 tokens)
+    const int d = tid >> 1, tb = (tid & 1) * 32;
+    bf16_t* vrow = (bf16_t*)p.Vt + (long)head * p.hs_v + (long)d * p.S_pad + p.tok_off + t0 + tb;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int tl = tb + 8 * c;
+        const int valid = p.n_tok - (t0 + tl);  // tokens valid in this chunk of 8
+        if (valid >= 8) {
+            uint4 o;
+            o.x = (uint32_t)sv[tl + 0][d] | ((uint32_t)sv[tl + 1][d] << 16);
+            o.y = (uint32_t)sv[tl + 2][d] | ((uint32_t)sv[tl + 3][d] << 16);
+            o.z = (uint32_t)sv[tl + 4][d] | ((uint32_t)sv[tl + 5][d] << 16);
+            o.w = (uint32_t)sv[tl + 6][d] | ((uint32_t)sv[tl + 7][d] << 16);
+            *reinterpret_cast<uint4*>(vrow + 8 * c) = o;
+        } else {
+            for (int e = 0; e < valid; ++e) vrow[8 * c + e] = sv[tl + e][d];
+        }
+    }
+}
+
+extern "C" int utx_launch_qkv_post(const QkvPostParams* hp, hipStream_t stream) {
+    QkvPostParams p = *hp;
+    if (p.n_tok <= 0 || p.H <= 0) return -1;
+    if ((p.tok_off & 7) || (p.S_pad & 7) || (p.ld & 1)) return -2;
+    dim3 grid((p.n_tok + 63) / 64, p.H);
+    hipLaunchKernelGGL(qkv_post_kernel, grid, dim3(256), 0, stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm (no affine, eps) + AdaLN modulation:  y = bf16( bf16( bf16(LN(x)) * bf16(1+scale) ) + shift )
+// AdaLayerNormZero / ZeroSingle / Continuous of the FLUX blocks [3p, SURVEY 3.4].  One block per token.
+
+__global__ __launch_bounds__(256) void ln_mod_kernel(LnModParams p) {
+    __shared__ float red[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tok = blockIdx.x;
+    const bf16_t* xr = (const bf16_t*)p.x + (long)tok * p.ldx;
+    const int nchunk = p.D >> 3;
+    float v[2][8];
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int c = tid + 256 * it;
+        if (c < nchunk) {
+            const uint4 raw = *reinterpret_cast<const uint4*>(xr + c * 8);
+            const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[it][2 * j] = bf2f((uint16_t)(w[j] & 0xffff));
+                v[it][2 * j + 1] = bf2f((uint16_t)(w[j] >> 16));
+                s += v[it][2 * j] + v[it][2 * j + 1];
+            }
+        }
+    }
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)p.D;
+    float q = 0.f;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int c = tid + 256 * it;
+        if (c < nchunk) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float dlt = v[it][j] - mean; q += dlt * dlt; }
+        }
+    }
+    q = wave_sum(q);
+    if (lane == 0) red[4 + wave] = q;
+    __syncthreads();
+    const float var = (red[4] + red[5] + red[6] + red[7]) / (float)p.D;
+    const float rstd = 1.0f / sqrtf(var + p.eps);
+    bf16_t* yr = (bf16_t*)p.y + (long)tok * p.ldy;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int c = tid + 256 * it;
+        if (c < nchunk) {
+            const uint4 sh = *reinterpret_cast<const uint4*>((const bf16_t*)p.shift + c * 8);
+            const uint4 sc = *reinterpret_cast<const uint4*>((const bf16_t*)p.scale + c * 8);
+            const uint32_t shw[4] = {sh.x, sh.y, sh.z, sh.w};
+            const uint32_t scw[4] = {sc.x, sc.y, sc.z, sc.w};
+            uint32_t ow[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float o[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float shf = bf2f((uint16_t)(e ? (shw[j] >> 16) : (shw[j] & 0xffff)));
+                    const float scf = bf2f((uint16_t)(e ? (scw[j] >> 16) : (scw[j] & 0xffff)));
+                    const float n = rbf((v[it][2 * j + e] - mean) * rstd);
+                    o[e] = rbf(n * rbf(1.0f + scf)) + shf;
+                }
+                ow[j] = pack2bf(o[0], o[1]);
+            }
+            *reinterpret_cast<uint4*>(yr + c * 8) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+        }
+    }
+}
+
+extern "C" int utx_launch_ln_mod(const LnModParams* hp, hipStream_t stream) {
+    LnModParams p = *hp;
+    if (p.n_tok <= 0 || p.D <= 0 || (p.D & 7) || p.D > 4096 || (p.ldx & 7) || (p.ldy & 7)) return -2;
+    hipLaunchKernelGGL(ln_mod_kernel, dim3(p.n_tok), dim3(256), 0, stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Flow-match Euler step + condition re-pin, fused:
+//   x[s] = bf16( float(x[s]) + dsigma * float(v[s]) )   for s <  n_noise   (scheduler.step, fp32 upcast)
+//   x[s] = cond[s - n_noise]                           for s >= n_noise   (re-pin of clean condition tokens)
+// /root/reference/flux_piplines/texturing/pipeline.py:644-645,660  (FlowMatchEulerDiscreteScheduler.step [3p])
+// NB the reference steps ALL tokens and overwrites the tail at the top of the next iteration; the
+// tail's stepped values are never observed, so writing the clean condition directly is equivalent.
+
+__global__ __launch_bounds__(256) void sched_step_kernel(SchedParams p) {
+    const long nchunk = p.n_total_elems >> 3;
+    bf16_t* px = (bf16_t*)p.x; const bf16_t* pv = (const bf16_t*)p.v; const bf16_t* pcond = (const bf16_t*)p.cond;
+    for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < nchunk; c += (long)gridDim.x * blockDim.x) {
+        const long e = c * 8;
+        if (e < p.n_noise_elems) {
+            const uint4 xr = *reinterpret_cast<const uint4*>(px + e);
+            const uint4 vr = *reinterpret_cast<const uint4*>(pv + e);
+            const uint32_t xw[4] = {xr.x, xr.y, xr.z, xr.w};
+            const uint32_t vw[4] = {vr.x, vr.y, vr.z, vr.w};
+            uint32_t ow[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a0 = bf2f((uint16_t)(xw[j] & 0xffff)) + p.dsigma * bf2f((uint16_t)(vw[j] & 0xffff));
+                const float a1 = bf2f((uint16_t)(xw[j] >> 16)) + p.dsigma * bf2f((uint16_t)(vw[j] >> 16));
+                ow[j] = pack2bf(a0, a1);
+            }
+            *reinterpret_cast<uint4*>(px + e) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+        } else if (pcond) {
+            *reinterpret_cast<uint4*>(px + e) = *reinterpret_cast<const uint4*>(pcond + (e - p.n_noise_elems));
+        }
+    }
+}
+
+extern "C" int utx_launch_sched_step(const SchedParams* hp, hipStream_t stream) {
+    SchedParams p = *hp;
+    if (p.n_total_elems <= 0 || (p.n_total_elems & 7) || (p.n_noise_elems & 7)) return -2;
+    long nchunk = p.n_total_elems >> 3;
+    int blocks = (int)((nchunk + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(sched_step_kernel, dim3(blocks), dim3(256), 0, stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}

@@ -1,0 +1,268 @@
+// bf16 MFMA GEMM with fused epilogues for the FLUX DiT linears (gfx950).
+//
+//   C[M,N] = epi( alpha * ( A[M,K] . B[N,K]^T  +  A2[M,K2] . B2[N,K2]^T ) + bias[N] )
+//
+// A = activations (token-major), B = torch Linear weight layout [out, in] -> both operands are
+// K-contiguous.  The optional second K-segment (A2/B2) is the LoRA path: A2 = s * (x A_lora^T)
+// (rank padded to 64), B2 = B_lora; it is consumed by the SAME K-loop / accumulators, i.e. the
+// LoRA up-projection is fused into the base GEMM instead of being a second GEMM + add
+// (peft semantics: /root/reference/pipeline.py:108-112,245,263; targets
+// /root/reference/flux_piplines/texturing/trainer.py:282-295).
+//
+// Epilogues (all applied on y = bf16(alpha*acc + bias), mirroring the bf16 tensor boundary of a
+// bf16 torch Linear):
+//   - GELU(tanh) on columns n >= gelu_from              (FeedForward 'gelu-approximate', proj_mlp)
+//   - gated residual  out = res + gate[n] * y            (AdaLN-Zero gates of the FLUX blocks)
+//   - column split: n >= n_split is written to a second buffer C1[m, n - n_split]
+//                                                        (single-stream block: [qkv | mlp] in one GEMM)
+//
+// Structure: 128x128x64 tile, 4 waves (2x2, 64x64 per wave = 2x2 MFMA 32x32x16 tiles), operands
+// staged HBM -> LDS with global_load_lds (16 B / lane, LDS image linear, XOR swizzle applied on the
+// SOURCE address and on the ds_read address), 2-deep LDS ring, one barrier per K-step.  MFMA is issued
+// "swapped" (A-operand = weight rows) so each lane owns 4 consecutive n for one m; C goes through LDS
+// so global stores / residual loads are full 256-byte rows.
+#include "common.h"
+#include "kernels.h"
+
+#define GM_BM 128
+#define GM_BN 128
+#define GM_BK 64
+#define GM_STAGE_BYTES (2 * GM_BM * GM_BK * 2)  // A tile + B tile = 32 KB
+#define GM_LDS_BYTES (2 * GM_STAGE_BYTES)       // 64 KB
+#define GM_CROW 272                             // epilogue C row stride in bytes (256 + 16 pad)
+
+
+__device__ __forceinline__ float gelu_tanh(float x) {
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    float inner = k0 * (x + k1 * x * x * x);
+    return 0.5f * x * (1.0f + tanhf(inner));
+}
+
+__device__ __forceinline__ void glds16(const bf16_t* g, char* lds) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const bf16_t* pA = (const bf16_t*)p.A; const bf16_t* pB = (const bf16_t*)p.B;
+    const bf16_t* pA2 = (const bf16_t*)p.A2; const bf16_t* pB2 = (const bf16_t*)p.B2;
+    const bf16_t* pbias = (const bf16_t*)p.bias; const bf16_t* pgate = (const bf16_t*)p.gate;
+    const bf16_t* pres = (const bf16_t*)p.res;
+    bf16_t* pC = (bf16_t*)p.C; bf16_t* pC1 = (bf16_t*)p.C1;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    // XCD-aware tile order: consecutive logical tiles share the same A panel (same M tile).
+    const int w = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = w / p.ntn, tn = w - tm * p.ntn;
+    const int m0 = tm * GM_BM, n0 = tn * GM_BN;
+
+    const int nk1 = p.K / GM_BK;
+    const bool lora = (p.K2 > 0) && (n0 < p.lora_n_limit);
+    const int nk = nk1 + (lora ? p.K2 / GM_BK : 0);
+    const long a2_off = lora ? (long)(n0 / p.lora_seg_n) * p.K2 : 0;
+
+    // ---- glds source addressing: wave-instruction i covers tile rows 8i..8i+7 (1 KB of LDS)
+    const int srow_in = lane >> 3, sslot = lane & 7;
+    auto stage = [&](int kt, int buf) {
+        const bf16_t* Ab; const bf16_t* Bb; long la, lb; long kof;
+        if (kt < nk1) { Ab = pA; la = p.lda; Bb = pB; lb = p.ldb; kof = (long)kt * GM_BK; }
+        else { Ab = pA2 + a2_off; la = p.lda2; Bb = pB2; lb = p.ldb2; kof = (long)(kt - nk1) * GM_BK; }
+        char* sa = smem + buf * GM_STAGE_BYTES;
+        char* sb = sa + GM_BM * GM_BK * 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = wave + 4 * j;
+            const int row = 8 * i + srow_in;
+            const int chunk = sslot ^ ((row >> 1) & 7);
+            int gm = m0 + row; if (gm > p.M - 1) gm = p.M - 1;
+            int gn = n0 + row; if (gn > p.N - 1) gn = p.N - 1;
+            glds16(Ab + (long)gm * la + kof + chunk * 8, sa + i * 1024);
+            glds16(Bb + (long)gn * lb + kof + chunk * 8, sb + i * 1024);
+        }
+    };
+
+    f32x16 acc[2][2];  // [ni][mi]  (swapped MFMA: rows = n, cols = m)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // per-lane fragment read offsets (row r, chunk c -> r*128 + ((c ^ ((r>>1)&7)) << 4))
+    int aoff[2], boff[2], aswz[2], bswz[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ra = wm * 64 + i * 32 + l31;
+        const int rb = wn * 64 + i * 32 + l31;
+        aoff[i] = ra * 128; aswz[i] = (ra >> 1) & 7;
+        boff[i] = rb * 128; bswz[i] = (rb >> 1) & 7;
+    }
+
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+        const char* sa = smem + buf * GM_STAGE_BYTES;
+        const char* sb = sa + GM_BM * GM_BK * 2;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8 af[2], bfr[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[i] = *reinterpret_cast<const bf16x8*>(sa + aoff[i] + (((2 * kk + lh) ^ aswz[i]) << 4));
+                bfr[i] = *reinterpret_cast<const bf16x8*>(sb + boff[i] + (((2 * kk + lh) ^ bswz[i]) << 4));
+            }
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ni], af[mi], acc[ni][mi], 0, 0, 0);
+        }
+    }
+    __syncthreads();  // all waves done with the operand ring; reuse LDS for the C tile
+
+    // ---- epilogue phase 1: y = bf16(alpha*acc + bias) (+GELU) -> LDS [128][272 B]
+    // lane (m = l31, h): acc[ni][mi][r] -> n = wn*64 + ni*32 + (r&3) + 8(r>>2) + 4h ; m = wm*64 + mi*32 + l31
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int nl = wn * 64 + ni * 32 + 8 * a + 4 * lh;  // local n of 4 consecutive columns
+            int gn = n0 + nl; if (gn > p.N - 4) gn = (p.N >= 4) ? p.N - 4 : 0;
+            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (pbias) {
+                const uint2 braw = *reinterpret_cast<const uint2*>(pbias + gn);
+                bv[0] = bf2f((uint16_t)(braw.x & 0xffff)); bv[1] = bf2f((uint16_t)(braw.x >> 16));
+                bv[2] = bf2f((uint16_t)(braw.y & 0xffff)); bv[3] = bf2f((uint16_t)(braw.y >> 16));
+            }
+            const bool do_gelu = (n0 + nl) >= p.gelu_from;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                float y[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float v = rbf(acc[ni][mi][4 * a + c] * p.alpha + bv[c]);
+                    if (do_gelu) v = gelu_tanh(v);
+                    y[c] = v;
+                }
+                uint2 o; o.x = pack2bf(y[0], y[1]); o.y = pack2bf(y[2], y[3]);
+                const int ml = wm * 64 + mi * 32 + l31;
+                *reinterpret_cast<uint2*>(smem + ml * GM_CROW + nl * 2) = o;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- epilogue phase 2: full-row (256 B) stores; gated residual fused here
+    const int rslot = tid & 15;      // 16-byte chunk within the 256-byte tile row
+    const int gn0 = n0 + rslot * 8;
+    if (gn0 < p.N) {
+        float gv[8];
+        if (pgate) {
+            const uint4 graw = *reinterpret_cast<const uint4*>(pgate + gn0);
+            const uint32_t gw[4] = {graw.x, graw.y, graw.z, graw.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { gv[2 * c] = bf2f((uint16_t)(gw[c] & 0xffff)); gv[2 * c + 1] = bf2f((uint16_t)(gw[c] >> 16)); }
+        }
+        bf16_t* cbase; long ldc; int cn;
+        if (gn0 >= p.n_split) { cbase = pC1; ldc = p.ldc1; cn = gn0 - p.n_split; }
+        else { cbase = pC; ldc = p.ldc; cn = gn0; }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int ml = (tid >> 4) + 16 * it;
+            const int gm = m0 + ml;
+            if (gm < p.M) {
+                uint4 yv = *reinterpret_cast<const uint4*>(smem + ml * GM_CROW + rslot * 16);
+                if (pgate) {
+                    const uint4 rv = *reinterpret_cast<const uint4*>(pres + (long)gm * p.ldres + gn0);
+                    uint32_t yw[4] = {yv.x, yv.y, yv.z, yv.w};
+                    const uint32_t rw[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float y0 = bf2f((uint16_t)(yw[c] & 0xffff)), y1 = bf2f((uint16_t)(yw[c] >> 16));
+                        const float r0 = bf2f((uint16_t)(rw[c] & 0xffff)), r1 = bf2f((uint16_t)(rw[c] >> 16));
+                        const float o0 = r0 + rbf(gv[2 * c] * y0);
+                        const float o1 = r1 + rbf(gv[2 * c + 1] * y1);
+                        yw[c] = pack2bf(o0, o1);
+                    }
+                    yv = make_uint4(yw[0], yw[1], yw[2], yw[3]);
+                }
+                *reinterpret_cast<uint4*>(cbase + (long)gm * ldc + cn) = yv;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Small-M path (M <= 8): y[m, n] = act_out( sum_k act_in(x[m,k]) * W[n,k] + b[n] ), one wave per n.
+// Used for the timestep / guidance / pooled-text embedders and all AdaLN modulation linears
+// (M = batch = 1): pure weight streaming, HBM-bound.
+
+__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+
+__global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvParams p) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= p.N) return;
+    const bf16_t* wrow = (const bf16_t*)p.W + (long)n * p.ldw;
+    const bf16_t* pbias = (const bf16_t*)p.bias;
+    for (int m = 0; m < p.M; ++m) {
+        const bf16_t* xr = (const bf16_t*)p.x + (long)m * p.ldx;
+        float s = 0.f;
+        for (int k = lane * 8; k < p.K; k += 64 * 8) {
+            const uint4 wv = *reinterpret_cast<const uint4*>(wrow + k);
+            const uint4 xv = *reinterpret_cast<const uint4*>(xr + k);
+            const uint32_t ww[4] = {wv.x, wv.y, wv.z, wv.w};
+            const uint32_t xw[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float x0 = bf2f((uint16_t)(xw[c] & 0xffff)), x1 = bf2f((uint16_t)(xw[c] >> 16));
+                if (p.silu_in) { x0 = rbf(silu_f(x0)); x1 = rbf(silu_f(x1)); }
+                s += x0 * bf2f((uint16_t)(ww[c] & 0xffff));
+                s += x1 * bf2f((uint16_t)(ww[c] >> 16));
+            }
+        }
+        s = wave_sum(s);
+        if (lane == 0) {
+            float v = s + (pbias ? bf2f(pbias[n]) : 0.f);
+            v = rbf(v);
+            if (p.silu_out) v = silu_f(v);
+            ((bf16_t*)p.y)[(long)m * p.ldy + n] = f2bf(v);
+        }
+    }
+}
+
+extern "C" int utx_launch_gemm_bf16(const GemmParams* hp, hipStream_t stream) {
+    GemmParams p = *hp;
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0) return -1;
+    if ((p.K % GM_BK) || (p.K2 % GM_BK) || (p.N % 8)) return -2;
+    if ((p.lda & 7) || (p.ldb & 7) || (p.ldc & 7)) return -2;
+    if (p.K2 > 0 && (!p.A2 || !p.B2 || (p.lda2 & 7) || (p.ldb2 & 7) || p.lora_seg_n <= 0 || (p.lora_seg_n % GM_BN))) return -2;
+    if (p.gate && (!p.res || (p.ldres & 7))) return -2;
+    if (p.n_split < p.N && (!p.C1 || (p.n_split % GM_BN) || (p.ldc1 & 7))) return -2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, GM_LDS_BYTES) != hipSuccess) return -3;
+        attr_set = true;
+    }
+    const int ntm = (p.M + GM_BM - 1) / GM_BM;
+    p.ntn = (p.N + GM_BN - 1) / GM_BN;
+    hipLaunchKernelGGL(gemm_bf16_kernel, dim3(ntm * p.ntn), dim3(256), GM_LDS_BYTES, stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+extern "C" int utx_launch_gemv_bf16(const GemvParams* hp, hipStream_t stream) {
+    GemvParams p = *hp;
+    if (p.M <= 0 || p.M > 8 || p.N <= 0 || p.K <= 0 || (p.K % 8) || (p.ldw & 7) || (p.ldx & 7)) return -2;
+    hipLaunchKernelGGL(gemv_bf16_kernel, dim3((p.N + 3) / 4), dim3(256), 0, stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}

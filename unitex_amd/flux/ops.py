@@ -1,0 +1,136 @@
+"""Functional wrappers over the C ABI for the DiT ops (tensor in / tensor out).
+
+These are what the parity tests call; FluxDiT (transformer.py) uses pre-built descriptors instead.
+All tensors are torch CUDA tensors (bf16 unless stated); nothing here computes on the host.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from .. import _lib
+from .._lib import GemmDesc, GemvDesc, LnModDesc, QkvPostDesc, SchedDesc, ptr
+
+_CTX = {}
+
+
+def get_ctx(device=None):
+    if device is None:
+        device = torch.cuda.current_device()
+    if device not in _CTX:
+        _CTX[device] = _lib.Context(device)
+    return _CTX[device]
+
+
+def _bf(t):
+    assert t.is_cuda and t.dtype == torch.bfloat16, "expected a CUDA bf16 tensor"
+    return t
+
+
+def attention(q, k, vt, S=None, scale=None, out=None, o_ss=None):
+    """q,k [H,S_pad,128]; vt [H,128,S_pad] (S_pad multiple of 64, zero padded) -> o [S, H*128]."""
+    ctx = get_ctx(q.device.index)
+    H, S_pad, D = q.shape
+    assert D == 128 and vt.shape[1] == 128 and vt.shape[2] % 64 == 0
+    S = S_pad if S is None else S
+    if scale is None:
+        scale = 1.0 / math.sqrt(D)
+    if out is None:
+        out = torch.empty(S, H * D, dtype=torch.bfloat16, device=q.device)
+    if o_ss is None:
+        o_ss = out.stride(0)
+    rc = ctx.lib.utx_attn_fwd_bf16(ctx.handle, ptr(_bf(q)), ptr(_bf(k)), ptr(_bf(vt)), ptr(out),
+                                   q.stride(0), q.stride(1), k.stride(0), k.stride(1),
+                                   vt.stride(0), vt.stride(1), o_ss, H, S, float(scale), ctx.stream())
+    ctx.check(rc)
+    return out
+
+
+def make_gemm_desc(A, B, C_out, bias=None, A2=None, B2=None, lora_n_limit=None, lora_seg_n=None, alpha=1.0,
+                   gelu_from=None, gate=None, res=None, n_split=None, C1=None):
+    M, K = A.shape
+    N = B.shape[0]
+    d = GemmDesc()
+    d.A, d.lda, d.B, d.ldb = ptr(A), A.stride(0), ptr(B), B.stride(0)
+    if A2 is not None:
+        d.A2, d.lda2, d.B2, d.ldb2 = ptr(A2), A2.stride(0), ptr(B2), B2.stride(0)
+        d.K2 = B2.shape[1]
+        d.lora_n_limit = N if lora_n_limit is None else lora_n_limit
+        d.lora_seg_n = N if lora_seg_n is None else lora_seg_n
+    else:
+        d.K2, d.lora_n_limit, d.lora_seg_n = 0, 0, 128
+    d.M, d.N, d.K = M, N, K
+    d.alpha = alpha
+    d.bias = ptr(bias)
+    d.gelu_from = N if gelu_from is None else gelu_from
+    d.gate = ptr(gate)
+    if gate is not None:
+        d.res, d.ldres = ptr(res), res.stride(0)
+    d.C, d.ldc = ptr(C_out), C_out.stride(0)
+    d.n_split = N if n_split is None else n_split
+    if C1 is not None:
+        d.C1, d.ldc1 = ptr(C1), C1.stride(0)
+    return d
+
+
+def gemm(A, B, bias=None, out=None, **kw):
+    """out = epi(alpha*(A B^T + A2 B2^T) + bias); see make_gemm_desc / gemm.hip for the epilogues."""
+    ctx = get_ctx(A.device.index)
+    M, N = A.shape[0], B.shape[0]
+    n_split = kw.get("n_split")
+    if out is None:
+        out = torch.empty(M, N if n_split is None else n_split, dtype=torch.bfloat16, device=A.device)
+    d = make_gemm_desc(_bf(A), _bf(B), out, bias=bias, **kw)
+    ctx.check(ctx.lib.utx_gemm_bf16(ctx.handle, C.byref(d), ctx.stream()))
+    return out
+
+
+def gemv(x, W, bias=None, silu_in=False, silu_out=False, out=None):
+    ctx = get_ctx(x.device.index)
+    M, K = x.shape
+    N = W.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
+    d = GemvDesc()
+    d.x, d.ldx, d.W, d.ldw, d.bias = ptr(_bf(x)), x.stride(0), ptr(_bf(W)), W.stride(0), ptr(bias)
+    d.y, d.ldy, d.M, d.N, d.K = ptr(out), out.stride(0), M, N, K
+    d.silu_in, d.silu_out = int(silu_in), int(silu_out)
+    ctx.check(ctx.lib.utx_gemv_bf16(ctx.handle, C.byref(d), ctx.stream()))
+    return out
+
+
+def qkv_post(qkv, q_col, k_col, v_col, wq, wk, cos, sin, Qh, Kh, Vt, n_tok, tok_off, H, eps=1e-6):
+    ctx = get_ctx(qkv.device.index)
+    d = QkvPostDesc()
+    d.qkv, d.ld = ptr(_bf(qkv)), qkv.stride(0)
+    d.q_col, d.k_col, d.v_col = q_col, k_col, v_col
+    d.wq, d.wk = ptr(_bf(wq)), ptr(_bf(wk))
+    assert cos.dtype == torch.float32 and sin.dtype == torch.float32 and cos.is_contiguous()
+    d.cosb, d.sinb = ptr(cos), ptr(sin)
+    d.Qh, d.Kh, d.Vt = ptr(Qh), ptr(Kh), ptr(Vt)
+    d.hs_qk, d.hs_v, d.S_pad = Qh.stride(0), Vt.stride(0), Vt.shape[2]
+    d.n_tok, d.tok_off, d.H, d.eps = n_tok, tok_off, H, eps
+    ctx.check(ctx.lib.utx_qkv_post(ctx.handle, C.byref(d), ctx.stream()))
+
+
+def ln_mod(x, shift, scale, out=None, eps=1e-6):
+    ctx = get_ctx(x.device.index)
+    if out is None:
+        out = torch.empty_like(x)
+    d = LnModDesc()
+    d.x, d.ldx, d.shift, d.scale = ptr(_bf(x)), x.stride(0), ptr(_bf(shift)), ptr(_bf(scale))
+    d.y, d.ldy, d.n_tok, d.D, d.eps = ptr(out), out.stride(0), x.shape[0], x.shape[1], eps
+    ctx.check(ctx.lib.utx_ln_mod(ctx.handle, C.byref(d), ctx.stream()))
+    return out
+
+
+def sched_step(x, v, dsigma, n_noise_tokens=None, cond=None):
+    """in-place: x[:n_noise] += dsigma * v[:n_noise] (fp32 math); x[n_noise:] = cond."""
+    ctx = get_ctx(x.device.index)
+    tok, ch = x.shape
+    n_noise = tok if n_noise_tokens is None else n_noise_tokens
+    d = SchedDesc()
+    d.x, d.v, d.cond = ptr(_bf(x)), ptr(_bf(v)), ptr(cond)
+    d.n_noise_elems, d.n_total_elems, d.dsigma = n_noise * ch, tok * ch, float(dsigma)
+    ctx.check(ctx.lib.utx_sched_step(ctx.handle, C.byref(d), ctx.stream()))
+    return x

@@ -1,0 +1,436 @@
+"""FluxDiT -- host-side driver of the FLUX.1-dev transformer forward on MI355X.
+
+Mirrors the call signature of diffusers' FluxTransformer2DModel.forward as used by the reference
+(/root/reference/flux_piplines/texturing/pipeline.py:646-656) for batch size 1.  All compute is HIP:
+the forward is a pre-built *plan* -- a flat list of (C-ABI entry point, descriptor) pairs over
+pre-allocated HBM workspaces -- replayed once per denoise step (and capturable into a hipGraph, since
+every launch is ordered on torch's current stream and nothing synchronises).
+
+Weight packing (done once at load):
+  double block : Wqkv_x = [to_q; to_k; to_v], Wqkv_c = [add_q; add_k; add_v]      -> one GEMM each
+  single block : Wqkvm  = [to_q; to_k; to_v; proj_mlp]                            -> one GEMM, split epilogue
+  every AdaLN modulation Linear of every block is concatenated into ONE [N_mod, D] matrix: all
+  shift/scale/gate vectors of a step come from a single weight-streaming GEMV.
+LoRA (peft semantics, reference pipeline.py:108-112,245,263): adapters stay un-merged; the active ones
+are concatenated along the rank axis (padded to 64) and consumed as an extra K-segment of the base GEMM.
+"""
+import ctypes as C
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from .. import _lib
+from .._lib import GemvDesc, LnModDesc, QkvPostDesc, ptr
+from . import ops
+
+BF16 = torch.bfloat16
+
+LORA_TARGETS_DOUBLE = ["attn.to_q", "attn.to_k", "attn.to_v", "attn.to_out.0", "attn.add_q_proj",
+                       "attn.add_k_proj", "attn.add_v_proj", "attn.to_add_out", "ff.net.0.proj", "ff.net.2",
+                       "ff_context.net.0.proj", "ff_context.net.2"]
+
+
+class FluxShape:
+    """FLUX.1-dev transformer hyper-parameters [3p config]; head_dim must be 128."""
+
+    def __init__(self, num_heads=24, num_double=19, num_single=38, in_channels=64, joint_dim=4096,
+                 pooled_dim=768, axes_dim=(16, 56, 56), theta=10000.0, mlp_ratio=4, guidance_embeds=True):
+        self.num_heads, self.head_dim = num_heads, 128
+        self.num_double, self.num_single = num_double, num_single
+        self.in_channels, self.joint_dim, self.pooled_dim = in_channels, joint_dim, pooled_dim
+        self.axes_dim, self.theta, self.mlp_ratio = tuple(axes_dim), theta, mlp_ratio
+        self.guidance_embeds = guidance_embeds
+        self.dim = num_heads * 128
+        assert sum(self.axes_dim) == 128
+
+
+def _pad64(n):
+    return (n + 63) // 64 * 64
+
+
+def rope_tables(ids: torch.Tensor, axes_dim, theta):
+    """FluxPosEmbed [3p]: float64 angles -> float32 cos/sin, one column per rotation pair: [S, 64]."""
+    cos, sin = [], []
+    pos = ids.detach().to("cpu", torch.float64)
+    for a, d in enumerate(axes_dim):
+        freqs = 1.0 / (theta ** (torch.arange(0, d, 2, dtype=torch.float64) / d))
+        ang = pos[:, a][:, None] * freqs[None, :]
+        cos.append(torch.cos(ang).to(torch.float32))
+        sin.append(torch.sin(ang).to(torch.float32))
+    return torch.cat(cos, dim=-1).contiguous(), torch.cat(sin, dim=-1).contiguous()
+
+
+def _timestep_proj(value_bf16_scaled: float):
+    """sinusoidal embedding of a scalar (diffusers Timesteps(256, flip_sin_to_cos=True, shift 0) [3p])."""
+    half = 128
+    exponent = -math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half
+    emb = torch.tensor([value_bf16_scaled], dtype=torch.float32)[:, None] * torch.exp(exponent)[None, :]
+    return torch.cat([torch.cos(emb), torch.sin(emb)], dim=-1).to(BF16)
+
+
+def _bf16_scalar(x: float) -> float:
+    return float(torch.tensor(x, dtype=torch.float32).to(BF16).to(torch.float32))
+
+
+class FluxDiT:
+    def __init__(self, state_dict: Dict[str, torch.Tensor], shape: Optional[FluxShape] = None, device="cuda:0"):
+        self.shape = shape or FluxShape()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("FluxDiT runs on an MI355X only (device must be cuda:N); there is no CPU path")
+        self.ctx = ops.get_ctx(self.device.index or 0)
+        self.lib = self.ctx.lib
+        self._plans = {}
+        self._lora_active: List[Tuple[Dict, float]] = []
+        self._lora_version = 0
+        self._pack(state_dict)
+
+    # ------------------------------------------------------------------ weights
+    def _t(self, sd, name):
+        if name not in sd:
+            raise KeyError("missing weight '%s' (expected diffusers FluxTransformer2DModel key names)" % name)
+        return sd[name].to(device=self.device, dtype=BF16)
+
+    def _cat(self, sd, names, suffix):
+        return torch.cat([self._t(sd, n + suffix) for n in names], dim=0).contiguous()
+
+    def _pack(self, sd):
+        sh, D = self.shape, self.shape.dim
+        W = {}
+        for nm in ("x_embedder", "context_embedder", "proj_out"):
+            W[nm + ".w"], W[nm + ".b"] = self._t(sd, nm + ".weight").contiguous(), self._t(sd, nm + ".bias")
+        emb = ["timestep_embedder", "text_embedder"] + (["guidance_embedder"] if sh.guidance_embeds else [])
+        for nm in emb:
+            for l in ("linear_1", "linear_2"):
+                k = "time_text_embed.%s.%s" % (nm, l)
+                W[k + ".w"], W[k + ".b"] = self._t(sd, k + ".weight").contiguous(), self._t(sd, k + ".bias")
+        mod_w, mod_b, self.mod_off = [], [], {}
+        off = 0
+
+        def add_mod(key, name):
+            nonlocal off
+            w = self._t(sd, name + ".weight")
+            mod_w.append(w)
+            mod_b.append(self._t(sd, name + ".bias"))
+            self.mod_off[key] = off
+            off += w.shape[0]
+
+        self.double, self.single = [], []
+        for i in range(sh.num_double):
+            p = "transformer_blocks.%d." % i
+            add_mod(("d", i, "x"), p + "norm1.linear")
+            add_mod(("d", i, "c"), p + "norm1_context.linear")
+            b = {}
+            b["qkv_x.w"] = self._cat(sd, [p + "attn.to_q", p + "attn.to_k", p + "attn.to_v"], ".weight")
+            b["qkv_x.b"] = self._cat(sd, [p + "attn.to_q", p + "attn.to_k", p + "attn.to_v"], ".bias")
+            b["qkv_c.w"] = self._cat(sd, [p + "attn.add_q_proj", p + "attn.add_k_proj", p + "attn.add_v_proj"], ".weight")
+            b["qkv_c.b"] = self._cat(sd, [p + "attn.add_q_proj", p + "attn.add_k_proj", p + "attn.add_v_proj"], ".bias")
+            for short, full in (("out_x", "attn.to_out.0"), ("out_c", "attn.to_add_out"), ("ff1_x", "ff.net.0.proj"),
+                                ("ff2_x", "ff.net.2"), ("ff1_c", "ff_context.net.0.proj"), ("ff2_c", "ff_context.net.2")):
+                b[short + ".w"] = self._t(sd, p + full + ".weight").contiguous()
+                b[short + ".b"] = self._t(sd, p + full + ".bias")
+            for short, full in (("nq", "norm_q"), ("nk", "norm_k"), ("naq", "norm_added_q"), ("nak", "norm_added_k")):
+                b[short] = self._t(sd, p + "attn.%s.weight" % full).contiguous()
+            self.double.append(b)
+        for i in range(sh.num_single):
+            p = "single_transformer_blocks.%d." % i
+            add_mod(("s", i), p + "norm.linear")
+            b = {}
+            names = [p + "attn.to_q", p + "attn.to_k", p + "attn.to_v", p + "proj_mlp"]
+            b["qkvm.w"] = self._cat(sd, names, ".weight")
+            b["qkvm.b"] = self._cat(sd, names, ".bias")
+            b["out.w"] = self._t(sd, p + "proj_out.weight").contiguous()
+            b["out.b"] = self._t(sd, p + "proj_out.bias")
+            b["nq"] = self._t(sd, p + "attn.norm_q.weight").contiguous()
+            b["nk"] = self._t(sd, p + "attn.norm_k.weight").contiguous()
+            self.single.append(b)
+        add_mod(("out",), "norm_out.linear")
+        W["mod.w"] = torch.cat(mod_w, dim=0).contiguous()
+        W["mod.b"] = torch.cat(mod_b, dim=0).contiguous()
+        self.n_mod = off
+        self.W = W
+
+    def num_params(self):
+        n = sum(v.numel() for v in self.W.values())
+        for b in self.double + self.single:
+            n += sum(v.numel() for v in b.values())
+        return n
+
+    # ------------------------------------------------------------------ LoRA
+    def set_lora(self, adapters: List[Tuple[Dict[str, Tuple[torch.Tensor, torch.Tensor]], float]]):
+        """adapters: [(lora_dict, scale)], lora_dict[module] = (A [r,in], B [out,r]) with diffusers module
+        names relative to the transformer.  Zero-scaled adapters are dropped (the reference keeps them
+        injected with weight 0: pipeline.py:110-111,245,263 -- contributing exactly 0)."""
+        self._lora_active = [(d, float(s)) for d, s in adapters if float(s) != 0.0]
+        self._lora_version += 1
+        self._plans.clear()
+        self._pack_lora()
+
+    def _pack_lora(self):
+        sh, D = self.shape, self.shape.dim
+        act = self._lora_active
+        self.lora_rank = 0
+        if not act:
+            return
+        for b in self.double + self.single:
+            for k in [k for k in b if k.startswith("lora.")]:
+                del b[k]
+
+        def build(mod_names):
+            """Concatenate the active adapters along rank for a (possibly fused) GEMM over `mod_names`
+            (its output segments).  Returns A_cat [nseg*Rp, in], B_cat [sum(out), Rp], alpha."""
+            ranks = [[(d[m][0].shape[0] if m in d else 0) for d, _ in act] for m in mod_names]
+            R = max(sum(r) for r in ranks)
+            if R == 0:
+                return None
+            Rp = _pad64(R)
+            single_scale = len(act) == 1
+            A_rows, B_rows = [], []
+            for m in mod_names:
+                a_seg, b_seg = [], []
+                for d, s in act:
+                    if m not in d:
+                        continue
+                    A, B = d[m]
+                    A = A.to(self.device, torch.float32)
+                    if not single_scale:
+                        A = A * s
+                    a_seg.append(A.to(BF16))
+                    b_seg.append(B.to(self.device, BF16))
+                in_f = a_seg[0].shape[1] if a_seg else None
+                out_f = b_seg[0].shape[0] if b_seg else None
+                A_rows.append((a_seg, in_f))
+                B_rows.append((b_seg, out_f))
+            return A_rows, B_rows, Rp, (act[0][1] if single_scale else 1.0)
+
+        def finish(built, in_f, out_fs):
+            if built is None:
+                return None
+            A_rows, B_rows, Rp, alpha = built
+            A_cat = torch.zeros(len(A_rows) * Rp, in_f, dtype=BF16, device=self.device)
+            B_cat = torch.zeros(sum(out_fs), Rp, dtype=BF16, device=self.device)
+            ro = 0
+            for si, ((a_seg, _), (b_seg, _), of) in enumerate(zip(A_rows, B_rows, out_fs)):
+                r0 = 0
+                for A, B in zip(a_seg, b_seg):
+                    r = A.shape[0]
+                    A_cat[si * Rp + r0: si * Rp + r0 + r] = A
+                    B_cat[ro: ro + of, r0: r0 + r] = B
+                    r0 += r
+                ro += of
+            return A_cat, B_cat, alpha, Rp
+
+        for i, b in enumerate(self.double):
+            p = "transformer_blocks.%d." % i
+            groups = {"qkv_x": [p + "attn.to_q", p + "attn.to_k", p + "attn.to_v"],
+                      "qkv_c": [p + "attn.add_q_proj", p + "attn.add_k_proj", p + "attn.add_v_proj"],
+                      "out_x": [p + "attn.to_out.0"], "out_c": [p + "attn.to_add_out"],
+                      "ff1_x": [p + "ff.net.0.proj"], "ff2_x": [p + "ff.net.2"],
+                      "ff1_c": [p + "ff_context.net.0.proj"], "ff2_c": [p + "ff_context.net.2"]}
+            for short, mods in groups.items():
+                w = b[short + ".w"]
+                out_fs = [w.shape[0] // len(mods)] * len(mods)
+                r = finish(build(mods), w.shape[1], out_fs)
+                if r is not None:
+                    b["lora." + short] = r
+        for i, b in enumerate(self.single):
+            p = "single_transformer_blocks.%d." % i
+            mods = [p + "attn.to_q", p + "attn.to_k", p + "attn.to_v"]
+            r = finish(build(mods), D, [D, D, D])
+            if r is not None:
+                b["lora.qkvm"] = r
+        rs = [v[3] for b in self.double + self.single for k, v in b.items() if k.startswith("lora.")]
+        self.lora_rank = max(rs) if rs else 0
+
+    # ------------------------------------------------------------------ plan
+    def _gemm(self, plan, A, B, Cout, bias=None, lora=None, lora_n_limit=None, lora_seg_n=None, T=None, **kw):
+        """append (optional LoRA-down GEMM +) the main GEMM to the plan."""
+        if lora is not None:
+            A_cat, B_cat, alpha, Rp = lora
+            Tv = T[: A.shape[0], : A_cat.shape[0]]
+            d0 = ops.make_gemm_desc(A, A_cat, Tv, alpha=alpha)
+            plan.append((self.lib.utx_gemm_bf16, d0))
+            d = ops.make_gemm_desc(A, B, Cout, bias=bias, A2=Tv, B2=B_cat, lora_n_limit=lora_n_limit,
+                                   lora_seg_n=lora_seg_n, **kw)
+        else:
+            d = ops.make_gemm_desc(A, B, Cout, bias=bias, **kw)
+        plan.append((self.lib.utx_gemm_bf16, d))
+
+    def _lnmod(self, plan, x, y, shift, scale):
+        d = LnModDesc()
+        d.x, d.ldx, d.shift, d.scale = ptr(x), x.stride(0), ptr(shift), ptr(scale)
+        d.y, d.ldy, d.n_tok, d.D, d.eps = ptr(y), y.stride(0), x.shape[0], x.shape[1], 1e-6
+        plan.append((self.lib.utx_ln_mod, d))
+
+    def _qkvpost(self, plan, qkv, wq, wk, ws, n_tok, tok_off):
+        sh, D = self.shape, self.shape.dim
+        d = QkvPostDesc()
+        d.qkv, d.ld, d.q_col, d.k_col, d.v_col = ptr(qkv), qkv.stride(0), 0, D, 2 * D
+        d.wq, d.wk, d.cosb, d.sinb = ptr(wq), ptr(wk), ptr(ws["cos"]), ptr(ws["sin"])
+        d.Qh, d.Kh, d.Vt = ptr(ws["Qh"]), ptr(ws["Kh"]), ptr(ws["Vt"])
+        d.hs_qk, d.hs_v, d.S_pad = ws["Qh"].stride(0), ws["Vt"].stride(0), ws["Vt"].shape[2]
+        d.n_tok, d.tok_off, d.H, d.eps = n_tok, tok_off, sh.num_heads, 1e-6
+        plan.append((self.lib.utx_qkv_post, d))
+
+    def _attn(self, plan, ws, out, S):
+        sh = self.shape
+        Qh, Kh, Vt = ws["Qh"], ws["Kh"], ws["Vt"]
+        args = (ptr(Qh), ptr(Kh), ptr(Vt), ptr(out), Qh.stride(0), Qh.stride(1), Kh.stride(0), Kh.stride(1),
+                Vt.stride(0), Vt.stride(1), out.stride(0), sh.num_heads, S, 1.0 / math.sqrt(128.0))
+        plan.append((self.lib.utx_attn_fwd_bf16, args))
+
+    def _gemv(self, plan, x, W, b, y, silu_in=False, silu_out=False):
+        d = GemvDesc()
+        d.x, d.ldx, d.W, d.ldw, d.bias = ptr(x), x.stride(0), ptr(W), W.stride(0), ptr(b)
+        d.y, d.ldy, d.M, d.N, d.K = ptr(y), y.stride(0), x.shape[0], W.shape[0], W.shape[1]
+        d.silu_in, d.silu_out = int(silu_in), int(silu_out)
+        plan.append((self.lib.utx_gemv_bf16, d))
+
+    def _build(self, S_txt, S_img):
+        sh, D, H, dev = self.shape, self.shape.dim, self.shape.num_heads, self.device
+        S = S_txt + S_img
+        S_pad = _pad64(S)
+        Rp = self.lora_rank if self._lora_active else 0
+        z = lambda *s, dtype=BF16: torch.zeros(*s, dtype=dtype, device=dev)
+        ws = {
+            "lat": z(S_img, sh.in_channels), "enc": z(S_txt, sh.joint_dim), "pooled": z(1, sh.pooled_dim),
+            "tproj": z(1, 256), "gproj": z(1, 256),
+            "e1": z(1, D), "e_t": z(1, D), "e_g": z(1, D), "e_p": z(1, D), "temb": z(1, D),
+            "mod": z(1, self.n_mod),
+            "h": z(S, D), "xn": z(S, D), "qkv": z(S, 3 * D), "cat": z(S, (1 + sh.mlp_ratio) * D),
+            "attn": z(S, D),
+            "Qh": z(H, S_pad, 128), "Kh": z(H, S_pad, 128), "Vt": z(H, 128, S_pad),
+            "cos": z(S, 64, dtype=torch.float32), "sin": z(S, 64, dtype=torch.float32),
+            "out": z(S_img, sh.in_channels),
+        }
+        if Rp:
+            ws["T"] = z(S, 3 * Rp)
+        T = ws.get("T")
+        W, mod = self.W, ws["mod"][0]
+        h, xn, qkv, cat, attn = ws["h"], ws["xn"], ws["qkv"], ws["cat"], ws["attn"]
+        h_c, h_x = h[:S_txt], h[S_txt:]
+        xn_c, xn_x = xn[:S_txt], xn[S_txt:]
+        ff = cat[:, : sh.mlp_ratio * D]  # double-block MLP hidden reuses the single-block cat buffer
+        plan = []
+        # ---- conditioning embeddings (M = 1 GEMVs) : CombinedTimestepGuidanceTextProjEmbeddings [3p]
+        k = "time_text_embed.%s.%s"
+        self._gemv(plan, ws["tproj"], W[k % ("timestep_embedder", "linear_1") + ".w"], W[k % ("timestep_embedder", "linear_1") + ".b"], ws["e1"], silu_out=True)
+        self._gemv(plan, ws["e1"], W[k % ("timestep_embedder", "linear_2") + ".w"], W[k % ("timestep_embedder", "linear_2") + ".b"], ws["e_t"])
+        if sh.guidance_embeds:
+            self._gemv(plan, ws["gproj"], W[k % ("guidance_embedder", "linear_1") + ".w"], W[k % ("guidance_embedder", "linear_1") + ".b"], ws["e1"], silu_out=True)
+            self._gemv(plan, ws["e1"], W[k % ("guidance_embedder", "linear_2") + ".w"], W[k % ("guidance_embedder", "linear_2") + ".b"], ws["e_g"])
+        self._gemv(plan, ws["pooled"], W[k % ("text_embedder", "linear_1") + ".w"], W[k % ("text_embedder", "linear_1") + ".b"], ws["e1"], silu_out=True)
+        self._gemv(plan, ws["e1"], W[k % ("text_embedder", "linear_2") + ".w"], W[k % ("text_embedder", "linear_2") + ".b"], ws["e_p"])
+        plan.append(("temb_sum", None))
+        # every AdaLN modulation vector of the step in one weight-streaming pass
+        self._gemv(plan, ws["temb"], W["mod.w"], W["mod.b"], ws["mod"], silu_in=True)
+        # ---- embedders
+        self._gemm(plan, ws["lat"], W["x_embedder.w"], h_x, bias=W["x_embedder.b"])
+        self._gemm(plan, ws["enc"], W["context_embedder.w"], h_c, bias=W["context_embedder.b"])
+
+        def chunks(key, n):
+            o = self.mod_off[key]
+            return [mod[o + j * D: o + (j + 1) * D] for j in range(n)]
+
+        for i, b in enumerate(self.double):
+            sh_a, sc_a, g_a, sh_m, sc_m, g_m = chunks(("d", i, "x"), 6)
+            csh_a, csc_a, cg_a, csh_m, csc_m, cg_m = chunks(("d", i, "c"), 6)
+            self._lnmod(plan, h_x, xn_x, sh_a, sc_a)
+            self._lnmod(plan, h_c, xn_c, csh_a, csc_a)
+            self._gemm(plan, xn_x, b["qkv_x.w"], qkv[S_txt:], bias=b["qkv_x.b"], lora=b.get("lora.qkv_x"),
+                       lora_n_limit=3 * D, lora_seg_n=D, T=T)
+            self._gemm(plan, xn_c, b["qkv_c.w"], qkv[:S_txt], bias=b["qkv_c.b"], lora=b.get("lora.qkv_c"),
+                       lora_n_limit=3 * D, lora_seg_n=D, T=T)
+            self._qkvpost(plan, qkv[S_txt:], b["nq"], b["nk"], ws, S_img, S_txt)
+            self._qkvpost(plan, qkv[:S_txt], b["naq"], b["nak"], ws, S_txt, 0)
+            self._attn(plan, ws, attn, S)
+            self._gemm(plan, attn[S_txt:], b["out_x.w"], h_x, bias=b["out_x.b"], lora=b.get("lora.out_x"), T=T,
+                       gate=g_a, res=h_x)
+            self._gemm(plan, attn[:S_txt], b["out_c.w"], h_c, bias=b["out_c.b"], lora=b.get("lora.out_c"), T=T,
+                       gate=cg_a, res=h_c)
+            self._lnmod(plan, h_x, xn_x, sh_m, sc_m)
+            self._gemm(plan, xn_x, b["ff1_x.w"], ff[S_txt:], bias=b["ff1_x.b"], lora=b.get("lora.ff1_x"), T=T, gelu_from=0)
+            self._gemm(plan, ff[S_txt:], b["ff2_x.w"], h_x, bias=b["ff2_x.b"], lora=b.get("lora.ff2_x"), T=T,
+                       gate=g_m, res=h_x)
+            self._lnmod(plan, h_c, xn_c, csh_m, csc_m)
+            self._gemm(plan, xn_c, b["ff1_c.w"], ff[:S_txt], bias=b["ff1_c.b"], lora=b.get("lora.ff1_c"), T=T, gelu_from=0)
+            self._gemm(plan, ff[:S_txt], b["ff2_c.w"], h_c, bias=b["ff2_c.b"], lora=b.get("lora.ff2_c"), T=T,
+                       gate=cg_m, res=h_c)
+        for i, b in enumerate(self.single):
+            sh_, sc_, g_ = chunks(("s", i), 3)
+            self._lnmod(plan, h, xn, sh_, sc_)
+            # one GEMM for [q|k|v|proj_mlp]: qkv -> qkv buffer, GELU(mlp) -> cat[:, D:]
+            self._gemm(plan, xn, b["qkvm.w"], qkv, bias=b["qkvm.b"], lora=b.get("lora.qkvm"), lora_n_limit=3 * D,
+                       lora_seg_n=D, T=T, gelu_from=3 * D, n_split=3 * D, C1=cat[:, D:])
+            self._qkvpost(plan, qkv, b["nq"], b["nk"], ws, S, 0)
+            self._attn(plan, ws, cat, S)  # attention output lands in cat[:, :D] (row stride 5D)
+            self._gemm(plan, cat, b["out.w"], h, bias=b["out.b"], gate=g_, res=h)
+        o = self.mod_off[("out",)]
+        scale, shift = mod[o: o + D], mod[o + D: o + 2 * D]  # AdaLayerNormContinuous: (scale, shift) [3p]
+        self._lnmod(plan, h_x, xn_x, shift, scale)
+        self._gemm(plan, xn_x, W["proj_out.w"], ws["out"], bias=W["proj_out.b"])
+        return {"ws": ws, "plan": plan, "S_txt": S_txt, "S_img": S_img}
+
+    def _get_plan(self, S_txt, S_img):
+        key = (S_txt, S_img, self._lora_version)
+        if key not in self._plans:
+            self._plans.clear()  # one live plan: workspaces are large
+            self._plans[key] = self._build(S_txt, S_img)
+        return self._plans[key]
+
+    # ------------------------------------------------------------------ forward
+    def set_positions(self, txt_ids, img_ids):
+        """Upload the rotary tables for ids = cat(txt_ids, img_ids) (once per pipeline call)."""
+        p = self._get_plan(txt_ids.shape[0], img_ids.shape[0])
+        cos, sin = rope_tables(torch.cat([txt_ids.cpu().float(), img_ids.cpu().float()], dim=0),
+                               self.shape.axes_dim, self.shape.theta)
+        p["ws"]["cos"].copy_(cos, non_blocking=True)
+        p["ws"]["sin"].copy_(sin, non_blocking=True)
+
+    def set_conditioning(self, encoder_hidden_states, pooled_projections, guidance: float):
+        S_txt = encoder_hidden_states.shape[-2]
+        p = next(iter(self._plans.values()))
+        ws = p["ws"]
+        assert S_txt == p["S_txt"]
+        ws["enc"].copy_(encoder_hidden_states.reshape(S_txt, -1).to(BF16))
+        ws["pooled"].copy_(pooled_projections.reshape(1, -1).to(BF16))
+        g1000 = _bf16_scalar(_bf16_scalar(guidance) * 1000.0)  # guidance.to(dtype) * 1000 in bf16 [3p]
+        ws["gproj"].copy_(_timestep_proj(g1000))
+
+    def run_plan(self, p):
+        h, st = self.ctx.handle, self.ctx.stream()
+        lib, ws = self.lib, p["ws"]
+        for fn, d in p["plan"]:
+            if fn == "temb_sum":
+                # conditioning = (timesteps_emb + guidance_emb) + pooled_projections, bf16 adds [3p]
+                t = ws["e_t"]
+                if self.shape.guidance_embeds:
+                    t = t + ws["e_g"]
+                torch.add(t, ws["e_p"], out=ws["temb"])
+            elif fn is lib.utx_attn_fwd_bf16:
+                rc = fn(h, *d, st)
+                if rc:
+                    self.ctx.check(rc)
+            else:
+                rc = fn(h, C.byref(d), st)
+                if rc:
+                    self.ctx.check(rc)
+
+    def forward(self, hidden_states, timestep: float, out: Optional[torch.Tensor] = None):
+        """One transformer evaluation.  hidden_states [S_img, 64] bf16 (noise ++ condition tokens);
+        `timestep` is the value the pipeline passes (t/1000, already rounded to the latent dtype).
+        Positions / conditioning must have been set.  Returns noise_pred [S_img, 64] bf16."""
+        p = next(iter(self._plans.values()))
+        ws = p["ws"]
+        t1000 = _bf16_scalar(_bf16_scalar(timestep) * 1000.0)  # timestep.to(dtype) * 1000 in bf16 [3p]
+        ws["tproj"].copy_(_timestep_proj(t1000), non_blocking=True)
+        if hidden_states.data_ptr() != ws["lat"].data_ptr():
+            ws["lat"].copy_(hidden_states.reshape(ws["lat"].shape))
+        self.run_plan(p)
+        if out is not None:
+            out.copy_(ws["out"])
+            return out
+        return ws["out"]
+
+    __call__ = forward
