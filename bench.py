@@ -1,0 +1,203 @@
+#!/usr/bin/env python
+"""bench.py -- denoising-steps/sec of the UniTEX FLUX-DiT texture denoise loop on MI355X.
+
+A "step" = one pass of the hot path over one batch of synthetic input: the full FLUX.1-dev transformer
+forward (19 double + 38 single blocks, texture LoRA rank 64 active, delight LoRA injected with weight 0)
+over the joint [text | noise | control | dual] token sequence, plus the fused flow-match Euler update +
+condition re-pin.  Inputs (latents, weights) are resident in HBM before the timed region.
+
+Workload (BASELINE.json configs[1], "1024^2 x 6 views, bf16, 1xMI355X"), in the reference's own
+joint-strip semantics: one 1024x6144 strip -> 24576 noise + 24576 control + 1024 dual
+(512^2 reference image) + 512 text tokens = 50688 tokens, 2454 TFLOP/step.
+`--workload ref512x6` is the reference's shipped operating point (512x3072 strip, S = 13824).
+
+N > 1: the joint-attention DiT does not shard by view -- ranks run independent replicas
+(one mesh per GPU, no data-path collective): value = N * steps / max-over-ranks time, scaling "weak".
+
+Contract: python bench.py --gpus N --steps K --warmup W  -> rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+WORKLOADS = {
+    # name: (strip_h, strip_w, dual_px, description)
+    "strip1024x6": (1024, 6144, 512, "FLUX.1-dev + texture LoRA r64, joint strip 1024x6144 (6 views @1024^2) + control strip + 512^2 dual"),
+    "ref512x6": (512, 3072, 512, "FLUX.1-dev + texture LoRA r64, joint strip 512x3072 (reference operating point) + control + 512^2 dual"),
+    "view1024": (1024, 1024, 512, "FLUX.1-dev + texture LoRA r64, single 1024^2 view + control + 512^2 dual (per-view variant; NOT the reference's joint semantics)"),
+}
+D, HEADS, N_DOUBLE, N_SINGLE = 3072, 24, 19, 38
+PEAK_BF16_TFLOPS = 2500.0  # dense MFMA peak, MI355X_MICROARCH.md
+
+
+def token_counts(name):
+    h, w, dual, _ = WORKLOADS[name]
+    n_noise = (h // 16) * (w // 16)
+    n_dual = (dual // 16) ** 2
+    return 512, n_noise, n_noise, n_dual
+
+
+def step_flops(S):
+    attn = 4.0 * S * S * D * (N_DOUBLE + N_SINGLE)
+    lin = 24.0 * D * D * S * (N_DOUBLE + N_SINGLE)
+    return attn + lin, attn
+
+
+def cpu_baseline(S_full, threads):
+    """Oracle (oracle/dit_ref.py, fp32 torch CPU) on a bounded sample: 1 double + 1 single FLUX block at
+    full width (D=3072, 24 heads), S_txt=256 + S_img=1792 tokens; extrapolated by algorithmic FLOPs."""
+    from oracle import dit_ref
+    torch.set_num_threads(threads)
+    cfg = dit_ref.FluxConfig(num_double=1, num_single=1)
+    sd = dit_ref.make_synthetic_state_dict(cfg, seed=0, dtype=torch.float32)
+    S_txt, S_img = 256, 1792
+    g = torch.Generator().manual_seed(63)
+    lat = torch.randn(S_img, 64, generator=g)
+    enc = torch.zeros(S_txt, cfg.joint_dim)
+    pooled = torch.zeros(1, cfg.pooled_dim)
+    txt_ids = torch.zeros(S_txt, 3)
+    img_ids = dit_ref.latent_image_ids(28, 64)
+    t0 = time.perf_counter()
+    dit_ref.flux_forward(sd, cfg, lat, enc, pooled, 0.5, 3.5, txt_ids, img_ids, emulate_bf16=False)
+    dt = time.perf_counter() - t0
+    S = S_txt + S_img
+    fl = 4.0 * S * S * D * 2 + 24.0 * D * D * S * 2
+    rate = fl / dt  # FLOP/s
+    full, _ = step_flops(S_full)
+    return {"value": rate / full, "unit": "steps/s", "cores": threads, "kind": "port",
+            "sample": "oracle/dit_ref.py fp32 torch-CPU: 1 double + 1 single FLUX block, D=3072, S=%d, %.1f s measured "
+                      "(%.2f TFLOP/s); extrapolated by FLOPs to the %d-token 57-block step" % (S, dt, rate / 1e12, S_full),
+            "measured_seconds": dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default=os.environ.get("UTX_WORKLOAD", "strip1024x6"), choices=sorted(WORKLOADS))
+    ap.add_argument("--lora-rank", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+
+    from unitex_amd.flux import ops
+    from unitex_amd.flux.synthetic import SyntheticFluxStateDict, synthetic_lora
+    from unitex_amd.flux.transformer import FluxDiT, FluxShape
+    from unitex_amd.flux.scheduler import FlowMatchEulerScheduler, calculate_shift
+
+    S_txt, n_noise, n_ctrl, n_dual = token_counts(args.workload)
+    S_img = n_noise + n_ctrl + n_dual
+    S = S_txt + S_img
+    h_px, w_px, dual_px, desc = WORKLOADS[args.workload]
+
+    shape = FluxShape()
+    sd = SyntheticFluxStateDict(shape, seed=0, device=dev)
+    model = FluxDiT(sd, shape, device=dev)
+    tex = synthetic_lora(sd, shape, rank=args.lora_rank, seed=1, device=dev)
+    dlt = synthetic_lora(sd, shape, rank=args.lora_rank, seed=2, device=dev)
+    model.set_lora([(tex, 1.0), (dlt, 0.0)])  # reference: weights_for_texture = [1, 0] (pipeline.py:110)
+
+    # synthetic latents: seed 63 (run.py:5) + rank so replicas differ
+    g = torch.Generator(device=dev).manual_seed(63 + rank)
+    lat = torch.randn(S_img, 64, generator=g, device=dev).to(torch.bfloat16)
+    cond = lat[n_noise:].clone()
+    HL, WL = h_px // 16, w_px // 16
+    ids = [torch.zeros(HL, WL, 3), torch.zeros(HL, WL, 3), torch.zeros(dual_px // 16, dual_px // 16, 3)]
+    offs = [(0, 0), (HL, 0), (HL, WL)]
+    for t, (oy, ox) in zip(ids, offs):
+        t[..., 1] += torch.arange(oy, oy + t.shape[0])[:, None]
+        t[..., 2] += torch.arange(ox, ox + t.shape[1])[None, :]
+    img_ids = torch.cat([t.reshape(-1, 3) for t in ids], 0)
+    model.set_positions(torch.zeros(S_txt, 3), img_ids)
+    model.set_conditioning(torch.zeros(S_txt, shape.joint_dim, device=dev), torch.zeros(1, shape.pooled_dim, device=dev), 3.5)
+    sched = FlowMatchEulerScheduler()
+    total = args.warmup + args.steps
+    nsched = max(28, total)
+    ts = sched.set_timesteps(nsched, calculate_shift(n_noise))
+
+    def one_step(i, events=None):
+        t_bf = torch.tensor(float(ts[i]), dtype=torch.float32).to(torch.bfloat16)
+        t_in = float((t_bf / 1000).to(torch.float32))
+        model.attn_events = events
+        v = model.forward(lat, t_in)
+        ops.sched_step(lat, v, sched.dsigma(i), n_noise_tokens=n_noise, cond=cond)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    for i in range(args.warmup):
+        one_step(i)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    events = []
+    t0 = time.perf_counter()
+    for i in range(args.warmup, total):
+        one_step(i, events)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert torch.isfinite(lat.float()).all(), "non-finite latents after the timed steps"
+
+    if rank == 0:
+        fl, fl_attn = step_flops(S)
+        attn_ms = [a.elapsed_time(b) for a, b in events]
+        attn_avg_ms = sum(attn_ms) / max(len(attn_ms), 1)
+        attn_launch_flops = 4.0 * S * S * 128 * HEADS
+        achieved = attn_launch_flops / (attn_avg_ms * 1e-3) / 1e12
+        value = world * args.steps / dt
+        out = {
+            "metric": "denoising-steps/sec", "value": value, "unit": "steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": args.workload, "description": desc, "tokens": S, "text_tokens": S_txt,
+                       "noise_tokens": n_noise, "control_tokens": n_ctrl, "dual_tokens": n_dual,
+                       "lora_rank": args.lora_rank, "guidance": 3.5, "parallelism": "replicas x%d" % world,
+                       "tflop_per_step": fl / 1e12, "achieved_tflops_per_gpu": fl / (dt / args.steps) / 1e12,
+                       "sec_per_mesh_texture_dit_only": 56.0 * dt / args.steps},
+            "roofline": {"bound": "mfma", "kernel": "attn_fwd_kernel", "achieved": achieved, "peak": PEAK_BF16_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                         "launches_timed": len(attn_ms), "avg_launch_ms": attn_avg_ms,
+                         "flops_per_launch": attn_launch_flops,
+                         "attention_share_of_step_time": (attn_avg_ms * (N_DOUBLE + N_SINGLE)) / (dt / args.steps * 1e3)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(S, os.cpu_count() or 1)
+            except Exception as e:  # the GPU number must still be reported
+                out["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": "failed: %r" % (e,)}
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

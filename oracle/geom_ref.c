@@ -1,0 +1,412 @@
+/*
+ * CPU oracle (TEST INFRASTRUCTURE ONLY) for the geometry half of the UniTEX hot path:
+ * rasterise -> interpolate -> LBVH ray visibility -> per-view bilinear gather.
+ * Plain C, single-threaded, compiled with -O2 -ffp-contract=off (no FMA contraction, IEEE div/sqrt)
+ * so that every float expression is the same sequence of roundings as the HIP kernels
+ * (unitex_amd/csrc/{raster,bvh,backproject}.hip are compiled with -ffp-contract=off as well).
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may call this.
+ *
+ * What is restated from where (paths relative to /root/reference/TextureTools/texturetools):
+ *  - LBVH build: raytracing/rt_aprmis/bvhworkers/get_elements.slang:1-39,
+ *    lbvh_morton_codes.slang:24-79, lbvh_single_radixsort.slang:27-137 (semantics: STABLE sort by the
+ *    32-bit Morton key), lbvh_hierarchy.slang:31-244, lbvh_bounding_boxes.slang:150-389, host driver
+ *    rt_aprmis/bvhhelpers.py:20-84.
+ *  - traversal: bvhworkers/intersect_test2.slang:14-146,270-309 -- reproduced WITH its quirks
+ *    (SURVEY 2.4): zero direction components replaced by 1e-6 in the slab test; triangle_hit accepts
+ *    t < 0 and ignores t_min/t_max; the reported triangle is the LAST triangle that hit in traversal
+ *    order (push left then right => right popped first) while closest_so_far = min(t, closest).
+ *    normalize() is restated as d / sqrt(dot(d,d)) with IEEE sqrt/div (Slang->CUDA uses rsqrtf:
+ *    unpinned, and exact for the axis-aligned unit rays this pipeline shoots).
+ *  - per-texel ray set-up / visibility / gather: render/nvdiffrast/renderer_inverse.py:262-298,316-325.
+ *  - dr.rasterize / dr.interpolate are nvdiffrast [3p, commit 729261dc..., docker/readme.md:8], absent
+ *    from /root/reference and with no golden vectors in the reference's tests => PARITY UNPINNED for
+ *    the coverage rule.  The rule implemented here is this project's own, documented in DESIGN.md:
+ *    8-bit sub-pixel snapping, inclusive int64 edge functions, pixel centres, nearest z/w wins,
+ *    ties -> lowest triangle id; output (u, v, z/w, id+1) with u,v the weights of vertices 0 and 1.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define SUBPIX 256
+
+/* ------------------------------------------------------------------------------------------- */
+/* rasteriser                                                                                   */
+/* ------------------------------------------------------------------------------------------- */
+static inline int64_t snap(float ndc, int size) {
+    /* (ndc*0.5+0.5)*size*SUBPIX rounded to nearest (ties away from zero via floor(x+0.5)) */
+    double v = ((double)ndc * 0.5 + 0.5) * (double)size * (double)SUBPIX;
+    return (int64_t)floor(v + 0.5);
+}
+
+/* pos: [V][4] clip-space; tri: [F][3]; rast out: [H][W][4] floats (u, v, z/w, id+1), zero = empty */
+void utxref_rasterize(const float* pos, int V, const int32_t* tri, int F, int H, int W, float* rast) {
+    (void)V;
+    size_t npix = (size_t)H * W;
+    memset(rast, 0, npix * 4 * sizeof(float));
+    float* zbuf = (float*)malloc(npix * sizeof(float));
+    for (size_t i = 0; i < npix; ++i) zbuf[i] = 3.0e38f;
+    for (int f = 0; f < F; ++f) {
+        const float* p0 = pos + 4 * (size_t)tri[3 * f + 0];
+        const float* p1 = pos + 4 * (size_t)tri[3 * f + 1];
+        const float* p2 = pos + 4 * (size_t)tri[3 * f + 2];
+        if (!(p0[3] > 0.f) || !(p1[3] > 0.f) || !(p2[3] > 0.f)) continue; /* no clipping: skip */
+        float iw0 = 1.0f / p0[3], iw1 = 1.0f / p1[3], iw2 = 1.0f / p2[3];
+        int64_t x0 = snap(p0[0] * iw0, W), y0 = snap(p0[1] * iw0, H);
+        int64_t x1 = snap(p1[0] * iw1, W), y1 = snap(p1[1] * iw1, H);
+        int64_t x2 = snap(p2[0] * iw2, W), y2 = snap(p2[1] * iw2, H);
+        int64_t area = (x1 - x0) * (y2 - y0) - (y1 - y0) * (x2 - x0);
+        if (area == 0) continue;
+        int64_t minx = x0 < x1 ? x0 : x1; if (x2 < minx) minx = x2;
+        int64_t maxx = x0 > x1 ? x0 : x1; if (x2 > maxx) maxx = x2;
+        int64_t miny = y0 < y1 ? y0 : y1; if (y2 < miny) miny = y2;
+        int64_t maxy = y0 > y1 ? y0 : y1; if (y2 > maxy) maxy = y2;
+        /* pixel px has centre (px*SUBPIX + SUBPIX/2) */
+        int64_t pxlo = (minx - SUBPIX / 2 + SUBPIX - 1) / SUBPIX; /* ceil((minx-128)/256) for >=0 */
+        if (minx - SUBPIX / 2 < 0) pxlo = 0;
+        int64_t pxhi = (maxx - SUBPIX / 2) >= 0 ? (maxx - SUBPIX / 2) / SUBPIX : -1;
+        int64_t pylo = (miny - SUBPIX / 2 + SUBPIX - 1) / SUBPIX;
+        if (miny - SUBPIX / 2 < 0) pylo = 0;
+        int64_t pyhi = (maxy - SUBPIX / 2) >= 0 ? (maxy - SUBPIX / 2) / SUBPIX : -1;
+        if (pxhi > W - 1) pxhi = W - 1;
+        if (pyhi > H - 1) pyhi = H - 1;
+        float z0 = p0[2] * iw0, z1 = p1[2] * iw1, z2 = p2[2] * iw2;
+        for (int64_t py = pylo; py <= pyhi; ++py) {
+            int64_t cy = py * SUBPIX + SUBPIX / 2;
+            for (int64_t px = pxlo; px <= pxhi; ++px) {
+                int64_t cx = px * SUBPIX + SUBPIX / 2;
+                /* e0 weights vertex 0 (edge 1->2), e1 vertex 1 (edge 2->0), e2 vertex 2 (edge 0->1) */
+                int64_t e0 = (x2 - x1) * (cy - y1) - (y2 - y1) * (cx - x1);
+                int64_t e1 = (x0 - x2) * (cy - y2) - (y0 - y2) * (cx - x2);
+                int64_t e2 = (x1 - x0) * (cy - y0) - (y1 - y0) * (cx - x0);
+                int inside = (area > 0) ? (e0 >= 0 && e1 >= 0 && e2 >= 0) : (e0 <= 0 && e1 <= 0 && e2 <= 0);
+                if (!inside) continue;
+                float b0 = (float)((double)e0 / (double)area);
+                float b1 = (float)((double)e1 / (double)area);
+                float b2 = (1.0f - b0) - b1;
+                float zw = (b0 * z0 + b1 * z1) + b2 * z2;
+                float u = b0, v = b1;
+                if (!(iw0 == 1.0f && iw1 == 1.0f && iw2 == 1.0f)) { /* perspective-correct weights */
+                    float a0 = b0 * iw0, a1 = b1 * iw1, a2 = b2 * iw2;
+                    float s = (a0 + a1) + a2;
+                    u = a0 / s; v = a1 / s;
+                }
+                if (zw < -1.0f || zw > 1.0f) continue;
+                size_t pi = (size_t)py * W + px;
+                /* triangles are visited in increasing id: strict '<' keeps the lowest id on ties */
+                if (zw < zbuf[pi]) {
+                    zbuf[pi] = zw;
+                    float* o = rast + 4 * pi;
+                    o[0] = u; o[1] = v; o[2] = zw; o[3] = (float)(f + 1);
+                }
+            }
+        }
+    }
+    free(zbuf);
+}
+
+/* attr [V][C]; rast [npix][4]; tri [F][3]; out [npix][C]  (zero where empty) */
+void utxref_interpolate(const float* attr, int C, const float* rast, const int32_t* tri, long npix, float* out) {
+    for (long i = 0; i < npix; ++i) {
+        const float* r = rast + 4 * i;
+        int id = (int)r[3] - 1;
+        float* o = out + (size_t)C * i;
+        if (id < 0) { for (int c = 0; c < C; ++c) o[c] = 0.f; continue; }
+        float u = r[0], v = r[1], w = (1.0f - u) - v;
+        const float* a0 = attr + (size_t)C * tri[3 * id + 0];
+        const float* a1 = attr + (size_t)C * tri[3 * id + 1];
+        const float* a2 = attr + (size_t)C * tri[3 * id + 2];
+        for (int c = 0; c < C; ++c) o[c] = (a0[c] * u + a1[c] * v) + a2[c] * w;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* LBVH build                                                                                   */
+/* ------------------------------------------------------------------------------------------- */
+static inline uint32_t expand_bits(uint32_t v) {
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+static inline uint32_t morton3d(float x, float y, float z) {
+    x = fminf(fmaxf(x * 1024.0f, 0.0f), 1023.0f);
+    y = fminf(fmaxf(y * 1024.0f, 0.0f), 1023.0f);
+    z = fminf(fmaxf(z * 1024.0f, 0.0f), 1023.0f);
+    return expand_bits((uint32_t)x) * 4 + expand_bits((uint32_t)y) * 2 + expand_bits((uint32_t)z);
+}
+static inline int find_msb(uint32_t v) { if (!v) return -1; int m = 31; while (!((v >> m) & 1)) --m; return m; }
+static inline int delta_fn(int i, uint32_t codeI, int j, int n, const uint32_t* codes) {
+    if (j < 0 || j > n - 1) return -1;
+    uint32_t codeJ = codes[j];
+    if (codeI == codeJ) return 32 + 31 - find_msb((uint32_t)i ^ (uint32_t)j);
+    return 31 - find_msb(codeI ^ codeJ);
+}
+
+/* outputs: info [2F-1][3] (left,right,prim; 0 = none), aabb [2F-1][6], sorted_codes/sorted_idx [F] */
+void utxref_bvh_build(const float* vert, int V, const int32_t* faces, int F, int32_t* info, float* aabb,
+                      uint32_t* sorted_codes, int32_t* sorted_idx) {
+    (void)V;
+    float* eb = (float*)malloc((size_t)F * 6 * sizeof(float));
+    float gmin[3] = {3.0e38f, 3.0e38f, 3.0e38f}, gmax[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (int f = 0; f < F; ++f) {
+        float mn[3] = {1e9f, 1e9f, 1e9f}, mx[3] = {-1e9f, -1e9f, -1e9f};
+        for (int i = 0; i < 3; ++i) {
+            const float* v = vert + 3 * (size_t)faces[3 * f + i];
+            for (int a = 0; a < 3; ++a) { mn[a] = fminf(mn[a], v[a]); mx[a] = fmaxf(mx[a], v[a]); }
+        }
+        for (int a = 0; a < 3; ++a) {
+            eb[6 * f + a] = fminf(mn[a], mx[a]); eb[6 * f + 3 + a] = fmaxf(mn[a], mx[a]);
+            gmin[a] = fminf(gmin[a], eb[6 * f + a]); gmax[a] = fmaxf(gmax[a], eb[6 * f + 3 + a]);
+        }
+    }
+    uint32_t* codes = (uint32_t*)malloc((size_t)F * sizeof(uint32_t));
+    for (int f = 0; f < F; ++f) {
+        float m[3];
+        for (int a = 0; a < 3; ++a) {
+            float lo = eb[6 * f + a], hi = eb[6 * f + 3 + a];
+            float center = lo + 0.5f * (hi - lo);
+            m[a] = (center - gmin[a]) / (gmax[a] - gmin[a]);
+        }
+        codes[f] = morton3d(m[0], m[1], m[2]);
+    }
+    /* stable LSD radix sort, 4 passes x 8 bits, key = code, value = element index */
+    uint32_t* k0 = (uint32_t*)malloc((size_t)F * 4); int32_t* v0 = (int32_t*)malloc((size_t)F * 4);
+    uint32_t* k1 = (uint32_t*)malloc((size_t)F * 4); int32_t* v1 = (int32_t*)malloc((size_t)F * 4);
+    for (int f = 0; f < F; ++f) { k0[f] = codes[f]; v0[f] = f; }
+    for (int pass = 0; pass < 4; ++pass) {
+        size_t hist[257]; memset(hist, 0, sizeof(hist));
+        int sh = 8 * pass;
+        for (int f = 0; f < F; ++f) hist[((k0[f] >> sh) & 255) + 1]++;
+        for (int b = 0; b < 256; ++b) hist[b + 1] += hist[b];
+        for (int f = 0; f < F; ++f) { size_t d = hist[(k0[f] >> sh) & 255]++; k1[d] = k0[f]; v1[d] = v0[f]; }
+        uint32_t* tk = k0; k0 = k1; k1 = tk; int32_t* tv = v0; v0 = v1; v1 = tv;
+    }
+    memcpy(sorted_codes, k0, (size_t)F * 4); memcpy(sorted_idx, v0, (size_t)F * 4);
+    const int n = F, LEAF = F - 1;
+    int32_t* parent = (int32_t*)calloc((size_t)(2 * F - 1), sizeof(int32_t));
+    for (int g = 0; g < n; ++g) { /* leaves */
+        int e = v0[g];
+        info[3 * (LEAF + g) + 0] = 0; info[3 * (LEAF + g) + 1] = 0; info[3 * (LEAF + g) + 2] = e;
+        memcpy(aabb + 6 * (size_t)(LEAF + g), eb + 6 * (size_t)e, 6 * sizeof(float));
+    }
+    for (int idx = 0; idx < n - 1; ++idx) { /* internal nodes (Karras 2012) */
+        uint32_t code = k0[idx];
+        int dL = delta_fn(idx, code, idx - 1, n, k0), dR = delta_fn(idx, code, idx + 1, n, k0);
+        int d = (dR >= dL) ? 1 : -1;
+        int dmin = dL < dR ? dL : dR;
+        int lmax = 2;
+        while (delta_fn(idx, code, idx + lmax * d, n, k0) > dmin) lmax <<= 1;
+        int l = 0;
+        for (int t = lmax >> 1; t > 0; t >>= 1)
+            if (delta_fn(idx, code, idx + (l + t) * d, n, k0) > dmin) l += t;
+        int jdx = idx + l * d;
+        int first = idx < jdx ? idx : jdx, last = idx > jdx ? idx : jdx;
+        uint32_t fcode = k0[first];
+        int common = delta_fn(first, fcode, last, n, k0);
+        int split = first, stride = last - first;
+        do {
+            stride = (stride + 1) >> 1;
+            int ns = split + stride;
+            if (ns < last) { if (delta_fn(first, fcode, ns, n, k0) > common) split = ns; }
+        } while (stride > 1);
+        int cA = (split == first) ? LEAF + split : split;
+        int cB = (split + 1 == last) ? LEAF + split + 1 : split + 1;
+        info[3 * idx + 0] = cA; info[3 * idx + 1] = cB; info[3 * idx + 2] = 0;
+        parent[cA] = idx; parent[cB] = idx;
+    }
+    /* bottom-up AABBs (exact min/max unions => order independent).  Post-order via explicit stack. */
+    if (n == 1) { /* degenerate: single leaf is node 0 */ }
+    else {
+        int* st = (int*)malloc((size_t)(2 * F) * sizeof(int)); char* seen = (char*)calloc((size_t)(2 * F - 1), 1);
+        int sp = 0; st[sp++] = 0;
+        while (sp > 0) {
+            int nd = st[sp - 1];
+            int L = info[3 * nd], R = info[3 * nd + 1];
+            if (L == 0 && R == 0) { --sp; continue; }
+            if (!seen[nd]) { seen[nd] = 1; st[sp++] = L; st[sp++] = R; continue; }
+            --sp;
+            for (int a = 0; a < 3; ++a) {
+                aabb[6 * (size_t)nd + a] = fminf(aabb[6 * (size_t)L + a], aabb[6 * (size_t)R + a]);
+                aabb[6 * (size_t)nd + 3 + a] = fmaxf(aabb[6 * (size_t)L + 3 + a], aabb[6 * (size_t)R + 3 + a]);
+            }
+        }
+        free(st); free(seen);
+    }
+    free(parent); free(k0); free(v0); free(k1); free(v1); free(codes); free(eb);
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* traversal (bug-compatible with intersect_test2.slang)                                        */
+/* ------------------------------------------------------------------------------------------- */
+static inline int aabb_hit(const float* ro, const float* rd, float tmin, float tmax, const float* bb) {
+    for (int i = 0; i < 3; ++i) {
+        float d = rd[i];
+        if (d == 0.f) d = 0.000001f;
+        float inv = 1.0f / d;
+        float t0 = (bb[i] - ro[i]) * inv;
+        float t1 = (bb[3 + i] - ro[i]) * inv;
+        if (inv < 0.0f) { float t = t1; t1 = t0; t0 = t; }
+        tmin = t0 > tmin ? t0 : tmin;
+        tmax = t1 < tmax ? t1 : tmax;
+        if (tmax < tmin) return 0;
+    }
+    return 1;
+}
+static inline void cross3(const float* a, const float* b, float* o) {
+    o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+}
+static inline float dot3(const float* a, const float* b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+static inline int tri_hit(const float* ro, const float* rd, const float* v0, const float* v1, const float* v2,
+                          float* t_out, float* u_out, float* v_out) {
+    const float eps = 1e-9f;
+    float E1[3] = {v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2]};
+    float E2[3] = {v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2]};
+    float P[3]; cross3(rd, E2, P);
+    float det = dot3(E1, P);
+    if (det > -eps && det < eps) return 0;
+    float inv = 1.0f / det;
+    float T[3] = {ro[0] - v0[0], ro[1] - v0[1], ro[2] - v0[2]};
+    float u = dot3(T, P) * inv;
+    if (u < 0 || u > 1) return 0;
+    float Q[3]; cross3(T, E1, Q);
+    float v = dot3(rd, Q) * inv;
+    if (v < 0 || u + v > 1) return 0;
+    *t_out = dot3(E2, Q) * inv; *u_out = u; *v_out = v;
+    return 1;
+}
+
+/* returns hit triangle id (or -1); also t / nodes visited (diagnostics) */
+int utxref_bvh_trace_one(const int32_t* info, const float* aabb, const float* vert, const int32_t* faces,
+                         const float* ro, const float* rd_in, float* t_hit, int* nodes_visited) {
+    float n2 = dot3(rd_in, rd_in);
+    float nrm = sqrtf(n2);
+    float rd[3] = {rd_in[0] / nrm, rd_in[1] / nrm, rd_in[2] / nrm};
+    int stack[64]; int count = 0; stack[count++] = 0;
+    float closest = 1e9f; int hit_tid = -1; int visited = 0;
+    while (count > 0) {
+        int nd = stack[--count];
+        ++visited;
+        if (!aabb_hit(ro, rd, 0.f, closest, aabb + 6 * (size_t)nd)) continue;
+        int L = info[3 * nd], R = info[3 * nd + 1];
+        if (L != 0 && R != 0) {
+            if (count + 2 <= 64) { stack[count++] = L; stack[count++] = R; }
+        } else if (L == 0 && R == 0) {
+            int prim = info[3 * nd + 2];
+            const int32_t* f = faces + 3 * (size_t)prim;
+            float t, u, v;
+            if (tri_hit(ro, rd, vert + 3 * (size_t)f[0], vert + 3 * (size_t)f[1], vert + 3 * (size_t)f[2], &t, &u, &v)) {
+                closest = t < closest ? t : closest;
+                hit_tid = prim;
+            }
+        }
+    }
+    if (t_hit) *t_hit = closest;
+    if (nodes_visited) *nodes_visited = visited;
+    return hit_tid;
+}
+
+void utxref_bvh_trace(const int32_t* info, const float* aabb, const float* vert, const int32_t* faces,
+                      const float* ro, const float* rd, long R, int32_t* tid_out, long* total_nodes) {
+    long tot = 0;
+    for (long i = 0; i < R; ++i) {
+        int nv = 0; float t;
+        tid_out[i] = utxref_bvh_trace_one(info, aabb, vert, faces, ro + 3 * i, rd + 3 * i, &t, &nv);
+        tot += nv;
+    }
+    if (total_nodes) *total_nodes = tot;
+}
+
+/* brute force closest hit (independent check of the traversal on non-degenerate cases) */
+void utxref_brute_trace(const float* vert, const int32_t* faces, int F, const float* ro, const float* rd_in, long R,
+                        int32_t* tid_out, float* t_out) {
+    for (long i = 0; i < R; ++i) {
+        const float* o = ro + 3 * i; const float* di = rd_in + 3 * i;
+        float nrm = sqrtf(dot3(di, di));
+        float rd[3] = {di[0] / nrm, di[1] / nrm, di[2] / nrm};
+        float best = 1e9f; int bid = -1;
+        for (int f = 0; f < F; ++f) {
+            const int32_t* fc = faces + 3 * (size_t)f;
+            float t, u, v;
+            if (tri_hit(o, rd, vert + 3 * (size_t)fc[0], vert + 3 * (size_t)fc[1], vert + 3 * (size_t)fc[2], &t, &u, &v)) {
+                if (t >= 0.f && t < best) { best = t; bid = f; }
+            }
+        }
+        tid_out[i] = bid; t_out[i] = best;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* per-(view, texel) back-projection gather + ray visibility                                    */
+/* renderer_inverse.py:262-298 (ray set-up, NDC, grid_sample) and :316-325 (BVH test)           */
+/* ------------------------------------------------------------------------------------------- */
+typedef struct {
+    int T_h, T_w;            /* atlas size */
+    int n_views, H, W;       /* view images [n_views][H][W][4] (rgb + alpha), float32 */
+    float cos_thresh;        /* cos(ray_normal_angle_threshold) */
+} utxref_bp_cfg;
+
+static inline float bilinear_tap(const float* img, int H, int W, int x, int y, int c) {
+    if (x < 0 || x >= W || y < 0 || y >= H) return 0.f;
+    return img[((size_t)y * W + x) * 4 + c];
+}
+
+/*
+ * rast2d [T][4]; vert [V][3]; faces [F][3]; fnormal [F][3]; vndc [n_views][V][2];
+ * dirs [n_views][3] = -c2w[:, :3, 2]; images [n_views][H][W][4];
+ * out color [n_views][T][3], rayvis [n_views][T] (u8: own-triangle hit & angle), alphaok [n_views][T] (u8)
+ */
+void utxref_backproject(const utxref_bp_cfg* cfg, const float* rast2d, const float* vert, const int32_t* faces,
+                        const float* fnormal, const float* vndc, int V, const float* dirs, const float* images,
+                        const int32_t* info, const float* aabb, float* color, uint8_t* rayvis, uint8_t* alphaok) {
+    const long T = (long)cfg->T_h * cfg->T_w;
+    const int H = cfg->H, W = cfg->W;
+    const float two_sqrt3 = (float)(2.0 * sqrt(3.0));
+    for (int vw = 0; vw < cfg->n_views; ++vw) {
+        const float* d_in = dirs + 3 * vw;
+        const float* img = images + (size_t)vw * H * W * 4;
+        const float* nd = vndc + (size_t)vw * V * 2;
+        for (long t = 0; t < T; ++t) {
+            const float* r = rast2d + 4 * t;
+            int id = (int)r[3] - 1;
+            float* oc = color + ((size_t)vw * T + t) * 3;
+            oc[0] = oc[1] = oc[2] = 0.f; rayvis[(size_t)vw * T + t] = 0; alphaok[(size_t)vw * T + t] = 0;
+            if (id < 0) continue;
+            float u = r[0], v = r[1], w = (1.0f - u) - v;
+            const int32_t* f = faces + 3 * (size_t)id;
+            const float* p0 = vert + 3 * (size_t)f[0]; const float* p1 = vert + 3 * (size_t)f[1]; const float* p2 = vert + 3 * (size_t)f[2];
+            float p[3];
+            for (int a = 0; a < 3; ++a) p[a] = (p0[a] * u + p1[a] * v) + p2[a] * w;
+            /* rays: o = p - 2*sqrt(3)*d ; d normalised (F.normalize: d / max(|d|, 1e-12)) */
+            float ro[3] = {p[0] - two_sqrt3 * d_in[0], p[1] - two_sqrt3 * d_in[1], p[2] - two_sqrt3 * d_in[2]};
+            float dn = sqrtf(dot3(d_in, d_in)); if (dn < 1e-12f) dn = 1e-12f;
+            float d[3] = {d_in[0] / dn, d_in[1] / dn, d_in[2] / dn};
+            const float* n = fnormal + 3 * (size_t)id;
+            /* cosine_similarity(d, n): (d.n) / (max(|d|,1e-8) * max(|n|,1e-8)) */
+            float ld = sqrtf(dot3(d, d)); if (ld < 1e-8f) ld = 1e-8f;
+            float ln = sqrtf(dot3(n, n)); if (ln < 1e-8f) ln = 1e-8f;
+            float cs = dot3(d, n) / (ld * ln);
+            /* per-view NDC of the texel, then grid_sample(bilinear, align_corners=False, zeros) */
+            const float* n0 = nd + 2 * (size_t)f[0]; const float* n1 = nd + 2 * (size_t)f[1]; const float* n2 = nd + 2 * (size_t)f[2];
+            float gx = (n0[0] * u + n1[0] * v) + n2[0] * w;
+            float gy = (n0[1] * u + n1[1] * v) + n2[1] * w;
+            float ix = ((gx + 1.0f) * (float)W - 1.0f) * 0.5f;
+            float iy = ((gy + 1.0f) * (float)H - 1.0f) * 0.5f;
+            float fx = floorf(ix), fy = floorf(iy);
+            int x0 = (int)fx, y0 = (int)fy;
+            float tx = ix - fx, ty = iy - fy;
+            float w00 = (1.0f - tx) * (1.0f - ty), w01 = tx * (1.0f - ty), w10 = (1.0f - tx) * ty, w11 = tx * ty;
+            float s[4];
+            for (int c = 0; c < 4; ++c)
+                s[c] = ((bilinear_tap(img, H, W, x0, y0, c) * w00 + bilinear_tap(img, H, W, x0 + 1, y0, c) * w01) +
+                        bilinear_tap(img, H, W, x0, y0 + 1, c) * w10) + bilinear_tap(img, H, W, x0 + 1, y0 + 1, c) * w11;
+            oc[0] = s[0]; oc[1] = s[1]; oc[2] = s[2];
+            alphaok[(size_t)vw * T + t] = s[3] > 0.999f;
+            float th; int nv;
+            int hit = utxref_bvh_trace_one(info, aabb, vert, faces, ro, d, &th, &nv);
+            rayvis[(size_t)vw * T + t] = (hit == id && hit != -1 && cs < cfg->cos_thresh) ? 1 : 0;
+        }
+    }
+}

@@ -1,0 +1,78 @@
+"""Synthetic FLUX.1-dev-shaped weights generated directly in HBM (no checkpoints exist in the build or
+GPU containers and there is no network).  A dict-like object with the diffusers FluxTransformer2DModel
+key names: tensors are produced on demand on the device, deterministically per (seed, key)."""
+import math
+import zlib
+
+import torch
+
+
+class SyntheticFluxStateDict:
+    def __init__(self, shape, seed=0, device="cuda:0", dtype=torch.bfloat16):
+        self.sh, self.seed, self.device, self.dtype = shape, seed, torch.device(device), dtype
+        D, sh = shape.dim, shape
+        self._shapes = {}
+        lin = self._lin
+        lin("x_embedder", D, sh.in_channels)
+        lin("context_embedder", D, sh.joint_dim)
+        for nm, kin in (("timestep_embedder", 256), ("guidance_embedder", 256), ("text_embedder", sh.pooled_dim)):
+            lin("time_text_embed.%s.linear_1" % nm, D, kin)
+            lin("time_text_embed.%s.linear_2" % nm, D, D)
+        for i in range(sh.num_double):
+            p = "transformer_blocks.%d." % i
+            lin(p + "norm1.linear", 6 * D, D, 0.5)
+            lin(p + "norm1_context.linear", 6 * D, D, 0.5)
+            for nm in ("to_q", "to_k", "to_v", "add_q_proj", "add_k_proj", "add_v_proj", "to_out.0", "to_add_out"):
+                lin(p + "attn." + nm, D, D)
+            for nm in ("norm_q", "norm_k", "norm_added_q", "norm_added_k"):
+                self._shapes[p + "attn.%s.weight" % nm] = ((128,), "norm")
+            lin(p + "ff.net.0.proj", sh.mlp_ratio * D, D)
+            lin(p + "ff.net.2", D, sh.mlp_ratio * D)
+            lin(p + "ff_context.net.0.proj", sh.mlp_ratio * D, D)
+            lin(p + "ff_context.net.2", D, sh.mlp_ratio * D)
+        for i in range(sh.num_single):
+            p = "single_transformer_blocks.%d." % i
+            lin(p + "norm.linear", 3 * D, D, 0.5)
+            lin(p + "proj_mlp", sh.mlp_ratio * D, D)
+            lin(p + "proj_out", D, (1 + sh.mlp_ratio) * D)
+            for nm in ("to_q", "to_k", "to_v"):
+                lin(p + "attn." + nm, D, D)
+            for nm in ("norm_q", "norm_k"):
+                self._shapes[p + "attn.%s.weight" % nm] = ((128,), "norm")
+        lin("norm_out.linear", 2 * D, D, 0.5)
+        lin("proj_out", sh.in_channels, D)
+
+    def _lin(self, name, out_f, in_f, gain=1.0):
+        self._shapes[name + ".weight"] = ((out_f, in_f), gain / math.sqrt(in_f))
+        self._shapes[name + ".bias"] = ((out_f,), 0.02)
+
+    def __contains__(self, k):
+        return k in self._shapes
+
+    def keys(self):
+        return self._shapes.keys()
+
+    def __getitem__(self, k):
+        shp, std = self._shapes[k]
+        g = torch.Generator(device=self.device)
+        g.manual_seed((self.seed * 1000003 + zlib.crc32(k.encode())) & 0x7FFFFFFF)
+        t = torch.randn(shp, generator=g, device=self.device, dtype=torch.float32)
+        if std == "norm":
+            return (1.0 + 0.1 * t).to(self.dtype)
+        return (t * std).to(self.dtype)
+
+
+def synthetic_lora(state, shape, rank=64, seed=1, targets_double=None, device="cuda:0", dtype=torch.bfloat16):
+    """{module: (A [r,in], B [out,r])} for the reference's LoRA targets (trainer.py:282-295)."""
+    from .transformer import LORA_TARGETS_DOUBLE
+    out = {}
+    names = ["transformer_blocks.%d.%s" % (i, t) for i in range(shape.num_double) for t in LORA_TARGETS_DOUBLE]
+    names += ["single_transformer_blocks.%d.attn.%s" % (i, t) for i in range(shape.num_single) for t in ("to_q", "to_k", "to_v")]
+    for n in names:
+        (o, i), _ = state._shapes[n + ".weight"]
+        g = torch.Generator(device=device)
+        g.manual_seed((seed * 7919 + zlib.crc32(n.encode())) & 0x7FFFFFFF)
+        A = torch.randn(rank, i, generator=g, device=device) / math.sqrt(i)
+        B = torch.randn(o, rank, generator=g, device=device) * (0.1 / math.sqrt(rank))
+        out[n] = (A.to(dtype), B.to(dtype))
+    return out

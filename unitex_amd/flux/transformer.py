@@ -84,6 +84,7 @@ class FluxDiT:
         self._plans = {}
         self._lora_active: List[Tuple[Dict, float]] = []
         self._lora_version = 0
+        self.attn_events = None
         self._pack(state_dict)
 
     # ------------------------------------------------------------------ weights
@@ -409,7 +410,16 @@ class FluxDiT:
                     t = t + ws["e_g"]
                 torch.add(t, ws["e_p"], out=ws["temb"])
             elif fn is lib.utx_attn_fwd_bf16:
-                rc = fn(h, *d, st)
+                ev = getattr(self, "attn_events", None)
+                if ev is not None:  # bench.py: HIP events on the launch stream around the dominant kernel
+                    a = torch.cuda.Event(enable_timing=True)
+                    b = torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    rc = fn(h, *d, st)
+                    b.record()
+                    ev.append((a, b))
+                else:
+                    rc = fn(h, *d, st)
                 if rc:
                     self.ctx.check(rc)
             else:
