@@ -52,18 +52,18 @@ def step_flops(S):
 
 def cpu_baseline(S_full, threads):
     """Oracle (oracle/dit_ref.py, fp32 torch CPU) on a bounded sample: 1 double + 1 single FLUX block at
-    full width (D=3072, 24 heads), S_txt=256 + S_img=1792 tokens; extrapolated by algorithmic FLOPs."""
+    full width (D=3072, 24 heads), S_txt=128 + S_img=896 tokens; extrapolated by algorithmic FLOPs."""
     from oracle import dit_ref
     torch.set_num_threads(threads)
     cfg = dit_ref.FluxConfig(num_double=1, num_single=1)
     sd = dit_ref.make_synthetic_state_dict(cfg, seed=0, dtype=torch.float32)
-    S_txt, S_img = 256, 1792
+    S_txt, S_img = 128, 896
     g = torch.Generator().manual_seed(63)
     lat = torch.randn(S_img, 64, generator=g)
     enc = torch.zeros(S_txt, cfg.joint_dim)
     pooled = torch.zeros(1, cfg.pooled_dim)
     txt_ids = torch.zeros(S_txt, 3)
-    img_ids = dit_ref.latent_image_ids(28, 64)
+    img_ids = dit_ref.latent_image_ids(28, 32)
     t0 = time.perf_counter()
     dit_ref.flux_forward(sd, cfg, lat, enc, pooled, 0.5, 3.5, txt_ids, img_ids, emulate_bf16=False)
     dt = time.perf_counter() - t0
@@ -189,7 +189,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(S, os.cpu_count() or 1)
+                ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+                out["cpu_baseline"] = cpu_baseline(S, max(1, min(ncpu, 64)))
             except Exception as e:  # the GPU number must still be reported
                 out["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": "failed: %r" % (e,)}
