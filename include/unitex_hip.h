@@ -118,6 +118,84 @@ typedef struct utx_sched_desc {
 } utx_sched_desc;
 int utx_sched_step(utx_ctx* ctx, const utx_sched_desc* d, utx_stream stream);
 
+
+/* ------------------------------------------------------------------------------------------------
+ * TextureTools render / UV back-projection
+ * (TextureTools/texturetools/render/nvdiffrast/renderer_inverse.py:159-365,574-633,
+ *  raytracing/rt_aprmis, texture/stitching/mip.py, image/lens_blur.py)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* clip[n][v] = [x y z 1] . mvp[n]^T ; ndc (optional, may be NULL) = clip.xy / clip.w
+ * (renderer_inverse.py:263-265).  verts [V][3], mvp [n][4][4] row-major, clip [n][V][4], ndc [n][V][2]. */
+int utx_transform_points(utx_ctx* ctx, const float* verts, int V, const float* mvp, int n_views,
+                         float* clip, float* ndc, utx_stream stream);
+
+/* dr.rasterize replacement (renderer_inverse.py:183,273): pos [V][4] clip space, tri [F][3] int32,
+ * rast [H][W][4] = (u, v, z/w, triangle_id + 1), 0 = empty.  work: utx_rasterize_workspace_bytes. */
+long utx_rasterize_workspace_bytes(int F, int H, int W);
+int utx_rasterize(utx_ctx* ctx, const float* pos, const int* tri, int F, int H, int W, float* rast,
+                  void* work, utx_stream stream);
+
+/* dr.interpolate replacement (renderer_inverse.py:188,277,288): attr [V][C] -> out [npix][C]. */
+int utx_interpolate(utx_ctx* ctx, const float* attr, int C, const float* rast, const int* tri, long npix,
+                    float* out, utx_stream stream);
+
+/* LBVH ray-mesh intersector (raytracing/__init__.py:12-83 RayTracing / rt_aprmis APRMISRayTracing).
+ * The handle owns its node arrays (hipMalloc inside build); verts/faces are borrowed and must stay
+ * alive while the handle is used. */
+typedef struct utx_bvh utx_bvh;
+int utx_bvh_build(utx_ctx* ctx, const float* verts, int V, const int* faces, int F, utx_bvh** out, utx_stream stream);
+void utx_bvh_free(utx_bvh* bvh);
+/* device pointers to the node arrays (tests / diagnostics): info [2F-1][3], aabb [2F-1][6], sorted Morton
+ * codes [F], sorted element ids [F]; returns F. */
+int utx_bvh_arrays(utx_bvh* bvh, int** info, float** aabb, unsigned** codes_sorted, int** idx_sorted);
+/* intersects_closest (rt_aprmis/__init__.py:40-86): tid [R] int32, -1 = miss. */
+int utx_bvh_trace(utx_ctx* ctx, utx_bvh* bvh, const float* rays_o, const float* rays_d, long R, int* tid, utx_stream stream);
+
+/* fused per-(view, texel) gather + visibility of uv_to_pcd (renderer_inverse.py:277-298,316-325) */
+typedef struct utx_backproject_desc {
+    const void* rast2d;                 /* [T][4] f32 UV-space raster */
+    const void* verts; const void* faces; const void* fnormal;   /* [V][3] f32, [F][3] i32, [F][3] f32 */
+    const void* vndc;                   /* [n_views][V][2] f32 */
+    const void* dirs;                   /* [n_views][3] f32 = -c2w[:, :3, 2] (orthographic) */
+    const void* images;                 /* [n_views][H][W][4] f32 (rgb + alpha) */
+    void* color; void* rayvis; void* alphaok;   /* [n_views][T][3] f32, [n_views][T] u8, [n_views][T] u8 */
+    int T_h, T_w, V, n_views, H, W;
+    int view_begin, view_count;         /* views handled by this launch (per-GPU view sharding) */
+    float cos_thresh, two_sqrt3;
+} utx_backproject_desc;
+int utx_backproject(utx_ctx* ctx, const utx_backproject_desc* d, utx_bvh* bvh, utx_stream stream);
+
+/* visibility hole filling k=3,5 + AND coverage + AND alpha>0.999 (renderer_inverse.py:326-343).
+ * rayvis/alphaok/vis_out/tmp: [n_views][H][W] u8. */
+int utx_dilate_visibility(utx_ctx* ctx, const void* rayvis, const void* alphaok, const float* rast2d, int n_views,
+                          int H, int W, void* tmp, void* vis_out, utx_stream stream);
+
+/* first-come-wins priority composite (renderer_inverse.py:595-602).  order: HOST array of view ids.
+ * colors [n][T][3] f32, vis [n][T] u8 -> atlas [T][3] f32, winner [T] int8 (-1 = unseen). */
+int utx_composite(utx_ctx* ctx, const float* colors, const void* vis, const int* order_host, int n_order, long T,
+                  float* atlas, void* winner, utx_stream stream);
+
+/* seam mask (renderer_inverse.py:602-604): winner [H][W] int8 -> seam [H][W] u8; tmp [H][W] u8. */
+int utx_seam_mask(utx_ctx* ctx, const void* winner, const float* rast2d, int H, int W, void* tmp, void* seam, utx_stream stream);
+
+/* exact 3-D nearest-seen-texel fill of unseen covered texels, in place on atlas (renderer_inverse.py:606-615).
+ * pos [T][3] f32; nn_index [T] int32 (optional): chosen source texel or -1. */
+long utx_nn_fill_workspace_bytes(long T);
+int utx_nn_fill(utx_ctx* ctx, const float* pos, const void* winner, const float* rast2d, long T, float* atlas,
+                int* nn_index, void* work, long work_bytes, utx_stream stream);
+
+/* lens blur consumed on the seam only (image/lens_blur.py:260-280; renderer_inverse.py:620-624).
+ * k49_host: HOST array, the collapsed real 7x7 kernel. src/dst [H][W][3] f32. */
+int utx_lens_blur_seam(utx_ctx* ctx, const float* src, const void* seam, int H, int W, const float* k49_host, float* dst, utx_stream stream);
+
+/* pull-push hole filling (texture/stitching/mip.py:51-95). kd/out [H][W][3] f32, mask [H][W] u8. */
+long utx_pull_push_workspace_bytes(int H, int W);
+int utx_pull_push(utx_ctx* ctx, const float* kd, const void* mask, int H, int W, float* out, void* work, utx_stream stream);
+
+/* tensor_to_image (renderer_utils.py:62-83): clamp*255 -> u8 by truncation, optional vertical flip. */
+int utx_to_u8(utx_ctx* ctx, const float* src, long n_rows, long row_elems, int flip, void* dst, utx_stream stream);
+
 /* sizeof() of the descriptor structs above, in declaration order (ABI self-check for FFI mirrors). */
 int utx_abi_sizes(int* out, int n);
 

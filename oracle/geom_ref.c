@@ -410,3 +410,32 @@ void utxref_backproject(const utxref_bp_cfg* cfg, const float* rast2d, const flo
         }
     }
 }
+
+/* ------------------------------------------------------------------------------------------- */
+/* exact 1-NN fill, brute force (renderer_inverse.py:606-615; torch_kdtree [3p] restated as the  */
+/* mathematical definition).  d2 = (dx*dx + dy*dy) + dz*dz in float32; ties -> lowest texel index */
+/* ------------------------------------------------------------------------------------------- */
+void utxref_nn_fill_brute(const float* pos, const int8_t* winner, const float* rast2d, long T, float* atlas, int32_t* nn_index) {
+    long ns = 0;
+    int32_t* seen = (int32_t*)malloc((size_t)T * sizeof(int32_t));
+    for (long t = 0; t < T; ++t) if (winner[t] >= 0) seen[ns++] = (int32_t)t;
+    for (long t = 0; t < T; ++t) {
+        nn_index[t] = -1;
+        if (winner[t] >= 0 || !(rast2d[4 * t + 3] > 0.f)) continue;
+        float qx = pos[3 * t], qy = pos[3 * t + 1], qz = pos[3 * t + 2];
+        float best = 3.0e38f; int32_t bi = -1;
+        for (long k = 0; k < ns; ++k) {
+            int32_t j = seen[k];
+            float dx = pos[3 * (long)j] - qx, dy = pos[3 * (long)j + 1] - qy, dz = pos[3 * (long)j + 2] - qz;
+            float d2 = (dx * dx + dy * dy) + dz * dz;
+            if (d2 < best) { best = d2; bi = j; }   /* ascending j: first minimum = lowest index */
+        }
+        nn_index[t] = bi;
+    }
+    /* gather after all decisions (sources are seen texels, never overwritten) */
+    for (long t = 0; t < T; ++t) {
+        int32_t bi = nn_index[t];
+        if (bi >= 0) { atlas[3 * t] = atlas[3 * (long)bi]; atlas[3 * t + 1] = atlas[3 * (long)bi + 1]; atlas[3 * t + 2] = atlas[3 * (long)bi + 2]; }
+    }
+    free(seen);
+}

@@ -50,6 +50,7 @@ def lib():
         L.utxref_brute_trace.argtypes = [f32p, i32p, C.c_int, f32p, f32p, C.c_long, i32p, f32p]
         L.utxref_backproject.argtypes = [C.POINTER(BpCfg), f32p, f32p, i32p, f32p, f32p, C.c_int, f32p, f32p, i32p,
                                          f32p, f32p, u8p, u8p]
+        L.utxref_nn_fill_brute.argtypes = [f32p, np.ctypeslib.ndpointer(dtype=np.int8, flags="C_CONTIGUOUS"), f32p, C.c_long, f32p, i32p]
         _lib = L
     return _lib
 
@@ -327,6 +328,16 @@ def nn_fill(atlas, seen, mask2d, pos):
     return out, best
 
 
+def nn_fill_brute(atlas, winner, rast2d, pos):
+    """exact 1-NN fill with the float32 distance expression and tie rule of the HIP kernel (brute force)."""
+    H, W = winner.shape
+    out = _f(atlas).copy()
+    idx = np.full(H * W, -1, dtype=np.int32)
+    lib().utxref_nn_fill_brute(_f(pos).reshape(-1, 3), np.ascontiguousarray(winner, dtype=np.int8).reshape(-1),
+                               _f(rast2d).reshape(-1, 4), H * W, out.reshape(-1, 3), idx)
+    return out, idx.reshape(H, W)
+
+
 # ---- lens blur (image/lens_blur.py) -----------------------------------------------------------
 _LB5 = [[4.892608, 1.685979, -22.356787, 85.91246], [4.71187, 4.998496, 35.918936, -28.875618],
         [4.052795, 8.244168, -13.212253, -1.578428], [2.929212, 11.900859, 0.507991, 1.816328],
@@ -383,6 +394,35 @@ def lens_blur(img, radius=3.0, gamma=5.0):
         acc = acc + ((f1 - f4) * A + (f2 + f3) * B)
     out = np.power(np.maximum(acc, 0).astype(np.float32), np.float32(1.0 / gamma))
     return np.clip(out, 0, 1).astype(np.float32)
+
+
+def lens_blur_kernel49(radius=3.0):
+    """the 5 complex separable components collapsed into one real 7x7 kernel (float64 accumulate -> f32)."""
+    kr = int(math.ceil(radius))
+    n = 2 * kr + 1
+    ax = np.linspace(-radius, radius, n, dtype=np.float32) * np.float32(_LB5_SCALE) * np.float32(1 / radius)
+    K = np.zeros((n, n), dtype=np.float64)
+    for a, b, A, B in _LB5:
+        re = (np.exp(-a * ax ** 2) * np.cos(b * ax ** 2)).astype(np.float32).astype(np.float64)
+        im = (np.exp(-a * ax ** 2) * np.sin(b * ax ** 2)).astype(np.float32).astype(np.float64)
+        K += A * (np.outer(re, re) - np.outer(im, im)) + B * (np.outer(re, im) + np.outer(im, re))
+    return (K / K.sum()).astype(np.float32)
+
+
+def lens_blur_collapsed(img_hwc, seam, k49=None):
+    """the HIP kernel's formulation (utx_lens_blur_seam): one real 7x7 correlation of x^5 (zero padding,
+    row-major float32 accumulation), ^(1/5), clamp; evaluated on seam texels only."""
+    K = lens_blur_kernel49() if k49 is None else np.asarray(k49, dtype=np.float32)
+    x = img_hwc.astype(np.float32)
+    x5 = ((x * x) * (x * x)) * x
+    H, W, _ = x.shape
+    p = np.pad(x5, [(3, 3), (3, 3), (0, 0)])
+    acc = np.zeros_like(x)
+    for dy in range(7):
+        for dx in range(7):
+            acc = acc + np.float32(K[dy, dx]) * p[dy:dy + H, dx:dx + W]
+    out = np.clip(np.power(np.maximum(acc, 0).astype(np.float32), np.float32(0.2)), 0, 1).astype(np.float32)
+    return np.where(seam.astype(bool)[..., None], out, x).astype(np.float32)
 
 
 # ---- pull-push (texture/stitching/mip.py) -------------------------------------------------------

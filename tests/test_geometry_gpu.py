@@ -1,0 +1,185 @@
+"""GPU parity tests (through the C ABI) of the render / back-projection kernels against the CPU oracle
+(oracle/geom_ref.c + geom_ref.py).  Bar: BIT-EXACT for every integer / index / mask output and for
+the float32 outputs whose expression order is fixed on both sides (raster record, interpolation, gather,
+pull-push); stated tolerance only where libm (powf) is involved (lens blur)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import geom_ref as G
+from unitex_amd.texturetools.meshes import sphere_with_faces
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from unitex_amd.texturetools import ops
+    return ops
+
+
+def _cu(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda().contiguous()
+
+
+def _scene(n_faces=3000, T=256, HW=128, seed=0):
+    verts, faces, uvs = sphere_with_faces(n_faces)
+    c2ws = G.box_views_c2ws(2.8)[[0, 1, 4, 2, 3, 5]]  # f, r, t, b, l, d (export_nvdiffrast_video.py:926-936)
+    intr = G.intrinsics(1.0, 1.0, fov=False)
+    mvp = G.mvp_matrices(c2ws, intr, perspective=False)
+    rng = np.random.default_rng(seed)
+    return dict(verts=verts, faces=faces, uvs=uvs, c2ws=c2ws, mvp=mvp, T=T, HW=HW, rng=rng)
+
+
+def test_transform_and_raster_bit_exact():
+    ops = _ops()
+    s = _scene()
+    clip_ref = G.transform_points(s["verts"], s["mvp"])
+    clip, ndc = ops.transform_points(_cu(s["verts"]), _cu(s["mvp"]))
+    assert np.array_equal(clip.cpu().numpy(), clip_ref)
+    assert np.array_equal(ndc.cpu().numpy(), (clip_ref[..., :2] / clip_ref[..., 3:4]).astype(np.float32))
+    faces_d = _cu(s["faces"])
+    for v in range(6):
+        r_ref = G.rasterize(clip_ref[v], s["faces"], 128, 128)
+        r = ops.rasterize(clip[v].contiguous(), faces_d, 128, 128).cpu().numpy()
+        assert np.array_equal(r, r_ref), "view raster %d differs" % v
+        assert (r_ref[..., 3] > 0).mean() > 0.3
+    uvclip = np.concatenate([s["uvs"] * 2 - 1, np.zeros((len(s["uvs"]), 1), np.float32), np.ones((len(s["uvs"]), 1), np.float32)], -1)
+    for T in (64, 256, 1024):
+        r_ref = G.rasterize(uvclip, s["faces"], T, T)
+        r = ops.rasterize(_cu(uvclip), faces_d, T, T)
+        assert np.array_equal(r.cpu().numpy(), r_ref)
+        a_ref = G.interpolate(s["verts"], r_ref, s["faces"])
+        a = ops.interpolate(_cu(s["verts"]), r, faces_d).cpu().numpy()
+        assert np.array_equal(a, a_ref)
+
+
+def test_raster_big_triangles_and_edge_cases():
+    ops = _ops()
+    # two big triangles covering the viewport + a sliver + a degenerate + an off-screen one
+    pos = np.array([[-1, -1, 0.5, 1], [1, -1, 0.5, 1], [1, 1, 0.5, 1], [-1, 1, 0.5, 1],
+                    [-0.5, -0.5, 0.2, 1], [0.5, -0.5001, 0.2, 1], [0.5, -0.5, 0.2, 1],
+                    [0.1, 0.1, 0.0, 1], [0.1, 0.1, 0.0, 1], [0.3, 0.3, 0, 1],
+                    [2, 2, 0, 1], [3, 2, 0, 1], [2, 3, 0, 1],
+                    [-0.3, 0.2, -0.4, 2.0], [0.4, 0.3, -0.4, 1.5], [0.0, 0.9, 0.5, 1.0]], dtype=np.float32)
+    tri = np.array([[0, 1, 2], [0, 2, 3], [4, 5, 6], [7, 8, 9], [10, 11, 12], [13, 14, 15], [2, 1, 0]], dtype=np.int32)
+    for H, W in ((97, 131), (512, 512)):
+        ref = G.rasterize(pos, tri, H, W)
+        got = ops.rasterize(_cu(pos), _cu(tri), H, W).cpu().numpy()
+        assert np.array_equal(got, ref)
+        assert (ref[..., 3] > 0).all()
+
+
+def test_bvh_build_and_trace_bit_exact():
+    ops = _ops()
+    for nf in (1, 2, 500, 20000):
+        verts, faces, _ = sphere_with_faces(max(nf, 64))
+        faces = faces[:nf] if nf < 64 else faces
+        ref = G.BVH(verts, faces)
+        b = ops.BVH(_cu(verts), _cu(faces))
+        info, aabb, codes, idx = b.arrays()
+        assert np.array_equal(codes.cpu().numpy().view(np.uint32), ref.codes), "sorted morton codes"
+        assert np.array_equal(idx.cpu().numpy(), ref.order), "stable sort order"
+        assert np.array_equal(info.cpu().numpy(), ref.info), "hierarchy"
+        assert np.array_equal(aabb.cpu().numpy(), ref.aabb), "node boxes"
+        rng = np.random.default_rng(nf)
+        R = 20000
+        ro = np.stack([rng.uniform(-1, 1, R), rng.uniform(-1, 1, R), np.full(R, 2.8)], -1).astype(np.float32)
+        rd = np.tile(np.array([[0, 0, -1]], np.float32), (R, 1))
+        d2 = rng.normal(size=(R, 3)).astype(np.float32)
+        o2 = (-3.0 * d2 / np.linalg.norm(d2, axis=1, keepdims=True)).astype(np.float32) + rng.uniform(-0.3, 0.3, (R, 3)).astype(np.float32)
+        for o, d in ((ro, rd), (o2, d2)):
+            t_ref = ref.trace(o, d)
+            t = b.trace(_cu(o), _cu(d)).cpu().numpy()
+            assert np.array_equal(t, t_ref)
+        if nf >= 500:
+            assert (t_ref >= 0).mean() > 0.3
+
+
+def _full_case(n_faces, T, HW, seed):
+    s = _scene(n_faces, T, HW, seed)
+    verts, faces, uvs, mvp = s["verts"], s["faces"], s["uvs"], s["mvp"]
+    rng = s["rng"]
+    clip = G.transform_points(verts, mvp)
+    vndc = (clip[..., :2] / clip[..., 3:4]).astype(np.float32)
+    uvclip = np.concatenate([uvs * 2 - 1, np.zeros((len(uvs), 1), np.float32), np.ones((len(uvs), 1), np.float32)], -1)
+    rast2d = G.rasterize(uvclip, faces, T, T)
+    fn = G.face_normals(verts, faces)
+    dirs = (-s["c2ws"][:, :3, 2]).astype(np.float32)
+    # view images: smooth random colours, alpha = view-space coverage (mv_to_pcd alpha, renderer_inverse.py:185)
+    imgs = np.zeros((6, HW, HW, 4), np.float32)
+    yy, xx = np.meshgrid(np.linspace(0, 1, HW), np.linspace(0, 1, HW), indexing="ij")
+    for v in range(6):
+        ph = rng.uniform(0, 6.28, 6)
+        for c in range(3):
+            imgs[v, ..., c] = 0.5 + 0.5 * np.sin(7 * xx + ph[c]) * np.cos(5 * yy + ph[c + 3])
+        imgs[v, ..., 3] = (G.rasterize(clip[v], faces, HW, HW)[..., 3] > 0)
+    return dict(verts=verts, faces=faces, uvs=uvs, vndc=vndc, rast2d=rast2d, fn=fn, dirs=dirs, imgs=imgs)
+
+
+@pytest.mark.parametrize("n_faces,T,HW", [(3000, 256, 128), (20000, 512, 256)])
+def test_backprojection_chain_bit_exact(n_faces, T, HW):
+    ops = _ops()
+    c = _full_case(n_faces, T, HW, seed=n_faces)
+    bvh_ref = G.BVH(c["verts"], c["faces"])
+    col_ref, rv_ref, ao_ref = G.backproject(c["rast2d"], c["verts"], c["faces"], c["fn"], c["vndc"], c["dirs"], c["imgs"], bvh_ref)
+    vd, fd = _cu(c["verts"]), _cu(c["faces"])
+    bvh = ops.BVH(vd, fd)
+    rast_d = _cu(c["rast2d"])
+    col, rv, ao = ops.backproject(rast_d, vd, fd, _cu(c["fn"]), _cu(c["vndc"]), _cu(c["dirs"]), _cu(c["imgs"]), bvh)
+    assert np.array_equal(rv.cpu().numpy(), rv_ref), "ray visibility mask"
+    assert np.array_equal(ao.cpu().numpy(), ao_ref), "alpha mask"
+    assert np.array_equal(col.cpu().numpy(), col_ref), "gathered colours"
+    assert 0.05 < rv_ref.mean() < 0.9
+    # view sharding: views [2,4) only
+    col2, rv2, ao2 = ops.backproject(rast_d, vd, fd, _cu(c["fn"]), _cu(c["vndc"]), _cu(c["dirs"]), _cu(c["imgs"]), bvh,
+                                     view_begin=2, view_count=2)
+    assert np.array_equal(rv2.cpu().numpy()[2:4], rv_ref[2:4]) and rv2.cpu().numpy()[[0, 1, 4, 5]].sum() == 0
+    # hole filling + coverage + alpha
+    mask2d = c["rast2d"][..., 3] > 0
+    vis_ref = G.dilate_visibility(rv_ref, mask2d, ao_ref)
+    vis = ops.dilate_visibility(rv, ao, rast_d)
+    assert np.array_equal(vis.cpu().numpy().astype(bool), vis_ref)
+    # priority composite
+    atlas_ref, seen_ref, win_ref, bnd_ref = G.composite(col_ref, vis_ref)
+    atlas, winner = ops.composite(col, vis, G.PRIORITY)
+    assert np.array_equal(winner.cpu().numpy(), win_ref), "composite winner (texel index parity)"
+    assert np.array_equal(atlas.cpu().numpy(), atlas_ref)
+    # seam mask
+    seam_ref = G.seam_mask(bnd_ref, mask2d)
+    seam = ops.seam_mask(winner, rast_d)
+    assert np.array_equal(seam.cpu().numpy().astype(bool), seam_ref)
+    # NN fill (exact, brute-force oracle with the same float32 distance + tie rule)
+    pos_ref = G.interpolate(c["verts"], c["rast2d"], c["faces"])
+    pos = ops.interpolate(vd, rast_d, fd)
+    if T <= 256:
+        filled_ref, idx_ref = G.nn_fill_brute(atlas_ref, win_ref, c["rast2d"], pos_ref)
+        idx = ops.nn_fill(atlas, winner, rast_d, pos, want_index=True)
+        assert np.array_equal(idx.cpu().numpy().reshape(T, T), idx_ref), "nearest-seen-texel index"
+        assert np.array_equal(atlas.cpu().numpy(), filled_ref)
+        # independent check of the definition: scipy kd-tree agrees except on exact float ties
+        f2, _ = G.nn_fill(atlas_ref, seen_ref, mask2d, pos_ref)
+        assert (np.abs(f2 - filled_ref).max(-1) > 0).mean() < 1e-3
+    else:
+        ops.nn_fill(atlas, winner, rast_d, pos)
+        filled_ref, _ = G.nn_fill(atlas_ref, seen_ref, mask2d, pos_ref)
+        assert (np.abs(atlas.cpu().numpy() - filled_ref).max(-1) > 0).mean() < 1e-3
+        filled_ref = atlas.cpu().numpy()
+    # lens blur on the seam: powf differs between libm and the GPU -> 2e-6 abs
+    blur_ref = G.lens_blur_collapsed(filled_ref, seam_ref)
+    blur = ops.lens_blur_seam(atlas, seam)
+    assert np.abs(blur.cpu().numpy() - blur_ref).max() < 2e-6
+    sep = G.lens_blur(filled_ref.transpose(2, 0, 1)).transpose(1, 2, 0)  # the reference's separable formulation
+    assert np.abs(np.where(seam_ref[..., None], sep, filled_ref) - blur.cpu().numpy()).max() < 2e-5
+    # pull-push
+    pp_in = blur.cpu().numpy()
+    pp_ref = G.pull_push(pp_in.transpose(2, 0, 1), mask2d).transpose(1, 2, 0)
+    pp = ops.pull_push(blur, _cu(mask2d.astype(np.uint8)))
+    assert np.array_equal(pp.cpu().numpy(), pp_ref), "pull-push"
+    # uint8 by truncation + vertical flip
+    u8 = ops.to_u8(pp, flip=True).cpu().numpy()
+    assert np.array_equal(u8, G.tensor_to_u8(pp_ref)[::-1])

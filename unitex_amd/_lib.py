@@ -47,7 +47,15 @@ class SchedDesc(C.Structure):
                 ("n_noise_elems", c_long), ("n_total_elems", c_long), ("dsigma", c_float)]
 
 
-ABI_STRUCTS = [GemmDesc, GemvDesc, QkvPostDesc, LnModDesc, SchedDesc]
+class BackprojectDesc(C.Structure):
+    _fields_ = [("rast2d", c_void_p), ("verts", c_void_p), ("faces", c_void_p), ("fnormal", c_void_p),
+                ("vndc", c_void_p), ("dirs", c_void_p), ("images", c_void_p),
+                ("color", c_void_p), ("rayvis", c_void_p), ("alphaok", c_void_p),
+                ("T_h", c_int), ("T_w", c_int), ("V", c_int), ("n_views", c_int), ("H", c_int), ("W", c_int),
+                ("view_begin", c_int), ("view_count", c_int), ("cos_thresh", c_float), ("two_sqrt3", c_float)]
+
+
+ABI_STRUCTS = [GemmDesc, GemvDesc, QkvPostDesc, LnModDesc, SchedDesc, BackprojectDesc]
 
 # every symbol include/unitex_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
@@ -62,6 +70,25 @@ SYMBOLS = {
     "utx_qkv_post": (c_int, [c_void_p, C.POINTER(QkvPostDesc), c_void_p]),
     "utx_ln_mod": (c_int, [c_void_p, C.POINTER(LnModDesc), c_void_p]),
     "utx_sched_step": (c_int, [c_void_p, C.POINTER(SchedDesc), c_void_p]),
+    # geometry
+    "utx_transform_points": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "utx_rasterize_workspace_bytes": (c_long, [c_int, c_int, c_int]),
+    "utx_rasterize": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "utx_interpolate": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_long, c_void_p, c_void_p]),
+    "utx_bvh_build": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, C.POINTER(c_void_p), c_void_p]),
+    "utx_bvh_free": (None, [c_void_p]),
+    "utx_bvh_arrays": (c_int, [c_void_p, C.POINTER(c_void_p), C.POINTER(c_void_p), C.POINTER(c_void_p), C.POINTER(c_void_p)]),
+    "utx_bvh_trace": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_void_p]),
+    "utx_backproject": (c_int, [c_void_p, C.POINTER(BackprojectDesc), c_void_p, c_void_p]),
+    "utx_dilate_visibility": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "utx_composite": (c_int, [c_void_p, c_void_p, c_void_p, C.POINTER(c_int), c_int, c_long, c_void_p, c_void_p, c_void_p]),
+    "utx_seam_mask": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "utx_nn_fill_workspace_bytes": (c_long, [c_long]),
+    "utx_nn_fill": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
+    "utx_lens_blur_seam": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, C.POINTER(c_float), c_void_p, c_void_p]),
+    "utx_pull_push_workspace_bytes": (c_long, [c_int, c_int]),
+    "utx_pull_push": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "utx_to_u8": (c_int, [c_void_p, c_void_p, c_long, c_long, c_int, c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -82,12 +82,79 @@ int utx_sched_step(utx_ctx* ctx, const utx_sched_desc* d, utx_stream stream) {
     UTX_CALL(ctx, "utx_sched_step", utx_launch_sched_step(d, (hipStream_t)stream));
 }
 
+
+// ---- geometry ----
+int utx_transform_points(utx_ctx* ctx, const float* verts, int V, const float* mvp, int n_views, float* clip, float* ndc, utx_stream stream) {
+    if (!verts || !mvp || !clip) return fail(ctx, -2, "utx_transform_points");
+    UTX_CALL(ctx, "utx_transform_points", utx_launch_transform(verts, V, mvp, n_views, clip, ndc, (hipStream_t)stream));
+}
+long utx_rasterize_workspace_bytes(int F, int H, int W) { return 8L * H * W + 16 + 4L * F + 64; }
+int utx_rasterize(utx_ctx* ctx, const float* pos, const int* tri, int F, int H, int W, float* rast, void* work, utx_stream stream) {
+    if (!pos || !tri || !rast || !work) return fail(ctx, -2, "utx_rasterize");
+    UTX_CALL(ctx, "utx_rasterize", utx_launch_rasterize(pos, tri, F, H, W, rast, work, (hipStream_t)stream));
+}
+int utx_interpolate(utx_ctx* ctx, const float* attr, int C, const float* rast, const int* tri, long npix, float* out, utx_stream stream) {
+    if (!attr || !rast || !tri || !out) return fail(ctx, -2, "utx_interpolate");
+    UTX_CALL(ctx, "utx_interpolate", utx_launch_interpolate(attr, C, rast, tri, npix, out, (hipStream_t)stream));
+}
+int utx_bvh_build(utx_ctx* ctx, const float* verts, int V, const int* faces, int F, utx_bvh** out, utx_stream stream) {
+    if (!verts || !faces || !out) return fail(ctx, -2, "utx_bvh_build");
+    UTX_CALL(ctx, "utx_bvh_build", utx_bvh_build_impl(verts, V, faces, F, out, (hipStream_t)stream));
+}
+void utx_bvh_free(utx_bvh* bvh) { utx_bvh_free_impl(bvh); }
+int utx_bvh_arrays(utx_bvh* bvh, int** info, float** aabb, unsigned** codes_sorted, int** idx_sorted) {
+    return utx_bvh_arrays_impl(bvh, info, aabb, codes_sorted, idx_sorted);
+}
+int utx_bvh_trace(utx_ctx* ctx, utx_bvh* bvh, const float* ro, const float* rd, long R, int* tid, utx_stream stream) {
+    if (!bvh || !ro || !rd || !tid) return fail(ctx, -2, "utx_bvh_trace");
+    UTX_CALL(ctx, "utx_bvh_trace", utx_bvh_trace_impl(bvh, ro, rd, R, tid, (hipStream_t)stream));
+}
+int utx_backproject(utx_ctx* ctx, const utx_backproject_desc* d, utx_bvh* bvh, utx_stream stream) {
+    if (!d || !bvh || !d->rast2d || !d->verts || !d->faces || !d->fnormal || !d->vndc || !d->dirs || !d->images ||
+        !d->color || !d->rayvis || !d->alphaok || d->view_begin < 0 || d->view_begin + d->view_count > d->n_views)
+        return fail(ctx, -2, "utx_backproject");
+    UTX_CALL(ctx, "utx_backproject", utx_launch_backproject(d, bvh, (hipStream_t)stream));
+}
+int utx_dilate_visibility(utx_ctx* ctx, const void* rayvis, const void* alphaok, const float* rast2d, int n_views, int H, int W,
+                          void* tmp, void* vis_out, utx_stream stream) {
+    if (!rayvis || !alphaok || !rast2d || !tmp || !vis_out) return fail(ctx, -2, "utx_dilate_visibility");
+    UTX_CALL(ctx, "utx_dilate_visibility", utx_launch_dilate_visibility(rayvis, alphaok, rast2d, n_views, H, W, tmp, vis_out, (hipStream_t)stream));
+}
+int utx_composite(utx_ctx* ctx, const float* colors, const void* vis, const int* order_host, int n_order, long T, float* atlas,
+                  void* winner, utx_stream stream) {
+    if (!colors || !vis || !order_host || !atlas || !winner) return fail(ctx, -2, "utx_composite");
+    UTX_CALL(ctx, "utx_composite", utx_launch_composite(colors, vis, order_host, n_order, T, atlas, winner, (hipStream_t)stream));
+}
+int utx_seam_mask(utx_ctx* ctx, const void* winner, const float* rast2d, int H, int W, void* tmp, void* seam, utx_stream stream) {
+    if (!winner || !rast2d || !tmp || !seam) return fail(ctx, -2, "utx_seam_mask");
+    UTX_CALL(ctx, "utx_seam_mask", utx_launch_seam_mask(winner, rast2d, H, W, tmp, seam, (hipStream_t)stream));
+}
+long utx_nn_fill_workspace_bytes(long T) { return (long)utx_nn_fill_workspace_bytes_impl(T); }
+int utx_nn_fill(utx_ctx* ctx, const float* pos, const void* winner, const float* rast2d, long T, float* atlas, int* nn_index,
+                void* work, long work_bytes, utx_stream stream) {
+    if (!pos || !winner || !rast2d || !atlas || !work) return fail(ctx, -2, "utx_nn_fill");
+    UTX_CALL(ctx, "utx_nn_fill", utx_launch_nn_fill(pos, winner, rast2d, T, atlas, nn_index, work, (size_t)work_bytes, (hipStream_t)stream));
+}
+int utx_lens_blur_seam(utx_ctx* ctx, const float* src, const void* seam, int H, int W, const float* k49_host, float* dst, utx_stream stream) {
+    if (!src || !seam || !k49_host || !dst) return fail(ctx, -2, "utx_lens_blur_seam");
+    UTX_CALL(ctx, "utx_lens_blur_seam", utx_launch_lens_blur_seam(src, seam, H, W, k49_host, dst, (hipStream_t)stream));
+}
+long utx_pull_push_workspace_bytes(int H, int W) { return (long)utx_pull_push_workspace_bytes_impl(H, W); }
+int utx_pull_push(utx_ctx* ctx, const float* kd, const void* mask, int H, int W, float* out, void* work, utx_stream stream) {
+    if (!kd || !mask || !out || !work) return fail(ctx, -2, "utx_pull_push");
+    UTX_CALL(ctx, "utx_pull_push", utx_launch_pull_push(kd, mask, H, W, out, work, (hipStream_t)stream));
+}
+int utx_to_u8(utx_ctx* ctx, const float* src, long n_rows, long row_elems, int flip, void* dst, utx_stream stream) {
+    if (!src || !dst) return fail(ctx, -2, "utx_to_u8");
+    UTX_CALL(ctx, "utx_to_u8", utx_launch_to_u8(src, n_rows, row_elems, flip, dst, (hipStream_t)stream));
+}
+
 }  // extern "C"
 
 // Layout self-description, so the ctypes mirror in unitex_amd/_lib.py can be checked without a GPU.
 extern "C" int utx_abi_sizes(int* out, int n) {
     const int v[] = {(int)sizeof(utx_gemm_desc), (int)sizeof(utx_gemv_desc), (int)sizeof(utx_qkv_post_desc),
-                     (int)sizeof(utx_ln_mod_desc), (int)sizeof(utx_sched_desc)};
+                     (int)sizeof(utx_ln_mod_desc), (int)sizeof(utx_sched_desc), (int)sizeof(utx_backproject_desc)};
     const int m = (int)(sizeof(v) / sizeof(v[0]));
     for (int i = 0; i < m && i < n; ++i) out[i] = v[i];
     return m;

@@ -33,4 +33,21 @@ int utx_launch_gemv_bf16(const GemvParams* p, hipStream_t stream);
 int utx_launch_qkv_post(const QkvPostParams* p, hipStream_t stream);
 int utx_launch_ln_mod(const LnModParams* p, hipStream_t stream);
 int utx_launch_sched_step(const SchedParams* p, hipStream_t stream);
+int utx_launch_transform(const float* verts, int V, const float* mvp, int n_views, float* clip, float* ndc, hipStream_t stream);
+int utx_launch_rasterize(const float* pos, const int* tri, int F, int H, int W, float* rast, void* work, hipStream_t stream);
+int utx_launch_interpolate(const float* attr, int C, const float* rast, const int* tri, long npix, float* out, hipStream_t stream);
+int utx_bvh_build_impl(const float* verts, int V, const int* faces, int F, utx_bvh** out, hipStream_t stream);
+void utx_bvh_free_impl(utx_bvh* b);
+int utx_bvh_arrays_impl(utx_bvh* b, int** info, float** aabb, unsigned** codes_sorted, int** idx_sorted);
+int utx_bvh_trace_impl(utx_bvh* b, const float* ro, const float* rd, long R, int* tid, hipStream_t stream);
+int utx_launch_backproject(const utx_backproject_desc* p, const utx_bvh* bvh, hipStream_t stream);
+int utx_launch_dilate_visibility(const void* rayvis, const void* alphaok, const void* rast2d, int n_views, int Hh, int Ww, void* tmp, void* vis_out, hipStream_t stream);
+int utx_launch_composite(const float* colors, const void* vis, const int* order, int n_order, long T, float* atlas, void* winner, hipStream_t stream);
+int utx_launch_seam_mask(const void* winner, const float* rast2d, int Hh, int Ww, void* tmp, void* seam, hipStream_t stream);
+size_t utx_nn_fill_workspace_bytes_impl(long T);
+int utx_launch_nn_fill(const float* pos, const void* winner, const float* rast2d, long T, float* atlas, int* nn_index, void* work, size_t work_bytes, hipStream_t stream);
+int utx_launch_lens_blur_seam(const float* src, const void* seam, int Hh, int Ww, const float* k49_host, float* dst, hipStream_t stream);
+size_t utx_pull_push_workspace_bytes_impl(int Hh, int Ww);
+int utx_launch_pull_push(const float* kd, const void* mask, int Hh, int Ww, float* out, void* work, hipStream_t stream);
+int utx_launch_to_u8(const float* src, long n_rows, long row_elems, int flip, void* dst, hipStream_t stream);
 }
