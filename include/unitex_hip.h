@@ -140,6 +140,12 @@ int utx_rasterize(utx_ctx* ctx, const float* pos, const int* tri, int F, int H, 
 int utx_interpolate(utx_ctx* ctx, const float* attr, int C, const float* rast, const int* tri, long npix,
                     float* out, utx_stream stream);
 
+/* geometry-condition shading of VideoExporter.export_condition (video/export_nvdiffrast_video.py:956-989):
+ * rast [npix][4], interpolated vertex normals / positions [npix][3] -> uint8 normal / ccm images [npix][3]
+ * and alpha [npix], composited on bg3_host (HOST array of 3 floats), uint8 by truncation. */
+int utx_condition_shade(utx_ctx* ctx, const float* rast, const float* nrm, const float* pos, const float* bg3_host,
+                        long npix, void* out_normal, void* out_ccm, void* out_alpha, utx_stream stream);
+
 /* LBVH ray-mesh intersector (raytracing/__init__.py:12-83 RayTracing / rt_aprmis APRMISRayTracing).
  * The handle owns its node arrays (hipMalloc inside build); verts/faces are borrowed and must stay
  * alive while the handle is used. */

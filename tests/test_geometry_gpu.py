@@ -118,6 +118,8 @@ def _full_case(n_faces, T, HW, seed):
         for c in range(3):
             imgs[v, ..., c] = 0.5 + 0.5 * np.sin(7 * xx + ph[c]) * np.cos(5 * yy + ph[c + 3])
         imgs[v, ..., 3] = (G.rasterize(clip[v], faces, HW, HW)[..., 3] > 0)
+        # punch a hole in every view's alpha so that some covered texels are seen by no view (exercises NN fill)
+        imgs[v, ..., 3] *= (((xx - 0.5) ** 2 + (yy - 0.5) ** 2) > 0.16 ** 2) | (xx < 0.3)
     return dict(verts=verts, faces=faces, uvs=uvs, vndc=vndc, rast2d=rast2d, fn=fn, dirs=dirs, imgs=imgs)
 
 

@@ -97,6 +97,11 @@ int utx_interpolate(utx_ctx* ctx, const float* attr, int C, const float* rast, c
     if (!attr || !rast || !tri || !out) return fail(ctx, -2, "utx_interpolate");
     UTX_CALL(ctx, "utx_interpolate", utx_launch_interpolate(attr, C, rast, tri, npix, out, (hipStream_t)stream));
 }
+int utx_condition_shade(utx_ctx* ctx, const float* rast, const float* nrm, const float* pos, const float* bg3_host, long npix,
+                        void* out_normal, void* out_ccm, void* out_alpha, utx_stream stream) {
+    if (!rast || !nrm || !pos || !bg3_host || !out_normal || !out_ccm || !out_alpha) return fail(ctx, -2, "utx_condition_shade");
+    UTX_CALL(ctx, "utx_condition_shade", utx_launch_condition_shade(rast, nrm, pos, bg3_host, npix, out_normal, out_ccm, out_alpha, (hipStream_t)stream));
+}
 int utx_bvh_build(utx_ctx* ctx, const float* verts, int V, const int* faces, int F, utx_bvh** out, utx_stream stream) {
     if (!verts || !faces || !out) return fail(ctx, -2, "utx_bvh_build");
     UTX_CALL(ctx, "utx_bvh_build", utx_bvh_build_impl(verts, V, faces, F, out, (hipStream_t)stream));

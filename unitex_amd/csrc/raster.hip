@@ -206,3 +206,36 @@ extern "C" int utx_launch_transform(const float* verts, int V, const float* mvp,
     hipLaunchKernelGGL(transform_kernel, dim3((V + 255) / 256, n_views), dim3(256), 0, stream, verts, V, mvp, n_views, clip, ndc);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
+
+// ---- geometry-condition shading of export_condition (video/export_nvdiffrast_video.py:956-989 on top of
+// simple_rendering, render/nvdiffrast/renderer_base.py:172-200, enable_antialis=False):
+//   normal = lerp(-1, normalize(interp(v_nrm)), alpha); ccm = lerp(-1, interp(v_pos), mask)
+//   img = (x*0.5+0.5)*alpha + bg*(1-alpha) -> clamp*255 -> uint8 (truncation, A4)
+__global__ __launch_bounds__(256) void condition_shade_kernel(const float4* rast, const float* nrm, const float* pos, float bg0, float bg1,
+                                                              float bg2, long npix, unsigned char* out_normal, unsigned char* out_ccm,
+                                                              unsigned char* out_alpha) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    const float a = rast[i].w > 0.f ? 1.0f : 0.0f;
+    float n[3] = {nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2]};
+    float len = sqrtf((n[0] * n[0] + n[1] * n[1]) + n[2] * n[2]);
+    if (len < 1e-12f) len = 1e-12f;
+    const float bg[3] = {bg0, bg1, bg2};
+    for (int c = 0; c < 3; ++c) {
+        const float nv = a > 0.f ? n[c] / len : -1.0f;
+        const float pv = a > 0.f ? pos[3 * i + c] : -1.0f;
+        const float ni = (nv * 0.5f + 0.5f) * a + bg[c] * (1.0f - a);
+        const float pi = (pv * 0.5f + 0.5f) * a + bg[c] * (1.0f - a);
+        out_normal[3 * i + c] = (unsigned char)(fminf(fmaxf(ni, 0.f), 1.f) * 255.0f);
+        out_ccm[3 * i + c] = (unsigned char)(fminf(fmaxf(pi, 0.f), 1.f) * 255.0f);
+    }
+    out_alpha[i] = (unsigned char)(a * 255.0f);
+}
+
+extern "C" int utx_launch_condition_shade(const float* rast, const float* nrm, const float* pos, const float* bg3_host, long npix,
+                                          void* out_normal, void* out_ccm, void* out_alpha, hipStream_t stream) {
+    if (npix <= 0 || !bg3_host) return -2;
+    hipLaunchKernelGGL(condition_shade_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, stream, (const float4*)rast, nrm, pos,
+                       bg3_host[0], bg3_host[1], bg3_host[2], npix, (unsigned char*)out_normal, (unsigned char*)out_ccm, (unsigned char*)out_alpha);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}

@@ -1,0 +1,63 @@
+"""Checkpoint readers for the formats the reference loads (diffusers directory layout + peft/diffusers LoRA
+safetensors): /root/reference/pipeline.py:83-109.  Pure host I/O (safetensors -> torch tensors)."""
+import glob
+import json
+import os
+import re
+
+import torch
+
+
+def _load_dir(path):
+    from safetensors.torch import load_file
+    sd = {}
+    files = sorted(glob.glob(os.path.join(path, "*.safetensors")))
+    if not files:
+        raise FileNotFoundError("no .safetensors under %s" % path)
+    for f in files:
+        sd.update(load_file(f))
+    return sd
+
+
+def load_flux_transformer_state_dict(path):
+    """diffusers FluxTransformer2DModel checkpoint directory -> {key: tensor} (keys used as is)."""
+    return _load_dir(path)
+
+
+def load_vae(path, device, dtype=torch.bfloat16):
+    from .vae import AutoencoderKL
+    sd = _load_dir(path)
+    m = AutoencoderKL()
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    if missing:
+        raise KeyError("VAE checkpoint is missing keys, e.g. %s" % missing[:5])
+    return m.to(device=device, dtype=dtype).eval()
+
+
+def load_lora_safetensors(path, default_alpha=None):
+    """diffusers / peft LoRA file -> {module: (A [r,in], B [out,r])} with module names relative to the
+    transformer.  Accepts 'transformer.<module>.lora_A.weight' / 'lora_B.weight' (diffusers save_lora_weights,
+    trainer.py:480-490) and the '.lora.down/up.weight' spelling.  peft scaling alpha/r is folded into B."""
+    from safetensors import safe_open
+    tensors, meta = {}, {}
+    with safe_open(path, framework="pt") as f:
+        meta = f.metadata() or {}
+        for k in f.keys():
+            tensors[k] = f.get_tensor(k)
+    out = {}
+    for k, v in tensors.items():
+        m = re.match(r"^(?:transformer\.)?(.*)\.(lora_A|lora\.down)\.weight$", k)
+        if not m:
+            continue
+        mod = m.group(1)
+        up = k.replace("lora_A", "lora_B").replace("lora.down", "lora.up")
+        if up not in tensors:
+            raise KeyError("LoRA up weight missing for %s" % k)
+        A, B = v, tensors[up]
+        alpha = tensors.get(k.replace(".lora_A.weight", ".alpha").replace(".lora.down.weight", ".alpha"))
+        r = A.shape[0]
+        scale = (float(alpha) / r) if alpha is not None else (float(default_alpha) / r if default_alpha else 1.0)
+        out[mod] = (A, B * scale if scale != 1.0 else B)
+    if not out:
+        raise ValueError("no LoRA tensors recognised in %s" % path)
+    return out

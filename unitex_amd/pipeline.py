@@ -1,0 +1,201 @@
+"""CustomRGBTextureFullPipeline -- the reference's call surface (/root/reference/pipeline.py:141-632) on MI355X.
+
+    pipe = CustomRGBTextureFullPipeline(pretrain_models=..., super_resolutions=False, seed=63)
+    rembg_png, glb = pipe(save_dir, input_image_path, input_mesh_path, clear_cache=False)
+
+Stage sequence, artefact names and the uint8-PNG hand-off between stages (A5) are the reference's.  The DiT
+is FluxDiT + PBRFluxPipeline (HIP kernels), render / back-projection are VideoExporter /
+NVDiffRendererInverse (HIP kernels).  Out of scope this round (SURVEY 8f "next"): UV unwrapping of meshes
+without UVs, RMBG-2.0 background removal, the orbit video, super-resolution (TSD_SR)."""
+import os
+import shutil
+from typing import Tuple
+
+import numpy as np
+import torch
+from PIL import Image
+
+from .texturetools.timer import CPUTimer
+
+
+def build_pipeline(pretrain_models=None, pipeline_name="texture_plus", device="cuda:0", seed=0, lora_rank=64, shape=None):
+    """FluxDiT + VAE + adapters.  With a `pretrain_models` directory holding diffusers-format safetensors the real
+    weights are loaded; otherwise (no checkpoints exist here) FLUX.1-dev-shaped synthetic weights are generated."""
+    from .flux.pipeline import PBRFluxPipeline
+    from .flux.synthetic import SyntheticFluxStateDict, synthetic_lora
+    from .flux.transformer import FluxDiT, FluxShape
+    from .flux.vae import AutoencoderKL
+    shape = shape or FluxShape()
+    ckpt = os.path.join(pretrain_models, "black-forest-labs", "FLUX.1-dev") if pretrain_models else None
+    if ckpt and os.path.isdir(os.path.join(ckpt, "transformer")):
+        from .flux.lora_io import load_flux_transformer_state_dict, load_lora_safetensors, load_vae
+        sd = load_flux_transformer_state_dict(os.path.join(ckpt, "transformer"))
+        vae = load_vae(os.path.join(ckpt, "vae"), device)
+        tex = load_lora_safetensors(os.path.join(pretrain_models, "UniTex", "texture_gen", "pytorch_lora_weights.safetensors"))
+        dlt = load_lora_safetensors(os.path.join(pretrain_models, "UniTex", "delight", "pytorch_lora_weights.safetensors"))
+    else:
+        sd = SyntheticFluxStateDict(shape, seed=0, device=device)
+        vae = AutoencoderKL.synthetic(seed=0, device=device)
+        tex = synthetic_lora(sd, shape, rank=lora_rank, seed=1, device=device)
+        dlt = synthetic_lora(sd, shape, rank=lora_rank, seed=2, device=device)
+    pipe = PBRFluxPipeline(FluxDiT(sd, shape, device=device), vae, device=device)
+    pipe.load_lora_weights(tex, adapter_name="texture")
+    pipe.load_lora_weights(dlt, adapter_name="delight")
+    pipe._num_inference_steps = 28
+    return pipe, [1.0, 0.0], [0.0, 1.0], ["texture", "delight"]
+
+
+class RGBTextureFullPipelineBase:
+    def __init__(self, pretrain_models=None, pipeline_name="texture_plus", super_resolutions=False, seed=0, speedup_mode=None,
+                 add_lora_path=None, add_lora_weights=None, enable_rembg=False, device="cuda:0", pipeline=None,
+                 num_inference_steps=None, atlas_size=2048):
+        from .texturetools.renderer_inverse import NVDiffRendererInverse
+        from .texturetools.video import VideoExporter
+        if super_resolutions:
+            raise NotImplementedError("TSD_SR super-resolution is off by default in the reference (run.py:4) and out of scope")
+        if pipeline is None:
+            pipeline, wt, wd, names = build_pipeline(pretrain_models, pipeline_name, device=device)
+        else:
+            wt, wd, names = [1.0, 0.0], [0.0, 1.0], ["texture", "delight"]
+        if num_inference_steps is not None:
+            pipeline._num_inference_steps = num_inference_steps
+        self.weights_for_texture, self.weights_for_delight, self.adapter_names = wt, wd, names
+        self.pipeline_name = pipeline_name
+        self.pipeline = pipeline
+        self.video_exporter = VideoExporter(device=device)
+        self.inverse_renderer = NVDiffRendererInverse(device=device)
+        self.generator = torch.Generator().manual_seed(seed)   # ONE CPU generator shared by all draws (A19)
+        self.super_resolutions = super_resolutions
+        self.atlas_size = atlas_size
+
+    @CPUTimer("preprocess_blank_mesh")
+    def preprocess_blank_mesh(self, save_dir, input_mesh_path, min_faces=20_000, max_faces=200_000, scale=0.95):
+        """reference: open3d clean / decimate / UVAtlas (geometry/uv/uv_atlas.py:131-194).  Here: normalise to
+        bbox*scale and pass an already-unwrapped mesh through ('next' row f1)."""
+        from .texturetools import meshes
+        verts, faces, uvs, faces_uv = meshes.load_obj(input_mesh_path)
+        if uvs is None:
+            raise NotImplementedError("UV unwrapping is out of scope this round: provide an OBJ with vt records")
+        lo, hi = verts.min(0), verts.max(0)
+        verts = (verts - 0.5 * (lo + hi)) / ((hi - lo).max() / (2.0 * scale))
+        meshes.save_obj(os.path.join(save_dir, "processed_mesh.obj"), verts.astype(np.float32), faces, uvs, faces_uv)
+
+    @CPUTimer("preprocess_reference_image")
+    def preprocess_reference_image(self, save_dir, input_image_path, scale=0.95, color="grey"):
+        """reference: RMBG-2.0 matting, crop, recentre (image/process_image.py:31-74).  Here ('next' row f2): an
+        existing alpha channel is honoured, otherwise the image is used as is; composited on grey."""
+        img = Image.open(input_image_path)
+        rgba = img.convert("RGBA").resize((1024, 1024))
+        bg = Image.new("RGBA", rgba.size, (128, 128, 128, 255))
+        out = Image.alpha_composite(bg, rgba).convert("RGB")
+        out.save(os.path.join(save_dir, "rembg_image.png"))
+        out.resize((512, 512)).save(os.path.join(save_dir, "processed_image.png"))
+
+    @CPUTimer("render_geometry_images")
+    def render_geometry_images(self, save_dir, input_mesh_path, geometry_scale=0.95, scale=1.0, color="grey"):
+        out = self.video_exporter.export_condition(input_mesh_path, geometry_scale=geometry_scale, n_views=6, n_rows=2, n_cols=3,
+                                                   H=512, W=512, fov_deg=49.1, scale=scale, perspective=False, orbit=False,
+                                                   background=color, return_image=True, return_camera=True)
+        out["alpha"].save(os.path.join(save_dir, "mv_alpha.png"))
+        out["ccm"].save(os.path.join(save_dir, "mv_ccm.png"))
+        out["normal"].save(os.path.join(save_dir, "mv_normal.png"))
+        torch.save({"c2ws": out["c2ws"], "intrinsics": out["intrinsics"], "perspective": out["perspective"]},
+                   os.path.join(save_dir, "camera_info.pth"))
+
+    @CPUTimer("infer_mv")
+    def infer_mv(self, save_dir, input_image_path, input_mv_image_path, add_input_mv_image_path):
+        """reference pipeline.py:232-291: control = trunc(0.5*normal + 0.5*ccm) (A3); 2x3 grid frtbld -> 1x6 strip
+        f,l,r,b,t,d with the 'down' tile rotated 180 deg (A2); texture pass then delight pass; inverse mapping."""
+        reference_image = Image.open(input_image_path).convert("RGB")
+        normal = np.array(Image.open(input_mv_image_path).convert("RGB"))
+        ccm = np.array(Image.open(add_input_mv_image_path).convert("RGB"))
+        steps = getattr(self.pipeline, "_num_inference_steps", 28)
+        if self.pipeline_name != "texture_plus":
+            raise NotImplementedError("pipeline_name %s is not supported" % self.pipeline_name)
+        mix = (0.5 * normal.reshape(2, 512, 3, 512, -1) + 0.5 * ccm.reshape(2, 512, 3, 512, -1)).astype(np.uint8)
+        mix[1, :, 2] = mix[1, ::-1, 2, ::-1]
+        tiles = mix.transpose(0, 2, 1, 3, 4).reshape(6, 512, 512, -1)[[0, 4, 1, 3, 2, 5]]
+        control_image = Image.fromarray(tiles.transpose(1, 0, 2, 3).reshape(512, 6 * 512, -1))
+        common = dict(prompt="[MVFLUX]", prompt_embeds=None, pooled_prompt_embeds=None, height=512, width=3072, n_rows=1,
+                      n_cols=6, num_inference_steps=steps, guidance_scale=3.5, max_sequence_length=512, generator=self.generator)
+        self.pipeline.set_adapters(adapter_names=self.adapter_names, adapter_weights=self.weights_for_texture)
+        out_image = self.pipeline(control_image=control_image, dual_image=reference_image, **common).images[0]
+        out_image.save(os.path.join(save_dir, "mv_rgb_w_light.png"))
+        self.pipeline.set_adapters(adapter_names=self.adapter_names, adapter_weights=self.weights_for_delight)
+        delit = self.pipeline(control_image=out_image, **common).images[0]
+        t = np.array(delit).reshape(512, 6, 512, -1)
+        t[:, 5] = t[::-1, 5, ::-1]
+        grid = t.transpose(1, 0, 2, 3)[[0, 2, 4, 3, 1, 5]].reshape(2, 3, 512, 512, -1).transpose(0, 2, 1, 3, 4).reshape(1024, 1536, -1)
+        Image.fromarray(grid).save(os.path.join(save_dir, "mv_rgb.png"))
+
+    @CPUTimer("export_video")
+    def export_video(self, save_dir, input_mesh_path, output_video_name):
+        print("export_orbit_video (120-frame turntable) is a 'next' row (SURVEY 8f rank 3): skipped")
+
+    @CPUTimer("reproject_and_query_field")
+    def reproject_and_query_field(self, save_dir, input_mesh_path, input_mv_image_path, camera_info_path, four_or_six=False,
+                                  flatten=False, method="reproject", inpainting=False):
+        assert method in ["kdtree", "reproject"] and not four_or_six and not flatten
+        img = np.asarray(Image.open(input_mv_image_path).convert("RGB"), dtype=np.float32) / 255.0   # image_to_tensor
+        Hh, Ww, Cc = img.shape
+        HP, WP = Hh // 2, Ww // 3
+        image_attrs = torch.from_numpy(img).reshape(2, HP, 3, WP, Cc).permute(0, 2, 1, 3, 4).reshape(6, HP, WP, Cc)
+        cam = torch.load(camera_info_path, weights_only=True, map_location="cpu")
+        self.inverse_renderer.update_from_file(input_mesh_path)
+        T = self.atlas_size
+        textured, reprojected_uv, visable_mask, completed = self.inverse_renderer.infer(
+            input_mesh_path, c2ws=cam["c2ws"], intrinsics=cam["intrinsics"], image_attrs=image_attrs, perspective=cam["perspective"],
+            H=HP, W=WP, H2D=T, W2D=T, method=method, reproject_inpainting=inpainting, grad_norm_threhold=0.15,
+            ray_normal_angle_threhold=100, filt_gradient_points=inpainting)
+        textured.export(os.path.join(save_dir, "textured_mesh.glb"))
+
+        def save_mask(t, name):   # torchvision save_image: *255 + 0.5, clamp, uint8 [3p]
+            a = (t.float().clamp(0, 1) * 255 + 0.5).clamp(0, 255).to(torch.uint8).cpu().numpy()
+            Image.fromarray(a if a.ndim == 2 else a).save(os.path.join(save_dir, name))
+        save_mask(reprojected_uv.any(dim=0)[..., 0], "visable_uv_mask.png")
+        save_mask(visable_mask[0, ..., 0], "valid_uv_mask.png")
+        save_mask(completed[0], "completed_uv.png")
+        self.inverse_renderer.clear()
+        torch.cuda.empty_cache()
+
+
+class RGBTextureFullPipeline(RGBTextureFullPipelineBase):
+    def step_1_1(self, cache_dir, input_image_path, input_mesh_path, clear_cache=False, *args, **kwargs):
+        print("step_1_1: %s, %s" % (input_image_path, input_mesh_path))
+        self.preprocess_blank_mesh(cache_dir, input_mesh_path)
+        self.preprocess_reference_image(cache_dir, input_image_path)
+        self.render_geometry_images(cache_dir, os.path.join(cache_dir, "processed_mesh.obj"))
+        self.infer_mv(cache_dir, os.path.join(cache_dir, "processed_image.png"), os.path.join(cache_dir, "mv_normal.png"),
+                      os.path.join(cache_dir, "mv_ccm.png"))
+
+    def step_2_1(self, cache_dir, input_image_path, input_mesh_path, clear_cache=False, *args, **kwargs):
+        self.reproject_and_query_field(cache_dir, os.path.join(cache_dir, "processed_mesh.obj"), os.path.join(cache_dir, "mv_rgb.png"),
+                                       os.path.join(cache_dir, "camera_info.pth"), inpainting=False)
+
+    step_seq = ["step_1_1", "step_2_1"]
+
+    def __call__(self, save_dir: str, input_image_path: str, input_mesh_path: str, clear_cache=False) -> Tuple[str, str]:
+        os.makedirs(save_dir, exist_ok=True)
+        cache_dir = os.path.join(os.path.abspath(save_dir), "cache")
+        os.makedirs(cache_dir, exist_ok=True)
+        for step in self.step_seq:
+            getattr(self, step)(cache_dir=cache_dir, input_image_path=input_image_path, input_mesh_path=input_mesh_path,
+                                clear_cache=clear_cache)
+        for name in ("rembg_image.png", "mv_rgb.png", "textured_mesh.glb"):
+            shutil.copy(os.path.join(cache_dir, name), os.path.join(save_dir, name))
+        if clear_cache:
+            shutil.rmtree(cache_dir)
+        return os.path.join(save_dir, "rembg_image.png"), os.path.join(save_dir, "textured_mesh.glb")
+
+
+class CustomRGBTextureFullPipeline(RGBTextureFullPipeline):
+    step_seq = ["step_1_1", "step_2_ablition"]
+
+    def step_2_ablition(self, cache_dir, input_image_path, input_mesh_path, clear_cache=False, *args, **kwargs):
+        os.makedirs(os.path.join(cache_dir, "wo_LTM"), exist_ok=True)
+        os.makedirs(os.path.join(cache_dir, "w_LTM"), exist_ok=True)
+        self.reproject_and_query_field(os.path.join(cache_dir, "wo_LTM"), os.path.join(cache_dir, "processed_mesh.obj"),
+                                       os.path.join(cache_dir, "mv_rgb.png"), os.path.join(cache_dir, "camera_info.pth"), inpainting=False)
+        self.export_video(os.path.join(cache_dir, "wo_LTM"), os.path.join(cache_dir, "wo_LTM/textured_mesh.glb"), "textured_mesh.mp4")
+        shutil.copy(os.path.join(cache_dir, "wo_LTM/textured_mesh.glb"), os.path.join(cache_dir, "textured_mesh.glb"))
+        print("The second stage (LTM part) is unreleased in the reference (pipeline.py:631).")

@@ -1,0 +1,84 @@
+"""Camera helpers with the reference's names and conventions (host-side torch, tiny matrices).
+
+Mirrors TextureTools/texturetools/camera/conversion.py:8-28,50-57 and camera/generator.py:93-114,153-185
+of the reference (pinned by tests/golden/g4_cameras.npz)."""
+import math
+
+import torch
+
+
+def intr_to_proj(intr_mtx: torch.Tensor, near=0.01, far=1000.0, perspective=True):
+    """Normalised intrinsics [...,3,3] -> GL-style projection [...,4,4]; row 1 negated (y flip) exactly as
+    the reference does 'for nvdiffrast', so image row 0 is the top of the view."""
+    fx, fy = intr_mtx[..., 0, 0], intr_mtx[..., 1, 1]
+    cx, cy = intr_mtx[..., 0, 2], intr_mtx[..., 1, 2]
+    P = torch.zeros((*intr_mtx.shape[:-2], 4, 4), dtype=intr_mtx.dtype, device=intr_mtx.device)
+    if perspective:
+        P[..., 0, 0], P[..., 1, 1] = 2 * fx, 2 * fy
+        P[..., 0, 2], P[..., 1, 2] = 2 * cx - 1, 2 * cy - 1
+        P[..., 2, 2] = -(far + near) / (far - near)
+        P[..., 2, 3] = -2.0 * far * near / (far - near)
+        P[..., 3, 2] = -1.0
+    else:
+        P[..., 0, 0], P[..., 1, 1] = fx, fy
+        P[..., 0, 3], P[..., 1, 3] = -(2 * cx - 1), -(2 * cy - 1)
+        P[..., 2, 2] = -2.0 / (far - near)
+        P[..., 2, 3] = -(far + near) / (far - near)
+        P[..., 3, 3] = 1.0
+    P[..., 1, :] = -P[..., 1, :]
+    return P
+
+
+def c2w_to_w2c(c2w: torch.Tensor):
+    """rigid inverse: R^T, -R^T t"""
+    Rt = c2w[..., :3, :3].transpose(-1, -2)
+    w2c = torch.zeros_like(c2w)
+    w2c[..., :3, :3] = Rt
+    w2c[..., :3, 3:] = -Rt @ c2w[..., :3, 3:]
+    w2c[..., 3, 3] = 1.0
+    return w2c
+
+
+def generate_intrinsics(f_x: float, f_y: float, fov=True, degree=False):
+    """focal/size (or fov) -> normalised [3,3]; for orthographic cameras f is the scale."""
+    if fov:
+        if degree:
+            f_x, f_y = math.radians(f_x), math.radians(f_y)
+        f_x, f_y = 1 / (2 * math.tan(f_x / 2)), 1 / (2 * math.tan(f_y / 2))
+    return torch.tensor([[f_x, 0.0, 0.5], [0.0, f_y, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float32)
+
+
+# axis (right, up, back) per box view: front, right, back, left, top, down -- camera centre = radius * back
+_BOX_AXES = [
+    ((1, 0, 0), (0, 1, 0), (0, 0, 1)),
+    ((0, 0, -1), (0, 1, 0), (1, 0, 0)),
+    ((-1, 0, 0), (0, 1, 0), (0, 0, -1)),
+    ((0, 0, 1), (0, 1, 0), (-1, 0, 0)),
+    ((1, 0, 0), (0, 0, -1), (0, 1, 0)),
+    ((-1, 0, 0), (0, 0, -1), (0, -1, 0)),
+]
+
+
+def generate_box_views_c2ws(radius=2.8):
+    """the six hard-coded axis views of the reference (generator.py:153-185), order f, r, b, l, t, d."""
+    out = torch.zeros(6, 4, 4, dtype=torch.float32)
+    for i, (rx, up, bk) in enumerate(_BOX_AXES):
+        out[i, :3, 0] = torch.tensor(rx, dtype=torch.float32)
+        out[i, :3, 1] = torch.tensor(up, dtype=torch.float32)
+        out[i, :3, 2] = torch.tensor(bk, dtype=torch.float32)
+        out[i, :3, 3] = radius * torch.tensor(bk, dtype=torch.float32)
+        out[i, 3, 3] = 1.0
+    return out
+
+
+def parse_color(color):
+    """'grey' -> (128,128,128)/255 etc. (utils/parse_color.py:5-19 via PIL's colour map)."""
+    if color is None:
+        return None
+    if isinstance(color, str):
+        from PIL import ImageColor
+        rgb = ImageColor.getrgb(color)[:3]
+        return torch.tensor([c / 255.0 for c in rgb], dtype=torch.float32)
+    if isinstance(color, (int, float)):
+        return torch.tensor([float(color)] * 3, dtype=torch.float32)
+    return torch.tensor(list(color), dtype=torch.float32)

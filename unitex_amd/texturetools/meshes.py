@@ -31,9 +31,9 @@ def make_bumpy_sphere(n_lon=64, n_lat=32, bump=0.18, scale=0.95):
         for i in range(n_lon):
             a, b, c, d = j * W + i, j * W + i + 1, (j + 1) * W + i, (j + 1) * W + i + 1
             if j != 0:
-                faces.append((a, c, b))
+                faces.append((a, b, c))
             if j != n_lat - 1:
-                faces.append((b, c, d))
+                faces.append((b, d, c))
     faces = np.asarray(faces, dtype=np.int32)
     lo, hi = verts.min(0), verts.max(0)
     s = (hi - lo).max() / (2.0 * scale)

@@ -53,6 +53,18 @@ def interpolate(attr, rast, tri):
     return out
 
 
+def condition_shade(rast, nrm, pos, bg):
+    """rast [N,H,W,4], nrm/pos [N,H,W,3] -> uint8 normal, ccm [N,H,W,3], alpha [N,H,W]"""
+    ctx = get_ctx(rast.device.index)
+    npix = rast.numel() // 4
+    on = torch.empty(rast.shape[:-1] + (3,), dtype=U8, device=rast.device)
+    oc = torch.empty_like(on)
+    oa = torch.empty(rast.shape[:-1], dtype=U8, device=rast.device)
+    arr = (C.c_float * 3)(*[float(x) for x in bg])
+    ctx.check(ctx.lib.utx_condition_shade(ctx.handle, ptr(_f(rast)), ptr(_f(nrm)), ptr(_f(pos)), arr, npix, ptr(on), ptr(oc), ptr(oa), ctx.stream()))
+    return on, oc, oa
+
+
 class BVH:
     """utx_bvh handle (RayTracing / APRMISRayTracing of the reference)."""
 
