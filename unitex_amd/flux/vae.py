@@ -6,6 +6,10 @@ PyTorch-ROCm modules (MIOpen convolutions) on the GPU -- plumbing, not yet hand-
 DESIGN.md "out of scope this round".  Key names follow diffusers so a real `vae/` checkpoint loads.
 Call sites in the reference: flux_piplines/texturing/pipeline.py:226-238 (encode + sample + shift/scale)
 and :683-692 (unscale + decode)."""
+import os
+
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")  # avoid minutes of exhaustive conv tuning on first use
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F

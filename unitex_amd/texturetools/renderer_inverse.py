@@ -154,9 +154,9 @@ class NVDiffRendererInverse:
         # UV-space raster: uv in [-1,1] used directly as clip xy, z = 0, w = 1 (renderer_inverse.py:268-274)
         uvclip = torch.cat([m.uvs_2d, torch.zeros_like(m.uvs_2d[:, :1]), torch.ones_like(m.uvs_2d[:, :1])], dim=-1).contiguous()
         rast2d = ops.rasterize(uvclip, m.faces, H2D, W2D)
+        from .distributed import view_range
         rank, world = self.view_shard
-        per = (n + world - 1) // world
-        v0, v1 = min(rank * per, n), min((rank + 1) * per, n)
+        v0, v1, per = view_range(rank, world, n)
         color = torch.zeros(n, H2D, W2D, 3, dtype=torch.float32, device=dev)
         rayvis = torch.zeros(n, H2D, W2D, dtype=torch.uint8, device=dev)
         alphaok = torch.zeros(n, H2D, W2D, dtype=torch.uint8, device=dev)
@@ -182,19 +182,7 @@ class NVDiffRendererInverse:
         return out
 
     def _gather_layers(self, color, vis, per, n):
-        """ONE all-gather of the per-view layers (colour f32 + visibility u8 packed per rank)."""
-        import torch.distributed as dist
+        """ONE all-gather of the per-view layers (texturetools/distributed.py)."""
+        from .distributed import gather_view_layers
         rank, world = self.view_shard
-        T = color.shape[1] * color.shape[2]
-        pay = torch.zeros(per, T * 13, dtype=torch.uint8, device=color.device)
-        v0 = rank * per
-        for j in range(per):
-            if v0 + j < n:
-                pay[j, : T * 12] = color[v0 + j].reshape(-1).view(torch.uint8)
-                pay[j, T * 12:] = vis[v0 + j].reshape(-1)
-        allp = torch.empty(world * per, T * 13, dtype=torch.uint8, device=color.device)
-        dist.all_gather_into_tensor(allp, pay, group=self.process_group)
-        H2, W2 = color.shape[1:3]
-        color = allp[:n, : T * 12].contiguous().view(torch.float32).view(n, H2, W2, 3)
-        vis = allp[:n, T * 12:].contiguous().view(n, H2, W2)
-        return color, vis
+        return gather_view_layers(color, vis, rank, world, group=self.process_group)
