@@ -26,9 +26,10 @@ def timeit(fn, iters=5, warm=2):
 
 def main():
     quick = "--quick" in sys.argv
+    attn_only, gemm_only = "--attn-only" in sys.argv, "--gemm-only" in sys.argv
     dev = "cuda"
     H = 24
-    for S in ([13824] if quick else [9728, 13824, 50688]):
+    for S in ([] if gemm_only else ([13824] if quick else [9728, 13824, 50688])):
         S_pad = (S + 63) // 64 * 64
         q = torch.randn(H, S_pad, 128, device=dev).to(BF)
         k = torch.randn(H, S_pad, 128, device=dev).to(BF)
@@ -38,6 +39,8 @@ def main():
         fl = 4.0 * S * S * 128 * H
         print("attn S=%6d  med %8.3f ms  best %8.3f ms  -> %7.1f TF/s (%.1f%% of 2500)" % (S, med, best, fl / med / 1e9, fl / med / 1e9 / 25.0))
         del q, k, vt, out
+    if attn_only:
+        return
     shapes = [(13824, 9216, 3072), (13824, 3072, 3072), (13824, 12288, 3072), (13824, 3072, 12288),
               (13824, 21504, 3072), (13824, 3072, 15360), (512, 9216, 3072)]
     if not quick:

@@ -24,14 +24,17 @@
 // Algorithmic FLOPs: 4 * S^2 * 128 per head (QK^T + PV, non-causal).
 #include "common.h"
 #include "kernels.h"
+#include <stdlib.h>
 
-#define ATT_QB 256
 #define ATT_KVB 64
 #define ATT_D 128
 #define ATT_LDS_BYTES (2 * 32768)
 
 
-__global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnParams p) {
+template <int NW, int DEFER>
+__global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(AttnParams p) {
+    constexpr int ATT_QB = 32 * NW;      // queries per workgroup
+    constexpr int NPASS = 1024 / (64 * NW);  // staging passes: 1024 16-byte chunks per K (and per V) tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -59,36 +62,39 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnParams p) {
         for (int kk = 0; kk < 8; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(qp + kk * 16);
     }
 
-    // ---- staging registers (global -> regs -> LDS); named scalars so they stay in VGPRs
-    uint4 kreg0, kreg1, vreg0, vreg1;
-    const int k_row0 = tid >> 4, k_slot = tid & 15;  // + 32 rows on the 2nd pass
-    const int v_d0 = tid >> 3, v_slot = tid & 7;     // + 64 rows on the 2nd pass
-    const bf16_t* vsrc0 = vbase + (long)v_d0 * p.vt_ds + v_slot * 8;
-    const bf16_t* vsrc1 = vbase + (long)(v_d0 + 64) * p.vt_ds + v_slot * 8;
-    const int k_lds0 = k_row0 * 256 + ((k_slot ^ (k_row0 & 15)) << 4);
-    const int k_lds1 = (k_row0 + 32) * 256 + ((k_slot ^ ((k_row0 + 32) & 15)) << 4);
-    const int v_lds0 = v_d0 * 128 + ((v_slot ^ ((v_d0 >> 1) & 7)) << 4);
-    const int v_lds1 = (v_d0 + 64) * 128 + ((v_slot ^ (((v_d0 + 64) >> 1) & 7)) << 4);
-
+    // ---- staging registers (global -> regs -> LDS).  Named scalars (not arrays) so they stay in VGPRs:
+    // hipcc demotes small arrays touched under a runtime branch to scratch.
+    uint4 kreg0, kreg1, kreg2, kreg3, vreg0, vreg1, vreg2, vreg3;
+    const int k_slot = tid & 15, v_slot = tid & 7;
+#define ATT_SETUP(i_)                                                                            \
+    const int krow##i_ = (tid >> 4) + (i_) * (4 * NW);                                           \
+    const int vd##i_ = (tid >> 3) + (i_) * (8 * NW);                                             \
+    const int k_lds##i_ = krow##i_ * 256 + ((k_slot ^ (krow##i_ & 15)) << 4);                    \
+    const int v_lds##i_ = vd##i_ * 128 + ((v_slot ^ ((vd##i_ >> 1) & 7)) << 4);                  \
+    const bf16_t* vsrc##i_ = vbase + (long)vd##i_ * p.vt_ds + v_slot * 8;
+    ATT_SETUP(0) ATT_SETUP(1) ATT_SETUP(2) ATT_SETUP(3)
+#define ATT_LOAD1(i_, kv0_)                                                                      \
+    {                                                                                            \
+        int r_ = (kv0_) + krow##i_;                                                              \
+        if (r_ > S - 1) r_ = S - 1; /* tail rows are masked to -inf later; stay in-bounds */     \
+        kreg##i_ = *reinterpret_cast<const uint4*>(kbase + (long)r_ * p.k_ss + k_slot * 8);      \
+        vreg##i_ = *reinterpret_cast<const uint4*>(vsrc##i_ + (kv0_));                           \
+    }
 #define ATT_LOAD_TILE(t_)                                                                        \
     do {                                                                                         \
-        const int kv0_ = (t_) * ATT_KVB;                                                         \
-        int r0_ = kv0_ + k_row0, r1_ = kv0_ + k_row0 + 32;                                       \
-        if (r0_ > S - 1) r0_ = S - 1; /* tail rows are masked to -inf later; stay in-bounds */   \
-        if (r1_ > S - 1) r1_ = S - 1;                                                            \
-        kreg0 = *reinterpret_cast<const uint4*>(kbase + (long)r0_ * p.k_ss + k_slot * 8);        \
-        kreg1 = *reinterpret_cast<const uint4*>(kbase + (long)r1_ * p.k_ss + k_slot * 8);        \
-        vreg0 = *reinterpret_cast<const uint4*>(vsrc0 + kv0_);                                   \
-        vreg1 = *reinterpret_cast<const uint4*>(vsrc1 + kv0_);                                   \
+        const int kv0__ = (t_) * ATT_KVB;                                                        \
+        ATT_LOAD1(0, kv0__) ATT_LOAD1(1, kv0__)                                                  \
+        if constexpr (NPASS > 2) { ATT_LOAD1(2, kv0__) ATT_LOAD1(3, kv0__) }                     \
     } while (0)
+#define ATT_STORE1(i_)                                                                           \
+    *reinterpret_cast<uint4*>(kb_ + k_lds##i_) = kreg##i_;                                       \
+    *reinterpret_cast<uint4*>(vb_ + v_lds##i_) = vreg##i_;
 #define ATT_STORE_TILE(buf_)                                                                     \
     do {                                                                                         \
         char* kb_ = smem + (buf_) * 32768;                                                       \
         char* vb_ = kb_ + 16384;                                                                 \
-        *reinterpret_cast<uint4*>(kb_ + k_lds0) = kreg0;                                         \
-        *reinterpret_cast<uint4*>(kb_ + k_lds1) = kreg1;                                         \
-        *reinterpret_cast<uint4*>(vb_ + v_lds0) = vreg0;                                         \
-        *reinterpret_cast<uint4*>(vb_ + v_lds1) = vreg1;                                         \
+        ATT_STORE1(0) ATT_STORE1(1)                                                              \
+        if constexpr (NPASS > 2) { ATT_STORE1(2) ATT_STORE1(3) }                                 \
     } while (0)
 
     // ---- per-lane LDS read offsets
@@ -122,6 +128,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnParams p) {
 
         // ---- S^T = K Q^T  (2 blocks of 32 keys)
         f32x16 sacc[2];
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
 #pragma unroll
@@ -133,6 +140,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnParams p) {
                 sacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[kk], sacc[b], 0, 0, 0);
             }
         }
+        __builtin_amdgcn_s_setprio(0);
         // lane (q, h): sacc[b][r] = score(key = kv0 + 32b + 16(r>>3) + 8h + (r&7), query q)
 
         if (t == nt - 1 && (S & (ATT_KVB - 1))) {
@@ -153,7 +161,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[b][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
+        // defer-max (guide T13): while no row's max grows by more than THR (in exp2 units) keep the old
+        // running max -- P <= 2^THR stays well inside bf16/fp32 range and the O rescale pass is skipped.
+        float m_new = fmaxf(m_run, mx);
+        if (DEFER) { if (__all((mx - m_run) * c2 <= 8.0f)) m_new = m_run; }
         const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
         const float mc = m_new * c2;
         m_run = m_new;
@@ -176,6 +187,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnParams p) {
         }
 
         // ---- O^T += Vt P^T   (4 blocks of 32 d, 4 k-steps of 16 keys)
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
 #pragma unroll
@@ -186,6 +198,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnParams p) {
             }
         }
 
+        __builtin_amdgcn_s_setprio(0);
         if (t + 1 < nt) ATT_STORE_TILE(buf ^ 1);
         __syncthreads();
     }
@@ -208,25 +221,41 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(AttnParams p) {
     }
 }
 
+template <int NW, int DEFER>
+static int launch_variant(const AttnParams& p0, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<NW, DEFER>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES) != hipSuccess) return -3;
+        attr_set = true;
+    }
+    AttnParams p = p0;
+    p.nqb = (p.S + 32 * NW - 1) / (32 * NW);
+    hipLaunchKernelGGL((attn_fwd_kernel<NW, DEFER>), dim3(p.nqb * p.H), dim3(64 * NW), ATT_LDS_BYTES, stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+// variant selection: UTX_ATTN_VARIANT = "<waves><defer>" e.g. "41" (default), "80" = the round-1 v0 structure
+static int attn_variant() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("UTX_ATTN_VARIANT"); v = e ? atoi(e) : 41; }
+    return v;
+}
+
 extern "C" int utx_launch_attn_fwd(const void* q, const void* k, const void* vt, void* o,
                                    long q_hs, long q_ss, long k_hs, long k_ss, long vt_hs, long vt_ds,
                                    long o_ss, int H, int S, float scale, hipStream_t stream) {
     if (S <= 0 || H <= 0) return -1;
     if ((vt_ds & 7) || (q_ss & 7) || (k_ss & 7) || (o_ss & 3)) return -2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES);
-        if (e != hipSuccess) return -3;
-        attr_set = true;
-    }
     AttnParams p;
     p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.vt = (const bf16_t*)vt; p.o = (bf16_t*)o;
     p.q_hs = q_hs; p.q_ss = q_ss; p.k_hs = k_hs; p.k_ss = k_ss; p.vt_hs = vt_hs; p.vt_ds = vt_ds;
-    p.o_ss = o_ss; p.H = H; p.S = S;
-    p.nqb = (S + ATT_QB - 1) / ATT_QB;
+    p.o_ss = o_ss; p.H = H; p.S = S; p.nqb = 0;
     p.scale_log2 = scale * 1.4426950408889634f;
-    dim3 grid(p.nqb * H), block(512);
-    hipLaunchKernelGGL(attn_fwd_kernel, grid, block, ATT_LDS_BYTES, stream, p);
-    return hipGetLastError() == hipSuccess ? 0 : -4;
+    switch (attn_variant()) {
+        case 80: return launch_variant<8, 0>(p, stream);
+        case 81: return launch_variant<8, 1>(p, stream);
+        case 40: return launch_variant<4, 0>(p, stream);
+        default: return launch_variant<4, 1>(p, stream);
+    }
 }

@@ -66,25 +66,32 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
     const int nk = nk1 + (lora ? p.K2 / GM_BK : 0);
     const long a2_off = lora ? (long)(n0 / p.lora_seg_n) * p.K2 : 0;
 
-    // ---- glds source addressing: wave-instruction i covers tile rows 8i..8i+7 (1 KB of LDS)
+    // ---- glds source addressing: wave-instruction i covers tile rows 8i..8i+7 (1 KB of LDS).
+    // Row pointers live in named VGPR pairs and advance by BK elements per K-step (one 64-bit add per load
+    // instead of a 64-bit multiply chain); they are re-based once when the loop enters the LoRA K-segment.
+    // (No lambda / arrays here: hipcc spills by-reference captures of pointer sets to scratch.)
     const int srow_in = lane >> 3, sslot = lane & 7;
-    auto stage = [&](int kt, int buf) {
-        const bf16_t* Ab; const bf16_t* Bb; long la, lb; long kof;
-        if (kt < nk1) { Ab = pA; la = p.lda; Bb = pB; lb = p.ldb; kof = (long)kt * GM_BK; }
-        else { Ab = pA2 + a2_off; la = p.lda2; Bb = pB2; lb = p.ldb2; kof = (long)(kt - nk1) * GM_BK; }
-        char* sa = smem + buf * GM_STAGE_BYTES;
-        char* sb = sa + GM_BM * GM_BK * 2;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int i = wave + 4 * j;
-            const int row = 8 * i + srow_in;
-            const int chunk = sslot ^ ((row >> 1) & 7);
-            int gm = m0 + row; if (gm > p.M - 1) gm = p.M - 1;
-            int gn = n0 + row; if (gn > p.N - 1) gn = p.N - 1;
-            glds16(Ab + (long)gm * la + kof + chunk * 8, sa + i * 1024);
-            glds16(Bb + (long)gn * lb + kof + chunk * 8, sb + i * 1024);
-        }
-    };
+#define GM_SRC(j_)                                                                                       \
+    const int srow##j_ = 8 * (wave + 4 * (j_)) + srow_in;                                               \
+    const int schunk##j_ = (sslot ^ ((srow##j_ >> 1) & 7)) * 8;                                          \
+    const int sgm##j_ = (m0 + srow##j_ > p.M - 1) ? p.M - 1 : m0 + srow##j_;                             \
+    const int sgn##j_ = (n0 + srow##j_ > p.N - 1) ? p.N - 1 : n0 + srow##j_;                             \
+    const bf16_t* pa##j_ = pA + (long)sgm##j_ * p.lda + schunk##j_;                                      \
+    const bf16_t* pb##j_ = pB + (long)sgn##j_ * p.ldb + schunk##j_;
+    GM_SRC(0) GM_SRC(1) GM_SRC(2) GM_SRC(3)
+#define GM_REBASE(j_)                                                                                    \
+    pa##j_ = pA2 + a2_off + (long)sgm##j_ * p.lda2 + schunk##j_;                                         \
+    pb##j_ = pB2 + (long)sgn##j_ * p.ldb2 + schunk##j_;
+#define GM_STAGE1(j_)                                                                                    \
+    glds16(pa##j_, sa_ + (wave + 4 * (j_)) * 1024); pa##j_ += GM_BK;                                     \
+    glds16(pb##j_, sb_ + (wave + 4 * (j_)) * 1024); pb##j_ += GM_BK;
+#define GM_STAGE(kt_, buf_)                                                                              \
+    do {                                                                                                 \
+        if ((kt_) == nk1) { GM_REBASE(0) GM_REBASE(1) GM_REBASE(2) GM_REBASE(3) }                        \
+        char* sa_ = smem + (buf_) * GM_STAGE_BYTES;                                                      \
+        char* sb_ = sa_ + GM_BM * GM_BK * 2;                                                             \
+        GM_STAGE1(0) GM_STAGE1(1) GM_STAGE1(2) GM_STAGE1(3)                                              \
+    } while (0)
 
     f32x16 acc[2][2];  // [ni][mi]  (swapped MFMA: rows = n, cols = m)
 #pragma unroll
@@ -104,12 +111,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
         boff[i] = rb * 128; bswz[i] = (rb >> 1) & 7;
     }
 
-    stage(0, 0);
+    GM_STAGE(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+        if (kt + 1 < nk) GM_STAGE(kt + 1, buf ^ 1);
         const char* sa = smem + buf * GM_STAGE_BYTES;
         const char* sb = sa + GM_BM * GM_BK * 2;
 #pragma unroll
