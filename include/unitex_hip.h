@@ -47,7 +47,9 @@ const char* utx_last_error(utx_ctx* ctx);
  *   vt   : V transposed, element (h, d, s) at base + h*vt_hs + d*vt_ds + s; every row must be readable
  *          (finite) up to the next multiple of 64 past S
  *   o    : element (s, h, d) at base + s*o_ss + h*128 + d
- * Strides in elements; q_ss, k_ss, vt_ds multiples of 8, o_ss multiple of 4. */
+ * Strides in elements; q_ss, k_ss, vt_ds multiples of 8, o_ss multiple of 4.
+ * softmax_scale > 0: the reference's scale (1/sqrt(128)); softmax_scale == 0: Q was pre-multiplied by
+ * scale*log2(e) by utx_qkv_post (q_scale) and scores are used as base-2 exponents directly. */
 int utx_attn_fwd_bf16(utx_ctx* ctx, const void* q, const void* k, const void* vt, void* o,
                       long q_hs, long q_ss, long k_hs, long k_ss, long vt_hs, long vt_ds, long o_ss,
                       int H, int S, float softmax_scale, utx_stream stream);
@@ -97,6 +99,8 @@ typedef struct utx_qkv_post_desc {
     long hs_qk, hs_v, S_pad;
     int n_tok, tok_off, H;
     float eps;
+    float q_scale;                           /* multiplies Q before its bf16 rounding (1 = reference layout;
+                                                scale*log2(e) feeds utx_attn_fwd_bf16(softmax_scale = 0)) */
 } utx_qkv_post_desc;
 int utx_qkv_post(utx_ctx* ctx, const utx_qkv_post_desc* d, utx_stream stream);
 

@@ -31,14 +31,17 @@ def _mk_attn_inputs(H, S, seed, spike=False):
     return q, k, v
 
 
-def _run_attn(q, k, v):
+def _run_attn(q, k, v, prescaled=False):
     ops = _ops()
     H, S, _ = q.shape
     S_pad = (S + 63) // 64 * 64
-    Qh = torch.zeros(H, S_pad, 128, dtype=BF, device="cuda"); Qh[:, :S] = q.cuda()
+    qd = q.cuda()
+    if prescaled:   # what qkv_post(q_scale) hands to the kernel: Q * scale * log2(e), rounded once to bf16
+        qd = (qd.float() * (1.4426950408889634 / math.sqrt(128.0))).to(BF)
+    Qh = torch.zeros(H, S_pad, 128, dtype=BF, device="cuda"); Qh[:, :S] = qd
     Kh = torch.zeros(H, S_pad, 128, dtype=BF, device="cuda"); Kh[:, :S] = k.cuda()
     Vt = torch.zeros(H, 128, S_pad, dtype=BF, device="cuda"); Vt[:, :, :S] = v.cuda().transpose(1, 2)
-    out = ops.attention(Qh, Kh, Vt, S=S)
+    out = ops.attention(Qh, Kh, Vt, S=S, scale=0.0 if prescaled else None)
     torch.cuda.synchronize()
     return out.float().cpu().view(S, H, 128).permute(1, 0, 2)
 
@@ -53,6 +56,28 @@ def test_attention_matches_oracle(H, S, spike):
     # |v| <= ~4.5; P rounded to bf16 (2^-9 rel) + bf16 output rounding
     assert err < 3e-2, "attention max-abs err %g (H=%d S=%d)" % (err, H, S)
     assert torch.isfinite(out).all()
+    # pre-scaled-Q mode (the one FluxDiT uses): one extra bf16 rounding of Q at a different scale
+    out2 = _run_attn(q, k, v, prescaled=True)
+    err2 = (out2 - ref).abs().max().item()
+    assert err2 < 4e-2, "prescaled attention max-abs err %g (H=%d S=%d)" % (err2, H, S)
+
+
+def test_attention_large_negative_and_positive_scores():
+    """first-tile maxima far from 0 (both signs) and a late spike: exercises the re-centring path."""
+    H, S = 1, 320
+    g = torch.Generator().manual_seed(2)
+    q = torch.randn(H, S, 128, generator=g)
+    k = torch.randn(H, S, 128, generator=g)
+    v = torch.randn(H, S, 128, generator=g)
+    q[:, :100] *= 12.0           # |scores| up to ~ +-150 / sqrt(128) * ...
+    k[:, 300] = q[:, 3] * 0.5     # late spike for row 3
+    k[:, :64] = -q[:, 7:8] * 0.3  # strongly negative first tile for row 7
+    q, k, v = q.to(BF), k.to(BF), v.to(BF)
+    ref = dit_ref.sdpa(q.float(), k.float(), v.float(), em=False)
+    for pre in (False, True):
+        out = _run_attn(q, k, v, prescaled=pre)
+        assert torch.isfinite(out).all()
+        assert (out - ref).abs().max().item() < 6e-2
 
 
 def test_attention_asymmetric_layout():
@@ -211,6 +236,13 @@ def test_qkv_post():
     q = dit_ref._rb(dit_ref.apply_rope(q, cos, sin), True)
     k = dit_ref._rb(dit_ref.apply_rope(k, cos, sin), True)
     v = dit_ref._heads(x[:, 2 * D:], H)
+    # q_scale: Q is multiplied before its (single) bf16 rounding
+    Q2 = torch.zeros_like(Qh); K2 = torch.zeros_like(Kh); V2 = torch.zeros_like(Vt)
+    ops.qkv_post(qd[S_txt:], 0, D, 2 * D, wq.cuda(), wk.cuda(), cos.cuda(), sin.cuda(), Q2, K2, V2, S_img, S_txt, H, q_scale=0.1275)
+    torch.cuda.synchronize()
+    qs = dit_ref._rb(dit_ref.apply_rope(dit_ref.rms_norm(dit_ref._heads(x[:, :D], H), wq.float(), 1e-6, True), cos, sin) * 0.1275, True)
+    assert (Q2[:, S_txt:S].float().cpu() - qs[:, S_txt:]).abs().max().item() < 6e-3
+    assert torch.equal(K2[:, S_txt:S].cpu(), Kh[:, S_txt:S].cpu())
     for name, got, ref in (("q", Qh[:, :S].float().cpu(), q), ("k", Kh[:, :S].float().cpu(), k)):
         assert (got - ref).abs().max().item() < 4e-2, name
         assert (got == ref).float().mean().item() > 0.98, name

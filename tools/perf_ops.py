@@ -31,11 +31,12 @@ def main():
     H = 24
     for S in ([] if gemm_only else ([13824] if quick else [9728, 13824, 50688])):
         S_pad = (S + 63) // 64 * 64
-        q = torch.randn(H, S_pad, 128, device=dev).to(BF)
+        q = (torch.randn(H, S_pad, 128, device=dev) * (0.1275 if os.environ.get("UTX_PERF_PRESC", "1") == "1" else 1.0)).to(BF)
         k = torch.randn(H, S_pad, 128, device=dev).to(BF)
         vt = torch.randn(H, 128, S_pad, device=dev).to(BF)
         out = torch.empty(S, H * 128, dtype=BF, device=dev)
-        med, best = timeit(lambda: ops.attention(q, k, vt, S=S, out=out), iters=5 if S < 30000 else 3)
+        presc = os.environ.get("UTX_PERF_PRESC", "1") == "1"
+        med, best = timeit(lambda: ops.attention(q, k, vt, S=S, out=out, scale=0.0 if presc else None), iters=5 if S < 30000 else 3)
         fl = 4.0 * S * S * 128 * H
         print("attn S=%6d  med %8.3f ms  best %8.3f ms  -> %7.1f TF/s (%.1f%% of 2500)" % (S, med, best, fl / med / 1e9, fl / med / 1e9 / 25.0))
         del q, k, vt, out

@@ -34,7 +34,7 @@ class QkvPostDesc(C.Structure):
                 ("wq", c_void_p), ("wk", c_void_p), ("cosb", c_void_p), ("sinb", c_void_p),
                 ("Qh", c_void_p), ("Kh", c_void_p), ("Vt", c_void_p),
                 ("hs_qk", c_long), ("hs_v", c_long), ("S_pad", c_long),
-                ("n_tok", c_int), ("tok_off", c_int), ("H", c_int), ("eps", c_float)]
+                ("n_tok", c_int), ("tok_off", c_int), ("H", c_int), ("eps", c_float), ("q_scale", c_float)]
 
 
 class LnModDesc(C.Structure):

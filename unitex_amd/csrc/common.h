@@ -18,14 +18,16 @@ typedef uint16_t bf16_t;  // raw storage type used across the C ABI
 // fp32 -> bf16 round-to-nearest-even on raw bits (NaN kept quiet). Matches torch's
 // float->bfloat16 conversion, which the oracle uses.
 __device__ __forceinline__ uint16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
+    // gfx950 has a hardware RNE convert (v_cvt_pk_bf16_f32); same rounding as torch's float->bfloat16
+    const __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(uint16_t, b);
 }
 __device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    bf16x2_t v;
+    v[0] = (__bf16)lo; v[1] = (__bf16)hi;   // one v_cvt_pk_bf16_f32
+    return __builtin_bit_cast(uint32_t, v);
 }
 // round an fp32 value through bf16 (used to mirror the reference's bf16 tensor boundaries)
 __device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }

@@ -42,8 +42,9 @@ __global__ __launch_bounds__(256) void qkv_post_kernel(QkvPostParams p) {
             const float w0 = which ? wk0 : wq0, w1 = which ? wk1 : wq1;
             const float a0 = rbf(rbf(x0 * rstd) * w0);
             const float a1 = rbf(rbf(x1 * rstd) * w1);
-            const float r0 = a0 * cs + (-a1) * sn;
-            const float r1 = a1 * cs + a0 * sn;
+            const float qs = which ? 1.0f : p.q_scale;
+            const float r0 = (a0 * cs + (-a1) * sn) * qs;
+            const float r1 = (a1 * cs + a0 * sn) * qs;
             bf16_t* dst = (bf16_t*)(which ? p.Kh : p.Qh) + (long)head * p.hs_qk + srow * 128 + 2 * lane;
             *reinterpret_cast<uint32_t*>(dst) = pack2bf(r0, r1);
         }

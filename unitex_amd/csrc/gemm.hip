@@ -23,10 +23,12 @@
 // so global stores / residual loads are full 256-byte rows.
 #include "common.h"
 #include "kernels.h"
+#include <stdlib.h>
 
 #define GM_BM 128
 #define GM_BN 128
 #define GM_BK 64
+#define GM_GROUP_M 8
 #define GM_STAGE_BYTES (2 * GM_BM * GM_BK * 2)  // A tile + B tile = 32 KB
 #define GM_LDS_BYTES (2 * GM_STAGE_BYTES)       // 64 KB
 #define GM_CROW 272                             // epilogue C row stride in bytes (256 + 16 pad)
@@ -56,9 +58,18 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, lh = lane >> 5;
 
-    // XCD-aware tile order: consecutive logical tiles share the same A panel (same M tile).
+    // XCD-aware, L2-blocked tile order.  Each XCD walks a contiguous range of logical ids; ids are laid out in
+    // groups of GM_GROUP_M tile-rows, tn-major inside a group, so the ~64 tiles resident on an XCD at any moment
+    // form an 8x8 block sharing 8 A panels + 8 B panels (rocprof r01: the row-major order had 1 A + 64 B panels
+    // live -> 52% L2 miss, 8.4 GB fetched for 0.5 GB of operands, fabric-bound at 7 TB/s).
     const int w = xcd_remap(blockIdx.x, gridDim.x);
-    const int tm = w / p.ntn, tn = w - tm * p.ntn;
+    const int ntn = p.ntn & 0xffff, group_m = p.ntn >> 16;
+    const int ntm_ = (p.M + GM_BM - 1) / GM_BM;
+    const int per_group = group_m * ntn;
+    const int grp = w / per_group, rem = w - grp * per_group;
+    const int first_tm = grp * group_m;
+    const int gsize = (ntm_ - first_tm < group_m) ? ntm_ - first_tm : group_m;
+    const int tm = first_tm + rem % gsize, tn = rem / gsize;
     const int m0 = tm * GM_BM, n0 = tn * GM_BN;
 
     const int nk1 = p.K / GM_BK;
@@ -262,8 +273,13 @@ extern "C" int utx_launch_gemm_bf16(const GemmParams* hp, hipStream_t stream) {
         attr_set = true;
     }
     const int ntm = (p.M + GM_BM - 1) / GM_BM;
-    p.ntn = (p.N + GM_BN - 1) / GM_BN;
-    hipLaunchKernelGGL(gemm_bf16_kernel, dim3(ntm * p.ntn), dim3(256), GM_LDS_BYTES, stream, p);
+    const int ntn = (p.N + GM_BN - 1) / GM_BN;
+    static int group_env = -1;
+    if (group_env < 0) { const char* e = getenv("UTX_GEMM_GROUP_M"); group_env = e ? atoi(e) : 0; }
+    int group_m = group_env > 0 ? group_env : GM_GROUP_M;
+    if (group_m > ntm) group_m = ntm;
+    p.ntn = ntn | (group_m << 16);
+    hipLaunchKernelGGL(gemm_bf16_kernel, dim3(ntm * ntn), dim3(256), GM_LDS_BYTES, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 

@@ -34,7 +34,7 @@ def attention(q, k, vt, S=None, scale=None, out=None, o_ss=None):
     assert D == 128 and vt.shape[1] == 128 and vt.shape[2] % 64 == 0
     S = S_pad if S is None else S
     if scale is None:
-        scale = 1.0 / math.sqrt(D)
+        scale = 1.0 / math.sqrt(D)   # pass scale=0.0 when Q was pre-scaled by scale*log2(e) in qkv_post
     if out is None:
         out = torch.empty(S, H * D, dtype=torch.bfloat16, device=q.device)
     if o_ss is None:
@@ -99,7 +99,7 @@ def gemv(x, W, bias=None, silu_in=False, silu_out=False, out=None):
     return out
 
 
-def qkv_post(qkv, q_col, k_col, v_col, wq, wk, cos, sin, Qh, Kh, Vt, n_tok, tok_off, H, eps=1e-6):
+def qkv_post(qkv, q_col, k_col, v_col, wq, wk, cos, sin, Qh, Kh, Vt, n_tok, tok_off, H, eps=1e-6, q_scale=1.0):
     ctx = get_ctx(qkv.device.index)
     d = QkvPostDesc()
     d.qkv, d.ld = ptr(_bf(qkv)), qkv.stride(0)
@@ -109,7 +109,7 @@ def qkv_post(qkv, q_col, k_col, v_col, wq, wk, cos, sin, Qh, Kh, Vt, n_tok, tok_
     d.cosb, d.sinb = ptr(cos), ptr(sin)
     d.Qh, d.Kh, d.Vt = ptr(Qh), ptr(Kh), ptr(Vt)
     d.hs_qk, d.hs_v, d.S_pad = Qh.stride(0), Vt.stride(0), Vt.shape[2]
-    d.n_tok, d.tok_off, d.H, d.eps = n_tok, tok_off, H, eps
+    d.n_tok, d.tok_off, d.H, d.eps, d.q_scale = n_tok, tok_off, H, eps, q_scale
     ctx.check(ctx.lib.utx_qkv_post(ctx.handle, C.byref(d), ctx.stream()))
 
 

@@ -272,13 +272,14 @@ class FluxDiT:
         d.Qh, d.Kh, d.Vt = ptr(ws["Qh"]), ptr(ws["Kh"]), ptr(ws["Vt"])
         d.hs_qk, d.hs_v, d.S_pad = ws["Qh"].stride(0), ws["Vt"].stride(0), ws["Vt"].shape[2]
         d.n_tok, d.tok_off, d.H, d.eps = n_tok, tok_off, sh.num_heads, 1e-6
+        d.q_scale = (1.0 / math.sqrt(128.0)) * 1.4426950408889634   # scores become base-2 exponents (attention scale=0)
         plan.append((self.lib.utx_qkv_post, d))
 
     def _attn(self, plan, ws, out, S):
         sh = self.shape
         Qh, Kh, Vt = ws["Qh"], ws["Kh"], ws["Vt"]
         args = (ptr(Qh), ptr(Kh), ptr(Vt), ptr(out), Qh.stride(0), Qh.stride(1), Kh.stride(0), Kh.stride(1),
-                Vt.stride(0), Vt.stride(1), out.stride(0), sh.num_heads, S, 1.0 / math.sqrt(128.0))
+                Vt.stride(0), Vt.stride(1), out.stride(0), sh.num_heads, S, 0.0)
         plan.append((self.lib.utx_attn_fwd_bf16, args))
 
     def _gemv(self, plan, x, W, b, y, silu_in=False, silu_out=False):
