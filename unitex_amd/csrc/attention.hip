@@ -16,17 +16,19 @@
 //     are read through a permutation kappa() chosen so that the C-layout of the 32x32x16 MFMA leaves, in each
 //     lane, exactly the 8 consecutive keys the PV MFMA's B-operand wants: P goes to bf16 in registers and
 //     straight into the second MFMA (no LDS round trip, no permlane).  O^T = Vt P^T accumulates in 4 x f32x16.
-//   * K tile [64][128] / Vt tile [128][64] staged global -> regs -> LDS (issue early, write late) into a 2-deep
-//     ring, one s_barrier per tile.  LDS rows are PADDED by 16 B (272 / 144-byte strides) instead of
-//     XOR-swizzled: conflict-free for the ds_read_b128 lane groups AND every fragment address is
-//     base + immediate, which removes ~20 address VALU ops per tile.
-//   * softmax is VALU-issue-bound beside the MFMAs (round-1 PMC: MFMA busy 40 %, VALU busy 40 %, no overlap),
-//     so the VALU stream per tile is minimised: the score accumulators are INITIALISED to -m_run, i.e. the MFMA
-//     chain itself performs the max subtraction; with Q pre-scaled by scale*log2(e) upstream (qkv_post) a
-//     probability is ONE v_exp_f32.  The running max is only moved when some row would exceed 2^8
-//     ("defer-max", guide T13); that re-centring path is wave-uniform and rare.
-//   * deep operand prefetch: the 8 K fragments of key-block 0 are fetched up front, then one ds_read per MFMA
-//     (key-block 1, then the first 8 V fragments under the second half of QK^T).
+//   * K tile [64][128] / Vt tile [128][64] staged global -> regs -> LDS (issue early, write late), one
+//     s_barrier per tile.  LDS rows are PADDED by 16 B (272 / 144-byte strides) instead of XOR-swizzled:
+//     conflict-free for the ds_read_b128 lane groups AND every fragment address is base + immediate.
+//   * the softmax VALU stream is minimised: score accumulators are INITIALISED to -m_run (the MFMA chain does
+//     the max subtraction); with Q pre-scaled by scale*log2(e) upstream (qkv_post) a probability is ONE
+//     v_exp_f32; the running max only moves when some row would exceed 2^8 ("defer-max", guide T13).
+//   * PING (opt-in, UTX_ATTN_PING=1; measured SLOWER, see attn_ping() below): round-1 PMC showed MFMA busy ~40-45 % with the two waves of every SIMD executing
+//     QK^T / softmax / PV in lockstep behind the per-tile barrier -- both in VALU while the matrix pipe idles.
+//     Here the second half of the workgroup (waves NW/2.., the SIMD partners of waves 0..NW/2-1) runs its PV
+//     product ONE ITERATION LATE:   early waves: QK(t)  SM(t)  PV(t)      late waves: PV(t-1)  QK(t)  SM(t)
+//     so on each SIMD  [QK || PV]  is followed by  [softmax || QK]  and  [PV || softmax]: one wave's VALU phase
+//     always sits under its partner's MFMA phase, still with ONE s_barrier per tile.  Cost: a third Vt buffer
+//     (V(t-1) must outlive the barrier) -> 88 KB LDS.
 //
 // Algorithmic FLOPs: 4 * S^2 * 128 per head (QK^T + PV, non-causal).
 #include "common.h"
@@ -39,19 +41,22 @@
 #define ATT_VSTR 144                       // Vt tile row stride (128 + 16 pad)
 #define ATT_KTILE (64 * ATT_KSTR)          // 17408
 #define ATT_VTILE (128 * ATT_VSTR)         // 18432
-#define ATT_STAGE (ATT_KTILE + ATT_VTILE)  // 35840
-#define ATT_LDS_BYTES (2 * ATT_STAGE)      // 71680
+#define ATT_LDS_BYTES(nvb) (2 * ATT_KTILE + (nvb) * ATT_VTILE)
 
-template <int NW, int PRESC>
+template <int NW, int PRESC, int PING>
 __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(AttnParams p) {
     constexpr int ATT_QB = 32 * NW;          // queries per workgroup
     constexpr int NPASS = 1024 / (64 * NW);  // staging passes: 1024 16-byte chunks per K (and per V) tile
+    constexpr int NVB = PING ? 3 : 2;        // Vt ring depth
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const kring = smem;
+    char* const vring = smem + 2 * ATT_KTILE;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lq = lane & 31;   // query column owned by this lane (MFMA C column)
     const int lh = lane >> 5;   // lane half
+    const bool late = PING && (wave >= NW / 2);   // wave-uniform
 
     // XCD-aware work mapping: consecutive logical ids (= same head) stay on one XCD's L2.
     const int w = xcd_remap(blockIdx.x, gridDim.x);
@@ -81,7 +86,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(AttnParams p) {
     const int krow##i_ = (tid >> 4) + (i_) * (4 * NW);                                           \
     const int vd##i_ = (tid >> 3) + (i_) * (8 * NW);                                             \
     const int k_lds##i_ = krow##i_ * ATT_KSTR + (k_slot << 4);                                   \
-    const int v_lds##i_ = ATT_KTILE + vd##i_ * ATT_VSTR + (v_slot << 4);                         \
+    const int v_lds##i_ = vd##i_ * ATT_VSTR + (v_slot << 4);                                     \
     const bf16_t* vsrc##i_ = vbase + (long)vd##i_ * p.vt_ds + v_slot * 8;
     ATT_SETUP(0) ATT_SETUP(1) ATT_SETUP(2) ATT_SETUP(3)
 #define ATT_LOAD1(i_, kv0_)                                                                      \
@@ -98,11 +103,12 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(AttnParams p) {
         if constexpr (NPASS > 2) { ATT_LOAD1(2, kv0__) ATT_LOAD1(3, kv0__) }                     \
     } while (0)
 #define ATT_STORE1(i_)                                                                           \
-    *reinterpret_cast<uint4*>(st_ + k_lds##i_) = kreg##i_;                                       \
-    *reinterpret_cast<uint4*>(st_ + v_lds##i_) = vreg##i_;
-#define ATT_STORE_TILE(buf_)                                                                     \
+    *reinterpret_cast<uint4*>(kst_ + k_lds##i_) = kreg##i_;                                      \
+    *reinterpret_cast<uint4*>(vst_ + v_lds##i_) = vreg##i_;
+#define ATT_STORE_TILE(kbuf_, vbuf_)                                                             \
     do {                                                                                         \
-        char* st_ = smem + (buf_) * ATT_STAGE;                                                   \
+        char* kst_ = kring + (kbuf_) * ATT_KTILE;                                                \
+        char* vst_ = vring + (vbuf_) * ATT_VTILE;                                                \
         ATT_STORE1(0) ATT_STORE1(1)                                                              \
         if constexpr (NPASS > 2) { ATT_STORE1(2) ATT_STORE1(3) }                                 \
     } while (0)
@@ -111,8 +117,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(AttnParams p) {
     // kappa: MFMA row i = 8a + 4h' + c  ->  key 16(a>>1) + 8h' + 4(a&1) + c   (within a 32-key block)
     const int ka = lq >> 3, khp = (lq >> 2) & 1, kc = lq & 3;
     const int krow = 16 * (ka >> 1) + 8 * khp + 4 * (ka & 1) + kc;
-    const int k_off = krow * ATT_KSTR + lh * 16;             // + b*32*ATT_KSTR + kk*32
-    const int v_off = ATT_KTILE + lq * ATT_VSTR + lh * 16;   // + db*32*ATT_VSTR + s*32
+    const int k_off = krow * ATT_KSTR + lh * 16;   // + b*32*ATT_KSTR + kk*32
+    const int v_off = lq * ATT_VSTR + lh * 16;     // + db*32*ATT_VSTR + s*32
 
     f32x16 oacc[4];
 #pragma unroll
@@ -122,10 +128,33 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(AttnParams p) {
     float m_run = 0.f;     // running (deferred) max, raw score units; set from tile 0
     float l_run = 0.f;     // this lane-half's partial row sum
     const float c2 = p.scale_log2;
+    bf16x8 pb[4];          // P of the current (late waves: previous) tile as PV B-operands
+
+    // O^T += Vt P^T for one tile: 4 blocks of 32 d x 4 k-steps of 16 keys; fragments 8 reads ahead
+#define ATT_PV(vb_)                                                                              \
+    {                                                                                            \
+        const char* vt__ = (vb_) + v_off;                                                        \
+        bf16x8 vf_[8], vg_[8];                                                                   \
+        __builtin_amdgcn_s_setprio(1);                                                           \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i)                                            \
+            vf_[i] = *reinterpret_cast<const bf16x8*>(vt__ + (i & 3) * 32 * ATT_VSTR + (i >> 2) * 32); \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                          \
+            vg_[i] = *reinterpret_cast<const bf16x8*>(vt__ + (i & 3) * 32 * ATT_VSTR + (2 + (i >> 2)) * 32); \
+            oacc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf_[i], pb[i >> 2], oacc[i & 3], 0, 0, 0); \
+        }                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i)                                            \
+            oacc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vg_[i], pb[2 + (i >> 2)], oacc[i & 3], 0, 0, 0); \
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                                       \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                       \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                   \
+        }                                                                                        \
+        __builtin_amdgcn_s_setprio(0);                                                           \
+    }
 
     const int nt = (S + ATT_KVB - 1) / ATT_KVB;
     ATT_LOAD_TILE(0);
-    ATT_STORE_TILE(0);
+    ATT_STORE_TILE(0, 0);
     __syncthreads();
     // Retire the Q loads HERE, in the compiler's own scoreboard: otherwise hipcc guards every QK^T MFMA of the
     // loop with vmcnt(7)..vmcnt(0) for "possibly still pending" Q fragments, which drains the NEXT tile's
@@ -133,10 +162,14 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) asm volatile("" : "+v"(qf[kk]));
 
+    int vcur = 0;   // ring slot of V(t); V(t-1) sits in the previous slot, V(t+1) goes to the next one
     for (int t = 0; t < nt; ++t) {
-        const int buf = t & 1;
         if (t + 1 < nt) ATT_LOAD_TILE(t + 1);
-        const char* st = smem + buf * ATT_STAGE;
+        const char* kb = kring + (t & 1) * ATT_KTILE;
+        const int vprev = (vcur == 0) ? NVB - 1 : vcur - 1;
+        const int vnext = (vcur == NVB - 1) ? 0 : vcur + 1;
+
+        if (PING && late && t > 0) ATT_PV(vring + vprev * ATT_VTILE)   // late waves: PV of the previous tile
 
         // ---- S'^T = K Q^T - m_run : accumulators start at -m_run, so the MFMA chain does the max subtraction
         f32x16 sacc[2];
@@ -145,26 +178,23 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(AttnParams p) {
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) sacc[b][r] = neg_m;
-        bf16x8 vf[8];   // first 8 V fragments, fetched under the second half of QK^T
         __builtin_amdgcn_s_setprio(1);
         {
             bf16x8 kf0[8], kf1[8];
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk)
-                kf0[kk] = *reinterpret_cast<const bf16x8*>(st + k_off + kk * 32);
+                kf0[kk] = *reinterpret_cast<const bf16x8*>(kb + k_off + kk * 32);
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) {
-                kf1[kk] = *reinterpret_cast<const bf16x8*>(st + k_off + 32 * ATT_KSTR + kk * 32);
+                kf1[kk] = *reinterpret_cast<const bf16x8*>(kb + k_off + 32 * ATT_KSTR + kk * 32);
                 sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[kk], qf[kk], sacc[0], 0, 0, 0);
             }
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk) {
-                vf[kk] = *reinterpret_cast<const bf16x8*>(st + v_off + (kk & 3) * 32 * ATT_VSTR + (kk >> 2) * 32);
+            for (int kk = 0; kk < 8; ++kk)
                 sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[kk], qf[kk], sacc[1], 0, 0, 0);
-            }
             __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
 #pragma unroll
-            for (int i_ = 0; i_ < 16; ++i_) {
+            for (int i_ = 0; i_ < 8; ++i_) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
@@ -208,7 +238,6 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(AttnParams p) {
                 for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
         }
         float psum = 0.f;
-        bf16x8 pb[4];
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -219,27 +248,15 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(AttnParams p) {
             }
         l_run += psum;
 
-        // ---- O^T += Vt P^T   (4 blocks of 32 d, 4 k-steps of 16 keys)
-        __builtin_amdgcn_s_setprio(1);
-        {
-            bf16x8 vg[8];   // fragments of PV k-steps 2,3, fetched under k-steps 0,1
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                vg[i] = *reinterpret_cast<const bf16x8*>(st + v_off + (i & 3) * 32 * ATT_VSTR + (2 + (i >> 2)) * 32);
-                oacc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[i], pb[i >> 2], oacc[i & 3], 0, 0, 0);
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                oacc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vg[i], pb[2 + (i >> 2)], oacc[i & 3], 0, 0, 0);
-#pragma unroll
-            for (int i_ = 0; i_ < 8; ++i_) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-        }
-        __builtin_amdgcn_s_setprio(0);
-        if (t + 1 < nt) ATT_STORE_TILE(buf ^ 1);
+        if (!(PING && late)) ATT_PV(vring + vcur * ATT_VTILE)   // early waves: PV of this tile
+
+        if (t + 1 < nt) ATT_STORE_TILE((t + 1) & 1, vnext);
         __syncthreads();
+        vcur = vnext;
+    }
+    if (PING && late) {   // the late waves still owe the last tile's PV (vcur advanced past it: previous slot)
+        const int vlast = (vcur == 0) ? NVB - 1 : vcur - 1;
+        ATT_PV(vring + vlast * ATT_VTILE)
     }
 
     // ---- epilogue: normalise, convert, store.  lane (q, h) holds O[q][32db + 8a + 4h + c], r = 4a + c
@@ -260,24 +277,26 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(AttnParams p) {
     }
 }
 
-template <int NW, int PRESC>
+template <int NW, int PRESC, int PING>
 static int launch_variant(const AttnParams& p0, hipStream_t stream) {
+    constexpr int lds = ATT_LDS_BYTES(PING ? 3 : 2);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<NW, PRESC>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES) != hipSuccess) return -3;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<NW, PRESC, PING>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -3;
         attr_set = true;
     }
     AttnParams p = p0;
     p.nqb = (p.S + 32 * NW - 1) / (32 * NW);
-    hipLaunchKernelGGL((attn_fwd_kernel<NW, PRESC>), dim3(p.nqb * p.H), dim3(64 * NW), ATT_LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((attn_fwd_kernel<NW, PRESC, PING>), dim3(p.nqb * p.H), dim3(64 * NW), lds, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
-// UTX_ATTN_WAVES=4 selects the 4-wave / 2-workgroups-per-CU geometry (A/B knob; default 8 waves, 1 per CU)
-static int attn_waves() {
+// A/B knob: UTX_ATTN_PING=1 selects the late-PV schedule.  Measured r01: 1066 TF/s vs 1153 TF/s lockstep at
+// S = 50688 (profiles/r01_perf_ops_attn_variants.log) -> default 0; kept as an instrumented negative result.
+static int attn_ping() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("UTX_ATTN_WAVES"); v = (e && atoi(e) == 4) ? 4 : 8; }
+    if (v < 0) { const char* e = getenv("UTX_ATTN_PING"); v = (e && atoi(e) == 1) ? 1 : 0; }
     return v;
 }
 
@@ -295,6 +314,6 @@ extern "C" int utx_launch_attn_fwd(const void* q, const void* k, const void* vt,
     p.o_ss = o_ss; p.H = H; p.S = S; p.nqb = 0;
     p.scale_log2 = scale * 1.4426950408889634f;
     const bool presc = (scale == 0.f);
-    if (attn_waves() == 4) return presc ? launch_variant<4, 1>(p, stream) : launch_variant<4, 0>(p, stream);
-    return presc ? launch_variant<8, 1>(p, stream) : launch_variant<8, 0>(p, stream);
+    if (attn_ping()) return presc ? launch_variant<8, 1, 1>(p, stream) : launch_variant<8, 0, 1>(p, stream);
+    return presc ? launch_variant<8, 1, 0>(p, stream) : launch_variant<8, 0, 0>(p, stream);
 }

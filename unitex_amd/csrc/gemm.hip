@@ -16,23 +16,26 @@
 //   - column split: n >= n_split is written to a second buffer C1[m, n - n_split]
 //                                                        (single-stream block: [qkv | mlp] in one GEMM)
 //
-// Structure: 128x128x64 tile, 4 waves (2x2, 64x64 per wave = 2x2 MFMA 32x32x16 tiles), operands
-// staged HBM -> LDS with global_load_lds (16 B / lane, LDS image linear, XOR swizzle applied on the
-// SOURCE address and on the ds_read address), 2-deep LDS ring, one barrier per K-step.  MFMA is issued
-// "swapped" (A-operand = weight rows) so each lane owns 4 consecutive n for one m; C goes through LDS
-// so global stores / residual loads are full 256-byte rows.
+// Structure (template): BM x BN x 64 tile, NWM x NWN waves, each wave (BM/NWM) x (BN/NWN) in 32x32x16 MFMAs,
+// operands staged HBM/L2 -> LDS with global_load_lds (16 B / lane, LDS image linear, XOR swizzle applied on
+// the SOURCE address and on the ds_read address), 2-deep LDS ring, one barrier per K-step, row pointers hoisted
+// out of the K loop.  MFMA is issued "swapped" (A-operand = weight rows) so each lane owns 4 consecutive n for
+// one m; C goes through LDS so global stores / residual loads are full rows.
+//
+// Two instantiations:
+//   256x256 (8 waves, 128x64 per wave, 128 KB LDS, 1 workgroup / CU)  -- the large-M FLUX linears
+//   128x128 (4 waves,  64x64 per wave,  64 KB LDS, 2 workgroups / CU) -- small M (text stream), ragged shapes
+// Why 256: round-1 ablation (profiles/r01_perf_gemm_ablation.log): with the MFMAs removed the 128^2 kernel
+// takes as long as with them -- it is bound by the L2 -> LDS fill rate (~10 TB/s chip-wide for LDS-DMA), i.e.
+// by bytes staged per flop: 1/64 B/flop at 128^2, 1/128 B/flop at 256^2.
+// Tile order: XCD-aware and L2-blocked (groups of GM_GROUP_M tile rows, tn-major) so the tiles resident on an
+// XCD share A/B panels in its 4 MB L2 (row-major order measured 52 % L2 miss, 8.4 GB fetched for 0.5 GB).
 #include "common.h"
 #include "kernels.h"
 #include <stdlib.h>
 
-#define GM_BM 128
-#define GM_BN 128
 #define GM_BK 64
-#define GM_GROUP_M 8
-#define GM_STAGE_BYTES (2 * GM_BM * GM_BK * 2)  // A tile + B tile = 32 KB
-#define GM_LDS_BYTES (2 * GM_STAGE_BYTES)       // 64 KB
-#define GM_CROW 272                             // epilogue C row stride in bytes (256 + 16 pad)
-
+#define GM_GROUP_M 4
 
 __device__ __forceinline__ float gelu_tanh(float x) {
     const float k0 = 0.7978845608028654f, k1 = 0.044715f;
@@ -45,7 +48,14 @@ __device__ __forceinline__ void glds16(const bf16_t* g, char* lds) {
                                      (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
+template <int BM, int BN, int NWM, int NWN>
+__global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_bf16_kernel(GemmParams p) {
+    constexpr int NW = NWM * NWN, NT = 64 * NW;
+    constexpr int WMR = BM / NWM, WNR = BN / NWN;   // rows of C per wave along m / n
+    constexpr int MI = WMR / 32, NI = WNR / 32;
+    constexpr int A_BYTES = BM * GM_BK * 2, B_BYTES = BN * GM_BK * 2, STAGE = A_BYTES + B_BYTES;
+    constexpr int CROW = BN * 2 + 16;              // epilogue C row stride in bytes (pad: <= 2-way write conflicts)
+    static_assert(BM / 8 / NW == 4 && BN / 8 / NW == 4, "4 A + 4 B global_load_lds per thread per K-step");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const bf16_t* pA = (const bf16_t*)p.A; const bf16_t* pB = (const bf16_t*)p.B;
     const bf16_t* pA2 = (const bf16_t*)p.A2; const bf16_t* pB2 = (const bf16_t*)p.B2;
@@ -55,22 +65,20 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / NWN, wn = wave % NWN;
     const int l31 = lane & 31, lh = lane >> 5;
 
-    // XCD-aware, L2-blocked tile order.  Each XCD walks a contiguous range of logical ids; ids are laid out in
-    // groups of GM_GROUP_M tile-rows, tn-major inside a group, so the ~64 tiles resident on an XCD at any moment
-    // form an 8x8 block sharing 8 A panels + 8 B panels (rocprof r01: the row-major order had 1 A + 64 B panels
-    // live -> 52% L2 miss, 8.4 GB fetched for 0.5 GB of operands, fabric-bound at 7 TB/s).
+    // ---- XCD-aware, L2-blocked tile order (see header)
     const int w = xcd_remap(blockIdx.x, gridDim.x);
-    const int ntn = p.ntn & 0xffff, group_m = p.ntn >> 16;
-    const int ntm_ = (p.M + GM_BM - 1) / GM_BM;
+    const int ntn = p.ntn & 0xffff, group_m = (p.ntn >> 16) & 0xff;
+    const int dbg = p.ntn >> 24;   // perf-debug only (UTX_GEMM_DEBUG): 1 = skip operand staging, 2 = skip MFMAs
+    const int ntm_ = (p.M + BM - 1) / BM;
     const int per_group = group_m * ntn;
     const int grp = w / per_group, rem = w - grp * per_group;
     const int first_tm = grp * group_m;
     const int gsize = (ntm_ - first_tm < group_m) ? ntm_ - first_tm : group_m;
     const int tm = first_tm + rem % gsize, tn = rem / gsize;
-    const int m0 = tm * GM_BM, n0 = tn * GM_BN;
+    const int m0 = tm * BM, n0 = tn * BN;
 
     const int nk1 = p.K / GM_BK;
     const bool lora = (p.K2 > 0) && (n0 < p.lora_n_limit);
@@ -78,12 +86,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
     const long a2_off = lora ? (long)(n0 / p.lora_seg_n) * p.K2 : 0;
 
     // ---- glds source addressing: wave-instruction i covers tile rows 8i..8i+7 (1 KB of LDS).
-    // Row pointers live in named VGPR pairs and advance by BK elements per K-step (one 64-bit add per load
-    // instead of a 64-bit multiply chain); they are re-based once when the loop enters the LoRA K-segment.
-    // (No lambda / arrays here: hipcc spills by-reference captures of pointer sets to scratch.)
+    // Row pointers live in named VGPR pairs and advance by BK elements per K-step; re-based once when the loop
+    // enters the LoRA K-segment.  (No lambda / arrays: hipcc spills by-reference pointer sets to scratch.)
     const int srow_in = lane >> 3, sslot = lane & 7;
 #define GM_SRC(j_)                                                                                       \
-    const int srow##j_ = 8 * (wave + 4 * (j_)) + srow_in;                                               \
+    const int srow##j_ = 8 * (wave + NW * (j_)) + srow_in;                                              \
     const int schunk##j_ = (sslot ^ ((srow##j_ >> 1) & 7)) * 8;                                          \
     const int sgm##j_ = (m0 + srow##j_ > p.M - 1) ? p.M - 1 : m0 + srow##j_;                             \
     const int sgn##j_ = (n0 + srow##j_ > p.N - 1) ? p.N - 1 : n0 + srow##j_;                             \
@@ -94,33 +101,31 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
     pa##j_ = pA2 + a2_off + (long)sgm##j_ * p.lda2 + schunk##j_;                                         \
     pb##j_ = pB2 + (long)sgn##j_ * p.ldb2 + schunk##j_;
 #define GM_STAGE1(j_)                                                                                    \
-    glds16(pa##j_, sa_ + (wave + 4 * (j_)) * 1024); pa##j_ += GM_BK;                                     \
-    glds16(pb##j_, sb_ + (wave + 4 * (j_)) * 1024); pb##j_ += GM_BK;
+    glds16(pa##j_, sa_ + (wave + NW * (j_)) * 1024); pa##j_ += GM_BK;                                    \
+    glds16(pb##j_, sb_ + (wave + NW * (j_)) * 1024); pb##j_ += GM_BK;
 #define GM_STAGE(kt_, buf_)                                                                              \
     do {                                                                                                 \
         if ((kt_) == nk1) { GM_REBASE(0) GM_REBASE(1) GM_REBASE(2) GM_REBASE(3) }                        \
-        char* sa_ = smem + (buf_) * GM_STAGE_BYTES;                                                      \
-        char* sb_ = sa_ + GM_BM * GM_BK * 2;                                                             \
+        char* sa_ = smem + (buf_) * STAGE;                                                               \
+        char* sb_ = sa_ + A_BYTES;                                                                       \
         GM_STAGE1(0) GM_STAGE1(1) GM_STAGE1(2) GM_STAGE1(3)                                              \
     } while (0)
 
-    f32x16 acc[2][2];  // [ni][mi]  (swapped MFMA: rows = n, cols = m)
+    f32x16 acc[NI][MI];  // swapped MFMA: rows = n, cols = m
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < NI; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < MI; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    // per-lane fragment read offsets (row r, chunk c -> r*128 + ((c ^ ((r>>1)&7)) << 4))
-    int aoff[2], boff[2], aswz[2], bswz[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int ra = wm * 64 + i * 32 + l31;
-        const int rb = wn * 64 + i * 32 + l31;
-        aoff[i] = ra * 128; aswz[i] = (ra >> 1) & 7;
-        boff[i] = rb * 128; bswz[i] = (rb >> 1) & 7;
-    }
+    // per-lane fragment read offsets: row r, chunk c -> r*128 + ((c ^ ((r>>1)&7)) << 4).  Rows of one wave differ
+    // by multiples of 32, which leaves (r>>1)&7 unchanged: ONE swizzle term per operand, the other fragments are
+    // immediate offsets (i * 32 rows * 128 B).
+    const int ra0 = wm * WMR + l31, rb0 = wn * WNR + l31;
+    const int aoff0 = ra0 * 128, aswz0 = (ra0 >> 1) & 7;
+    const int boff0 = rb0 * 128 + A_BYTES, bswz0 = (rb0 >> 1) & 7;
+    (void)dbg;
 
     GM_STAGE(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
@@ -128,92 +133,100 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (kt + 1 < nk) GM_STAGE(kt + 1, buf ^ 1);
-        const char* sa = smem + buf * GM_STAGE_BYTES;
-        const char* sb = sa + GM_BM * GM_BK * 2;
+        const char* st = smem + buf * STAGE;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            bf16x8 af[2], bfr[2];
+            bf16x8 af[MI], bfr[NI];
+            const char* pbk = st + boff0 + (((2 * kk + lh) ^ bswz0) << 4);
+            const char* pak = st + aoff0 + (((2 * kk + lh) ^ aswz0) << 4);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                af[i] = *reinterpret_cast<const bf16x8*>(sa + aoff[i] + (((2 * kk + lh) ^ aswz[i]) << 4));
-                bfr[i] = *reinterpret_cast<const bf16x8*>(sb + boff[i] + (((2 * kk + lh) ^ bswz[i]) << 4));
-            }
+            for (int i = 0; i < NI; ++i) bfr[i] = *reinterpret_cast<const bf16x8*>(pbk + i * 4096);
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
+            for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const bf16x8*>(pak + i * 4096);
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ni], af[mi], acc[ni][mi], 0, 0, 0);
         }
     }
-    __syncthreads();  // all waves done with the operand ring; reuse LDS for the C tile
 
-    // ---- epilogue phase 1: y = bf16(alpha*acc + bias) (+GELU) -> LDS [128][272 B]
-    // lane (m = l31, h): acc[ni][mi][r] -> n = wn*64 + ni*32 + (r&3) + 8(r>>2) + 4h ; m = wm*64 + mi*32 + l31
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const int nl = wn * 64 + ni * 32 + 8 * a + 4 * lh;  // local n of 4 consecutive columns
-            int gn = n0 + nl; if (gn > p.N - 4) gn = (p.N >= 4) ? p.N - 4 : 0;
-            float bv[4] = {0.f, 0.f, 0.f, 0.f};
-            if (pbias) {
-                const uint2 braw = *reinterpret_cast<const uint2*>(pbias + gn);
-                bv[0] = bf2f((uint16_t)(braw.x & 0xffff)); bv[1] = bf2f((uint16_t)(braw.x >> 16));
-                bv[2] = bf2f((uint16_t)(braw.y & 0xffff)); bv[3] = bf2f((uint16_t)(braw.y >> 16));
-            }
-            const bool do_gelu = (n0 + nl) >= p.gelu_from;
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-                float y[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    float v = rbf(acc[ni][mi][4 * a + c] * p.alpha + bv[c]);
-                    if (do_gelu) v = gelu_tanh(v);
-                    y[c] = v;
-                }
-                uint2 o; o.x = pack2bf(y[0], y[1]); o.y = pack2bf(y[2], y[3]);
-                const int ml = wm * 64 + mi * 32 + l31;
-                *reinterpret_cast<uint2*>(smem + ml * GM_CROW + nl * 2) = o;
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- epilogue phase 2: full-row (256 B) stores; gated residual fused here
-    const int rslot = tid & 15;      // 16-byte chunk within the 256-byte tile row
+    // ---- epilogue, in chunks of 128 tile rows through LDS
+    const int rslot = tid % (BN / 8);           // 16-byte chunk within the tile row
+    const int rrow0 = tid / (BN / 8);
+    constexpr int RPP = NT / (BN / 8);          // rows stored per pass
     const int gn0 = n0 + rslot * 8;
-    if (gn0 < p.N) {
-        float gv[8];
-        if (pgate) {
-            const uint4 graw = *reinterpret_cast<const uint4*>(pgate + gn0);
-            const uint32_t gw[4] = {graw.x, graw.y, graw.z, graw.w};
+    float gv[8];
+    if (pgate && gn0 < p.N) {
+        const uint4 graw = *reinterpret_cast<const uint4*>(pgate + gn0);
+        const uint32_t gw[4] = {graw.x, graw.y, graw.z, graw.w};
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { gv[2 * c] = bf2f((uint16_t)(gw[c] & 0xffff)); gv[2 * c + 1] = bf2f((uint16_t)(gw[c] >> 16)); }
-        }
-        bf16_t* cbase; long ldc; int cn;
-        if (gn0 >= p.n_split) { cbase = pC1; ldc = p.ldc1; cn = gn0 - p.n_split; }
-        else { cbase = pC; ldc = p.ldc; cn = gn0; }
+        for (int c = 0; c < 4; ++c) { gv[2 * c] = bf2f((uint16_t)(gw[c] & 0xffff)); gv[2 * c + 1] = bf2f((uint16_t)(gw[c] >> 16)); }
+    }
+    bf16_t* cbase; long ldc; int cn;
+    if (gn0 >= p.n_split) { cbase = pC1; ldc = p.ldc1; cn = gn0 - p.n_split; }
+    else { cbase = pC; ldc = p.ldc; cn = gn0; }
+
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int ml = (tid >> 4) + 16 * it;
-            const int gm = m0 + ml;
-            if (gm < p.M) {
-                uint4 yv = *reinterpret_cast<const uint4*>(smem + ml * GM_CROW + rslot * 16);
-                if (pgate) {
-                    const uint4 rv = *reinterpret_cast<const uint4*>(pres + (long)gm * p.ldres + gn0);
-                    uint32_t yw[4] = {yv.x, yv.y, yv.z, yv.w};
-                    const uint32_t rw[4] = {rv.x, rv.y, rv.z, rv.w};
+    for (int chunk = 0; chunk < BM / 128; ++chunk) {
+        __syncthreads();  // operand ring (or the previous chunk's C image) no longer needed
+        // phase 1: y = bf16(alpha*acc + bias) (+GELU) -> LDS [128][CROW]
+        // lane (m = l31, h): acc[ni][mi][r] -> n = wn*WNR + ni*32 + (r&3) + 8(r>>2) + 4h ; m = wm*WMR + mi*32 + l31
+        if ((wm * WMR) / 128 == chunk) {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const float y0 = bf2f((uint16_t)(yw[c] & 0xffff)), y1 = bf2f((uint16_t)(yw[c] >> 16));
-                        const float r0 = bf2f((uint16_t)(rw[c] & 0xffff)), r1 = bf2f((uint16_t)(rw[c] >> 16));
-                        const float o0 = r0 + rbf(gv[2 * c] * y0);
-                        const float o1 = r1 + rbf(gv[2 * c + 1] * y1);
-                        yw[c] = pack2bf(o0, o1);
+            for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const int nl = wn * WNR + ni * 32 + 8 * a + 4 * lh;  // local n of 4 consecutive columns
+                    int gn = n0 + nl; if (gn > p.N - 4) gn = (p.N >= 4) ? p.N - 4 : 0;
+                    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (pbias) {
+                        const uint2 braw = *reinterpret_cast<const uint2*>(pbias + gn);
+                        bv[0] = bf2f((uint16_t)(braw.x & 0xffff)); bv[1] = bf2f((uint16_t)(braw.x >> 16));
+                        bv[2] = bf2f((uint16_t)(braw.y & 0xffff)); bv[3] = bf2f((uint16_t)(braw.y >> 16));
                     }
-                    yv = make_uint4(yw[0], yw[1], yw[2], yw[3]);
+                    const bool do_gelu = (n0 + nl) >= p.gelu_from;
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) {
+                        float y[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            float v = rbf(acc[ni][mi][4 * a + c] * p.alpha + bv[c]);
+                            if (do_gelu) v = gelu_tanh(v);
+                            y[c] = v;
+                        }
+                        uint2 o; o.x = pack2bf(y[0], y[1]); o.y = pack2bf(y[2], y[3]);
+                        const int ml = wm * WMR + mi * 32 + l31 - 128 * chunk;
+                        *reinterpret_cast<uint2*>(smem + ml * CROW + nl * 2) = o;
+                    }
                 }
-                *reinterpret_cast<uint4*>(cbase + (long)gm * ldc + cn) = yv;
+            }
+        }
+        __syncthreads();
+        // phase 2: full-row stores; gated residual fused here
+        if (gn0 < p.N) {
+#pragma unroll
+            for (int it = 0; it < 128 / RPP; ++it) {
+                const int ml = rrow0 + RPP * it;
+                const int gm = m0 + 128 * chunk + ml;
+                if (gm < p.M) {
+                    uint4 yv = *reinterpret_cast<const uint4*>(smem + ml * CROW + rslot * 16);
+                    if (pgate) {
+                        const uint4 rv = *reinterpret_cast<const uint4*>(pres + (long)gm * p.ldres + gn0);
+                        uint32_t yw[4] = {yv.x, yv.y, yv.z, yv.w};
+                        const uint32_t rw[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const float y0 = bf2f((uint16_t)(yw[c] & 0xffff)), y1 = bf2f((uint16_t)(yw[c] >> 16));
+                            const float r0 = bf2f((uint16_t)(rw[c] & 0xffff)), r1 = bf2f((uint16_t)(rw[c] >> 16));
+                            const float o0 = r0 + rbf(gv[2 * c] * y0);
+                            const float o1 = r1 + rbf(gv[2 * c + 1] * y1);
+                            yw[c] = pack2bf(o0, o1);
+                        }
+                        yv = make_uint4(yw[0], yw[1], yw[2], yw[3]);
+                    }
+                    *reinterpret_cast<uint4*>(cbase + (long)gm * ldc + cn) = yv;
+                }
             }
         }
     }
@@ -258,29 +271,46 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvParams p) {
     }
 }
 
+template <int BM, int BN, int NWM, int NWN>
+static int launch_gemm(GemmParams p, hipStream_t stream, int group_env, int dbg_env) {
+    constexpr int LDS = 2 * (BM + BN) * GM_BK * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<BM, BN, NWM, NWN>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
+        attr_set = true;
+    }
+    const int ntm = (p.M + BM - 1) / BM;
+    const int ntn = (p.N + BN - 1) / BN;
+    int group_m = group_env > 0 ? group_env : GM_GROUP_M;
+    if (group_m > ntm) group_m = ntm;
+    p.ntn = ntn | (group_m << 16) | (dbg_env << 24);
+    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, NWM, NWN>), dim3(ntm * ntn), dim3(64 * NWM * NWN), LDS, stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
 extern "C" int utx_launch_gemm_bf16(const GemmParams* hp, hipStream_t stream) {
     GemmParams p = *hp;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return -1;
     if ((p.K % GM_BK) || (p.K2 % GM_BK) || (p.N % 8)) return -2;
     if ((p.lda & 7) || (p.ldb & 7) || (p.ldc & 7)) return -2;
-    if (p.K2 > 0 && (!p.A2 || !p.B2 || (p.lda2 & 7) || (p.ldb2 & 7) || p.lora_seg_n <= 0 || (p.lora_seg_n % GM_BN))) return -2;
+    if (p.K2 > 0 && (!p.A2 || !p.B2 || (p.lda2 & 7) || (p.ldb2 & 7) || p.lora_seg_n <= 0 || (p.lora_seg_n % 128))) return -2;
     if (p.gate && (!p.res || (p.ldres & 7))) return -2;
-    if (p.n_split < p.N && (!p.C1 || (p.n_split % GM_BN) || (p.ldc1 & 7))) return -2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, GM_LDS_BYTES) != hipSuccess) return -3;
-        attr_set = true;
-    }
-    const int ntm = (p.M + GM_BM - 1) / GM_BM;
-    const int ntn = (p.N + GM_BN - 1) / GM_BN;
-    static int group_env = -1;
+    if (p.n_split < p.N && (!p.C1 || (p.n_split % 128) || (p.ldc1 & 7))) return -2;
+    static int group_env = -1, dbg_env = -1, tile_env = -1;
     if (group_env < 0) { const char* e = getenv("UTX_GEMM_GROUP_M"); group_env = e ? atoi(e) : 0; }
-    int group_m = group_env > 0 ? group_env : GM_GROUP_M;
-    if (group_m > ntm) group_m = ntm;
-    p.ntn = ntn | (group_m << 16);
-    hipLaunchKernelGGL(gemm_bf16_kernel, dim3(ntm * ntn), dim3(256), GM_LDS_BYTES, stream, p);
-    return hipGetLastError() == hipSuccess ? 0 : -4;
+    if (dbg_env < 0) { const char* e = getenv("UTX_GEMM_DEBUG"); dbg_env = e ? atoi(e) : 0; }
+    if (tile_env < 0) { const char* e = getenv("UTX_GEMM_TILE"); tile_env = e ? atoi(e) : 0; }
+    // 256^2 tiles need every column boundary on a 256 multiple and enough tiles to fill the chip
+    const bool ok256 = (p.N % 256 == 0) && (p.n_split >= p.N || p.n_split % 256 == 0) &&
+                       (p.gelu_from >= p.N || p.gelu_from % 256 == 0) &&
+                       (p.K2 == 0 || (p.lora_seg_n % 256 == 0 && p.lora_n_limit % 256 == 0));
+    const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+    bool use256 = ok256 && tiles256 >= 192;
+    if (tile_env == 128) use256 = false;
+    if (tile_env == 256 && ok256) use256 = true;
+    if (use256) return launch_gemm<256, 256, 2, 4>(p, stream, group_env, dbg_env);
+    return launch_gemm<128, 128, 2, 2>(p, stream, group_env, dbg_env);
 }
 
 extern "C" int utx_launch_gemv_bf16(const GemvParams* hp, hipStream_t stream) {
