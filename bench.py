@@ -51,29 +51,30 @@ def step_flops(S):
 
 
 def cpu_baseline(S_full, threads):
-    """Oracle (oracle/dit_ref.py, fp32 torch CPU) on a bounded sample: 1 double + 1 single FLUX block at
-    full width (D=3072, 24 heads), S_txt=128 + S_img=896 tokens; extrapolated by algorithmic FLOPs."""
+    """Oracle (oracle/dit_ref.py, fp32 torch CPU) on a bounded sample: NB double + NB single FLUX blocks at
+    full width (D=3072, 24 heads), S_txt=256 + S_img=1792 tokens; extrapolated by algorithmic FLOPs."""
     from oracle import dit_ref
     torch.set_num_threads(threads)
-    cfg = dit_ref.FluxConfig(num_double=1, num_single=1)
+    NB = 2
+    cfg = dit_ref.FluxConfig(num_double=NB, num_single=NB)
     sd = dit_ref.make_synthetic_state_dict(cfg, seed=0, dtype=torch.float32)
-    S_txt, S_img = 128, 896
+    S_txt, S_img = 256, 1792
     g = torch.Generator().manual_seed(63)
     lat = torch.randn(S_img, 64, generator=g)
     enc = torch.zeros(S_txt, cfg.joint_dim)
     pooled = torch.zeros(1, cfg.pooled_dim)
     txt_ids = torch.zeros(S_txt, 3)
-    img_ids = dit_ref.latent_image_ids(28, 32)
+    img_ids = dit_ref.latent_image_ids(28, 64)
     t0 = time.perf_counter()
     dit_ref.flux_forward(sd, cfg, lat, enc, pooled, 0.5, 3.5, txt_ids, img_ids, emulate_bf16=False)
     dt = time.perf_counter() - t0
     S = S_txt + S_img
-    fl = 4.0 * S * S * D * 2 + 24.0 * D * D * S * 2
+    fl = (4.0 * S * S * D + 24.0 * D * D * S) * 2 * NB
     rate = fl / dt  # FLOP/s
     full, _ = step_flops(S_full)
     return {"value": rate / full, "unit": "steps/s", "cores": threads, "kind": "port",
-            "sample": "oracle/dit_ref.py fp32 torch-CPU: 1 double + 1 single FLUX block, D=3072, S=%d, %.1f s measured "
-                      "(%.2f TFLOP/s); extrapolated by FLOPs to the %d-token 57-block step" % (S, dt, rate / 1e12, S_full),
+            "sample": "oracle/dit_ref.py fp32 torch-CPU: %d double + %d single FLUX blocks, D=3072, S=%d, %.1f s measured "
+                      "(%.2f TFLOP/s); extrapolated by FLOPs to the %d-token 57-block step" % (NB, NB, S, dt, rate / 1e12, S_full),
             "measured_seconds": dt}
 
 
@@ -187,6 +188,27 @@ def main():
                          "flops_per_launch": attn_launch_flops,
                          "attention_share_of_step_time": (attn_avg_ms * (N_DOUBLE + N_SINGLE)) / (dt / args.steps * 1e3)},
         }
+        # HBM traffic of the dominant kernel: PMC passes cannot run inside the timed run (they serialise kernels), so
+        # the per-launch figure is the one measured by tools/pmc_kernel.sh on THIS command and committed under profiles/
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(args.workload)
+            if tr:
+                out["roofline"]["traffic"] = tr["traffic_bytes_per_launch"]
+                out["roofline"]["traffic_unit"] = "bytes/launch (FETCH_SIZE x2 + WRITE_SIZE, %s)" % tr["source"]
+                out["roofline"]["algorithmic_hbm_bytes_per_launch"] = tr["algorithmic_bytes_per_launch"]
+        except OSError:
+            pass
+        if world == 1:
+            # metric (ii) of SURVEY 8d, geometry part: render -> UV back-projection of 6 x 1024^2 views into a 2048^2
+            # atlas of a 50k-face mesh (outside the timed region; a few hundred ms)
+            try:
+                from unitex_amd.texturetools.benchmarks import time_backprojection
+                bp = time_backprojection(50000, 1024, 2048, iters=2, warmup=1, device=dev)
+                out["config"]["backprojection"] = {"total_ms": bp["total_ms"], "faces": bp["faces"], "atlas_px": 2048,
+                                                   "view_px": 1024, "stages_ms": bp["stages_ms"]}
+                out["config"]["sec_per_mesh_texture"] = 56.0 * dt / args.steps + bp["total_ms"] * 1e-3
+            except Exception as e:
+                out["config"]["backprojection"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)

@@ -3,7 +3,8 @@
 #   bash tools/pmc_kernel.sh <outdir> <kernel-name-substring> <command ...>
 OUT=$1; KN=$2; shift 2
 R=$PWD; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
-run() { timeout 300 rocprofv3 --kernel-trace --pmc $2 --output-format csv -d $R/$OUT/$1 -o run -- "${@:3}" > $R/$OUT/$1.log 2>&1; }
+PASSES=${PASSES:-"sq1 sq2 tcc1 tcc2"}
+run() { case " $PASSES " in *" $1 "*) ;; *) return;; esac; timeout 300 rocprofv3 --kernel-trace --pmc $2 --output-format csv -d $R/$OUT/$1 -o run -- "${@:3}" > $R/$OUT/$1.log 2>&1; }
 run sq1 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "$@"
 run sq2 "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_WAVES" "$@"
 run tcc1 "FETCH_SIZE GRBM_GUI_ACTIVE" "$@"

@@ -17,6 +17,7 @@ Multi-GPU: views are sharded over ranks (`view_shard=(rank, world)`)
 views' colour/visibility layers, ONE all_gather (RCCL over xGMI, or gloo in the CPU tests) assembles the
 layers, and the composite + post-processing run replicated on every rank.
 """
+import contextlib
 import math
 import os
 from typing import Callable, Optional, Tuple
@@ -98,6 +99,19 @@ class NVDiffRendererInverse:
         self.view_shard = view_shard
         self.process_group = process_group
         self.last = {}
+        self.stage_events = None   # set to [] to collect (stage, start_event, end_event) per infer() stage
+
+    @contextlib.contextmanager
+    def _stage(self, name):
+        """optional HIP-event bracket per stage (bench.py / tools/bench_backproject.py); no sync, no cost when off."""
+        if self.stage_events is None:
+            yield
+            return
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        yield
+        b.record()
+        self.stage_events.append((name, a, b))
 
     # ---- reference surface
     def clear(self):
@@ -147,33 +161,45 @@ class NVDiffRendererInverse:
         m = self.pbr_mesh
         n = image_attrs.shape[0]
         dev = self.device
-        mv = self.mv_to_pcd(c2ws, intrinsics, (H, W), perspective=perspective)
+        with self._stage("view_raster"):
+            mv = self.mv_to_pcd(c2ws, intrinsics, (H, W), perspective=perspective)
         images = torch.cat([torch.as_tensor(image_attrs, dtype=torch.float32).to(dev), mv["alpha"][..., None]], dim=-1).contiguous()
         _, c2ws_cpu = self._mvp(c2ws, intrinsics, perspective)
         dirs = (-c2ws_cpu[:, :3, 2]).contiguous().to(dev)
         # UV-space raster: uv in [-1,1] used directly as clip xy, z = 0, w = 1 (renderer_inverse.py:268-274)
         uvclip = torch.cat([m.uvs_2d, torch.zeros_like(m.uvs_2d[:, :1]), torch.ones_like(m.uvs_2d[:, :1])], dim=-1).contiguous()
-        rast2d = ops.rasterize(uvclip, m.faces, H2D, W2D)
+        with self._stage("uv_raster"):
+            rast2d = ops.rasterize(uvclip, m.faces, H2D, W2D)
         from .distributed import view_range
         rank, world = self.view_shard
         v0, v1, per = view_range(rank, world, n)
         color = torch.zeros(n, H2D, W2D, 3, dtype=torch.float32, device=dev)
         rayvis = torch.zeros(n, H2D, W2D, dtype=torch.uint8, device=dev)
         alphaok = torch.zeros(n, H2D, W2D, dtype=torch.uint8, device=dev)
+        with self._stage("bvh_build"):
+            bvh = m.optix
         if v1 > v0:
-            ops.backproject(rast2d, m.vertices, m.faces, m.normals, mv["ndc"].contiguous(), dirs, images, m.optix,
-                            angle_deg=ray_normal_angle_threhold, view_begin=v0, view_count=v1 - v0, out=(color, rayvis, alphaok))
-        vis = ops.dilate_visibility(rayvis, alphaok, rast2d)
+            with self._stage("backproject"):
+                ops.backproject(rast2d, m.vertices, m.faces, m.normals, mv["ndc"].contiguous(), dirs, images, bvh,
+                                angle_deg=ray_normal_angle_threhold, view_begin=v0, view_count=v1 - v0, out=(color, rayvis, alphaok))
+        with self._stage("dilate_visibility"):
+            vis = ops.dilate_visibility(rayvis, alphaok, rast2d)
         if world > 1:
             color, vis = self._gather_layers(color, vis, per, n)
-        atlas, winner = ops.composite(color, vis, self.index)
-        seam = ops.seam_mask(winner, rast2d)
-        pos = ops.interpolate(m.vertices, rast2d, m.faces)
-        ops.nn_fill(atlas, winner, rast2d, pos)
-        blurred = ops.lens_blur_seam(atlas, seam)
+        with self._stage("composite"):
+            atlas, winner = ops.composite(color, vis, self.index)
+        with self._stage("seam_mask"):
+            seam = ops.seam_mask(winner, rast2d)
+        with self._stage("nn_fill"):
+            pos = ops.interpolate(m.vertices, rast2d, m.faces)
+            ops.nn_fill(atlas, winner, rast2d, pos)
+        with self._stage("lens_blur_seam"):
+            blurred = ops.lens_blur_seam(atlas, seam)
         mask_u8 = (rast2d[..., 3] > 0).to(torch.uint8).contiguous()
-        color_2d = ops.pull_push(blurred, mask_u8)
-        tex = ops.to_u8(color_2d, flip=True)  # tensor_to_image + FLIP_TOP_BOTTOM (link_pbr_to_mesh.py:17)
+        with self._stage("pull_push"):
+            color_2d = ops.pull_push(blurred, mask_u8)
+        with self._stage("to_u8"):
+            tex = ops.to_u8(color_2d, flip=True)  # tensor_to_image + FLIP_TOP_BOTTOM (link_pbr_to_mesh.py:17)
         textured = TexturedMesh(m.vertices.cpu().numpy(), m.faces.cpu().numpy(), m.uvs01, tex.cpu().numpy())
         self.last = {"rast2d": rast2d, "winner": winner, "seam": seam, "atlas_prefill": atlas}
         out = (textured, vis.bool()[..., None], (rast2d[..., 3] > 0)[None, ..., None], color_2d[None])
