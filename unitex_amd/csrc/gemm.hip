@@ -233,6 +233,263 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_bf16_kernel(GemmParams
 }
 
 // ---------------------------------------------------------------------------------------------
+// 256x256x64 tile, 8 waves, "8-phase" schedule (4 phases per K-tile): the large-M FLUX linears.
+//
+// Each wave (wr = wave>>2, wc = wave&3) owns output rows {i*128 + wr*64 + [0,64)} and columns
+// {j*128 + wc*32 + [0,32)}, i, j in {0,1}: one 64-row piece of EACH A half-tile and one 32-column piece of
+// EACH B half-tile.  A K-tile is staged as four 16 KB half-tiles (A0, A1, B0, B1; 2 global_load_lds per
+// thread each) and consumed as four quadrant phases:
+//     q0: read B0 (4 ds_read_b128), A0 (8)   MFMA (a0,b0)      stage A1 of K-tile t+1
+//     q1: read B1 (4)                        MFMA (a0,b1)      stage B0 of K-tile t+2   (same LDS buffer as t)
+//     q2: read A1 (8)                        MFMA (a1,b1)      stage A0 of K-tile t+2
+//     q3: --                                 MFMA (a1,b0)      stage B1 of K-tile t+2 ; s_waitcnt vmcnt(6)
+// Every phase is [ds_reads, 2 glds] barrier [8 MFMA] barrier, and the wr=1 waves run one barrier behind the
+// wr=0 waves, so on each SIMD one wave is in its MFMA cluster while the other issues LDS reads / DMA.
+// Three half-tiles (6 glds per thread) stay in flight across every barrier; the only vmcnt wait of the loop
+// is the counted one in q3, which retires K-tile t+1 one full phase before its first read.
+// LDS hazards (derivation in DESIGN.md "GEMM schedule"):
+//   RAW  a half-tile is read >= 1 phase after the q3 wait that retired it and after a barrier both wave
+//        groups passed;
+//   WAR  a region is re-staged >= 2 phases after its last ds_read, except B0 (1 phase), whose reads are
+//        retired by the s_waitcnt lgkmcnt(8) BEFORE the first barrier of q0 (B reads are issued first).
+// LDS map (bytes): region r in {A0,A1,B0,B1} at r*32768, K-tile parity at +16384: every fragment read is
+// base VGPR + immediate.
+
+#define G8_BAR()                                      \
+    do {                                              \
+        __builtin_amdgcn_sched_barrier(0);            \
+        asm volatile("" ::: "memory");                \
+        __builtin_amdgcn_s_barrier();                 \
+        asm volatile("" ::: "memory");                \
+        __builtin_amdgcn_sched_barrier(0);            \
+    } while (0)
+
+__global__ __launch_bounds__(512, 2) void gemm256_8ph_kernel(GemmParams p) {
+    constexpr int BM = 256, BN = 256, NT = 512;
+    constexpr int CROW = BN * 2 + 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const bf16_t* pbias = (const bf16_t*)p.bias; const bf16_t* pgate = (const bf16_t*)p.gate;
+    const bf16_t* pres = (const bf16_t*)p.res;
+    bf16_t* pC = (bf16_t*)p.C; bf16_t* pC1 = (bf16_t*)p.C1;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    const int w = xcd_remap(blockIdx.x, gridDim.x);
+    const int ntn = p.ntn & 0xffff, group_m = (p.ntn >> 16) & 0xff;
+    const int ntm_ = p.M / BM;
+    const int per_group = group_m * ntn;
+    const int grp = w / per_group, rem = w - grp * per_group;
+    const int first_tm = grp * group_m;
+    const int gsize = (ntm_ - first_tm < group_m) ? ntm_ - first_tm : group_m;
+    const int tm = first_tm + rem % gsize, tn = rem / gsize;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int nk1 = p.K / GM_BK;
+    const bool lora = (p.K2 > 0) && (n0 < p.lora_n_limit);
+    const int nk = nk1 + (lora ? p.K2 / GM_BK : 0);
+    const long a2_off = lora ? (long)(n0 / p.lora_seg_n) * p.K2 : 0;
+
+    // ---- staging sources: wave-uniform base (SGPR) + one per-lane byte offset per operand and K-segment.
+    // glds instruction (wave, j) of a half-tile covers its rows 8*(wave + 8j) .. +7  (1 KB of LDS, lane-linear).
+    const int srow_in = lane >> 3, sslot = lane & 7;
+    const unsigned chunkb = (unsigned)((sslot ^ (((8 * wave + srow_in) >> 1) & 7)) << 4);
+    const long ldaB = (long)p.lda * 2, ldbB = (long)p.ldb * 2, lda2B = (long)p.lda2 * 2, ldb2B = (long)p.ldb2 * 2;
+    const unsigned voA1 = (unsigned)(srow_in * ldaB) + chunkb, voB1 = (unsigned)(srow_in * ldbB) + chunkb;
+    const unsigned voA2 = (unsigned)(srow_in * lda2B) + chunkb, voB2 = (unsigned)(srow_in * ldb2B) + chunkb;
+    const char* ubA1 = (const char*)p.A + (long)(m0 + 8 * wave) * ldaB;
+    const char* ubB1 = (const char*)p.B + (long)(n0 + 8 * wave) * ldbB;
+    const char* ubA2 = (const char*)p.A2 + a2_off * 2 + (long)(m0 + 8 * wave) * lda2B;
+    const char* ubB2 = (const char*)p.B2 + (long)(n0 + 8 * wave) * ldb2B;
+    char* const ldst = smem + wave * 1024;
+    // stage half-tile h of operand A (isb = 0) / B (isb = 1) of K-tile t_
+#define G8_STAGE(t_, isb_, h_)                                                                              \
+    do {                                                                                                    \
+        const int tt_ = (t_);                                                                               \
+        const bool s2_ = tt_ >= nk1;                                                                        \
+        const long rs_ = (isb_) ? (s2_ ? ldb2B : ldbB) : (s2_ ? lda2B : ldaB);                              \
+        const char* ub_ = ((isb_) ? (s2_ ? ubB2 : ubB1) : (s2_ ? ubA2 : ubA1)) +                            \
+                          (long)(s2_ ? tt_ - nk1 : tt_) * (GM_BK * 2) + (long)(128 * (h_)) * rs_;           \
+        const unsigned vo_ = (isb_) ? (s2_ ? voB2 : voB1) : (s2_ ? voA2 : voA1);                            \
+        char* l_ = ldst + (2 * (isb_) + (h_)) * 32768 + (tt_ & 1) * 16384;                                  \
+        glds16((const bf16_t*)(ub_ + vo_), l_);                                                             \
+        glds16((const bf16_t*)(ub_ + 64 * rs_ + vo_), l_ + 8192);                                           \
+    } while (0)
+
+    f32x16 acc[2][4];   // [j][2i+f], swapped MFMA: rows = n, cols = m
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // fragment read bases: row*128 + ((2kk + lh) ^ swz) * 16, swz = (row>>1)&7 = (l31>>1)&7 for every fragment
+    const int swz = (l31 >> 1) & 7;
+    const int arow = (wr * 64 + l31) * 128, brow = 65536 + (wc * 32 + l31) * 128;
+    const int x0 = ((0 + lh) ^ swz) << 4, x1 = ((2 + lh) ^ swz) << 4, x2 = ((4 + lh) ^ swz) << 4, x3 = ((6 + lh) ^ swz) << 4;
+    const char* const fa0 = smem + arow + x0; const char* const fa1 = smem + arow + x1;
+    const char* const fa2 = smem + arow + x2; const char* const fa3 = smem + arow + x3;
+    const char* const fb0 = smem + brow + x0; const char* const fb1 = smem + brow + x1;
+    const char* const fb2 = smem + brow + x2; const char* const fb3 = smem + brow + x3;
+#define G8_LD(ptr_, off_) (*reinterpret_cast<const bf16x8*>((ptr_) + (off_)))
+#define G8_LOAD_B(dst_, j_, par_)                                                      \
+    dst_##0 = G8_LD(fb0, (j_) * 32768 + (par_) * 16384); dst_##1 = G8_LD(fb1, (j_) * 32768 + (par_) * 16384); \
+    dst_##2 = G8_LD(fb2, (j_) * 32768 + (par_) * 16384); dst_##3 = G8_LD(fb3, (j_) * 32768 + (par_) * 16384);
+#define G8_LOAD_A(i_, par_)                                                            \
+    a00 = G8_LD(fa0, (i_) * 32768 + (par_) * 16384);        a01 = G8_LD(fa1, (i_) * 32768 + (par_) * 16384);        \
+    a02 = G8_LD(fa2, (i_) * 32768 + (par_) * 16384);        a03 = G8_LD(fa3, (i_) * 32768 + (par_) * 16384);        \
+    a10 = G8_LD(fa0, (i_) * 32768 + (par_) * 16384 + 4096); a11 = G8_LD(fa1, (i_) * 32768 + (par_) * 16384 + 4096); \
+    a12 = G8_LD(fa2, (i_) * 32768 + (par_) * 16384 + 4096); a13 = G8_LD(fa3, (i_) * 32768 + (par_) * 16384 + 4096);
+#define G8_MFMA(b_, j_, i_)                                                                                     \
+    do {                                                                                                        \
+        __builtin_amdgcn_s_setprio(1);                                                                          \
+        acc[j_][2 * (i_)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_##0, a00, acc[j_][2 * (i_)], 0, 0, 0);          \
+        acc[j_][2 * (i_) + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_##0, a10, acc[j_][2 * (i_) + 1], 0, 0, 0);  \
+        acc[j_][2 * (i_)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_##1, a01, acc[j_][2 * (i_)], 0, 0, 0);          \
+        acc[j_][2 * (i_) + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_##1, a11, acc[j_][2 * (i_) + 1], 0, 0, 0);  \
+        acc[j_][2 * (i_)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_##2, a02, acc[j_][2 * (i_)], 0, 0, 0);          \
+        acc[j_][2 * (i_) + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_##2, a12, acc[j_][2 * (i_) + 1], 0, 0, 0);  \
+        acc[j_][2 * (i_)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_##3, a03, acc[j_][2 * (i_)], 0, 0, 0);          \
+        acc[j_][2 * (i_) + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_##3, a13, acc[j_][2 * (i_) + 1], 0, 0, 0);  \
+        __builtin_amdgcn_s_setprio(0);                                                                          \
+    } while (0)
+    bf16x8 a00, a01, a02, a03, a10, a11, a12, a13;       // a{f}{kk}: current A piece (64 rows x 64 k)
+    bf16x8 bz0, bz1, bz2, bz3, bo0, bo1, bo2, bo3;       // B pieces j = 0 (bz) and j = 1 (bo)
+
+    // one K-tile (4 phases); par_ = t & 1 is a literal so every LDS offset is an immediate
+#define G8_KTILE(t_, par_)                                                                         \
+    do {                                                                                           \
+        const int t__ = (t_);                                                                      \
+        /* q0 */                                                                                   \
+        G8_LOAD_B(bz, 0, par_)                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        G8_LOAD_A(0, par_)                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        if (t__ + 1 < nk) G8_STAGE(t__ + 1, 0, 1);                                                 \
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");                                         \
+        G8_BAR();                                                                                  \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                         \
+        G8_MFMA(bz, 0, 0);                                                                         \
+        G8_BAR();                                                                                  \
+        /* q1 */                                                                                   \
+        G8_LOAD_B(bo, 1, par_)                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        if (t__ + 2 < nk) G8_STAGE(t__ + 2, 1, 0);                                                 \
+        G8_BAR();                                                                                  \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                         \
+        G8_MFMA(bo, 1, 0);                                                                         \
+        G8_BAR();                                                                                  \
+        /* q2 */                                                                                   \
+        G8_LOAD_A(1, par_)                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        if (t__ + 2 < nk) G8_STAGE(t__ + 2, 0, 0);                                                 \
+        G8_BAR();                                                                                  \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                         \
+        G8_MFMA(bo, 1, 1);                                                                         \
+        G8_BAR();                                                                                  \
+        /* q3 */                                                                                   \
+        if (t__ + 2 < nk) {                                                                        \
+            G8_STAGE(t__ + 2, 1, 1);                                                               \
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                       \
+        } else {                                                                                   \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                       \
+        }                                                                                          \
+        G8_BAR();                                                                                  \
+        G8_MFMA(bz, 0, 1);                                                                         \
+        G8_BAR();                                                                                  \
+    } while (0)
+
+    // ---- prologue: K-tile 0 complete, B0/A0/B1 of K-tile 1 in flight
+    G8_STAGE(0, 1, 0); G8_STAGE(0, 0, 0); G8_STAGE(0, 1, 1); G8_STAGE(0, 0, 1);
+    if (nk > 1) {
+        G8_STAGE(1, 1, 0); G8_STAGE(1, 0, 0); G8_STAGE(1, 1, 1);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    G8_BAR();
+    if (wr == 1) G8_BAR();          // stagger: the wr = 1 waves run one barrier behind
+    for (int t = 0; t < nk; t += 2) {
+        G8_KTILE(t, 0);
+        if (t + 1 < nk) G8_KTILE(t + 1, 1);
+    }
+    if (wr == 0) G8_BAR();          // re-align the barrier count
+
+    // ---- epilogue: two chunks of 128 tile rows (chunk i = A half i) through LDS; every wave has rows in both
+    const int rslot = tid % (BN / 8);
+    const int rrow0 = tid / (BN / 8);
+    constexpr int RPP = NT / (BN / 8);
+    const int gn0 = n0 + rslot * 8;
+    float gv[8];
+    if (pgate) {
+        const uint4 graw = *reinterpret_cast<const uint4*>(pgate + gn0);
+        const uint32_t gw[4] = {graw.x, graw.y, graw.z, graw.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { gv[2 * c] = bf2f((uint16_t)(gw[c] & 0xffff)); gv[2 * c + 1] = bf2f((uint16_t)(gw[c] >> 16)); }
+    }
+    bf16_t* cbase; long ldc; int cn;
+    if (gn0 >= p.n_split) { cbase = pC1; ldc = p.ldc1; cn = gn0 - p.n_split; }
+    else { cbase = pC; ldc = p.ldc; cn = gn0; }
+#pragma unroll
+    for (int chunk = 0; chunk < 2; ++chunk) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int nl = j * 128 + wc * 32 + 8 * a + 4 * lh;
+                const int gn = n0 + nl;
+                float bv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (pbias) {
+                    const uint2 braw = *reinterpret_cast<const uint2*>(pbias + gn);
+                    bv[0] = bf2f((uint16_t)(braw.x & 0xffff)); bv[1] = bf2f((uint16_t)(braw.x >> 16));
+                    bv[2] = bf2f((uint16_t)(braw.y & 0xffff)); bv[3] = bf2f((uint16_t)(braw.y >> 16));
+                }
+                const bool do_gelu = gn >= p.gelu_from;
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    float y[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        float v = rbf(acc[j][2 * chunk + f][4 * a + c] * p.alpha + bv[c]);
+                        if (do_gelu) v = gelu_tanh(v);
+                        y[c] = v;
+                    }
+                    uint2 o; o.x = pack2bf(y[0], y[1]); o.y = pack2bf(y[2], y[3]);
+                    const int ml = wr * 64 + f * 32 + l31;
+                    *reinterpret_cast<uint2*>(smem + ml * CROW + nl * 2) = o;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 128 / RPP; ++it) {
+            const int ml = rrow0 + RPP * it;
+            const int gm = m0 + 128 * chunk + ml;
+            uint4 yv = *reinterpret_cast<const uint4*>(smem + ml * CROW + rslot * 16);
+            if (pgate) {
+                const uint4 rv = *reinterpret_cast<const uint4*>(pres + (long)gm * p.ldres + gn0);
+                uint32_t yw[4] = {yv.x, yv.y, yv.z, yv.w};
+                const uint32_t rw[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float y0 = bf2f((uint16_t)(yw[c] & 0xffff)), y1 = bf2f((uint16_t)(yw[c] >> 16));
+                    const float r0 = bf2f((uint16_t)(rw[c] & 0xffff)), r1 = bf2f((uint16_t)(rw[c] >> 16));
+                    const float o0 = r0 + rbf(gv[2 * c] * y0);
+                    const float o1 = r1 + rbf(gv[2 * c + 1] * y1);
+                    yw[c] = pack2bf(o0, o1);
+                }
+                yv = make_uint4(yw[0], yw[1], yw[2], yw[3]);
+            }
+            *reinterpret_cast<uint4*>(cbase + (long)gm * ldc + cn) = yv;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Small-M path (M <= 8): y[m, n] = act_out( sum_k act_in(x[m,k]) * W[n,k] + b[n] ), one wave per n.
 // Used for the timestep / guidance / pooled-text embedders and all AdaLN modulation linears
 // (M = batch = 1): pure weight streaming, HBM-bound.
@@ -289,6 +546,22 @@ static int launch_gemm(GemmParams p, hipStream_t stream, int group_env, int dbg_
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
+static int launch_gemm8(GemmParams p, hipStream_t stream, int group_env) {
+    constexpr int LDS = 131072;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_8ph_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
+        attr_set = true;
+    }
+    const int ntm = p.M / 256, ntn = p.N / 256;
+    int group_m = group_env > 0 ? group_env : GM_GROUP_M;
+    if (group_m > ntm) group_m = ntm;
+    p.ntn = ntn | (group_m << 16);
+    hipLaunchKernelGGL(gemm256_8ph_kernel, dim3(ntm * ntn), dim3(512), LDS, stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
 extern "C" int utx_launch_gemm_bf16(const GemmParams* hp, hipStream_t stream) {
     GemmParams p = *hp;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return -1;
@@ -300,7 +573,7 @@ extern "C" int utx_launch_gemm_bf16(const GemmParams* hp, hipStream_t stream) {
     static int group_env = -1, dbg_env = -1, tile_env = -1;
     if (group_env < 0) { const char* e = getenv("UTX_GEMM_GROUP_M"); group_env = e ? atoi(e) : 0; }
     if (dbg_env < 0) { const char* e = getenv("UTX_GEMM_DEBUG"); dbg_env = e ? atoi(e) : 0; }
-    if (tile_env < 0) { const char* e = getenv("UTX_GEMM_TILE"); tile_env = e ? atoi(e) : 0; }
+    { const char* e = getenv("UTX_GEMM_TILE"); tile_env = e ? atoi(e) : 0; }   // re-read per call: lets one process A/B the kernels
     // 256^2 tiles need every column boundary on a 256 multiple and enough tiles to fill the chip
     const bool ok256 = (p.N % 256 == 0) && (p.n_split >= p.N || p.n_split % 256 == 0) &&
                        (p.gelu_from >= p.N || p.gelu_from % 256 == 0) &&
@@ -308,7 +581,8 @@ extern "C" int utx_launch_gemm_bf16(const GemmParams* hp, hipStream_t stream) {
     const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
     bool use256 = ok256 && tiles256 >= 192;
     if (tile_env == 128) use256 = false;
-    if (tile_env == 256 && ok256) use256 = true;
+    if ((tile_env == 256 || tile_env == 2562) && ok256) use256 = true;   // 2562 = the 2-barrier 256^2 kernel (A/B testing)
+    if (use256 && (p.M % 256 == 0) && tile_env != 2562) return launch_gemm8(p, stream, group_env);
     if (use256) return launch_gemm<256, 256, 2, 4>(p, stream, group_env, dbg_env);
     return launch_gemm<128, 128, 2, 2>(p, stream, group_env, dbg_env);
 }
