@@ -279,6 +279,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_8ph_kernel(GemmParams p) {
 
     const int w = xcd_remap(blockIdx.x, gridDim.x);
     const int ntn = p.ntn & 0xffff, group_m = (p.ntn >> 16) & 0xff;
+    const int dbg = p.ntn >> 24;   // perf ablation only (UTX_GEMM_DEBUG): 1 = no operand staging, 2 = always stage K-tile 0
     const int ntm_ = p.M / BM;
     const int per_group = group_m * ntn;
     const int grp = w / per_group, rem = w - grp * per_group;
@@ -308,10 +309,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_8ph_kernel(GemmParams p) {
 #define G8_STAGE(t_, isb_, h_)                                                                              \
     do {                                                                                                    \
         const int tt_ = (t_);                                                                               \
-        const bool s2_ = tt_ >= nk1;                                                                        \
+        if (dbg == 1) break;                                                                                \
+        const int ts_ = (dbg == 2) ? 0 : tt_;                                                               \
+        const bool s2_ = ts_ >= nk1;                                                                        \
         const long rs_ = (isb_) ? (s2_ ? ldb2B : ldbB) : (s2_ ? lda2B : ldaB);                              \
         const char* ub_ = ((isb_) ? (s2_ ? ubB2 : ubB1) : (s2_ ? ubA2 : ubA1)) +                            \
-                          (long)(s2_ ? tt_ - nk1 : tt_) * (GM_BK * 2) + (long)(128 * (h_)) * rs_;           \
+                          (long)(s2_ ? ts_ - nk1 : ts_) * (GM_BK * 2) + (long)(128 * (h_)) * rs_;           \
         const unsigned vo_ = (isb_) ? (s2_ ? voB2 : voB1) : (s2_ ? voA2 : voA1);                            \
         char* l_ = ldst + (2 * (isb_) + (h_)) * 32768 + (tt_ & 1) * 16384;                                  \
         glds16((const bf16_t*)(ub_ + vo_), l_);                                                             \
@@ -546,7 +549,7 @@ static int launch_gemm(GemmParams p, hipStream_t stream, int group_env, int dbg_
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
-static int launch_gemm8(GemmParams p, hipStream_t stream, int group_env) {
+static int launch_gemm8(GemmParams p, hipStream_t stream, int group_env, int dbg_env) {
     constexpr int LDS = 131072;
     static bool attr_set = false;
     if (!attr_set) {
@@ -557,7 +560,7 @@ static int launch_gemm8(GemmParams p, hipStream_t stream, int group_env) {
     const int ntm = p.M / 256, ntn = p.N / 256;
     int group_m = group_env > 0 ? group_env : GM_GROUP_M;
     if (group_m > ntm) group_m = ntm;
-    p.ntn = ntn | (group_m << 16);
+    p.ntn = ntn | (group_m << 16) | (dbg_env << 24);
     hipLaunchKernelGGL(gemm256_8ph_kernel, dim3(ntm * ntn), dim3(512), LDS, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
@@ -571,8 +574,8 @@ extern "C" int utx_launch_gemm_bf16(const GemmParams* hp, hipStream_t stream) {
     if (p.gate && (!p.res || (p.ldres & 7))) return -2;
     if (p.n_split < p.N && (!p.C1 || (p.n_split % 128) || (p.ldc1 & 7))) return -2;
     static int group_env = -1, dbg_env = -1, tile_env = -1;
-    if (group_env < 0) { const char* e = getenv("UTX_GEMM_GROUP_M"); group_env = e ? atoi(e) : 0; }
-    if (dbg_env < 0) { const char* e = getenv("UTX_GEMM_DEBUG"); dbg_env = e ? atoi(e) : 0; }
+    { const char* e = getenv("UTX_GEMM_GROUP_M"); group_env = e ? atoi(e) : 0; }
+    { const char* e = getenv("UTX_GEMM_DEBUG"); dbg_env = e ? atoi(e) : 0; }
     { const char* e = getenv("UTX_GEMM_TILE"); tile_env = e ? atoi(e) : 0; }   // re-read per call: lets one process A/B the kernels
     // 256^2 tiles need every column boundary on a 256 multiple and enough tiles to fill the chip
     const bool ok256 = (p.N % 256 == 0) && (p.n_split >= p.N || p.n_split % 256 == 0) &&
@@ -582,7 +585,7 @@ extern "C" int utx_launch_gemm_bf16(const GemmParams* hp, hipStream_t stream) {
     bool use256 = ok256 && tiles256 >= 192;
     if (tile_env == 128) use256 = false;
     if ((tile_env == 256 || tile_env == 2562) && ok256) use256 = true;   // 2562 = the 2-barrier 256^2 kernel (A/B testing)
-    if (use256 && (p.M % 256 == 0) && tile_env != 2562) return launch_gemm8(p, stream, group_env);
+    if (use256 && (p.M % 256 == 0) && tile_env != 2562) return launch_gemm8(p, stream, group_env, dbg_env);
     if (use256) return launch_gemm<256, 256, 2, 4>(p, stream, group_env, dbg_env);
     return launch_gemm<128, 128, 2, 2>(p, stream, group_env, dbg_env);
 }
