@@ -43,7 +43,8 @@ const char* utx_last_error(utx_ctx* ctx);
 
 /* Flash attention forward, bf16 in/out, fp32 softmax + accumulation, non-causal, head_dim 128.
  * Replaces F.scaled_dot_product_attention at attention_processor.py:89-91.
- *   q, k : element (h, s, d) at base + h*{q,k}_hs + s*{q,k}_ss + d
+ *   q, k : element (h, s, d) at base + h*{q,k}_hs + s*{q,k}_ss + d; k rows must be readable (finite)
+ *          up to the next multiple of 64 past S (keys >= S are masked, never used)
  *   vt   : V transposed, element (h, d, s) at base + h*vt_hs + d*vt_ds + s; every row must be readable
  *          (finite) up to the next multiple of 64 past S
  *   o    : element (s, h, d) at base + s*o_ss + h*128 + d

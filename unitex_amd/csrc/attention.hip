@@ -22,13 +22,16 @@
 //   * the softmax VALU stream is minimised: score accumulators are INITIALISED to -m_run (the MFMA chain does
 //     the max subtraction); with Q pre-scaled by scale*log2(e) upstream (qkv_post) a probability is ONE
 //     v_exp_f32; the running max only moves when some row would exceed 2^8 ("defer-max", guide T13).
-//   * PING (opt-in, UTX_ATTN_PING=1; measured SLOWER, see attn_ping() below): round-1 PMC showed MFMA busy ~40-45 % with the two waves of every SIMD executing
-//     QK^T / softmax / PV in lockstep behind the per-tile barrier -- both in VALU while the matrix pipe idles.
-//     Here the second half of the workgroup (waves NW/2.., the SIMD partners of waves 0..NW/2-1) runs its PV
-//     product ONE ITERATION LATE:   early waves: QK(t)  SM(t)  PV(t)      late waves: PV(t-1)  QK(t)  SM(t)
-//     so on each SIMD  [QK || PV]  is followed by  [softmax || QK]  and  [PV || softmax]: one wave's VALU phase
-//     always sits under its partner's MFMA phase, still with ONE s_barrier per tile.  Cost: a third Vt buffer
-//     (V(t-1) must outlive the barrier) -> 88 KB LDS.
+//   * FAST (default; UTX_ATTN_FAST=0 selects the per-tile-max form for A/B): tools/coissue_probe.hip shows that on
+//     this chip VALU work is NOT hidden under another wave's MFMAs (cross-wave overlap ~0, same-wave ~0.5), so
+//     every softmax instruction costs wall time.  The common path therefore has NO max reduction at all: the tile
+//     is exponentiated against the running max as it stands (accumulator C-input = a register block holding
+//     -m_run, so not even the accumulator initialisation is per-tile VALU work) and only the row sum is checked:
+//     if any lane's partial sum exceeds 2^13 (some probability > 2^8 at the least), the tile is redone on the slow
+//     path -- QK^T again with the true max, O/l rescaled -- before anything was accumulated.  Per tile and lane
+//     that removes 16 v_max3 + 2 v_max + a ds_bpermute round trip + 18 v_mov; the row sum uses v_pk_add_f32.
+//     Measured-negative schedules (kept out of the build, logs in profiles/r01_perf_ops_attn_variants.log): 4 waves x
+//     2 workgroups / CU, QK(t+1) software-pipelined under softmax(t), late-PV "ping-pong" between wave halves.
 //
 // Algorithmic FLOPs: 4 * S^2 * 128 per head (QK^T + PV, non-causal).
 #include "common.h"
@@ -43,11 +46,11 @@
 #define ATT_VTILE (128 * ATT_VSTR)         // 18432
 #define ATT_LDS_BYTES(nvb) (2 * ATT_KTILE + (nvb) * ATT_VTILE)
 
-template <int NW, int PRESC, int PING>
+template <int NW, int PRESC, int FAST>
 __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(AttnParams p) {
     constexpr int ATT_QB = 32 * NW;          // queries per workgroup
     constexpr int NPASS = 1024 / (64 * NW);  // staging passes: 1024 16-byte chunks per K (and per V) tile
-    constexpr int NVB = PING ? 3 : 2;        // Vt ring depth
+    constexpr int NVB = 2;                   // Vt ring depth
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const kring = smem;
     char* const vring = smem + 2 * ATT_KTILE;
@@ -56,13 +59,13 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(AttnParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lq = lane & 31;   // query column owned by this lane (MFMA C column)
     const int lh = lane >> 5;   // lane half
-    const bool late = PING && (wave >= NW / 2);   // wave-uniform
 
     // XCD-aware work mapping: consecutive logical ids (= same head) stay on one XCD's L2.
     const int w = xcd_remap(blockIdx.x, gridDim.x);
     const int head = w / p.nqb;
     const int qb = w - head * p.nqb;
     const int S = p.S;
+    const int dbg = p.dbg;
 
     const bf16_t* kbase = p.k + (long)head * p.k_hs;
     const bf16_t* vbase = p.vt + (long)head * p.vt_hs;
@@ -87,13 +90,12 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(AttnParams p) {
     const int vd##i_ = (tid >> 3) + (i_) * (8 * NW);                                             \
     const int k_lds##i_ = krow##i_ * ATT_KSTR + (k_slot << 4);                                   \
     const int v_lds##i_ = vd##i_ * ATT_VSTR + (v_slot << 4);                                     \
-    const bf16_t* vsrc##i_ = vbase + (long)vd##i_ * p.vt_ds + v_slot * 8;
+    const bf16_t* vsrc##i_ = vbase + (long)vd##i_ * p.vt_ds + v_slot * 8;                       \
+    const bf16_t* ksrc##i_ = kbase + (long)krow##i_ * p.k_ss + k_slot * 8;
     ATT_SETUP(0) ATT_SETUP(1) ATT_SETUP(2) ATT_SETUP(3)
 #define ATT_LOAD1(i_, kv0_)                                                                      \
-    {                                                                                            \
-        int r_ = (kv0_) + krow##i_;                                                              \
-        if (r_ > S - 1) r_ = S - 1; /* tail rows are masked to -inf later; stay in-bounds */     \
-        kreg##i_ = *reinterpret_cast<const uint4*>(kbase + (long)r_ * p.k_ss + k_slot * 8);      \
+    {   /* K rows / Vt columns are readable up to the next multiple of 64 past S (ABI contract) */  \
+        kreg##i_ = *reinterpret_cast<const uint4*>(ksrc##i_ + (long)(kv0_) * p.k_ss);            \
         vreg##i_ = *reinterpret_cast<const uint4*>(vsrc##i_ + (kv0_));                           \
     }
 #define ATT_LOAD_TILE(t_)                                                                        \
@@ -128,7 +130,10 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(AttnParams p) {
     float m_run = 0.f;     // running (deferred) max, raw score units; set from tile 0
     float l_run = 0.f;     // this lane-half's partial row sum
     const float c2 = p.scale_log2;
-    bf16x8 pb[4];          // P of the current (late waves: previous) tile as PV B-operands
+    bf16x8 pb[4];          // P of the current tile as PV B-operands
+    f32x16 negm;           // -m_run in every element: C-input of the first QK^T MFMA of each block
+#pragma unroll
+    for (int r = 0; r < 16; ++r) negm[r] = 0.f;
 
     // O^T += Vt P^T for one tile: 4 blocks of 32 d x 4 k-steps of 16 keys; fragments 8 reads ahead
 #define ATT_PV(vb_)                                                                              \
@@ -164,101 +169,104 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(AttnParams p) {
 
     int vcur = 0;   // ring slot of V(t); V(t-1) sits in the previous slot, V(t+1) goes to the next one
     for (int t = 0; t < nt; ++t) {
-        if (t + 1 < nt) ATT_LOAD_TILE(t + 1);
+        if (t + 1 < nt && !(dbg & 1)) ATT_LOAD_TILE(t + 1);
         const char* kb = kring + (t & 1) * ATT_KTILE;
-        const int vprev = (vcur == 0) ? NVB - 1 : vcur - 1;
         const int vnext = (vcur == NVB - 1) ? 0 : vcur + 1;
 
-        if (PING && late && t > 0) ATT_PV(vring + vprev * ATT_VTILE)   // late waves: PV of the previous tile
-
-        // ---- S'^T = K Q^T - m_run : accumulators start at -m_run, so the MFMA chain does the max subtraction
         f32x16 sacc[2];
-        const float neg_m = -m_run;
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sacc[b][r] = neg_m;
-        __builtin_amdgcn_s_setprio(1);
-        {
-            bf16x8 kf0[8], kf1[8];
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk)
-                kf0[kk] = *reinterpret_cast<const bf16x8*>(kb + k_off + kk * 32);
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk) {
-                kf1[kk] = *reinterpret_cast<const bf16x8*>(kb + k_off + 32 * ATT_KSTR + kk * 32);
-                sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[kk], qf[kk], sacc[0], 0, 0, 0);
-            }
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk)
-                sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[kk], qf[kk], sacc[1], 0, 0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-#pragma unroll
-            for (int i_ = 0; i_ < 8; ++i_) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-        }
-        __builtin_amdgcn_s_setprio(0);
+        float psum = 1.0f;
+        // S'^T = K Q^T - m_run : the accumulator chain starts from the -m_run block, so the MFMAs do the subtraction.
         // lane (q, h): sacc[b][r] = score(key = kv0 + 32b + 16(r>>3) + 8h + (r&7), query q) - m_run
-
-        if (t == nt - 1 && (S & (ATT_KVB - 1))) {
-            const int kv0 = t * ATT_KVB;
+#define ATT_QK()                                                                                         \
+        {                                                                                                \
+            __builtin_amdgcn_s_setprio(1);                                                               \
+            bf16x8 kf0[8], kf1[8];                                                                       \
+            /* the two 32-key blocks alternate so consecutive MFMAs never share an accumulator; fragments  \
+               run 4 k-steps (8 reads) ahead */                                                          \
+            _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                           \
+                kf0[kk] = *reinterpret_cast<const bf16x8*>(kb + k_off + kk * 32);                        \
+                kf1[kk] = *reinterpret_cast<const bf16x8*>(kb + k_off + 32 * ATT_KSTR + kk * 32);        \
+            }                                                                                            \
+            _Pragma("unroll") for (int kk = 0; kk < 8; ++kk) {                                           \
+                if (kk + 4 < 8) {                                                                        \
+                    kf0[kk + 4] = *reinterpret_cast<const bf16x8*>(kb + k_off + (kk + 4) * 32);          \
+                    kf1[kk + 4] = *reinterpret_cast<const bf16x8*>(kb + k_off + 32 * ATT_KSTR + (kk + 4) * 32); \
+                }                                                                                        \
+                sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[kk], qf[kk], kk == 0 ? negm : sacc[0], 0, 0, 0); \
+                sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[kk], qf[kk], kk == 0 ? negm : sacc[1], 0, 0, 0); \
+            }                                                                                            \
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                                           \
+            _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                           \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                       \
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                       \
+            }                                                                                            \
+            __builtin_amdgcn_s_setprio(0);                                                               \
+            if (t == nt - 1 && (S & (ATT_KVB - 1))) {   /* ragged last tile: keys >= S -> -inf */        \
+                const int lim_ = S - t * ATT_KVB - 8 * lh;                                               \
+                _Pragma("unroll") for (int b = 0; b < 2; ++b)                                            \
+                    _Pragma("unroll") for (int r = 0; r < 16; ++r)                                       \
+                        if (32 * b + 16 * (r >> 3) + (r & 7) >= lim_) sacc[b][r] = -INFINITY;            \
+            }                                                                                            \
+        }
+        // probabilities (one v_exp_f32 each when Q is pre-scaled), bf16 PV operands, packed row sum
+#define ATT_EXP()                                                                                        \
+        {                                                                                                \
+            f32x2 ps2_ = {0.f, 0.f};                                                                     \
+            _Pragma("unroll") for (int b = 0; b < 2; ++b)                                                \
+                _Pragma("unroll") for (int r = 0; r < 16; r += 2) {                                      \
+                    f32x2 pv_;                                                                           \
+                    pv_[0] = __builtin_amdgcn_exp2f(PRESC ? sacc[b][r] : sacc[b][r] * c2);               \
+                    pv_[1] = __builtin_amdgcn_exp2f(PRESC ? sacc[b][r + 1] : sacc[b][r + 1] * c2);       \
+                    ps2_ += pv_;                                                                         \
+                    pb[2 * b + (r >> 3)][r & 7] = (__bf16)pv_[0];                                        \
+                    pb[2 * b + (r >> 3)][(r & 7) + 1] = (__bf16)pv_[1];                                  \
+                }                                                                                        \
+            psum = ps2_[0] + ps2_[1];                                                                    \
+        }
+        bool slow = !FAST || (t == 0);
+        if (!slow) {
+            // common path: no max reduction.  Any probability above 2^13 shows up in the lane's row sum; the
+            // tile is then redone below against the true max (nothing has been accumulated yet).
+            if (!(dbg & 16)) ATT_QK()
+            if (!(dbg & 2)) ATT_EXP()
+            slow = !__all(psum <= 8192.0f);
+        }
+        if (slow) {
+            ATT_QK()
+            float mx = sacc[0][0];
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = kv0 + 32 * b + 16 * (r >> 3) + 8 * lh + (r & 7);
-                    if (key >= S) sacc[b][r] = -INFINITY;
-                }
-        }
-
-        // ---- online softmax (per query column; partner half = lane ^ 32), deferred max
-        float mx = sacc[0][0];
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[b][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));      // tile max relative to m_run
+            if (FAST || t == 0 || !__all((PRESC ? mx : mx * c2) <= 8.0f)) {
+                // re-centre (wave-uniform): move the running max to the true max
+                const float d = (t == 0) ? mx : fmaxf(mx, 0.f);
+                // tile 0: O = l = 0, nothing to rescale (and exp2(-d) may overflow for very negative first maxima)
+                const float alpha = (t == 0) ? 1.0f : __builtin_amdgcn_exp2f(PRESC ? -d : -d * c2);
+                m_run += d;
+                l_run *= alpha;
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+                for (int r = 0; r < 16; ++r) negm[r] = -m_run;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[b][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));      // tile max relative to m_run
-        const float mxs = PRESC ? mx : mx * c2;      // ... in exp2 units
-        if (t == 0 || !__all(mxs <= 8.0f)) {
-            // re-centre (wave-uniform, rare after the first tiles): move the running max to the true max
-            const float d = (t == 0) ? mx : fmaxf(mx, 0.f);
-            // tile 0: O = l = 0, nothing to rescale (and exp2(-d) may overflow for very negative first maxima)
-            const float alpha = (t == 0) ? 1.0f : __builtin_amdgcn_exp2f(PRESC ? -d : -d * c2);
-            m_run += d;
-            l_run *= alpha;
+                for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+                    for (int r = 0; r < 16; ++r) sacc[b][r] -= d;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) sacc[b][r] -= d;
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
-        }
-        float psum = 0.f;
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pv = __builtin_amdgcn_exp2f(PRESC ? sacc[b][r] : sacc[b][r] * c2);
-                psum += pv;
-                pb[2 * b + (r >> 3)][r & 7] = (__bf16)pv;
+                    for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
             }
+            ATT_EXP()
+        }
         l_run += psum;
 
-        if (!(PING && late)) ATT_PV(vring + vcur * ATT_VTILE)   // early waves: PV of this tile
+        if (!(dbg & 8)) ATT_PV(vring + vcur * ATT_VTILE)
 
-        if (t + 1 < nt) ATT_STORE_TILE((t + 1) & 1, vnext);
-        __syncthreads();
+        if (t + 1 < nt && !(dbg & 1)) ATT_STORE_TILE((t + 1) & 1, vnext);
+        if (!(dbg & 4)) __syncthreads();
         vcur = vnext;
     }
-    if (PING && late) {   // the late waves still owe the last tile's PV (vcur advanced past it: previous slot)
-        const int vlast = (vcur == 0) ? NVB - 1 : vcur - 1;
-        ATT_PV(vring + vlast * ATT_VTILE)
-    }
-
     // ---- epilogue: normalise, convert, store.  lane (q, h) holds O[q][32db + 8a + 4h + c], r = 4a + c
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
@@ -277,27 +285,25 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(AttnParams p) {
     }
 }
 
-template <int NW, int PRESC, int PING>
+template <int NW, int PRESC, int FAST>
 static int launch_variant(const AttnParams& p0, hipStream_t stream) {
-    constexpr int lds = ATT_LDS_BYTES(PING ? 3 : 2);
+    constexpr int lds = ATT_LDS_BYTES(2);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<NW, PRESC, PING>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<NW, PRESC, FAST>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -3;
         attr_set = true;
     }
     AttnParams p = p0;
     p.nqb = (p.S + 32 * NW - 1) / (32 * NW);
-    hipLaunchKernelGGL((attn_fwd_kernel<NW, PRESC, PING>), dim3(p.nqb * p.H), dim3(64 * NW), lds, stream, p);
+    hipLaunchKernelGGL((attn_fwd_kernel<NW, PRESC, FAST>), dim3(p.nqb * p.H), dim3(64 * NW), lds, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
-// A/B knob: UTX_ATTN_PING=1 selects the late-PV schedule.  Measured r01: 1066 TF/s vs 1153 TF/s lockstep at
-// S = 50688 (profiles/r01_perf_ops_attn_variants.log) -> default 0; kept as an instrumented negative result.
-static int attn_ping() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("UTX_ATTN_PING"); v = (e && atoi(e) == 1) ? 1 : 0; }
-    return v;
+// A/B knob: UTX_ATTN_FAST=0 selects the per-tile-max softmax (re-read per call so one process can compare).
+static int attn_fast() {
+    const char* e = getenv("UTX_ATTN_FAST");
+    return (e && atoi(e) == 0) ? 0 : 1;
 }
 
 // softmax_scale > 0: scores are multiplied by softmax_scale (natural-exp softmax, the reference's SDPA).
@@ -312,8 +318,9 @@ extern "C" int utx_launch_attn_fwd(const void* q, const void* k, const void* vt,
     p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.vt = (const bf16_t*)vt; p.o = (bf16_t*)o;
     p.q_hs = q_hs; p.q_ss = q_ss; p.k_hs = k_hs; p.k_ss = k_ss; p.vt_hs = vt_hs; p.vt_ds = vt_ds;
     p.o_ss = o_ss; p.H = H; p.S = S; p.nqb = 0;
+    { const char* e = getenv("UTX_ATTN_DEBUG"); p.dbg = e ? atoi(e) : 0; }
     p.scale_log2 = scale * 1.4426950408889634f;
     const bool presc = (scale == 0.f);
-    if (attn_ping()) return presc ? launch_variant<8, 1, 1>(p, stream) : launch_variant<8, 0, 1>(p, stream);
-    return presc ? launch_variant<8, 1, 0>(p, stream) : launch_variant<8, 0, 0>(p, stream);
+    if (!attn_fast()) return presc ? launch_variant<8, 1, 0>(p, stream) : launch_variant<8, 0, 0>(p, stream);
+    return presc ? launch_variant<8, 1, 1>(p, stream) : launch_variant<8, 0, 1>(p, stream);
 }

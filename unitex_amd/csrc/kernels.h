@@ -16,6 +16,7 @@ struct AttnParams {
     bf16_t* o;
     long q_hs, q_ss, k_hs, k_ss, vt_hs, vt_ds, o_ss;  // element strides
     int H, S, nqb;
+    int dbg;           // perf ablation only (UTX_ATTN_DEBUG bits): 1 no staging, 2 no exp, 4 no barrier, 8 no PV, 16 no QK
     float scale_log2;  // softmax_scale * log2(e)
 };
 typedef utx_gemm_desc GemmParams;
