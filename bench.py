@@ -209,6 +209,26 @@ def main():
                 out["config"]["sec_per_mesh_texture"] = 56.0 * dt / args.steps + bp["total_ms"] * 1e-3
             except Exception as e:
                 out["config"]["backprojection"] = {"error": repr(e)}
+            # VAE part of a job (HIP AutoencoderKL): pass 1 encodes the control strip + the 512^2 reference image and
+            # decodes the strip, pass 2 (delight) encodes the control strip and decodes once more
+            try:
+                from unitex_amd.flux.vae_hip import AutoencoderKL
+                vae = AutoencoderKL.synthetic(seed=0, device=dev)
+                img = (torch.rand(1, 3, h_px, w_px, device=dev) * 2 - 1).to(torch.bfloat16)
+                ref_img = (torch.rand(1, 3, dual_px, dual_px, device=dev) * 2 - 1).to(torch.bfloat16)
+                zz = torch.randn(1, 16, h_px // 8, w_px // 8, device=dev).to(torch.bfloat16)
+                vae.encode(ref_img); vae.encode(img); vae.decode(zz)
+                torch.cuda.synchronize()
+                tv = time.perf_counter()
+                vae.encode(img); vae.encode(ref_img); vae.decode(zz); vae.encode(img); vae.decode(zz)
+                torch.cuda.synchronize()
+                vae_s = time.perf_counter() - tv
+                out["config"]["vae_sec_per_mesh"] = vae_s
+                if "sec_per_mesh_texture" in out["config"]:
+                    out["config"]["sec_per_mesh_texture"] += vae_s
+                del vae, img, zz
+            except Exception as e:
+                out["config"]["vae_sec_per_mesh"] = "error: %r" % (e,)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)

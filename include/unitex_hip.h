@@ -75,6 +75,13 @@ typedef struct utx_gemm_desc {
     void* C; long ldc;
     int n_split; void* C1; long ldc1;  /* columns >= n_split go to C1[m, n - n_split]; N for none */
     int ntn;                      /* internal */
+    /* implicit 3x3 convolution (conv_Wo > 0): A is an NHWC activation [Hi*Wi, Cin] (Cin = 1 << conv_cin_log2 >= 64),
+     * B the weight [N, 9*Cin] with K order (ky, kx, cin), M = Ho*Wo output pixels, K = 9*Cin.  Tap (ky,kx) of output
+     * pixel (oy,ox) reads input (oy*stride + ky - pad, ox*stride + kx - pad) of the (conv_up ? 2x nearest-upsampled
+     * : plain) image; out-of-range taps read zero_page (>= 128 zero bytes).  Replaces torch Conv2d(3x3) (+ the
+     * F.pad(0,1,0,1) stride-2 downsampler and the nearest-2x upsampler) of the FLUX VAE [3p]. */
+    int conv_Hi, conv_Wi, conv_Wo, conv_cin_log2, conv_stride, conv_pad, conv_up;
+    const void* zero_page;
 } utx_gemm_desc;
 int utx_gemm_bf16(utx_ctx* ctx, const utx_gemm_desc* d, utx_stream stream);
 
@@ -88,6 +95,18 @@ typedef struct utx_gemv_desc {
     int silu_in, silu_out;
 } utx_gemv_desc;
 int utx_gemv_bf16(utx_ctx* ctx, const utx_gemv_desc* d, utx_stream stream);
+
+/* ---- FLUX AutoencoderKL pieces (diffusers [3p]; encode at flux_piplines/texturing/pipeline.py:226-238, decode at
+ * :683-692).  Activations are NHWC bf16 [H*W, C].  Convolutions with Cin >= 64 are utx_gemm_bf16 in conv mode. */
+/* GroupNorm(32 groups, C % 128 == 0) + affine (+ SiLU): work = utx_group_norm_workspace_bytes() bytes. */
+size_t utx_group_norm_workspace_bytes(void);
+int utx_group_norm(utx_ctx* ctx, const void* x, long npix, int C, const void* gamma, const void* beta, float eps, int silu,
+                   void* y, void* work, utx_stream stream);
+/* in-place row softmax of a bf16 matrix [nrow, ncol] (row stride ld elements; ncol, ld multiples of 8). */
+int utx_softmax_rows(utx_ctx* ctx, void* s, long nrow, long ld, int ncol, utx_stream stream);
+/* 3x3 / stride 1 / pad 1 convolution for thin inputs (Cin = 3 or 16): wt is [9*Cin][Cout] bf16 (tap-major). */
+int utx_conv3x3_thin(utx_ctx* ctx, const void* x, int H, int W, int Cin, const void* wt, const void* bias, int Cout, void* y,
+                     utx_stream stream);
 
 /* per-head RMSNorm(q,k) + RoPE + head-major relayout + V transpose
  * (attention_processor.py:50-57,76-87). */

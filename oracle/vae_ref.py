@@ -1,15 +1,14 @@
-"""AutoencoderKL of FLUX.1-dev (diffusers [3p]: block_out_channels (128,256,512,512), 2 layers/block,
-16 latent channels, GroupNorm(32), SiLU, single-head mid attention, scaling 0.3611, shift 0.1159).
+"""ORACLE (test infrastructure, not product): fp32 PyTorch restatement of the FLUX.1-dev AutoencoderKL.
 
-Round-1 status: < 1 % of the FLOPs of a texture job.  It runs as plain
-PyTorch-ROCm modules (MIOpen convolutions) on the GPU -- plumbing, not yet hand-written HIP; see
-DESIGN.md "out of scope this round".  Key names follow diffusers so a real `vae/` checkpoint loads.
-Call sites in the reference: flux_piplines/texturing/pipeline.py:226-238 (encode + sample + shift/scale)
-and :683-692 (unscale + decode)."""
-import os
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may import this.  The product VAE is
+unitex_amd/flux/vae_hip.py (hand-written HIP kernels behind the C ABI).
 
-os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")  # avoid minutes of exhaustive conv tuning on first use
-
+Architecture restated from the public diffusers AutoencoderKL [3p] (absent from /root/reference and from this
+image -> parity unpinned against diffusers itself): block_out_channels (128, 256, 512, 512), 2 layers / block
+(3 in the decoder), 16 latent channels, GroupNorm(32, eps 1e-6), SiLU, single-head mid attention, stride-2
+downsampler with F.pad (0,1,0,1), nearest-2x upsampler, scaling 0.3611, shift 0.1159.  Call sites in the reference:
+flux_piplines/texturing/pipeline.py:226-238 (encode + sample + shift/scale) and :683-692 (unscale + decode).
+Parameter names follow diffusers so the same state dict drives the oracle and the product."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -167,7 +166,13 @@ class AutoencoderKL(nn.Module):
         return self.decoder(z)
 
     @classmethod
-    def synthetic(cls, seed=0, device="cuda:0", dtype=torch.bfloat16):
+    def from_state_dict(cls, sd):
+        m = cls()
+        m.load_state_dict({k: v.float().cpu() for k, v in sd.items()}, strict=True)
+        return m.eval()
+
+    @classmethod
+    def synthetic(cls, seed=0, device="cpu", dtype=torch.float32):
         g = torch.Generator().manual_seed(seed)
         m = cls()
         with torch.no_grad():

@@ -20,7 +20,9 @@ class GemmDesc(C.Structure):
                 ("lora_n_limit", c_int), ("lora_seg_n", c_int), ("alpha", c_float),
                 ("bias", c_void_p), ("gelu_from", c_int), ("gate", c_void_p),
                 ("res", c_void_p), ("ldres", c_long), ("C", c_void_p), ("ldc", c_long),
-                ("n_split", c_int), ("C1", c_void_p), ("ldc1", c_long), ("ntn", c_int)]
+                ("n_split", c_int), ("C1", c_void_p), ("ldc1", c_long), ("ntn", c_int),
+                ("conv_Hi", c_int), ("conv_Wi", c_int), ("conv_Wo", c_int), ("conv_cin_log2", c_int),
+                ("conv_stride", c_int), ("conv_pad", c_int), ("conv_up", c_int), ("zero_page", c_void_p)]
 
 
 class GemvDesc(C.Structure):
@@ -67,6 +69,10 @@ SYMBOLS = {
     "utx_attn_fwd_bf16": (c_int, [c_void_p] * 5 + [c_long] * 7 + [c_int, c_int, c_float, c_void_p]),
     "utx_gemm_bf16": (c_int, [c_void_p, C.POINTER(GemmDesc), c_void_p]),
     "utx_gemv_bf16": (c_int, [c_void_p, C.POINTER(GemvDesc), c_void_p]),
+    "utx_group_norm_workspace_bytes": (c_long, []),
+    "utx_group_norm": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p]),
+    "utx_softmax_rows": (c_int, [c_void_p, c_void_p, c_long, c_long, c_int, c_void_p]),
+    "utx_conv3x3_thin": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "utx_qkv_post": (c_int, [c_void_p, C.POINTER(QkvPostDesc), c_void_p]),
     "utx_ln_mod": (c_int, [c_void_p, C.POINTER(LnModDesc), c_void_p]),
     "utx_sched_step": (c_int, [c_void_p, C.POINTER(SchedDesc), c_void_p]),

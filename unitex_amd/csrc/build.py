@@ -20,6 +20,7 @@ SOURCES = [
     ("attention.hip", []),
     ("gemm.hip", []),
     ("dit_elementwise.hip", ["-ffp-contract=off"]),
+    ("vae.hip", []),
     ("capi.cpp", []),
 ]
 GEOM = [

@@ -66,6 +66,25 @@ int utx_gemv_bf16(utx_ctx* ctx, const utx_gemv_desc* d, utx_stream stream) {
     UTX_CALL(ctx, "utx_gemv_bf16", utx_launch_gemv_bf16(d, (hipStream_t)stream));
 }
 
+size_t utx_group_norm_workspace_bytes(void) { return utx_group_norm_workspace_bytes_impl(); }
+
+int utx_group_norm(utx_ctx* ctx, const void* x, long npix, int C, const void* gamma, const void* beta, float eps, int silu,
+                   void* y, void* work, utx_stream stream) {
+    if (!x || !gamma || !beta || !y || !work) return fail(ctx, -2, "utx_group_norm");
+    UTX_CALL(ctx, "utx_group_norm", utx_launch_group_norm(x, npix, C, gamma, beta, eps, silu, y, work, (hipStream_t)stream));
+}
+
+int utx_softmax_rows(utx_ctx* ctx, void* s, long nrow, long ld, int ncol, utx_stream stream) {
+    if (!s) return fail(ctx, -2, "utx_softmax_rows");
+    UTX_CALL(ctx, "utx_softmax_rows", utx_launch_softmax_rows(s, nrow, ld, ncol, (hipStream_t)stream));
+}
+
+int utx_conv3x3_thin(utx_ctx* ctx, const void* x, int H, int W, int Cin, const void* wt, const void* bias, int Cout, void* y,
+                     utx_stream stream) {
+    if (!x || !wt || !bias || !y) return fail(ctx, -2, "utx_conv3x3_thin");
+    UTX_CALL(ctx, "utx_conv3x3_thin", utx_launch_conv3x3_thin(x, H, W, Cin, wt, bias, Cout, y, (hipStream_t)stream));
+}
+
 int utx_qkv_post(utx_ctx* ctx, const utx_qkv_post_desc* d, utx_stream stream) {
     if (!d || !d->qkv || !d->Qh || !d->Kh || !d->Vt || !d->cosb || !d->sinb || !d->wq || !d->wk)
         return fail(ctx, -2, "utx_qkv_post");

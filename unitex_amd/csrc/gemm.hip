@@ -48,7 +48,7 @@ __device__ __forceinline__ void glds16(const bf16_t* g, char* lds) {
                                      (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
 }
 
-template <int BM, int BN, int NWM, int NWN>
+template <int BM, int BN, int NWM, int NWN, bool CONV>
 __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_bf16_kernel(GemmParams p) {
     constexpr int NW = NWM * NWN, NT = 64 * NW;
     constexpr int WMR = BM / NWM, WNR = BN / NWN;   // rows of C per wave along m / n
@@ -97,6 +97,21 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_bf16_kernel(GemmParams
     const bf16_t* pa##j_ = pA + (long)sgm##j_ * p.lda + schunk##j_;                                      \
     const bf16_t* pb##j_ = pB + (long)sgn##j_ * p.ldb + schunk##j_;
     GM_SRC(0) GM_SRC(1) GM_SRC(2) GM_SRC(3)
+    // CONV (implicit 3x3 convolution, see unitex_hip.h): A row m is output pixel (oy, ox); the source row of K-step kt
+    // is input pixel (oy*stride + ky - pad, ox*stride + kx - pad) of tap = kt*64 / Cin, or the zero page.
+    const bf16_t* pzero = (const bf16_t*)p.zero_page;
+    const int chlim = CONV ? (p.conv_Hi << p.conv_up) : 0, cwlim = CONV ? (p.conv_Wi << p.conv_up) : 0;
+#define GM_CONV_PIX(j_)                                                                                  \
+    const int coy##j_ = CONV ? (sgm##j_ / p.conv_Wo) * p.conv_stride - p.conv_pad : 0;                   \
+    const int cox##j_ = CONV ? (sgm##j_ % p.conv_Wo) * p.conv_stride - p.conv_pad : 0;
+    GM_CONV_PIX(0) GM_CONV_PIX(1) GM_CONV_PIX(2) GM_CONV_PIX(3)
+#define GM_CONV_PTR(j_)                                                                                  \
+    {                                                                                                    \
+        const int iy_ = coy##j_ + ky_, ix_ = cox##j_ + kx_;                                              \
+        const bool ok_ = (iy_ >= 0) & (iy_ < chlim) & (ix_ >= 0) & (ix_ < cwlim);                        \
+        const long src_ = (((long)(iy_ >> p.conv_up) * p.conv_Wi + (ix_ >> p.conv_up)) << p.conv_cin_log2) + c0_; \
+        pa##j_ = (ok_ ? pA + src_ : pzero) + schunk##j_;                                                 \
+    }
 #define GM_REBASE(j_)                                                                                    \
     pa##j_ = pA2 + a2_off + (long)sgm##j_ * p.lda2 + schunk##j_;                                         \
     pb##j_ = pB2 + (long)sgn##j_ * p.ldb2 + schunk##j_;
@@ -105,6 +120,12 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_bf16_kernel(GemmParams
     glds16(pb##j_, sb_ + (wave + NW * (j_)) * 1024); pb##j_ += GM_BK;
 #define GM_STAGE(kt_, buf_)                                                                              \
     do {                                                                                                 \
+        if constexpr (CONV) {                                                                            \
+            const int kk0_ = (kt_) * GM_BK;                                                              \
+            const int tap_ = kk0_ >> p.conv_cin_log2, c0_ = kk0_ & ((1 << p.conv_cin_log2) - 1);         \
+            const int ky_ = tap_ / 3, kx_ = tap_ - 3 * ky_;                                              \
+            GM_CONV_PTR(0) GM_CONV_PTR(1) GM_CONV_PTR(2) GM_CONV_PTR(3)                                  \
+        }                                                                                                \
         if ((kt_) == nk1) { GM_REBASE(0) GM_REBASE(1) GM_REBASE(2) GM_REBASE(3) }                        \
         char* sa_ = smem + (buf_) * STAGE;                                                               \
         char* sb_ = sa_ + A_BYTES;                                                                       \
@@ -531,12 +552,12 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvParams p) {
     }
 }
 
-template <int BM, int BN, int NWM, int NWN>
+template <int BM, int BN, int NWM, int NWN, bool CONV = false>
 static int launch_gemm(GemmParams p, hipStream_t stream, int group_env, int dbg_env) {
     constexpr int LDS = 2 * (BM + BN) * GM_BK * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<BM, BN, NWM, NWN>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<BM, BN, NWM, NWN, CONV>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
         attr_set = true;
     }
@@ -545,7 +566,7 @@ static int launch_gemm(GemmParams p, hipStream_t stream, int group_env, int dbg_
     int group_m = group_env > 0 ? group_env : GM_GROUP_M;
     if (group_m > ntm) group_m = ntm;
     p.ntn = ntn | (group_m << 16) | (dbg_env << 24);
-    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, NWM, NWN>), dim3(ntm * ntn), dim3(64 * NWM * NWN), LDS, stream, p);
+    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, NWM, NWN, CONV>), dim3(ntm * ntn), dim3(64 * NWM * NWN), LDS, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
@@ -574,6 +595,12 @@ extern "C" int utx_launch_gemm_bf16(const GemmParams* hp, hipStream_t stream) {
     if (p.gate && (!p.res || (p.ldres & 7))) return -2;
     if (p.n_split < p.N && (!p.C1 || (p.n_split % 128) || (p.ldc1 & 7))) return -2;
     static int group_env = -1, dbg_env = -1, tile_env = -1;
+    if (p.conv_Wo > 0) {   // implicit 3x3 convolution: 128^2 kernel, A rows gathered per tap
+        if (p.K2 > 0 || !p.zero_page || p.conv_cin_log2 < 6 || p.K != (9 << p.conv_cin_log2) || p.conv_Hi <= 0 || p.conv_Wi <= 0 ||
+            p.conv_stride < 1 || p.conv_stride > 2 || p.conv_pad < 0 || p.conv_pad > 1 || (p.conv_up & ~1) || (p.M % p.conv_Wo))
+            return -2;
+        return launch_gemm<128, 128, 2, 2, true>(p, stream, 0, 0);
+    }
     { const char* e = getenv("UTX_GEMM_GROUP_M"); group_env = e ? atoi(e) : 0; }
     { const char* e = getenv("UTX_GEMM_DEBUG"); dbg_env = e ? atoi(e) : 0; }
     { const char* e = getenv("UTX_GEMM_TILE"); tile_env = e ? atoi(e) : 0; }   // re-read per call: lets one process A/B the kernels

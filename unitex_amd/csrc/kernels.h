@@ -32,6 +32,10 @@ int utx_launch_attn_fwd(const void* q, const void* k, const void* vt, void* o,
 int utx_launch_gemm_bf16(const GemmParams* p, hipStream_t stream);
 int utx_launch_gemv_bf16(const GemvParams* p, hipStream_t stream);
 int utx_launch_qkv_post(const QkvPostParams* p, hipStream_t stream);
+size_t utx_group_norm_workspace_bytes_impl(void);
+int utx_launch_group_norm(const void* x, long npix, int C, const void* gamma, const void* beta, float eps, int silu, void* y, void* work, hipStream_t stream);
+int utx_launch_softmax_rows(void* s, long nrow, long ld, int ncol, hipStream_t stream);
+int utx_launch_conv3x3_thin(const void* x, int H, int W, int Cin, const void* wt, const void* bias, int Cout, void* y, hipStream_t stream);
 int utx_launch_ln_mod(const LnModParams* p, hipStream_t stream);
 int utx_launch_sched_step(const SchedParams* p, hipStream_t stream);
 int utx_launch_transform(const float* verts, int V, const float* mvp, int n_views, float* clip, float* ndc, hipStream_t stream);

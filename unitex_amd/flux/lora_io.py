@@ -24,14 +24,21 @@ def load_flux_transformer_state_dict(path):
     return _load_dir(path)
 
 
-def load_vae(path, device, dtype=torch.bfloat16):
-    from .vae import AutoencoderKL
+def load_vae(path, device):
+    """diffusers AutoencoderKL checkpoint directory -> the HIP VAE (vae_hip.AutoencoderKL)."""
+    from .synthetic import vae_param_shapes
+    from .vae_hip import AutoencoderKL
     sd = _load_dir(path)
-    m = AutoencoderKL()
-    missing, unexpected = m.load_state_dict(sd, strict=False)
+    want = vae_param_shapes()
+    missing = [k for k in want if k not in sd]
     if missing:
         raise KeyError("VAE checkpoint is missing keys, e.g. %s" % missing[:5])
-    return m.to(device=device, dtype=dtype).eval()
+    for k, shp in want.items():
+        if tuple(sd[k].shape) != tuple(shp):
+            if sd[k].numel() == 1 or tuple(sd[k].reshape(shp).shape) != tuple(shp):
+                raise ValueError("VAE parameter %s has shape %s, expected %s" % (k, tuple(sd[k].shape), shp))
+            sd[k] = sd[k].reshape(shp)   # older checkpoints store the attention projections as 1x1 convs
+    return AutoencoderKL({k: sd[k] for k in want}, device=device)
 
 
 def load_lora_safetensors(path, default_alpha=None):

@@ -11,7 +11,7 @@ Semantics kept: T5/CLIP are never run -- zero embeddin
 [text | noise | control | dual]; RNG draw order noise -> dual -> control from ONE shared CPU generator;
 mu from the noise-token count only; condition tail re-pinned every step; Euler step in fp32.
 The transformer is FluxDiT (HIP kernels behind the C ABI); the scheduler update is the fused HIP
-kernel utx_sched_step; the VAE is PyTorch-ROCm (see vae.py).
+kernel utx_sched_step; the VAE runs on the same library (vae_hip.py).
 """
 from typing import List, Optional
 

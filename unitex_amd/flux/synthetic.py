@@ -76,3 +76,82 @@ def synthetic_lora(state, shape, rank=64, seed=1, targets_double=None, device="c
         B = torch.randn(o, rank, generator=g, device=device) * (0.1 / math.sqrt(rank))
         out[n] = (A.to(dtype), B.to(dtype))
     return out
+
+
+# ---- FLUX AutoencoderKL (diffusers key names / shapes [3p]) -------------------------------------------------
+VAE_CHANNELS = (128, 256, 512, 512)
+VAE_LATENT = 16
+
+
+def vae_param_shapes(ch=VAE_CHANNELS, latent=VAE_LATENT, layers=2):
+    """{diffusers parameter name: shape} of the FLUX AutoencoderKL (no quant convs)."""
+    shp = {}
+
+    def conv(name, cin, cout, k):
+        shp[name + ".weight"] = (cout, cin, k, k)
+        shp[name + ".bias"] = (cout,)
+
+    def norm(name, c):
+        shp[name + ".weight"] = (c,)
+        shp[name + ".bias"] = (c,)
+
+    def lin(name, cin, cout):
+        shp[name + ".weight"] = (cout, cin)
+        shp[name + ".bias"] = (cout,)
+
+    def resnet(name, cin, cout):
+        norm(name + ".norm1", cin); conv(name + ".conv1", cin, cout, 3)
+        norm(name + ".norm2", cout); conv(name + ".conv2", cout, cout, 3)
+        if cin != cout:
+            conv(name + ".conv_shortcut", cin, cout, 1)
+
+    def mid(name, c):
+        resnet(name + ".resnets.0", c, c)
+        norm(name + ".attentions.0.group_norm", c)
+        for t in ("to_q", "to_k", "to_v", "to_out.0"):
+            lin(name + ".attentions.0." + t, c, c)
+        resnet(name + ".resnets.1", c, c)
+
+    conv("encoder.conv_in", 3, ch[0], 3)
+    cin = ch[0]
+    for i, c in enumerate(ch):
+        for j in range(layers):
+            resnet("encoder.down_blocks.%d.resnets.%d" % (i, j), cin if j == 0 else c, c)
+        if i < len(ch) - 1:
+            conv("encoder.down_blocks.%d.downsamplers.0.conv" % i, c, c, 3)
+        cin = c
+    mid("encoder.mid_block", ch[-1])
+    norm("encoder.conv_norm_out", ch[-1])
+    conv("encoder.conv_out", ch[-1], 2 * latent, 3)
+    rch = list(reversed(ch))
+    conv("decoder.conv_in", latent, rch[0], 3)
+    mid("decoder.mid_block", rch[0])
+    cin = rch[0]
+    for i, c in enumerate(rch):
+        for j in range(layers + 1):
+            resnet("decoder.up_blocks.%d.resnets.%d" % (i, j), cin if j == 0 else c, c)
+        if i < len(rch) - 1:
+            conv("decoder.up_blocks.%d.upsamplers.0.conv" % i, c, c, 3)
+        cin = c
+    norm("decoder.conv_norm_out", rch[-1])
+    conv("decoder.conv_out", rch[-1], 3, 3)
+    return shp
+
+
+def synthetic_vae_state_dict(seed=0):
+    """random-init VAE weights (fan-in scaled; norms near identity), CPU fp32 rounded to bf16-representable values
+    so that the product (bf16) and the oracle (fp32) see identical parameters."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for name, shape in vae_param_shapes().items():
+        if len(shape) > 1:
+            fan_in = 1
+            for s in shape[1:]:
+                fan_in *= s
+            t = torch.randn(shape, generator=g) / math.sqrt(fan_in)
+        elif ".norm" in name or "group_norm" in name or "conv_norm_out" in name:
+            t = (1.0 + 0.05 * torch.randn(shape, generator=g)) if name.endswith(".weight") else 0.05 * torch.randn(shape, generator=g)
+        else:
+            t = 0.02 * torch.randn(shape, generator=g)
+        sd[name] = t.to(torch.bfloat16).float()
+    return sd

@@ -24,7 +24,7 @@ def build_pipeline(pretrain_models=None, pipeline_name="texture_plus", device="c
     from .flux.pipeline import PBRFluxPipeline
     from .flux.synthetic import SyntheticFluxStateDict, synthetic_lora
     from .flux.transformer import FluxDiT, FluxShape
-    from .flux.vae import AutoencoderKL
+    from .flux.vae_hip import AutoencoderKL
     shape = shape or FluxShape()
     ckpt = os.path.join(pretrain_models, "black-forest-labs", "FLUX.1-dev") if pretrain_models else None
     if ckpt and os.path.isdir(os.path.join(ckpt, "transformer")):
