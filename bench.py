@@ -52,19 +52,19 @@ def step_flops(S):
 
 def cpu_baseline(S_full, threads):
     """Oracle (oracle/dit_ref.py, fp32 torch CPU) on a bounded sample: NB double + NB single FLUX blocks at
-    full width (D=3072, 24 heads), S_txt=256 + S_img=1792 tokens; extrapolated by algorithmic FLOPs."""
+    full width (D=3072, 24 heads), S_txt=512 + S_img=2560 tokens; extrapolated by algorithmic FLOPs."""
     from oracle import dit_ref
     torch.set_num_threads(threads)
-    NB = 2
+    NB = 3
     cfg = dit_ref.FluxConfig(num_double=NB, num_single=NB)
     sd = dit_ref.make_synthetic_state_dict(cfg, seed=0, dtype=torch.float32)
-    S_txt, S_img = 256, 1792
+    S_txt, S_img = 512, 2560
     g = torch.Generator().manual_seed(63)
     lat = torch.randn(S_img, 64, generator=g)
     enc = torch.zeros(S_txt, cfg.joint_dim)
     pooled = torch.zeros(1, cfg.pooled_dim)
     txt_ids = torch.zeros(S_txt, 3)
-    img_ids = dit_ref.latent_image_ids(28, 64)
+    img_ids = dit_ref.latent_image_ids(40, 64)
     t0 = time.perf_counter()
     dit_ref.flux_forward(sd, cfg, lat, enc, pooled, 0.5, 3.5, txt_ids, img_ids, emulate_bf16=False)
     dt = time.perf_counter() - t0

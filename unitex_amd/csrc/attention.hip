@@ -173,6 +173,115 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(AttnParams p) {
         const char* kb = kring + (t & 1) * ATT_KTILE;
         const int vnext = (vcur == NVB - 1) ? 0 : vcur + 1;
 
+
+        if constexpr (FAST == 2) {
+            // ---- PIPE: the 64-key tile is processed as two 32-key blocks, software-pipelined inside ONE wave so that the
+            // exponentials of a block sit in the shadow of independent MFMAs (same-wave MFMA/VALU interleave is the only
+            // overlap this chip grants, tools/coissue_probe.hip):
+            //     S0  QK(0)                       S1  QK(1)  ||  exp(0)  -> check(0)
+            //     S2  PV(0)  ||  exp(1) -> check(1)                       S3  PV(1)
+            // check(b): lane row sums of block b must stay <= 2^13, else the block is redone against its true max (slow
+            // path: QK(b) again, O / l rescaled; already-accumulated blocks are consistent with the old max by construction).
+            f32x16 sa0, sa1;
+            bf16x8 kfa[8], kfb[8], vfa[8], vfb[8];
+            const char* vtb = vring + vcur * ATT_VTILE + v_off;
+            // the last, partially filled tile takes the slow path for both blocks: keys >= S are masked there (cold code)
+            const bool ragged = (t == nt - 1) && (S & (ATT_KVB - 1));
+            const int lim = S - t * ATT_KVB - 8 * lh;
+#define ATT_EXPB(sa_, p0_, p1_, ps_)                                                                 \
+            {                                                                                        \
+                f32x2 acc2_ = {0.f, 0.f};                                                            \
+                _Pragma("unroll") for (int r = 0; r < 16; r += 2) {                                  \
+                    f32x2 pv_;                                                                       \
+                    pv_[0] = __builtin_amdgcn_exp2f(PRESC ? sa_[r] : sa_[r] * c2);                   \
+                    pv_[1] = __builtin_amdgcn_exp2f(PRESC ? sa_[r + 1] : sa_[r + 1] * c2);           \
+                    acc2_ += pv_;                                                                    \
+                    if (r < 8) { p0_[r] = (__bf16)pv_[0]; p0_[r + 1] = (__bf16)pv_[1]; }             \
+                    else { p1_[r - 8] = (__bf16)pv_[0]; p1_[r - 7] = (__bf16)pv_[1]; }               \
+                }                                                                                    \
+                ps_ = acc2_[0] + acc2_[1];                                                           \
+            }
+            // slow path for block (sa_, K rows at krow_off_): true max, move the running max, rescale what exists
+#define ATT_SLOW(sa_, other_, fix_other_, krow_off_, boff_, first_)                                  \
+            {                                                                                        \
+                _Pragma("unroll") for (int kk = 0; kk < 8; ++kk) {                                   \
+                    const bf16x8 kf_ = *reinterpret_cast<const bf16x8*>(kb + k_off + (krow_off_) + kk * 32); \
+                    sa_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf_, qf[kk], kk == 0 ? negm : sa_, 0, 0, 0); \
+                }                                                                                    \
+                if (ragged) {                                                                        \
+                    _Pragma("unroll") for (int r = 0; r < 16; ++r)                                   \
+                        if ((boff_) + 16 * (r >> 3) + (r & 7) >= lim) sa_[r] = -INFINITY;            \
+                }                                                                                    \
+                float mx_ = sa_[0];                                                                  \
+                _Pragma("unroll") for (int r = 1; r < 16; ++r) mx_ = fmaxf(mx_, sa_[r]);             \
+                mx_ = fmaxf(mx_, __shfl_xor(mx_, 32, 64));                                           \
+                const float d_ = (first_) ? mx_ : fmaxf(mx_, 0.f);                                   \
+                const float alpha_ = (first_) ? 1.0f : __builtin_amdgcn_exp2f(PRESC ? -d_ : -d_ * c2); \
+                m_run += d_;                                                                         \
+                l_run *= alpha_;                                                                     \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) { negm[r] = -m_run; sa_[r] -= d_; }   \
+                if (fix_other_) { _Pragma("unroll") for (int r = 0; r < 16; ++r) other_[r] -= d_; }  \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i)                                        \
+                    _Pragma("unroll") for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha_;             \
+            }
+            float ps0 = 0.f, ps1 = 0.f;
+            // S0: QK(0); block-1 K fragments stream in behind the MFMAs
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) kfa[kk] = *reinterpret_cast<const bf16x8*>(kb + k_off + kk * 32);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                kfb[kk] = *reinterpret_cast<const bf16x8*>(kb + k_off + 32 * ATT_KSTR + kk * 32);
+                sa0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfa[kk], qf[kk], kk == 0 ? negm : sa0, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+            for (int i_ = 0; i_ < 8; ++i_) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            // S1: QK(1) || exp(0); V fragments of block 0 stream in
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                vfa[kk] = *reinterpret_cast<const bf16x8*>(vtb + (kk & 3) * 32 * ATT_VSTR + (kk >> 2) * 32);
+                sa1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfb[kk], qf[kk], kk == 0 ? negm : sa1, 0, 0, 0);
+            }
+            ATT_EXPB(sa0, pb[0], pb[1], ps0)
+#pragma unroll
+            for (int i_ = 0; i_ < 8; ++i_) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+                __builtin_amdgcn_sched_group_barrier(0x402, 4, 1);
+            }
+            if (t == 0 || ragged || !__all(ps0 <= 8192.0f)) {
+                ATT_SLOW(sa0, sa1, true, 0, 0, t == 0)
+                ATT_EXPB(sa0, pb[0], pb[1], ps0)
+            }
+            l_run += ps0;
+            // S2: PV(0) || exp(1); V fragments of block 1 stream in
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                vfb[i] = *reinterpret_cast<const bf16x8*>(vtb + (i & 3) * 32 * ATT_VSTR + (2 + (i >> 2)) * 32);
+                oacc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfa[i], pb[i >> 2], oacc[i & 3], 0, 0, 0);
+            }
+            ATT_EXPB(sa1, pb[2], pb[3], ps1)
+#pragma unroll
+            for (int i_ = 0; i_ < 8; ++i_) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 2);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 2);
+                __builtin_amdgcn_sched_group_barrier(0x402, 4, 2);
+            }
+            if (ragged || !__all(ps1 <= 8192.0f)) {
+                ATT_SLOW(sa1, sa0, false, 32 * ATT_KSTR, 32, false)
+                ATT_EXPB(sa1, pb[2], pb[3], ps1)
+            }
+            l_run += ps1;
+            // S3: PV(1)
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                oacc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfb[i], pb[2 + (i >> 2)], oacc[i & 3], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        } else {
         f32x16 sacc[2];
         float psum = 1.0f;
         // S'^T = K Q^T - m_run : the accumulator chain starts from the -m_run block, so the MFMAs do the subtraction.
@@ -223,7 +332,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(AttnParams p) {
                 }                                                                                        \
             psum = ps2_[0] + ps2_[1];                                                                    \
         }
-        bool slow = !FAST || (t == 0);
+        bool slow = (FAST == 0) || (t == 0);
         if (!slow) {
             // common path: no max reduction.  Any probability above 2^13 shows up in the lane's row sum; the
             // tile is then redone below against the true max (nothing has been accumulated yet).
@@ -239,7 +348,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[b][r]);
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));      // tile max relative to m_run
-            if (FAST || t == 0 || !__all((PRESC ? mx : mx * c2) <= 8.0f)) {
+            if (FAST != 0 || t == 0 || !__all((PRESC ? mx : mx * c2) <= 8.0f)) {
                 // re-centre (wave-uniform): move the running max to the true max
                 const float d = (t == 0) ? mx : fmaxf(mx, 0.f);
                 // tile 0: O = l = 0, nothing to rescale (and exp2(-d) may overflow for very negative first maxima)
@@ -262,6 +371,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(AttnParams p) {
         l_run += psum;
 
         if (!(dbg & 8)) ATT_PV(vring + vcur * ATT_VTILE)
+        }
 
         if (t + 1 < nt && !(dbg & 1)) ATT_STORE_TILE((t + 1) & 1, vnext);
         if (!(dbg & 4)) __syncthreads();
@@ -303,7 +413,7 @@ static int launch_variant(const AttnParams& p0, hipStream_t stream) {
 // A/B knob: UTX_ATTN_FAST=0 selects the per-tile-max softmax (re-read per call so one process can compare).
 static int attn_fast() {
     const char* e = getenv("UTX_ATTN_FAST");
-    return (e && atoi(e) == 0) ? 0 : 1;
+    return e ? atoi(e) : 2;
 }
 
 // softmax_scale > 0: scores are multiplied by softmax_scale (natural-exp softmax, the reference's SDPA).
@@ -321,6 +431,8 @@ extern "C" int utx_launch_attn_fwd(const void* q, const void* k, const void* vt,
     { const char* e = getenv("UTX_ATTN_DEBUG"); p.dbg = e ? atoi(e) : 0; }
     p.scale_log2 = scale * 1.4426950408889634f;
     const bool presc = (scale == 0.f);
-    if (!attn_fast()) return presc ? launch_variant<8, 1, 0>(p, stream) : launch_variant<8, 0, 0>(p, stream);
-    return presc ? launch_variant<8, 1, 1>(p, stream) : launch_variant<8, 0, 1>(p, stream);
+    const int fast = attn_fast();   // 2 = block-pipelined sum-checked softmax (default), 1 = sum-checked, 0 = per-tile max
+    if (fast == 0) return presc ? launch_variant<8, 1, 0>(p, stream) : launch_variant<8, 0, 0>(p, stream);
+    if (fast == 1) return presc ? launch_variant<8, 1, 1>(p, stream) : launch_variant<8, 0, 1>(p, stream);
+    return presc ? launch_variant<8, 1, 2>(p, stream) : launch_variant<8, 0, 2>(p, stream);
 }
