@@ -170,6 +170,12 @@ int utx_interpolate(utx_ctx* ctx, const float* attr, int C, const float* rast, c
 int utx_condition_shade(utx_ctx* ctx, const float* rast, const float* nrm, const float* pos, const float* bg3_host,
                         long npix, void* out_normal, void* out_ccm, void* out_alpha, utx_stream stream);
 
+/* textured shading of the orbit video (video/export_nvdiffrast_video.py:141-256 -> renderer_base.py:289-336
+ * uv_rendering): rast [npix][4], per-vertex uv [V][2] in [0,1], tex [Ht][Wt][3] fp32 in UV-raster orientation (row
+ * grows with v) -> uint8 RGB [npix][3]: bilinear fetch (wrap), background bg3_host where empty, truncation to uint8. */
+int utx_texture_shade(utx_ctx* ctx, const float* rast, const float* uv, const int* tri, const float* tex, int Ht, int Wt,
+                      const float* bg3_host, long npix, void* out, utx_stream stream);
+
 /* LBVH ray-mesh intersector (raytracing/__init__.py:12-83 RayTracing / rt_aprmis APRMISRayTracing).
  * The handle owns its node arrays (hipMalloc inside build); verts/faces are borrowed and must stay
  * alive while the handle is used. */

@@ -493,3 +493,33 @@ def pull_push(kd, mask):
 def tensor_to_u8(img):
     """tensor_to_image (renderer_utils.py:62-83): clamp(0,1)*255 -> uint8 by TRUNCATION (A4)."""
     return (np.clip(img, 0.0, 1.0).astype(np.float32) * np.float32(255.0)).astype(np.uint8)
+
+
+def texture_shade(rast, uv01, tri, tex, bg=(1.0, 1.0, 1.0)):
+    """NVDiffRendererBase.uv_rendering restricted to what export_orbit_video uses (renderer_base.py:289-336):
+    UV interpolation -> dr.texture(filter 'linear', wrap) -> lerp with the background by the coverage mask ->
+    clamp * 255 -> uint8 (truncation).  float32 arithmetic in the order the kernel uses."""
+    rast, uv01, tri, tex = _f(rast), _f(uv01), _i(tri), _f(tex)
+    H, W = rast.shape[:2]
+    Ht, Wt = tex.shape[:2]
+    f32 = np.float32
+    idx = rast[..., 3].astype(np.int32) - 1
+    cov = idx >= 0
+    t = tri[np.where(cov, idx, 0)]
+    u, v = rast[..., 0], rast[..., 1]
+    w = (f32(1.0) - u) - v
+    a0, a1, a2 = uv01[t[..., 0]], uv01[t[..., 1]], uv01[t[..., 2]]
+    tu = (a0[..., 0] * u + a1[..., 0] * v) + a2[..., 0] * w
+    tv = (a0[..., 1] * u + a1[..., 1] * v) + a2[..., 1] * w
+    x = tu * f32(Wt) - f32(0.5)
+    y = tv * f32(Ht) - f32(0.5)
+    x0, y0 = np.floor(x), np.floor(y)
+    fx, fy = (x - x0).astype(f32), (y - y0).astype(f32)
+    ix0 = np.mod(x0.astype(np.int64), Wt); ix1 = np.mod(x0.astype(np.int64) + 1, Wt)
+    iy0 = np.mod(y0.astype(np.int64), Ht); iy1 = np.mod(y0.astype(np.int64) + 1, Ht)
+    one = f32(1.0)
+    top = tex[iy0, ix0] * (one - fx)[..., None] + tex[iy0, ix1] * fx[..., None]
+    bot = tex[iy1, ix0] * (one - fx)[..., None] + tex[iy1, ix1] * fx[..., None]
+    c = top * (one - fy)[..., None] + bot * fy[..., None]
+    c = np.where(cov[..., None], c, np.asarray(bg, dtype=f32)[None, None, :]).astype(f32)
+    return (np.clip(c, f32(0.0), f32(1.0)) * f32(255.0)).astype(np.uint8)

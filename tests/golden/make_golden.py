@@ -418,6 +418,9 @@ def g4_cameras(out):
         fix["intr_" + tag] = intr.numpy()
         fix["proj_" + tag] = conv.intr_to_proj(intr, perspective=persp).numpy()
         fix["mvp_" + tag] = torch.matmul(conv.intr_to_proj(intr, perspective=persp), conv.c2w_to_w2c(c2ws)).numpy()
+    # orbit cameras of export_orbit_video (video/export_nvdiffrast_video.py:193): 120 of 121 views, radius 2.8
+    fix["orbit_c2ws"] = gen.generate_orbit_views_c2ws(121, radius=2.8, height=0.0, theta_0=0.0, degree=True)[:120].numpy()
+    fix["orbit_c2ws_pitch"] = gen.generate_orbit_views_c2ws(9, radius=2.8, height=1.4, theta_0=30.0, degree=True).numpy()
     np.savez_compressed(os.path.join(out, "g4_cameras.npz"), **fix)
 
 

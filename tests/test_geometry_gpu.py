@@ -3,6 +3,7 @@
 the float32 outputs whose expression order is fixed on both sides (raster record, interpolation, gather,
 pull-push); stated tolerance only where libm (powf) is involved (lens blur)."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -185,3 +186,38 @@ def test_backprojection_chain_bit_exact(n_faces, T, HW):
     # uint8 by truncation + vertical flip
     u8 = ops.to_u8(pp, flip=True).cpu().numpy()
     assert np.array_equal(u8, G.tensor_to_u8(pp_ref)[::-1])
+
+
+def test_orbit_video_frames_bit_exact_and_mux(tmp_path):
+    """export_orbit_video (turntable of the textured mesh): perspective raster + fused UV interpolation / bilinear
+    texture fetch / background composite on the GPU vs the oracle, bit for bit; container round trip."""
+    import io
+    from PIL import Image
+    from unitex_amd.texturetools import camera, meshes, video
+    from unitex_amd.texturetools.video import VideoExporter
+    v, f, uv = meshes.sphere_with_faces(4000)
+    rng = np.random.default_rng(5)
+    tex = (rng.random((96, 128, 3)) * 255).astype(np.uint8)          # top-down image as stored in the GLB
+    R, n = 160, 6
+    path = str(tmp_path / "turn.mp4")
+    frames = VideoExporter(device="cuda:0").export_orbit_video((v, f, uv, tex), path, n_frames=n, render_size=R, return_frames=True,
+                                                               save_cover=True)
+    # cameras: the host-side matrix product is pinned separately (fixture G4); feed the oracle the same fp32 MVPs so
+    # that the comparison below isolates the kernels (transform, raster, shade) and can be exact
+    c2ws = camera.generate_orbit_views_c2ws(n + 1, radius=2.8, height=0.0, theta_0=0.0, degree=True)[:n]
+    intr = camera.generate_intrinsics(49.1, 49.1, fov=True, degree=True)
+    mvp = torch.matmul(camera.intr_to_proj(intr, perspective=True), camera.c2w_to_w2c(c2ws)).numpy()
+    clip = G.transform_points(v, mvp)
+    texf = (tex[::-1].astype(np.float32) / np.float32(255.0))
+    cover = 0
+    for i in range(n):
+        rast = G.rasterize(clip[i], f, R, R)
+        ref = G.texture_shade(rast, uv, f, texf, bg=(1.0, 1.0, 1.0))
+        assert np.array_equal(frames[i], ref), "frame %d differs in %d bytes" % (i, int((frames[i] != ref).sum()))
+        cover += int((rast[..., 3] > 0).sum())
+    assert cover > 0.2 * n * R * R
+    fps, jpgs = video.read_mjpeg_mp4(path)
+    assert fps == 15 and len(jpgs) == n
+    im = np.asarray(Image.open(io.BytesIO(jpgs[0])).convert("RGB")).astype(np.int32)
+    assert np.abs(im - frames[0]).mean() < 20.0
+    assert os.path.exists(os.path.splitext(path)[0] + "_cover.png")

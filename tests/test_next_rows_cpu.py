@@ -1,0 +1,84 @@
+"""CPU tests of the 'next' rows around the hot path: mesh input (GLB / UV-less meshes), the
+builder-defined UV atlas, the orbit cameras of the turntable video (pinned by the reference fixture G4) and the
+Motion-JPEG MP4 muxer."""
+import io
+import os
+
+import numpy as np
+import torch
+from PIL import Image
+
+from oracle import geom_ref as G
+from unitex_amd.texturetools import camera, meshes, video
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_orbit_cameras_match_reference_fixture():
+    f = np.load(os.path.join(HERE, "golden", "g4_cameras.npz"))
+    a = camera.generate_orbit_views_c2ws(121, radius=2.8, height=0.0, theta_0=0.0, degree=True)[:120].numpy()
+    assert np.array_equal(a, f["orbit_c2ws"])
+    b = camera.generate_orbit_views_c2ws(9, radius=2.8, height=1.4, theta_0=30.0, degree=True).numpy()
+    assert np.array_equal(b, f["orbit_c2ws_pitch"])
+    # straight-down view takes the hard-coded x axis (generator.py:28-31)
+    c = camera.lookat_to_matrix(torch.tensor([[0.0, 0.0, 2.8]])).numpy()[0]
+    assert np.isfinite(c).all() and abs(np.linalg.det(c[:3, :3])) > 0.99
+
+
+def test_glb_round_trip(tmp_path):
+    v, f, uv = meshes.sphere_with_faces(1200)
+    tex = (np.random.default_rng(0).random((32, 48, 3)) * 255).astype(np.uint8)
+    p = str(tmp_path / "m.glb")
+    meshes.save_glb(p, v, f, uv, tex)
+    v2, f2, uv2, t2 = meshes.load_mesh(p)
+    assert np.array_equal(v, v2) and np.array_equal(f, f2) and np.array_equal(tex, t2)
+    assert np.allclose(uv, uv2, atol=1e-6)
+
+
+def test_unwrap_grid_is_a_valid_atlas():
+    v, f, _ = meshes.sphere_with_faces(1500)
+    T = 512
+    vv, ff, uu = meshes.unwrap_grid(v, f, atlas=T, gutter=2.0)
+    assert ff.shape == f.shape and uu.min() > 0 and uu.max() < 1
+    assert np.array_equal(vv[ff.reshape(-1)].reshape(-1, 3, 3), v[f.reshape(-1)].reshape(-1, 3, 3))   # geometry unchanged
+    # rasterise the atlas with the oracle rasteriser: every face owns texels, and a 1-texel dilation of any face
+    # never touches another face (gutter), so bilinear fetches / dilation cannot bleed between triangles
+    uvclip = np.concatenate([uu * 2 - 1, np.zeros((len(uu), 1), np.float32), np.ones((len(uu), 1), np.float32)], -1)
+    ids = G.rasterize(uvclip, ff, T, T)[..., 3].astype(np.int64)
+    owned = np.bincount(ids.reshape(-1), minlength=len(ff) + 1)[1:]
+    assert (owned > 0).all(), "%d faces have no texel" % int((owned == 0).sum())
+    for dy, dx in ((0, 1), (1, 0), (1, 1), (1, -1)):
+        a = ids[max(dy, 0):, max(dx, 0):][:T - abs(dy), :T - abs(dx)]
+        b = ids[:T - dy, max(-dx, 0):][:T - abs(dy), :T - abs(dx)]
+        both = (a > 0) & (b > 0)
+        assert (a[both] == b[both]).all(), "adjacent texels belong to different faces"
+
+
+def test_prepare_blank_mesh_without_uvs(tmp_path):
+    v, f, _ = meshes.sphere_with_faces(900)
+    v = np.concatenate([v, v[:5] + 1e-12])                       # duplicate vertices, an unreferenced one
+    f = np.concatenate([f, [[0, 0, 1]]]).astype(np.int32)        # a degenerate face
+    p = str(tmp_path / "blank.obj")
+    meshes.save_obj(p, v, f)
+    vv, ff, uu = meshes.prepare_blank_mesh(p, min_faces=3000, max_faces=20000, scale=0.95, atlas=1024, gutter=2.0)
+    assert 3000 <= len(ff) <= 20000 and len(uu) == len(vv) == 3 * len(ff)
+    assert abs((vv.max(0) - vv.min(0)).max() - 1.9) < 1e-5
+    big_v, big_f, _ = meshes.sphere_with_faces(30000)
+    dv, df = meshes.decimate_cluster(*meshes.clean_mesh(big_v, big_f), max_faces=8000)
+    assert 500 < len(df) <= 8000 and df.max() < len(dv)
+
+
+def test_mjpeg_mp4_round_trip(tmp_path):
+    yy, xx = np.mgrid[0:64, 0:96]
+    frames = [np.stack([(xx * 2 + 10 * i) % 256, yy * 3 % 256, (xx + yy) % 256], -1).astype(np.uint8) for i in range(7)]
+    p = str(tmp_path / "t.mp4")
+    video.write_mjpeg_mp4(p, frames, fps=15)
+    blob = open(p, "rb").read()
+    assert blob[4:8] == b"ftyp" and b"moov" in blob and b"jpeg" in blob
+    fps, jpgs = video.read_mjpeg_mp4(p)
+    assert fps == 15 and len(jpgs) == 7
+    for j, fr in zip(jpgs, frames):
+        im = np.asarray(Image.open(io.BytesIO(j)).convert("RGB")).astype(np.int32)
+        assert im.shape == fr.shape and np.abs(im - fr).mean() < 12.0     # JPEG, smooth content
+    video.write_gif(str(tmp_path / "t.gif"), frames, fps=15)
+    assert Image.open(str(tmp_path / "t.gif")).n_frames == 7

@@ -61,7 +61,7 @@ def test_full_pipeline_end_to_end_tiny(tmp_path):
     png, glb = pipe(out_dir, img_path, mesh_path)
     cache = os.path.join(out_dir, "cache")
     for name in ("processed_mesh.obj", "processed_image.png", "rembg_image.png", "mv_alpha.png", "mv_ccm.png", "mv_normal.png",
-                 "camera_info.pth", "mv_rgb_w_light.png", "mv_rgb.png", "wo_LTM/textured_mesh.glb", "wo_LTM/visable_uv_mask.png",
+                 "camera_info.pth", "mv_rgb_w_light.png", "mv_rgb.png", "wo_LTM/textured_mesh.glb", "wo_LTM/textured_mesh.mp4", "wo_LTM/visable_uv_mask.png",
                  "wo_LTM/valid_uv_mask.png", "wo_LTM/completed_uv.png", "textured_mesh.glb"):
         assert os.path.exists(os.path.join(cache, name)), name
     assert os.path.exists(png) and os.path.exists(glb) and open(glb, "rb").read(4) == b"glTF"

@@ -116,6 +116,12 @@ int utx_interpolate(utx_ctx* ctx, const float* attr, int C, const float* rast, c
     if (!attr || !rast || !tri || !out) return fail(ctx, -2, "utx_interpolate");
     UTX_CALL(ctx, "utx_interpolate", utx_launch_interpolate(attr, C, rast, tri, npix, out, (hipStream_t)stream));
 }
+int utx_texture_shade(utx_ctx* ctx, const float* rast, const float* uv, const int* tri, const float* tex, int Ht, int Wt,
+                      const float* bg3_host, long npix, void* out, utx_stream stream) {
+    if (!rast || !uv || !tri || !tex || !out) return fail(ctx, -2, "utx_texture_shade");
+    UTX_CALL(ctx, "utx_texture_shade", utx_launch_texture_shade(rast, uv, tri, tex, Ht, Wt, bg3_host, npix, out, (hipStream_t)stream));
+}
+
 int utx_condition_shade(utx_ctx* ctx, const float* rast, const float* nrm, const float* pos, const float* bg3_host, long npix,
                         void* out_normal, void* out_ccm, void* out_alpha, utx_stream stream) {
     if (!rast || !nrm || !pos || !bg3_host || !out_normal || !out_ccm || !out_alpha) return fail(ctx, -2, "utx_condition_shade");

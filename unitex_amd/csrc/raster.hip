@@ -239,3 +239,52 @@ extern "C" int utx_launch_condition_shade(const float* rast, const float* nrm, c
                        bg3_host[0], bg3_host[1], bg3_host[2], npix, (unsigned char*)out_normal, (unsigned char*)out_ccm, (unsigned char*)out_alpha);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
+
+// ---- textured shading of the orbit video (VideoExporter.export_orbit_video -> NVDiffRendererBase.uv_rendering,
+// render/nvdiffrast/renderer_base.py:289-336): per pixel, interpolate the vertex UVs with the raster barycentrics,
+// fetch the base-colour map bilinearly (dr.texture filter 'linear', wrap addressing, texel centres at +0.5), composite
+// over the background with the coverage mask and convert to uint8 by truncation (clamp * 255 -> astype(uint8)).
+// tex is [Ht][Wt][3] fp32 in UV-raster orientation (row index grows with v).
+__device__ __forceinline__ int wrapi(int i, int n) { i %= n; return i < 0 ? i + n : i; }
+
+__global__ __launch_bounds__(256) void texture_shade_kernel(const float4* rast, const float* uv, const int* tri, const float* tex, int Ht,
+                                                            int Wt, float bg0, float bg1, float bg2, long npix, unsigned char* out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    const float4 r = rast[i];
+    const int id = (int)r.w - 1;
+    const float bg[3] = {bg0, bg1, bg2};
+    float c[3] = {bg0, bg1, bg2};
+    if (id >= 0) {
+        const float u = r.x, v = r.y, w = (1.0f - u) - v;
+        const float* a0 = uv + 2 * (long)tri[3 * id + 0];
+        const float* a1 = uv + 2 * (long)tri[3 * id + 1];
+        const float* a2 = uv + 2 * (long)tri[3 * id + 2];
+        const float tu = (a0[0] * u + a1[0] * v) + a2[0] * w;
+        const float tv = (a0[1] * u + a1[1] * v) + a2[1] * w;
+        const float x = tu * (float)Wt - 0.5f, y = tv * (float)Ht - 0.5f;
+        const float x0 = floorf(x), y0 = floorf(y);
+        const float fx = x - x0, fy = y - y0;
+        const int ix0 = wrapi((int)x0, Wt), ix1 = wrapi((int)x0 + 1, Wt);
+        const int iy0 = wrapi((int)y0, Ht), iy1 = wrapi((int)y0 + 1, Ht);
+        const float* t00 = tex + 3 * ((long)iy0 * Wt + ix0);
+        const float* t01 = tex + 3 * ((long)iy0 * Wt + ix1);
+        const float* t10 = tex + 3 * ((long)iy1 * Wt + ix0);
+        const float* t11 = tex + 3 * ((long)iy1 * Wt + ix1);
+        for (int k = 0; k < 3; ++k) {
+            const float top = t00[k] * (1.0f - fx) + t01[k] * fx;
+            const float bot = t10[k] * (1.0f - fx) + t11[k] * fx;
+            c[k] = top * (1.0f - fy) + bot * fy;
+        }
+    }
+    (void)bg;
+    for (int k = 0; k < 3; ++k) out[3 * i + k] = (unsigned char)(fminf(fmaxf(c[k], 0.f), 1.f) * 255.0f);
+}
+
+extern "C" int utx_launch_texture_shade(const float* rast, const float* uv, const int* tri, const float* tex, int Ht, int Wt,
+                                        const float* bg3_host, long npix, void* out, hipStream_t stream) {
+    if (npix <= 0 || Ht <= 0 || Wt <= 0 || !bg3_host) return -2;
+    hipLaunchKernelGGL(texture_shade_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, stream, (const float4*)rast, uv, tri, tex,
+                       Ht, Wt, bg3_host[0], bg3_host[1], bg3_host[2], npix, (unsigned char*)out);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}

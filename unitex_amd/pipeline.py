@@ -70,15 +70,13 @@ class RGBTextureFullPipelineBase:
 
     @CPUTimer("preprocess_blank_mesh")
     def preprocess_blank_mesh(self, save_dir, input_mesh_path, min_faces=20_000, max_faces=200_000, scale=0.95):
-        """reference: open3d clean / decimate / UVAtlas (geometry/uv/uv_atlas.py:131-194).  Here: normalise to
-        bbox*scale and pass an already-unwrapped mesh through ('next' row f1)."""
+        """reference: open3d clean / decimate / subdivide / UVAtlas (geometry/uv/uv_atlas.py:131-194).  Here the
+        host-side equivalents of texturetools/meshes.py: .obj / .glb in, rescaled to bbox*scale; a mesh with UVs passes
+        through, one without is cleaned, brought into [min_faces, max_faces] and unwrapped (builder-defined atlas)."""
         from .texturetools import meshes
-        verts, faces, uvs, faces_uv = meshes.load_obj(input_mesh_path)
-        if uvs is None:
-            raise NotImplementedError("UV unwrapping is out of scope this round: provide an OBJ with vt records")
-        lo, hi = verts.min(0), verts.max(0)
-        verts = (verts - 0.5 * (lo + hi)) / ((hi - lo).max() / (2.0 * scale))
-        meshes.save_obj(os.path.join(save_dir, "processed_mesh.obj"), verts.astype(np.float32), faces, uvs, faces_uv)
+        verts, faces, uvs = meshes.prepare_blank_mesh(input_mesh_path, min_faces=min_faces, max_faces=max_faces, scale=scale,
+                                                      atlas=self.atlas_size, gutter=4.0)
+        meshes.save_obj(os.path.join(save_dir, "processed_mesh.obj"), verts, faces, uvs)
 
     @CPUTimer("preprocess_reference_image")
     def preprocess_reference_image(self, save_dir, input_image_path, scale=0.95, color="grey"):
@@ -130,7 +128,10 @@ class RGBTextureFullPipelineBase:
 
     @CPUTimer("export_video")
     def export_video(self, save_dir, input_mesh_path, output_video_name):
-        print("export_orbit_video (120-frame turntable) is a 'next' row (SURVEY 8f rank 3): skipped")
+        output_video_path = os.path.join(save_dir, os.path.splitext(output_video_name)[0] + ".mp4")
+        self.video_exporter.export_orbit_video(input_mesh_path, output_video_path, n_frames=120, enhance_mode=None, perspective=True,
+                                               video_type="rgb", save_frames=False, save_grid=False, save_cover=False,
+                                               save_camera=False, rename_with_euler=False)
 
     @CPUTimer("reproject_and_query_field")
     def reproject_and_query_field(self, save_dir, input_mesh_path, input_mv_image_path, camera_info_path, four_or_six=False,

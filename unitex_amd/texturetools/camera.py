@@ -71,6 +71,35 @@ def generate_box_views_c2ws(radius=2.8):
     return out
 
 
+def lookat_to_matrix(lookat: torch.Tensor) -> torch.Tensor:
+    """camera positions looking at the origin -> c2w (camera/generator.py:8-40).  World x forward / y right / z up is
+    re-expressed as z forward / x right / y up by the fixed axis permutation applied on the left."""
+    lookat = torch.as_tensor(lookat, dtype=torch.float32)
+    e2 = torch.tensor([0.0, 1.0, 0.0]); e3 = torch.tensor([0.0, 0.0, 1.0])
+    z_axis = torch.nn.functional.normalize(lookat, dim=-1)
+    x_axis = torch.linalg.cross(e3.expand_as(z_axis), z_axis, dim=-1)
+    degenerate = (x_axis == 0).all(dim=-1, keepdim=True)          # looking straight down / up: x is hard-coded
+    x_axis = torch.where(degenerate, e2, x_axis)
+    y_axis = torch.linalg.cross(z_axis, x_axis, dim=-1)
+    rots = torch.stack([x_axis, y_axis, z_axis], dim=-1)
+    top = torch.cat([rots, lookat.unsqueeze(-1)], dim=-1)
+    bottom = torch.tensor([0.0, 0.0, 0.0, 1.0]).expand(lookat.shape[:-1] + (1, 4))
+    c2ws = torch.cat([top, bottom], dim=-2)
+    perm = torch.tensor([[0.0, 1.0, 0.0, 0.0], [0.0, 0.0, 1.0, 0.0], [1.0, 0.0, 0.0, 0.0], [0.0, 0.0, 0.0, 1.0]])
+    return torch.matmul(perm, c2ws)
+
+
+def generate_orbit_views_c2ws(num_views: int, radius: float = 1.0, height: float = 0.0, theta_0: float = 0.0, degree=False):
+    """cameras on a horizontal circle at `height` on the sphere of `radius` (camera/generator.py:117-127)."""
+    if degree:
+        theta_0 = math.radians(theta_0)
+    projected_radius = math.sqrt(radius ** 2 - height ** 2)
+    theta = torch.linspace(theta_0, 2.0 * math.pi + theta_0, num_views, dtype=torch.float32)
+    xyz = torch.stack([projected_radius * torch.cos(theta), projected_radius * torch.sin(theta),
+                       torch.full((num_views,), fill_value=height, dtype=torch.float32)], dim=-1)
+    return lookat_to_matrix(xyz)
+
+
 def parse_color(color):
     """'grey' -> (128,128,128)/255 etc. (utils/parse_color.py:5-19 via PIL's colour map)."""
     if color is None:

@@ -152,3 +152,215 @@ def save_glb(path, verts, faces, uvs, texture_rgb_u8):
         f.write(js)
         f.write(struct.pack("<II", len(bin_blob), 0x004E4942))
         f.write(bin_blob)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Mesh input for real user meshes.  The reference goes through open3d / trimesh / UVAtlas
+# (geometry/uv/uv_atlas.py:131-194, io/mesh_loader.py:22-30) -- none of which exist in this image and whose outputs
+# cannot be pinned -- so the functions below are builder-defined host-side equivalents with the same role and the
+# same knobs (min_faces / max_faces / scale / atlas size / gutter); they are numpy data preparation, not hot path.
+
+_GLTF_DTYPES = {5120: np.int8, 5121: np.uint8, 5122: np.int16, 5123: np.uint16, 5125: np.uint32, 5126: np.float32}
+_GLTF_NCOMP = {"SCALAR": 1, "VEC2": 2, "VEC3": 3, "VEC4": 4, "MAT4": 16}
+
+
+def load_glb(path):
+    """glTF 2.0 binary reader: all triangle primitives of all meshes (node transforms applied), merged.
+    Returns verts [V,3] f32, faces [F,3] i32, uvs [V,2] f32 in [0,1] with v bottom-up | None, texture u8 [H,W,3] | None."""
+    import io
+    with open(path, "rb") as f:
+        blob = f.read()
+    magic, version, total = struct.unpack_from("<III", blob, 0)
+    if magic != 0x46546C67:
+        raise ValueError("%s is not a .glb file" % path)
+    off, js, binc = 12, None, b""
+    while off < total:
+        clen, ctype = struct.unpack_from("<II", blob, off)
+        data = blob[off + 8: off + 8 + clen]
+        if ctype == 0x4E4F534A:
+            js = json.loads(data.decode("utf-8"))
+        elif ctype == 0x004E4942:
+            binc = data
+        off += 8 + clen + ((-clen) % 4)
+
+    def accessor(i):
+        a = js["accessors"][i]
+        bv = js["bufferViews"][a["bufferView"]]
+        dt, nc = _GLTF_DTYPES[a["componentType"]], _GLTF_NCOMP[a["type"]]
+        start = bv.get("byteOffset", 0) + a.get("byteOffset", 0)
+        stride = bv.get("byteStride", 0)
+        item = np.dtype(dt).itemsize * nc
+        if stride and stride != item:
+            raw = np.frombuffer(binc, dtype=np.uint8, count=stride * a["count"], offset=start).reshape(a["count"], stride)[:, :item]
+            arr = np.frombuffer(raw.tobytes(), dtype=dt).reshape(a["count"], nc)
+        else:
+            arr = np.frombuffer(binc, dtype=dt, count=a["count"] * nc, offset=start).reshape(a["count"], nc)
+        if a.get("normalized") and dt != np.float32:
+            arr = arr.astype(np.float32) / float(np.iinfo(dt).max)
+        return arr
+
+    def node_matrix(n):
+        if "matrix" in n:
+            return np.asarray(n["matrix"], dtype=np.float64).reshape(4, 4).T
+        m = np.eye(4)
+        if "scale" in n:
+            m = np.diag(list(n["scale"]) + [1.0]) @ m
+        if "rotation" in n:
+            x, y, z, w = n["rotation"]
+            r = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                          [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                          [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+            rm = np.eye(4); rm[:3, :3] = r
+            m = rm @ m
+        if "translation" in n:
+            tm = np.eye(4); tm[:3, 3] = n["translation"]
+            m = tm @ m
+        return m
+
+    vs, fs, ts, base, tex, have_uv = [], [], [], 0, None, True
+
+    def visit(ni, parent):
+        nonlocal base, tex, have_uv
+        n = js["nodes"][ni]
+        m = parent @ node_matrix(n)
+        if "mesh" in n:
+            for prim in js["meshes"][n["mesh"]]["primitives"]:
+                if prim.get("mode", 4) != 4:
+                    continue
+                pos = accessor(prim["attributes"]["POSITION"]).astype(np.float64)
+                pos = (np.concatenate([pos, np.ones((len(pos), 1))], 1) @ m.T)[:, :3]
+                idx = accessor(prim["indices"]).reshape(-1, 3).astype(np.int64) if "indices" in prim else np.arange(len(pos)).reshape(-1, 3)
+                vs.append(pos.astype(np.float32)); fs.append(idx + base); base += len(pos)
+                if "TEXCOORD_0" in prim["attributes"]:
+                    t = accessor(prim["attributes"]["TEXCOORD_0"]).astype(np.float32)
+                    ts.append(np.stack([t[:, 0], 1.0 - t[:, 1]], -1))        # glTF v runs top-down
+                else:
+                    have_uv = False
+                mat = prim.get("material")
+                if tex is None and mat is not None:
+                    bct = js["materials"][mat].get("pbrMetallicRoughness", {}).get("baseColorTexture")
+                    if bct is not None:
+                        img = js["images"][js["textures"][bct["index"]]["source"]]
+                        if "bufferView" in img:
+                            bv = js["bufferViews"][img["bufferView"]]
+                            from PIL import Image
+                            tex = np.asarray(Image.open(io.BytesIO(binc[bv.get("byteOffset", 0): bv.get("byteOffset", 0) + bv["byteLength"]])).convert("RGB"))
+        for c in n.get("children", []):
+            visit(c, m)
+
+    scene = js["scenes"][js.get("scene", 0)]
+    for ni in scene["nodes"]:
+        visit(ni, np.eye(4))
+    if not vs:
+        raise ValueError("no triangle primitives in %s" % path)
+    verts, faces = np.concatenate(vs), np.concatenate(fs).astype(np.int32)
+    uvs = np.concatenate(ts) if (have_uv and ts) else None
+    return verts, faces, uvs, tex
+
+
+def load_mesh(path):
+    """.obj / .glb -> (verts, faces, uvs | None [one per vertex], texture | None)."""
+    ext = path.lower().rsplit(".", 1)[-1]
+    if ext == "obj":
+        v, f, uv, fuv = load_obj(path)
+        if uv is not None:
+            v, f, uv = unify_uv_indexing(v, f, uv, fuv)
+        return v, f, uv, None
+    if ext == "glb":
+        return load_glb(path)
+    raise NotImplementedError("mesh format .%s is not read natively (supported: .obj, .glb)" % ext)
+
+
+def clean_mesh(verts, faces, merge_eps=1e-8):
+    """merge_close_vertices + remove_degenerate_triangles + remove_unreferenced_vertices (uv_atlas.py:150-152,169)."""
+    key = np.round(verts.astype(np.float64) / max(merge_eps, 1e-12)).astype(np.int64) if merge_eps > 0 else None
+    if key is not None and np.abs(key).max() < 2 ** 62:
+        _, first, inv = np.unique(key, axis=0, return_index=True, return_inverse=True)
+        verts, faces = verts[first], inv.reshape(-1)[faces]
+    a, b, c = verts[faces[:, 0]].astype(np.float64), verts[faces[:, 1]].astype(np.float64), verts[faces[:, 2]].astype(np.float64)
+    area2 = np.linalg.norm(np.cross(b - a, c - a), axis=1)
+    keep = (faces[:, 0] != faces[:, 1]) & (faces[:, 1] != faces[:, 2]) & (faces[:, 0] != faces[:, 2]) & (area2 > 0)
+    faces = faces[keep]
+    used = np.unique(faces)
+    remap = -np.ones(len(verts), dtype=np.int64); remap[used] = np.arange(len(used))
+    return verts[used].astype(np.float32), remap[faces].astype(np.int32)
+
+
+def subdivide_midpoint(verts, faces):
+    """one 1:4 midpoint subdivision (the reference calls open3d subdivide_loop x2 for meshes under min_faces,
+    uv_atlas.py:164-165; positions are not smoothed here)."""
+    e = np.sort(np.concatenate([faces[:, [0, 1]], faces[:, [1, 2]], faces[:, [2, 0]]]), axis=1)
+    ue, inv = np.unique(e, axis=0, return_inverse=True)
+    mid = 0.5 * (verts[ue[:, 0]] + verts[ue[:, 1]])
+    F, V = len(faces), len(verts)
+    m01, m12, m20 = inv[:F] + V, inv[F:2 * F] + V, inv[2 * F:] + V
+    a, b, c = faces[:, 0], faces[:, 1], faces[:, 2]
+    nf = np.concatenate([np.stack([a, m01, m20], 1), np.stack([m01, b, m12], 1), np.stack([m20, m12, c], 1), np.stack([m01, m12, m20], 1)])
+    return np.concatenate([verts, mid]).astype(np.float32), nf.astype(np.int32)
+
+
+def decimate_cluster(verts, faces, max_faces):
+    """vertex-clustering decimation until F <= max_faces (the reference uses open3d quadric decimation,
+    uv_atlas.py:154-160): vertices are snapped to a uniform grid, cells collapse to their mean."""
+    lo, hi = verts.min(0), verts.max(0)
+    res = int(np.ceil(np.sqrt(max_faces / 2.0))) * 2
+    while len(faces) > max_faces and res >= 4:
+        cell = np.floor((verts - lo) / np.maximum(hi - lo, 1e-12) * (res - 1e-6)).astype(np.int64)
+        key = (cell[:, 0] * res + cell[:, 1]) * res + cell[:, 2]
+        uk, inv = np.unique(key, return_inverse=True)
+        cnt = np.bincount(inv, minlength=len(uk)).astype(np.float64)
+        nv = np.stack([np.bincount(inv, weights=verts[:, k].astype(np.float64), minlength=len(uk)) / cnt for k in range(3)], 1)
+        v2, f2 = clean_mesh(nv.astype(np.float32), inv[faces].astype(np.int32), merge_eps=0)
+        f2 = f2[np.sort(np.unique(np.sort(f2, 1), axis=0, return_index=True)[1])]      # drop duplicate faces
+        if len(f2) <= max_faces:
+            return v2, f2
+        res = int(res * 0.85)
+    return verts, faces
+
+
+def unwrap_grid(verts, faces, atlas=2048, gutter=4.0):
+    """Builder-defined UV atlas (the reference calls UVAtlas through open3d, uv_atlas.py:171: size 2048, gutter 4):
+    every triangle gets its own right-triangle slot, two slots per square cell of a regular grid, each inset by
+    `gutter`/2 texels so that no two triangles share a texel.  Bijective by construction, no parametrisation distortion
+    control; vertices are duplicated per face.  Returns verts [3F,3], faces [F,3], uvs [3F,2] in [0,1]."""
+    F = len(faces)
+    ncell = (F + 1) // 2
+    n = int(np.ceil(np.sqrt(ncell)))
+    cs = atlas / float(n)                         # cell size in texels
+    g = gutter * 0.5
+    if cs < 3.0 * gutter:
+        raise ValueError("atlas %d too small for %d faces with gutter %.1f" % (atlas, F, gutter))
+    fi = np.arange(F)
+    cx, cy = (fi // 2) % n, (fi // 2) // n
+    upper = (fi % 2) == 1
+    x0, y0 = cx * cs, cy * cs
+    # lower triangle: (g, g), (cs-2g-g.., g), (g, cs-...) ; upper: mirrored, with a full gutter across the diagonal
+    d = cs - g * (2.0 + np.sqrt(2.0))             # leg length that keeps `gutter` texels between the two hypotenuses
+    lo = np.stack([np.stack([x0 + g, y0 + g], 1), np.stack([x0 + g + d, y0 + g], 1), np.stack([x0 + g, y0 + g + d], 1)], 1)
+    up = np.stack([np.stack([x0 + cs - g, y0 + cs - g], 1), np.stack([x0 + cs - g - d, y0 + cs - g], 1),
+                   np.stack([x0 + cs - g, y0 + cs - g - d], 1)], 1)
+    tri_uv = np.where(upper[:, None, None], up, lo) / float(atlas)          # [F,3,2]
+    v_out = verts[faces.reshape(-1)].astype(np.float32)
+    f_out = np.arange(3 * F, dtype=np.int32).reshape(F, 3)
+    return v_out, f_out, tri_uv.reshape(-1, 2).astype(np.float32)
+
+
+def normalise_to_bbox(verts, scale):
+    lo, hi = verts.min(0), verts.max(0)
+    return ((verts - 0.5 * (lo + hi)) / ((hi - lo).max() / (2.0 * scale))).astype(np.float32)
+
+
+def prepare_blank_mesh(path, min_faces=20_000, max_faces=200_000, scale=1.0, atlas=2048, gutter=4.0):
+    """preprocess_blank_mesh_o3d (uv_atlas.py:131-175) with the host-side equivalents above: rescale to the bbox;
+    a mesh that already has UVs passes through; otherwise clean, bring the face count into [min_faces, max_faces],
+    and unwrap.  Returns verts, faces, uvs (one uv per vertex)."""
+    verts, faces, uvs, _ = load_mesh(path)
+    verts = normalise_to_bbox(verts, scale)
+    if uvs is not None:
+        return verts, faces, uvs
+    verts, faces = clean_mesh(verts, faces)
+    if len(faces) > max_faces:
+        verts, faces = decimate_cluster(verts, faces, max_faces)
+    while len(faces) < min_faces and 4 * len(faces) <= max_faces:
+        verts, faces = subdivide_midpoint(verts, faces)
+    return unwrap_grid(verts, faces, atlas=atlas, gutter=gutter)

@@ -65,6 +65,17 @@ def condition_shade(rast, nrm, pos, bg):
     return on, oc, oa
 
 
+def texture_shade(rast, uv01, tri, tex, bg=(1.0, 1.0, 1.0)):
+    """rast [H,W,4], uv01 [V,2], tex [Ht,Wt,3] fp32 (UV-raster orientation) -> uint8 RGB [H,W,3]."""
+    ctx = get_ctx(rast.device.index)
+    H, W = rast.shape[:2]
+    out = torch.empty(H, W, 3, dtype=U8, device=rast.device)
+    bgv = (C.c_float * 3)(*[float(b) for b in bg])
+    ctx.check(ctx.lib.utx_texture_shade(ctx.handle, ptr(_f(rast)), ptr(_f(uv01)), ptr(_i(tri)), ptr(_f(tex)), tex.shape[0], tex.shape[1],
+                                        bgv, H * W, ptr(out), ctx.stream()))
+    return out
+
+
 class BVH:
     """utx_bvh handle (RayTracing / APRMISRayTracing of the reference)."""
 

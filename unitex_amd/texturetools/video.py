@@ -3,7 +3,14 @@ grids) that feeds the DiT (reference: TextureTools/texturetools/video/export_nvd
 top of NVDiffRendererBase.simple_rendering, render/nvdiffrast/renderer_base.py:101-200).
 
 HIP path: clip transform -> rasterise per view -> interpolate vertex normals / positions -> fused shade +
-uint8 conversion kernel.  The orbit-video export (export_orbit_video) is a 'next' row."""
+uint8 conversion kernel.  export_orbit_video (video/export_nvdiffrast_video.py:141-256): per frame clip transform ->
+perspective raster -> fused UV interpolation + bilinear texture fetch + background composite (utx_texture_shade);
+frames are muxed on the host (Motion-JPEG in an MP4 container, or GIF -- there is no video encoder in this image)."""
+import io
+import math
+import os
+import struct
+
 import numpy as np
 import torch
 from PIL import Image
@@ -71,3 +78,148 @@ class VideoExporter:
         if return_camera:
             results.update({"c2ws": c2ws, "intrinsics": intrinsics, "perspective": perspective})
         return results
+
+
+    def export_orbit_video(self, mesh_obj, video_path, n_frames=120, enhance_mode=None, perspective=True, video_type="rgb",
+                           save_frames=False, save_grid=False, save_cover=False, save_camera=False, rename_with_euler=False,
+                           render_size=1024, fps=15, return_frames=False):
+        """turntable of a textured mesh on a white background.  mesh_obj: path to a textured .glb, a TexturedMesh
+        (renderer_inverse.py) or (verts, faces, uvs01, texture_u8_top_down)."""
+        ext = os.path.splitext(video_path)[1]
+        assert ext in [".mp4", ".gif"]
+        if video_type != "rgb":
+            raise NotImplementedError("video_type %s: only the 'rgb' turntable of the texture pipeline is built" % video_type)
+        if isinstance(mesh_obj, str):
+            verts, faces, uvs, tex = meshes.load_mesh(mesh_obj)
+            verts = meshes.normalise_to_bbox(verts, 1.0)              # texture.mesh.scale_to_bbox() (:178)
+        elif isinstance(mesh_obj, (tuple, list)):
+            verts, faces, uvs, tex = mesh_obj
+        else:
+            verts, faces, uvs, tex = mesh_obj.vertices, mesh_obj.faces, mesh_obj.uv, mesh_obj.texture
+        assert uvs is not None and tex is not None, "missing map_Kd in texture"
+        if enhance_mode is None:
+            c2ws = camera.generate_orbit_views_c2ws(n_frames + 1, radius=2.8, height=0.0, theta_0=0.0, degree=True)[:n_frames]
+        elif enhance_mode == "pitch":
+            c2ws = torch.cat([camera.generate_orbit_views_c2ws(n_frames + 1, radius=2.8, height=h, theta_0=0.0, degree=True)[:n_frames]
+                              for h in (-2.425, -1.4, 0.0, 1.4, 2.425)])
+        elif enhance_mode == "box":
+            c2ws = camera.generate_box_views_c2ws(radius=2.8)
+        else:
+            raise NotImplementedError("enhance_mode %s is not supported" % enhance_mode)
+        intrinsics = (camera.generate_intrinsics(49.1, 49.1, fov=True, degree=True) if perspective
+                      else camera.generate_intrinsics(0.85, 0.85, fov=False, degree=False))
+        dev = self.device
+        vd = torch.as_tensor(np.asarray(verts), dtype=torch.float32, device=dev).contiguous()
+        fd = torch.as_tensor(np.asarray(faces), dtype=torch.int32, device=dev).contiguous()
+        uvd = torch.as_tensor(np.asarray(uvs), dtype=torch.float32, device=dev).contiguous()
+        # the stored texture image is top-down (row 0 = v = 1); the sampler wants rows growing with v
+        # (uint8 -> float on the host: an exact IEEE division, like the reference's image_to_tensor; torch's GPU
+        # division by a scalar multiplies by the reciprocal and differs in the last ulp)
+        texd = torch.from_numpy(np.ascontiguousarray(np.asarray(tex)[::-1, :, :3]).astype(np.float32) / np.float32(255.0)).to(dev).contiguous()
+        mvp = torch.matmul(camera.intr_to_proj(intrinsics, perspective=perspective), camera.c2w_to_w2c(c2ws)).to(dev).contiguous()
+        clip, _ = ops.transform_points(vd, mvp, want_ndc=False)
+        frames = []
+        for i in range(c2ws.shape[0]):
+            rast = ops.rasterize(clip[i].contiguous(), fd, render_size, render_size)
+            frames.append(ops.texture_shade(rast, uvd, fd, texd, bg=(1.0, 1.0, 1.0)).cpu().numpy())
+        os.makedirs(os.path.dirname(os.path.abspath(video_path)), exist_ok=True)
+        if ext == ".gif":
+            write_gif(video_path, frames, fps)
+        else:
+            write_mjpeg_mp4(video_path, frames, fps)
+        base = os.path.splitext(video_path)[0]
+        if save_frames:
+            os.makedirs(base + "_frames", exist_ok=True)
+            for i, fr in enumerate(frames):
+                Image.fromarray(fr).save(os.path.join(base + "_frames", "%04d.png" % i))
+        if save_cover:
+            Image.fromarray(frames[0]).save(base + "_cover.png")
+        if save_grid:
+            nc = int(math.floor(math.sqrt(len(frames)))); nr = int(math.ceil(len(frames) / nc))
+            pad = frames + [np.zeros_like(frames[0])] * (nc * nr - len(frames))
+            g = np.stack(pad).reshape(nr, nc, render_size, render_size, 3).transpose(0, 2, 1, 3, 4).reshape(nr * render_size, nc * render_size, 3)
+            Image.fromarray(g).save(base + "_grid.png")
+        if save_camera:
+            torch.save({"c2ws": c2ws, "intrinsics": intrinsics, "perspective": perspective}, base + "_camera.pth")
+        return frames if return_frames else video_path
+
+
+def write_gif(path, frames, fps=15):
+    ims = [Image.fromarray(f) for f in frames]
+    ims[0].save(path, save_all=True, append_images=ims[1:], duration=int(round(1000.0 / fps)), loop=0)
+
+
+def _box(kind, payload):
+    return struct.pack(">I4s", 8 + len(payload), kind) + payload
+
+
+def _full(kind, version, flags, payload):
+    return _box(kind, struct.pack(">I", (version << 24) | flags) + payload)
+
+
+def write_mjpeg_mp4(path, frames, fps=15, quality=92):
+    """ISO base media file with one video track of JPEG samples (sample entry 'jpeg', one sample per chunk).
+    The image has no H.264 encoder (imageio / ffmpeg are absent); Motion-JPEG plays in ffmpeg, VLC and QuickTime."""
+    jpgs = []
+    for f in frames:
+        b = io.BytesIO()
+        Image.fromarray(f).save(b, format="JPEG", quality=quality)
+        jpgs.append(b.getvalue())
+    h, w = frames[0].shape[:2]
+    n = len(jpgs)
+    ftyp = _box(b"ftyp", b"isom" + struct.pack(">I", 512) + b"isomiso2mp41")
+    mdat_payload = b"".join(jpgs)
+    mdat = _box(b"mdat", mdat_payload)
+    first = len(ftyp) + 8
+    offsets, pos = [], first
+    for j in jpgs:
+        offsets.append(pos); pos += len(j)
+    ident = struct.pack(">9I", 0x10000, 0, 0, 0, 0x10000, 0, 0, 0, 0x40000000)
+    dur_ms = int(round(n * 1000.0 / fps))
+    mvhd = _full(b"mvhd", 0, 0, struct.pack(">IIII", 0, 0, 1000, dur_ms) + struct.pack(">IH", 0x10000, 0x100) + b"\x00" * 10 + ident +
+                 b"\x00" * 24 + struct.pack(">I", 2))
+    tkhd = _full(b"tkhd", 0, 3, struct.pack(">IIIII", 0, 0, 1, 0, dur_ms) + b"\x00" * 8 + struct.pack(">HHHH", 0, 0, 0, 0) + ident +
+                 struct.pack(">II", w << 16, h << 16))
+    mdhd = _full(b"mdhd", 0, 0, struct.pack(">IIII", 0, 0, int(fps), n) + struct.pack(">HH", 0x55C4, 0))
+    hdlr = _full(b"hdlr", 0, 0, struct.pack(">I4s", 0, b"vide") + b"\x00" * 12 + b"unitex_amd turntable\x00")
+    vmhd = _full(b"vmhd", 0, 1, b"\x00" * 8)
+    dinf = _box(b"dinf", _full(b"dref", 0, 0, struct.pack(">I", 1) + _full(b"url ", 0, 1, b"")))
+    entry = (b"\x00" * 6 + struct.pack(">H", 1) + b"\x00" * 16 + struct.pack(">HH", w, h) + struct.pack(">II", 0x480000, 0x480000) +
+             struct.pack(">I", 0) + struct.pack(">H", 1) + bytes([10]) + b"Photo-JPEG".ljust(31, b"\x00") + struct.pack(">Hh", 0x18, -1))
+    stsd = _full(b"stsd", 0, 0, struct.pack(">I", 1) + _box(b"jpeg", entry))
+    stts = _full(b"stts", 0, 0, struct.pack(">III", 1, n, 1))
+    stsc = _full(b"stsc", 0, 0, struct.pack(">IIII", 1, 1, 1, 1))
+    stsz = _full(b"stsz", 0, 0, struct.pack(">II", 0, n) + b"".join(struct.pack(">I", len(j)) for j in jpgs))
+    stco = _full(b"stco", 0, 0, struct.pack(">I", n) + b"".join(struct.pack(">I", o) for o in offsets))
+    stbl = _box(b"stbl", stsd + stts + stsc + stsz + stco)
+    minf = _box(b"minf", vmhd + dinf + stbl)
+    mdia = _box(b"mdia", mdhd + hdlr + minf)
+    moov = _box(b"moov", mvhd + _box(b"trak", tkhd + mdia))
+    with open(path, "wb") as f:
+        f.write(ftyp); f.write(mdat); f.write(moov)
+
+
+def read_mjpeg_mp4(path):
+    """inverse of write_mjpeg_mp4 (used by the tests): returns (fps, [jpeg bytes])."""
+    blob = open(path, "rb").read()
+
+    def find(buf, kinds, start=0, end=None):
+        end = len(buf) if end is None else end
+        pos = start
+        while pos < end:
+            size, kind = struct.unpack_from(">I4s", buf, pos)
+            if kind == kinds[0]:
+                if len(kinds) == 1:
+                    return pos + 8, pos + size
+                hdr = 8 + (8 if kind == b"stsd" else 0)
+                return find(buf, kinds[1:], pos + hdr, pos + size)
+            pos += size
+        raise KeyError(kinds)
+    a, _ = find(blob, [b"moov", b"trak", b"mdia", b"mdhd"])
+    fps = struct.unpack_from(">I", blob, a + 12)[0]
+    a, _ = find(blob, [b"moov", b"trak", b"mdia", b"minf", b"stbl", b"stsz"])
+    n = struct.unpack_from(">I", blob, a + 8)[0]
+    sizes = struct.unpack_from(">%dI" % n, blob, a + 12)
+    a, _ = find(blob, [b"moov", b"trak", b"mdia", b"minf", b"stbl", b"stco"])
+    offs = struct.unpack_from(">%dI" % n, blob, a + 8)
+    return fps, [blob[o:o + s] for o, s in zip(offs, sizes)]
