@@ -11,8 +11,10 @@ joint-strip semantics: one 1024x6144 strip -> 24576 noise + 24576 c
 (512^2 reference image) + 512 text tokens = 50688 tokens, 2454 TFLOP/step.
 `--workload ref512x6` is the reference's shipped operating point (512x3072 strip, S = 13824).
 
-N > 1: the joint-attention DiT does not shard by view -- ranks run independent replicas
+N > 1: the joint-attention DiT does not shard by view -- by default ranks run independent replicas
 (one mesh per GPU, no data-path collective): value = N * steps / max-over-ranks time, scaling "weak".
+`--parallelism ulysses` (opt-in) runs ONE job head-parallel over the N GPUs (unitex_amd/flux/ulysses.py: two
+all-to-alls per layer over RCCL/xGMI): value = steps / time, scaling "strong".
 
 Contract: python bench.py --gpus N --steps K --warmup W  -> rank 0 prints ONE JSON line.
 """
@@ -86,6 +88,9 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("UTX_WORKLOAD", "strip1024x6"), choices=sorted(WORKLOADS))
     ap.add_argument("--lora-rank", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--parallelism", default=os.environ.get("UTX_PARALLELISM", "replicas"), choices=["replicas", "ulysses"],
+                    help="N > 1: 'replicas' = N independent jobs (weak scaling, default); 'ulysses' = ONE job, head-parallel "
+                         "sequence parallelism with two all-to-alls per layer over RCCL (strong scaling)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -111,15 +116,22 @@ def main():
 
     shape = FluxShape()
     sd = SyntheticFluxStateDict(shape, seed=0, device=dev)
-    model = FluxDiT(sd, shape, device=dev)
+    ulysses = args.parallelism == "ulysses" and world > 1
+    model = FluxDiT(sd, shape, device=dev, sequence_parallel=ulysses)
     tex = synthetic_lora(sd, shape, rank=args.lora_rank, seed=1, device=dev)
     dlt = synthetic_lora(sd, shape, rank=args.lora_rank, seed=2, device=dev)
     model.set_lora([(tex, 1.0), (dlt, 0.0)])  # reference: weights_for_texture = [1, 0] (pipeline.py:110)
 
     # synthetic latents: seed 63 (run.py:5) + rank so replicas differ
-    g = torch.Generator(device=dev).manual_seed(63 + rank)
+    g = torch.Generator(device=dev).manual_seed(63 + (0 if ulysses else rank))
     lat = torch.randn(S_img, 64, generator=g, device=dev).to(torch.bfloat16)
     cond = lat[n_noise:].clone()
+    n_noise_sched = n_noise
+    if ulysses:   # this rank's contiguous slice of the image tokens; the scheduler step / re-pin are per token
+        i0, i1 = model.local_image_range(S_img)
+        cond = lat[max(i0, n_noise):i1].clone() if i1 > n_noise else None
+        n_noise_sched = min(max(n_noise - i0, 0), i1 - i0)
+        lat = lat[i0:i1].clone()
     HL, WL = h_px // 16, w_px // 16
     ids = [torch.zeros(HL, WL, 3), torch.zeros(HL, WL, 3), torch.zeros(dual_px // 16, dual_px // 16, 3)]
     offs = [(0, 0), (HL, 0), (HL, WL)]
@@ -139,7 +151,7 @@ def main():
         t_in = float((t_bf / 1000).to(torch.float32))
         model.attn_events = events
         v = model.forward(lat, t_in)
-        ops.sched_step(lat, v, sched.dsigma(i), n_noise_tokens=n_noise, cond=cond)
+        ops.sched_step(lat, v, sched.dsigma(i), n_noise_tokens=n_noise_sched, cond=cond)
 
     def barrier():
         if world > 1:
@@ -170,17 +182,17 @@ def main():
         fl, fl_attn = step_flops(S)
         attn_ms = [a.elapsed_time(b) for a, b in events]
         attn_avg_ms = sum(attn_ms) / max(len(attn_ms), 1)
-        attn_launch_flops = 4.0 * S * S * 128 * HEADS
+        attn_launch_flops = 4.0 * S * S * 128 * HEADS / (world if ulysses else 1)
         achieved = attn_launch_flops / (attn_avg_ms * 1e-3) / 1e12
-        value = world * args.steps / dt
+        value = (1 if ulysses else world) * args.steps / dt
         out = {
             "metric": "denoising-steps/sec", "value": value, "unit": "steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if ulysses else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": args.workload, "description": desc, "tokens": S, "text_tokens": S_txt,
                        "noise_tokens": n_noise, "control_tokens": n_ctrl, "dual_tokens": n_dual,
-                       "lora_rank": args.lora_rank, "guidance": 3.5, "parallelism": "replicas x%d" % world,
-                       "tflop_per_step": fl / 1e12, "achieved_tflops_per_gpu": fl / (dt / args.steps) / 1e12,
+                       "lora_rank": args.lora_rank, "guidance": 3.5, "parallelism": ("ulysses sp%d (one job, 2 all-to-alls / layer)" % world) if ulysses else "replicas x%d" % world,
+                       "tflop_per_step": fl / 1e12, "achieved_tflops_per_gpu": fl / (dt / args.steps) / 1e12 / (world if ulysses else 1),
                        "sec_per_mesh_texture_dit_only": 56.0 * dt / args.steps},
             "roofline": {"bound": "mfma", "kernel": "attn_fwd_kernel", "achieved": achieved, "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,

@@ -284,3 +284,38 @@ def test_tiny_dit_forward_matches_oracle(use_lora):
     if use_lora:
         base = dit_ref.flux_forward(sd, cfg, lat.float(), enc.float(), pooled.float(), 0.4375, 3.5, txt_ids, img_ids)
         assert (base - ref).abs().max().item() > 5 * err, "LoRA branch must matter in this test"
+
+
+def test_sequence_parallel_plan_world1_matches_plain_forward():
+    """the head-parallel (Ulysses) plan with a 1-rank group must reproduce the plain plan bit for bit (same kernels,
+    the exchange degenerates to layout copies); multi-rank exchange logic is covered on CPU (tests/test_multigpu_cpu.py)."""
+    import os
+    import torch.distributed as dist
+    from unitex_amd.flux.transformer import FluxDiT, FluxShape
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29800 + os.getpid() % 100))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+        created = True
+    try:
+        cfg = dit_ref.tiny_config(heads=2, double=1, single=2, joint_dim=64, pooled_dim=64)
+        sd = dit_ref.make_synthetic_state_dict(cfg, seed=3)
+        shape = FluxShape(num_heads=2, num_double=1, num_single=2, joint_dim=64, pooled_dim=64)
+        S_txt, S_img = 64, 192
+        g = torch.Generator().manual_seed(5)
+        lat = torch.randn(S_img, 64, generator=g).to(BF).cuda()
+        enc = (0.5 * torch.randn(S_txt, 64, generator=g)).to(BF).cuda()
+        pooled = (0.5 * torch.randn(1, 64, generator=g)).to(BF).cuda()
+        txt_ids, img_ids = torch.zeros(S_txt, 3), dit_ref.latent_image_ids(8, 24)
+        outs = []
+        for sp in (False, True):
+            m = FluxDiT(sd, shape, device="cuda:0", sequence_parallel=sp)
+            m.set_positions(txt_ids, img_ids)
+            m.set_conditioning(enc, pooled, 3.5)
+            outs.append(m.forward(lat, 0.5).clone())
+            torch.cuda.synchronize()
+        assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+    finally:
+        if created:
+            dist.destroy_process_group()

@@ -50,3 +50,46 @@ def test_view_sharded_layers_allgather(world):
     assert all(ok for _, ok, _ in res), res
     covered = sorted(rg for _, _, rg in res)
     assert covered[0][0] == 0 and covered[-1][1] == 6
+
+
+def _ulysses_worker(rank, world, port, q):
+    """sequence-parallel attention exchange (product comm code, oracle compute): token-sharded q/k/v -> all-to-all ->
+    each rank attends with H/P heads over the FULL sequence -> all-to-all back; must equal unsharded attention."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import dit_ref
+    from unitex_amd.flux.ulysses import UlyssesExchange, local_slice
+    H, S_txt, S_img = 12, 64 * world, 128 * world
+    g = torch.Generator().manual_seed(3)                     # same data on every rank
+    S = S_txt + S_img
+    qf, kf, vf = (torch.randn(H, S, 128, generator=g) for _ in range(3))
+    t0, t1 = local_slice(S_txt, rank, world)
+    i0, i1 = local_slice(S_img, rank, world)
+    own = torch.cat([torch.arange(t0, t1), S_txt + torch.arange(i0, i1)])          # this rank's tokens: [txt_loc | img_loc]
+    ex = UlyssesExchange(H, own.numel(), device="cpu", dtype=torch.float32)
+    q_h, k_h, vt_h = ex.heads_in(qf[:, own].contiguous(), kf[:, own].contiguous(), vf[:, own].transpose(1, 2).contiguous())
+    o = dit_ref.sdpa(q_h, k_h, vt_h.transpose(1, 2), em=False)                     # [H/P, S, 128], rows = (src rank, local token)
+    ex.o.copy_(o.permute(1, 0, 2).reshape(S, -1))
+    out = torch.empty(own.numel(), 5 * H * 128)[:, : H * 128]                      # strided rows, like the single-block cat buffer
+    ex.tokens_out(out)
+    ref = dit_ref.sdpa(qf, kf, vf, em=False)[:, own].permute(1, 0, 2).reshape(own.numel(), -1)
+    err = (out - ref).abs().max().item()
+    q.put((rank, err < 1e-5, err))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_ulysses_exchange_matches_unsharded_attention(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + world + (os.getpid() % 200)
+    procs = [ctx.Process(target=_ulysses_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res

@@ -74,8 +74,16 @@ def _bf16_scalar(x: float) -> float:
 
 
 class FluxDiT:
-    def __init__(self, state_dict: Dict[str, torch.Tensor], shape: Optional[FluxShape] = None, device="cuda:0"):
+    def __init__(self, state_dict: Dict[str, torch.Tensor], shape: Optional[FluxShape] = None, device="cuda:0",
+                 sequence_parallel=False, sp_group=None):
+        """sequence_parallel: head-parallel ("Ulysses") sharding of ONE job over the ranks of `sp_group` (ulysses.py):
+        set_positions / set_conditioning still take the FULL id / embedding tensors, forward() takes and returns this
+        rank's slice of the image tokens (local_image_range)."""
         self.shape = shape or FluxShape()
+        self.sp = None
+        if sequence_parallel:
+            import torch.distributed as dist
+            self.sp = (dist.get_rank(sp_group), dist.get_world_size(sp_group), sp_group) if dist.is_initialized() else (0, 1, None)
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("FluxDiT runs on an MI355X only (device must be cuda:N); there is no CPU path")
@@ -276,6 +284,9 @@ class FluxDiT:
         plan.append((self.lib.utx_qkv_post, d))
 
     def _attn(self, plan, ws, out, S):
+        if self.sp is not None:
+            plan.append(("sp_attn", out[:, : self.shape.dim]))      # all-to-all in, attention over H/P heads x full sequence, all-to-all out
+            return
         sh = self.shape
         Qh, Kh, Vt = ws["Qh"], ws["Kh"], ws["Vt"]
         args = (ptr(Qh), ptr(Kh), ptr(Vt), ptr(out), Qh.stride(0), Qh.stride(1), Kh.stride(0), Kh.stride(1),
@@ -308,6 +319,11 @@ class FluxDiT:
         }
         if Rp:
             ws["T"] = z(S, 3 * Rp)
+        if self.sp is not None:
+            from .ulysses import UlyssesExchange
+            if S_pad != S:
+                raise ValueError("sequence parallel: the local token count %d must be a multiple of 64" % S)
+            self.ex = UlyssesExchange(H, S, group=self.sp[2], device=dev, dtype=BF16)
         T = ws.get("T")
         W, mod = self.W, ws["mod"][0]
         h, xn, qkv, cat, attn = ws["h"], ws["xn"], ws["qkv"], ws["cat"], ws["attn"]
@@ -382,8 +398,20 @@ class FluxDiT:
         return self._plans[key]
 
     # ------------------------------------------------------------------ forward
+    def local_text_range(self, S_txt):
+        from .ulysses import local_slice
+        return (0, S_txt) if self.sp is None else local_slice(S_txt, self.sp[0], self.sp[1])
+
+    def local_image_range(self, S_img):
+        from .ulysses import local_slice
+        return (0, S_img) if self.sp is None else local_slice(S_img, self.sp[0], self.sp[1])
+
     def set_positions(self, txt_ids, img_ids):
         """Upload the rotary tables for ids = cat(txt_ids, img_ids) (once per pipeline call)."""
+        if self.sp is not None:
+            t0, t1 = self.local_text_range(txt_ids.shape[0])
+            i0, i1 = self.local_image_range(img_ids.shape[0])
+            txt_ids, img_ids = txt_ids[t0:t1], img_ids[i0:i1]
         p = self._get_plan(txt_ids.shape[0], img_ids.shape[0])
         cos, sin = rope_tables(torch.cat([txt_ids.cpu().float(), img_ids.cpu().float()], dim=0),
                                self.shape.axes_dim, self.shape.theta)
@@ -394,8 +422,9 @@ class FluxDiT:
         S_txt = encoder_hidden_states.shape[-2]
         p = next(iter(self._plans.values()))
         ws = p["ws"]
-        assert S_txt == p["S_txt"]
-        ws["enc"].copy_(encoder_hidden_states.reshape(S_txt, -1).to(BF16))
+        t0, t1 = self.local_text_range(S_txt)
+        assert t1 - t0 == p["S_txt"]
+        ws["enc"].copy_(encoder_hidden_states.reshape(S_txt, -1)[t0:t1].to(BF16))
         ws["pooled"].copy_(pooled_projections.reshape(1, -1).to(BF16))
         g1000 = _bf16_scalar(_bf16_scalar(guidance) * 1000.0)  # guidance.to(dtype) * 1000 in bf16 [3p]
         ws["gproj"].copy_(_timestep_proj(g1000))
@@ -410,6 +439,22 @@ class FluxDiT:
                 if self.shape.guidance_embeds:
                     t = t + ws["e_g"]
                 torch.add(t, ws["e_p"], out=ws["temb"])
+            elif fn == "sp_attn":
+                ex = self.ex
+                q, k, vt = ex.heads_in(ws["Qh"], ws["Kh"], ws["Vt"])
+                ev = getattr(self, "attn_events", None)
+                if ev is not None:
+                    a = torch.cuda.Event(enable_timing=True)
+                    b = torch.cuda.Event(enable_timing=True)
+                    a.record()
+                rc = lib.utx_attn_fwd_bf16(h, ptr(q), ptr(k), ptr(vt), ptr(ex.o), q.stride(0), q.stride(1), k.stride(0), k.stride(1),
+                                           vt.stride(0), vt.stride(1), ex.o.stride(0), ex.Hp, ex.S, 0.0, st)
+                if ev is not None:
+                    b.record()
+                    ev.append((a, b))
+                if rc:
+                    self.ctx.check(rc)
+                ex.tokens_out(d)
             elif fn is lib.utx_attn_fwd_bf16:
                 ev = getattr(self, "attn_events", None)
                 if ev is not None:  # bench.py: HIP events on the launch stream around the dominant kernel
