@@ -126,3 +126,42 @@ def test_gemm_full_size_kernels_agree_bitwise_and_match_oracle_rows(M):
     yy = (res[rows].float().cpu() + (gate.float().cpu() * yy).to(BF).float()).to(BF).float()
     rel = ((o["256"][rows].float().cpu() - yy).abs() / yy.abs().clamp_min(1.0)).max().item()
     assert rel < 1.6e-2, "gated residual vs oracle rows: %g" % rel
+
+
+def test_full_width_dit_blocks_at_config1_shape_match_oracle():
+    """BASELINE.json configs[0] shape (512^2 x 4 views: 4096 noise + 4096 control + 1024 dual + 512 text = 9728 tokens) at
+    the real FLUX width (D = 3072, 24 heads, joint_dim 4096, rank-64 LoRA), depth cut to 1 double + 1 single block so
+    the fp32 CPU oracle finishes in seconds.  This is the shape at which every large-M kernel choice (8-phase GEMM,
+    fused LoRA K-segment, split / GELU / gated epilogues, 24-head attention) is the production one."""
+    from unitex_amd.flux.transformer import FluxDiT, FluxShape
+    cfg = dit_ref.FluxConfig(num_double=1, num_single=1)
+    sd = dit_ref.make_synthetic_state_dict(cfg, seed=0)
+    shape = FluxShape(num_double=1, num_single=1)
+    S_txt = 512
+    ids = [dit_ref.latent_image_ids(32, 128), dit_ref.latent_image_ids(32, 128, offset_y=32),
+           dit_ref.latent_image_ids(32, 32, offset_x=128, offset_y=32)]
+    img_ids = torch.cat(ids, 0)
+    S_img = img_ids.shape[0]
+    assert S_txt + S_img == 9728
+    g = torch.Generator().manual_seed(63)
+    lat = torch.randn(S_img, 64, generator=g).to(BF)
+    enc = torch.zeros(S_txt, cfg.joint_dim).to(BF)              # the reference feeds zero prompt embeddings
+    pooled = torch.zeros(1, cfg.pooled_dim).to(BF)
+    txt_ids = torch.zeros(S_txt, 3)
+    la = dit_ref.make_synthetic_lora(cfg, sd, rank=64, seed=2)
+    lb = dit_ref.make_synthetic_lora(cfg, sd, rank=64, seed=3)
+    loras = [(la, 1.0), (lb, 0.0)]
+    m = FluxDiT(sd, shape, device="cuda:0")
+    m.set_lora(loras)
+    m.set_positions(txt_ids, img_ids)
+    m.set_conditioning(enc.cuda(), pooled.cuda(), 3.5)
+    out = m.forward(lat.cuda(), 0.4375).float().cpu()
+    torch.cuda.synchronize()
+    torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 64)))
+    ref = dit_ref.flux_forward(sd, cfg, lat.float(), enc.float(), pooled.float(), 0.4375, 3.5, txt_ids, img_ids,
+                               loras=loras, emulate_bf16=True)
+    err = (out - ref).abs().max().item()
+    mx = ref.abs().max().item()
+    assert torch.isfinite(out).all()
+    assert err < 0.03 * max(mx, 1.0), "full-width DiT blocks: err %g (ref max %g)" % (err, mx)
+    assert (out - ref).abs().mean().item() < 0.004 * max(mx, 1.0)
