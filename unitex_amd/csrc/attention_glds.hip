@@ -1,0 +1,245 @@
+// bf16 MFMA flash-attention forward, LDS-DMA staged variant (gfx950).  Same contract, maths and block-pipelined
+// sum-checked softmax as attn_fwd_kernel<8, PRESC, 2> in attention.hip (see the header there); what differs is how the
+// K / Vt tiles reach LDS:
+//   attention.hip      global_load -> 8 staging VGPRs x 4 -> ds_write_b128 (padded rows, immediate fragment offsets)
+//   this file          global_load_lds (16 B / lane, no VGPRs, no ds_write): the LDS image of a wave-instruction is
+//                      lane-linear (1 KB = 4 K rows or 8 Vt rows), so rows cannot be padded; bank conflicts are
+//                      removed by an XOR swizzle applied on the SOURCE address (which 16-byte chunk a lane fetches)
+//                      and on the fragment read address:
+//                          K  tile [64 keys][256 B] : slot = chunk ^ (row & 15)
+//                          Vt tile [128 d ][128 B]  : slot = chunk ^ ((row >> 1) & 7)
+//                      both conflict-free for the ds_read_b128 lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31}.
+// Why: round-1 ablation (profiles/r01_perf_attn_ablation.log) charges 2.9 of 27.8 ms per launch at S = 50 688 to the
+// register staging (a ds_write_b128 costs ~13 LDS cycles per wave-instruction, 4 per lane and tile) -- the kernel is
+// power/clock limited, so fewer instructions and less register traffic per tile is the lever that is left.
+// Ring: K and Vt 2-deep (64 KB); tile t+1 is requested at the top of tile t into the slot last read in tile t-1 (free
+// since the barrier that ended it) and retired by the vmcnt(0) that __syncthreads() carries while a DMA is in flight.
+#include "common.h"
+#include "kernels.h"
+#include <stdlib.h>
+
+#define AG_KVB 64
+#define AG_KTILE 16384
+#define AG_VTILE 16384
+#define AG_LDS (2 * AG_KTILE + 2 * AG_VTILE)
+
+__device__ __forceinline__ void ag_glds16(const bf16_t* g, char* lds) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+
+template <int PRESC>
+__global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const kring = smem;
+    char* const vring = smem + 2 * AG_KTILE;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lq = lane & 31, lh = lane >> 5;
+
+    const int w = xcd_remap(blockIdx.x, gridDim.x);
+    const int head = w / p.nqb;
+    const int qb = w - head * p.nqb;
+    const int S = p.S;
+    const bf16_t* kbase = p.k + (long)head * p.k_hs;
+    const bf16_t* vbase = p.vt + (long)head * p.vt_hs;
+
+    const int q0 = qb * 256 + wave * 32;
+    bf16x8 qf[8];
+    {
+        int qrow = q0 + lq;
+        if (qrow > S - 1) qrow = S - 1;
+        const bf16_t* qp = p.q + (long)head * p.q_hs + (long)qrow * p.q_ss + lh * 8;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(qp + kk * 16);
+    }
+
+    // ---- DMA sources: wave-instruction (wave, j) fills LDS bytes [(2*wave + j) * 1024, +1024) of a tile
+    //   K : slot s = (2*wave+j)*64 + lane -> row s>>4, LDS chunk s&15 <- global chunk (s&15) ^ (row&15)
+    //   Vt: slot s                        -> row s>>3, LDS chunk s&7  <- global chunk (s&7) ^ ((row>>1)&7)
+    const int ks0 = (2 * wave) * 64 + lane, ks1 = ks0 + 64;
+    const int kr0 = ks0 >> 4, kr1 = ks1 >> 4;
+    const bf16_t* ksrc0 = kbase + (long)kr0 * p.k_ss + (((ks0 & 15) ^ (kr0 & 15)) << 3);
+    const bf16_t* ksrc1 = kbase + (long)kr1 * p.k_ss + (((ks1 & 15) ^ (kr1 & 15)) << 3);
+    const int vr0 = ks0 >> 3, vr1 = ks1 >> 3;
+    const bf16_t* vsrc0 = vbase + (long)vr0 * p.vt_ds + (((ks0 & 7) ^ ((vr0 >> 1) & 7)) << 3);
+    const bf16_t* vsrc1 = vbase + (long)vr1 * p.vt_ds + (((ks1 & 7) ^ ((vr1 >> 1) & 7)) << 3);
+    const int dma_off = (2 * wave) * 1024;
+#define AG_STAGE(t_, slot_)                                                                      \
+    do {                                                                                         \
+        const long kadv_ = (long)(t_) * AG_KVB * p.k_ss;                                         \
+        const int vadv_ = (t_) * AG_KVB;                                                         \
+        ag_glds16(ksrc0 + kadv_, kring + (slot_) * AG_KTILE + dma_off);                          \
+        ag_glds16(ksrc1 + kadv_, kring + (slot_) * AG_KTILE + dma_off + 1024);                   \
+        ag_glds16(vsrc0 + vadv_, vring + (slot_) * AG_VTILE + dma_off);                          \
+        ag_glds16(vsrc1 + vadv_, vring + (slot_) * AG_VTILE + dma_off + 1024);                   \
+    } while (0)
+
+    // ---- fragment read offsets.  kappa: MFMA row i = 8a + 4h' + c -> key 16(a>>1) + 8h' + 4(a&1) + c (attention.hip)
+    const int ka = lq >> 3, khp = (lq >> 2) & 1, kc = lq & 3;
+    const int krow = 16 * (ka >> 1) + 8 * khp + 4 * (ka & 1) + kc;
+    const int kswz = krow & 15, vswz = (lq >> 1) & 7;
+    int kx[8], vx[4];     // byte offset of (row, chunk 2kk+lh) / (row, chunk 2s+lh) inside a tile
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) kx[kk] = krow * 256 + (((2 * kk + lh) ^ kswz) << 4);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) vx[s] = lq * 128 + (((2 * s + lh) ^ vswz) << 4);
+
+    f32x16 oacc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+    float m_run = 0.f, l_run = 0.f;
+    const float c2 = p.scale_log2;
+    bf16x8 pb[4];
+    f32x16 negm;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) negm[r] = 0.f;
+
+    const int nt = (S + AG_KVB - 1) / AG_KVB;
+    AG_STAGE(0, 0);
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) asm volatile("" : "+v"(qf[kk]));
+
+    for (int t = 0; t < nt; ++t) {
+        const int slot = t & 1;
+        if (t + 1 < nt) AG_STAGE(t + 1, slot ^ 1);
+        const char* kb = kring + slot * AG_KTILE;
+        const char* vb = vring + slot * AG_VTILE;
+        const bool ragged = (t == nt - 1) && (S & (AG_KVB - 1));
+        const int lim = S - t * AG_KVB - 8 * lh;
+
+        f32x16 sa0, sa1;
+        bf16x8 kfa[8], kfb[8], vfa[8], vfb[8];
+#define AG_EXPB(sa_, p0_, p1_, ps_)                                                                  \
+        {                                                                                            \
+            f32x2 acc2_ = {0.f, 0.f};                                                                \
+            _Pragma("unroll") for (int r = 0; r < 16; r += 2) {                                      \
+                f32x2 pv_;                                                                           \
+                pv_[0] = __builtin_amdgcn_exp2f(PRESC ? sa_[r] : sa_[r] * c2);                       \
+                pv_[1] = __builtin_amdgcn_exp2f(PRESC ? sa_[r + 1] : sa_[r + 1] * c2);               \
+                acc2_ += pv_;                                                                        \
+                if (r < 8) { p0_[r] = (__bf16)pv_[0]; p0_[r + 1] = (__bf16)pv_[1]; }                 \
+                else { p1_[r - 8] = (__bf16)pv_[0]; p1_[r - 7] = (__bf16)pv_[1]; }                   \
+            }                                                                                        \
+            ps_ = acc2_[0] + acc2_[1];                                                               \
+        }
+#define AG_SLOW(sa_, other_, fix_other_, kblk_, boff_, first_)                                       \
+        {                                                                                            \
+            _Pragma("unroll") for (int kk = 0; kk < 8; ++kk) {                                       \
+                const bf16x8 kf_ = *reinterpret_cast<const bf16x8*>(kb + (kblk_) + kx[kk]);          \
+                sa_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf_, qf[kk], kk == 0 ? negm : sa_, 0, 0, 0); \
+            }                                                                                        \
+            if (ragged) {                                                                            \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r)                                       \
+                    if ((boff_) + 16 * (r >> 3) + (r & 7) >= lim) sa_[r] = -INFINITY;                \
+            }                                                                                        \
+            float mx_ = sa_[0];                                                                      \
+            _Pragma("unroll") for (int r = 1; r < 16; ++r) mx_ = fmaxf(mx_, sa_[r]);                 \
+            mx_ = fmaxf(mx_, __shfl_xor(mx_, 32, 64));                                               \
+            const float d_ = (first_) ? mx_ : fmaxf(mx_, 0.f);                                       \
+            const float alpha_ = (first_) ? 1.0f : __builtin_amdgcn_exp2f(PRESC ? -d_ : -d_ * c2);   \
+            m_run += d_;                                                                             \
+            l_run *= alpha_;                                                                         \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) { negm[r] = -m_run; sa_[r] -= d_; }       \
+            if (fix_other_) { _Pragma("unroll") for (int r = 0; r < 16; ++r) other_[r] -= d_; }      \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                            \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha_;                 \
+        }
+        float ps0 = 0.f, ps1 = 0.f;
+        // S0: QK(0); block-1 K fragments stream in behind the MFMAs
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) kfa[kk] = *reinterpret_cast<const bf16x8*>(kb + kx[kk]);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            kfb[kk] = *reinterpret_cast<const bf16x8*>(kb + 8192 + kx[kk]);
+            sa0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfa[kk], qf[kk], kk == 0 ? negm : sa0, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+        for (int i_ = 0; i_ < 8; ++i_) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        // S1: QK(1) || exp(0); V fragments of block 0 (key chunks s = 0, 1) stream in
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            vfa[kk] = *reinterpret_cast<const bf16x8*>(vb + (kk & 3) * 4096 + vx[kk >> 2]);
+            sa1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfb[kk], qf[kk], kk == 0 ? negm : sa1, 0, 0, 0);
+        }
+        AG_EXPB(sa0, pb[0], pb[1], ps0)
+#pragma unroll
+        for (int i_ = 0; i_ < 8; ++i_) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+            __builtin_amdgcn_sched_group_barrier(0x402, 4, 1);
+        }
+        if (t == 0 || ragged || !__all(ps0 <= 8192.0f)) {
+            AG_SLOW(sa0, sa1, true, 0, 0, t == 0)
+            AG_EXPB(sa0, pb[0], pb[1], ps0)
+        }
+        l_run += ps0;
+        // S2: PV(0) || exp(1); V fragments of block 1 (s = 2, 3) stream in
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            vfb[i] = *reinterpret_cast<const bf16x8*>(vb + (i & 3) * 4096 + vx[2 + (i >> 2)]);
+            oacc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfa[i], pb[i >> 2], oacc[i & 3], 0, 0, 0);
+        }
+        AG_EXPB(sa1, pb[2], pb[3], ps1)
+#pragma unroll
+        for (int i_ = 0; i_ < 8; ++i_) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 2);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 2);
+            __builtin_amdgcn_sched_group_barrier(0x402, 4, 2);
+        }
+        if (ragged || !__all(ps1 <= 8192.0f)) {
+            AG_SLOW(sa1, sa0, false, 8192, 32, false)
+            AG_EXPB(sa1, pb[2], pb[3], ps1)
+        }
+        l_run += ps1;
+        // S3: PV(1)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            oacc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfb[i], pb[2 + (i >> 2)], oacc[i & 3], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __syncthreads();     // tile t fully read by every wave; tile t+1 (DMA) retired by the vmcnt(0) of this fence
+    }
+
+    // ---- epilogue: lane (q, h) holds O[q][32db + 8a + 4h + c], r = 4a + c
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int qrow = q0 + lq;
+    if (qrow < S) {
+        bf16_t* op = p.o + (long)qrow * p.o_ss + head * 128 + 4 * lh;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                uint2 v;
+                v.x = pack2bf(oacc[db][4 * a + 0] * inv, oacc[db][4 * a + 1] * inv);
+                v.y = pack2bf(oacc[db][4 * a + 2] * inv, oacc[db][4 * a + 3] * inv);
+                *reinterpret_cast<uint2*>(op + 32 * db + 8 * a) = v;
+            }
+    }
+}
+
+template <int PRESC>
+static int launch_glds(AttnParams p, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_glds_kernel<PRESC>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, AG_LDS) != hipSuccess) return -3;
+        attr_set = true;
+    }
+    p.nqb = (p.S + 255) / 256;
+    hipLaunchKernelGGL((attn_fwd_glds_kernel<PRESC>), dim3(p.nqb * p.H), dim3(512), AG_LDS, stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+extern "C" int utx_launch_attn_fwd_glds(const AttnParams* p, int presc, hipStream_t stream) {
+    return presc ? launch_glds<1>(*p, stream) : launch_glds<0>(*p, stream);
+}

@@ -18,6 +18,7 @@ ARCH = "gfx950"
 # (source, extra flags)
 SOURCES = [
     ("attention.hip", []),
+    ("attention_glds.hip", []),
     ("gemm.hip", []),
     ("dit_elementwise.hip", ["-ffp-contract=off"]),
     ("vae.hip", []),
