@@ -21,18 +21,18 @@
 #define AG_KVB 64
 #define AG_KTILE 16384
 #define AG_VTILE 16384
-#define AG_LDS (2 * AG_KTILE + 2 * AG_VTILE)
+#define AG_LDS(tpb) ((tpb) * 2 * (AG_KTILE + AG_VTILE))
 
 __device__ __forceinline__ void ag_glds16(const bf16_t* g, char* lds) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
 }
 
-template <int PRESC>
+template <int PRESC, int TPB>
 __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const kring = smem;
-    char* const vring = smem + 2 * AG_KTILE;
+    char* const vring = smem + 2 * TPB * AG_KTILE;    // ring: 2 groups of TPB tiles, one barrier per group
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -99,16 +99,24 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
     for (int r = 0; r < 16; ++r) negm[r] = 0.f;
 
     const int nt = (S + AG_KVB - 1) / AG_KVB;
-    AG_STAGE(0, 0);
+    const int ngrp = (nt + TPB - 1) / TPB;
+#pragma unroll
+    for (int i = 0; i < TPB; ++i)
+        if (i < nt) AG_STAGE(i, i);
     __syncthreads();
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) asm volatile("" : "+v"(qf[kk]));
 
-    for (int t = 0; t < nt; ++t) {
-        const int slot = t & 1;
-        if (t + 1 < nt) AG_STAGE(t + 1, slot ^ 1);
-        const char* kb = kring + slot * AG_KTILE;
-        const char* vb = vring + slot * AG_VTILE;
+    for (int u = 0; u < ngrp; ++u) {
+      const int gs = (u & 1) * TPB;                      // first ring slot of this group
+#pragma unroll
+      for (int i = 0; i < TPB; ++i)
+          if ((u + 1) * TPB + i < nt) AG_STAGE((u + 1) * TPB + i, (gs ^ TPB) + i);
+      for (int sub = 0; sub < TPB; ++sub) {
+        const int t = u * TPB + sub;
+        if (t >= nt) break;
+        const char* kb = kring + (gs + sub) * AG_KTILE;
+        const char* vb = vring + (gs + sub) * AG_VTILE;
         const bool ragged = (t == nt - 1) && (S & (AG_KVB - 1));
         const int lim = S - t * AG_KVB - 8 * lh;
 
@@ -206,7 +214,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
         for (int i = 0; i < 8; ++i)
             oacc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfb[i], pb[2 + (i >> 2)], oacc[i & 3], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
-        __syncthreads();     // tile t fully read by every wave; tile t+1 (DMA) retired by the vmcnt(0) of this fence
+      }
+      __syncthreads();     // this group fully read by every wave; the next group (DMA) retired by the vmcnt(0) of this fence
     }
 
     // ---- epilogue: lane (q, h) holds O[q][32db + 8a + 4h + c], r = 4a + c
@@ -227,19 +236,23 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
     }
 }
 
-template <int PRESC>
+template <int PRESC, int TPB>
 static int launch_glds(AttnParams p, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_glds_kernel<PRESC>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, AG_LDS) != hipSuccess) return -3;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_glds_kernel<PRESC, TPB>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, AG_LDS(TPB)) != hipSuccess) return -3;
         attr_set = true;
     }
     p.nqb = (p.S + 255) / 256;
-    hipLaunchKernelGGL((attn_fwd_glds_kernel<PRESC>), dim3(p.nqb * p.H), dim3(512), AG_LDS, stream, p);
+    hipLaunchKernelGGL((attn_fwd_glds_kernel<PRESC, TPB>), dim3(p.nqb * p.H), dim3(512), AG_LDS(TPB), stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
+// UTX_ATTN_TPB: tiles per barrier (ring = 2 groups of TPB tiles): 1 -> 64 KB LDS, 2 -> 128 KB
 extern "C" int utx_launch_attn_fwd_glds(const AttnParams* p, int presc, hipStream_t stream) {
-    return presc ? launch_glds<1>(*p, stream) : launch_glds<0>(*p, stream);
+    const char* e = getenv("UTX_ATTN_TPB");
+    const int tpb = e ? atoi(e) : 1;
+    if (tpb == 2) return presc ? launch_glds<1, 2>(*p, stream) : launch_glds<0, 2>(*p, stream);
+    return presc ? launch_glds<1, 1>(*p, stream) : launch_glds<0, 1>(*p, stream);
 }
