@@ -28,7 +28,7 @@ __device__ __forceinline__ void ag_glds16(const bf16_t* g, char* lds) {
                                      (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
 }
 
-template <int PRESC, int TPB>
+template <int PRESC, int TPB, int VAR>
 __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const kring = smem;
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
         // S0: QK(0); block-1 K fragments stream in behind the MFMAs
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) kfa[kk] = *reinterpret_cast<const bf16x8*>(kb + kx[kk]);
-        __builtin_amdgcn_s_setprio(1);
+        if (VAR != 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
             kfb[kk] = *reinterpret_cast<const bf16x8*>(kb + 8192 + kx[kk]);
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
         }
         AG_EXPB(sa0, pb[0], pb[1], ps0)
 #pragma unroll
-        for (int i_ = 0; i_ < 8; ++i_) {
+        for (int i_ = 0; i_ < (VAR == 2 ? 0 : 8); ++i_) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
             __builtin_amdgcn_sched_group_barrier(0x402, 4, 1);
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
         }
         AG_EXPB(sa1, pb[2], pb[3], ps1)
 #pragma unroll
-        for (int i_ = 0; i_ < 8; ++i_) {
+        for (int i_ = 0; i_ < (VAR == 2 ? 0 : 8); ++i_) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 2);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 2);
             __builtin_amdgcn_sched_group_barrier(0x402, 4, 2);
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
             oacc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfb[i], pb[2 + (i >> 2)], oacc[i & 3], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+        if (VAR != 1) __builtin_amdgcn_s_setprio(0);
       }
       __syncthreads();     // this group fully read by every wave; the next group (DMA) retired by the vmcnt(0) of this fence
     }
@@ -236,16 +236,16 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
     }
 }
 
-template <int PRESC, int TPB>
+template <int PRESC, int TPB, int VAR = 0>
 static int launch_glds(AttnParams p, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_glds_kernel<PRESC, TPB>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_glds_kernel<PRESC, TPB, VAR>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, AG_LDS(TPB)) != hipSuccess) return -3;
         attr_set = true;
     }
     p.nqb = (p.S + 255) / 256;
-    hipLaunchKernelGGL((attn_fwd_glds_kernel<PRESC, TPB>), dim3(p.nqb * p.H), dim3(512), AG_LDS(TPB), stream, p);
+    hipLaunchKernelGGL((attn_fwd_glds_kernel<PRESC, TPB, VAR>), dim3(p.nqb * p.H), dim3(512), AG_LDS(TPB), stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
@@ -254,5 +254,8 @@ extern "C" int utx_launch_attn_fwd_glds(const AttnParams* p, int presc, hipStrea
     const char* e = getenv("UTX_ATTN_TPB");
     const int tpb = e ? atoi(e) : 1;
     if (tpb == 2) return presc ? launch_glds<1, 2>(*p, stream) : launch_glds<0, 2>(*p, stream);
+    { const char* v = getenv("UTX_ATTN_VAR"); const int var = v ? atoi(v) : 0;   // A/B only: 1 = no s_setprio, 2 = no interleave hints
+      if (var == 1 && presc) return launch_glds<1, 1, 1>(*p, stream);
+      if (var == 2 && presc) return launch_glds<1, 1, 2>(*p, stream); }
     return presc ? launch_glds<1, 1>(*p, stream) : launch_glds<0, 1>(*p, stream);
 }
