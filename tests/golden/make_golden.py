@@ -535,13 +535,48 @@ def g67_backprojection(out):
     np.savez_compressed(os.path.join(out, "g67_backprojection.npz"), **fix)
 
 
+def g8_bunny(out):
+    """known-answer input of the reference's own LBVH test (raytracing/rt_aprmis/test2.py:33-41: bunny.obj, pinhole rays
+    from (0, 0.1, 0.3) towards (x, y, -1)); the reference stores no outputs, so the expected hit mask is an independent
+    float64 brute-force Moeller-Trumbore over all 69 451 faces on a 96 x 96 subsample of the 1024^2 ray grid."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from unitex_amd.texturetools.meshes import load_obj
+    v, f, _, _ = load_obj(os.path.join(REF, "TextureTools/texturetools/raytracing/rt_aprmis/bunny.obj"))
+    lin = torch.linspace(-1, 1, 1024)[torch.linspace(0, 1023, 96).round().long()]
+    y, x = torch.meshgrid([lin.flip(0), lin], indexing="ij")
+    d = torch.nn.functional.normalize(torch.stack([x, y, -torch.ones_like(x)], -1).reshape(-1, 3), dim=-1).numpy()
+    o = np.tile(np.array([[0.0, 0.1, 0.3]], np.float32), (d.shape[0], 1))
+    v0, e1, e2 = v[f[:, 0]].astype(np.float64), (v[f[:, 1]] - v[f[:, 0]]).astype(np.float64), (v[f[:, 2]] - v[f[:, 0]]).astype(np.float64)
+    hit = np.zeros(d.shape[0], bool)
+    margin = np.full(d.shape[0], np.inf)
+    for i in range(d.shape[0]):
+        dd, oo = d[i].astype(np.float64), o[i].astype(np.float64)
+        pv = np.cross(dd[None], e2)
+        det = (e1 * pv).sum(-1)
+        ok = np.abs(det) > 1e-300
+        inv = np.where(ok, 1.0 / np.where(ok, det, 1.0), 0.0)
+        tv = oo[None] - v0
+        u = (tv * pv).sum(-1) * inv
+        qv = np.cross(tv, e1)
+        vv = (dd[None] * qv).sum(-1) * inv
+        t = (e2 * qv).sum(-1) * inv
+        inside = ok & (u >= 0) & (vv >= 0) & (u + vv <= 1) & (t > 0)
+        hit[i] = inside.any()
+        near = ok & (t > 0)
+        m = np.minimum(np.minimum(np.abs(u), np.abs(vv)), np.abs(1 - u - vv))
+        band = near & (u > -1e-3) & (vv > -1e-3) & (u + vv < 1 + 1e-3)
+        margin[i] = m[band].min() if band.any() else np.inf
+    np.savez_compressed(os.path.join(out, "g8_bunny.npz"), verts=v, faces=f, rays_o=o, rays_d=d.astype(np.float32), hit=hit,
+                        edge_margin=margin.astype(np.float32))
+
+
 def main():
     sys.path.insert(0, REF)
     install_stubs()
     out = HERE
     torch.set_num_threads(4)
     only = set(sys.argv[1:])
-    for fn in (g1_pipeline, g2_attention, g3_infer_mv, g4_cameras, g5_image_ops, g67_backprojection):
+    for fn in (g1_pipeline, g2_attention, g3_infer_mv, g4_cameras, g5_image_ops, g67_backprojection, g8_bunny):
         if only and fn.__name__ not in only:
             continue
         fn(out)

@@ -221,3 +221,21 @@ def test_orbit_video_frames_bit_exact_and_mux(tmp_path):
     im = np.asarray(Image.open(io.BytesIO(jpgs[0])).convert("RGB")).astype(np.int32)
     assert np.abs(im - frames[0]).mean() < 20.0
     assert os.path.exists(os.path.splitext(path)[0] + "_cover.png")
+
+
+def test_bvh_on_reference_bunny_bit_exact():
+    """GPU LBVH build + trace on the reference's own test mesh / ray set (fixture G8) vs the oracle, bit for bit."""
+    ops = _ops()
+    f = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g8_bunny.npz"))
+    verts, faces, ro, rd = f["verts"], f["faces"], f["rays_o"], f["rays_d"]
+    ref = G.BVH(verts, faces)
+    b = ops.BVH(_cu(verts), _cu(faces))
+    info, aabb, codes, idx = b.arrays()
+    assert np.array_equal(codes.cpu().numpy().view(np.uint32), ref.codes)
+    assert np.array_equal(idx.cpu().numpy(), ref.order)
+    assert np.array_equal(info.cpu().numpy(), ref.info)
+    assert np.array_equal(aabb.cpu().numpy(), ref.aabb)
+    t = b.trace(_cu(ro), _cu(rd)).cpu().numpy()
+    assert np.array_equal(t, ref.trace(ro, rd))
+    clear = f["edge_margin"] > 1e-4
+    assert np.array_equal((t >= 0)[clear], f["hit"][clear])       # float64 brute-force mask stored with the fixture

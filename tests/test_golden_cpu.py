@@ -231,3 +231,26 @@ def test_g3_infer_mv_permutations_match_reference(tmp_path):
     assert np.array_equal(np.array(pipe.adapters, np.float32), f["adapters"])
     assert np.array_equal(np.asarray(Image.open(tmp_path / "mv_rgb.png")), f["mv_rgb"])
     assert np.array_equal(np.asarray(Image.open(tmp_path / "mv_rgb_w_light.png")), f["mv_rgb_w_light"])
+
+
+# ------------------------------------------------------------------------------------------------ G8
+def test_g8_lbvh_on_reference_bunny_vs_brute_force():
+    """the reference's own LBVH known-answer input (rt_aprmis/bunny.obj + the pinhole rays of test2.py:33-41).  The
+    reference stores no outputs, so the oracle's build + bug-compatible traversal is checked two independent ways:
+    (1) against its own all-faces loop (same float32 triangle test: isolates hierarchy / AABB / traversal errors, exact);
+    (2) against a float64 Moeller-Trumbore brute force computed when the fixture was made (independent arithmetic; rays
+    grazing a triangle edge within 1e-4 barycentric units are excluded)."""
+    f = _load("g8_bunny.npz")
+    verts, faces, ro, rd = f["verts"], f["faces"], f["rays_o"], f["rays_d"]
+    assert faces.shape == (69451, 3)
+    bvh = G.BVH(verts, faces)
+    # structural sanity of the LBVH: every leaf appears once, root box = mesh box
+    assert sorted(bvh.order.tolist()) == list(range(len(faces)))
+    assert np.allclose(bvh.aabb[0, :3], verts.min(0), atol=1e-6) and np.allclose(bvh.aabb[0, 3:], verts.max(0), atol=1e-6)
+    tid = bvh.trace(ro, rd)
+    bid, _ = bvh.brute(ro, rd)
+    assert np.array_equal(tid >= 0, bid >= 0), "LBVH traversal misses / invents hits vs the all-faces loop"
+    clear = f["edge_margin"] > 1e-4
+    assert clear.mean() > 0.99
+    assert np.array_equal((tid >= 0)[clear], f["hit"][clear]), "hit mask differs from the float64 brute force"
+    assert 0.03 < (tid >= 0).mean() < 0.07
