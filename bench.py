@@ -80,6 +80,37 @@ def cpu_baseline(S_full, threads):
             "measured_seconds": dt}
 
 
+def cpu_baseline_backprojection():
+    """oracle/geom_ref (single-threaded C + numpy) on a bounded sample of the back-projection: 20k-face mesh, six
+    256^2 views, 512^2 atlas (1/16 of the texels of the GPU measurement); scaled by texel count."""
+    import numpy as np
+    from oracle import geom_ref as G
+    from unitex_amd.texturetools import meshes
+    from unitex_amd.texturetools.benchmarks import smooth_views
+    T, HW = 512, 256
+    v, f, uv = meshes.sphere_with_faces(20000)
+    c2ws = G.box_views_c2ws(2.8)[[0, 1, 4, 2, 3, 5]]
+    mvp = G.mvp_matrices(c2ws, G.intrinsics(1.0, 1.0, fov=False), False)
+    t0 = time.perf_counter()
+    clip = G.transform_points(v, mvp)
+    vndc = (clip[..., :2] / clip[..., 3:4]).astype(np.float32)
+    alpha = np.stack([(G.rasterize(clip[i], f, HW, HW)[..., 3] > 0).astype(np.float32) for i in range(6)])
+    imgs = np.concatenate([smooth_views(6, HW, HW), alpha[..., None]], -1).astype(np.float32)
+    uvclip = np.concatenate([uv * 2 - 1, np.zeros((len(uv), 1), np.float32), np.ones((len(uv), 1), np.float32)], -1)
+    rast2d = G.rasterize(uvclip, f, T, T)
+    mask2d = rast2d[..., 3] > 0
+    bvh = G.BVH(v, f)
+    col, rv, ao = G.backproject(rast2d, v, f, G.face_normals(v, f), vndc, (-c2ws[:, :3, 2]).astype(np.float32), imgs, bvh, angle_deg=100.0)
+    vis = G.dilate_visibility(rv, mask2d, ao)
+    atlas, seen, win, bnd = G.composite(col, vis)
+    filled, _ = G.nn_fill(atlas, seen, mask2d, G.interpolate(v, rast2d, f))
+    blur = G.lens_blur_collapsed(filled, G.seam_mask(bnd, mask2d))
+    G.tensor_to_u8(G.pull_push(blur.transpose(2, 0, 1), mask2d).transpose(1, 2, 0))
+    dt = time.perf_counter() - t0
+    return {"seconds_sample": dt, "seconds_scaled_to_2048": dt * 16.0, "cores": 1, "kind": "port",
+            "sample": "oracle/geom_ref.c + numpy, 20k faces, 6 x 256^2 views, 512^2 atlas (x16 texels -> 2048^2)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -245,6 +276,10 @@ def main():
             try:
                 ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
                 out["cpu_baseline"] = cpu_baseline(S, max(1, min(ncpu, 64)))
+                try:
+                    out["cpu_baseline"]["backprojection"] = cpu_baseline_backprojection()
+                except Exception as e:
+                    out["cpu_baseline"]["backprojection"] = {"error": repr(e)}
             except Exception as e:  # the GPU number must still be reported
                 out["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": "failed: %r" % (e,)}
