@@ -328,8 +328,11 @@ def unwrap_grid(verts, faces, atlas=2048, gutter=4.0):
     n = int(np.ceil(np.sqrt(ncell)))
     cs = atlas / float(n)                         # cell size in texels
     g = gutter * 0.5
-    if cs < 3.0 * gutter:
-        raise ValueError("atlas %d too small for %d faces with gutter %.1f" % (atlas, F, gutter))
+    if cs < 4.0:
+        raise ValueError("atlas %d too small for %d faces (%.1f texels per cell)" % (atlas, F, cs))
+    if cs < 3.5 * gutter:          # dense meshes: shrink the gutter rather than fail (a 200k-face mesh has 6.5-texel cells at 2048^2)
+        gutter = cs / 3.5
+        g = gutter * 0.5
     fi = np.arange(F)
     cx, cy = (fi // 2) % n, (fi // 2) // n
     upper = (fi % 2) == 1
