@@ -82,3 +82,40 @@ def test_mjpeg_mp4_round_trip(tmp_path):
         assert im.shape == fr.shape and np.abs(im - fr).mean() < 12.0     # JPEG, smooth content
     video.write_gif(str(tmp_path / "t.gif"), frames, fps=15)
     assert Image.open(str(tmp_path / "t.gif")).n_frames == 7
+
+
+def test_lora_safetensors_reader_accepts_both_spellings(tmp_path):
+    """checkpoint boundary of the drop-in (reference pipeline.py:96-112 loads diffusers / peft LoRA files): module names
+    relative to the transformer, peft alpha / r scaling folded into B, '.lora_A/.lora_B' and '.lora.down/.lora.up'."""
+    from safetensors.torch import save_file
+    from unitex_amd.flux.lora_io import load_lora_safetensors
+    g = torch.Generator().manual_seed(0)
+    A = torch.randn(16, 64, generator=g); B = torch.randn(96, 16, generator=g)
+    A2 = torch.randn(8, 64, generator=g); B2 = torch.randn(64, 8, generator=g)
+    p1 = str(tmp_path / "a.safetensors")
+    save_file({"transformer.single_transformer_blocks.0.attn.to_q.lora_A.weight": A,
+               "transformer.single_transformer_blocks.0.attn.to_q.lora_B.weight": B,
+               "transformer.single_transformer_blocks.0.attn.to_q.alpha": torch.tensor(8.0),
+               "transformer_blocks.1.ff.net.2.lora.down.weight": A2,
+               "transformer_blocks.1.ff.net.2.lora.up.weight": B2}, p1)
+    d = load_lora_safetensors(p1)
+    assert set(d) == {"single_transformer_blocks.0.attn.to_q", "transformer_blocks.1.ff.net.2"}
+    a, b = d["single_transformer_blocks.0.attn.to_q"]
+    assert torch.equal(a, A) and torch.allclose(b, B * (8.0 / 16.0))
+    a2, b2 = d["transformer_blocks.1.ff.net.2"]
+    assert torch.equal(a2, A2) and torch.equal(b2, B2)
+    p2 = str(tmp_path / "bad.safetensors")
+    save_file({"transformer.x.lora_A.weight": A}, p2)
+    try:
+        load_lora_safetensors(p2)
+        assert False, "missing lora_B must raise"
+    except KeyError:
+        pass
+
+
+def test_vae_parameter_table_matches_oracle_module():
+    """the product's diffusers-keyed VAE parameter table (flux/synthetic.py) is exactly the oracle module's state dict."""
+    from oracle import vae_ref
+    from unitex_amd.flux.synthetic import vae_param_shapes
+    ref = {k: tuple(v.shape) for k, v in vae_ref.AutoencoderKL().state_dict().items()}
+    assert ref == {k: tuple(v) for k, v in vae_param_shapes().items()}
