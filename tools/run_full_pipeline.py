@@ -16,6 +16,8 @@ ap.add_argument("--faces", type=int, default=50000)
 ap.add_argument("--steps", type=int, default=28)
 ap.add_argument("--no-uv", action="store_true", help="feed a mesh without UVs (exercises clean / unwrap)")
 ap.add_argument("--out", default=None)
+ap.add_argument("--view", type=int, default=512, help="per-view resolution: 512 = reference, 1024 = BASELINE configs[1..2]")
+ap.add_argument("--reps", type=int, default=2)
 a = ap.parse_args()
 out = a.out or tempfile.mkdtemp(prefix="utx_full_")
 v, f, uv = meshes.sphere_with_faces(a.faces)
@@ -24,16 +26,16 @@ meshes.save_obj(mesh_path, v, f, None if a.no_uv else uv)
 yy, xx = np.mgrid[0:768, 0:768]
 Image.fromarray(np.stack([xx % 256, yy % 256, (xx + yy) % 256], -1).astype(np.uint8)).save(os.path.join(out, "ref.png"))
 t0 = time.perf_counter()
-pipe = CustomRGBTextureFullPipeline(pretrain_models=None, super_resolutions=False, seed=63, num_inference_steps=a.steps)
+pipe = CustomRGBTextureFullPipeline(pretrain_models=None, super_resolutions=False, seed=63, num_inference_steps=a.steps, view_size=a.view)
 torch.cuda.synchronize()
 t1 = time.perf_counter()
 print("pipeline construction (synthetic 12B-parameter weights): %.1f s" % (t1 - t0), flush=True)
-for rep in range(2):
+for rep in range(a.reps):
     t2 = time.perf_counter()
     png, glb = pipe(os.path.join(out, "run%d" % rep), os.path.join(out, "ref.png"), mesh_path)
     torch.cuda.synchronize()
     t3 = time.perf_counter()
     print("run %d: sec_per_mesh_texture = %.2f s  (%d steps x 2 passes)  -> %s (%.1f MB)" %
           (rep, t3 - t2, a.steps, glb, os.path.getsize(glb) / 1e6), flush=True)
-tex = np.asarray(Image.open(os.path.join(out, "run1", "cache", "wo_LTM", "completed_uv.png")))
+tex = np.asarray(Image.open(os.path.join(out, "run%d" % (a.reps - 1), "cache", "wo_LTM", "completed_uv.png")))
 print("atlas", tex.shape, "mean", float(tex.mean()), "peak mem %.1f GB" % (torch.cuda.max_memory_allocated() / 2**30))

@@ -48,7 +48,7 @@ def build_pipeline(pretrain_models=None, pipeline_name="texture_plus", device="c
 class RGBTextureFullPipelineBase:
     def __init__(self, pretrain_models=None, pipeline_name="texture_plus", super_resolutions=False, seed=0, speedup_mode=None,
                  add_lora_path=None, add_lora_weights=None, enable_rembg=False, device="cuda:0", pipeline=None,
-                 num_inference_steps=None, atlas_size=2048):
+                 num_inference_steps=None, atlas_size=2048, view_size=512):
         from .texturetools.renderer_inverse import NVDiffRendererInverse
         from .texturetools.video import VideoExporter
         if super_resolutions:
@@ -67,6 +67,9 @@ class RGBTextureFullPipelineBase:
         self.generator = torch.Generator().manual_seed(seed)   # ONE CPU generator shared by all draws (A19)
         self.super_resolutions = super_resolutions
         self.atlas_size = atlas_size
+        # per-view resolution: 512 is the reference's hard-wired operating point (pipeline.py:239-255); 1024 is
+        # BASELINE.json's configs[1..2] (joint strip 1024 x 6144, 50 688 tokens)
+        self.view_size = int(view_size)
 
     @CPUTimer("preprocess_blank_mesh")
     def preprocess_blank_mesh(self, save_dir, input_mesh_path, min_faces=20_000, max_faces=200_000, scale=0.95):
@@ -92,7 +95,7 @@ class RGBTextureFullPipelineBase:
     @CPUTimer("render_geometry_images")
     def render_geometry_images(self, save_dir, input_mesh_path, geometry_scale=0.95, scale=1.0, color="grey"):
         out = self.video_exporter.export_condition(input_mesh_path, geometry_scale=geometry_scale, n_views=6, n_rows=2, n_cols=3,
-                                                   H=512, W=512, fov_deg=49.1, scale=scale, perspective=False, orbit=False,
+                                                   H=self.view_size, W=self.view_size, fov_deg=49.1, scale=scale, perspective=False, orbit=False,
                                                    background=color, return_image=True, return_camera=True)
         out["alpha"].save(os.path.join(save_dir, "mv_alpha.png"))
         out["ccm"].save(os.path.join(save_dir, "mv_ccm.png"))
@@ -110,20 +113,21 @@ class RGBTextureFullPipelineBase:
         steps = getattr(self.pipeline, "_num_inference_steps", 28)
         if self.pipeline_name != "texture_plus":
             raise NotImplementedError("pipeline_name %s is not supported" % self.pipeline_name)
-        mix = (0.5 * normal.reshape(2, 512, 3, 512, -1) + 0.5 * ccm.reshape(2, 512, 3, 512, -1)).astype(np.uint8)
+        V = self.view_size
+        mix = (0.5 * normal.reshape(2, V, 3, V, -1) + 0.5 * ccm.reshape(2, V, 3, V, -1)).astype(np.uint8)
         mix[1, :, 2] = mix[1, ::-1, 2, ::-1]
-        tiles = mix.transpose(0, 2, 1, 3, 4).reshape(6, 512, 512, -1)[[0, 4, 1, 3, 2, 5]]
-        control_image = Image.fromarray(tiles.transpose(1, 0, 2, 3).reshape(512, 6 * 512, -1))
-        common = dict(prompt="[MVFLUX]", prompt_embeds=None, pooled_prompt_embeds=None, height=512, width=3072, n_rows=1,
+        tiles = mix.transpose(0, 2, 1, 3, 4).reshape(6, V, V, -1)[[0, 4, 1, 3, 2, 5]]
+        control_image = Image.fromarray(tiles.transpose(1, 0, 2, 3).reshape(V, 6 * V, -1))
+        common = dict(prompt="[MVFLUX]", prompt_embeds=None, pooled_prompt_embeds=None, height=V, width=6 * V, n_rows=1,
                       n_cols=6, num_inference_steps=steps, guidance_scale=3.5, max_sequence_length=512, generator=self.generator)
         self.pipeline.set_adapters(adapter_names=self.adapter_names, adapter_weights=self.weights_for_texture)
         out_image = self.pipeline(control_image=control_image, dual_image=reference_image, **common).images[0]
         out_image.save(os.path.join(save_dir, "mv_rgb_w_light.png"))
         self.pipeline.set_adapters(adapter_names=self.adapter_names, adapter_weights=self.weights_for_delight)
         delit = self.pipeline(control_image=out_image, **common).images[0]
-        t = np.array(delit).reshape(512, 6, 512, -1)
+        t = np.array(delit).reshape(V, 6, V, -1)
         t[:, 5] = t[::-1, 5, ::-1]
-        grid = t.transpose(1, 0, 2, 3)[[0, 2, 4, 3, 1, 5]].reshape(2, 3, 512, 512, -1).transpose(0, 2, 1, 3, 4).reshape(1024, 1536, -1)
+        grid = t.transpose(1, 0, 2, 3)[[0, 2, 4, 3, 1, 5]].reshape(2, 3, V, V, -1).transpose(0, 2, 1, 3, 4).reshape(2 * V, 3 * V, -1)
         Image.fromarray(grid).save(os.path.join(save_dir, "mv_rgb.png"))
 
     @CPUTimer("export_video")
