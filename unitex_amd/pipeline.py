@@ -5,8 +5,9 @@
 
 Stage sequence, artefact names and the uint8-PNG hand-off between stages (A5) are the reference's.  The DiT
 is FluxDiT + PBRFluxPipeline (HIP kernels), render / back-projection are VideoExporter /
-NVDiffRendererInverse (HIP kernels).  Out of scope this round (SURVEY 8f "next"): UV unwrapping of meshes
-without UVs, RMBG-2.0 background removal, the orbit video, super-resolution (TSD_SR)."""
+NVDiffRendererInverse (HIP kernels); meshes without UVs are cleaned and unwrapped on the host (texturetools/meshes.py),
+the orbit video is rendered by VideoExporter.export_orbit_video.  Not built: RMBG-2.0 background removal (an existing
+alpha channel is honoured instead) and super-resolution (TSD_SR, off by default in the reference)."""
 import os
 import shutil
 from typing import Tuple

@@ -60,12 +60,9 @@ class DeviceMesh:
 
 
 def load_device_mesh(path, device):
-    if not path.lower().endswith(".obj"):
-        raise NotImplementedError("only .obj meshes with UVs are read natively (GLB input is a 'next' row, DESIGN.md)")
-    verts, faces, uvs, faces_uv = meshes.load_obj(path)
+    verts, faces, uvs, _ = meshes.load_mesh(path)        # .obj / .glb
     if uvs is None:
-        raise ValueError("mesh %s has no UVs; UV unwrapping (open3d/xatlas in the reference) is out of scope this round" % path)
-    verts, faces, uvs = meshes.unify_uv_indexing(verts, faces, uvs, faces_uv)
+        raise ValueError("mesh %s has no UVs: run it through meshes.prepare_blank_mesh (pipeline.preprocess_blank_mesh) first" % path)
     return DeviceMesh(verts, faces, uvs, device)
 
 
