@@ -114,7 +114,7 @@ class RGBTextureFullPipelineBase:
         steps = getattr(self.pipeline, "_num_inference_steps", 28)
         if self.pipeline_name != "texture_plus":
             raise NotImplementedError("pipeline_name %s is not supported" % self.pipeline_name)
-        V = self.view_size
+        V = getattr(self, "view_size", 512)
         mix = (0.5 * normal.reshape(2, V, 3, V, -1) + 0.5 * ccm.reshape(2, V, 3, V, -1)).astype(np.uint8)
         mix[1, :, 2] = mix[1, ::-1, 2, ::-1]
         tiles = mix.transpose(0, 2, 1, 3, 4).reshape(6, V, V, -1)[[0, 4, 1, 3, 2, 5]]
