@@ -119,3 +119,19 @@ def test_vae_parameter_table_matches_oracle_module():
     from unitex_amd.flux.synthetic import vae_param_shapes
     ref = {k: tuple(v.shape) for k, v in vae_ref.AutoencoderKL().state_dict().items()}
     assert ref == {k: tuple(v) for k, v in vae_param_shapes().items()}
+
+
+def test_bench_workload_arithmetic_matches_baseline_md():
+    """bench.py's token counts / algorithmic FLOPs are the ones BASELINE.md section 2 tabulates."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(HERE), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for name, S_ref, tflop_ref, attn_ref in (("strip1024x6", 50688, 2454.0, 1800.0), ("ref512x6", 13824, 312.3, 133.9),
+                                             ("view1024", 9728, 191.9, 66.3), ("view2048", 34304, 1267.0, None)):
+        S = sum(bench.token_counts(name))
+        assert S == S_ref
+        fl, fa = bench.step_flops(S)
+        assert abs(fl / 1e12 - tflop_ref) / tflop_ref < 2e-3
+        if attn_ref:
+            assert abs(fa / 1e12 - attn_ref) / attn_ref < 5e-3
