@@ -31,6 +31,9 @@ class UlyssesExchange:
         if S_loc % 64:
             raise ValueError("local token count %d must be a multiple of 64" % S_loc)
         self.H, self.Hp, self.S_loc, self.S = H, H // P, S_loc, S_loc * P
+        # gloo cannot move device tensors through all_to_all: stage through the host (test configurations only --
+        # production uses NCCL = RCCL, device to device over xGMI)
+        self.host_staged = bool(P > 1 and torch.device(device).type == "cuda" and dist.get_backend(group) == "gloo")
         n = self.Hp * S_loc * 128
         z = lambda *s: torch.empty(*s, dtype=dtype, device=device)
         self.send = z(P, 3, n)
@@ -47,7 +50,12 @@ class UlyssesExchange:
         self.send[:, 0].view(P, Hp, S_loc, 128).copy_(Qh.view(P, Hp, S_loc, 128))
         self.send[:, 1].view(P, Hp, S_loc, 128).copy_(Kh.view(P, Hp, S_loc, 128))
         self.send[:, 2].view(P, Hp, 128, S_loc).copy_(Vt.view(P, Hp, 128, S_loc))
-        if P > 1:
+        if P > 1 and self.host_staged:
+            rc, sc = torch.empty_like(self.recv, device="cpu"), self.send.cpu()
+            dist.all_to_all_single(rc, sc, group=self.group)
+            self.recv.copy_(rc)
+            r = self.recv
+        elif P > 1:
             dist.all_to_all_single(self.recv, self.send, group=self.group)
             r = self.recv
         else:
@@ -61,7 +69,12 @@ class UlyssesExchange:
         """self.o [S, (H/P)*128] (rows ordered (source rank, local token))  ->  out [S_loc, H*128] (rows may be strided)."""
         P, Hp, S_loc = self.P, self.Hp, self.S_loc
         src = self.o.view(P, S_loc, Hp * 128)
-        if P > 1:
+        if P > 1 and self.host_staged:
+            rc, sc = torch.empty_like(self.o_recv, device="cpu"), src.cpu()
+            dist.all_to_all_single(rc, sc, group=self.group)
+            self.o_recv.copy_(rc)
+            r = self.o_recv
+        elif P > 1:
             dist.all_to_all_single(self.o_recv, src, group=self.group)
             r = self.o_recv
         else:
