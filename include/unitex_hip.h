@@ -170,6 +170,9 @@ int utx_interpolate(utx_ctx* ctx, const float* attr, int C, const float* rast, c
 int utx_condition_shade(utx_ctx* ctx, const float* rast, const float* nrm, const float* pos, const float* bg3_host,
                         long npix, void* out_normal, void* out_ccm, void* out_alpha, utx_stream stream);
 
+/* per-face unit normals of PBRMesh (mesh/structure_v2.py:49-50): verts [V][3], faces [F][3] -> out [F][3]. */
+int utx_face_normals(utx_ctx* ctx, const float* verts, const int* faces, int F, float* out, utx_stream stream);
+
 /* textured shading of the orbit video (video/export_nvdiffrast_video.py:141-256 -> renderer_base.py:289-336
  * uv_rendering): rast [npix][4], per-vertex uv [V][2] in [0,1], tex [Ht][Wt][3] fp32 in UV-raster orientation (row
  * grows with v) -> uint8 RGB [npix][3]: bilinear fetch (wrap), background bg3_host where empty, truncation to uint8. */

@@ -239,3 +239,11 @@ def test_bvh_on_reference_bunny_bit_exact():
     assert np.array_equal(t, ref.trace(ro, rd))
     clear = f["edge_margin"] > 1e-4
     assert np.array_equal((t >= 0)[clear], f["hit"][clear])       # float64 brute-force mask stored with the fixture
+
+
+def test_face_normals_bit_exact():
+    ops = _ops()
+    verts, faces, _ = sphere_with_faces(5000)
+    faces = np.concatenate([faces, [[0, 0, 1]]]).astype(np.int32)     # a degenerate face: normalised with eps 1e-12 -> zeros
+    got = ops.face_normals(_cu(verts), _cu(faces)).cpu().numpy()
+    assert np.array_equal(got, G.face_normals(verts, faces))

@@ -82,6 +82,7 @@ SYMBOLS = {
     "utx_rasterize": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "utx_interpolate": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_long, c_void_p, c_void_p]),
     "utx_condition_shade": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, C.POINTER(c_float), c_long, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "utx_face_normals": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "utx_texture_shade": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, C.POINTER(c_float), c_long, c_void_p, c_void_p]),
     "utx_bvh_build": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, C.POINTER(c_void_p), c_void_p]),
     "utx_bvh_free": (None, [c_void_p]),

@@ -116,6 +116,11 @@ int utx_interpolate(utx_ctx* ctx, const float* attr, int C, const float* rast, c
     if (!attr || !rast || !tri || !out) return fail(ctx, -2, "utx_interpolate");
     UTX_CALL(ctx, "utx_interpolate", utx_launch_interpolate(attr, C, rast, tri, npix, out, (hipStream_t)stream));
 }
+int utx_face_normals(utx_ctx* ctx, const float* verts, const int* faces, int F, float* out, utx_stream stream) {
+    if (!verts || !faces || !out) return fail(ctx, -2, "utx_face_normals");
+    UTX_CALL(ctx, "utx_face_normals", utx_launch_face_normals(verts, faces, F, out, (hipStream_t)stream));
+}
+
 int utx_texture_shade(utx_ctx* ctx, const float* rast, const float* uv, const int* tri, const float* tex, int Ht, int Wt,
                       const float* bg3_host, long npix, void* out, utx_stream stream) {
     if (!rast || !uv || !tri || !tex || !out) return fail(ctx, -2, "utx_texture_shade");

@@ -43,6 +43,7 @@ int utx_launch_transform(const float* verts, int V, const float* mvp, int n_view
 int utx_launch_rasterize(const float* pos, const int* tri, int F, int H, int W, float* rast, void* work, hipStream_t stream);
 int utx_launch_interpolate(const float* attr, int C, const float* rast, const int* tri, long npix, float* out, hipStream_t stream);
 int utx_launch_condition_shade(const float* rast, const float* nrm, const float* pos, const float* bg3_host, long npix, void* out_normal, void* out_ccm, void* out_alpha, hipStream_t stream);
+int utx_launch_face_normals(const float* verts, const int* faces, int F, float* out, hipStream_t stream);
 int utx_launch_texture_shade(const float* rast, const float* uv, const int* tri, const float* tex, int Ht, int Wt, const float* bg3_host, long npix, void* out, hipStream_t stream);
 int utx_bvh_build_impl(const float* verts, int V, const int* faces, int F, utx_bvh** out, hipStream_t stream);
 void utx_bvh_free_impl(utx_bvh* b);

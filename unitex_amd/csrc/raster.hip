@@ -288,3 +288,25 @@ extern "C" int utx_launch_texture_shade(const float* rast, const float* uv, cons
                        Ht, Wt, bg3_host[0], bg3_host[1], bg3_host[2], npix, (unsigned char*)out);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
+
+// ---- per-face unit normals (mesh/structure_v2.py:49-50: cross(v1 - v0, v2 - v0), F.normalize eps 1e-12); same float32
+// operation order as oracle/geom_ref.py face_normals (this file is compiled with -ffp-contract=off).
+__global__ __launch_bounds__(256) void face_normals_kernel(const float* verts, const int* faces, int F, float* out) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    const float* v0 = verts + 3 * (long)faces[3 * f + 0];
+    const float* v1 = verts + 3 * (long)faces[3 * f + 1];
+    const float* v2 = verts + 3 * (long)faces[3 * f + 2];
+    const float a0 = v1[0] - v0[0], a1 = v1[1] - v0[1], a2 = v1[2] - v0[2];
+    const float b0 = v2[0] - v0[0], b1 = v2[1] - v0[1], b2 = v2[2] - v0[2];
+    const float c0 = a1 * b2 - a2 * b1, c1 = a2 * b0 - a0 * b2, c2 = a0 * b1 - a1 * b0;
+    float n = sqrtf((c0 * c0 + c1 * c1) + c2 * c2);
+    n = fmaxf(n, 1e-12f);
+    out[3 * f + 0] = c0 / n; out[3 * f + 1] = c1 / n; out[3 * f + 2] = c2 / n;
+}
+
+extern "C" int utx_launch_face_normals(const float* verts, const int* faces, int F, float* out, hipStream_t stream) {
+    if (F <= 0) return -2;
+    hipLaunchKernelGGL(face_normals_kernel, dim3((F + 255) / 256), dim3(256), 0, stream, verts, faces, F, out);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}

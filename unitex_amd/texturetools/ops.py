@@ -65,6 +65,13 @@ def condition_shade(rast, nrm, pos, bg):
     return on, oc, oa
 
 
+def face_normals(verts, faces):
+    ctx = get_ctx(verts.device.index)
+    out = torch.empty(faces.shape[0], 3, dtype=F32, device=verts.device)
+    ctx.check(ctx.lib.utx_face_normals(ctx.handle, ptr(_f(verts)), ptr(_i(faces)), faces.shape[0], ptr(out), ctx.stream()))
+    return out
+
+
 def texture_shade(rast, uv01, tri, tex, bg=(1.0, 1.0, 1.0)):
     """rast [H,W,4], uv01 [V,2], tex [Ht,Wt,3] fp32 (UV-raster orientation) -> uint8 RGB [H,W,3]."""
     ctx = get_ctx(rast.device.index)

@@ -40,16 +40,7 @@ class DeviceMesh:
         self.faces = torch.as_tensor(faces, dtype=torch.int32).to(self.device).contiguous()
         self.uvs01 = np.asarray(uvs, dtype=np.float32)
         self.uvs_2d = (torch.as_tensor(uvs, dtype=torch.float32) * 2.0 - 1.0).to(self.device).contiguous()  # structure_v2.py:287
-        v = self.vertices
-        f = self.faces.long()
-        a, b = v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]]
-        # cross product with the fixed (no-FMA) term order the oracle uses; tiny tensor, host-orchestrated torch op
-        cx = a[:, 1] * b[:, 2] - a[:, 2] * b[:, 1]
-        cy = a[:, 2] * b[:, 0] - a[:, 0] * b[:, 2]
-        cz = a[:, 0] * b[:, 1] - a[:, 1] * b[:, 0]
-        areas = torch.stack([cx, cy, cz], -1)
-        nrm = torch.sqrt((cx * cx + cy * cy) + cz * cz).clamp_min(1e-12)
-        self.normals = (areas / nrm[:, None]).contiguous()
+        self.normals = ops.face_normals(self.vertices, self.faces)      # HIP, bit-exact vs the oracle's op order
         self._bvh = None
 
     @property
