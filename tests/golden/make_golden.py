@@ -535,6 +535,44 @@ def g67_backprojection(out):
     np.savez_compressed(os.path.join(out, "g67_backprojection.npz"), **fix)
 
 
+def g9_export_condition(out):
+    """VideoExporter.export_condition (video/export_nvdiffrast_video.py:900-999) run through the reference's own code:
+    Mesh.scale_to_bbox / apply_transform / vertex normals (mesh/structure.py:190-303,522-548), the 6-view selection and
+    NVDiffRendererBase.simple_rendering (renderer_base.py:101-200), with dr.rasterize / dr.interpolate delegated to the
+    build's CPU oracle and the mesh loader replaced by an in-memory mesh (trimesh is absent).  Pins the orchestration of
+    the geometry-condition render: normalisation, view order, -1 background lerp, x0.5+0.5, grey composite, uint8
+    truncation, 2x3 grid."""
+    _make_inverse_renderer()           # installs the dr stubs (rasterize / interpolate -> oracle)
+    V = importlib.import_module("TextureTools.texturetools.video.export_nvdiffrast_video")
+    S = importlib.import_module("TextureTools.texturetools.mesh.structure")
+    RB = importlib.import_module("TextureTools.texturetools.render.nvdiffrast.renderer_base")
+    verts, faces, _ = _sphere()
+    verts = (verts * np.array([1.3, 0.8, 1.0], np.float32) + np.array([0.2, -0.1, 0.05], np.float32)).astype(np.float32)
+    ref_mesh = S.Mesh(v_pos=torch.from_numpy(verts), t_pos_idx=torch.from_numpy(faces).long())
+    V.load_whole_mesh = lambda p: "in-memory"
+    V.Texture = types.SimpleNamespace(from_trimesh=lambda m: types.SimpleNamespace(mesh=ref_mesh))
+    orig_to = torch.Tensor.to
+
+    def to_cpu(self, *a, **k):         # the reference moves everything to 'cuda'
+        is_cuda = lambda x: (isinstance(x, str) and x.startswith("cuda")) or (isinstance(x, torch.device) and x.type == "cuda")
+        a = tuple("cpu" if is_cuda(x) else x for x in a)
+        if is_cuda(k.get("device")):
+            k["device"] = "cpu"
+        return orig_to(self, *a, **k)
+    torch.Tensor.to = to_cpu
+    try:
+        fake_self = types.SimpleNamespace(mesh_renderer=RB.NVDiffRendererBase(device="cpu"))
+        res = V.VideoExporter.export_condition(fake_self, "mesh.obj", geometry_scale=0.95, n_views=6, n_rows=2, n_cols=3, H=64, W=64,
+                                               fov_deg=49.1, scale=1.0, perspective=False, orbit=False, background="grey",
+                                               return_image=True, return_camera=True)
+    finally:
+        torch.Tensor.to = orig_to
+    np.savez_compressed(os.path.join(out, "g9_export_condition.npz"), verts=verts, faces=faces,
+                        alpha=np.asarray(res["alpha"]), ccm=np.asarray(res["ccm"]), normal=np.asarray(res["normal"]),
+                        c2ws=res["c2ws"].numpy(), intrinsics=res["intrinsics"].numpy(), v_pos_scaled=ref_mesh.v_pos.numpy(),
+                        v_nrm=ref_mesh.v_nrm.numpy())
+
+
 def g8_bunny(out):
     """known-answer input of the reference's own LBVH test (raytracing/rt_aprmis/test2.py:33-41: bunny.obj, pinhole rays
     from (0, 0.1, 0.3) towards (x, y, -1)); the reference stores no outputs, so the expected hit mask is an independent
@@ -576,7 +614,7 @@ def main():
     out = HERE
     torch.set_num_threads(4)
     only = set(sys.argv[1:])
-    for fn in (g1_pipeline, g2_attention, g3_infer_mv, g4_cameras, g5_image_ops, g67_backprojection, g8_bunny):
+    for fn in (g1_pipeline, g2_attention, g3_infer_mv, g4_cameras, g5_image_ops, g67_backprojection, g8_bunny, g9_export_condition):
         if only and fn.__name__ not in only:
             continue
         fn(out)

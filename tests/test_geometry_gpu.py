@@ -247,3 +247,21 @@ def test_face_normals_bit_exact():
     faces = np.concatenate([faces, [[0, 0, 1]]]).astype(np.int32)     # a degenerate face: normalised with eps 1e-12 -> zeros
     got = ops.face_normals(_cu(verts), _cu(faces)).cpu().numpy()
     assert np.array_equal(got, G.face_normals(verts, faces))
+
+
+def test_condition_render_matches_reference_fixture():
+    """fixture G9 = the reference's own VideoExporter.export_condition + simple_rendering (dr seams on the oracle
+    rasteriser): the HIP condition render must reproduce its alpha / world-position / normal grids.  Coverage (alpha) is
+    exact; colours may differ by one uint8 step where fp32 rounding order (torch normalize / lerp vs the fused kernel)
+    flips a truncation."""
+    from unitex_amd.texturetools.video import VideoExporter
+    f = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g9_export_condition.npz"))
+    out = VideoExporter(device="cuda:0").export_condition((f["verts"], f["faces"]), geometry_scale=0.95, n_views=6, n_rows=2, n_cols=3,
+                                                          H=64, W=64, fov_deg=49.1, scale=1.0, perspective=False, orbit=False,
+                                                          background="grey", return_image=True, return_camera=True)
+    assert np.array_equal(np.asarray(out["alpha"]), f["alpha"])
+    for key in ("ccm", "normal"):
+        d = np.abs(np.asarray(out[key]).astype(np.int32) - f[key].astype(np.int32))
+        assert d.max() <= 1, "%s differs by %d" % (key, int(d.max()))
+        assert (d > 0).mean() < 5e-3, "%s: %.4f of the bytes differ" % (key, float((d > 0).mean()))
+    assert np.array_equal(out["c2ws"].numpy(), f["c2ws"])

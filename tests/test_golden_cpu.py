@@ -254,3 +254,18 @@ def test_g8_lbvh_on_reference_bunny_vs_brute_force():
     assert clear.mean() > 0.99
     assert np.array_equal((tid >= 0)[clear], f["hit"][clear]), "hit mask differs from the float64 brute force"
     assert 0.03 < (tid >= 0).mean() < 0.07
+
+
+# ------------------------------------------------------------------------------------------------ G9
+def test_g9_condition_render_host_math_matches_reference():
+    """bbox normalisation (Mesh.scale_to_bbox + apply_transform, mesh/structure.py:190-303) and area-weighted vertex
+    normals (structure.py:522-548) as the reference computed them for fixture G9; cameras as returned by export_condition."""
+    from unitex_amd.texturetools import camera, meshes
+    from unitex_amd.texturetools.video import _vertex_normals
+    f = _load("g9_export_condition.npz")
+    scaled = meshes.normalise_to_bbox(f["verts"], 0.95)
+    assert np.allclose(scaled, f["v_pos_scaled"], rtol=0, atol=2e-7)
+    n = _vertex_normals(torch.from_numpy(f["v_pos_scaled"]), torch.from_numpy(f["faces"]).int()).numpy()
+    assert np.abs(n - f["v_nrm"]).max() < 2e-6
+    assert np.array_equal(camera.generate_box_views_c2ws(2.8)[[0, 1, 4, 2, 3, 5]].numpy(), f["c2ws"])
+    assert np.array_equal(camera.generate_intrinsics(1.0, 1.0, fov=False, degree=False).numpy(), f["intrinsics"])

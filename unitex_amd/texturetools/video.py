@@ -19,13 +19,15 @@ from . import camera, meshes, ops
 
 
 def _vertex_normals(verts, faces):
-    """area-weighted vertex normals (sum of face cross products, normalised).  The reference's forward render
-    takes trimesh's vertex normals (mesh/structure.py:355-356) [3p, unpinned]."""
+    """area-weighted vertex normals: face cross products splatted to the vertices, normalised; vertices with a zero sum
+    (unreferenced / degenerate) get (0, 0, 1) -- Mesh._compute_vertex_normal (mesh/structure.py:522-548), which the
+    reference falls back to when trimesh supplies no normals (pinned by fixture G9)."""
     v, f = verts.double(), faces.long()
     c = torch.linalg.cross(v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]], dim=-1)
     n = torch.zeros_like(v)
     for k in range(3):
         n.index_add_(0, f[:, k], c)
+    n = torch.where((n * n).sum(-1, keepdim=True) > 1e-20, n, torch.tensor([0.0, 0.0, 1.0], dtype=n.dtype))
     return torch.nn.functional.normalize(n, dim=-1).float().contiguous()
 
 
