@@ -4,7 +4,6 @@ fixtures were captured.  Exact arithmetic only (powers of two, max-pool, nearest
 agree bit for bit.  Test infrastructure."""
 import types
 
-import numpy as np
 import torch
 
 

@@ -1,7 +1,5 @@
 """Edge cases and error behaviour through the C ABI (GPU): invalid descriptors must come back as a negative return
 code + utx_last_error message (the Python shim raises RuntimeError), never as a fault; degenerate sizes must work."""
-import math
-
 import numpy as np
 import pytest
 import torch

@@ -2,7 +2,6 @@
 (oracle/geom_ref.c + geom_ref.py).  Bar: BIT-EXACT for every integer / index / mask output and for
 the float32 outputs whose expression order is fixed on both sides (raster record, interpolation, gather,
 pull-push); stated tolerance only where libm (powf) is involved (lens blur)."""
-import math
 import os
 
 import numpy as np

@@ -1,6 +1,5 @@
 """CPU tests: the oracle (and the product's host-side logic) against golden fixtures captured from the
 REFERENCE's own Python (tests/golden/make_golden.py).  This is what pins the oracle."""
-import math
 import os
 
 import numpy as np

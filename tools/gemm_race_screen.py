@@ -4,7 +4,6 @@
 BIT-IDENTICAL.  Runs each shape several times on fresh random operands and compares exactly."""
 import os
 import sys
-import time
 
 import torch
 

@@ -1,11 +1,9 @@
 """Checkpoint readers for the formats the reference loads (diffusers directory layout + peft/diffusers LoRA
 safetensors): /root/reference/pipeline.py:83-109.  Pure host I/O (safetensors -> torch tensors)."""
 import glob
-import json
 import os
 import re
 
-import torch
 
 
 def _load_dir(path):

@@ -20,7 +20,6 @@ from typing import Dict, List, Optional, Tuple
 
 import torch
 
-from .. import _lib
 from .._lib import GemvDesc, LnModDesc, QkvPostDesc, ptr
 from . import ops
 

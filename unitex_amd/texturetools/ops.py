@@ -6,7 +6,6 @@ import math
 import numpy as np
 import torch
 
-from .. import _lib
 from .._lib import BackprojectDesc, ptr
 from ..flux.ops import get_ctx
 

@@ -18,7 +18,6 @@ views' colour/visibility layers, ONE all_gather (RCCL over xGMI, or gloo in the 
 layers, and the composite + post-processing run replicated on every rank.
 """
 import contextlib
-import math
 import os
 from typing import Callable, Optional, Tuple
 
