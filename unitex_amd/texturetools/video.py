@@ -18,22 +18,39 @@ from PIL import Image
 from . import camera, meshes, ops
 
 
-def _vertex_normals(verts, faces):
-    """area-weighted vertex normals: face cross products splatted to the vertices, normalised; vertices with a zero sum
-    (unreferenced / degenerate) get (0, 0, 1) -- Mesh._compute_vertex_normal (mesh/structure.py:522-548), which the
-    reference falls back to when trimesh supplies no normals (pinned by fixture G9)."""
+def _vertex_normals(verts, faces, weighting="area"):
+    """per-vertex normals, float64 on the host (mesh preparation, not hot path).
+
+    weighting="area": face cross products splatted to the vertices, normalised; vertices with a zero sum (unreferenced /
+      degenerate) get (0, 0, 1) -- Mesh._compute_vertex_normal (mesh/structure.py:522-548), the reference's own code,
+      pinned by fixture G9.
+    weighting="angle": unit face normals weighted by the corner angle at the vertex, normalised -- what trimesh's
+      `vertex_normals` computes [3p, trimesh==3.20.2, restated from its published algorithm; unpinned], which is what the
+      reference's forward render actually consumes when trimesh is installed (Mesh.from_trimesh, structure.py:355-356)."""
     v, f = verts.double(), faces.long()
-    c = torch.linalg.cross(v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]], dim=-1)
+    p0, p1, p2 = v[f[:, 0]], v[f[:, 1]], v[f[:, 2]]
+    c = torch.linalg.cross(p1 - p0, p2 - p0, dim=-1)
     n = torch.zeros_like(v)
-    for k in range(3):
-        n.index_add_(0, f[:, k], c)
-    n = torch.where((n * n).sum(-1, keepdim=True) > 1e-20, n, torch.tensor([0.0, 0.0, 1.0], dtype=n.dtype))
+    if weighting == "area":
+        for k in range(3):
+            n.index_add_(0, f[:, k], c)
+        n = torch.where((n * n).sum(-1, keepdim=True) > 1e-20, n, torch.tensor([0.0, 0.0, 1.0], dtype=n.dtype))
+    elif weighting == "angle":
+        fn = torch.nn.functional.normalize(c, dim=-1)
+        unit = lambda a: torch.nn.functional.normalize(a, dim=-1)
+        corners = ((p0, p1, p2), (p1, p2, p0), (p2, p0, p1))
+        for k, (a, b, d) in enumerate(corners):
+            ang = torch.arccos(torch.clamp((unit(b - a) * unit(d - a)).sum(-1), -1.0, 1.0))
+            n.index_add_(0, f[:, k], fn * ang[:, None])
+    else:
+        raise ValueError("weighting must be 'area' or 'angle'")
     return torch.nn.functional.normalize(n, dim=-1).float().contiguous()
 
 
 class VideoExporter:
-    def __init__(self, device="cuda"):
+    def __init__(self, device="cuda", normal_weighting="angle"):
         self.device = torch.device(device if device != "cuda" else "cuda:%d" % torch.cuda.current_device())
+        self.normal_weighting = normal_weighting      # see _vertex_normals: "angle" = trimesh semantics (SURVEY A9)
 
     def export_condition(self, mesh_path, geometry_scale=1.0, n_views=4, n_rows=2, n_cols=2, H=512, W=512, scale=0.85,
                          fov_deg=49.1, perspective=False, orbit=True, background=None, return_info=False,
@@ -57,7 +74,7 @@ class VideoExporter:
         bg = camera.parse_color(background)
         dev = self.device
         vd, fd = verts.to(dev), faces.to(dev).contiguous()
-        nrm = _vertex_normals(verts, faces).to(dev)
+        nrm = _vertex_normals(verts, faces, self.normal_weighting).to(dev)
         mvp = torch.matmul(camera.intr_to_proj(intrinsics, perspective=False), camera.c2w_to_w2c(c2ws)).to(dev).contiguous()
         clip, _ = ops.transform_points(vd, mvp, want_ndc=False)
         rasts, ns, ps = [], [], []
