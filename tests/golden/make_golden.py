@@ -573,6 +573,26 @@ def g9_export_condition(out):
                         v_nrm=ref_mesh.v_nrm.numpy())
 
 
+def g10_preprocess_image(out):
+    """image/process_image.py:31-74 preprocess(): alpha-bbox crop, rescale to `scale` of the frame, paste on the colour
+    (the matting model itself is [3p] RMBG-2.0 and is bypassed by giving the image an alpha channel, the function's own
+    RGBA branch)."""
+    from PIL import Image
+    P = importlib.import_module("TextureTools.texturetools.image.process_image")
+    rng = np.random.default_rng(4)
+    yy, xx = np.mgrid[0:150, 0:200]
+    rgb = np.stack([(xx * 255 // 199), (yy * 255 // 149), ((xx + yy) % 256)], -1).astype(np.uint8)
+    alpha = ((((xx - 115) / 60.0) ** 2 + ((yy - 70) / 45.0) ** 2) < 1.0).astype(np.uint8) * 255
+    alpha[50:60, 30:45] = 128
+    img = Image.fromarray(np.concatenate([rgb, alpha[..., None]], -1), mode="RGBA")
+    fix = {"rgba_in": np.asarray(img)}
+    for tag, (H, W, scale, color) in {"a": (256, 256, 0.95, "grey"), "b": (128, 192, 0.8, "white")}.items():
+        o = P.preprocess(img, alpha=None, H=H, W=W, scale=scale, color=color, return_alpha=False, rembg_session=None)
+        fix["out_" + tag] = np.asarray(o)
+        fix["rgb_half_" + tag] = np.asarray(o.convert("RGB").resize((W // 2, H // 2)))
+    np.savez_compressed(os.path.join(out, "g10_preprocess_image.npz"), **fix)
+
+
 def g8_bunny(out):
     """known-answer input of the reference's own LBVH test (raytracing/rt_aprmis/test2.py:33-41: bunny.obj, pinhole rays
     from (0, 0.1, 0.3) towards (x, y, -1)); the reference stores no outputs, so the expected hit mask is an independent
@@ -614,7 +634,7 @@ def main():
     out = HERE
     torch.set_num_threads(4)
     only = set(sys.argv[1:])
-    for fn in (g1_pipeline, g2_attention, g3_infer_mv, g4_cameras, g5_image_ops, g67_backprojection, g8_bunny, g9_export_condition):
+    for fn in (g1_pipeline, g2_attention, g3_infer_mv, g4_cameras, g5_image_ops, g67_backprojection, g8_bunny, g9_export_condition, g10_preprocess_image):
         if only and fn.__name__ not in only:
             continue
         fn(out)

@@ -268,3 +268,15 @@ def test_g9_condition_render_host_math_matches_reference():
     assert np.abs(n - f["v_nrm"]).max() < 2e-6
     assert np.array_equal(camera.generate_box_views_c2ws(2.8)[[0, 1, 4, 2, 3, 5]].numpy(), f["c2ws"])
     assert np.array_equal(camera.generate_intrinsics(1.0, 1.0, fov=False, degree=False).numpy(), f["intrinsics"])
+
+
+# ------------------------------------------------------------------------------------------------ G10
+def test_g10_reference_image_preprocess_matches_reference():
+    from PIL import Image
+    from unitex_amd.texturetools.process_image import preprocess
+    f = _load("g10_preprocess_image.npz")
+    img = Image.fromarray(f["rgba_in"], mode="RGBA")
+    for tag, (H, W, scale, color) in {"a": (256, 256, 0.95, "grey"), "b": (128, 192, 0.8, "white")}.items():
+        o = preprocess(img, alpha=None, H=H, W=W, scale=scale, color=color)
+        assert np.array_equal(np.asarray(o), f["out_" + tag])
+        assert np.array_equal(np.asarray(o.convert("RGB").resize((W // 2, H // 2))), f["rgb_half_" + tag])

@@ -84,14 +84,15 @@ class RGBTextureFullPipelineBase:
 
     @CPUTimer("preprocess_reference_image")
     def preprocess_reference_image(self, save_dir, input_image_path, scale=0.95, color="grey"):
-        """reference: RMBG-2.0 matting, crop, recentre (image/process_image.py:31-74).  Here ('next' row f2): an
-        existing alpha channel is honoured, otherwise the image is used as is; composited on grey."""
-        img = Image.open(input_image_path)
-        rgba = img.convert("RGBA").resize((1024, 1024))
-        bg = Image.new("RGBA", rgba.size, (128, 128, 128, 255))
-        out = Image.alpha_composite(bg, rgba).convert("RGB")
+        """reference: RMBG-2.0 matte, then crop to the matte's bbox, rescale to 0.95 of a 1024^2 frame on grey
+        (pipeline.py:182-197, image/process_image.py:31-74; crop / rescale / paste pinned by fixture G10).  The matting
+        model is [3p] and absent: the input's own alpha channel is the matte when it has one, else the whole frame."""
+        from .texturetools.process_image import preprocess
+        src = Image.open(input_image_path)
+        src = src.resize((1024, 1024)) if src.mode == "RGBA" else src.convert("RGB").resize((1024, 1024))
+        out = preprocess(src, alpha=None, H=1024, W=1024, scale=scale, color=color)
         out.save(os.path.join(save_dir, "rembg_image.png"))
-        out.resize((512, 512)).save(os.path.join(save_dir, "processed_image.png"))
+        out.convert("RGB").resize((512, 512)).save(os.path.join(save_dir, "processed_image.png"))
 
     @CPUTimer("render_geometry_images")
     def render_geometry_images(self, save_dir, input_mesh_path, geometry_scale=0.95, scale=1.0, color="grey"):
