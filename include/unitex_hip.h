@@ -48,7 +48,8 @@ const char* utx_last_error(utx_ctx* ctx);
  *   vt   : V transposed, element (h, d, s) at base + h*vt_hs + d*vt_ds + s; every row must be readable
  *          (finite) up to the next multiple of 64 past S
  *   o    : element (s, h, d) at base + s*o_ss + h*128 + d
- * Strides in elements; q_ss, k_ss, vt_ds multiples of 8, o_ss multiple of 4.
+ * Strides in elements; q/k/vt base pointers 16-byte aligned; q_hs, k_hs, vt_hs, q_ss, k_ss, vt_ds multiples of 8,
+ * o_ss multiple of 4.
  * softmax_scale > 0: the reference's scale (1/sqrt(128)); softmax_scale == 0: Q was pre-multiplied by
  * scale*log2(e) by utx_qkv_post (q_scale) and scores are used as base-2 exponents directly. */
 int utx_attn_fwd_bf16(utx_ctx* ctx, const void* q, const void* k, const void* vt, void* o,

@@ -423,7 +423,8 @@ extern "C" int utx_launch_attn_fwd(const void* q, const void* k, const void* vt,
                                    long q_hs, long q_ss, long k_hs, long k_ss, long vt_hs, long vt_ds,
                                    long o_ss, int H, int S, float scale, hipStream_t stream) {
     if (S <= 0 || H <= 0 || scale < 0.f) return -1;
-    if ((vt_ds & 7) || (q_ss & 7) || (k_ss & 7) || (o_ss & 3)) return -2;
+    if ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)vt)) & 15) return -2;                       // 16-byte aligned bases (LDS-DMA / b128 loads)
+    if ((vt_ds & 7) || (q_ss & 7) || (k_ss & 7) || (o_ss & 3) || (q_hs & 7) || (k_hs & 7) || (vt_hs & 7)) return -2;   // 16-byte rows
     AttnParams p;
     p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.vt = (const bf16_t*)vt; p.o = (bf16_t*)o;
     p.q_hs = q_hs; p.q_ss = q_ss; p.k_hs = k_hs; p.k_ss = k_ss; p.vt_hs = vt_hs; p.vt_ds = vt_ds;
