@@ -48,6 +48,36 @@ __device__ __forceinline__ void glds16(const bf16_t* g, char* lds) {
                                      (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
 }
 
+
+// Epilogue row pass shared by the GEMM kernels: full-row 16-byte stores from the C staging image, gated residual fused.
+// The 8 residual rows of a chunk live in NAMED registers (rq0..rq7) requested together before the chunk is processed:
+// a load placed next to its store is serialised behind vmcnt(0) (res may alias C, the compiler cannot hoist it -- each
+// thread only re-reads what it alone writes, so hoisting by hand is safe), which made the gated epilogue 8 serial HBM
+// round trips per chunk (profiles/r01_perf_gemm_8phase.log: 19.6 us fixed cost per tile vs 9.5 us plain).  Named scalars
+// because hipcc demotes arrays written under a runtime branch to scratch.
+#define GM_RES_LOAD1(it_, rowexpr_) rq##it_ = *reinterpret_cast<const uint4*>(pres + (long)(rowexpr_) * p.ldres + gn0);
+#define GM_ROW_PASS1(it_, guard_)                                                                                \
+    {                                                                                                            \
+        const int ml = rrow0 + RPP * (it_);                                                                      \
+        const int gm = m0 + 128 * chunk + ml;                                                                    \
+        if (guard_) {                                                                                            \
+            uint4 yv = *reinterpret_cast<const uint4*>(smem + ml * CROW + rslot * 16);                           \
+            if (pgate) {                                                                                         \
+                uint32_t yw[4] = {yv.x, yv.y, yv.z, yv.w};                                                       \
+                const uint32_t rw[4] = {rq##it_.x, rq##it_.y, rq##it_.z, rq##it_.w};                             \
+                _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                  \
+                    const float y0 = bf2f((uint16_t)(yw[c] & 0xffff)), y1 = bf2f((uint16_t)(yw[c] >> 16));       \
+                    const float r0 = bf2f((uint16_t)(rw[c] & 0xffff)), r1 = bf2f((uint16_t)(rw[c] >> 16));       \
+                    const float o0 = r0 + rbf(gv[2 * c] * y0);                                                   \
+                    const float o1 = r1 + rbf(gv[2 * c + 1] * y1);                                               \
+                    yw[c] = pack2bf(o0, o1);                                                                     \
+                }                                                                                                \
+                yv = make_uint4(yw[0], yw[1], yw[2], yw[3]);                                                     \
+            }                                                                                                    \
+            *reinterpret_cast<uint4*>(cbase + (long)gm * ldc + cn) = yv;                                         \
+        }                                                                                                        \
+    }
+
 template <int BM, int BN, int NWM, int NWN, bool CONV>
 __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_bf16_kernel(GemmParams p) {
     constexpr int NW = NWM * NWN, NT = 64 * NW;
@@ -188,8 +218,27 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_bf16_kernel(GemmParams
     if (gn0 >= p.n_split) { cbase = pC1; ldc = p.ldc1; cn = gn0 - p.n_split; }
     else { cbase = pC; ldc = p.ldc; cn = gn0; }
 
+    // every bias word of this lane is requested up front (a load inside the loops below is followed by vmcnt(0))
+    uint2 bq[NI][4];
+    {
+        const bf16_t* bsrc = pbias ? pbias : pB;   // always a readable address: no branch around the array writes
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                int gnb = n0 + wn * WNR + ni * 32 + 8 * a + 4 * lh; if (gnb > p.N - 4) gnb = (p.N >= 4) ? p.N - 4 : 0;
+                bq[ni][a] = *reinterpret_cast<const uint2*>(bsrc + gnb);
+            }
+    }
+    static_assert(128 / RPP == 8, "8 row passes per 128-row chunk");
+#define GM_RROW(it_) ((m0 + 128 * chunk + rrow0 + RPP * (it_) > p.M - 1) ? p.M - 1 : m0 + 128 * chunk + rrow0 + RPP * (it_))
 #pragma unroll
     for (int chunk = 0; chunk < BM / 128; ++chunk) {
+        uint4 rq0, rq1, rq2, rq3, rq4, rq5, rq6, rq7;
+        if (pgate && gn0 < p.N) {
+            GM_RES_LOAD1(0, GM_RROW(0)) GM_RES_LOAD1(1, GM_RROW(1)) GM_RES_LOAD1(2, GM_RROW(2)) GM_RES_LOAD1(3, GM_RROW(3))
+            GM_RES_LOAD1(4, GM_RROW(4)) GM_RES_LOAD1(5, GM_RROW(5)) GM_RES_LOAD1(6, GM_RROW(6)) GM_RES_LOAD1(7, GM_RROW(7))
+        }
         __syncthreads();  // operand ring (or the previous chunk's C image) no longer needed
         // phase 1: y = bf16(alpha*acc + bias) (+GELU) -> LDS [128][CROW]
         // lane (m = l31, h): acc[ni][mi][r] -> n = wn*WNR + ni*32 + (r&3) + 8(r>>2) + 4h ; m = wm*WMR + mi*32 + l31
@@ -199,10 +248,9 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_bf16_kernel(GemmParams
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
                     const int nl = wn * WNR + ni * 32 + 8 * a + 4 * lh;  // local n of 4 consecutive columns
-                    int gn = n0 + nl; if (gn > p.N - 4) gn = (p.N >= 4) ? p.N - 4 : 0;
                     float bv[4] = {0.f, 0.f, 0.f, 0.f};
                     if (pbias) {
-                        const uint2 braw = *reinterpret_cast<const uint2*>(pbias + gn);
+                        const uint2 braw = bq[ni][a];
                         bv[0] = bf2f((uint16_t)(braw.x & 0xffff)); bv[1] = bf2f((uint16_t)(braw.x >> 16));
                         bv[2] = bf2f((uint16_t)(braw.y & 0xffff)); bv[3] = bf2f((uint16_t)(braw.y >> 16));
                     }
@@ -226,29 +274,8 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_bf16_kernel(GemmParams
         __syncthreads();
         // phase 2: full-row stores; gated residual fused here
         if (gn0 < p.N) {
-#pragma unroll
-            for (int it = 0; it < 128 / RPP; ++it) {
-                const int ml = rrow0 + RPP * it;
-                const int gm = m0 + 128 * chunk + ml;
-                if (gm < p.M) {
-                    uint4 yv = *reinterpret_cast<const uint4*>(smem + ml * CROW + rslot * 16);
-                    if (pgate) {
-                        const uint4 rv = *reinterpret_cast<const uint4*>(pres + (long)gm * p.ldres + gn0);
-                        uint32_t yw[4] = {yv.x, yv.y, yv.z, yv.w};
-                        const uint32_t rw[4] = {rv.x, rv.y, rv.z, rv.w};
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            const float y0 = bf2f((uint16_t)(yw[c] & 0xffff)), y1 = bf2f((uint16_t)(yw[c] >> 16));
-                            const float r0 = bf2f((uint16_t)(rw[c] & 0xffff)), r1 = bf2f((uint16_t)(rw[c] >> 16));
-                            const float o0 = r0 + rbf(gv[2 * c] * y0);
-                            const float o1 = r1 + rbf(gv[2 * c + 1] * y1);
-                            yw[c] = pack2bf(o0, o1);
-                        }
-                        yv = make_uint4(yw[0], yw[1], yw[2], yw[3]);
-                    }
-                    *reinterpret_cast<uint4*>(cbase + (long)gm * ldc + cn) = yv;
-                }
-            }
+            GM_ROW_PASS1(0, gm < p.M) GM_ROW_PASS1(1, gm < p.M) GM_ROW_PASS1(2, gm < p.M) GM_ROW_PASS1(3, gm < p.M)
+            GM_ROW_PASS1(4, gm < p.M) GM_ROW_PASS1(5, gm < p.M) GM_ROW_PASS1(6, gm < p.M) GM_ROW_PASS1(7, gm < p.M)
         }
     }
 }
@@ -457,8 +484,23 @@ __global__ __launch_bounds__(512, 2) void gemm256_8ph_kernel(GemmParams p) {
     bf16_t* cbase; long ldc; int cn;
     if (gn0 >= p.n_split) { cbase = pC1; ldc = p.ldc1; cn = gn0 - p.n_split; }
     else { cbase = pC; ldc = p.ldc; cn = gn0; }
+    uint2 bq[2][4];
+    {
+        const bf16_t* bsrc = pbias ? pbias : (const bf16_t*)p.B;   // always readable: no branch around the array writes
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) bq[j][a] = *reinterpret_cast<const uint2*>(bsrc + n0 + j * 128 + wc * 32 + 8 * a + 4 * lh);
+    }
+    static_assert(128 / RPP == 8, "8 row passes per 128-row chunk");
+#define G8_RROW(it_) (m0 + 128 * chunk + rrow0 + RPP * (it_))
 #pragma unroll
     for (int chunk = 0; chunk < 2; ++chunk) {
+        uint4 rq0, rq1, rq2, rq3, rq4, rq5, rq6, rq7;
+        if (pgate) {
+            GM_RES_LOAD1(0, G8_RROW(0)) GM_RES_LOAD1(1, G8_RROW(1)) GM_RES_LOAD1(2, G8_RROW(2)) GM_RES_LOAD1(3, G8_RROW(3))
+            GM_RES_LOAD1(4, G8_RROW(4)) GM_RES_LOAD1(5, G8_RROW(5)) GM_RES_LOAD1(6, G8_RROW(6)) GM_RES_LOAD1(7, G8_RROW(7))
+        }
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -468,7 +510,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_8ph_kernel(GemmParams p) {
                 const int gn = n0 + nl;
                 float bv[4] = {0.f, 0.f, 0.f, 0.f};
                 if (pbias) {
-                    const uint2 braw = *reinterpret_cast<const uint2*>(pbias + gn);
+                    const uint2 braw = bq[j][a];
                     bv[0] = bf2f((uint16_t)(braw.x & 0xffff)); bv[1] = bf2f((uint16_t)(braw.x >> 16));
                     bv[2] = bf2f((uint16_t)(braw.y & 0xffff)); bv[3] = bf2f((uint16_t)(braw.y >> 16));
                 }
@@ -489,27 +531,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_8ph_kernel(GemmParams p) {
             }
         }
         __syncthreads();
-#pragma unroll
-        for (int it = 0; it < 128 / RPP; ++it) {
-            const int ml = rrow0 + RPP * it;
-            const int gm = m0 + 128 * chunk + ml;
-            uint4 yv = *reinterpret_cast<const uint4*>(smem + ml * CROW + rslot * 16);
-            if (pgate) {
-                const uint4 rv = *reinterpret_cast<const uint4*>(pres + (long)gm * p.ldres + gn0);
-                uint32_t yw[4] = {yv.x, yv.y, yv.z, yv.w};
-                const uint32_t rw[4] = {rv.x, rv.y, rv.z, rv.w};
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float y0 = bf2f((uint16_t)(yw[c] & 0xffff)), y1 = bf2f((uint16_t)(yw[c] >> 16));
-                    const float r0 = bf2f((uint16_t)(rw[c] & 0xffff)), r1 = bf2f((uint16_t)(rw[c] >> 16));
-                    const float o0 = r0 + rbf(gv[2 * c] * y0);
-                    const float o1 = r1 + rbf(gv[2 * c + 1] * y1);
-                    yw[c] = pack2bf(o0, o1);
-                }
-                yv = make_uint4(yw[0], yw[1], yw[2], yw[3]);
-            }
-            *reinterpret_cast<uint4*>(cbase + (long)gm * ldc + cn) = yv;
-        }
+        GM_ROW_PASS1(0, true) GM_ROW_PASS1(1, true) GM_ROW_PASS1(2, true) GM_ROW_PASS1(3, true)
+        GM_ROW_PASS1(4, true) GM_ROW_PASS1(5, true) GM_ROW_PASS1(6, true) GM_ROW_PASS1(7, true)
     }
 }
 
