@@ -14,7 +14,7 @@ def timeit(fn, n=20):
 os.environ["UTX_GEMM_TILE"] = "256"
 M, N = 50688, 3072     # 2376 tiles = 9.28 rounds of 256 CUs -> 10 rounds
 rounds = 10
-for kind in ("plain", "bias", "gate"):
+for kind in ("plain", "bias", "gate", "gelu"):
     pts = []
     for K in (64, 256, 1024, 3072, 6144):
         A = (torch.rand(M, K, device=dev) - 0.5).to(torch.bfloat16); B = (torch.rand(N, K, device=dev) - 0.5).to(torch.bfloat16)
@@ -22,6 +22,7 @@ for kind in ("plain", "bias", "gate"):
         kw = {}
         if kind != "plain": kw["bias"] = torch.zeros(N, device=dev, dtype=torch.bfloat16)
         if kind == "gate": kw.update(gate=torch.ones(N, device=dev, dtype=torch.bfloat16), res=C)
+        if kind == "gelu": kw.update(gelu_from=0)
         ms = timeit(lambda: ops.gemm(A, B, out=C, **kw))
         pts.append((K // 64, ms * 1e3 / rounds))
     (k0, t0), (k1, t1) = pts[-2], pts[-1]

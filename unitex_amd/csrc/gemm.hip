@@ -37,10 +37,14 @@
 #define GM_BK 64
 #define GM_GROUP_M 4
 
+// GELU (tanh approximation, diffusers FeedForward 'gelu-approximate' [3p]):  0.5 x (1 + tanh u) == x * sigmoid(2u),
+// u = sqrt(2/pi) (x + 0.044715 x^3).  Evaluated in the sigmoid form with the hardware exp / rcp (~8 instructions) instead
+// of libm tanhf (~40): the result is rounded to bf16 right after, and the GELU columns cost +14 us per 256x256 tile with
+// tanhf (profiles/r01_perf_gemm_8phase.log).  Limits are exact: exp -> inf gives x * 0, exp -> 0 gives x.
 __device__ __forceinline__ float gelu_tanh(float x) {
     const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-    float inner = k0 * (x + k1 * x * x * x);
-    return 0.5f * x * (1.0f + tanhf(inner));
+    const float u = k0 * (x + k1 * x * x * x);
+    return x * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * u));
 }
 
 __device__ __forceinline__ void glds16(const bf16_t* g, char* lds) {
