@@ -130,11 +130,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; no HIP device visible (there is no CPU fallback)")
+    if local_rank >= torch.cuda.device_count():   # fewer visible devices than ranks (single-GPU control-flow test only)
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        backend = os.environ.get("UTX_DIST_BACKEND", "nccl")   # "gloo" only to exercise the N > 1 control flow on one GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(dev))
+        else:
+            dist.init_process_group(backend)
 
     from unitex_amd.flux import ops
     from unitex_amd.flux.synthetic import SyntheticFluxStateDict, synthetic_lora
