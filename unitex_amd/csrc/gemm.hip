@@ -332,7 +332,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_8ph_kernel(GemmParams p) {
     const int w = xcd_remap(blockIdx.x, gridDim.x);
     const int ntn = p.ntn & 0xffff, group_m = (p.ntn >> 16) & 0xff;
     const int dbg = p.ntn >> 24;   // perf ablation only (UTX_GEMM_DEBUG): 1 = no operand staging, 2 = always stage K-tile 0
-    const int ntm_ = p.M / BM;
+    const int ntm_ = (p.M + BM - 1) / BM;
     const int per_group = group_m * ntn;
     const int grp = w / per_group, rem = w - grp * per_group;
     const int first_tm = grp * group_m;
@@ -357,6 +357,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_8ph_kernel(GemmParams p) {
     const char* ubA2 = (const char*)p.A2 + a2_off * 2 + (long)(m0 + 8 * wave) * lda2B;
     const char* ubB2 = (const char*)p.B2 + (long)(n0 + 8 * wave) * ldb2B;
     char* const ldst = smem + wave * 1024;
+    const bool ragged_m = (m0 + BM > p.M);                 // wave-uniform
+    const int arow_lane = m0 + 8 * wave + srow_in;         // first A row this lane stages (half-tile 0, first DMA)
     // stage half-tile h of operand A (isb = 0) / B (isb = 1) of K-tile t_
 #define G8_STAGE(t_, isb_, h_)                                                                              \
     do {                                                                                                    \
@@ -369,8 +371,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_8ph_kernel(GemmParams p) {
                           (long)(s2_ ? ts_ - nk1 : ts_) * (GM_BK * 2) + (long)(128 * (h_)) * rs_;           \
         const unsigned vo_ = (isb_) ? (s2_ ? voB2 : voB1) : (s2_ ? voA2 : voA1);                            \
         char* l_ = ldst + (2 * (isb_) + (h_)) * 32768 + (tt_ & 1) * 16384;                                  \
-        glds16((const bf16_t*)(ub_ + vo_), l_);                                                             \
-        glds16((const bf16_t*)(ub_ + 64 * rs_ + vo_), l_ + 8192);                                           \
+        const char* g0_ = ub_ + vo_;                                                                        \
+        const char* g1_ = ub_ + 64 * rs_ + vo_;                                                             \
+        if (!(isb_) && ragged_m) {   /* last tile row of a ragged M: rows >= M re-read row M-1 (never stored) */ \
+            const int r_ = arow_lane + 128 * (h_);                                                          \
+            g0_ -= (long)((r_ > p.M - 1) ? r_ - (p.M - 1) : 0) * rs_;                                       \
+            g1_ -= (long)((r_ + 64 > p.M - 1) ? r_ + 64 - (p.M - 1) : 0) * rs_;                             \
+        }                                                                                                   \
+        glds16((const bf16_t*)g0_, l_);                                                                     \
+        glds16((const bf16_t*)g1_, l_ + 8192);                                                              \
     } while (0)
 
     f32x16 acc[2][4];   // [j][2i+f], swapped MFMA: rows = n, cols = m
@@ -497,7 +506,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_8ph_kernel(GemmParams p) {
             for (int a = 0; a < 4; ++a) bq[j][a] = *reinterpret_cast<const uint2*>(bsrc + n0 + j * 128 + wc * 32 + 8 * a + 4 * lh);
     }
     static_assert(128 / RPP == 8, "8 row passes per 128-row chunk");
-#define G8_RROW(it_) (m0 + 128 * chunk + rrow0 + RPP * (it_))
+#define G8_RROW(it_) ((m0 + 128 * chunk + rrow0 + RPP * (it_) > p.M - 1) ? p.M - 1 : m0 + 128 * chunk + rrow0 + RPP * (it_))
 #pragma unroll
     for (int chunk = 0; chunk < 2; ++chunk) {
         uint4 rq0, rq1, rq2, rq3, rq4, rq5, rq6, rq7;
@@ -535,8 +544,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_8ph_kernel(GemmParams p) {
             }
         }
         __syncthreads();
-        GM_ROW_PASS1(0, true) GM_ROW_PASS1(1, true) GM_ROW_PASS1(2, true) GM_ROW_PASS1(3, true)
-        GM_ROW_PASS1(4, true) GM_ROW_PASS1(5, true) GM_ROW_PASS1(6, true) GM_ROW_PASS1(7, true)
+        GM_ROW_PASS1(0, gm < p.M) GM_ROW_PASS1(1, gm < p.M) GM_ROW_PASS1(2, gm < p.M) GM_ROW_PASS1(3, gm < p.M)
+        GM_ROW_PASS1(4, gm < p.M) GM_ROW_PASS1(5, gm < p.M) GM_ROW_PASS1(6, gm < p.M) GM_ROW_PASS1(7, gm < p.M)
     }
 }
 
@@ -605,7 +614,7 @@ static int launch_gemm8(GemmParams p, hipStream_t stream, int group_env, int dbg
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
         attr_set = true;
     }
-    const int ntm = p.M / 256, ntn = p.N / 256;
+    const int ntm = (p.M + 255) / 256, ntn = p.N / 256;
     int group_m = group_env > 0 ? group_env : GM_GROUP_M;
     if (group_m > ntm) group_m = ntm;
     p.ntn = ntn | (group_m << 16) | (dbg_env << 24);
@@ -639,7 +648,7 @@ extern "C" int utx_launch_gemm_bf16(const GemmParams* hp, hipStream_t stream) {
     bool use256 = ok256 && tiles256 >= 192;
     if (tile_env == 128) use256 = false;
     if ((tile_env == 256 || tile_env == 2562) && ok256) use256 = true;   // 2562 = the 2-barrier 256^2 kernel (A/B testing)
-    if (use256 && (p.M % 256 == 0) && tile_env != 2562) return launch_gemm8(p, stream, group_env, dbg_env);
+    if (use256 && tile_env != 2562) return launch_gemm8(p, stream, group_env, dbg_env);
     if (use256) return launch_gemm<256, 256, 2, 4>(p, stream, group_env, dbg_env);
     return launch_gemm<128, 128, 2, 2>(p, stream, group_env, dbg_env);
 }
