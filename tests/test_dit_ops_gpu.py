@@ -377,3 +377,23 @@ def test_sequence_parallel_two_ranks_match_unsharded_forward(world):
         p.join(timeout=120)
         assert p.exitcode == 0
     assert err <= 0.02 * max(mx, 1.0), "sequence-parallel forward differs: %g (ref max %g, %.3f of elements differ)" % (err, mx, frac)
+
+
+def test_attention_running_max_keeps_growing():
+    """pathological order for the sum-checked softmax: the scores of every query grow steadily along the key axis, so the
+    running max has to be re-centred again and again (slow path on most tiles, in either 32-key block)."""
+    H, S = 2, 1536
+    g = torch.Generator().manual_seed(11)
+    q = torch.randn(H, S, 128, generator=g).to(BF)
+    k = (0.05 * torch.randn(H, S, 128, generator=g))
+    ramp = torch.linspace(0.0, 6.0, S)[None, :, None]                 # key j is aligned with a common direction, growing with j
+    u = torch.nn.functional.normalize(torch.randn(H, 1, 128, generator=g), dim=-1)
+    k = (k + ramp * u).to(BF)
+    q = (q + 8.0 * u).to(BF)                                           # every query has a large positive component along u
+    v = torch.randn(H, S, 128, generator=g).to(BF)
+    ref = dit_ref.sdpa(q.float(), k.float(), v.float(), em=False)
+    for prescaled in (False, True):
+        out = _run_attn(q, k, v, prescaled=prescaled)
+        assert torch.isfinite(out).all()
+        err = (out - ref).abs().max().item()
+        assert err < 4e-2, "ramp attention err %g (prescaled=%s)" % (err, prescaled)
