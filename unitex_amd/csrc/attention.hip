@@ -432,6 +432,7 @@ extern "C" int utx_launch_attn_fwd(const void* q, const void* k, const void* vt,
     { const char* e = getenv("UTX_ATTN_DEBUG"); p.dbg = e ? atoi(e) : 0; }
     p.scale_log2 = scale * 1.4426950408889634f;
     const bool presc = (scale == 0.f);
+    { const char* e = getenv("UTX_ATTN_Q64"); if (e && atoi(e) == 1) return utx_launch_attn_fwd_q64(&p, presc ? 1 : 0, stream); }
     // default: the LDS-DMA staged kernel (attention_glds.hip), +5 % over register staging (profiles/r01_perf_attn_ablation.log);
     // UTX_ATTN_GLDS=0 selects the register-staged variants below for A/B
     { const char* e = getenv("UTX_ATTN_GLDS"); if (!e || atoi(e) != 0) return utx_launch_attn_fwd_glds(&p, presc ? 1 : 0, stream); }

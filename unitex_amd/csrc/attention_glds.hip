@@ -125,15 +125,16 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
 #define AG_EXPB(sa_, p0_, p1_, ps_)                                                                  \
         {                                                                                            \
             f32x2 acc2_ = {0.f, 0.f};                                                                \
+            float sc0_ = 0.f, sc1_ = 0.f;                                                            \
             _Pragma("unroll") for (int r = 0; r < 16; r += 2) {                                      \
                 f32x2 pv_;                                                                           \
                 pv_[0] = __builtin_amdgcn_exp2f(PRESC ? sa_[r] : sa_[r] * c2);                       \
                 pv_[1] = __builtin_amdgcn_exp2f(PRESC ? sa_[r + 1] : sa_[r + 1] * c2);               \
-                acc2_ += pv_;                                                                        \
+                if (VAR != 4) { sc0_ += pv_[0]; sc1_ += pv_[1]; } else acc2_ += pv_;                 \
                 if (r < 8) { p0_[r] = (__bf16)pv_[0]; p0_[r + 1] = (__bf16)pv_[1]; }                 \
                 else { p1_[r - 8] = (__bf16)pv_[0]; p1_[r - 7] = (__bf16)pv_[1]; }                   \
             }                                                                                        \
-            ps_ = acc2_[0] + acc2_[1];                                                               \
+            ps_ = VAR != 4 ? sc0_ + sc1_ : acc2_[0] + acc2_[1];                                      \
         }
 #define AG_SLOW(sa_, other_, fix_other_, kblk_, boff_, first_)                                       \
         {                                                                                            \
@@ -164,7 +165,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
         if (VAR != 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
-            kfb[kk] = *reinterpret_cast<const bf16x8*>(kb + 8192 + kx[kk]);
+            if (VAR == 3) kfb[kk] = kfa[kk];   /* ablation: half of the K fragment reads removed (wrong results) */
+            else kfb[kk] = *reinterpret_cast<const bf16x8*>(kb + 8192 + kx[kk]);
             sa0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfa[kk], qf[kk], kk == 0 ? negm : sa0, 0, 0, 0);
         }
         __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
@@ -194,7 +196,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
         // S2: PV(0) || exp(1); V fragments of block 1 (s = 2, 3) stream in
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            vfb[i] = *reinterpret_cast<const bf16x8*>(vb + (i & 3) * 4096 + vx[2 + (i >> 2)]);
+            if (VAR == 3) vfb[i] = vfa[i];   /* ablation: half of the V fragment reads removed (wrong results) */
+            else vfb[i] = *reinterpret_cast<const bf16x8*>(vb + (i & 3) * 4096 + vx[2 + (i >> 2)]);
             oacc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfa[i], pb[i >> 2], oacc[i & 3], 0, 0, 0);
         }
         AG_EXPB(sa1, pb[2], pb[3], ps1)
@@ -254,8 +257,10 @@ extern "C" int utx_launch_attn_fwd_glds(const AttnParams* p, int presc, hipStrea
     const char* e = getenv("UTX_ATTN_TPB");
     const int tpb = e ? atoi(e) : 1;
     if (tpb == 2) return presc ? launch_glds<1, 2>(*p, stream) : launch_glds<0, 2>(*p, stream);
-    { const char* v = getenv("UTX_ATTN_VAR"); const int var = v ? atoi(v) : 0;   // A/B only: 1 = no s_setprio, 2 = no interleave hints
+    { const char* v = getenv("UTX_ATTN_VAR"); const int var = v ? atoi(v) : 0;   // A/B only: 1 = no s_setprio, 2 = no interleave hints, 3 = half the fragment reads (wrong results), 4 = row sums with v_pk_add_f32 (slower beside MFMAs)
       if (var == 1 && presc) return launch_glds<1, 1, 1>(*p, stream);
-      if (var == 2 && presc) return launch_glds<1, 1, 2>(*p, stream); }
+      if (var == 2 && presc) return launch_glds<1, 1, 2>(*p, stream);
+      if (var == 3 && presc) return launch_glds<1, 1, 3>(*p, stream);
+      if (var == 4 && presc) return launch_glds<1, 1, 4>(*p, stream); }
     return presc ? launch_glds<1, 1>(*p, stream) : launch_glds<0, 1>(*p, stream);
 }

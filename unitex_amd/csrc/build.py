@@ -18,7 +18,8 @@ ARCH = "gfx950"
 # (source, extra flags)
 SOURCES = [
     ("attention.hip", []),
-    ("attention_glds.hip", []),
+    ("attention_glds.hip", ["-fno-slp-vectorize"]),
+    ("attention_q64.hip", []),
     ("gemm.hip", []),
     ("dit_elementwise.hip", ["-ffp-contract=off"]),
     ("vae.hip", []),

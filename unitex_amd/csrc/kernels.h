@@ -30,6 +30,7 @@ int utx_launch_attn_fwd(const void* q, const void* k, const void* vt, void* o,
                         long q_hs, long q_ss, long k_hs, long k_ss, long vt_hs, long vt_ds,
                         long o_ss, int H, int S, float scale, hipStream_t stream);
 int utx_launch_attn_fwd_glds(const AttnParams* p, int presc, hipStream_t stream);
+int utx_launch_attn_fwd_q64(const AttnParams* p, int presc, hipStream_t stream);
 int utx_launch_gemm_bf16(const GemmParams* p, hipStream_t stream);
 int utx_launch_gemv_bf16(const GemvParams* p, hipStream_t stream);
 int utx_launch_qkv_post(const QkvPostParams* p, hipStream_t stream);
