@@ -5,6 +5,7 @@ at the same tensor boundaries as the kernels, so differences come from accumulat
 the P-matrix bf16 quantisation inside flash attention.
 """
 import math
+import os
 
 import pytest
 import torch
@@ -397,3 +398,34 @@ def test_attention_running_max_keeps_growing():
         assert torch.isfinite(out).all()
         err = (out - ref).abs().max().item()
         assert err < 4e-2, "ramp attention err %g (prescaled=%s)" % (err, prescaled)
+
+
+@pytest.mark.parametrize("S,ramp_max", [(64, 0.0), (512, 0.0), (1536, 6.0), (1536, 45.0), (1024, 150.0)])
+def test_attention_q64_kernel_and_repair_pass(S, ramp_max):
+    """the opt-in 4 x 64 kernel (UTX_ATTN_Q64=1, whole 64-key tiles only) against the oracle: plain inputs, the growing
+    running maximum, and ramps steep enough to leave its 2^40 softmax headroom (45: finite overflow of the head-room check,
+    150: fp32 overflow inside the kernel) so that the repair pass with the 8 x 32 kernel has to rewrite the query blocks."""
+    H = 2
+    g = torch.Generator().manual_seed(S + int(ramp_max))
+    q = torch.randn(H, S, 128, generator=g)
+    k = torch.randn(H, S, 128, generator=g)
+    if ramp_max > 0:
+        u = torch.nn.functional.normalize(torch.randn(H, 1, 128, generator=g), dim=-1)
+        k = 0.05 * k + torch.linspace(0.0, ramp_max, S)[None, :, None] * u
+        q = q + 8.0 * u
+    q, k = q.to(BF), k.to(BF)
+    v = torch.randn(H, S, 128, generator=g).to(BF)
+    ref = dit_ref.sdpa(q.float(), k.float(), v.float(), em=False)
+    old = os.environ.get("UTX_ATTN_Q64")
+    os.environ["UTX_ATTN_Q64"] = "1"
+    try:
+        for prescaled in (False, True):
+            out = _run_attn(q, k, v, prescaled=prescaled)
+            assert torch.isfinite(out).all()
+            err = (out - ref).abs().max().item()
+            assert err < 4e-2, "4 x 64 attention err %g (S=%d ramp=%g prescaled=%s)" % (err, S, ramp_max, prescaled)
+    finally:
+        if old is None:
+            os.environ.pop("UTX_ATTN_Q64", None)
+        else:
+            os.environ["UTX_ATTN_Q64"] = old

@@ -33,6 +33,8 @@ def main():
         q = (torch.randn(H, S_pad, 128, device=dev) * (0.1275 if os.environ.get("UTX_PERF_PRESC", "1") == "1" else 1.0)).to(BF)
         k = torch.randn(H, S_pad, 128, device=dev).to(BF)
         vt = torch.randn(H, 128, S_pad, device=dev).to(BF)
+        if os.environ.get("UTX_PERF_ZERO") == "1":   # zero operands: same instruction stream, far less switching power -> shows the clock-unconstrained rate
+            q.zero_(); k.zero_(); vt.zero_()
         out = torch.empty(S, H * 128, dtype=BF, device=dev)
         presc = os.environ.get("UTX_PERF_PRESC", "1") == "1"
         med, best = timeit(lambda: ops.attention(q, k, vt, S=S, out=out, scale=0.0 if presc else None), iters=5 if S < 30000 else 3)

@@ -432,7 +432,23 @@ extern "C" int utx_launch_attn_fwd(const void* q, const void* k, const void* vt,
     { const char* e = getenv("UTX_ATTN_DEBUG"); p.dbg = e ? atoi(e) : 0; }
     p.scale_log2 = scale * 1.4426950408889634f;
     const bool presc = (scale == 0.f);
-    { const char* e = getenv("UTX_ATTN_Q64"); if (e && atoi(e) == 1) return utx_launch_attn_fwd_q64(&p, presc ? 1 : 0, stream); }
+    p.flags = nullptr; p.flag_hs = 0;
+    // opt-in: the 4 x 64 kernel (attention_q64.hip) followed by its repair pass; it needs whole 64-key tiles
+    { const char* e = getenv("UTX_ATTN_Q64");
+      if (e && atoi(e) == 1 && (S & 63) == 0) {
+          static unsigned char* flag_buf[16] = {nullptr}; static size_t flag_cap[16] = {0};
+          int dev = 0; if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return -5;
+          const size_t need = (size_t)H * (size_t)(S / 64);
+          if (flag_cap[dev] < need) {
+              if (flag_buf[dev]) (void)hipFree(flag_buf[dev]);
+              if (hipMalloc((void**)&flag_buf[dev], need) != hipSuccess) { flag_buf[dev] = nullptr; flag_cap[dev] = 0; return -5; }
+              flag_cap[dev] = need;
+          }
+          p.flags = flag_buf[dev]; p.flag_hs = S / 64;
+          const int rc = utx_launch_attn_fwd_q64(&p, presc ? 1 : 0, stream);
+          if (rc) return rc;
+          return utx_launch_attn_fwd_glds(&p, presc ? 1 : 0, stream);
+      } }
     // default: the LDS-DMA staged kernel (attention_glds.hip), +5 % over register staging (profiles/r01_perf_attn_ablation.log);
     // UTX_ATTN_GLDS=0 selects the register-staged variants below for A/B
     { const char* e = getenv("UTX_ATTN_GLDS"); if (!e || atoi(e) != 0) return utx_launch_attn_fwd_glds(&p, presc ? 1 : 0, stream); }

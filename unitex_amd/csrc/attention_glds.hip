@@ -42,6 +42,13 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
     const int head = w / p.nqb;
     const int qb = w - head * p.nqb;
     const int S = p.S;
+    if (p.flags) {
+        // repair pass behind the 4 x 64 kernel: only query blocks in which one of its waves ran out of softmax headroom
+        const unsigned char* f = p.flags + head * p.flag_hs + qb * 4;
+        int any = 0;
+        for (int g = 0; g < 4; ++g) any |= (qb * 4 + g < p.flag_hs) ? f[g] : 0;
+        if (!any) return;
+    }
     const bf16_t* kbase = p.k + (long)head * p.k_hs;
     const bf16_t* vbase = p.vt + (long)head * p.vt_hs;
 

@@ -1,34 +1,56 @@
-// bf16 MFMA flash-attention forward, 64 queries per wave (gfx950).  Same contract, maths and LDS-DMA staging as
-// attention_glds.hip; what differs is the work split: 4 waves x 64 queries per workgroup instead of 8 x 32, so every K / Vt
-// fragment read from LDS feeds TWO MFMAs (one per 32-query half) -- the per-MFMA ds_read_b128 traffic is halved.
-// Why: with half of the fragment reads removed (ablation UTX_ATTN_VAR=3, wrong results by design) the 32-query kernel runs
-// 25.9 -> 19.9 ms per launch at S = 50 688 (profiles/r01_perf_attn_ablation.log): the LDS fragment stream, not the MFMA
-// pipe, is what the waves wait on.  One wave per SIMD with the full 512-entry register file (accumulators for both halves:
-// 2 x 64 output + 4 x 16 score registers per lane, Q fragments for both halves).
+// bf16 MFMA flash-attention forward, 64 queries per wave, one wave per SIMD (gfx950).  Same contract and maths as
+// attention_glds.hip (swapped QK^T, -m accumulator block, sum-checked softmax with a rare exact path, LDS-DMA staged
+// K / Vt tiles with XOR-swizzled rows); what differs is the work split and the schedule.
+//
+// Work split: 4 waves x 64 queries per workgroup.  Every K / Vt fragment read from LDS feeds TWO MFMAs (one per 32-query
+// half), so the ds_read_b128 stream per MFMA is half that of the 8 x 32 kernel, and a wave owns its SIMD: no second wave
+// competes for the matrix pipe or the VALU issue slots.  The wave uses the whole 512-entry register file: the 2 x 64
+// output accumulators and the Q fragments live in AGPRs (192); the four 16-register score blocks, the two -m blocks, the
+// probabilities and a short window of K / Vt fragments in VGPRs.  hipcc gives every MFMA of a 512-register kernel AGPR
+// accumulators, and a score that sits in an AGPR costs one extra v_accvgpr_read per element before the VALU can touch it
+// (64 per tile), so the QK^T MFMAs are written as inline asm in their VGPR form; PV stays a builtin (AGPR form).
+//
+// Schedule: a software pipeline over 32-key blocks.  Stage b issues, in eight groups of four MFMAs,
+//      QK^T(b+1, h0)  QK^T(b+1, h1)  PV(b-1, h0)  PV(b-1, h1)           (32 MFMAs)
+// and behind every MFMA one softmax element of block b (exp2, add; a cvt_pk behind every second one) plus, per
+// group, one K and one Vt fragment read two groups ahead of its use -- 4 to 5 single-issue instructions per MFMA, which is
+// what one wave alone on a SIMD can hide behind a 32x32x16 MFMA (32 cycles of matrix pipe = ~8 issue slots).
+// LDS: 3-slot rings of 16 KB K and Vt tiles; one barrier per 64-key tile, K(t+2) and V(t+1) are DMA'd right after it.
 #include "common.h"
 #include "kernels.h"
 #include <stdlib.h>
 
 #define AQ_KVB 64
-#define AQ_KTILE 16384
-#define AQ_VTILE 16384
-#define AQ_LDS (2 * (AQ_KTILE + AQ_VTILE))
+#define AQ_TILE 16384
+#define AQ_NSLOT 3
+#define AQ_VRING (AQ_NSLOT * AQ_TILE)
+#define AQ_LDS (2 * AQ_NSLOT * AQ_TILE)
+#define AQ_HEADROOM 1.0995116e12f   /* 2^40 */
+typedef __attribute__((ext_vector_type(4))) uint32_t aq_u32x4;
 
 __device__ __forceinline__ void aq_glds16(const bf16_t* g, char* lds) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
 }
 
-// Output accumulators, running-max blocks and nothing else live in AGPRs for the whole loop.  The two rare operations that
-// touch them with the VALU (rescale by alpha, re-splat of -m) go through opaque asm so that the register allocator never
-// sees a VALU use and keeps them in place (a visible VALU use makes it copy all 128 accumulators through VGPRs every tile).
-// MFMA -> VALU and VALU -> MFMA hazards around the asm are covered by explicit s_nop (the hazard recogniser does not look
-// inside inline asm); this is cold code.
+// The accumulators and the -m blocks stay in AGPRs for the whole loop.  The rare operations that touch them with the VALU
+// (rescale by alpha, re-splat of -m, shifting a score block that was produced under the old maximum) go through opaque asm
+// so that the register allocator never sees a VALU use (a visible one makes it copy accumulators through VGPRs every
+// stage).  The hazard recogniser does not look inside inline asm: MFMA -> VALU and VALU -> MFMA distances around these are
+// covered by explicit s_nop.  Cold code.
 __device__ __forceinline__ void aq_scale_acc(f32x16& a, float alpha) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         float x = a[r], t;
         asm volatile("v_accvgpr_read_b32 %1, %0\n\tv_mul_f32 %1, %1, %2\n\tv_accvgpr_write_b32 %0, %1" : "+a"(x), "=&v"(t) : "v"(alpha));
+        a[r] = x;
+    }
+}
+__device__ __forceinline__ void aq_sub_acc(f32x16& a, float d) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float x = a[r], t;
+        asm volatile("v_accvgpr_read_b32 %1, %0\n\tv_sub_f32 %1, %1, %2\n\tv_accvgpr_write_b32 %0, %1" : "+a"(x), "=&v"(t) : "v"(d));
         a[r] = x;
     }
 }
@@ -40,15 +62,22 @@ __device__ __forceinline__ void aq_splat_acc(f32x16& a, float v) {
         a[r] = x;
     }
 }
+__device__ __forceinline__ bf16x8 aq_pfrag(const uint32_t* w) {
+    aq_u32x4 v = {w[0], w[1], w[2], w[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+// QK^T MFMA in VGPR form (scores and -m in VGPRs, Q fragment in AGPRs).  The hazard recogniser does not see inside: the
+// schedule keeps every VALU read of a score block >= 2 MFMAs behind the chain that wrote it, and the exact path pads itself.
+#define AQ_QK_FIRST(dst_, kf_, qf_, negm_) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(dst_) : "v"(kf_), "a"(qf_), "v"(negm_))
+#define AQ_QK_ACC(dst_, kf_, qf_) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(dst_) : "v"(kf_), "a"(qf_))
 
-// VAR: timing ablations (wrong results by design): 1 = no v_exp, 2 = no softmax VALU at all, 3 = block-1 fragments reuse the
-// block-0 registers (half the ds_reads), 4 = no DMA staging after the first tile, 5 = fragments read once (no ds_reads in
-// steady state), 6 = 5 + 4, 7 = 6 + no barrier, 8 = no barrier only.
-template <int PRESC, int VAR>
+// ABL (timing ablations, wrong results by design; UTX_ATTN_VAR): bit 0 no v_exp, 1 no fragment refills, 2 no DMA in the
+// loop, 3 no barrier in the loop, 4 no softmax VALU at all
+template <int PRESC, int ABL>
 __global__ __launch_bounds__(256) void attn_fwd_q64_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const kring = smem;
-    char* const vring = smem + 2 * AQ_KTILE;
+    char* const vring = smem + AQ_VRING;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -70,205 +99,222 @@ __global__ __launch_bounds__(256) void attn_fwd_q64_kernel(AttnParams p) {
         if (r1 > S - 1) r1 = S - 1;
         const bf16_t* qp0 = p.q + (long)head * p.q_hs + (long)r0 * p.q_ss + lh * 8;
         const bf16_t* qp1 = p.q + (long)head * p.q_hs + (long)r1 * p.q_ss + lh * 8;
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            qf0[kk] = *reinterpret_cast<const bf16x8*>(qp0 + kk * 16);
-            qf1[kk] = *reinterpret_cast<const bf16x8*>(qp1 + kk * 16);
-        }
+        // straight into AGPRs (they are only ever MFMA B operands), so that the allocator keeps them there
+#define AQ_QLD(dst_, ptr_, off_) asm volatile("global_load_dwordx4 %0, %1, off offset:" #off_ : "=a"(dst_) : "v"(ptr_))
+        AQ_QLD(qf0[0], qp0, 0);   AQ_QLD(qf0[1], qp0, 32);  AQ_QLD(qf0[2], qp0, 64);  AQ_QLD(qf0[3], qp0, 96);
+        AQ_QLD(qf0[4], qp0, 128); AQ_QLD(qf0[5], qp0, 160); AQ_QLD(qf0[6], qp0, 192); AQ_QLD(qf0[7], qp0, 224);
+        AQ_QLD(qf1[0], qp1, 0);   AQ_QLD(qf1[1], qp1, 32);  AQ_QLD(qf1[2], qp1, 64);  AQ_QLD(qf1[3], qp1, 96);
+        AQ_QLD(qf1[4], qp1, 128); AQ_QLD(qf1[5], qp1, 160); AQ_QLD(qf1[6], qp1, 192); AQ_QLD(qf1[7], qp1, 224);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 
-    // ---- DMA sources (4 waves: wave-instruction (wave, j), j = 0..3, fills LDS bytes [(4*wave + j) * 1024, +1024))
+    // ---- DMA sources (wave-instruction (wave, j), j = 0..3, fills LDS bytes [(4*wave + j) * 1024, +1024) of a 16 KB tile)
     //   K : slot s = (4*wave+j)*64 + lane -> row s>>4, LDS chunk s&15 <- global chunk (s&15) ^ (row&15)
     //   Vt: slot s                        -> row s>>3, LDS chunk s&7  <- global chunk (s&7) ^ ((row>>1)&7)
+    // per-lane 32-bit byte offsets; the tile advance is added to the uniform base on the scalar unit
 #define AQ_SRC(j_)                                                                                          \
     const int ks##j_ = (4 * wave + (j_)) * 64 + lane;                                                       \
-    const bf16_t* ksrc##j_ = kbase + (long)(ks##j_ >> 4) * p.k_ss + (((ks##j_ & 15) ^ ((ks##j_ >> 4) & 15)) << 3); \
-    const bf16_t* vsrc##j_ = vbase + (long)(ks##j_ >> 3) * p.vt_ds + (((ks##j_ & 7) ^ ((ks##j_ >> 4) & 7)) << 3);
+    const uint32_t ko##j_ = 2u * (uint32_t)((ks##j_ >> 4) * p.k_ss + (((ks##j_ & 15) ^ ((ks##j_ >> 4) & 15)) << 3)); \
+    const uint32_t vo##j_ = 2u * (uint32_t)((ks##j_ >> 3) * p.vt_ds + (((ks##j_ & 7) ^ ((ks##j_ >> 4) & 7)) << 3));
     AQ_SRC(0) AQ_SRC(1) AQ_SRC(2) AQ_SRC(3)
     const int dma_off = (4 * wave) * 1024;
-#define AQ_STAGE1(j_, slot_)                                                                               \
-    aq_glds16(ksrc##j_ + kadv_, kring + (slot_) * AQ_KTILE + dma_off + (j_) * 1024);                       \
-    aq_glds16(vsrc##j_ + vadv_, vring + (slot_) * AQ_VTILE + dma_off + (j_) * 1024);
-#define AQ_STAGE(t_, slot_)                                                                                \
-    do {                                                                                                   \
-        const long kadv_ = (long)(t_) * AQ_KVB * p.k_ss;                                                   \
-        const int vadv_ = (t_) * AQ_KVB;                                                                   \
-        AQ_STAGE1(0, slot_) AQ_STAGE1(1, slot_) AQ_STAGE1(2, slot_) AQ_STAGE1(3, slot_)                    \
-    } while (0)
+    const int nt = (S + AQ_KVB - 1) / AQ_KVB;
+#define AQ_G(base_, off_) reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(base_) + (off_))
+#define AQ_MIN(a_, b_) ((a_) < (b_) ? (a_) : (b_))
+    // whole-tile DMA of K tile tk_ into K slot ks_ / Vt tile tv_ into V slot vs_.  Tile indices are clamped: past the end
+    // the last tile is re-loaded into a free slot, which keeps the stages free of branches and the LDS free of garbage.
+#define AQ_DMA_K4(tk_, ks_)                                                                                 \
+    {                                                                                                       \
+        const bf16_t* const kt_ = kbase + (long)AQ_MIN(tk_, nt - 1) * AQ_KVB * p.k_ss;                      \
+        char* const kd_ = kring + (ks_) * AQ_TILE + dma_off;                                                \
+        aq_glds16(AQ_G(kt_, ko0), kd_); aq_glds16(AQ_G(kt_, ko1), kd_ + 1024);                              \
+        aq_glds16(AQ_G(kt_, ko2), kd_ + 2048); aq_glds16(AQ_G(kt_, ko3), kd_ + 3072);                       \
+    }
+#define AQ_DMA_V4(tv_, vs_)                                                                                 \
+    {                                                                                                       \
+        const bf16_t* const vt_ = vbase + AQ_MIN(tv_, nt - 1) * AQ_KVB;                                     \
+        char* const vd_ = vring + (vs_) * AQ_TILE + dma_off;                                                \
+        aq_glds16(AQ_G(vt_, vo0), vd_); aq_glds16(AQ_G(vt_, vo1), vd_ + 1024);                              \
+        aq_glds16(AQ_G(vt_, vo2), vd_ + 2048); aq_glds16(AQ_G(vt_, vo3), vd_ + 3072);                       \
+    }
 
-    // ---- fragment read offsets (kappa permutation and swizzles as in attention_glds.hip)
+    // ---- fragment read addresses (kappa permutation and swizzles as in attention_glds.hip): absolute LDS byte offsets
+    // that include the ring slot of the tile each register currently points at (advanced once per tile, see AQ_ADV_*)
     const int ka = lq >> 3, khp = (lq >> 2) & 1, kc = lq & 3;
     const int krow = 16 * (ka >> 1) + 8 * khp + 4 * (ka & 1) + kc;
     const int kswz = krow & 15, vswz = (lq >> 1) & 7;
     int kx[8], vx[4];
+    const int lds0 = (int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) kx[kk] = krow * 256 + (((2 * kk + lh) ^ kswz) << 4);
+    for (int kk = 0; kk < 8; ++kk) kx[kk] = lds0 + krow * 256 + (((2 * kk + lh) ^ kswz) << 4);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) vx[s] = lq * 128 + (((2 * s + lh) ^ vswz) << 4);
+    for (int s = 0; s < 4; ++s) vx[s] = lds0 + AQ_VRING + lq * 128 + (((2 * s + lh) ^ vswz) << 4);
+// fragment reads through a plain 32-bit LDS address (kx / vx hold absolute LDS byte addresses): no add of the symbol base
+#define AQ_LDSV(off_) (*(const __attribute__((address_space(3))) bf16x8*)(uint32_t)(off_))
+#define AQ_EXP(x_) ((ABL & 1) ? (x_) : __builtin_amdgcn_exp2f(x_))
+    // step from the slot of tile u-1 to the slot of tile u
+#define AQ_STEP(u_) ((((u_) % AQ_NSLOT) == 0) ? -(AQ_NSLOT - 1) * AQ_TILE : AQ_TILE)
 
-    f32x16 oacc0[4], oacc1[4];
+    f32x16 oacc0[4], oacc1[4], negm0, negm1, sa0_0, sa0_1, sa1_0, sa1_1;   // sa{block parity}_{half}
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { oacc0[i][r] = 0.f; oacc1[i][r] = 0.f; }
-    float m_run0 = 0.f, l_run0 = 0.f, m_run1 = 0.f, l_run1 = 0.f;
-    const float c2 = p.scale_log2;
-    bf16x8 pb0[4], pb1[4];
-    f32x16 negm0, negm1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { negm0[r] = 0.f; negm1[r] = 0.f; }
+    float m_run0 = 0.f, l_run0 = 0.f, m_run1 = 0.f, l_run1 = 0.f;
+    const float c2 = p.scale_log2;
+    uint32_t P0_0[8], P0_1[8], P1_0[8], P1_1[8];   // bf16 probabilities, P{block parity}_{half}; word i = elements 2i, 2i+1
+    bf16x8 kf[8], vf[8];
 
-    const int nt = (S + AQ_KVB - 1) / AQ_KVB;
-    AQ_STAGE(0, 0);
+    float ps0 = 0.f, ps1 = 0.f;   // row sums of the block whose softmax ran last (added to l_run once they are final)
+
+    // Exact step for half H of a block whose fast softmax overflowed its headroom (or the first / a ragged block): true
+    // maximum of the block, move the half's running maximum, redo the block's probabilities, shift the next block's scores
+    // (already produced under the old maximum) and rescale what exists of the half.  Lives only outside the hot loop.
+#define AQ_EXACT(H, SAR, SAW, PW, FIRST, rag_, lim_, BOFF)                                                                \
+    {                                                                                                                     \
+        float sv_[16];                                                                                                    \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) sv_[r] = SAR[r];                                                   \
+        if (rag_) {                                                                                                       \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                                \
+                if ((BOFF) + 16 * (r >> 3) + (r & 7) >= lim_) sv_[r] = -INFINITY;                                         \
+        }                                                                                                                 \
+        float mx_ = sv_[0];                                                                                               \
+        _Pragma("unroll") for (int r = 1; r < 16; ++r) mx_ = fmaxf(mx_, sv_[r]);                                          \
+        mx_ = fmaxf(mx_, __shfl_xor(mx_, 32, 64));                                                                        \
+        const float d_ = (FIRST) ? mx_ : fmaxf(mx_, 0.f);                                                                 \
+        const float alpha_ = (FIRST) ? 1.0f : __builtin_amdgcn_exp2f(PRESC ? -d_ : -d_ * c2);                             \
+        m_run##H += d_;                                                                                                   \
+        l_run##H *= alpha_;                                                                                               \
+        float t0_ = 0.f, t1_ = 0.f;                                                                                       \
+        _Pragma("unroll") for (int r = 0; r < 16; r += 2) {                                                               \
+            const float e0_ = __builtin_amdgcn_exp2f(PRESC ? sv_[r] - d_ : (sv_[r] - d_) * c2);                           \
+            const float e1_ = __builtin_amdgcn_exp2f(PRESC ? sv_[r + 1] - d_ : (sv_[r + 1] - d_) * c2);                   \
+            t0_ += e0_; t1_ += e1_;                                                                                       \
+            PW[r >> 1] = pack2bf(e0_, e1_);                                                                               \
+        }                                                                                                                 \
+        ps##H = t0_ + t1_;                                                                                                \
+        asm volatile("s_nop 15\n\ts_nop 7");   /* the last MFMAs of the stage have written SAW / oacc */                  \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                                  \
+            negm##H[r] = -m_run##H;                                                                                       \
+            SAW[r] -= d_;                                                                                                 \
+        }                                                                                                                 \
+        if (!(FIRST)) { _Pragma("unroll") for (int i = 0; i < 4; ++i) aq_scale_acc(oacc##H[i], alpha_); }                 \
+        asm volatile("s_nop 4" : "+v"(negm##H), "+v"(SAW));                                                               \
+    }
+    // One pipeline stage for block b of parity PAR (NPAR = 1 - PAR): QK^T of block b+1 into sa{NPAR}, fast softmax of block b
+    // from sa{PAR} into P{PAR} (row sums -> ps0, ps1), PV of block b-1 from P{NPAR}.  DO_SM / DO_PV switch the latter two
+    // off (pipeline fill); DO_DMA issues DMA piece g behind the first MFMA of group g (AQ_DMA_PIECE as defined at the
+    // expansion site).  No control flow inside: one basic block of 32 MFMAs.
+#define AQ_STAGE(PAR, NPAR, DO_SM, DO_PV, DO_DMA)                                                                         \
+    {                                                                                                                     \
+        float a0_ = 0.f, a1_ = 0.f, b0_ = 0.f, b1_ = 0.f, ea_ = 0.f, eb_ = 0.f, ec_ = 0.f, ed_ = 0.f;                    \
+        _Pragma("unroll") for (int g = 0; g < 8; ++g) {                                                                   \
+            /* slot 0: QK^T half 0 | DMA piece | element 2g of half 0 */                                                  \
+            if (g == 0) AQ_QK_FIRST(sa##NPAR##_0, kf[g], qf0[g], negm0); else AQ_QK_ACC(sa##NPAR##_0, kf[g], qf0[g]);     \
+            if ((DO_DMA) && !(ABL & 4)) AQ_DMA_PIECE(g);                                                                                  \
+            if ((DO_SM) && !(ABL & 16)) { ea_ = AQ_EXP(PRESC ? sa##PAR##_0[2 * g] : sa##PAR##_0[2 * g] * c2); if (g) b1_ = (g > 1) ? b1_ + ed_ : ed_; } \
+            __builtin_amdgcn_sched_barrier(0);                                                                            \
+            /* slot 1: QK^T half 1 | K fragment two groups ahead | element 2g+1 of half 0, pack */                        \
+            if (g == 0) AQ_QK_FIRST(sa##NPAR##_1, kf[g], qf1[g], negm1); else AQ_QK_ACC(sa##NPAR##_1, kf[g], qf1[g]);     \
+            if (!(ABL & 2) || !(DO_PV)) kf[(g + 2) & 7] = AQ_LDSV(kx[(g + 2) & 7] + (g < 6 ? (NPAR) : (PAR)) * 8192);                                \
+            if ((DO_SM) && !(ABL & 16)) {                                                                                                  \
+                eb_ = AQ_EXP(PRESC ? sa##PAR##_0[2 * g + 1] : sa##PAR##_0[2 * g + 1] * c2); a0_ = g ? a0_ + ea_ : ea_;   \
+                P##PAR##_0[g] = pack2bf(ea_, eb_); asm volatile("" : "+v"(P##PAR##_0[g]));                                \
+            }                                                                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                                            \
+            /* slot 2: PV half 0 | element 2g of half 1 */                                                                \
+            if (DO_PV) oacc0[g & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[g], aq_pfrag(P##NPAR##_0 + 4 * (g >> 2)), oacc0[g & 3], 0, 0, 0); \
+            if ((DO_SM) && !(ABL & 16)) { ec_ = AQ_EXP(PRESC ? sa##PAR##_1[2 * g] : sa##PAR##_1[2 * g] * c2); a1_ = g ? a1_ + eb_ : eb_; } \
+            __builtin_amdgcn_sched_barrier(0);                                                                            \
+            /* slot 3: PV half 1 | Vt fragment two groups ahead | element 2g+1 of half 1, pack */                         \
+            if (DO_PV) oacc1[g & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[g], aq_pfrag(P##NPAR##_1 + 4 * (g >> 2)), oacc1[g & 3], 0, 0, 0); \
+            if (!(ABL & 2) || !(DO_PV)) vf[(g + 2) & 7] = AQ_LDSV(vx[(((g + 2) & 7) >> 2) + 2 * (g < 6 ? (NPAR) : (PAR))] + ((g + 2) & 3) * 4096);    \
+            if ((DO_SM) && !(ABL & 16)) {                                                                                                  \
+                ed_ = AQ_EXP(PRESC ? sa##PAR##_1[2 * g + 1] : sa##PAR##_1[2 * g + 1] * c2); b0_ = g ? b0_ + ec_ : ec_;   \
+                P##PAR##_1[g] = pack2bf(ec_, ed_); asm volatile("" : "+v"(P##PAR##_1[g]));                                \
+            }                                                                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                                            \
+        }                                                                                                                 \
+        if ((DO_SM) && !(ABL & 16)) { b1_ += ed_; ps0 = a0_ + a1_; ps1 = b0_ + b1_; }                                                      \
+    }
+#define AQ_DMA_PIECE(g_) do { } while (0)
+    // address bookkeeping after a stage (t_ = tile of an odd stage 2t+1, or tile - 1 of an even stage 2t+2):
+    //   after odd stage 2t+1 : kx[0], kx[1] -> tile t+2, vx[0], vx[1] -> tile t+1; tile boundary (barrier, DMA)
+    //   after even stage 2t+2: kx[2..7]     -> tile t+2, vx[2], vx[3] -> tile t+1
+#define AQ_STEPK(t_) (((((t_) + 2) % AQ_NSLOT) == 0) ? -(AQ_NSLOT - 1) * AQ_TILE : AQ_TILE)
+#define AQ_STEPV(t_) (((((t_) + 1) % AQ_NSLOT) == 0) ? -(AQ_NSLOT - 1) * AQ_TILE : AQ_TILE)
+
+    // ---- prologue: first tiles in flight, fragments [0], [1] of K block 0, then stage -1 (QK^T of block 0 only) and stage 0
+    AQ_DMA_K4(0, 0)
+    AQ_DMA_V4(0, 0)
+    AQ_DMA_K4(1, 1)
+    AQ_DMA_V4(1, 1)
+    AQ_DMA_K4(2, 2)
     __syncthreads();
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) { asm volatile("" : "+v"(qf0[kk])); asm volatile("" : "+v"(qf1[kk])); }
-
-    bf16x8 kfa[8], kfb[8], vfa[8], vfb[8];
-    constexpr bool NOFRAG = (VAR >= 5 && VAR <= 7);
-    if (NOFRAG) {
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            kfa[kk] = *reinterpret_cast<const bf16x8*>(kring + kx[kk]);
-            kfb[kk] = *reinterpret_cast<const bf16x8*>(kring + 8192 + kx[kk]);
-            vfa[kk] = *reinterpret_cast<const bf16x8*>(vring + (kk & 3) * 4096 + vx[kk >> 2]);
-            vfb[kk] = *reinterpret_cast<const bf16x8*>(vring + (kk & 3) * 4096 + vx[2 + (kk >> 2)]);
-        }
+    kf[0] = AQ_LDSV(kx[0]); kf[1] = AQ_LDSV(kx[1]);
+    // stage -1 (parity 1: writes sa0 from K block 0; its Vt reads are harmless prefetches that stage 0 overwrites)
+    AQ_STAGE(1, 0, false, false, false)
+    kx[0] += AQ_STEPK(-1); kx[1] += AQ_STEPK(-1);      // K fragments [0], [1] of block 2 = tile 1 are read in stage 0
+    asm volatile("s_nop 15");
+    // stage 0 (tile 0, block 0): fast softmax, then unconditionally the exact step (it establishes the running maxima);
+    // QK^T of block 1, no PV
+    AQ_STAGE(0, 1, true, false, false)
+    {
+        AQ_EXACT(0, sa0_0, sa1_0, P0_0, true, false, 0, 0)
+        AQ_EXACT(1, sa0_1, sa1_1, P0_1, true, false, 0, 0)
+        l_run0 += ps0; l_run1 += ps1;
     }
+#pragma unroll
+    for (int kk = 2; kk < 8; ++kk) kx[kk] += AQ_STEPK(-1);
+
+    // ---- main loop: two stages per 64-key tile, no control flow inside a stage and none between stages except the loop.
+    // A block whose row sums leave the fp32 / bf16 headroom (a logit 2^40 above the maximum of the first 32 keys) cannot be
+    // repaired here without dragging the exact step's live ranges through the loop: the wave just records it (`bad`) and
+    // the launcher's second pass recomputes that query block with the 8 x 32 kernel, which re-centres on the fly.
+    bool bad = false;
+    int c3 = 1;   // (t + 1) % 3 at the top of iteration t
     for (int t = 0; t < nt; ++t) {
-        const int slot = t & 1;
-        if (NOFRAG) {
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk) { asm volatile("" : "+v"(kfa[kk]), "+v"(kfb[kk]), "+v"(vfa[kk]), "+v"(vfb[kk])); }
-        }
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) { asm volatile("" : "+v"(qf0[kk])); asm volatile("" : "+v"(qf1[kk])); }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { asm volatile("" : "+a"(oacc0[i])); asm volatile("" : "+a"(oacc1[i])); }
-        asm volatile("" : "+a"(negm0)); asm volatile("" : "+a"(negm1));
-        if (t + 1 < nt && ((VAR != 4 && VAR != 6 && VAR != 7) || t == 0)) AQ_STAGE(t + 1, slot ^ 1);
-        const char* kb = kring + slot * AQ_KTILE;
-        const char* vb = vring + slot * AQ_VTILE;
-        const bool ragged = (t == nt - 1) && (S & (AQ_KVB - 1));
-        const int lim = S - t * AQ_KVB - 8 * lh;
-
-        f32x16 sa00, sa01, sa10, sa11;     // sa{block}{half}
-#define AQ_EXPB(sa_, p0_, p1_, ps_)                                                                  \
-        if (VAR != 2) {                                                                              \
-            f32x2 acc2_ = {0.f, 0.f};                                                                \
-            _Pragma("unroll") for (int r = 0; r < 16; r += 2) {                                      \
-                f32x2 pv_;                                                                           \
-                pv_[0] = VAR == 1 ? sa_[r] : __builtin_amdgcn_exp2f(PRESC ? sa_[r] : sa_[r] * c2);   \
-                pv_[1] = VAR == 1 ? sa_[r + 1] : __builtin_amdgcn_exp2f(PRESC ? sa_[r + 1] : sa_[r + 1] * c2); \
-                acc2_ += pv_;                                                                        \
-                if (r < 8) { p0_[r] = (__bf16)pv_[0]; p0_[r + 1] = (__bf16)pv_[1]; }                 \
-                else { p1_[r - 8] = (__bf16)pv_[0]; p1_[r - 7] = (__bf16)pv_[1]; }                   \
-            }                                                                                        \
-            ps_ = acc2_[0] + acc2_[1];                                                               \
-        }
-        // slow path for (block, half H): true max, move that half's running max, rescale what exists of that half
-#define AQ_SLOW(sa_, other_, fix_other_, kblk_, boff_, first_, H)                                    \
-        {                                                                                            \
-            _Pragma("unroll") for (int kk = 0; kk < 8; ++kk) {                                       \
-                const bf16x8 kf_ = *reinterpret_cast<const bf16x8*>(kb + (kblk_) + kx[kk]);          \
-                sa_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf_, qf##H[kk], kk == 0 ? negm##H : sa_, 0, 0, 0); \
-            }                                                                                        \
-            if (ragged) {                                                                            \
-                _Pragma("unroll") for (int r = 0; r < 16; ++r)                                       \
-                    if ((boff_) + 16 * (r >> 3) + (r & 7) >= lim) sa_[r] = -INFINITY;                \
-            }                                                                                        \
-            float mx_ = sa_[0];                                                                      \
-            _Pragma("unroll") for (int r = 1; r < 16; ++r) mx_ = fmaxf(mx_, sa_[r]);                 \
-            mx_ = fmaxf(mx_, __shfl_xor(mx_, 32, 64));                                               \
-            const float d_ = (first_) ? mx_ : fmaxf(mx_, 0.f);                                       \
-            const float alpha_ = (first_) ? 1.0f : __builtin_amdgcn_exp2f(PRESC ? -d_ : -d_ * c2);   \
-            m_run##H += d_;                                                                          \
-            l_run##H *= alpha_;                                                                      \
-            _Pragma("unroll") for (int r = 0; r < 16; ++r) sa_[r] -= d_;                             \
-            if (fix_other_) { _Pragma("unroll") for (int r = 0; r < 16; ++r) other_[r] -= d_; }      \
-            asm volatile("s_nop 15\n\ts_nop 7");                                                     \
-            aq_splat_acc(negm##H, -m_run##H);                                                        \
-            if (!(first_)) { _Pragma("unroll") for (int i = 0; i < 4; ++i) aq_scale_acc(oacc##H[i], alpha_); } \
-            asm volatile("s_nop 4");                                                                 \
-        }
-        float ps00 = 0.f, ps01 = 0.f, ps10 = 0.f, ps11 = 0.f;
-        // S0: QK(block 0) for both halves from one set of K fragments; block-1 fragments stream in behind the MFMAs
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) if (!NOFRAG) kfa[kk] = *reinterpret_cast<const bf16x8*>(kb + kx[kk]);
+        // ---- stage 2t+1 (tile t, block 1)
         __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            if (VAR == 3) kfb[kk] = kfa[kk]; else if (!NOFRAG) kfb[kk] = *reinterpret_cast<const bf16x8*>(kb + 8192 + kx[kk]);
-            sa00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfa[kk], qf0[kk], kk == 0 ? negm0 : sa00, 0, 0, 0);
-            sa01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfa[kk], qf1[kk], kk == 0 ? negm1 : sa01, 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-#pragma unroll
-        for (int i_ = 0; i_ < 8; ++i_) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        // S1: QK(block 1) || exp(block 0); V fragments of block 0 stream in
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            if (!NOFRAG) vfa[kk] = *reinterpret_cast<const bf16x8*>(vb + (kk & 3) * 4096 + vx[kk >> 2]);
-            sa10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfb[kk], qf0[kk], kk == 0 ? negm0 : sa10, 0, 0, 0);
-            sa11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfb[kk], qf1[kk], kk == 0 ? negm1 : sa11, 0, 0, 0);
-        }
-        AQ_EXPB(sa00, pb0[0], pb0[1], ps00)
-        AQ_EXPB(sa01, pb1[0], pb1[1], ps01)
-#pragma unroll
-        for (int i_ = 0; i_ < 16; ++i_) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-            if (i_ & 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
-            __builtin_amdgcn_sched_group_barrier(0x402, 9, 1);
-        }
-        if (t == 0 || ragged || !__all(fmaxf(ps00, ps01) <= 8192.0f)) {      // one branch for both halves (keeps the exps above it)
-            if (t == 0 || ragged || !__all(ps00 <= 8192.0f)) {
-                AQ_SLOW(sa00, sa10, true, 0, 0, t == 0, 0)
-                AQ_EXPB(sa00, pb0[0], pb0[1], ps00)
-            }
-            if (t == 0 || ragged || !__all(ps01 <= 8192.0f)) {
-                AQ_SLOW(sa01, sa11, true, 0, 0, t == 0, 1)
-                AQ_EXPB(sa01, pb1[0], pb1[1], ps01)
-            }
-        }
-        l_run0 += ps00; l_run1 += ps01;
-        // S2: PV(block 0) for both halves from one set of Vt fragments || exp(block 1); block-1 Vt fragments stream in
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if (VAR == 3) vfb[i] = vfa[i]; else if (!NOFRAG) vfb[i] = *reinterpret_cast<const bf16x8*>(vb + (i & 3) * 4096 + vx[2 + (i >> 2)]);
-            oacc0[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfa[i], pb0[i >> 2], oacc0[i & 3], 0, 0, 0);
-            oacc1[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfa[i], pb1[i >> 2], oacc1[i & 3], 0, 0, 0);
-        }
-        AQ_EXPB(sa10, pb0[2], pb0[3], ps10)
-        AQ_EXPB(sa11, pb1[2], pb1[3], ps11)
-#pragma unroll
-        for (int i_ = 0; i_ < 16; ++i_) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 2);
-            if (i_ & 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 2);
-            __builtin_amdgcn_sched_group_barrier(0x402, 9, 2);
-        }
-        if (ragged || !__all(fmaxf(ps10, ps11) <= 8192.0f)) {
-            if (ragged || !__all(ps10 <= 8192.0f)) {
-                AQ_SLOW(sa10, sa00, false, 8192, 32, false, 0)
-                AQ_EXPB(sa10, pb0[2], pb0[3], ps10)
-            }
-            if (ragged || !__all(ps11 <= 8192.0f)) {
-                AQ_SLOW(sa11, sa01, false, 8192, 32, false, 1)
-                AQ_EXPB(sa11, pb1[2], pb1[3], ps11)
-            }
-        }
-        l_run0 += ps10; l_run1 += ps11;
-        // S3: PV(block 1)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            oacc0[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfb[i], pb0[2 + (i >> 2)], oacc0[i & 3], 0, 0, 0);
-            oacc1[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfb[i], pb1[2 + (i >> 2)], oacc1[i & 3], 0, 0, 0);
-        }
+        AQ_STAGE(1, 0, true, true, false)
         __builtin_amdgcn_s_setprio(0);
-        if (VAR != 7 && VAR != 8) __syncthreads();
+        bad |= !__all(ps0 <= AQ_HEADROOM) | !__all(ps1 <= AQ_HEADROOM);
+        l_run0 += ps0; l_run1 += ps1;
+        const int c3n = (c3 == AQ_NSLOT - 1) ? 0 : c3 + 1;                       // (t + 2) % 3
+        const int stepk = (c3n == 0) ? -(AQ_NSLOT - 1) * AQ_TILE : AQ_TILE;      // slot(t+1) -> slot(t+2)
+        const int stepv = (c3 == 0) ? -(AQ_NSLOT - 1) * AQ_TILE : AQ_TILE;       // slot(t)   -> slot(t+1)
+        kx[0] += stepk; kx[1] += stepk; vx[0] += stepv; vx[1] += stepv;
+        // ---- tile boundary: everything issued one tile ago has landed; K(t+3) -> slot of K(t), V(t+2) -> slot of V(t-1)
+        if (!(ABL & 8)) __syncthreads();
+        const bf16_t* const kt_ = kbase + (long)AQ_MIN(t + 3, nt - 1) * AQ_KVB * p.k_ss;
+        const bf16_t* const vt_ = vbase + AQ_MIN(t + 2, nt - 1) * AQ_KVB;
+        const int ksl = (c3 == 0) ? AQ_NSLOT - 1 : c3 - 1;                       // t % 3 = (t + 3) % 3
+        char* const kd_ = kring + ksl * AQ_TILE + dma_off;
+        char* const vd_ = vring + c3n * AQ_TILE + dma_off;                       // (t + 2) % 3
+#undef AQ_DMA_PIECE
+#define AQ_DMA_PIECE(g_)                                                                                    \
+        do {                                                                                                \
+            if ((g_) == 0) aq_glds16(AQ_G(kt_, ko0), kd_); if ((g_) == 1) aq_glds16(AQ_G(kt_, ko1), kd_ + 1024);      \
+            if ((g_) == 2) aq_glds16(AQ_G(kt_, ko2), kd_ + 2048); if ((g_) == 3) aq_glds16(AQ_G(kt_, ko3), kd_ + 3072); \
+            if ((g_) == 4) aq_glds16(AQ_G(vt_, vo0), vd_); if ((g_) == 5) aq_glds16(AQ_G(vt_, vo1), vd_ + 1024);      \
+            if ((g_) == 6) aq_glds16(AQ_G(vt_, vo2), vd_ + 2048); if ((g_) == 7) aq_glds16(AQ_G(vt_, vo3), vd_ + 3072); \
+        } while (0)
+        // ---- stage 2t+2 (tile t+1, block 0).  Past the last tile it still runs: its PV half finishes the last block, its
+        // softmax half works on scores of a tile that does not exist and is ignored
+        const bool valid = t + 1 < nt;
+        __builtin_amdgcn_s_setprio(1);
+        AQ_STAGE(0, 1, true, true, true)
+        __builtin_amdgcn_s_setprio(0);
+        bad |= valid & (!__all(ps0 <= AQ_HEADROOM) | !__all(ps1 <= AQ_HEADROOM));
+        l_run0 += valid ? ps0 : 0.f; l_run1 += valid ? ps1 : 0.f;
+#pragma unroll
+        for (int kk = 2; kk < 8; ++kk) kx[kk] += stepk;
+        vx[2] += stepv; vx[3] += stepv;
+        c3 = c3n;
     }
+    if (lane == 0) p.flags[head * p.flag_hs + (q0 >> 6)] = bad ? 1 : 0;
 
     // ---- epilogue, one 32-query half at a time: lane (q, h) holds O[q][32db + 8a + 4h + c], r = 4a + c
 #define AQ_STORE(H, qoff_)                                                                           \
@@ -291,29 +337,31 @@ __global__ __launch_bounds__(256) void attn_fwd_q64_kernel(AttnParams p) {
     AQ_STORE(1, 32)
 }
 
-template <int PRESC, int VAR>
+template <int PRESC, int ABL>
 static int launch_q64(AttnParams p, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_q64_kernel<PRESC, VAR>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_q64_kernel<PRESC, ABL>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, AQ_LDS) != hipSuccess) return -3;
         attr_set = true;
     }
     p.nqb = (p.S + 255) / 256;
-    hipLaunchKernelGGL((attn_fwd_q64_kernel<PRESC, VAR>), dim3(p.nqb * p.H), dim3(256), AQ_LDS, stream, p);
+    hipLaunchKernelGGL((attn_fwd_q64_kernel<PRESC, ABL>), dim3(p.nqb * p.H), dim3(256), AQ_LDS, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
 extern "C" int utx_launch_attn_fwd_q64(const AttnParams* p, int presc, hipStream_t stream) {
-    static int var = -1;
-    if (var < 0) { const char* e = getenv("UTX_ATTN_VAR"); var = e ? atoi(e) : 0; }
-    if (presc && var == 1) return launch_q64<1, 1>(*p, stream);
-    if (presc && var == 2) return launch_q64<1, 2>(*p, stream);
-    if (presc && var == 3) return launch_q64<1, 3>(*p, stream);
-    if (presc && var == 4) return launch_q64<1, 4>(*p, stream);
-    if (presc && var == 5) return launch_q64<1, 5>(*p, stream);
-    if (presc && var == 6) return launch_q64<1, 6>(*p, stream);
-    if (presc && var == 7) return launch_q64<1, 7>(*p, stream);
-    if (presc && var == 8) return launch_q64<1, 8>(*p, stream);
+    static int abl = -1;
+    if (abl < 0) { const char* e = getenv("UTX_ATTN_VAR"); abl = e ? atoi(e) : 0; }
+    if (presc) switch (abl) {
+        case 1: return launch_q64<1, 1>(*p, stream);
+        case 2: return launch_q64<1, 2>(*p, stream);
+        case 4: return launch_q64<1, 4>(*p, stream);
+        case 8: return launch_q64<1, 8>(*p, stream);
+        case 14: return launch_q64<1, 14>(*p, stream);
+        case 16: return launch_q64<1, 16>(*p, stream);
+        case 30: return launch_q64<1, 30>(*p, stream);
+        default: break;
+    }
     return presc ? launch_q64<1, 0>(*p, stream) : launch_q64<0, 0>(*p, stream);
 }

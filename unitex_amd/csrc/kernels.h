@@ -18,6 +18,8 @@ struct AttnParams {
     int H, S, nqb;
     int dbg;           // perf ablation only (UTX_ATTN_DEBUG bits): 1 no staging, 2 no exp, 4 no barrier, 8 no PV, 16 no QK
     float scale_log2;  // softmax_scale * log2(e)
+    unsigned char* flags;  // per (head, 64-query group) overflow marks: written by the 4 x 64 kernel, read by the repair pass (else null)
+    int flag_hs;           // flags per head
 };
 typedef utx_gemm_desc GemmParams;
 typedef utx_gemv_desc GemvParams;
