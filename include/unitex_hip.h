@@ -225,6 +225,25 @@ long utx_nn_fill_workspace_bytes(long T);
 int utx_nn_fill(utx_ctx* ctx, const float* pos, const void* winner, const float* rast2d, long T, float* atlas,
                 int* nn_index, void* work, long work_bytes, utx_stream stream);
 
+/* view-space visibility with the gradient filter (mv_to_pcd, filt_gradient_points=True; renderer_inverse.py:189-209).
+ * attr6 [n][H][W][6] f32 interpolated (position, vertex normal), rast [n][H][W][4], fnormal [F][3], dirs [n][3] ray directions.
+ * tmp: 2*n*H*W bytes.  vis [n][H][W] u8, alpha [n][H][W] f32 (optional).  radius = 15 (the reference's 31-wide pool, along W). */
+int utx_view_visibility(utx_ctx* ctx, const float* attr6, const float* rast, const float* fnormal, const float* dirs, int n, int H, int W,
+                        float grad_thr, float cos_thr, int radius, void* tmp, void* vis, float* alpha, utx_stream stream);
+
+/* exact k-NN gather in 3-D (bake_mv_to_uv_kdtree, renderer_inverse.py:367-433; search = torch_kdtree [3p], pcd/knn/__init__.py:103-113).
+ * Sources and queries are dense arrays with optional byte masks (view pixels / atlas texels); k <= 32.
+ * mode 0: out_attr = mean of the k neighbours' attributes; mode 1: MVPaint weighting (needs normals).
+ * out_idx / out_d2 ([M][k], optional): neighbour ids (ascending squared distance, ties -> lower id), -1 / inf when fewer exist. */
+typedef struct utx_knn_desc {
+    const float* src_pos; const float* src_attr; const float* src_nrm; const unsigned char* src_mask; long N;
+    const float* dst_pos; const float* dst_nrm; const unsigned char* dst_mask; long M;
+    int k, C, mode;
+    float* out_attr; int* out_idx; float* out_d2;
+} utx_knn_desc;
+long utx_knn_workspace_bytes(long N);
+int utx_knn(utx_ctx* ctx, const utx_knn_desc* d, void* work, long work_bytes, utx_stream stream);
+
 /* lens blur consumed on the seam only (image/lens_blur.py:260-280; renderer_inverse.py:620-624).
  * k49_host: HOST array, the collapsed real 7x7 kernel. src/dst [H][W][3] f32. */
 int utx_lens_blur_seam(utx_ctx* ctx, const float* src, const void* seam, int H, int W, const float* k49_host, float* dst, utx_stream stream);

@@ -523,3 +523,148 @@ def texture_shade(rast, uv01, tri, tex, bg=(1.0, 1.0, 1.0)):
     c = top * (one - fy)[..., None] + bot * fy[..., None]
     c = np.where(cov[..., None], c, np.asarray(bg, dtype=f32)[None, None, :]).astype(f32)
     return (np.clip(c, f32(0.0), f32(1.0)) * f32(255.0)).astype(np.uint8)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# non-default back-projection variants
+# ------------------------------------------------------------------------------------------------------------------
+def vertex_normals_area(verts, faces):
+    """PBRMesh.vertex_normals (mesh/structure_v2.py:64-71): face cross products scattered to the three corners, summed,
+    normalised (the mean over the three corner slots only scales the sum)."""
+    v = np.asarray(verts, np.float64)
+    f = np.asarray(faces, np.int64)
+    c = np.cross(v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]])
+    n = np.zeros_like(v)
+    for k in range(3):
+        np.add.at(n, f[:, k], c)
+    zero = (n * n).sum(-1, keepdims=True) <= 1e-20
+    n = np.where(zero, np.array([0.0, 0.0, 1.0]), n)
+    return (n / np.maximum(np.linalg.norm(n, axis=-1, keepdims=True), 1e-12)).astype(np.float32)
+
+
+def view_visibility(attr6, rast, fnormal, dirs, grad_thr=0.20, angle_deg=115.0, radius=15):
+    """mv_to_pcd with filt_gradient_points=True (renderer_inverse.py:189-209), float32, same operation order as the kernel.
+    attr6 [n,H,W,6], rast [n,H,W,4], fnormal [F,3], dirs [n,3] (ray direction per view) -> vis bool [n,H,W].
+    torch.gradient: central differences inside, one-sided at the border.  The reference's MaxPool2d(31, 1, 15) runs on a
+    [n,H,W,1] tensor, i.e. with H as channels: it pools along W only -- a 31-wide erosion of each image ROW."""
+    a = np.asarray(attr6, np.float32)
+    n, H, W, _ = a.shape
+    xm = np.concatenate([a[:, :, :1], a[:, :, :-1]], 2); xp = np.concatenate([a[:, :, 1:], a[:, :, -1:]], 2)
+    ym = np.concatenate([a[:, :1], a[:, :-1]], 1); yp = np.concatenate([a[:, 1:], a[:, -1:]], 1)
+    sx = np.full((1, 1, W, 1), 2.0, np.float32); sx[0, 0, 0, 0] = sx[0, 0, -1, 0] = 1.0
+    sy = np.full((1, H, 1, 1), 2.0, np.float32); sy[0, 0, 0, 0] = sy[0, -1, 0, 0] = 1.0
+    dx = ((xp - xm) / sx).astype(np.float32); dy = ((yp - ym) / sy).astype(np.float32)
+    acc = np.zeros((n, H, W), np.float32)
+    for c in range(6):
+        acc = (acc + (dx[..., c] * dx[..., c] + dy[..., c] * dy[..., c]).astype(np.float32)).astype(np.float32)
+    smooth = np.sqrt(acc).astype(np.float32) < np.float32(grad_thr)
+    tid = np.maximum(rast[..., 3].astype(np.int64) - 1, 0)
+    fn = np.asarray(fnormal, np.float32)[tid]
+    d = np.asarray(dirs, np.float32)[:, None, None, :]
+    nd = np.maximum(np.sqrt(((d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]).astype(np.float32)), np.float32(1e-8))
+    nn = np.maximum(np.sqrt(((fn[..., 0] * fn[..., 0] + fn[..., 1] * fn[..., 1]) + fn[..., 2] * fn[..., 2]).astype(np.float32)), np.float32(1e-8))
+    cs = (((d[..., 0] * fn[..., 0] + d[..., 1] * fn[..., 1]) + d[..., 2] * fn[..., 2]).astype(np.float32) / (nd * nn).astype(np.float32)).astype(np.float32)
+    facing = cs < np.float32(math.cos(math.radians(angle_deg)))
+    er = np.ones_like(smooth)
+    for o in range(-radius, radius + 1):          # erosion along W, out-of-range ignored
+        sh = np.ones_like(smooth)
+        if o < 0:
+            sh[:, :, -o:] = smooth[:, :, :o]
+        elif o > 0:
+            sh[:, :, :-o] = smooth[:, :, o:]
+        else:
+            sh = smooth
+        er &= sh
+    return (rast[..., 3] > 0) & facing & er
+
+
+def knn_brute(src_pos, dst_pos, k, src_mask=None, chunk=2048):
+    """exact k nearest sources per query: d2 = (dx*dx + dy*dy) + dz*dz in float32, ascending, ties -> lower source index.
+    Returns idx [M,k] (into the unmasked source array, -1 when fewer than k exist) and d2 [M,k]."""
+    s = np.asarray(src_pos, np.float32).reshape(-1, 3)
+    q = np.asarray(dst_pos, np.float32).reshape(-1, 3)
+    ids = np.arange(len(s)) if src_mask is None else np.flatnonzero(np.asarray(src_mask).reshape(-1))
+    sv = s[ids]
+    M = len(q)
+    kk = min(k, len(ids))
+    idx = np.full((M, k), -1, np.int64)
+    d2o = np.full((M, k), np.inf, np.float32)
+    for a in range(0, M, chunk):
+        qq = q[a:a + chunk]
+        dx = sv[None, :, 0] - qq[:, None, 0]; dy = sv[None, :, 1] - qq[:, None, 1]; dz = sv[None, :, 2] - qq[:, None, 2]
+        d2 = ((dx * dx + dy * dy).astype(np.float32) + dz * dz).astype(np.float32)
+        order = np.lexsort((np.broadcast_to(ids[None, :], d2.shape), d2), axis=1)[:, :kk]      # by d2, then by index
+        idx[a:a + chunk, :kk] = ids[order]
+        d2o[a:a + chunk, :kk] = np.take_along_axis(d2, order, 1)
+    return idx, d2o
+
+
+def knn_gather(src_pos, src_attr, dst_pos, k, src_mask=None, dst_mask=None, out=None, mode="mean", src_nrm=None, dst_nrm=None):
+    """mean (or MVPaint-weighted mean, renderer_inverse.py:389-399) of the k nearest sources' attributes, written to
+    out[dst_mask]; float32, neighbour order = ascending distance."""
+    sa = np.asarray(src_attr, np.float32).reshape(len(np.asarray(src_pos).reshape(-1, 3)), -1)
+    q = np.asarray(dst_pos, np.float32).reshape(-1, 3)
+    C = sa.shape[1]
+    if out is None:
+        out = np.zeros((len(q), C), np.float32)
+    sel = np.arange(len(q)) if dst_mask is None else np.flatnonzero(np.asarray(dst_mask).reshape(-1))
+    if len(sel) == 0:
+        return out
+    idx, d2 = knn_brute(src_pos, q[sel], k, src_mask)
+    have = (idx >= 0).sum(1)
+    res = np.zeros((len(sel), C), np.float32)
+    if mode == "mean":
+        acc = np.zeros((len(sel), C), np.float32)
+        for j in range(idx.shape[1]):
+            ok = idx[:, j] >= 0
+            acc[ok] = (acc[ok] + sa[idx[ok, j]]).astype(np.float32)
+        res = (acc / np.maximum(have, 1)[:, None].astype(np.float32)).astype(np.float32)
+    else:
+        sn = np.asarray(src_nrm, np.float32).reshape(-1, 3); dn = np.asarray(dst_nrm, np.float32).reshape(-1, 3)[sel]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            inv = (np.float32(1.0) / d2).astype(np.float32)
+        inv = np.where(np.isnan(inv) | (idx < 0), np.float32(0), inv)
+        l1 = np.zeros(len(sel), np.float32)
+        for j in range(idx.shape[1]):
+            l1 = (l1 + np.abs(inv[:, j])).astype(np.float32)
+        ndn = np.maximum(np.sqrt(((dn[:, 0] * dn[:, 0] + dn[:, 1] * dn[:, 1]) + dn[:, 2] * dn[:, 2]).astype(np.float32)), np.float32(1e-8))
+        wsum = np.zeros(len(sel), np.float32)
+        acc = np.zeros((len(sel), C), np.float32)
+        ws = []
+        for j in range(idx.shape[1]):
+            nj = sn[np.maximum(idx[:, j], 0)]
+            nsn = np.maximum(np.sqrt(((nj[:, 0] * nj[:, 0] + nj[:, 1] * nj[:, 1]) + nj[:, 2] * nj[:, 2]).astype(np.float32)), np.float32(1e-8))
+            cs = (((nj[:, 0] * dn[:, 0] + nj[:, 1] * dn[:, 1]) + nj[:, 2] * dn[:, 2]).astype(np.float32) / (nsn * ndn).astype(np.float32)).astype(np.float32)
+            w = ((inv[:, j] / np.maximum(l1, np.float32(1e-12))).astype(np.float32) * cs).astype(np.float32)
+            w = np.where(idx[:, j] >= 0, w, np.float32(0))
+            ws.append(w)
+            wsum = (wsum + w).astype(np.float32)
+        for j in range(idx.shape[1]):
+            acc = (acc + (sa[np.maximum(idx[:, j], 0)] * ws[j][:, None]).astype(np.float32)).astype(np.float32)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            res = (acc / wsum[:, None]).astype(np.float32)
+        res = np.where(np.isfinite(res), res, np.float32(0)).astype(np.float32)
+    out[sel[have > 0]] = res[have > 0]
+    return out
+
+
+def bake_kdtree(view_pos, view_mask, images, vis2d, mask2d, pos2d, nrm2d=None, view_fnormal=None, method="order_mean",
+                k_all=32, k_vis=1, k_inv=32, order=PRIORITY):
+    """bake_mv_to_uv_kdtree (renderer_inverse.py:367-433) on dense layers, before pull_push.
+    view_pos [n,H,W,3], view_mask [n,H,W] bool (mask_visiable), images [n,H,W,C], vis2d [n,T,T] bool, mask2d [T,T] bool,
+    pos2d / nrm2d [T,T,3]; view_fnormal [n,H,W,3] (face normal per view pixel, 'mvpaint')."""
+    n, H, W, C = images.shape
+    T0, T1 = mask2d.shape
+    atlas = np.zeros((T0 * T1, C), np.float32)
+    if method in ("mean", "mvpaint"):
+        kw = {} if method == "mean" else dict(mode="mvpaint", src_nrm=view_fnormal, dst_nrm=nrm2d)
+        knn_gather(view_pos, images, pos2d, k_all, src_mask=view_mask, dst_mask=mask2d, out=atlas, **kw)
+    else:
+        cur = np.zeros((T0, T1), bool)
+        for i in order:
+            extra = (~cur) & vis2d[i]
+            knn_gather(view_pos[i], images[i], pos2d, k_vis, src_mask=view_mask[i], dst_mask=extra, out=atlas)
+            cur |= extra
+        seen = cur & mask2d
+        knn_gather(pos2d, atlas.copy(), pos2d, k_inv, src_mask=seen, dst_mask=mask2d & ~seen, out=atlas)
+    return atlas.reshape(T0, T1, C)

@@ -535,6 +535,52 @@ def g67_backprojection(out):
     np.savez_compressed(os.path.join(out, "g67_backprojection.npz"), **fix)
 
 
+def g11_kdtree_and_filter(out):
+    """the non-default back-projection variants on the small case of G6/G7 (atlas 96^2, views 48^2):
+    mv_to_pcd(filt_gradient_points=True) and bake_mv_to_uv_kdtree ('order_mean', 'mean', 'mvpaint').
+    The knn seam returns SQUARED distances as torch_kdtree does [3p] (only 'mvpaint' reads the scores)."""
+    inv, R, (verts, faces, uvs) = _make_inverse_renderer()
+
+    def knn_sq(src, dst, k=1, **kw):
+        from scipy.spatial import cKDTree
+        d, i = cKDTree(src.numpy().astype(np.float64)).query(dst.numpy().astype(np.float64), k=k)
+        i = torch.from_numpy(np.asarray(i).reshape(dst.shape[0], k)).long()
+        return torch.from_numpy(np.asarray(d).reshape(dst.shape[0], k) ** 2).float(), i
+    R.knn = knn_sq
+    gen = importlib.import_module("TextureTools.texturetools.camera.generator")
+    c2ws = gen.generate_box_views_c2ws(2.8)[[0, 1, 4, 2, 3, 5]]
+    intr = gen.generate_intrinsics(1.0, 1.0, fov=False, degree=False)
+    HW, T = 96, 96
+    rng = np.random.default_rng(23)
+    yy, xx = np.meshgrid(np.linspace(0, 1, HW), np.linspace(0, 1, HW), indexing="ij")
+    imgs = np.zeros((6, HW, HW, 3), np.float32)
+    for v in range(6):
+        ph = rng.uniform(0, 6.28, 6)
+        for c in range(3):
+            imgs[v, ..., c] = 0.5 + 0.5 * np.sin(6 * xx + ph[c]) * np.cos(4 * yy + ph[c + 3])
+    imgs = imgs.astype(np.float16).astype(np.float32)      # exactly representable in half: stored as float16
+    image_attrs = torch.from_numpy(imgs)
+    fix = dict(verts=verts, faces=faces, uvs=uvs, c2ws=c2ws.numpy(), intr=intr.numpy(), images=imgs.astype(np.float16))
+    with torch.no_grad():
+        mv = inv.mv_to_pcd(c2ws, intr, (HW, HW), image_attrs=image_attrs, perspective=False, grad_norm_threhold=0.20,
+                           ray_normal_angle_threhold=115.0, filt_gradient_points=True)
+        fix["mask"] = np.packbits(mv["mask"].numpy())
+        fix["mask_visiable"] = np.packbits(mv["mask_visiable"].numpy())
+        print("view mask: covered %d, visible after filter %d" % (int(mv["mask"].sum()), int(mv["mask_visiable"].sum())))
+        uv = inv.uv_to_pcd(c2ws, intr, (T, T), image_attrs=image_attrs, alpha_attrs=mv["alpha_visiable"], perspective=False,
+                           ray_normal_angle_threhold=115.0)
+        fix["mask_2d"] = np.packbits(uv["mask_2d"].numpy())
+        fix["mask_2d_visiable"] = np.packbits(uv["mask_2d_visiable"].numpy())
+        print("atlas: covered %d, visible per view %s" % (int(uv["mask_2d"].sum()), uv["mask_2d_visiable"].sum((1, 2, 3)).tolist()))
+        for name, kw in (("order_mean", dict(method="order_mean", n_neighbors_visiable=1, n_neighbors_invisiable=4)),
+                         ("mean", dict(method="mean", n_neighbors=4)), ("mvpaint", dict(method="mvpaint", n_neighbors=4))):
+            import copy
+            bake = inv.bake_mv_to_uv_kdtree(mv["point_cloud_visiable"], copy.copy(uv["point_cloud_2d"]), uv["mask_2d"], mv["mask_visiable"],
+                                            uv["mask_2d_visiable"], **kw)
+            fix["color_2d_" + name] = bake["color_2d"].numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(out, "g11_kdtree_and_filter.npz"), **fix)
+
+
 def g9_export_condition(out):
     """VideoExporter.export_condition (video/export_nvdiffrast_video.py:900-999) run through the reference's own code:
     Mesh.scale_to_bbox / apply_transform / vertex normals (mesh/structure.py:190-303,522-548), the 6-view selection and
@@ -634,7 +680,8 @@ def main():
     out = HERE
     torch.set_num_threads(4)
     only = set(sys.argv[1:])
-    for fn in (g1_pipeline, g2_attention, g3_infer_mv, g4_cameras, g5_image_ops, g67_backprojection, g8_bunny, g9_export_condition, g10_preprocess_image):
+    for fn in (g1_pipeline, g2_attention, g3_infer_mv, g4_cameras, g5_image_ops, g67_backprojection, g8_bunny, g9_export_condition, g10_preprocess_image,
+               g11_kdtree_and_filter):
         if only and fn.__name__ not in only:
             continue
         fn(out)

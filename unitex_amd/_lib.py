@@ -57,7 +57,14 @@ class BackprojectDesc(C.Structure):
                 ("view_begin", c_int), ("view_count", c_int), ("cos_thresh", c_float), ("two_sqrt3", c_float)]
 
 
-ABI_STRUCTS = [GemmDesc, GemvDesc, QkvPostDesc, LnModDesc, SchedDesc, BackprojectDesc]
+class KnnDesc(C.Structure):
+    _fields_ = [("src_pos", c_void_p), ("src_attr", c_void_p), ("src_nrm", c_void_p), ("src_mask", c_void_p), ("N", c_long),
+                ("dst_pos", c_void_p), ("dst_nrm", c_void_p), ("dst_mask", c_void_p), ("M", c_long),
+                ("k", c_int), ("C", c_int), ("mode", c_int),
+                ("out_attr", c_void_p), ("out_idx", c_void_p), ("out_d2", c_void_p)]
+
+
+ABI_STRUCTS = [GemmDesc, GemvDesc, QkvPostDesc, LnModDesc, SchedDesc, BackprojectDesc, KnnDesc]
 
 # every symbol include/unitex_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
@@ -92,6 +99,10 @@ SYMBOLS = {
     "utx_dilate_visibility": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "utx_composite": (c_int, [c_void_p, c_void_p, c_void_p, C.POINTER(c_int), c_int, c_long, c_void_p, c_void_p, c_void_p]),
     "utx_seam_mask": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "utx_view_visibility": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_int,
+                                    c_void_p, c_void_p, c_void_p, c_void_p]),
+    "utx_knn_workspace_bytes": (c_long, [c_long]),
+    "utx_knn": (c_int, [c_void_p, C.POINTER(KnnDesc), c_void_p, c_long, c_void_p]),
     "utx_nn_fill_workspace_bytes": (c_long, [c_long]),
     "utx_nn_fill": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
     "utx_lens_blur_seam": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, C.POINTER(c_float), c_void_p, c_void_p]),

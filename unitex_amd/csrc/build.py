@@ -30,6 +30,7 @@ GEOM = [
     ("bvh.hip", ["-ffp-contract=off"]),
     ("backproject.hip", ["-ffp-contract=off"]),
     ("texture_post.hip", ["-ffp-contract=off"]),
+    ("knn.hip", ["-ffp-contract=off"]),
 ]
 for s in GEOM:
     if os.path.exists(os.path.join(HERE, s[0])):

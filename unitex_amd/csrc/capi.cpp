@@ -164,6 +164,16 @@ int utx_seam_mask(utx_ctx* ctx, const void* winner, const float* rast2d, int H, 
     if (!winner || !rast2d || !tmp || !seam) return fail(ctx, -2, "utx_seam_mask");
     UTX_CALL(ctx, "utx_seam_mask", utx_launch_seam_mask(winner, rast2d, H, W, tmp, seam, (hipStream_t)stream));
 }
+int utx_view_visibility(utx_ctx* ctx, const float* attr6, const float* rast, const float* fnormal, const float* dirs, int n, int H, int W,
+                        float grad_thr, float cos_thr, int radius, void* tmp, void* vis, float* alpha, utx_stream stream) {
+    if (!attr6 || !rast || !fnormal || !dirs || !tmp || !vis) return fail(ctx, -2, "utx_view_visibility");
+    UTX_CALL(ctx, "utx_view_visibility", utx_launch_view_visibility(attr6, rast, fnormal, dirs, n, H, W, grad_thr, cos_thr, radius, tmp, vis, alpha, (hipStream_t)stream));
+}
+long utx_knn_workspace_bytes(long N) { return (long)utx_knn_workspace_bytes_impl(N); }
+int utx_knn(utx_ctx* ctx, const utx_knn_desc* d, void* work, long work_bytes, utx_stream stream) {
+    if (!d || !d->src_pos || !d->dst_pos || !work) return fail(ctx, -2, "utx_knn");
+    UTX_CALL(ctx, "utx_knn", utx_launch_knn(d, work, (size_t)work_bytes, (hipStream_t)stream));
+}
 long utx_nn_fill_workspace_bytes(long T) { return (long)utx_nn_fill_workspace_bytes_impl(T); }
 int utx_nn_fill(utx_ctx* ctx, const float* pos, const void* winner, const float* rast2d, long T, float* atlas, int* nn_index,
                 void* work, long work_bytes, utx_stream stream) {
@@ -189,7 +199,8 @@ int utx_to_u8(utx_ctx* ctx, const float* src, long n_rows, long row_elems, int f
 // Layout self-description, so the ctypes mirror in unitex_amd/_lib.py can be checked without a GPU.
 extern "C" int utx_abi_sizes(int* out, int n) {
     const int v[] = {(int)sizeof(utx_gemm_desc), (int)sizeof(utx_gemv_desc), (int)sizeof(utx_qkv_post_desc),
-                     (int)sizeof(utx_ln_mod_desc), (int)sizeof(utx_sched_desc), (int)sizeof(utx_backproject_desc)};
+                     (int)sizeof(utx_ln_mod_desc), (int)sizeof(utx_sched_desc), (int)sizeof(utx_backproject_desc),
+                     (int)sizeof(utx_knn_desc)};
     const int m = (int)(sizeof(v) / sizeof(v[0]));
     for (int i = 0; i < m && i < n; ++i) out[i] = v[i];
     return m;

@@ -22,6 +22,7 @@ struct AttnParams {
     int flag_hs;           // flags per head
 };
 typedef utx_gemm_desc GemmParams;
+typedef utx_knn_desc KnnParams;
 typedef utx_gemv_desc GemvParams;
 typedef utx_qkv_post_desc QkvPostParams;
 typedef utx_ln_mod_desc LnModParams;
@@ -47,6 +48,10 @@ int utx_launch_rasterize(const float* pos, const int* tri, int F, int H, int W, 
 int utx_launch_interpolate(const float* attr, int C, const float* rast, const int* tri, long npix, float* out, hipStream_t stream);
 int utx_launch_condition_shade(const float* rast, const float* nrm, const float* pos, const float* bg3_host, long npix, void* out_normal, void* out_ccm, void* out_alpha, hipStream_t stream);
 int utx_launch_face_normals(const float* verts, const int* faces, int F, float* out, hipStream_t stream);
+int utx_launch_view_visibility(const float* attr6, const float* rast, const float* fnormal, const float* dirs, int n, int H, int W,
+                               float grad_thr, float cos_thr, int radius, void* tmp, void* vis, float* alpha, hipStream_t stream);
+size_t utx_knn_workspace_bytes_impl(long N);
+int utx_launch_knn(const KnnParams* p, void* work, size_t work_bytes, hipStream_t stream);
 int utx_launch_texture_shade(const float* rast, const float* uv, const int* tri, const float* tex, int Ht, int Wt, const float* bg3_host, long npix, void* out, hipStream_t stream);
 int utx_bvh_build_impl(const float* verts, int V, const int* faces, int F, utx_bvh** out, hipStream_t stream);
 void utx_bvh_free_impl(utx_bvh* b);

@@ -310,3 +310,59 @@ extern "C" int utx_launch_face_normals(const float* verts, const int* faces, int
     hipLaunchKernelGGL(face_normals_kernel, dim3((F + 255) / 256), dim3(256), 0, stream, verts, faces, F, out);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
+
+// ---- view-space visibility filter of mv_to_pcd with filt_gradient_points=True (renderer_inverse.py:189-209):
+//   grad  = sqrt(sum_c (d/dx attr_c)^2 + (d/dy attr_c)^2) over the 6 interpolated channels (position, vertex normal),
+//           torch.gradient differences: central (f[i+1] - f[i-1]) / 2 inside, one-sided at the image border;
+//   smooth = grad < grad_thr;   facing = cos(ray, face normal) < cos_thr   (orthographic: one ray direction per view)
+//   visible = covered & facing & erode(smooth), where the reference's nn.MaxPool2d(31, 1, 15) runs on a [n, H, W, 1] tensor,
+//   i.e. it treats H as channels and pools along W only: the erosion is a 31-wide window along the image ROW (kept as is).
+__global__ __launch_bounds__(256) void mv_grad_kernel(const float* attr, const float4* rast, const float* fnormal, const float* dirs,
+                                                      int n, int H, int W, float grad_thr, float cos_thr,
+                                                      unsigned char* smooth, unsigned char* facing) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long npix = (long)n * H * W;
+    if (i >= npix) return;
+    const int x = (int)(i % W), y = (int)((i / W) % H), v = (int)(i / ((long)W * H));
+    const long xm = x > 0 ? i - 1 : i, xp = x < W - 1 ? i + 1 : i;
+    const long ym = y > 0 ? i - W : i, yp = y < H - 1 ? i + W : i;
+    const float sx = (x > 0 && x < W - 1) ? 2.0f : 1.0f, sy = (y > 0 && y < H - 1) ? 2.0f : 1.0f;
+    float acc = 0.f;
+    for (int c = 0; c < 6; ++c) {
+        const float dx = (attr[6 * xp + c] - attr[6 * xm + c]) / sx;
+        const float dy = (attr[6 * yp + c] - attr[6 * ym + c]) / sy;
+        acc += dx * dx + dy * dy;
+    }
+    smooth[i] = (unsigned char)(sqrtf(acc) < grad_thr);
+    const int id = (int)rast[i].w - 1;
+    const float* fn = fnormal + 3 * (long)(id < 0 ? 0 : id);
+    const float* d = dirs + 3 * v;
+    const float nd = fmaxf(sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]), 1e-8f);
+    const float nn = fmaxf(sqrtf((fn[0] * fn[0] + fn[1] * fn[1]) + fn[2] * fn[2]), 1e-8f);
+    const float cs = ((d[0] * fn[0] + d[1] * fn[1]) + d[2] * fn[2]) / (nd * nn);
+    facing[i] = (unsigned char)(cs < cos_thr);
+}
+__global__ __launch_bounds__(256) void mv_visible_kernel(const unsigned char* smooth, const unsigned char* facing, const float4* rast,
+                                                         int n, int H, int W, int radius, unsigned char* vis, float* alpha) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long npix = (long)n * H * W;
+    if (i >= npix) return;
+    const int x = (int)(i % W);
+    bool ok = rast[i].w > 0.f && facing[i];
+    if (ok) {
+        const int x0 = x - radius < 0 ? 0 : x - radius, x1 = x + radius > W - 1 ? W - 1 : x + radius;
+        for (int xx = x0; xx <= x1 && ok; ++xx) ok = smooth[i - x + xx] != 0;
+    }
+    vis[i] = (unsigned char)ok;
+    if (alpha) alpha[i] = ok ? 1.0f : 0.0f;
+}
+extern "C" int utx_launch_view_visibility(const float* attr6, const float* rast, const float* fnormal, const float* dirs, int n, int H, int W,
+                                          float grad_thr, float cos_thr, int radius, void* tmp, void* vis, float* alpha, hipStream_t stream) {
+    const long npix = (long)n * H * W;
+    if (npix <= 0 || radius < 0) return -1;
+    unsigned char* smooth = (unsigned char*)tmp; unsigned char* facing = smooth + npix;
+    const unsigned nb = (unsigned)((npix + 255) / 256);
+    hipLaunchKernelGGL(mv_grad_kernel, dim3(nb), dim3(256), 0, stream, attr6, (const float4*)rast, fnormal, dirs, n, H, W, grad_thr, cos_thr, smooth, facing);
+    hipLaunchKernelGGL(mv_visible_kernel, dim3(nb), dim3(256), 0, stream, smooth, facing, (const float4*)rast, n, H, W, radius, (unsigned char*)vis, alpha);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}

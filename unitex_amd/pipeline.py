@@ -152,7 +152,7 @@ class RGBTextureFullPipelineBase:
         T = self.atlas_size
         textured, reprojected_uv, visable_mask, completed = self.inverse_renderer.infer(
             input_mesh_path, c2ws=cam["c2ws"], intrinsics=cam["intrinsics"], image_attrs=image_attrs, perspective=cam["perspective"],
-            H=HP, W=WP, H2D=T, W2D=T, method=method, reproject_inpainting=inpainting, grad_norm_threhold=0.15,
+            H=HP, W=WP, H2D=T, W2D=T, method=method, kdtree_inpainting=inpainting, reproject_inpainting=inpainting, grad_norm_threhold=0.15,
             ray_normal_angle_threhold=100, filt_gradient_points=inpainting)
         textured.export(os.path.join(save_dir, "textured_mesh.glb"))
 

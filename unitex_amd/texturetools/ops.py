@@ -181,6 +181,65 @@ def seam_mask(winner, rast2d):
     return seam
 
 
+def view_visibility(attr6, rast, fnormal, dirs, grad_thr=0.20, angle_deg=115.0, radius=15):
+    """mv_to_pcd's filt_gradient_points=True visibility (renderer_inverse.py:189-209): attr6 [n,H,W,6] interpolated
+    (position, vertex normal), rast [n,H,W,4], dirs [n,3] ray directions -> (vis u8 [n,H,W], alpha f32 [n,H,W])."""
+    ctx = get_ctx(rast.device.index)
+    n, H, W, _ = rast.shape
+    tmp = torch.empty(2 * n * H * W, dtype=U8, device=rast.device)
+    vis = torch.empty(n, H, W, dtype=U8, device=rast.device)
+    alpha = torch.empty(n, H, W, dtype=F32, device=rast.device)
+    cos_thr = float(np.float32(math.cos(math.radians(angle_deg))))
+    ctx.check(ctx.lib.utx_view_visibility(ctx.handle, ptr(_f(attr6)), ptr(_f(rast)), ptr(_f(fnormal)), ptr(_f(dirs)), n, H, W,
+                                          float(grad_thr), cos_thr, int(radius), ptr(tmp), ptr(vis), ptr(alpha), ctx.stream()))
+    return vis, alpha
+
+
+def knn_gather(src_pos, dst_pos, k, src_attr=None, src_mask=None, dst_mask=None, out=None, mode="mean", src_nrm=None, dst_nrm=None,
+               want_index=False):
+    """exact k-NN in 3-D over dense, byte-masked point sets (bake_mv_to_uv_kdtree, renderer_inverse.py:367-433).
+    src_pos [N,3], dst_pos [M,3]; src_attr [N,C] -> out [M,C] (written only where dst_mask): mean of the k neighbours'
+    attributes, or the MVPaint weighting (mode='mvpaint').  want_index: also return (idx [M,k] i32, d2 [M,k] f32)."""
+    from .._lib import KnnDesc
+    ctx = get_ctx(src_pos.device.index)
+    dev = src_pos.device
+    src_pos, dst_pos = _f(src_pos).reshape(-1, 3), _f(dst_pos).reshape(-1, 3)
+    N, M = src_pos.shape[0], dst_pos.shape[0]
+    d = KnnDesc()
+    keep = [src_pos, dst_pos]
+    d.src_pos, d.dst_pos, d.N, d.M, d.k = ptr(src_pos), ptr(dst_pos), N, M, int(k)
+    d.mode = {"mean": 0, "mvpaint": 1}[mode]
+    if src_attr is not None:
+        src_attr = _f(src_attr).reshape(N, -1)
+        d.C = src_attr.shape[1]
+        if out is None:
+            out = torch.zeros(M, d.C, dtype=F32, device=dev)
+        assert out.is_contiguous() and out.dtype == F32 and out.numel() == M * d.C
+        d.src_attr, d.out_attr = ptr(src_attr), ptr(out)
+        keep += [src_attr, out]
+    for name, t in (("src_mask", src_mask), ("dst_mask", dst_mask)):
+        if t is not None:
+            t = t.reshape(-1).to(U8).contiguous()
+            keep.append(t)
+            setattr(d, name, ptr(t))
+    for name, t in (("src_nrm", src_nrm), ("dst_nrm", dst_nrm)):
+        if t is not None:
+            t = _f(t).reshape(-1, 3)
+            keep.append(t)
+            setattr(d, name, ptr(t))
+    idx = d2 = None
+    if want_index:
+        idx = torch.empty(M, int(k), dtype=I32, device=dev)
+        d2 = torch.empty(M, int(k), dtype=F32, device=dev)
+        d.out_idx, d.out_d2 = ptr(idx), ptr(d2)
+    wb = ctx.lib.utx_knn_workspace_bytes(N)
+    work = torch.empty(wb, dtype=U8, device=dev)
+    ctx.check(ctx.lib.utx_knn(ctx.handle, C.byref(d), ptr(work), wb, ctx.stream()))
+    if want_index:
+        return out, idx, d2
+    return out
+
+
 def nn_fill(atlas, winner, rast2d, pos, want_index=False):
     """in place on atlas [H,W,3]"""
     ctx = get_ctx(atlas.device.index)

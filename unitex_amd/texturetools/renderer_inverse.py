@@ -41,6 +41,15 @@ class DeviceMesh:
         self.uvs_2d = (torch.as_tensor(uvs, dtype=torch.float32) * 2.0 - 1.0).to(self.device).contiguous()  # structure_v2.py:287
         self.normals = ops.face_normals(self.vertices, self.faces)      # HIP, bit-exact vs the oracle's op order
         self._bvh = None
+        self._vertex_normals = None
+
+    @property
+    def vertex_normals(self):
+        """area-weighted vertex normals (mesh/structure_v2.py:64-71: face cross products scattered to the corners, normalised)."""
+        if self._vertex_normals is None:
+            from .video import _vertex_normals
+            self._vertex_normals = _vertex_normals(self.vertices.cpu(), self.faces.cpu(), weighting="area").to(self.device)
+        return self._vertex_normals
 
     @property
     def optix(self):
@@ -125,32 +134,112 @@ class NVDiffRendererInverse:
         mvp = torch.matmul(camera.intr_to_proj(intr, perspective=perspective), camera.c2w_to_w2c(c2ws))
         return mvp.to(self.device).contiguous(), c2ws
 
-    def mv_to_pcd(self, c2ws, intrinsics, render_size, perspective=True):
-        """view-space coverage alpha [n,H,W] (float 0/1) -- all that the 'reproject' path consumes of the
-        reference's mv_to_pcd when filt_gradient_points=False (renderer_inverse.py:183-185,211-213)."""
+    def mv_to_pcd(self, c2ws, intrinsics, render_size, perspective=True, grad_norm_threhold=0.20, ray_normal_angle_threhold=115.0,
+                  filt_gradient_points=False, want_points=False):
+        """view-space pass of the reference's mv_to_pcd (renderer_inverse.py:159-241), dense instead of compacted:
+          alpha [n,H,W] f32 = mask_visiable as float: plain coverage, or with filt_gradient_points=True coverage AND
+          back-facing-ray test AND the (row-wise, 31 wide) eroded gradient test (:189-209);
+          want_points: also pos [n,H,W,3] (interpolated vertex positions = the point cloud of :224-232) and the raster."""
         H, W = (render_size, render_size) if isinstance(render_size, int) else render_size
         m = self.pbr_mesh
-        mvp, _ = self._mvp(c2ws, intrinsics, perspective)
+        mvp, c2ws_cpu = self._mvp(c2ws, intrinsics, perspective)
         clip, ndc = ops.transform_points(m.vertices, mvp)
-        alpha = torch.empty(mvp.shape[0], H, W, dtype=torch.float32, device=self.device)
-        for v in range(mvp.shape[0]):
-            rast = ops.rasterize(clip[v].contiguous(), m.faces, H, W)
-            alpha[v] = (rast[..., 3] > 0).float()
-        return {"alpha": alpha, "clip": clip, "ndc": ndc}
+        n = mvp.shape[0]
+        rast = torch.empty(n, H, W, 4, dtype=torch.float32, device=self.device)
+        for v in range(n):
+            rast[v] = ops.rasterize(clip[v].contiguous(), m.faces, H, W)
+        out = {"clip": clip, "ndc": ndc}
+        attrs = None
+        if filt_gradient_points or want_points:
+            va = torch.cat([m.vertices, m.vertex_normals], dim=-1).contiguous()
+            attrs = ops.interpolate(va, rast.view(n * H, W, 4), m.faces).view(n, H, W, 6)
+        if filt_gradient_points:
+            assert not perspective
+            dirs = torch.nn.functional.normalize(-c2ws_cpu[:, :3, 2], dim=-1).contiguous().to(self.device)
+            vis, alpha = ops.view_visibility(attrs, rast, m.normals, dirs, grad_thr=grad_norm_threhold, angle_deg=ray_normal_angle_threhold)
+        else:
+            alpha = (rast[..., 3] > 0).float()
+            vis = (rast[..., 3] > 0).to(torch.uint8)
+        out["alpha"], out["mask_visiable"] = alpha, vis
+        if want_points:
+            out["pos"] = attrs[..., :3].contiguous()
+            out["rast"] = rast
+        return out
+
+    def query_field(self, vertices_visiable, colors_visiable, vertices_invisiable):
+        """the LTM hook (renderer_inverse.py:143-157): colours for unseen points from the seen ones."""
+        if self.query_field_function is None:
+            raise NotImplementedError("using register_query_field before query")
+        return self.query_field_function(vertices_visiable, colors_visiable, vertices_invisiable)
+
+    def _fill_unseen(self, atlas, seen_u8, covered, pos, inpainting, k=1):
+        """colours for covered-but-unseen texels, in place on atlas [H2D,W2D,C]: the k nearest seen texels in 3-D (mean),
+        or the registered query field (renderer_inverse.py:420-426 / :606-615)."""
+        unseen = covered & (seen_u8 == 0)
+        if inpainting:
+            seen_b = seen_u8.bool()
+            col = self.query_field(pos[seen_b], atlas[seen_b], pos[unseen])      # compaction only at this (user) boundary
+            atlas[unseen] = torch.as_tensor(col, dtype=torch.float32, device=atlas.device)
+        else:
+            ops.knn_gather(pos, pos, k, src_attr=atlas, src_mask=seen_u8, dst_mask=unseen.to(torch.uint8), out=atlas.view(-1, atlas.shape[-1]))
+        return unseen
+
+    def _bake_kdtree(self, mv, images, vis, rast2d, pos2d, method, k_all, k_vis, k_inv, inpainting):
+        """bake_mv_to_uv_kdtree (renderer_inverse.py:367-433) on dense layers.
+        mv: view pass (pos [n,H,W,3], mask_visiable [n,H,W]); images [n,H,W,C]; vis [n,H2D,W2D] u8; pos2d [H2D,W2D,3]."""
+        n, Hh, Ww, C = images.shape
+        H2D, W2D = rast2d.shape[:2]
+        covered = rast2d[..., 3] > 0
+        cov_u8 = covered.to(torch.uint8)
+        atlas = torch.zeros(H2D, W2D, C, dtype=torch.float32, device=self.device)
+        if method in ("mean", "mvpaint"):
+            if method == "mean" and inpainting:
+                b = mv["mask_visiable"].bool()
+                col = self.query_field(mv["pos"][b], images[b], pos2d[covered])
+                atlas[covered] = torch.as_tensor(col, dtype=torch.float32, device=self.device)
+            else:
+                kw = {}
+                if method == "mvpaint":   # both point clouds carry FACE normals (renderer_inverse.py:226-233, 350)
+                    tid = (mv["rast"][..., 3].long() - 1).clamp_(min=0)
+                    tid2 = (rast2d[..., 3].long() - 1).clamp_(min=0)
+                    kw = dict(mode="mvpaint", src_nrm=self.pbr_mesh.normals[tid.view(-1)], dst_nrm=self.pbr_mesh.normals[tid2.view(-1)])
+                ops.knn_gather(mv["pos"], pos2d, k_all, src_attr=images, src_mask=mv["mask_visiable"], dst_mask=cov_u8,
+                               out=atlas.view(-1, C), **kw)
+        elif method == "order_mean":
+            current = torch.zeros(H2D, W2D, dtype=torch.bool, device=self.device)
+            for i in self.index:
+                extra = (~current) & vis[i].bool()
+                ops.knn_gather(mv["pos"][i], pos2d, k_vis, src_attr=images[i], src_mask=mv["mask_visiable"][i],
+                               dst_mask=extra.to(torch.uint8), out=atlas.view(-1, C))
+                current |= extra
+            self._fill_unseen(atlas, (current & covered).to(torch.uint8), covered, pos2d, inpainting, k=k_inv)
+        else:
+            raise NotImplementedError("method %s is not supported" % method)
+        return atlas
 
     def infer(self, blank_mesh, c2ws, intrinsics, image_attrs, H=512, W=512, H2D=2048, W2D=2048, perspective=True,
               grad_norm_threhold=0.20, ray_normal_angle_threhold=115.0, grid_interpolate_mode="torch", method="reproject",
-              reproject_method="lens", reproject_inpainting=False, filt_gradient_points=True, return_layers=False, **unused):
-        assert method == "reproject", "only the default 'reproject' path is built (kdtree / blending variants: SURVEY 8f rank 4)"
+              kdtree_n_neighbors=32, kdtree_n_neighbors_visiable=1, kdtree_n_neighbors_invisiable=32, kdtree_method="order_mean",
+              kdtree_inpainting=False, reproject_method="lens", reproject_inpainting=False, filt_gradient_points=True,
+              return_layers=False, **unused):
+        """renderer_inverse.py:635-726.  method='reproject' is bake_mv_to_uv_reproject_blur (the pipeline's path),
+        method='kdtree' bake_mv_to_uv_kdtree ('order_mean' | 'mean' | 'mvpaint'); *_inpainting=True routes the unseen texels
+        through the registered query field (the LTM hook) instead of the nearest-neighbour fill; filt_gradient_points adds
+        the gradient / facing filter to the view masks.  Colours: 3 channels (rgb) or 9 (PBR stack) for 'kdtree', 3 for 'reproject'."""
+        assert method in ("kdtree", "reproject")
         assert not perspective, "the reference's texture path is orthographic (pipeline.py:208-210)"
-        assert not filt_gradient_points and not reproject_inpainting, "LTM / inpainting branch is unreleased in the reference"
+        assert reproject_method == "lens"
         assert len(self.index) == image_attrs.shape[0] == torch.as_tensor(c2ws).shape[0]
         m = self.pbr_mesh
         n = image_attrs.shape[0]
         dev = self.device
+        image_attrs = torch.as_tensor(image_attrs, dtype=torch.float32).to(dev)
         with self._stage("view_raster"):
-            mv = self.mv_to_pcd(c2ws, intrinsics, (H, W), perspective=perspective)
-        images = torch.cat([torch.as_tensor(image_attrs, dtype=torch.float32).to(dev), mv["alpha"][..., None]], dim=-1).contiguous()
+            mv = self.mv_to_pcd(c2ws, intrinsics, (H, W), perspective=perspective, grad_norm_threhold=grad_norm_threhold,
+                                ray_normal_angle_threhold=ray_normal_angle_threhold, filt_gradient_points=filt_gradient_points,
+                                want_points=(method == "kdtree"))
+        # the alpha channel the texels sample is mask_visiable (uv_to_pcd(alpha_attrs=alpha_visiable), :661-670)
+        images = torch.cat([image_attrs[..., :3], mv["alpha"][..., None]], dim=-1).contiguous()
         _, c2ws_cpu = self._mvp(c2ws, intrinsics, perspective)
         dirs = (-c2ws_cpu[:, :3, 2]).contiguous().to(dev)
         # UV-space raster: uv in [-1,1] used directly as clip xy, z = 0, w = 1 (renderer_inverse.py:268-274)
@@ -173,22 +262,37 @@ class NVDiffRendererInverse:
             vis = ops.dilate_visibility(rayvis, alphaok, rast2d)
         if world > 1:
             color, vis = self._gather_layers(color, vis, per, n)
-        with self._stage("composite"):
-            atlas, winner = ops.composite(color, vis, self.index)
-        with self._stage("seam_mask"):
-            seam = ops.seam_mask(winner, rast2d)
-        with self._stage("nn_fill"):
-            pos = ops.interpolate(m.vertices, rast2d, m.faces)
-            ops.nn_fill(atlas, winner, rast2d, pos)
-        with self._stage("lens_blur_seam"):
-            blurred = ops.lens_blur_seam(atlas, seam)
         mask_u8 = (rast2d[..., 3] > 0).to(torch.uint8).contiguous()
+        winner = seam = None
+        if method == "reproject":
+            assert image_attrs.shape[-1] == 3
+            with self._stage("composite"):
+                atlas, winner = ops.composite(color, vis, self.index)
+            with self._stage("seam_mask"):
+                seam = ops.seam_mask(winner, rast2d)
+            with self._stage("nn_fill"):
+                pos = ops.interpolate(m.vertices, rast2d, m.faces)
+                if reproject_inpainting:
+                    self._fill_unseen(atlas, (winner >= 0).to(torch.uint8), rast2d[..., 3] > 0, pos, True)
+                else:
+                    ops.nn_fill(atlas, winner, rast2d, pos)
+            with self._stage("lens_blur_seam"):
+                baked = ops.lens_blur_seam(atlas, seam)
+        else:
+            with self._stage("kdtree_bake"):
+                pos2d = ops.interpolate(m.vertices, rast2d, m.faces)
+                baked = self._bake_kdtree(mv, image_attrs.contiguous(), vis, rast2d, pos2d,
+                                          kdtree_method, kdtree_n_neighbors, kdtree_n_neighbors_visiable, kdtree_n_neighbors_invisiable,
+                                          kdtree_inpainting)
         with self._stage("pull_push"):
-            color_2d = ops.pull_push(blurred, mask_u8)
+            if baked.shape[-1] == 3:
+                color_2d = ops.pull_push(baked, mask_u8)
+            else:   # PBR stack: three rgb groups through the same 3-channel kernel
+                color_2d = torch.cat([ops.pull_push(baked[..., c:c + 3].contiguous(), mask_u8) for c in range(0, baked.shape[-1], 3)], dim=-1)
         with self._stage("to_u8"):
-            tex = ops.to_u8(color_2d, flip=True)  # tensor_to_image + FLIP_TOP_BOTTOM (link_pbr_to_mesh.py:17)
+            tex = ops.to_u8(color_2d[..., :3].contiguous(), flip=True)  # tensor_to_image + FLIP_TOP_BOTTOM (link_pbr_to_mesh.py:17)
         textured = TexturedMesh(m.vertices.cpu().numpy(), m.faces.cpu().numpy(), m.uvs01, tex.cpu().numpy())
-        self.last = {"rast2d": rast2d, "winner": winner, "seam": seam, "atlas_prefill": atlas}
+        self.last = {"rast2d": rast2d, "winner": winner, "seam": seam, "atlas_prefill": baked, "view_mask": mv["mask_visiable"]}
         out = (textured, vis.bool()[..., None], (rast2d[..., 3] > 0)[None, ..., None], color_2d[None])
         if return_layers:
             return out + (color, vis)
