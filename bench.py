@@ -120,6 +120,9 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("UTX_WORKLOAD", "strip1024x6"), choices=sorted(WORKLOADS))
     ap.add_argument("--lora-rank", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the per-step plan as one HIP graph (FluxDiT.capture_graph) in the timed region; the roofline "
+                         "kernel is then timed in one extra eager step after it (events cannot bracket kernels inside a graph)")
     ap.add_argument("--parallelism", default=os.environ.get("UTX_PARALLELISM", "replicas"), choices=["replicas", "ulysses"],
                     help="N > 1: 'replicas' = N independent jobs (weak scaling, default); 'ulysses' = ONE job, head-parallel "
                          "sequence parallelism with two all-to-alls per layer over RCCL (strong scaling)")
@@ -198,17 +201,26 @@ def main():
 
     for i in range(args.warmup):
         one_step(i)
+    use_graph = args.graph and not ulysses
+    if use_graph:
+        model.attn_events = None
+        model.capture_graph()
+        one_step(0)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     events = []
     t0 = time.perf_counter()
     for i in range(args.warmup, total):
-        one_step(i, events)
+        one_step(i, None if use_graph else events)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if use_graph:
+        model.release_graph()
+        one_step(total - 1, events)
+        torch.cuda.synchronize()
     if world > 1:
         import torch.distributed as dist
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -229,12 +241,13 @@ def main():
             "higher_is_better": True, "scaling": "strong" if ulysses else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": args.workload, "description": desc, "tokens": S, "text_tokens": S_txt,
                        "noise_tokens": n_noise, "control_tokens": n_ctrl, "dual_tokens": n_dual,
-                       "lora_rank": args.lora_rank, "guidance": 3.5, "parallelism": ("ulysses sp%d (one job, 2 all-to-alls / layer)" % world) if ulysses else "replicas x%d" % world,
+                       "lora_rank": args.lora_rank, "guidance": 3.5, "launch": "hip graph replay" if use_graph else "eager stream launches", "parallelism": ("ulysses sp%d (one job, 2 all-to-alls / layer)" % world) if ulysses else "replicas x%d" % world,
                        "tflop_per_step": fl / 1e12, "achieved_tflops_per_gpu": fl / (dt / args.steps) / 1e12 / (world if ulysses else 1),
                        "sec_per_mesh_texture_dit_only": 56.0 * dt / args.steps},
             "roofline": {"bound": "mfma", "kernel": "attn_fwd_glds_kernel", "achieved": achieved, "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
                          "launches_timed": len(attn_ms), "avg_launch_ms": attn_avg_ms,
+                         "timed_in": "one eager step after the timed region (graph mode)" if use_graph else "the timed region",
                          "flops_per_launch": attn_launch_flops,
                          "attention_share_of_step_time": (attn_avg_ms * (N_DOUBLE + N_SINGLE)) / (dt / args.steps * 1e3)},
         }

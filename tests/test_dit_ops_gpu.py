@@ -429,3 +429,39 @@ def test_attention_q64_kernel_and_repair_pass(S, ramp_max):
             os.environ.pop("UTX_ATTN_Q64", None)
         else:
             os.environ["UTX_ATTN_Q64"] = old
+
+
+def test_hip_graph_replay_is_bit_identical_to_the_eager_plan():
+    """FluxDiT.capture_graph(): the whole per-step plan recorded into one HIP graph.  Replays must equal eager launches bit
+    for bit, follow new latents / timesteps / conditioning (device-side inputs of the captured kernels), and a changed
+    adapter set must drop the graph."""
+    from unitex_amd.flux.transformer import FluxDiT, FluxShape
+    cfg = dit_ref.tiny_config(heads=2, double=2, single=2, joint_dim=64, pooled_dim=64)
+    sd = dit_ref.make_synthetic_state_dict(cfg, seed=4)
+    shape = FluxShape(num_heads=2, num_double=2, num_single=2, joint_dim=64, pooled_dim=64)
+    S_txt, S_img = 64, 8 * 24 + 8 * 24 + 16
+    g = torch.Generator().manual_seed(9)
+    lats = [torch.randn(S_img, 64, generator=g).to(BF).cuda() for _ in range(3)]
+    encs = [(0.5 * torch.randn(S_txt, 64, generator=g)).to(BF).cuda() for _ in range(2)]
+    pooled = (0.5 * torch.randn(1, 64, generator=g)).to(BF).cuda()
+    txt_ids = torch.zeros(S_txt, 3)
+    img_ids = torch.cat([dit_ref.latent_image_ids(8, 24), dit_ref.latent_image_ids(8, 24, offset_y=8),
+                         dit_ref.latent_image_ids(4, 4, offset_x=24, offset_y=8)], 0)
+    m = FluxDiT(sd, shape, device="cuda:0")
+    m.set_lora([(dit_ref.make_synthetic_lora(cfg, sd, rank=16, seed=2), 1.0)])
+    m.set_positions(txt_ids, img_ids)
+    cases = [(lats[0], 0.4375, encs[0]), (lats[1], 0.875, encs[0]), (lats[2], 0.125, encs[1])]
+    eager = []
+    for lat, t, enc in cases:
+        m.set_conditioning(enc, pooled, 3.5)
+        eager.append(m.forward(lat, t).clone())
+    m.set_conditioning(encs[0], pooled, 3.5)
+    m.capture_graph()
+    assert m._graphs
+    for (lat, t, enc), ref in zip(cases, eager):
+        m.set_conditioning(enc, pooled, 3.5)
+        out = m.forward(lat, t).clone()
+        torch.cuda.synchronize()
+        assert torch.equal(out.view(torch.int16), ref.view(torch.int16)), "graph replay differs from eager launches"
+    m.set_lora([])
+    assert not m._graphs, "a new adapter set must drop the captured graph"

@@ -89,6 +89,7 @@ class FluxDiT:
         self.ctx = ops.get_ctx(self.device.index or 0)
         self.lib = self.ctx.lib
         self._plans = {}
+        self._graphs = {}
         self._lora_active: List[Tuple[Dict, float]] = []
         self._lora_version = 0
         self.attn_events = None
@@ -173,6 +174,7 @@ class FluxDiT:
         self._lora_active = [(d, float(s)) for d, s in adapters if float(s) != 0.0]
         self._lora_version += 1
         self._plans.clear()
+        self._graphs = {}
         self._pack_lora()
 
     def _pack_lora(self):
@@ -393,6 +395,7 @@ class FluxDiT:
         key = (S_txt, S_img, self._lora_version)
         if key not in self._plans:
             self._plans.clear()  # one live plan: workspaces are large
+            self._graphs = {}
             self._plans[key] = self._build(S_txt, S_img)
         return self._plans[key]
 
@@ -482,10 +485,34 @@ class FluxDiT:
         ws["tproj"].copy_(_timestep_proj(t1000), non_blocking=True)
         if hidden_states.data_ptr() != ws["lat"].data_ptr():
             ws["lat"].copy_(hidden_states.reshape(ws["lat"].shape))
-        self.run_plan(p)
+        g = self._graphs.get(id(p))
+        if g is not None:
+            g.replay()
+        else:
+            self.run_plan(p)
         if out is not None:
             out.copy_(ws["out"])
             return out
         return ws["out"]
+
+    def capture_graph(self):
+        """Record the current plan (~700 stream-ordered launches, fixed descriptors and workspaces, no host syncs) into a
+        HIP graph; forward() then replays it.  The two host->device copies of forward (timestep projection, latents) stay
+        outside the graph.  One eager run first: first-use setup (kernel attributes, lazily sized buffers) must not happen
+        under capture.  Positions, conditioning and LoRA scales are read from device buffers, so they can change between
+        replays; a new sequence length or adapter set builds a new plan and drops the graph."""
+        p = next(iter(self._plans.values()))
+        if getattr(self, "attn_events", None) is not None:
+            raise RuntimeError("per-kernel event timing and graph replay are exclusive")
+        self.run_plan(p)
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.run_plan(p)
+        self._graphs = {id(p): g}
+        return g
+
+    def release_graph(self):
+        self._graphs = {}
 
     __call__ = forward
