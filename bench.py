@@ -244,7 +244,7 @@ def main():
                        "lora_rank": args.lora_rank, "guidance": 3.5, "launch": "hip graph replay" if use_graph else "eager stream launches", "parallelism": ("ulysses sp%d (one job, 2 all-to-alls / layer)" % world) if ulysses else "replicas x%d" % world,
                        "tflop_per_step": fl / 1e12, "achieved_tflops_per_gpu": fl / (dt / args.steps) / 1e12 / (world if ulysses else 1),
                        "sec_per_mesh_texture_dit_only": 56.0 * dt / args.steps},
-            "roofline": {"bound": "mfma", "kernel": "attn_fwd_glds_kernel", "achieved": achieved, "peak": PEAK_BF16_TFLOPS,
+            "roofline": {"bound": "mfma", "kernel": "attn_fwd_glds_kernel", "launches_per_call": "full rounds + key-split tail round (same kernel) + attn_merge_kernel; a 'launch' below is one utx_attn_fwd_bf16 call", "achieved": achieved, "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
                          "launches_timed": len(attn_ms), "avg_launch_ms": attn_avg_ms,
                          "timed_in": "one eager step after the timed region (graph mode)" if use_graph else "the timed region",

@@ -465,3 +465,29 @@ def test_hip_graph_replay_is_bit_identical_to_the_eager_plan():
         assert torch.equal(out.view(torch.int16), ref.view(torch.int16)), "graph replay differs from eager launches"
     m.set_lora([])
     assert not m._graphs, "a new adapter set must drop the captured graph"
+
+
+@pytest.mark.parametrize("S", [2830, 4096])
+def test_attention_tail_split_matches_oracle_and_unsplit_launch(S):
+    """more workgroups than CUs: the partly filled last round is cut along the keys (partial outputs + log-sum-exp, merged by
+    a second kernel).  Rows of the full rounds must be bit-identical to the unsplit launch, tail rows within the usual
+    tolerance of the oracle (one more bf16 rounding of the partial outputs)."""
+    H = 24
+    q, k, v = _mk_attn_inputs(H, S, seed=S, spike=True)
+    old = os.environ.get("UTX_ATTN_TAILSPLIT")
+    try:
+        os.environ["UTX_ATTN_TAILSPLIT"] = "0"
+        plain = _run_attn(q, k, v)
+        os.environ["UTX_ATTN_TAILSPLIT"] = "1"
+        split = _run_attn(q, k, v)
+    finally:
+        if old is None:
+            os.environ.pop("UTX_ATTN_TAILSPLIT", None)
+        else:
+            os.environ["UTX_ATTN_TAILSPLIT"] = old
+    ref = dit_ref.sdpa(q.float(), k.float(), v.float(), em=False)
+    assert (split - ref).abs().max().item() < 4e-2
+    same = (split == plain).all(dim=-1)                       # [H, S] rows identical to the unsplit launch
+    frac_changed = 1.0 - same.float().mean().item()
+    assert 0.0 < frac_changed < 0.5, "the tail (and only the tail) goes through the split path: %g of the rows changed" % frac_changed
+    assert (split - plain).abs().max().item() < 3e-2

@@ -38,10 +38,17 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lq = lane & 31, lh = lane >> 5;
 
-    const int w = xcd_remap(blockIdx.x, gridDim.x);
+    const int wid = xcd_remap(blockIdx.x, gridDim.x);
+    const int nsp = p.nsplit;                        // > 1: this launch covers the tail items, each cut along the keys
+    const int item = nsp > 1 ? wid / nsp : wid;
+    const int split = wid - item * nsp;
+    const int w = p.w_base + item;
     const int head = w / p.nqb;
     const int qb = w - head * p.nqb;
     const int S = p.S;
+    // keys of this workgroup: all of them, or tiles [tb, tb + tiles_per_split) of the sequence (base pointers are advanced, Sk counts from there)
+    const int tb = nsp > 1 ? split * p.tiles_per_split : 0;
+    const int Sk = nsp > 1 ? ((S - tb * AG_KVB < p.tiles_per_split * AG_KVB) ? S - tb * AG_KVB : p.tiles_per_split * AG_KVB) : S;
     if (p.flags) {
         // repair pass behind the 4 x 64 kernel: only query blocks in which one of its waves ran out of softmax headroom
         const unsigned char* f = p.flags + head * p.flag_hs + qb * 4;
@@ -49,8 +56,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
         for (int g = 0; g < 4; ++g) any |= (qb * 4 + g < p.flag_hs) ? f[g] : 0;
         if (!any) return;
     }
-    const bf16_t* kbase = p.k + (long)head * p.k_hs;
-    const bf16_t* vbase = p.vt + (long)head * p.vt_hs;
+    const bf16_t* kbase = p.k + (long)head * p.k_hs + (long)tb * AG_KVB * p.k_ss;
+    const bf16_t* vbase = p.vt + (long)head * p.vt_hs + tb * AG_KVB;
 
     const int q0 = qb * 256 + wave * 32;
     bf16x8 qf[8];
@@ -105,7 +112,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) negm[r] = 0.f;
 
-    const int nt = (S + AG_KVB - 1) / AG_KVB;
+    const int nt = (Sk + AG_KVB - 1) / AG_KVB;
     const int ngrp = (nt + TPB - 1) / TPB;
 #pragma unroll
     for (int i = 0; i < TPB; ++i)
@@ -124,8 +131,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
         if (t >= nt) break;
         const char* kb = kring + (gs + sub) * AG_KTILE;
         const char* vb = vring + (gs + sub) * AG_VTILE;
-        const bool ragged = (t == nt - 1) && (S & (AG_KVB - 1));
-        const int lim = S - t * AG_KVB - 8 * lh;
+        const bool ragged = (t == nt - 1) && (Sk & (AG_KVB - 1));
+        const int lim = Sk - t * AG_KVB - 8 * lh;
 
         f32x16 sa0, sa1;
         bf16x8 kfa[8], kfb[8], vfa[8], vfb[8];
@@ -232,6 +239,24 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
     const int qrow = q0 + lq;
+    if (nsp > 1) {
+        // partial result of this key range: normalised rows (bf16) + log2-sum-exp; attn_merge_kernel combines the ranges
+        const long prow = ((long)item * nsp + split) * 256 + wave * 32 + lq;
+        if (qrow < S) {
+            bf16_t* op = p.part_o + prow * 128 + 4 * lh;
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    uint2 v;
+                    v.x = pack2bf(oacc[db][4 * a + 0] * inv, oacc[db][4 * a + 1] * inv);
+                    v.y = pack2bf(oacc[db][4 * a + 2] * inv, oacc[db][4 * a + 3] * inv);
+                    *reinterpret_cast<uint2*>(op + 32 * db + 8 * a) = v;
+                }
+            if (lh == 0) p.part_lse[prow] = (PRESC ? m_run : m_run * c2) + __builtin_amdgcn_logf(l_tot);
+        }
+        return;
+    }
     if (qrow < S) {
         bf16_t* op = p.o + (long)qrow * p.o_ss + head * 128 + 4 * lh;
 #pragma unroll
@@ -246,6 +271,41 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
     }
 }
 
+// combine the key ranges of the tail items: out = sum_i 2^(lse_i - M) O_i / sum_i 2^(lse_i - M).  One thread per (query, 8 channels).
+__global__ __launch_bounds__(256) void attn_merge_kernel(AttnParams p, int n_items) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)n_items * 256 * 16;
+    if (t >= total) return;
+    const int c8 = (int)(t & 15);
+    const int ql = (int)((t >> 4) & 255);
+    const int item = (int)(t >> 12);
+    const int w = p.w_base + item;
+    const int head = w / p.nqb, qb = w - head * p.nqb;
+    const int qrow = qb * 256 + ql;
+    if (qrow >= p.S) return;
+    const int nsp = p.nsplit;
+    float M = -INFINITY;
+    for (int i = 0; i < nsp; ++i) M = fmaxf(M, p.part_lse[((long)item * nsp + i) * 256 + ql]);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, W = 0.f;
+    for (int i = 0; i < nsp; ++i) {
+        const long prow = ((long)item * nsp + i) * 256 + ql;
+        const float wgt = __builtin_amdgcn_exp2f(p.part_lse[prow] - M);
+        W += wgt;
+        const uint4 v = *reinterpret_cast<const uint4*>(p.part_o + prow * 128 + 8 * c8);
+        const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc[2 * j] += wgt * __uint_as_float(u[j] << 16);
+            acc[2 * j + 1] += wgt * __uint_as_float(u[j] & 0xffff0000u);
+        }
+    }
+    const float inv = 1.0f / W;
+    uint4 o;
+    o.x = pack2bf(acc[0] * inv, acc[1] * inv); o.y = pack2bf(acc[2] * inv, acc[3] * inv);
+    o.z = pack2bf(acc[4] * inv, acc[5] * inv); o.w = pack2bf(acc[6] * inv, acc[7] * inv);
+    *reinterpret_cast<uint4*>(p.o + (long)qrow * p.o_ss + head * 128 + 8 * c8) = o;
+}
+
 template <int PRESC, int TPB, int VAR = 0>
 static int launch_glds(AttnParams p, hipStream_t stream) {
     static bool attr_set = false;
@@ -255,7 +315,49 @@ static int launch_glds(AttnParams p, hipStream_t stream) {
         attr_set = true;
     }
     p.nqb = (p.S + 255) / 256;
-    hipLaunchKernelGGL((attn_fwd_glds_kernel<PRESC, TPB, VAR>), dim3(p.nqb * p.H), dim3(512), AG_LDS(TPB), stream, p);
+    p.w_base = 0; p.nsplit = 1; p.tiles_per_split = 0; p.part_o = nullptr; p.part_lse = nullptr;
+    const int nwg = p.nqb * p.H;
+    // Tail split: the workgroups of the last, partly filled round are cut along the keys so that the round costs a fraction
+    // of a workgroup's duration instead of a whole one (S = 13 824: 1296 workgroups = 5 rounds of 256 CUs + 16 -> the 16 run
+    // as 256 sixteenths; S = 50 688: 18 rounds + 144 -> 1008 sevenths).  UTX_ATTN_TAILSPLIT=0 disables it.
+    static int ncu = 0;
+    const char* ts_env = getenv("UTX_ATTN_TAILSPLIT");
+    const int enabled = (ts_env && atoi(ts_env) == 0) ? 0 : 1;
+    if (!ncu) { int dev = 0; hipDeviceProp_t pr; ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
+    const int nfull = (nwg / ncu) * ncu, r = nwg - nfull;
+    const int nt_all = (p.S + AG_KVB - 1) / AG_KVB;
+    int best_ns = 1;
+    if (enabled && TPB == 1 && VAR == 0 && !p.flags && nfull > 0 && r > 0) {
+        double best = 0.92;                                    // worth it only below ~0.9 of a round
+        for (int ns = 2; ns <= 16; ++ns) {
+            if (r * ns > 2048 || (nt_all + ns - 1) / ns < 12) break;      // workspace bound; >= 12 tiles per split
+            const double cost = (double)((r * ns + ncu - 1) / ncu) * (1.0 / ns + 0.02);   // rounds x (share + fixed cost of a workgroup)
+            if (cost < best) { best = cost; best_ns = ns; }
+        }
+    }
+    if (best_ns == 1) {
+        hipLaunchKernelGGL((attn_fwd_glds_kernel<PRESC, TPB, VAR>), dim3(nwg), dim3(512), AG_LDS(TPB), stream, p);
+        return hipGetLastError() == hipSuccess ? 0 : -4;
+    }
+    const int tps = (nt_all + best_ns - 1) / best_ns;
+    const int ns = (nt_all + tps - 1) / tps;                   // every split owns at least one tile
+    static bf16_t* ws_o[16] = {nullptr}; static float* ws_l[16] = {nullptr}; static size_t ws_cap[16] = {0};
+    int dev = 0; if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return -5;
+    const size_t rows = (size_t)r * ns * 256;
+    if (ws_cap[dev] < rows) {
+        if (ws_o[dev]) (void)hipFree(ws_o[dev]);
+        if (ws_l[dev]) (void)hipFree(ws_l[dev]);
+        ws_o[dev] = nullptr; ws_l[dev] = nullptr; ws_cap[dev] = 0;
+        if (hipMalloc((void**)&ws_o[dev], rows * 128 * sizeof(bf16_t)) != hipSuccess) return -5;
+        if (hipMalloc((void**)&ws_l[dev], rows * sizeof(float)) != hipSuccess) return -5;
+        ws_cap[dev] = rows;
+    }
+    hipLaunchKernelGGL((attn_fwd_glds_kernel<PRESC, TPB, VAR>), dim3(nfull), dim3(512), AG_LDS(TPB), stream, p);
+    AttnParams t = p;
+    t.w_base = nfull; t.nsplit = ns; t.tiles_per_split = tps; t.part_o = ws_o[dev]; t.part_lse = ws_l[dev];
+    hipLaunchKernelGGL((attn_fwd_glds_kernel<PRESC, TPB, VAR>), dim3(r * ns), dim3(512), AG_LDS(TPB), stream, t);
+    const long mt = (long)r * 256 * 16;
+    hipLaunchKernelGGL(attn_merge_kernel, dim3((unsigned)((mt + 255) / 256)), dim3(256), 0, stream, t, r);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 

@@ -20,6 +20,11 @@ struct AttnParams {
     float scale_log2;  // softmax_scale * log2(e)
     unsigned char* flags;  // per (head, 64-query group) overflow marks: written by the 4 x 64 kernel, read by the repair pass (else null)
     int flag_hs;           // flags per head
+    // tail split (attention_glds.hip): work items [w_base, ...) of this launch, each cut into nsplit key ranges of
+    // tiles_per_split 64-key tiles; a split writes its normalised partial output + log2-sum-exp instead of the final rows
+    int w_base, nsplit, tiles_per_split;
+    bf16_t* part_o;        // [items][nsplit][256][128] bf16
+    float* part_lse;       // [items][nsplit][256] f32: running maximum + log2(row sum)
 };
 typedef utx_gemm_desc GemmParams;
 typedef utx_knn_desc KnnParams;
