@@ -30,6 +30,11 @@ def _worker(rank, world, port, q):
     ref_atlas, _, ref_win, _ = G.composite(color, vis)
     ok = np.array_equal(c_all.numpy(), color) and np.array_equal(v_all.numpy().astype(bool), vis) and \
         np.array_equal(atlas, ref_atlas) and np.array_equal(win, ref_win)
+    # geometry-condition render: per-view uint8 images (normal rgb, ccm rgb, alpha), same sharding, one all-gather
+    from unitex_amd.texturetools.distributed import gather_view_images
+    imgs = rng.integers(0, 256, (n, 16, 24, 7), dtype=np.uint8)
+    loc = np.zeros_like(imgs); loc[v0:v1] = imgs[v0:v1]
+    ok = ok and np.array_equal(gather_view_images(torch.from_numpy(loc), rank, world).numpy(), imgs)
     q.put((rank, bool(ok), (v0, v1)))
     dist.barrier()
     dist.destroy_process_group()

@@ -30,3 +30,16 @@ def gather_view_layers(color, vis, rank, world, group=None):
     color_all = allp[:n, : T * 12].contiguous().view(torch.float32).view(n, H, W, 3)
     vis_all = allp[:n, T * 12:].contiguous().view(n, H, W)
     return color_all, vis_all
+
+
+def gather_view_images(stack, rank, world, group=None):
+    """stack [n, ...] uint8 (e.g. the condition renders [n,H,W,7] = normal rgb, ccm rgb, alpha): rank r rendered its own
+    view_range only; ONE all-gather returns the complete stack on every rank (geometry-condition render)."""
+    n = stack.shape[0]
+    v0, v1, per = view_range(rank, world, n)
+    flat = stack.reshape(n, -1)
+    pay = torch.zeros(per, flat.shape[1], dtype=torch.uint8, device=stack.device)
+    pay[: v1 - v0] = flat[v0:v1]
+    allp = torch.empty(world * per, flat.shape[1], dtype=torch.uint8, device=stack.device)
+    dist.all_gather_into_tensor(allp, pay, group=group)
+    return allp[:n].reshape(stack.shape)

@@ -48,9 +48,11 @@ def _vertex_normals(verts, faces, weighting="area"):
 
 
 class VideoExporter:
-    def __init__(self, device="cuda", normal_weighting="angle"):
+    def __init__(self, device="cuda", normal_weighting="angle", view_shard=(0, 1), process_group=None):
         self.device = torch.device(device if device != "cuda" else "cuda:%d" % torch.cuda.current_device())
         self.normal_weighting = normal_weighting      # see _vertex_normals: "angle" = trimesh semantics
+        self.view_shard = view_shard                  # (rank, world): this rank renders its block of the condition views,
+        self.process_group = process_group            # one all-gather of the uint8 images completes the grids on every rank
 
     def export_condition(self, mesh_path, geometry_scale=1.0, n_views=4, n_rows=2, n_cols=2, H=512, W=512, scale=0.85,
                          fov_deg=49.1, perspective=False, orbit=True, background=None, return_info=False,
@@ -77,15 +79,23 @@ class VideoExporter:
         nrm = _vertex_normals(verts, faces, self.normal_weighting).to(dev)
         mvp = torch.matmul(camera.intr_to_proj(intrinsics, perspective=False), camera.c2w_to_w2c(c2ws)).to(dev).contiguous()
         clip, _ = ops.transform_points(vd, mvp, want_ndc=False)
+        from .distributed import gather_view_images, view_range
+        rank, world = self.view_shard
+        v0, v1, _ = view_range(rank, world, n_views)
         rasts, ns, ps = [], [], []
-        for v in range(n_views):
+        for v in range(v0, v1):
             r = ops.rasterize(clip[v].contiguous(), fd, H, W)
             rasts.append(r)
             ns.append(ops.interpolate(nrm, r, fd))
             ps.append(ops.interpolate(vd, r, fd))
-        rast, ni, pi = torch.stack(rasts), torch.stack(ns), torch.stack(ps)
         bgv = bg.tolist() if bg is not None else [0.0, 0.0, 0.0]
-        normal_u8, ccm_u8, alpha_u8 = ops.condition_shade(rast, ni, pi, bgv)
+        stack = torch.zeros(n_views, H, W, 7, dtype=torch.uint8, device=dev)
+        if v1 > v0:
+            n8, c8, a8 = ops.condition_shade(torch.stack(rasts), torch.stack(ns), torch.stack(ps), bgv)
+            stack[v0:v1, ..., 0:3], stack[v0:v1, ..., 3:6], stack[v0:v1, ..., 6] = n8, c8, a8
+        if world > 1:
+            stack = gather_view_images(stack, rank, world, group=self.process_group)
+        normal_u8, ccm_u8, alpha_u8 = stack[..., 0:3].contiguous(), stack[..., 3:6].contiguous(), stack[..., 6].contiguous()
 
         def grid(t):
             a = t.cpu().numpy()
