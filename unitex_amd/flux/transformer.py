@@ -16,6 +16,7 @@ are concatenated along the rank axis (padded to 64) and consumed as an extra K-s
 """
 import ctypes as C
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -93,6 +94,10 @@ class FluxDiT:
         self._lora_active: List[Tuple[Dict, float]] = []
         self._lora_version = 0
         self.attn_events = None
+        # double blocks: the text-token half (M = 512: a fraction of one round of tiles) runs on a second HIP stream beside the
+        # image-token half, which fills CUs that the image GEMMs' tail rounds leave idle.  UTX_TXT_STREAM=0 keeps one stream.
+        self.overlap_text = os.environ.get("UTX_TXT_STREAM", "1") != "0" and self.sp is None
+        self._side = torch.cuda.Stream(device=self.device) if self.overlap_text else None
         self._pack(state_dict)
 
     # ------------------------------------------------------------------ weights
@@ -267,6 +272,14 @@ class FluxDiT:
             d = ops.make_gemm_desc(A, B, Cout, bias=bias, **kw)
         plan.append((self.lib.utx_gemm_bf16, d))
 
+    def _par(self, plan, main_ops, side_ops):
+        """two independent op lists: side by side on two streams (fork / join events) or one after the other."""
+        if self.overlap_text and side_ops:
+            plan.append(("par", (main_ops, side_ops, torch.cuda.Event(), torch.cuda.Event())))
+        else:
+            plan.extend(main_ops)
+            plan.extend(side_ops)
+
     def _lnmod(self, plan, x, y, shift, scale):
         d = LnModDesc()
         d.x, d.ldx, d.shift, d.scale = ptr(x), x.stride(0), ptr(shift), ptr(scale)
@@ -320,12 +333,14 @@ class FluxDiT:
         }
         if Rp:
             ws["T"] = z(S, 3 * Rp)
+            ws["Tc"] = z(S_txt, 3 * Rp)     # LoRA-down temp of the text half (it runs concurrently with the image half)
         if self.sp is not None:
             from .ulysses import UlyssesExchange
             if S_pad != S:
                 raise ValueError("sequence parallel: the local token count %d must be a multiple of 64" % S)
             self.ex = UlyssesExchange(H, S, group=self.sp[2], device=dev, dtype=BF16)
         T = ws.get("T")
+        Tc = ws.get("Tc") if self.overlap_text else T
         W, mod = self.W, ws["mod"][0]
         h, xn, qkv, cat, attn = ws["h"], ws["xn"], ws["qkv"], ws["cat"], ws["attn"]
         h_c, h_x = h[:S_txt], h[S_txt:]
@@ -355,27 +370,32 @@ class FluxDiT:
         for i, b in enumerate(self.double):
             sh_a, sc_a, g_a, sh_m, sc_m, g_m = chunks(("d", i, "x"), 6)
             csh_a, csc_a, cg_a, csh_m, csc_m, cg_m = chunks(("d", i, "c"), 6)
-            self._lnmod(plan, h_x, xn_x, sh_a, sc_a)
-            self._lnmod(plan, h_c, xn_c, csh_a, csc_a)
-            self._gemm(plan, xn_x, b["qkv_x.w"], qkv[S_txt:], bias=b["qkv_x.b"], lora=b.get("lora.qkv_x"),
+            # image half / text half of the block are independent except at the joint attention: two op lists per segment
+            px, pc = [], []
+            self._lnmod(px, h_x, xn_x, sh_a, sc_a)
+            self._lnmod(pc, h_c, xn_c, csh_a, csc_a)
+            self._gemm(px, xn_x, b["qkv_x.w"], qkv[S_txt:], bias=b["qkv_x.b"], lora=b.get("lora.qkv_x"),
                        lora_n_limit=3 * D, lora_seg_n=D, T=T)
-            self._gemm(plan, xn_c, b["qkv_c.w"], qkv[:S_txt], bias=b["qkv_c.b"], lora=b.get("lora.qkv_c"),
-                       lora_n_limit=3 * D, lora_seg_n=D, T=T)
-            self._qkvpost(plan, qkv[S_txt:], b["nq"], b["nk"], ws, S_img, S_txt)
-            self._qkvpost(plan, qkv[:S_txt], b["naq"], b["nak"], ws, S_txt, 0)
+            self._gemm(pc, xn_c, b["qkv_c.w"], qkv[:S_txt], bias=b["qkv_c.b"], lora=b.get("lora.qkv_c"),
+                       lora_n_limit=3 * D, lora_seg_n=D, T=Tc)
+            self._qkvpost(px, qkv[S_txt:], b["nq"], b["nk"], ws, S_img, S_txt)
+            self._qkvpost(pc, qkv[:S_txt], b["naq"], b["nak"], ws, S_txt, 0)
+            self._par(plan, px, pc)
             self._attn(plan, ws, attn, S)
-            self._gemm(plan, attn[S_txt:], b["out_x.w"], h_x, bias=b["out_x.b"], lora=b.get("lora.out_x"), T=T,
+            px, pc = [], []
+            self._gemm(px, attn[S_txt:], b["out_x.w"], h_x, bias=b["out_x.b"], lora=b.get("lora.out_x"), T=T,
                        gate=g_a, res=h_x)
-            self._gemm(plan, attn[:S_txt], b["out_c.w"], h_c, bias=b["out_c.b"], lora=b.get("lora.out_c"), T=T,
+            self._gemm(pc, attn[:S_txt], b["out_c.w"], h_c, bias=b["out_c.b"], lora=b.get("lora.out_c"), T=Tc,
                        gate=cg_a, res=h_c)
-            self._lnmod(plan, h_x, xn_x, sh_m, sc_m)
-            self._gemm(plan, xn_x, b["ff1_x.w"], ff[S_txt:], bias=b["ff1_x.b"], lora=b.get("lora.ff1_x"), T=T, gelu_from=0)
-            self._gemm(plan, ff[S_txt:], b["ff2_x.w"], h_x, bias=b["ff2_x.b"], lora=b.get("lora.ff2_x"), T=T,
+            self._lnmod(px, h_x, xn_x, sh_m, sc_m)
+            self._gemm(px, xn_x, b["ff1_x.w"], ff[S_txt:], bias=b["ff1_x.b"], lora=b.get("lora.ff1_x"), T=T, gelu_from=0)
+            self._gemm(px, ff[S_txt:], b["ff2_x.w"], h_x, bias=b["ff2_x.b"], lora=b.get("lora.ff2_x"), T=T,
                        gate=g_m, res=h_x)
-            self._lnmod(plan, h_c, xn_c, csh_m, csc_m)
-            self._gemm(plan, xn_c, b["ff1_c.w"], ff[:S_txt], bias=b["ff1_c.b"], lora=b.get("lora.ff1_c"), T=T, gelu_from=0)
-            self._gemm(plan, ff[:S_txt], b["ff2_c.w"], h_c, bias=b["ff2_c.b"], lora=b.get("lora.ff2_c"), T=T,
+            self._lnmod(pc, h_c, xn_c, csh_m, csc_m)
+            self._gemm(pc, xn_c, b["ff1_c.w"], ff[:S_txt], bias=b["ff1_c.b"], lora=b.get("lora.ff1_c"), T=Tc, gelu_from=0)
+            self._gemm(pc, ff[:S_txt], b["ff2_c.w"], h_c, bias=b["ff2_c.b"], lora=b.get("lora.ff2_c"), T=Tc,
                        gate=cg_m, res=h_c)
+            self._par(plan, px, pc)
         for i, b in enumerate(self.single):
             sh_, sc_, g_ = chunks(("s", i), 3)
             self._lnmod(plan, h, xn, sh_, sc_)
@@ -435,7 +455,23 @@ class FluxDiT:
         h, st = self.ctx.handle, self.ctx.stream()
         lib, ws = self.lib, p["ws"]
         for fn, d in p["plan"]:
-            if fn == "temb_sum":
+            if fn == "par":
+                main_ops, side_ops, ev_fork, ev_join = d
+                main = torch.cuda.current_stream(self.device)
+                ev_fork.record(main)
+                self._side.wait_event(ev_fork)
+                st2 = C.c_void_p(self._side.cuda_stream)
+                for f2, d2 in side_ops:
+                    rc = f2(h, C.byref(d2), st2)
+                    if rc:
+                        self.ctx.check(rc)
+                for f2, d2 in main_ops:
+                    rc = f2(h, C.byref(d2), st)
+                    if rc:
+                        self.ctx.check(rc)
+                ev_join.record(self._side)
+                main.wait_event(ev_join)
+            elif fn == "temb_sum":
                 # conditioning = (timesteps_emb + guidance_emb) + pooled_projections, bf16 adds [3p]
                 t = ws["e_t"]
                 if self.shape.guidance_embeds:
