@@ -13,6 +13,7 @@ mu from the noise-token count only; condition tail re-pinned every step; Euler s
 The transformer is FluxDiT (HIP kernels behind the C ABI); the scheduler update is the fused HIP
 kernel utx_sched_step; the VAE runs on the same library (vae_hip.py).
 """
+import os
 from typing import List, Optional
 
 import numpy as np
@@ -152,10 +153,13 @@ class PBRFluxPipeline:
             ids, cond = noise_ids, None
         tr.set_positions(text_ids, ids)
         tr.set_conditioning(prompt_embeds, pooled, guidance_scale)
+        use_graph = os.environ.get("UTX_HIP_GRAPH", "0") == "1" and num_inference_steps > 2 and hasattr(tr, "capture_graph")
         for i in range(num_inference_steps):
             # timestep = t.expand(B).to(latents.dtype); transformer(timestep=timestep / 1000)
             t_bf = torch.tensor(float(timesteps[i]), dtype=torch.float32).to(BF16)
             t_in = float((t_bf / 1000).to(torch.float32))
+            if use_graph and i == 1 and not getattr(tr, "_graphs", None):
+                tr.capture_graph(warm=False)      # step 0 ran eagerly (first-use setup); the remaining steps replay one HIP graph
             v = tr.forward(latents, t_in)
             # Euler step on the noise tokens + re-pin of the clean condition tail, one fused kernel
             ops.sched_step(latents, v, self.scheduler.dsigma(i), n_noise_tokens=n_noise, cond=cond)

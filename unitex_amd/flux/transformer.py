@@ -531,7 +531,7 @@ class FluxDiT:
             return out
         return ws["out"]
 
-    def capture_graph(self):
+    def capture_graph(self, warm=True):
         """Record the current plan (~700 stream-ordered launches, fixed descriptors and workspaces, no host syncs) into a
         HIP graph; forward() then replays it.  The two host->device copies of forward (timestep projection, latents) stay
         outside the graph.  One eager run first: first-use setup (kernel attributes, lazily sized buffers) must not happen
@@ -540,7 +540,8 @@ class FluxDiT:
         p = next(iter(self._plans.values()))
         if getattr(self, "attn_events", None) is not None:
             raise RuntimeError("per-kernel event timing and graph replay are exclusive")
-        self.run_plan(p)
+        if warm:        # skip when the plan has already run eagerly (the denoise loop captures after its first step)
+            self.run_plan(p)
         torch.cuda.synchronize(self.device)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
