@@ -51,7 +51,11 @@ const char* utx_last_error(utx_ctx* ctx);
  * Strides in elements; q/k/vt base pointers 16-byte aligned; q_hs, k_hs, vt_hs, q_ss, k_ss, vt_ds multiples of 8,
  * o_ss multiple of 4.
  * softmax_scale > 0: the reference's scale (1/sqrt(128)); softmax_scale == 0: Q was pre-multiplied by
- * scale*log2(e) by utx_qkv_post (q_scale) and scores are used as base-2 exponents directly. */
+ * scale*log2(e) by utx_qkv_post (q_scale) and scores are used as base-2 exponents directly.
+ * One call may issue up to three stream-ordered launches (full rounds of workgroups, the key-split tail round, its merge).
+ * The tail round uses a library-owned scratch buffer per device, grown with hipMalloc on the first call that needs it:
+ * make one eager call per (H, S) before capturing the stream into a HIP graph.  Calls on the same device must not run
+ * concurrently on different streams (the scratch is shared). */
 int utx_attn_fwd_bf16(utx_ctx* ctx, const void* q, const void* k, const void* vt, void* o,
                       long q_hs, long q_ss, long k_hs, long k_ss, long vt_hs, long vt_ds, long o_ss,
                       int H, int S, float softmax_scale, utx_stream stream);
