@@ -491,3 +491,47 @@ def test_attention_tail_split_matches_oracle_and_unsplit_launch(S):
     frac_changed = 1.0 - same.float().mean().item()
     assert 0.0 < frac_changed < 0.5, "the tail (and only the tail) goes through the split path: %g of the rows changed" % frac_changed
     assert (split - plain).abs().max().item() < 3e-2
+
+
+@pytest.mark.parametrize("M,N,K,lora", [(5120, 3584, 1024, False), (4900, 3584, 1536, True), (8192, 2304, 3072, False)])
+def test_gemm_tail_split_matches_unsplit_launch_and_oracle(M, N, K, lora):
+    """opt-in UTX_GEMM_TAILSPLIT=1: with more 256 x 256 tiles than CUs the tiles of the last, partly filled round are cut
+    along K (fp32 partials, the last split to arrive sums them in split order and runs the normal epilogue).  Deterministic,
+    equal to the unsplit launch up to the fp32 summation order, tiles of the full rounds bit-identical; gated residual in place,
+    ragged M and a LoRA K-segment included."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = (torch.randn(M, K, generator=g) / 4).to(BF)
+    B = (torch.randn(N, K, generator=g) / math.sqrt(K) * 2).to(BF)
+    bias = torch.randn(N, generator=g).to(BF)
+    gate = (0.5 * torch.randn(N, generator=g)).to(BF)
+    res = torch.randn(M, N, generator=g).to(BF)
+    kw, rkw = {}, {}
+    if lora:
+        R = 64
+        T = (torch.randn(M, R, generator=g) / 8).to(BF)
+        Bl = (torch.randn(N, R, generator=g) / 4).to(BF)
+        kw = dict(A2=T.cuda(), B2=Bl.cuda(), lora_n_limit=N, lora_seg_n=N)
+        rkw = dict(A2=T, B2=Bl, lora_seg=N, lora_limit=N)
+    Ad, Bd, bd, gd = A.cuda(), B.cuda(), bias.cuda(), gate.cuda()
+    outs = []
+    old = os.environ.get("UTX_GEMM_TAILSPLIT")
+    try:
+        for mode in ("0", "1", "1"):
+            os.environ["UTX_GEMM_TAILSPLIT"] = mode
+            rd = res.cuda().clone()
+            ops.gemm(Ad, Bd, bias=bd, out=rd, gate=gd, res=rd, **kw)
+            torch.cuda.synchronize()
+            outs.append(rd.clone())
+    finally:
+        if old is None:
+            os.environ.pop("UTX_GEMM_TAILSPLIT", None)
+        else:
+            os.environ["UTX_GEMM_TAILSPLIT"] = old
+    plain, s1, s2 = outs
+    ref = _gemm_ref(A, B, bias, gate=gate, res=res, **rkw)
+    _close(plain, ref, "unsplit gemm")
+    _close(s1, ref, "tail-split gemm")
+    assert torch.equal(s1.view(torch.int16), s2.view(torch.int16)), "split launch is not deterministic"
+    changed = (s1 != plain).float().mean().item()
+    assert 0.0 < changed < 0.02, "only roundings inside the tail tiles may move: %g of the elements differ" % changed

@@ -316,7 +316,14 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_bf16_kernel(GemmParams
         __builtin_amdgcn_sched_barrier(0);            \
     } while (0)
 
-__global__ __launch_bounds__(512, 2) void gemm256_8ph_kernel(GemmParams p) {
+// tail split (launcher: launch_gemm8, opt-in UTX_GEMM_TAILSPLIT=1): the tiles of the last, partly filled round are cut along
+// K into `ks` workgroups each.  Every split writes its fp32 accumulators (lane-linear) to `part` with agent-scope (write-through)
+// stores, takes a ticket, and the LAST one to arrive sums all ks partials in split order (deterministic) and runs the normal
+// epilogue -- no second kernel, no duplicated epilogue, and no agent-scope fence (an L2 write-back + invalidate on this part,
+// measured -20 %, profiles/r01_perf_gemm_tailsplit_negative.log).
+struct G8Split { int ks; int tile_base; float* part; int* tick; };
+
+__global__ __launch_bounds__(512, 2) void gemm256_8ph_kernel(GemmParams p, G8Split sp) {
     constexpr int BM = 256, BN = 256, NT = 512;
     constexpr int CROW = BN * 2 + 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -329,7 +336,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_8ph_kernel(GemmParams p) {
     const int wr = wave >> 2, wc = wave & 3;
     const int l31 = lane & 31, lh = lane >> 5;
 
-    const int w = xcd_remap(blockIdx.x, gridDim.x);
+    const int wid = xcd_remap(blockIdx.x, gridDim.x);
+    const int ks = sp.ks;                                  // 1: one workgroup per tile
+    const int item = ks > 1 ? wid / ks : wid;
+    const int split = wid - item * ks;
+    const int w = sp.tile_base + item;
     const int ntn = p.ntn & 0xffff, group_m = (p.ntn >> 16) & 0xff;
     const int dbg = p.ntn >> 24;   // perf ablation only (UTX_GEMM_DEBUG): 1 = no operand staging, 2 = always stage K-tile 0
     const int ntm_ = (p.M + BM - 1) / BM;
@@ -342,7 +353,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_8ph_kernel(GemmParams p) {
 
     const int nk1 = p.K / GM_BK;
     const bool lora = (p.K2 > 0) && (n0 < p.lora_n_limit);
-    const int nk = nk1 + (lora ? p.K2 / GM_BK : 0);
+    const int nk_all = nk1 + (lora ? p.K2 / GM_BK : 0);
+    // K-tiles [kb, kb + nk) of the concatenated (K ++ K2) range belong to this workgroup (all of them without a split)
+    int kb = 0, nk = nk_all;
+    if (ks > 1) {
+        const int q = nk_all / ks, rm = nk_all - q * ks;
+        kb = split * q + (split < rm ? split : rm);
+        nk = q + (split < rm ? 1 : 0);
+    }
     const long a2_off = lora ? (long)(n0 / p.lora_seg_n) * p.K2 : 0;
 
     // ---- staging sources: wave-uniform base (SGPR) + one per-lane byte offset per operand and K-segment.
@@ -364,7 +382,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_8ph_kernel(GemmParams p) {
     do {                                                                                                    \
         const int tt_ = (t_);                                                                               \
         if (dbg == 1) break;                                                                                \
-        const int ts_ = (dbg == 2) ? 0 : tt_;                                                               \
+        const int ts_ = (dbg == 2) ? 0 : tt_ + kb;                                                          \
         const bool s2_ = ts_ >= nk1;                                                                        \
         const long rs_ = (isb_) ? (s2_ ? ldb2B : ldbB) : (s2_ ? lda2B : ldaB);                              \
         const char* ub_ = ((isb_) ? (s2_ ? ubB2 : ubB1) : (s2_ ? ubA2 : ubA1)) +                            \
@@ -481,6 +499,37 @@ __global__ __launch_bounds__(512, 2) void gemm256_8ph_kernel(GemmParams p) {
         if (t + 1 < nk) G8_KTILE(t + 1, 1);
     }
     if (wr == 0) G8_BAR();          // re-align the barrier count
+
+    if (ks > 1) {
+        float* mine = sp.part + ((long)item * ks + split) * 65536 + tid;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    __hip_atomic_store(mine + ((j * 4 + i) * 16 + r) * 512, acc[j][i][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the write-through stores have been acknowledged
+        __syncthreads();
+        int* flag = reinterpret_cast<int*>(smem);
+        if (tid == 0) *flag = (__hip_atomic_fetch_add(sp.tick + item, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ks - 1) ? 1 : 0;
+        __syncthreads();
+        const int last = *flag;
+        __syncthreads();                 // smem is reused by the epilogue
+        if (!last) return;
+        const float* base = sp.part + (long)item * ks * 65536 + tid;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float sum = 0.f;
+                    for (int q = 0; q < ks; ++q)
+                        sum += __hip_atomic_load(base + (long)q * 65536 + ((j * 4 + i) * 16 + r) * 512, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    acc[j][i][r] = sum;
+                }
+    }
 
     // ---- epilogue: two chunks of 128 tile rows (chunk i = A half i) through LDS; every wave has rows in both
     const int rslot = tid % (BN / 8);
@@ -618,7 +667,45 @@ static int launch_gemm8(GemmParams p, hipStream_t stream, int group_env, int dbg
     int group_m = group_env > 0 ? group_env : GM_GROUP_M;
     if (group_m > ntm) group_m = ntm;
     p.ntn = ntn | (group_m << 16) | (dbg_env << 24);
-    hipLaunchKernelGGL(gemm256_8ph_kernel, dim3(ntm * ntn), dim3(512), LDS, stream, p);
+    G8Split sp = {1, 0, nullptr, nullptr};
+    const int tiles = ntm * ntn;
+    // Tail split, opt-in (UTX_GEMM_TAILSPLIT=1): see G8Split.  Candidate when the last round is sparsely filled and K is long
+    // enough that a tile's fixed cost (prologue + epilogue, ~10 us against ~1.4 us per K-tile) does not dominate.
+    static int ncu = 0;
+    if (!ncu) { int dev = 0; hipDeviceProp_t pr; ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
+    const char* ts_env = getenv("UTX_GEMM_TAILSPLIT");
+    const bool enabled = ts_env && atoi(ts_env) == 1 && dbg_env == 0;
+    const int nfull = (tiles / ncu) * ncu, r = tiles - nfull;
+    int best_ks = 1;
+    if (enabled && nfull > 0 && r > 0) {
+        const int nkt = p.K / GM_BK;
+        const double f = 10.0 / (1.4 * nkt + 10.0);
+        double best = 0.88;
+        for (int ks = 2; ks <= 8; ++ks) {
+            if (ks * 3 > nkt || r * ks > 512) break;
+            const double cost = (double)((r * ks + ncu - 1) / ncu) * ((1.0 - f) / ks + f + 0.02 * ks);
+            if (cost < best) { best = cost; best_ks = ks; }
+        }
+    }
+    if (best_ks == 1) {
+        hipLaunchKernelGGL(gemm256_8ph_kernel, dim3(tiles), dim3(512), LDS, stream, p, sp);
+        return hipGetLastError() == hipSuccess ? 0 : -4;
+    }
+    static float* ws_part[16] = {nullptr}; static int* ws_tick[16] = {nullptr}; static size_t ws_cap[16] = {0};
+    int dev = 0; if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return -5;
+    const size_t need = (size_t)r * best_ks;
+    if (ws_cap[dev] < need) {
+        if (ws_part[dev]) (void)hipFree(ws_part[dev]);
+        if (ws_tick[dev]) (void)hipFree(ws_tick[dev]);
+        ws_part[dev] = nullptr; ws_tick[dev] = nullptr; ws_cap[dev] = 0;
+        if (hipMalloc((void**)&ws_part[dev], need * 65536 * sizeof(float)) != hipSuccess) return -5;
+        if (hipMalloc((void**)&ws_tick[dev], 1024 * sizeof(int)) != hipSuccess) return -5;
+        ws_cap[dev] = need;
+    }
+    if (hipMemsetAsync(ws_tick[dev], 0, (size_t)r * sizeof(int), stream) != hipSuccess) return -5;
+    hipLaunchKernelGGL(gemm256_8ph_kernel, dim3(nfull), dim3(512), LDS, stream, p, sp);
+    G8Split st = {best_ks, nfull, ws_part[dev], ws_tick[dev]};
+    hipLaunchKernelGGL(gemm256_8ph_kernel, dim3(r * best_ks), dim3(512), LDS, stream, p, st);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
