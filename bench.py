@@ -249,6 +249,9 @@ def main():
                          "launches_timed": len(attn_ms), "avg_launch_ms": attn_avg_ms,
                          "timed_in": "one eager step after the timed region (graph mode)" if use_graph else "the timed region",
                          "flops_per_launch": attn_launch_flops,
+                         # context, not the judged fraction: an MFMA-only stream of the same shape sustains 1.73 PF on random operands
+                         # on this board (power-limited clock, profiles/r01_perf_attn_q64.log)
+                         "sustained_mfma_only_tflops": 1730.0, "frac_of_sustained": achieved / 1730.0,
                          "attention_share_of_step_time": (attn_avg_ms * (N_DOUBLE + N_SINGLE)) / (dt / args.steps * 1e3)},
         }
         # HBM traffic of the dominant kernel: PMC passes cannot run inside the timed run (they serialise kernels), so
