@@ -135,3 +135,58 @@ def test_bench_workload_arithmetic_matches_baseline_md():
         assert abs(fl / 1e12 - tflop_ref) / tflop_ref < 2e-3
         if attn_ref:
             assert abs(fa / 1e12 - attn_ref) / attn_ref < 5e-3
+
+
+def test_reproject_and_query_field_forwards_variant_switches(tmp_path):
+    """host logic of RGBTextureFullPipelineBase.reproject_and_query_field (reference pipeline.py:313-347): the 2 x 3 grid is
+    cut into six view images in (row, col) order, and `method` / `inpainting` reach the inverse renderer as method,
+    kdtree_inpainting, reproject_inpainting and filt_gradient_points with the reference's thresholds (0.15, 100 degrees)."""
+    import types
+
+    import numpy as np
+    import torch
+    from PIL import Image
+
+    from unitex_amd.pipeline import RGBTextureFullPipelineBase
+    HP = WP = 8
+    grid = np.zeros((2 * HP, 3 * WP, 3), np.uint8)
+    for r in range(2):
+        for c in range(3):
+            grid[r * HP:(r + 1) * HP, c * WP:(c + 1) * WP] = 40 * (3 * r + c) + 10
+    Image.fromarray(grid).save(tmp_path / "mv.png")
+    torch.save({"c2ws": torch.eye(4)[None].repeat(6, 1, 1), "intrinsics": torch.eye(3), "perspective": False}, tmp_path / "cam.pth")
+    seen = {}
+
+    class FakeTextured:
+        def export(self, path):
+            seen["export"] = path
+
+    class FakeInverse:
+        def update_from_file(self, p):
+            seen["mesh"] = p
+
+        def infer(self, mesh, **kw):
+            seen["kw"] = kw
+            T = kw["H2D"]
+            return FakeTextured(), torch.zeros(6, T, T, 1, dtype=torch.bool), torch.ones(1, T, T, 1, dtype=torch.bool), torch.zeros(1, T, T, 3)
+
+        def clear(self):
+            seen["cleared"] = True
+
+    fake = types.SimpleNamespace(inverse_renderer=FakeInverse(), atlas_size=16)
+    fn = RGBTextureFullPipelineBase.reproject_and_query_field
+    fn = getattr(fn, "__wrapped__", fn)
+    for method, inp in (("reproject", False), ("kdtree", True)):
+        seen.clear()
+        fn(fake, str(tmp_path), "mesh.obj", str(tmp_path / "mv.png"), str(tmp_path / "cam.pth"), method=method, inpainting=inp)
+        kw = seen["kw"]
+        assert kw["method"] == method and kw["kdtree_inpainting"] is inp and kw["reproject_inpainting"] is inp
+        assert kw["filt_gradient_points"] is inp and kw["grad_norm_threhold"] == 0.15 and kw["ray_normal_angle_threhold"] == 100
+        assert kw["H"] == HP and kw["W"] == WP and kw["H2D"] == 16 and kw["perspective"] is False
+        ia = kw["image_attrs"]
+        assert tuple(ia.shape) == (6, HP, WP, 3)
+        for v in range(6):
+            assert torch.allclose(ia[v], torch.full((HP, WP, 3), (40 * v + 10) / 255.0)), "view %d of the 2 x 3 grid" % v
+        assert seen["export"].endswith("textured_mesh.glb") and seen["cleared"]
+        for name in ("visable_uv_mask.png", "valid_uv_mask.png", "completed_uv.png"):
+            assert (tmp_path / name).exists()
