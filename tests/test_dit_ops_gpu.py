@@ -287,6 +287,52 @@ def test_tiny_dit_forward_matches_oracle(use_lora):
         assert (base - ref).abs().max().item() > 5 * err, "LoRA branch must matter in this test"
 
 
+def test_adapter_switching_module_copies_and_all_zero_weights():
+    """(i) an adapter that carries a full x_embedder copy (peft modules_to_save, trainer.py:297-304) swaps it in while it is
+    switched on, and the other adapter's copy when the weights flip (texture pass / delight pass, pipeline.py:245,263);
+    (ii) all-zero weights after an active pass leave no stale adapter behind: the forward equals the base model's;
+    (iii) two switched-on adapters that both carry a copy are refused."""
+    from unitex_amd.flux.transformer import FluxDiT, FluxShape
+    cfg = dit_ref.tiny_config(heads=2, double=1, single=1, joint_dim=64, pooled_dim=64)
+    sd = dit_ref.make_synthetic_state_dict(cfg, seed=0)
+    shape = FluxShape(num_heads=2, num_double=1, num_single=1, joint_dim=64, pooled_dim=64)
+    S_txt, S_img = 64, 192
+    g = torch.Generator().manual_seed(11)
+    lat = torch.randn(S_img, 64, generator=g).to(BF)
+    enc = (0.5 * torch.randn(S_txt, 64, generator=g)).to(BF)
+    pooled = (0.5 * torch.randn(1, 64, generator=g)).to(BF)
+    txt_ids, img_ids = torch.zeros(S_txt, 3), dit_ref.latent_image_ids(8, 24)
+    la = dit_ref.make_synthetic_lora(cfg, sd, rank=16, seed=2)
+    lb = dit_ref.make_synthetic_lora(cfg, sd, rank=16, seed=3)
+    for i, l in enumerate((la, lb)):
+        l["__full__"] = {"x_embedder.weight": (sd["x_embedder.weight"].float() + 0.05 * torch.randn(sd["x_embedder.weight"].shape, generator=g)).to(BF),
+                         "x_embedder.bias": (sd["x_embedder.bias"].float() + 0.1 * (i + 1)).to(BF)}
+    m = FluxDiT(sd, shape, device="cuda:0")
+
+    def run(loras):
+        m.set_lora(loras)
+        m.set_positions(txt_ids, img_ids)
+        m.set_conditioning(enc.cuda(), pooled.cuda(), 3.5)
+        out = m.forward(lat.cuda(), 0.4375).float().cpu()
+        torch.cuda.synchronize()
+        ref = dit_ref.flux_forward(sd, cfg, lat.float(), enc.float(), pooled.float(), 0.4375, 3.5, txt_ids, img_ids,
+                                   loras=loras, emulate_bf16=True)
+        return out, ref
+
+    o_t, r_t = run([(la, 1.0), (lb, 0.0)])
+    o_d, r_d = run([(la, 0.0), (lb, 1.0)])
+    o_0, r_0 = run([(la, 0.0), (lb, 0.0)])
+    base = dit_ref.flux_forward(sd, cfg, lat.float(), enc.float(), pooled.float(), 0.4375, 3.5, txt_ids, img_ids, emulate_bf16=True)
+    assert torch.equal(r_0, base)
+    for o, r in ((o_t, r_t), (o_d, r_d), (o_0, r_0)):
+        assert (o - r).abs().max().item() < 0.03 * max(r.abs().max().item(), 1.0)
+    assert (r_t - r_d).abs().max().item() > 0.2 and (r_t - base).abs().max().item() > 0.2    # the passes really differ
+    o_e, _ = run([])
+    assert torch.equal(o_e, o_0)
+    with pytest.raises(ValueError):
+        m.set_lora([(la, 1.0), (lb, 0.5)])
+
+
 def test_sequence_parallel_plan_world1_matches_plain_forward():
     """the head-parallel (Ulysses) plan with a 1-rank group must reproduce the plain plan bit for bit (same kernels,
     the exchange degenerates to layout copies); multi-rank exchange logic is covered on CPU (tests/test_multigpu_cpu.py)."""

@@ -113,6 +113,32 @@ def test_lora_safetensors_reader_accepts_both_spellings(tmp_path):
         pass
 
 
+def test_lora_safetensors_reader_returns_module_copies_and_rejects_unknown_keys(tmp_path):
+    """the trainer saves whole-module copies with every adapter (peft modules_to_save: x_embedder, trainer.py:297-304, written
+    through get_peft_model_state_dict, trainer.py:480-490): they must come back under FULL_KEY in both spellings, and a key that
+    is neither a LoRA factor, an alpha nor a module copy must raise instead of vanishing."""
+    from safetensors.torch import save_file
+    from unitex_amd.flux.lora_io import FULL_KEY, load_lora_safetensors
+    g = torch.Generator().manual_seed(1)
+    A = torch.randn(4, 64, generator=g); B = torch.randn(32, 4, generator=g)
+    Wx = torch.randn(32, 64, generator=g); bx = torch.randn(32, generator=g)
+    base = {"transformer.transformer_blocks.0.attn.to_out.0.lora_A.weight": A, "transformer.transformer_blocks.0.attn.to_out.0.lora_B.weight": B}
+    for spelling in ("transformer.x_embedder.%s", "transformer.x_embedder.modules_to_save.default.%s", "x_embedder.modules_to_save.%s"):
+        p = str(tmp_path / "m.safetensors")
+        save_file(dict(base, **{spelling % "weight": Wx, spelling % "bias": bx}), p)
+        d = load_lora_safetensors(p)
+        assert set(d) == {"transformer_blocks.0.attn.to_out.0", FULL_KEY}
+        assert set(d[FULL_KEY]) == {"x_embedder.weight", "x_embedder.bias"}
+        assert torch.equal(d[FULL_KEY]["x_embedder.weight"], Wx) and torch.equal(d[FULL_KEY]["x_embedder.bias"], bx)
+    p = str(tmp_path / "u.safetensors")
+    save_file(dict(base, **{"transformer.x_embedder.magnitude": bx}), p)
+    try:
+        load_lora_safetensors(p)
+        assert False, "an unrecognised tensor must raise"
+    except ValueError as e:
+        assert "magnitude" in str(e)
+
+
 def test_vae_parameter_table_matches_oracle_module():
     """the product's diffusers-keyed VAE parameter table (flux/synthetic.py) is exactly the oracle module's state dict."""
     from oracle import vae_ref

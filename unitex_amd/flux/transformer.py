@@ -180,17 +180,44 @@ class FluxDiT:
         self._lora_version += 1
         self._plans.clear()
         self._graphs = {}
+        self._pack_full_overrides()
         self._pack_lora()
+
+    FULL_OVERRIDE_MODULES = ("x_embedder",)   # the only parameterised entry of the trainer's modules_to_save (trainer.py:297-304)
+
+    def _pack_full_overrides(self):
+        """Whole-module copies saved with an adapter (lora_io.FULL_KEY; peft modules_to_save, trainer.py:297-304): the copy of
+        the adapter that is switched on replaces the base module for this pass (texture vs delight x_embedder).  peft's
+        ModulesToSaveWrapper serves ONE adapter's copy [3p]; two switched-on adapters that both carry a copy are ambiguous
+        and raise instead of silently picking one."""
+        self.W_override = {}
+        owners = {}
+        for idx, (d, s) in enumerate(self._lora_active):
+            full = d.get("__full__") if isinstance(d, dict) else None
+            for k, v in (full or {}).items():
+                mod, kind = k.rsplit(".", 1)
+                if mod not in self.FULL_OVERRIDE_MODULES:
+                    raise NotImplementedError("adapter carries a full copy of '%s'; only %s can be swapped per adapter"
+                                              % (mod, list(self.FULL_OVERRIDE_MODULES)))
+                if owners.setdefault(mod, idx) != idx:
+                    raise ValueError("two active adapters both carry a full copy of '%s' -- which one applies is undefined" % mod)
+                base = self.W[mod + (".w" if kind == "weight" else ".b")]
+                if tuple(v.shape) != tuple(base.shape):
+                    raise ValueError("adapter copy of %s has shape %s, base has %s" % (k, tuple(v.shape), tuple(base.shape)))
+                self.W_override[mod + (".w" if kind == "weight" else ".b")] = v.to(device=self.device, dtype=BF16).contiguous()
+
+    def _w(self, key):
+        return self.W_override.get(key, self.W[key]) if getattr(self, "W_override", None) else self.W[key]
 
     def _pack_lora(self):
         sh, D = self.shape, self.shape.dim
         act = self._lora_active
         self.lora_rank = 0
-        if not act:
-            return
-        for b in self.double + self.single:
+        for b in self.double + self.single:      # stale packed adapters go first: set_lora([]) must leave none behind
             for k in [k for k in b if k.startswith("lora.")]:
                 del b[k]
+        if not act:
+            return
 
         def build(mod_names):
             """Concatenate the active adapters along rank for a (possibly fused) GEMM over `mod_names`
@@ -360,7 +387,7 @@ class FluxDiT:
         # every AdaLN modulation vector of the step in one weight-streaming pass
         self._gemv(plan, ws["temb"], W["mod.w"], W["mod.b"], ws["mod"], silu_in=True)
         # ---- embedders
-        self._gemm(plan, ws["lat"], W["x_embedder.w"], h_x, bias=W["x_embedder.b"])
+        self._gemm(plan, ws["lat"], self._w("x_embedder.w"), h_x, bias=self._w("x_embedder.b"))   # per-adapter copy if one is active
         self._gemm(plan, ws["enc"], W["context_embedder.w"], h_c, bias=W["context_embedder.b"])
 
         def chunks(key, n):

@@ -1,40 +1,80 @@
-"""Reference-image preprocessing (host side, PIL): crop to the matte's bounding box, rescale to `scale` of the frame,
-centre on a background colour -- TextureTools/texturetools/image/process_image.py:10-74 (`get_bbox`, `preprocess`).
+"""Reference-image preprocessing (host side, PIL): the matte's bounding box is cut out, scaled so that its longer
+relative side fills `scale` of the output frame, and centred on a flat background.  Replaces `preprocess` of
+TextureTools/texturetools/image/process_image.py:31-74 (output bytes pinned by fixture G10).
 
-The matte itself comes from RMBG-2.0 in the reference ([3p] model + checkpoint, not available here): this build takes
-the alpha channel of the input image when it has one (the function's own RGBA branch), otherwise treats the whole
-frame as foreground."""
+Matte source, in order: an explicit `alpha` image; the input's own alpha channel when it is a real matte (more than 8
+transparent pixels -- the reference's test, process_image.py:45); otherwise the whole frame.  The reference's third source,
+the RMBG-2.0 network ([3p] model + checkpoint), does not exist in this build: pass `matting_fn(image) -> RGBA` to plug one in.
+"""
+from typing import Callable, NamedTuple, Optional
+
 import numpy as np
 from PIL import Image, ImageOps
 
 
-def get_bbox(mask: np.ndarray):
-    assert mask.ndim == 2
-    rows = np.where(mask.sum(-1) > 0)[0]
-    cols = np.where(mask.sum(-2) > 0)[0]
-    return np.array([cols.min(), rows.min(), cols.max(), rows.max()])
+class Box(NamedTuple):
+    """pixel rectangle in PIL order; right / bottom follow whoever produced the box (see foreground_box)."""
+    left: int
+    top: int
+    right: int
+    bottom: int
+
+    @property
+    def width(self):
+        return self.right - self.left
+
+    @property
+    def height(self):
+        return self.bottom - self.top
 
 
-def preprocess(image: Image.Image, alpha=None, H=2048, W=2048, scale=0.8, color="white", return_alpha=False):
+def foreground_box(matte: np.ndarray) -> Box:
+    """tight box of the non-zero matte pixels, max INDEX as right / bottom (so the box is one pixel short of PIL's
+    exclusive convention -- the reference crops with exactly this box, process_image.py:10-18,55,63)."""
+    if matte.ndim != 2:
+        raise ValueError("matte must be a single-channel image")
+    occupied_cols = np.flatnonzero(matte.any(axis=0))
+    occupied_rows = np.flatnonzero(matte.any(axis=1))
+    if occupied_cols.size == 0:
+        raise ValueError("matte is empty")
+    return Box(int(occupied_cols[0]), int(occupied_rows[0]), int(occupied_cols[-1]), int(occupied_rows[-1]))
+
+
+def select_matte(image: Image.Image, alpha: Optional[Image.Image], matting_fn: Optional[Callable]) -> Image.Image:
+    if alpha is not None:
+        return alpha
+    if image.mode == "RGBA":
+        own = image.getchannel("A")
+        opaque = int(np.count_nonzero(np.asarray(own)))
+        if opaque < image.width * image.height - 8:
+            return own
+    if matting_fn is not None:
+        return matting_fn(image).getchannel("A")
+    return Image.new("L", image.size, 255)
+
+
+def fit_centered(src: Box, frame_w: int, frame_h: int, scale: float) -> Box:
+    """destination rectangle: uniform zoom that brings the box to `scale` of the frame along its tighter axis, truncated to
+    whole pixels, centred with truncation (same float expressions as the reference so the sizes agree to the pixel)."""
+    zoom = min(frame_h * scale / src.height, frame_w * scale / src.width)
+    out_w, out_h = int(src.width * zoom), int(src.height * zoom)
+    left, top = int((frame_w - out_w) / 2), int((frame_h - out_h) / 2)
+    return Box(left, top, left + out_w, top + out_h)
+
+
+def preprocess(image: Image.Image, alpha: Optional[Image.Image] = None, H=2048, W=2048, scale=0.8, color="white",
+               return_alpha=False, matting_fn: Optional[Callable] = None):
+    """-> RGBA frame W x H: the foreground composited over `color` through its (resampled) matte, alpha = the placed matte."""
     image = ImageOps.exif_transpose(image)
-    rgb = image.convert("RGB")
-    if alpha is None:
-        if image.mode == "RGBA" and np.sum(np.array(image.getchannel("A")) > 0) < image.size[0] * image.size[1] - 8:
-            alpha = image.getchannel("A")
-        else:
-            alpha = Image.new("L", image.size, 255)          # no matting model: everything is foreground
-    box = get_bbox(np.array(alpha))
-    x1, y1, x2, y2 = box
-    dy, dx = y2 - y1, x2 - x1
-    s = min(H * scale / dy, W * scale / dx)
-    Ht, Wt = int(dy * s), int(dx * s)
-    ox, oy = int((W - Wt) / 2), int((H - Ht) / 2)
-    target = np.array([ox, oy, ox + Wt, oy + Ht])
-    rgbc = rgb.crop(box).resize((Wt, Ht))
-    alphac = alpha.crop(box).resize((Wt, Ht))
-    alphat = Image.new("L", (W, H))
-    alphat.paste(alphac, target)
-    out = Image.new("RGBA", (W, H), color)
-    out.paste(rgbc, target, alphac)
-    out.putalpha(alphat)
-    return (out, alpha) if return_alpha else out
+    matte = select_matte(image, alpha, matting_fn)
+    src = foreground_box(np.asarray(matte))
+    dst = fit_centered(src, W, H, scale)
+    size = (dst.width, dst.height)
+    fg = image.convert("RGB").crop(tuple(src)).resize(size)
+    fg_matte = matte.crop(tuple(src)).resize(size)
+    frame = Image.new("RGBA", (W, H), color)
+    frame.paste(fg, tuple(dst), fg_matte)
+    placed = Image.new("L", (W, H))
+    placed.paste(fg_matte, tuple(dst))
+    frame.putalpha(placed)
+    return (frame, matte) if return_alpha else frame
