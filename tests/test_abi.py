@@ -27,6 +27,31 @@ def test_library_loads_and_exports_all_declared_symbols():
     assert lib.utx_version() == 100
 
 
+def test_product_library_has_no_wrong_result_switches():
+    """the timing ablations that compute wrong results (UTX_ATTN_VAR / UTX_ATTN_DEBUG / UTX_GEMM_DEBUG) are compiled only into
+    libunitex_hip_ablate.so; the product library refuses them by name and lists only result-preserving options."""
+    import ctypes as C
+    import pytest
+    lib = _lib.load_library()
+    assert lib.utx_is_ablation_build() == 0
+    for n in ("UTX_ATTN_VAR", "UTX_ATTN_DEBUG", "UTX_GEMM_DEBUG"):
+        assert lib.utx_set_option(n.encode(), 3) == -7
+        v = C.c_int()
+        assert lib.utx_get_option(n.encode(), C.byref(v)) == -7
+        with pytest.raises(ValueError):
+            _lib.set_option(n, 1)
+    assert lib.utx_set_option(b"UTX_NO_SUCH", 1) == -2
+    opts = _lib.get_options()
+    assert set(opts) == set(_lib.OPTION_NAMES)
+    _lib.set_option("UTX_GEMM_TILE", 128)
+    assert _lib.get_options()["UTX_GEMM_TILE"] == 128
+    _lib.set_option("UTX_GEMM_TILE", 0)
+    # no getenv on the launch path
+    for f in os.listdir(os.path.join(ROOT, "unitex_amd", "csrc")):
+        if f.endswith(".hip"):
+            assert "getenv" not in open(os.path.join(ROOT, "unitex_amd", "csrc", f)).read(), f
+
+
 def test_struct_layouts_match():
     assert _lib.check_abi()
 

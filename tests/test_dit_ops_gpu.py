@@ -462,8 +462,8 @@ def test_attention_q64_kernel_and_repair_pass(S, ramp_max):
     q, k = q.to(BF), k.to(BF)
     v = torch.randn(H, S, 128, generator=g).to(BF)
     ref = dit_ref.sdpa(q.float(), k.float(), v.float(), em=False)
-    old = os.environ.get("UTX_ATTN_Q64")
-    os.environ["UTX_ATTN_Q64"] = "1"
+    from unitex_amd import _lib
+    _lib.set_option("UTX_ATTN_Q64", 1)
     try:
         for prescaled in (False, True):
             out = _run_attn(q, k, v, prescaled=prescaled)
@@ -471,10 +471,7 @@ def test_attention_q64_kernel_and_repair_pass(S, ramp_max):
             err = (out - ref).abs().max().item()
             assert err < 4e-2, "4 x 64 attention err %g (S=%d ramp=%g prescaled=%s)" % (err, S, ramp_max, prescaled)
     finally:
-        if old is None:
-            os.environ.pop("UTX_ATTN_Q64", None)
-        else:
-            os.environ["UTX_ATTN_Q64"] = old
+        _lib.set_option("UTX_ATTN_Q64", 0)
 
 
 def test_hip_graph_replay_is_bit_identical_to_the_eager_plan():
@@ -520,17 +517,14 @@ def test_attention_tail_split_matches_oracle_and_unsplit_launch(S):
     tolerance of the oracle (one more bf16 rounding of the partial outputs)."""
     H = 24
     q, k, v = _mk_attn_inputs(H, S, seed=S, spike=True)
-    old = os.environ.get("UTX_ATTN_TAILSPLIT")
+    from unitex_amd import _lib
     try:
-        os.environ["UTX_ATTN_TAILSPLIT"] = "0"
+        _lib.set_option("UTX_ATTN_TAILSPLIT", 0)
         plain = _run_attn(q, k, v)
-        os.environ["UTX_ATTN_TAILSPLIT"] = "1"
+        _lib.set_option("UTX_ATTN_TAILSPLIT", 1)
         split = _run_attn(q, k, v)
     finally:
-        if old is None:
-            os.environ.pop("UTX_ATTN_TAILSPLIT", None)
-        else:
-            os.environ["UTX_ATTN_TAILSPLIT"] = old
+        _lib.set_option("UTX_ATTN_TAILSPLIT", 1)
     ref = dit_ref.sdpa(q.float(), k.float(), v.float(), em=False)
     assert (split - ref).abs().max().item() < 4e-2
     same = (split == plain).all(dim=-1)                       # [H, S] rows identical to the unsplit launch
@@ -561,19 +555,16 @@ def test_gemm_tail_split_matches_unsplit_launch_and_oracle(M, N, K, lora):
         rkw = dict(A2=T, B2=Bl, lora_seg=N, lora_limit=N)
     Ad, Bd, bd, gd = A.cuda(), B.cuda(), bias.cuda(), gate.cuda()
     outs = []
-    old = os.environ.get("UTX_GEMM_TAILSPLIT")
+    from unitex_amd import _lib
     try:
-        for mode in ("0", "1", "1"):
-            os.environ["UTX_GEMM_TAILSPLIT"] = mode
+        for mode in (0, 1, 1):
+            _lib.set_option("UTX_GEMM_TAILSPLIT", mode)
             rd = res.cuda().clone()
             ops.gemm(Ad, Bd, bias=bd, out=rd, gate=gd, res=rd, **kw)
             torch.cuda.synchronize()
             outs.append(rd.clone())
     finally:
-        if old is None:
-            os.environ.pop("UTX_GEMM_TAILSPLIT", None)
-        else:
-            os.environ["UTX_GEMM_TAILSPLIT"] = old
+        _lib.set_option("UTX_GEMM_TAILSPLIT", 0)
     plain, s1, s2 = outs
     ref = _gemm_ref(A, B, bias, gate=gate, res=res, **rkw)
     _close(plain, ref, "unsplit gemm")

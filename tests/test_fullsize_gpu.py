@@ -56,10 +56,8 @@ def test_attention_full_size_sampled_rows_and_properties():
 
 
 def _set_tile(v):
-    if v is None:
-        os.environ.pop("UTX_GEMM_TILE", None)
-    else:
-        os.environ["UTX_GEMM_TILE"] = v
+    from unitex_amd import _lib
+    _lib.set_option("UTX_GEMM_TILE", 0 if v is None else int(v))
 
 
 def _gemm_variants(fn):

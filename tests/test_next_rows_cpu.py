@@ -38,9 +38,9 @@ def test_glb_round_trip(tmp_path):
 def test_unwrap_grid_is_a_valid_atlas():
     v, f, _ = meshes.sphere_with_faces(1500)
     T = 512
-    vv, ff, uu = meshes.unwrap_grid(v, f, atlas=T, gutter=2.0)
+    vv, fp, uu, ff = meshes.unwrap_grid(v, f, atlas=T, gutter=2.0)
     assert ff.shape == f.shape and uu.min() > 0 and uu.max() < 1
-    assert np.array_equal(vv[ff.reshape(-1)].reshape(-1, 3, 3), v[f.reshape(-1)].reshape(-1, 3, 3))   # geometry unchanged
+    assert np.array_equal(vv, v) and np.array_equal(fp, f)      # positions stay shared (smooth condition normals), UVs per corner
     # rasterise the atlas with the oracle rasteriser: every face owns texels, and a 1-texel dilation of any face
     # never touches another face (gutter), so bilinear fetches / dilation cannot bleed between triangles
     uvclip = np.concatenate([uu * 2 - 1, np.zeros((len(uu), 1), np.float32), np.ones((len(uu), 1), np.float32)], -1)
@@ -60,8 +60,15 @@ def test_prepare_blank_mesh_without_uvs(tmp_path):
     f = np.concatenate([f, [[0, 0, 1]]]).astype(np.int32)        # a degenerate face
     p = str(tmp_path / "blank.obj")
     meshes.save_obj(p, v, f)
-    vv, ff, uu = meshes.prepare_blank_mesh(p, min_faces=3000, max_faces=20000, scale=0.95, atlas=1024, gutter=2.0)
-    assert 3000 <= len(ff) <= 20000 and len(uu) == len(vv) == 3 * len(ff)
+    vv, ff, uu, fu = meshes.prepare_blank_mesh(p, min_faces=3000, max_faces=20000, scale=0.95, atlas=1024, gutter=2.0)
+    assert 3000 <= len(ff) <= 20000 and len(uu) == 3 * len(ff) and fu.shape == ff.shape and len(vv) < len(ff)   # shared positions
+    # round trip through the OBJ the pipeline writes: the condition render sees shared positions, the inverse renderer one vertex per (v, vt)
+    q = str(tmp_path / "processed_mesh.obj")
+    meshes.save_obj(q, vv, ff, uu, faces_uv=fu)
+    v1, f1, t1, ft1 = meshes.load_obj(q)
+    assert len(v1) == len(vv) and np.array_equal(f1, ff) and np.array_equal(ft1, fu)
+    v2, f2, t2, _ = meshes.load_mesh(q)
+    assert len(v2) == len(t2) == 3 * len(ff) and np.allclose(v2[f2.reshape(-1)], vv[ff.reshape(-1)], atol=1e-6)
     assert abs((vv.max(0) - vv.min(0)).max() - 1.9) < 1e-5
     big_v, big_f, _ = meshes.sphere_with_faces(30000)
     dv, df = meshes.decimate_cluster(*meshes.clean_mesh(big_v, big_f), max_faces=8000)

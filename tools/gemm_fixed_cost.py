@@ -11,7 +11,8 @@ def timeit(fn, n=20):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(); fn(); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
     ts.sort(); return ts[len(ts) // 2]
-os.environ["UTX_GEMM_TILE"] = "256"
+from unitex_amd import _lib
+_lib.set_option("UTX_GEMM_TILE", 256)
 M, N = 50688, 3072     # 2376 tiles = 9.28 rounds of 256 CUs -> 10 rounds
 rounds = 10
 for kind in ("plain", "bias", "gate", "gelu"):

@@ -8,6 +8,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from unitex_amd import _lib  # noqa: E402
 from unitex_amd.flux import ops  # noqa: E402
 
 dev = "cuda:0"
@@ -23,7 +24,7 @@ for (M, N, K) in shapes:
         bias = (torch.rand(N, device=dev, generator=g) - 0.5).to(torch.bfloat16)
         outs = {}
         for tile in ("128", "2562", "256"):
-            os.environ["UTX_GEMM_TILE"] = tile
+            _lib.set_option("UTX_GEMM_TILE", int(tile))
             C = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
             ops.gemm(A, B, bias=bias, out=C)
             outs[tile] = C
@@ -57,7 +58,7 @@ for (M, N, K) in [(13824, 3072, 3072), (13824, 9216, 3072), (13824, 12288, 3072)
     C = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     line = "gemm M=%6d N=%6d K=%6d :" % (M, N, K)
     for tile in ("128", "2562", "256"):
-        os.environ["UTX_GEMM_TILE"] = tile
+        _lib.set_option("UTX_GEMM_TILE", int(tile))
         ms = timeit(lambda: ops.gemm(A, B, out=C))
         line += "  %s %7.3f ms %7.1f TF/s" % (tile, ms, 2.0 * M * N * K / ms / 1e9)
     print(line, flush=True)

@@ -6,6 +6,9 @@ import os
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from unitex_amd import _lib
+if "--ablate" in sys.argv:      # timing ablations (wrong results): libunitex_hip_ablate.so, options still come from UTX_* at utx_init
+    _lib.use_ablation_library()
 from unitex_amd.flux import ops
 
 BF = torch.bfloat16

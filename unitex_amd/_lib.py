@@ -73,6 +73,9 @@ SYMBOLS = {
     "utx_free": (None, [c_void_p]),
     "utx_last_error": (C.c_char_p, [c_void_p]),
     "utx_abi_sizes": (c_int, [C.POINTER(c_int), c_int]),
+    "utx_set_option": (c_int, [C.c_char_p, c_int]),
+    "utx_get_option": (c_int, [C.c_char_p, C.POINTER(c_int)]),
+    "utx_is_ablation_build": (c_int, []),
     "utx_attn_fwd_bf16": (c_int, [c_void_p] * 5 + [c_long] * 7 + [c_int, c_int, c_float, c_void_p]),
     "utx_gemm_bf16": (c_int, [c_void_p, C.POINTER(GemmDesc), c_void_p]),
     "utx_gemv_bf16": (c_int, [c_void_p, C.POINTER(GemvDesc), c_void_p]),
@@ -114,6 +117,15 @@ SYMBOLS = {
 _lib = None
 
 
+def use_ablation_library():
+    """tools/ only: bind libunitex_hip_ablate.so (built by `python unitex_amd/csrc/build.py --ablate`), the build that still
+    contains the wrong-result timing ablations.  Must be called before the first op; never called by the product."""
+    global LIB_PATH
+    if _lib is not None:
+        raise RuntimeError("the library is already loaded")
+    LIB_PATH = os.path.join(_HERE, "lib", "libunitex_hip_ablate.so")
+
+
 def load_library():
     """dlopen the C-ABI library and bind prototypes.  Raises if it has not been built."""
     global _lib
@@ -130,6 +142,27 @@ def load_library():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+OPTION_NAMES = ["UTX_ATTN_GLDS", "UTX_ATTN_FAST", "UTX_ATTN_Q64", "UTX_ATTN_TPB", "UTX_ATTN_TAILSPLIT",
+                "UTX_GEMM_GROUP_M", "UTX_GEMM_TILE", "UTX_GEMM_TAILSPLIT"]
+
+
+def set_option(name, value):
+    """result-preserving launch option (include/unitex_hip.h `utx_set_option`); raises on unknown / ablation-only names."""
+    rc = load_library().utx_set_option(name.encode(), int(value))
+    if rc != 0:
+        raise ValueError("utx_set_option(%s) -> %d (%s)" % (name, rc, "ablation-only switch: not in this library" if rc == -7 else "unknown option"))
+
+
+def get_options():
+    """{name: value} of every launch option as the library currently holds them (what bench.py reports)."""
+    lib, out = load_library(), {}
+    for n in OPTION_NAMES:
+        v = c_int()
+        if lib.utx_get_option(n.encode(), C.byref(v)) == 0:
+            out[n] = v.value
+    return out
 
 
 def check_abi():

@@ -65,7 +65,11 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(AttnParams p) {
     const int head = w / p.nqb;
     const int qb = w - head * p.nqb;
     const int S = p.S;
+#ifdef UTX_ABLATION
     const int dbg = p.dbg;
+#else
+    constexpr int dbg = 0;   // timing ablations (wrong results) are compiled only into libunitex_hip_ablate.so
+#endif
 
     const bf16_t* kbase = p.k + (long)head * p.k_hs;
     const bf16_t* vbase = p.vt + (long)head * p.vt_hs;
@@ -410,11 +414,8 @@ static int launch_variant(const AttnParams& p0, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
-// A/B knob: UTX_ATTN_FAST=0 selects the per-tile-max softmax (re-read per call so one process can compare).
-static int attn_fast() {
-    const char* e = getenv("UTX_ATTN_FAST");
-    return e ? atoi(e) : 2;
-}
+// A/B knob (utx_set_option UTX_ATTN_FAST): 0 selects the per-tile-max softmax of the register-staged kernel.
+static int attn_fast() { return g_utx_opt.attn_fast; }
 
 // softmax_scale > 0: scores are multiplied by softmax_scale (natural-exp softmax, the reference's SDPA).
 // softmax_scale == 0: Q was pre-multiplied by scale*log2(e) upstream (utx_qkv_post q_scale) -> scores are
@@ -429,13 +430,12 @@ extern "C" int utx_launch_attn_fwd(const void* q, const void* k, const void* vt,
     p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.vt = (const bf16_t*)vt; p.o = (bf16_t*)o;
     p.q_hs = q_hs; p.q_ss = q_ss; p.k_hs = k_hs; p.k_ss = k_ss; p.vt_hs = vt_hs; p.vt_ds = vt_ds;
     p.o_ss = o_ss; p.H = H; p.S = S; p.nqb = 0;
-    { const char* e = getenv("UTX_ATTN_DEBUG"); p.dbg = e ? atoi(e) : 0; }
+    p.dbg = g_utx_opt.attn_debug_abl;   // always 0 in the product library (capi.cpp)
     p.scale_log2 = scale * 1.4426950408889634f;
     const bool presc = (scale == 0.f);
     p.flags = nullptr; p.flag_hs = 0;
     // opt-in: the 4 x 64 kernel (attention_q64.hip) followed by its repair pass; it needs whole 64-key tiles
-    { const char* e = getenv("UTX_ATTN_Q64");
-      if (e && atoi(e) == 1 && (S & 63) == 0) {
+    { if (g_utx_opt.attn_q64 == 1 && (S & 63) == 0) {
           static unsigned char* flag_buf[16] = {nullptr}; static size_t flag_cap[16] = {0};
           int dev = 0; if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return -5;
           const size_t need = (size_t)H * (size_t)(S / 64);
@@ -451,7 +451,7 @@ extern "C" int utx_launch_attn_fwd(const void* q, const void* k, const void* vt,
       } }
     // default: the LDS-DMA staged kernel (attention_glds.hip), +5 % over register staging (profiles/r01_perf_attn_ablation.log);
     // UTX_ATTN_GLDS=0 selects the register-staged variants below for A/B
-    { const char* e = getenv("UTX_ATTN_GLDS"); if (!e || atoi(e) != 0) return utx_launch_attn_fwd_glds(&p, presc ? 1 : 0, stream); }
+    if (g_utx_opt.attn_glds != 0) return utx_launch_attn_fwd_glds(&p, presc ? 1 : 0, stream);
     const int fast = attn_fast();   // 2 = block-pipelined sum-checked softmax (default), 1 = sum-checked, 0 = per-tile max
     if (fast == 0) return presc ? launch_variant<8, 1, 0>(p, stream) : launch_variant<8, 0, 0>(p, stream);
     if (fast == 1) return presc ? launch_variant<8, 1, 1>(p, stream) : launch_variant<8, 0, 1>(p, stream);

@@ -321,8 +321,7 @@ static int launch_glds(AttnParams p, hipStream_t stream) {
     // of a workgroup's duration instead of a whole one (S = 13 824: 1296 workgroups = 5 rounds of 256 CUs + 16 -> the 16 run
     // as 256 sixteenths; S = 50 688: 18 rounds + 144 -> 1008 sevenths).  UTX_ATTN_TAILSPLIT=0 disables it.
     static int ncu = 0;
-    const char* ts_env = getenv("UTX_ATTN_TAILSPLIT");
-    const int enabled = (ts_env && atoi(ts_env) == 0) ? 0 : 1;
+    const int enabled = g_utx_opt.attn_tailsplit != 0;
     if (!ncu) { int dev = 0; hipDeviceProp_t pr; ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
     const int nfull = (nwg / ncu) * ncu, r = nwg - nfull;
     const int nt_all = (p.S + AG_KVB - 1) / AG_KVB;
@@ -363,13 +362,14 @@ static int launch_glds(AttnParams p, hipStream_t stream) {
 
 // UTX_ATTN_TPB: tiles per barrier (ring = 2 groups of TPB tiles): 1 -> 64 KB LDS, 2 -> 128 KB
 extern "C" int utx_launch_attn_fwd_glds(const AttnParams* p, int presc, hipStream_t stream) {
-    const char* e = getenv("UTX_ATTN_TPB");
-    const int tpb = e ? atoi(e) : 1;
+    const int tpb = g_utx_opt.attn_tpb;
     if (tpb == 2) return presc ? launch_glds<1, 2>(*p, stream) : launch_glds<0, 2>(*p, stream);
-    { const char* v = getenv("UTX_ATTN_VAR"); const int var = v ? atoi(v) : 0;   // A/B only: 1 = no s_setprio, 2 = no interleave hints, 3 = half the fragment reads (wrong results), 4 = row sums with v_pk_add_f32 (slower beside MFMAs)
+#ifdef UTX_ABLATION
+    { const int var = g_utx_opt.attn_var_abl;   // timing A/B only: 1 = no s_setprio, 2 = no interleave hints, 3 = half the fragment reads (WRONG results), 4 = row sums with v_pk_add_f32
       if (var == 1 && presc) return launch_glds<1, 1, 1>(*p, stream);
       if (var == 2 && presc) return launch_glds<1, 1, 2>(*p, stream);
       if (var == 3 && presc) return launch_glds<1, 1, 3>(*p, stream);
       if (var == 4 && presc) return launch_glds<1, 1, 4>(*p, stream); }
+#endif
     return presc ? launch_glds<1, 1>(*p, stream) : launch_glds<0, 1>(*p, stream);
 }

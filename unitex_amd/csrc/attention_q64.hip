@@ -351,8 +351,8 @@ static int launch_q64(AttnParams p, hipStream_t stream) {
 }
 
 extern "C" int utx_launch_attn_fwd_q64(const AttnParams* p, int presc, hipStream_t stream) {
-    static int abl = -1;
-    if (abl < 0) { const char* e = getenv("UTX_ATTN_VAR"); abl = e ? atoi(e) : 0; }
+#ifdef UTX_ABLATION
+    const int abl = g_utx_opt.attn_var_abl;   // timing ablations, wrong results by design
     if (presc) switch (abl) {
         case 1: return launch_q64<1, 1>(*p, stream);
         case 2: return launch_q64<1, 2>(*p, stream);
@@ -363,5 +363,6 @@ extern "C" int utx_launch_attn_fwd_q64(const AttnParams* p, int presc, hipStream
         case 30: return launch_q64<1, 30>(*p, stream);
         default: break;
     }
+#endif
     return presc ? launch_q64<1, 0>(*p, stream) : launch_q64<0, 0>(*p, stream);
 }

@@ -49,24 +49,30 @@ def _newer(src, obj):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def _compile(item):
+def _compile(item, objdir=None, defines=()):
     name, extra = item
+    objdir = objdir or OBJDIR
     src = os.path.join(HERE, name)
-    obj = os.path.join(OBJDIR, name + ".o")
+    obj = os.path.join(objdir, name + ".o")
     if _newer(src, obj):
-        cmd = [HIPCC] + COMMON + extra + ["-c", src, "-o", obj]
+        cmd = [HIPCC] + COMMON + list(defines) + extra + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (name, r.stderr[-4000:]))
     return obj
 
 
-def build(verbose=True):
-    os.makedirs(OBJDIR, exist_ok=True)
+def build(verbose=True, ablate=False):
+    """ablate=True builds libunitex_hip_ablate.so instead: the same sources with -DUTX_ABLATION, i.e. with the timing-ablation
+    switches (UTX_ATTN_VAR / UTX_ATTN_DEBUG / UTX_GEMM_DEBUG -- wrong results by design) compiled in.  Only tools/ load it
+    (unitex_amd._lib.use_ablation_library()); the product, the tests and bench.py never do."""
+    objdir = OBJDIR + ("_ablate" if ablate else "")
+    defines = ["-DUTX_ABLATION"] if ablate else []
+    os.makedirs(objdir, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
     with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
-        objs = list(ex.map(_compile, SOURCES))
-    out = os.path.join(LIBDIR, "libunitex_hip.so")
+        objs = list(ex.map(lambda it: _compile(it, objdir, defines), SOURCES))
+    out = os.path.join(LIBDIR, "libunitex_hip_ablate.so" if ablate else "libunitex_hip.so")
     if (not os.path.exists(out)) or any(os.path.getmtime(o) > os.path.getmtime(out) for o in objs):
         cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", out] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -78,5 +84,5 @@ def build(verbose=True):
 
 
 if __name__ == "__main__":
-    build()
+    build(ablate="--ablate" in sys.argv)
     sys.exit(0)

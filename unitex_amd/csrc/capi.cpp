@@ -4,7 +4,37 @@
 #include <stdio.h>
 #include <string.h>
 #include <string>
+#include <stdlib.h>
 #include "kernels.h"
+
+UtxOptions g_utx_opt = {1, 2, 0, 1, 1, 0, 0, 0, 0, 0, 0};
+
+struct OptName { const char* name; int UtxOptions::*field; bool ablation; };
+static const OptName kOptions[] = {
+    {"UTX_ATTN_GLDS", &UtxOptions::attn_glds, false},       {"UTX_ATTN_FAST", &UtxOptions::attn_fast, false},
+    {"UTX_ATTN_Q64", &UtxOptions::attn_q64, false},         {"UTX_ATTN_TPB", &UtxOptions::attn_tpb, false},
+    {"UTX_ATTN_TAILSPLIT", &UtxOptions::attn_tailsplit, false},
+    {"UTX_GEMM_GROUP_M", &UtxOptions::gemm_group_m, false}, {"UTX_GEMM_TILE", &UtxOptions::gemm_tile, false},
+    {"UTX_GEMM_TAILSPLIT", &UtxOptions::gemm_tailsplit, false},
+    {"UTX_ATTN_VAR", &UtxOptions::attn_var_abl, true},      {"UTX_ATTN_DEBUG", &UtxOptions::attn_debug_abl, true},
+    {"UTX_GEMM_DEBUG", &UtxOptions::gemm_debug_abl, true},
+};
+#ifdef UTX_ABLATION
+static const bool kAblationBuild = true;
+#else
+static const bool kAblationBuild = false;
+#endif
+
+static void options_from_env_once() {
+    static bool done = false;
+    if (done) return;
+    done = true;
+    for (const OptName& o : kOptions) {
+        if (o.ablation && !kAblationBuild) continue;      // wrong-result switches do not exist in the product library
+        const char* e = getenv(o.name);
+        if (e && *e) g_utx_opt.*(o.field) = atoi(e);
+    }
+}
 
 struct utx_ctx {
     int device;
@@ -37,11 +67,36 @@ int utx_init(int device, utx_ctx** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return -5;
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return -6;  // MI355X only, by design
+    options_from_env_once();
     utx_ctx* c = new utx_ctx();
     c->device = device;
     *out = c;
     return 0;
 }
+
+int utx_set_option(const char* name, int value) {
+    if (!name) return -2;
+    for (const OptName& o : kOptions)
+        if (strcmp(name, o.name) == 0) {
+            if (o.ablation && !kAblationBuild) return -7;
+            g_utx_opt.*(o.field) = value;
+            return 0;
+        }
+    return -2;
+}
+
+int utx_get_option(const char* name, int* value) {
+    if (!name || !value) return -2;
+    for (const OptName& o : kOptions)
+        if (strcmp(name, o.name) == 0) {
+            if (o.ablation && !kAblationBuild) return -7;
+            *value = g_utx_opt.*(o.field);
+            return 0;
+        }
+    return -2;
+}
+
+int utx_is_ablation_build(void) { return kAblationBuild ? 1 : 0; }
 
 void utx_free(utx_ctx* ctx) { delete ctx; }
 

@@ -105,7 +105,6 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_bf16_kernel(GemmParams
     // ---- XCD-aware, L2-blocked tile order (see header)
     const int w = xcd_remap(blockIdx.x, gridDim.x);
     const int ntn = p.ntn & 0xffff, group_m = (p.ntn >> 16) & 0xff;
-    const int dbg = p.ntn >> 24;   // perf-debug only (UTX_GEMM_DEBUG): 1 = skip operand staging, 2 = skip MFMAs
     const int ntm_ = (p.M + BM - 1) / BM;
     const int per_group = group_m * ntn;
     const int grp = w / per_group, rem = w - grp * per_group;
@@ -180,8 +179,6 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_bf16_kernel(GemmParams
     const int ra0 = wm * WMR + l31, rb0 = wn * WNR + l31;
     const int aoff0 = ra0 * 128, aswz0 = (ra0 >> 1) & 7;
     const int boff0 = rb0 * 128 + A_BYTES, bswz0 = (rb0 >> 1) & 7;
-    (void)dbg;
-
     GM_STAGE(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
@@ -342,7 +339,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_8ph_kernel(GemmParams p, G8Spl
     const int split = wid - item * ks;
     const int w = sp.tile_base + item;
     const int ntn = p.ntn & 0xffff, group_m = (p.ntn >> 16) & 0xff;
-    const int dbg = p.ntn >> 24;   // perf ablation only (UTX_GEMM_DEBUG): 1 = no operand staging, 2 = always stage K-tile 0
+#ifdef UTX_ABLATION
+    const int dbg = p.ntn >> 24;   // timing ablation (libunitex_hip_ablate.so only; wrong results): 1 = no operand staging, 2 = always stage K-tile 0
+#else
+    constexpr int dbg = 0;
+#endif
     const int ntm_ = (p.M + BM - 1) / BM;
     const int per_group = group_m * ntn;
     const int grp = w / per_group, rem = w - grp * per_group;
@@ -673,8 +674,7 @@ static int launch_gemm8(GemmParams p, hipStream_t stream, int group_env, int dbg
     // enough that a tile's fixed cost (prologue + epilogue, ~10 us against ~1.4 us per K-tile) does not dominate.
     static int ncu = 0;
     if (!ncu) { int dev = 0; hipDeviceProp_t pr; ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
-    const char* ts_env = getenv("UTX_GEMM_TAILSPLIT");
-    const bool enabled = ts_env && atoi(ts_env) == 1 && dbg_env == 0;
+    const bool enabled = g_utx_opt.gemm_tailsplit == 1 && dbg_env == 0;
     const int nfull = (tiles / ncu) * ncu, r = tiles - nfull;
     int best_ks = 1;
     if (enabled && nfull > 0 && r > 0) {
@@ -717,16 +717,13 @@ extern "C" int utx_launch_gemm_bf16(const GemmParams* hp, hipStream_t stream) {
     if (p.K2 > 0 && (!p.A2 || !p.B2 || (p.lda2 & 7) || (p.ldb2 & 7) || p.lora_seg_n <= 0 || (p.lora_seg_n % 128))) return -2;
     if (p.gate && (!p.res || (p.ldres & 7))) return -2;
     if (p.n_split < p.N && (!p.C1 || (p.n_split % 128) || (p.ldc1 & 7))) return -2;
-    static int group_env = -1, dbg_env = -1, tile_env = -1;
+    const int group_env = g_utx_opt.gemm_group_m, dbg_env = g_utx_opt.gemm_debug_abl, tile_env = g_utx_opt.gemm_tile;
     if (p.conv_Wo > 0) {   // implicit 3x3 convolution: 128^2 kernel, A rows gathered per tap
         if (p.K2 > 0 || !p.zero_page || p.conv_cin_log2 < 6 || p.K != (9 << p.conv_cin_log2) || p.conv_Hi <= 0 || p.conv_Wi <= 0 ||
             p.conv_stride < 1 || p.conv_stride > 2 || p.conv_pad < 0 || p.conv_pad > 1 || (p.conv_up & ~1) || (p.M % p.conv_Wo))
             return -2;
         return launch_gemm<128, 128, 2, 2, true>(p, stream, 0, 0);
     }
-    { const char* e = getenv("UTX_GEMM_GROUP_M"); group_env = e ? atoi(e) : 0; }
-    { const char* e = getenv("UTX_GEMM_DEBUG"); dbg_env = e ? atoi(e) : 0; }
-    { const char* e = getenv("UTX_GEMM_TILE"); tile_env = e ? atoi(e) : 0; }   // re-read per call: lets one process A/B the kernels
     // 256^2 tiles need every column boundary on a 256 multiple and enough tiles to fill the chip
     const bool ok256 = (p.N % 256 == 0) && (p.n_split >= p.N || p.n_split % 256 == 0) &&
                        (p.gelu_from >= p.N || p.gelu_from % 256 == 0) &&

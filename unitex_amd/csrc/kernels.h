@@ -26,6 +26,23 @@ struct AttnParams {
     bf16_t* part_o;        // [items][nsplit][256][128] bf16
     float* part_lse;       // [items][nsplit][256] f32: running maximum + log2(row sum)
 };
+// Launch options.  Every field is result-preserving (kernel selection / scheduling A/B): read ONCE from the environment by
+// the first utx_init (UTX_ATTN_*, UTX_GEMM_* variables of the same names), afterwards changed only through utx_set_option.
+// The three `*_abl` fields switch timing ablations that compute WRONG results; they exist only in the UTX_ABLATION build
+// (libunitex_hip_ablate.so, used by tools/ -- never by the product, the tests or bench.py).
+struct UtxOptions {
+    int attn_glds;        // 1 (default): LDS-DMA staged attention kernel; 0: register-staged variants
+    int attn_fast;        // register-staged kernel only: 2 block-pipelined sum-checked softmax, 1 sum-checked, 0 per-tile max
+    int attn_q64;         // 1: the 4 x 64 kernel + repair pass
+    int attn_tpb;         // tiles per barrier of the LDS-DMA kernel (1 | 2)
+    int attn_tailsplit;   // 1 (default): key-split tail round
+    int gemm_group_m;     // 0 = built-in GROUP_M
+    int gemm_tile;        // 0 auto, 128, 256, 2562 (2-barrier 256^2)
+    int gemm_tailsplit;   // 1: K-split tail round of the 8-phase GEMM (off by default)
+    int attn_var_abl, attn_debug_abl, gemm_debug_abl;
+};
+extern UtxOptions g_utx_opt;
+
 typedef utx_gemm_desc GemmParams;
 typedef utx_knn_desc KnnParams;
 typedef utx_gemv_desc GemvParams;

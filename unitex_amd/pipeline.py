@@ -78,9 +78,11 @@ class RGBTextureFullPipelineBase:
         host-side equivalents of texturetools/meshes.py: .obj / .glb in, rescaled to bbox*scale; a mesh with UVs passes
         through, one without is cleaned, brought into [min_faces, max_faces] and unwrapped (builder-defined atlas)."""
         from .texturetools import meshes
-        verts, faces, uvs = meshes.prepare_blank_mesh(input_mesh_path, min_faces=min_faces, max_faces=max_faces, scale=scale,
-                                                      atlas=self.atlas_size, gutter=4.0)
-        meshes.save_obj(os.path.join(save_dir, "processed_mesh.obj"), verts, faces, uvs)
+        verts, faces, uvs, faces_uv = meshes.prepare_blank_mesh(input_mesh_path, min_faces=min_faces, max_faces=max_faces, scale=scale,
+                                                                atlas=self.atlas_size, gutter=4.0)
+        # shared positions + per-corner UVs: the condition render smooths normals over position indices (export_condition reads
+        # them through load_obj), the inverse renderer splits per (v, vt) pair (load_mesh)
+        meshes.save_obj(os.path.join(save_dir, "processed_mesh.obj"), verts, faces, uvs, faces_uv=faces_uv)
 
     @CPUTimer("preprocess_reference_image")
     def preprocess_reference_image(self, save_dir, input_image_path, scale=0.95, color="grey"):
@@ -152,8 +154,9 @@ class RGBTextureFullPipelineBase:
         T = self.atlas_size
         textured, reprojected_uv, visable_mask, completed = self.inverse_renderer.infer(
             input_mesh_path, c2ws=cam["c2ws"], intrinsics=cam["intrinsics"], image_attrs=image_attrs, perspective=cam["perspective"],
-            H=HP, W=WP, H2D=T, W2D=T, method=method, kdtree_inpainting=inpainting, reproject_inpainting=inpainting, grad_norm_threhold=0.15,
-            ray_normal_angle_threhold=100, filt_gradient_points=inpainting)
+            H=HP, W=WP, H2D=T, W2D=T, method=method, kdtree_n_neighbors=8, kdtree_n_neighbors_visiable=4, kdtree_inpainting=inpainting,
+            reproject_inpainting=inpainting, grad_norm_threhold=0.15, ray_normal_angle_threhold=100,
+            filt_gradient_points=inpainting)   # keyword set of the reference call, pipeline.py:333-348
         textured.export(os.path.join(save_dir, "textured_mesh.glb"))
 
         def save_mask(t, name):   # torchvision save_image: *255 + 0.5, clamp, uint8 [3p]

@@ -191,8 +191,11 @@ def load_glb(path):
         stride = bv.get("byteStride", 0)
         item = np.dtype(dt).itemsize * nc
         if stride and stride != item:
-            raw = np.frombuffer(binc, dtype=np.uint8, count=stride * a["count"], offset=start).reshape(a["count"], stride)[:, :item]
-            arr = np.frombuffer(raw.tobytes(), dtype=dt).reshape(a["count"], nc)
+            # interleaved attributes: element i sits at start + i*stride; the last element ends `item` bytes in, NOT a full
+            # stride -- reading count*stride bytes runs past the bufferView when accessor.byteOffset > 0
+            span = np.frombuffer(binc, dtype=np.uint8, count=stride * (a["count"] - 1) + item, offset=start)
+            raw = np.lib.stride_tricks.as_strided(span, shape=(a["count"], item), strides=(stride, 1))
+            arr = np.frombuffer(np.ascontiguousarray(raw).tobytes(), dtype=dt).reshape(a["count"], nc)
         else:
             arr = np.frombuffer(binc, dtype=dt, count=a["count"] * nc, offset=start).reshape(a["count"], nc)
         if a.get("normalized") and dt != np.float32:
@@ -319,10 +322,10 @@ def decimate_cluster(verts, faces, max_faces):
 
 
 def unwrap_grid(verts, faces, atlas=2048, gutter=4.0):
-    """Builder-defined UV atlas (the reference calls UVAtlas through open3d, uv_atlas.py:171: size 2048, gutter 4):
-    every triangle gets its own right-triangle slot, two slots per square cell of a regular grid, each inset by
-    `gutter`/2 texels so that no two triangles share a texel.  Bijective by construction, no parametrisation distortion
-    control; vertices are duplicated per face.  Returns verts [3F,3], faces [F,3], uvs [3F,2] in [0,1]."""
+    """Fallback UV atlas: every triangle gets its own right-triangle slot, two slots per square cell of a regular grid, each
+    inset by `gutter`/2 texels so that no two triangles share a texel.  Bijective by construction, no distortion control.
+    Positions stay SHARED (smooth vertex normals for the condition render, as with the reference's per-corner
+    `triangle_uvs`, uv_atlas.py:171-175): returns verts [V,3], faces [F,3], uvs [3F,2] in [0,1], faces_uv [F,3]."""
     F = len(faces)
     ncell = (F + 1) // 2
     n = int(np.ceil(np.sqrt(ncell)))
@@ -343,9 +346,8 @@ def unwrap_grid(verts, faces, atlas=2048, gutter=4.0):
     up = np.stack([np.stack([x0 + cs - g, y0 + cs - g], 1), np.stack([x0 + cs - g - d, y0 + cs - g], 1),
                    np.stack([x0 + cs - g, y0 + cs - g - d], 1)], 1)
     tri_uv = np.where(upper[:, None, None], up, lo) / float(atlas)          # [F,3,2]
-    v_out = verts[faces.reshape(-1)].astype(np.float32)
-    f_out = np.arange(3 * F, dtype=np.int32).reshape(F, 3)
-    return v_out, f_out, tri_uv.reshape(-1, 2).astype(np.float32)
+    f_uv = np.arange(3 * F, dtype=np.int32).reshape(F, 3)
+    return verts.astype(np.float32), faces.astype(np.int32), tri_uv.reshape(-1, 2).astype(np.float32), f_uv
 
 
 def normalise_to_bbox(verts, scale):
@@ -353,17 +355,25 @@ def normalise_to_bbox(verts, scale):
     return ((verts - 0.5 * (lo + hi)) / ((hi - lo).max() / (2.0 * scale))).astype(np.float32)
 
 
-def prepare_blank_mesh(path, min_faces=20_000, max_faces=200_000, scale=1.0, atlas=2048, gutter=4.0):
+def prepare_blank_mesh(path, min_faces=20_000, max_faces=200_000, scale=1.0, atlas=2048, gutter=4.0, unwrap="grid"):
     """preprocess_blank_mesh_o3d (uv_atlas.py:131-175) with the host-side equivalents above: rescale to the bbox;
     a mesh that already has UVs passes through; otherwise clean, bring the face count into [min_faces, max_faces],
-    and unwrap.  Returns verts, faces, uvs (one uv per vertex)."""
-    verts, faces, uvs, _ = load_mesh(path)
+    and unwrap.  Returns verts [V,3], faces [F,3], uvs [Vt,2], faces_uv [F,3]: positions stay shared, UVs are per corner
+    (write with save_obj(..., faces_uv=faces_uv); load_mesh splits per (v, vt) pair for the inverse renderer)."""
+    ext = path.lower().rsplit(".", 1)[-1]
+    if ext == "obj":
+        verts, faces, uvs, faces_uv = load_obj(path)
+    else:
+        verts, faces, uvs, _ = load_mesh(path)
+        faces_uv = faces if uvs is not None else None
     verts = normalise_to_bbox(verts, scale)
     if uvs is not None:
-        return verts, faces, uvs
+        return verts, faces, uvs, faces_uv
     verts, faces = clean_mesh(verts, faces)
     if len(faces) > max_faces:
         verts, faces = decimate_cluster(verts, faces, max_faces)
     while len(faces) < min_faces and 4 * len(faces) <= max_faces:
         verts, faces = subdivide_midpoint(verts, faces)
-    return unwrap_grid(verts, faces, atlas=atlas, gutter=gutter)
+    if unwrap == "grid":
+        return unwrap_grid(verts, faces, atlas=atlas, gutter=gutter)
+    raise ValueError("unknown unwrap method %r" % (unwrap,))
