@@ -223,3 +223,39 @@ def test_reproject_and_query_field_forwards_variant_switches(tmp_path):
         assert seen["export"].endswith("textured_mesh.glb") and seen["cleared"]
         for name in ("visable_uv_mask.png", "valid_uv_mask.png", "completed_uv.png"):
             assert (tmp_path / name).exists()
+
+
+def test_vertex_normal_weightings_area_and_angle():
+    """VideoExporter's production default is trimesh's angle weighting (`video._vertex_normals`), the reference's own
+    fallback is area weighting (mesh/structure.py:522-548, pinned by G9).  (i) On a finely tessellated unit sphere both must be
+    the radial direction (1 - cos < 1e-4, outward); (ii) on a regular fan both give the axis exactly; (iii) on a skewed fan --
+    one long thin triangle of large area but small corner angle -- they must differ, and the angle-weighted normal must equal
+    an independent per-corner evaluation of sum(angle_i * n_i)."""
+    from unitex_amd.texturetools.video import _vertex_normals
+    v, f = meshes.closed_sphere(128, 64)
+    for w in ("area", "angle"):
+        n = _vertex_normals(torch.from_numpy(v), torch.from_numpy(f), weighting=w).double().numpy()
+        d = (n * v.astype(np.float64)).sum(-1)
+        assert d.min() > 1.0 - 1e-4, (w, d.min())
+    # regular hexagonal fan around the apex of a cone: symmetric -> the axis for both weightings
+    ring = [[np.cos(t), np.sin(t), -0.5] for t in np.arange(6) * np.pi / 3]
+    fv = np.asarray([[0.0, 0.0, 0.0]] + ring, np.float32)
+    ff = np.asarray([[0, 1 + i, 1 + (i + 1) % 6] for i in range(6)], np.int32)
+    for w in ("area", "angle"):
+        n0 = _vertex_normals(torch.from_numpy(fv), torch.from_numpy(ff), weighting=w)[0].numpy()
+        assert np.allclose(n0, [0, 0, 1], atol=1e-6), (w, n0)
+    # skewed fan: two triangles share vertex 0; the second is long and thin (area 10x, corner angle at vertex 0 ~ 0.1 rad)
+    sv = np.asarray([[0, 0, 0], [1, 0, 0], [0, 1, 0],          # triangle A in the z = 0 plane: normal +z, angle pi/2, area 0.5
+                     [0, 50.0, 0.0], [0, 50.0, -5.0]], np.float32)   # triangle B in the x = 0 plane: normal -x... see below
+    sf = np.asarray([[0, 1, 2], [0, 3, 4]], np.int32)
+    na = _vertex_normals(torch.from_numpy(sv), torch.from_numpy(sf), weighting="area")[0].double().numpy()
+    ng = _vertex_normals(torch.from_numpy(sv), torch.from_numpy(sf), weighting="angle")[0].double().numpy()
+    exp = np.zeros(3)
+    for tri in sf:       # independent evaluation, corner of vertex 0 only
+        p0, p1, p2 = (sv[i].astype(np.float64) for i in tri)
+        fn = np.cross(p1 - p0, p2 - p0); fn /= np.linalg.norm(fn)
+        e1, e2 = (p1 - p0) / np.linalg.norm(p1 - p0), (p2 - p0) / np.linalg.norm(p2 - p0)
+        exp += np.arccos(np.clip(e1 @ e2, -1, 1)) * fn
+    exp /= np.linalg.norm(exp)
+    assert np.allclose(ng, exp, atol=1e-6)
+    assert np.linalg.norm(na - ng) > 0.5, "the skewed fan must separate the two weightings (area %s, angle %s)" % (na, ng)

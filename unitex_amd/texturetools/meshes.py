@@ -48,6 +48,23 @@ def sphere_with_faces(n_faces, **kw):
     return make_bumpy_sphere(n_lon, n_lat, **kw)
 
 
+def closed_sphere(n_lon, n_lat):
+    """closed unit lat-long sphere WITHOUT UVs (shared pole vertices, no seam duplicates): the UV-less input case of
+    prepare_blank_mesh and the analytic case of the vertex-normal tests."""
+    lon = np.linspace(0, 2 * np.pi, n_lon, endpoint=False)
+    lat = np.linspace(0, np.pi, n_lat + 1)[1:-1]
+    v = [[0.0, 1.0, 0.0]] + [[np.sin(a) * np.cos(o), np.cos(a), np.sin(a) * np.sin(o)] for a in lat for o in lon] + [[0.0, -1.0, 0.0]]
+    R, f = len(lat), []
+    f += [[0, 1 + (i + 1) % n_lon, 1 + i] for i in range(n_lon)]
+    for r in range(R - 1):
+        for i in range(n_lon):
+            a, b = 1 + r * n_lon + i, 1 + r * n_lon + (i + 1) % n_lon
+            f += [[a, b, a + n_lon], [b, b + n_lon, a + n_lon]]
+    last = len(v) - 1
+    f += [[last, 1 + (R - 1) * n_lon + i, 1 + (R - 1) * n_lon + (i + 1) % n_lon] for i in range(n_lon)]
+    return np.asarray(v, np.float32), np.asarray(f, np.int32)
+
+
 def save_obj(path, verts, faces, uvs=None, faces_uv=None, mtl=None):
     with open(path, "w") as f:
         if mtl:
