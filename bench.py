@@ -11,10 +11,12 @@ joint-strip semantics: one 1024x6144 strip -> 24576 noise + 24576 c
 (512^2 reference image) + 512 text tokens = 50688 tokens, 2454 TFLOP/step.
 `--workload ref512x6` is the reference's shipped operating point (512x3072 strip, S = 13824).
 
-N > 1: the joint-attention DiT does not shard by view -- by default ranks run independent replicas
-(one mesh per GPU, no data-path collective): value = N * steps / max-over-ranks time, scaling "weak".
-`--parallelism ulysses` (opt-in) runs ONE job head-parallel over the N GPUs (unitex_amd/flux/ulysses.py: two
-all-to-alls per layer over RCCL/xGMI): value = steps / time, scaling "strong".
+N > 1 (default `--parallelism ulysses`): ONE job over the N GPUs, the way north_star asks for a single mesh -- the joint-attention
+DiT cannot shard by view, so it runs head-parallel sequence parallelism (unitex_amd/flux/ulysses.py: per-token
+work on S/N tokens, attention on 24/N heads over the full sequence, two all-to-alls per layer over RCCL/xGMI): value = steps /
+max-over-ranks time, scaling "strong".  The view-sharded back-projection (one view block per rank + ONE all-gather of the atlas
+layers) is run and timed after the timed region, with the all-gather reported separately.  `--parallelism replicas` keeps the
+round-1 behaviour (N independent meshes, no data-path collective, weak scaling) as a secondary mode.
 
 Contract: python bench.py --gpus N --steps K --warmup W  -> rank 0 prints ONE JSON line.
 """
@@ -81,6 +83,45 @@ def cpu_baseline(S_full, threads):
             "measured_seconds": dt}
 
 
+def host_cores():
+    """(threads usable by this process, physical cores from lscpu or None)."""
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    phys = None
+    try:
+        import subprocess
+        txt = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        kv = {l.split(":")[0].strip(): l.split(":", 1)[1].strip() for l in txt.splitlines() if ":" in l}
+        phys = int(kv["Socket(s)"]) * int(kv["Core(s) per socket"])
+    except Exception:  # noqa: BLE001 -- lscpu missing / unparsable: report None, never guess
+        pass
+    return ncpu, phys
+
+
+def cpu_config1(threads):
+    """BASELINE configs[0] run to COMPLETION on the host cores (the one CPU number that is not extrapolated):
+    oracle/dit_ref.py fp32, full FLUX.1-dev shape (19 + 38 blocks, D = 3072), 512 x 2048 strip of 4 views + control strip +
+    512^2 dual + 512 text tokens = 9728 tokens, 4 flow-match Euler steps with the condition re-pin."""
+    from oracle import dit_ref
+    torch.set_num_threads(threads)
+    cfg = dit_ref.FluxConfig()
+    sd = dit_ref.make_synthetic_state_dict(cfg, seed=0, dtype=torch.float32)
+    HL, WL, DL = 32, 128, 32
+    g = torch.Generator().manual_seed(63)
+    noise = torch.randn(HL * WL, 64, generator=g)
+    cond = torch.randn(HL * WL + DL * DL, 64, generator=g)
+    img_ids = torch.cat([dit_ref.latent_image_ids(HL, WL), dit_ref.latent_image_ids(HL, WL, offset_y=HL),
+                         dit_ref.latent_image_ids(DL, DL, offset_x=WL, offset_y=HL)], 0)
+    t0 = time.perf_counter()
+    out = dit_ref.denoise_loop(sd, cfg, noise, cond, torch.zeros(512, cfg.joint_dim), torch.zeros(1, cfg.pooled_dim),
+                               torch.zeros(512, 3), img_ids, 4, guidance=3.5, emulate_bf16=False)
+    dt = time.perf_counter() - t0
+    S = 512 + noise.shape[0] + cond.shape[0]
+    fl, _ = step_flops(S)
+    return {"seconds": dt, "steps": 4, "steps_per_s": 4.0 / dt, "tokens": S, "tflops": 4.0 * fl / dt / 1e12, "cores": threads,
+            "finite": bool(torch.isfinite(torch.as_tensor(out)).all()), "kind": "port",
+            "sample": "BASELINE configs[0] complete: 4 steps x 57 blocks at S = %d, fp32, not extrapolated" % S}
+
+
 def cpu_baseline_backprojection():
     """oracle/geom_ref (single-threaded C + numpy) on a bounded sample of the back-projection: 20k-face mesh, six
     256^2 views, 512^2 atlas (1/16 of the texels of the GPU measurement); scaled by texel count."""
@@ -123,9 +164,12 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="replay the per-step plan as one HIP graph (FluxDiT.capture_graph) in the timed region; the roofline "
                          "kernel is then timed in one extra eager step after it (events cannot bracket kernels inside a graph)")
-    ap.add_argument("--parallelism", default=os.environ.get("UTX_PARALLELISM", "replicas"), choices=["replicas", "ulysses"],
-                    help="N > 1: 'replicas' = N independent jobs (weak scaling, default); 'ulysses' = ONE job, head-parallel "
-                         "sequence parallelism with two all-to-alls per layer over RCCL (strong scaling)")
+    ap.add_argument("--parallelism", default=os.environ.get("UTX_PARALLELISM", "ulysses"), choices=["replicas", "ulysses"],
+                    help="N > 1: 'ulysses' (default) = ONE job, head-parallel sequence parallelism with two all-to-alls per layer "
+                         "over RCCL (strong scaling) + view-sharded back-projection; 'replicas' = N independent jobs (weak scaling)")
+    ap.add_argument("--cpu-config1", action="store_true",
+                    help="also run BASELINE configs[0] (512^2 x 4 views, S = 9728, 4 denoise steps, fp32) to COMPLETION on the host "
+                         "cores with the oracle (~15-30 min): the one CPU number that is not extrapolated (SURVEY 8d)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -228,22 +272,57 @@ def main():
         dt = float(tt.item())
     assert torch.isfinite(lat.float()).all(), "non-finite latents after the timed steps"
 
+    # ---- N > 1, one job: un-overlapped cost of the two exchanges of a layer on the real buffers (outside the timed region),
+    # and the view-sharded back-projection with its ONE all-gather -- every rank takes part, rank 0 reports
+    exchange = None
+    if ulysses:
+        ex = model.ex
+        tmp = torch.empty(ex.S_loc, shape.dim, dtype=torch.bfloat16, device=dev)
+        reps = 8
+        for _ in range(2):
+            ex.heads_in(); ex.tokens_out(tmp)
+        torch.cuda.synchronize(); barrier()
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        t_in = t_out = 0.0
+        for _ in range(reps):
+            e[0].record(); ex.heads_in(); e[1].record(); ex.tokens_out(tmp); e[2].record()
+            torch.cuda.synchronize()
+            t_in += e[0].elapsed_time(e[1]); t_out += e[1].elapsed_time(e[2])
+        exchange = {"qkv_all_to_all_plus_unpack_ms": t_in / reps, "out_all_to_all_plus_unpack_ms": t_out / reps,
+                    "bytes_per_rank_per_layer": ex.bytes_per_layer, "layers": N_DOUBLE + N_SINGLE,
+                    "note": "measured back to back without compute; in the step the Q/K/V exchange of the 38 single blocks runs beside the MLP half of the projection GEMM"}
+    bp = None
+    if world > 1:
+        try:
+            from unitex_amd.texturetools.benchmarks import time_backprojection
+            bp = time_backprojection(50000, 1024, 2048, iters=2, warmup=1, device=dev, view_shard=(rank, world))
+        except Exception as ex_:  # noqa: BLE001 -- the DiT number must still be reported
+            bp = {"error": repr(ex_)}
+        barrier()
+
     if rank == 0:
+        from unitex_amd import _lib
         fl, fl_attn = step_flops(S)
         attn_ms = [a.elapsed_time(b) for a, b in events]
         attn_avg_ms = sum(attn_ms) / max(len(attn_ms), 1)
         attn_launch_flops = 4.0 * S * S * 128 * HEADS / (world if ulysses else 1)
         achieved = attn_launch_flops / (attn_avg_ms * 1e-3) / 1e12
         value = (1 if ulysses else world) * args.steps / dt
+        par = ("ulysses sp%d: ONE job, 2 all-to-alls / layer (RCCL) + view-sharded back-projection with one all-gather" % world) if ulysses \
+            else ("single GPU" if world == 1 else "replicas x%d (independent jobs, no data-path collective)" % world)
         out = {
             "metric": "denoising-steps/sec", "value": value, "unit": "steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong" if ulysses else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak" if (world > 1 and not ulysses) else "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": args.workload, "description": desc, "tokens": S, "text_tokens": S_txt,
                        "noise_tokens": n_noise, "control_tokens": n_ctrl, "dual_tokens": n_dual,
-                       "lora_rank": args.lora_rank, "guidance": 3.5, "launch": "hip graph replay" if use_graph else "eager stream launches", "parallelism": ("ulysses sp%d (one job, 2 all-to-alls / layer)" % world) if ulysses else "replicas x%d" % world,
+                       "lora_rank": args.lora_rank, "guidance": 3.5, "launch": "hip graph replay" if use_graph else "eager stream launches", "parallelism": par,
                        "tflop_per_step": fl / 1e12, "achieved_tflops_per_gpu": fl / (dt / args.steps) / 1e12 / (world if ulysses else 1),
-                       "sec_per_mesh_texture_dit_only": 56.0 * dt / args.steps},
+                       "sec_per_mesh_texture_dit_only": 56.0 * dt / args.steps,
+                       # every switch that could change what was measured: the library's launch options (all result-preserving; the
+                       # wrong-result ablations do not exist in this library) and every UTX_* variable of the environment
+                       "launch_options": _lib.get_options(), "ablation_build": bool(_lib.load_library().utx_is_ablation_build()),
+                       "env_UTX": {k: v for k, v in sorted(os.environ.items()) if k.startswith("UTX_")}},
             "roofline": {"bound": "mfma", "kernel": "attn_fwd_glds_kernel", "launches_per_call": "full rounds + key-split tail round (same kernel) + attn_merge_kernel; a 'launch' below is one utx_attn_fwd_bf16 call", "achieved": achieved, "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
                          "launches_timed": len(attn_ms), "avg_launch_ms": attn_avg_ms,
@@ -254,11 +333,13 @@ def main():
                          "sustained_mfma_only_tflops": 1730.0, "frac_of_sustained": achieved / 1730.0,
                          "attention_share_of_step_time": (attn_avg_ms * (N_DOUBLE + N_SINGLE)) / (dt / args.steps * 1e3)},
         }
+        if exchange:
+            out["config"]["exchange"] = exchange
         # HBM traffic of the dominant kernel: PMC passes cannot run inside the timed run (they serialise kernels), so
         # the per-launch figure is the one measured by tools/pmc_kernel.sh on THIS command and committed under profiles/
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(args.workload)
-            if tr:
+            if tr and world == 1:
                 out["roofline"]["traffic"] = tr["traffic_bytes_per_launch"]
                 out["roofline"]["traffic_unit"] = "bytes/launch (FETCH_SIZE x2 + WRITE_SIZE, %s)" % tr["source"]
                 out["roofline"]["algorithmic_hbm_bytes_per_launch"] = tr["algorithmic_bytes_per_launch"]
@@ -270,11 +351,31 @@ def main():
             try:
                 from unitex_amd.texturetools.benchmarks import time_backprojection
                 bp = time_backprojection(50000, 1024, 2048, iters=2, warmup=1, device=dev)
-                out["config"]["backprojection"] = {"total_ms": bp["total_ms"], "faces": bp["faces"], "atlas_px": 2048,
-                                                   "view_px": 1024, "stages_ms": bp["stages_ms"]}
-                out["config"]["sec_per_mesh_texture"] = 56.0 * dt / args.steps + bp["total_ms"] * 1e-3
-            except Exception as e:
-                out["config"]["backprojection"] = {"error": repr(e)}
+            except Exception as e:  # noqa: BLE001
+                bp = {"error": repr(e)}
+        if bp is not None and "error" not in bp:
+            out["config"]["backprojection"] = {"total_ms": bp["total_ms"], "faces": bp["faces"], "atlas_px": 2048, "view_px": 1024,
+                                               "stages_ms": bp["stages_ms"], "view_shard": "views split over %d rank(s)" % world}
+            out["config"]["sec_per_mesh_texture"] = 56.0 * dt / args.steps + bp["total_ms"] * 1e-3
+            # fused-floor traffic of the back-projection = atlas raster read (16 B/texel) + the six view images read once
+            # (6 x 1024^2 x 16 B) + the uint8 atlas written = 0.15 GB, against the measured wall time of the whole stage chain
+            fused_floor = 2048 * 2048 * 16.0 + 6 * 1024 * 1024 * 16.0 + 2048 * 2048 * 3.0
+            rays = 6.0 * bp["texels"] * bp["covered_frac"]
+            out["roofline_backprojection"] = {
+                "bound": "hbm", "achieved": fused_floor / (bp["total_ms"] * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                "frac": fused_floor / (bp["total_ms"] * 1e-3) / 8e12, "algorithmic_bytes": fused_floor,
+                "ms": bp["total_ms"], "dominant_stage": max(bp["stages_ms"], key=bp["stages_ms"].get),
+                "rays": rays, "rays_per_s": rays / (bp["stages_ms"].get("backproject", bp["total_ms"]) * 1e-3),
+                "nodes_visited_per_ray": bp.get("nodes_per_ray"),
+                "note": "latency-bound LBVH walk, 0.02 % of a mesh's wall time; stage GB/s in stages_gbps",
+                "stages_gbps": bp.get("stages_gbps")}
+            if world > 1 and "all_gather" in bp["stages_ms"]:
+                ag_bytes = 13.0 * 2048 * 2048 * ((6 + world - 1) // world) * (world - 1)
+                out["config"]["backprojection"]["all_gather_ms"] = bp["stages_ms"]["all_gather"]
+                out["config"]["backprojection"]["all_gather_bytes_received_per_rank"] = ag_bytes
+        elif bp is not None:
+            out["config"]["backprojection"] = bp
+        if world == 1:
             # VAE part of a job (HIP AutoencoderKL): pass 1 encodes the control strip + the 512^2 reference image and
             # decodes the strip, pass 2 (delight) encodes the control strip and decodes once more
             try:
@@ -293,18 +394,22 @@ def main():
                 if "sec_per_mesh_texture" in out["config"]:
                     out["config"]["sec_per_mesh_texture"] += vae_s
                 del vae, img, zz
-            except Exception as e:
+            except Exception as e:  # noqa: BLE001
                 out["config"]["vae_sec_per_mesh"] = "error: %r" % (e,)
         if world == 1 and not args.no_cpu_baseline:
+            ncpu, phys = host_cores()
             try:
-                ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-                out["cpu_baseline"] = cpu_baseline(S, max(1, min(ncpu, 64)))
+                threads = max(1, min(ncpu, phys or ncpu))     # one thread per physical core when lscpu tells us; else what we may use
+                out["cpu_baseline"] = cpu_baseline(S, threads)
+                out["cpu_baseline"]["host"] = {"usable_threads": ncpu, "physical_cores_lscpu": phys}
                 try:
                     out["cpu_baseline"]["backprojection"] = cpu_baseline_backprojection()
-                except Exception as e:
+                except Exception as e:  # noqa: BLE001
                     out["cpu_baseline"]["backprojection"] = {"error": repr(e)}
-            except Exception as e:  # the GPU number must still be reported
-                out["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": os.cpu_count(), "kind": "port",
+                if args.cpu_config1:
+                    out["cpu_baseline"]["config1_complete"] = cpu_config1(threads)
+            except Exception as e:  # noqa: BLE001 -- the GPU number must still be reported
+                out["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": ncpu, "kind": "port",
                                        "sample": "failed: %r" % (e,)}
         print(json.dumps(out))
     if world > 1:

@@ -136,8 +136,22 @@ typedef struct utx_qkv_post_desc {
     float eps;
     float q_scale;                           /* multiplies Q before its bf16 rounding (1 = reference layout;
                                                 scale*log2(e) feeds utx_attn_fwd_bf16(softmax_scale = 0)) */
+    /* grouped head addressing (sequence-parallel send layout, unitex_amd/flux/ulysses.py): with heads_per_group = g > 0 head h
+     * lives at (h / g) * gs + (h % g) * hs instead of h * hs, i.e. the kernel writes straight into the all-to-all send buffer
+     * [P][3][H/P][...] (one group per destination rank) and no pack pass exists.  0 = plain [H][...] layout. */
+    int heads_per_group;
+    long gs_qk, gs_v;
 } utx_qkv_post_desc;
 int utx_qkv_post(utx_ctx* ctx, const utx_qkv_post_desc* d, utx_stream stream);
+
+/* Sequence-parallel ("Ulysses") exchange, receive side (unitex_amd/flux/ulysses.py; no counterpart in the single-GPU reference,
+ * flux_piplines/texturing/pipeline.py:633-681 -- this is SURVEY 8(e)'s parity-preserving split of the ONE joint sequence).
+ * Both are pure 16-byte-vector copies (HBM-bound), one launch each; S = P * S_loc, S_loc % 64 == 0, E = S_loc * 128.
+ *   utx_sp_unpack_qkv: recv [P src][3][Hp][E]  ->  q, k [Hp][S][128] (row = src*S_loc + tok),  vt [Hp][128][S]
+ *                      (recv[src][0|1][hp] is [S_loc][128]; recv[src][2][hp] is [128][S_loc])
+ *   utx_sp_unpack_o  : recv [P src][S_loc][Hp*128]  ->  out [S_loc][ld]: columns src*Hp*128 .. of row tok */
+int utx_sp_unpack_qkv(utx_ctx* ctx, const void* recv, int P, int Hp, int S_loc, void* q, void* k, void* vt, utx_stream stream);
+int utx_sp_unpack_o(utx_ctx* ctx, const void* recv, int P, int Hp, int S_loc, void* out, long ld, utx_stream stream);
 
 /* LayerNorm(no affine) + AdaLN modulation (AdaLayerNormZero/ZeroSingle/Continuous [3p]). */
 typedef struct utx_ln_mod_desc {

@@ -572,3 +572,43 @@ def test_gemm_tail_split_matches_unsplit_launch_and_oracle(M, N, K, lora):
     assert torch.equal(s1.view(torch.int16), s2.view(torch.int16)), "split launch is not deterministic"
     changed = (s1 != plain).float().mean().item()
     assert 0.0 < changed < 0.02, "only roundings inside the tail tiles may move: %g of the elements differ" % changed
+
+
+@pytest.mark.parametrize("P,Hp,S_loc", [(4, 3, 128), (8, 3, 64), (2, 1, 192)])
+def test_sequence_parallel_relayout_kernels(P, Hp, S_loc):
+    """receive-side relayouts of the sequence-parallel exchange (utx_sp_unpack_qkv / utx_sp_unpack_o) and the grouped head
+    addressing of utx_qkv_post (send side written in place) against torch index arithmetic: pure data movement, bit-exact."""
+    import ctypes as C
+    ops = _ops()
+    ctx = ops.get_ctx(0)
+    g = torch.Generator().manual_seed(P * 100 + Hp)
+    S, E = P * S_loc, S_loc * 128
+    recv = torch.randn(P, 3, Hp, E, generator=g).to(BF).cuda()
+    q = torch.empty(Hp, S, 128, dtype=BF, device="cuda"); k = torch.empty_like(q); vt = torch.empty(Hp, 128, S, dtype=BF, device="cuda")
+    ctx.check(ctx.lib.utx_sp_unpack_qkv(ctx.handle, C.c_void_p(recv.data_ptr()), P, Hp, S_loc, C.c_void_p(q.data_ptr()),
+                                        C.c_void_p(k.data_ptr()), C.c_void_p(vt.data_ptr()), ctx.stream()))
+    assert torch.equal(q.view(Hp, P, S_loc, 128), recv[:, 0].view(P, Hp, S_loc, 128).permute(1, 0, 2, 3))
+    assert torch.equal(k.view(Hp, P, S_loc, 128), recv[:, 1].view(P, Hp, S_loc, 128).permute(1, 0, 2, 3))
+    assert torch.equal(vt.view(Hp, 128, P, S_loc), recv[:, 2].view(P, Hp, 128, S_loc).permute(1, 2, 0, 3))
+    W = Hp * 128
+    orecv = torch.randn(P, S_loc, W, generator=g).to(BF).cuda()
+    out = torch.zeros(S_loc, 5 * P * W, dtype=BF, device="cuda")                  # strided rows, like the single-block cat buffer
+    ctx.check(ctx.lib.utx_sp_unpack_o(ctx.handle, C.c_void_p(orecv.data_ptr()), P, Hp, S_loc, C.c_void_p(out.data_ptr()), out.stride(0), ctx.stream()))
+    assert torch.equal(out[:, : P * W].view(S_loc, P, W), orecv.permute(1, 0, 2))
+    assert out[:, P * W:].abs().max().item() == 0
+    # send side: qkv_post with grouped head addressing == plain qkv_post followed by the pack permutation
+    H, D = P * Hp, P * Hp * 128
+    qkv = torch.randn(S_loc, 3 * D, generator=g).to(BF).cuda()
+    wq = (1 + 0.1 * torch.randn(128, generator=g)).to(BF).cuda(); wk = (1 + 0.1 * torch.randn(128, generator=g)).to(BF).cuda()
+    ang = torch.rand(S_loc, 64, generator=g) * 6.28
+    cos, sin = torch.cos(ang).cuda().contiguous(), torch.sin(ang).cuda().contiguous()
+    Qh = torch.zeros(H, S_loc, 128, dtype=BF, device="cuda"); Kh = torch.zeros_like(Qh); Vt = torch.zeros(H, 128, S_loc, dtype=BF, device="cuda")
+    ops.qkv_post(qkv, 0, D, 2 * D, wq, wk, cos, sin, Qh, Kh, Vt, S_loc, 0, H, q_scale=0.1275)
+    send = torch.zeros(P, 3, Hp, E, dtype=BF, device="cuda")
+    flat = send.view(-1)
+    ops.qkv_post(qkv, 0, D, 2 * D, wq, wk, cos, sin, flat, flat[Hp * E:], flat[2 * Hp * E:], S_loc, 0, H, q_scale=0.1275,
+                 heads_per_group=Hp, group_stride=3 * Hp * E, head_stride=E, row_stride_v=S_loc)
+    torch.cuda.synchronize()
+    assert torch.equal(send[:, 0].view(P, Hp, S_loc, 128), Qh.view(P, Hp, S_loc, 128))
+    assert torch.equal(send[:, 1].view(P, Hp, S_loc, 128), Kh.view(P, Hp, S_loc, 128))
+    assert torch.equal(send[:, 2].view(P, Hp, 128, S_loc), Vt.view(P, Hp, 128, S_loc))

@@ -146,6 +146,16 @@ int utx_qkv_post(utx_ctx* ctx, const utx_qkv_post_desc* d, utx_stream stream) {
     UTX_CALL(ctx, "utx_qkv_post", utx_launch_qkv_post(d, (hipStream_t)stream));
 }
 
+int utx_sp_unpack_qkv(utx_ctx* ctx, const void* recv, int P, int Hp, int S_loc, void* q, void* k, void* vt, utx_stream stream) {
+    if (!recv || !q || !k || !vt) return fail(ctx, -2, "utx_sp_unpack_qkv");
+    UTX_CALL(ctx, "utx_sp_unpack_qkv", utx_launch_sp_unpack_qkv(recv, P, Hp, S_loc, q, k, vt, (hipStream_t)stream));
+}
+
+int utx_sp_unpack_o(utx_ctx* ctx, const void* recv, int P, int Hp, int S_loc, void* out, long ld, utx_stream stream) {
+    if (!recv || !out) return fail(ctx, -2, "utx_sp_unpack_o");
+    UTX_CALL(ctx, "utx_sp_unpack_o", utx_launch_sp_unpack_o(recv, P, Hp, S_loc, out, ld, (hipStream_t)stream));
+}
+
 int utx_ln_mod(utx_ctx* ctx, const utx_ln_mod_desc* d, utx_stream stream) {
     if (!d || !d->x || !d->y || !d->shift || !d->scale) return fail(ctx, -2, "utx_ln_mod");
     UTX_CALL(ctx, "utx_ln_mod", utx_launch_ln_mod(d, (hipStream_t)stream));

@@ -23,6 +23,11 @@ __global__ __launch_bounds__(256) void qkv_post_kernel(QkvPostParams p) {
     const int trow = tid >> 4;           // token within a pass (0..15)
     const int head = blockIdx.y;
     const int t0 = blockIdx.x * 64;
+    // head -> offset: plain [H][...] or grouped (sequence-parallel send layout: one group of heads per destination rank)
+    const int hg = p.heads_per_group > 0 ? head / p.heads_per_group : 0;
+    const int hi = p.heads_per_group > 0 ? head - hg * p.heads_per_group : head;
+    const long hoff_qk = (long)hg * p.gs_qk + (long)hi * p.hs_qk;
+    const long hoff_v = (long)hg * p.gs_v + (long)hi * p.hs_v;
     float wq[8], wk[8];
     {
         const uint4 a = *reinterpret_cast<const uint4*>((const bf16_t*)p.wq + 8 * sub);
@@ -75,7 +80,7 @@ __global__ __launch_bounds__(256) void qkv_post_kernel(QkvPostParams p) {
                 const float r1 = (a1 * csv[c] + a0 * snv[c]) * qs;
                 ow[c] = pack2bf(r0, r1);
             }
-            bf16_t* dst = (bf16_t*)(which ? p.Kh : p.Qh) + (long)head * p.hs_qk + srow * 128 + 8 * sub;
+            bf16_t* dst = (bf16_t*)(which ? p.Kh : p.Qh) + hoff_qk + srow * 128 + 8 * sub;
             *reinterpret_cast<uint4*>(dst) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
         }
         *reinterpret_cast<uint4*>(&sv[tl][8 * sub]) = vraw;
@@ -83,7 +88,7 @@ __global__ __launch_bounds__(256) void qkv_post_kernel(QkvPostParams p) {
     __syncthreads();
     // transpose-store: thread -> (d = tid>>1, 32 tokens)
     const int d = tid >> 1, tb = (tid & 1) * 32;
-    bf16_t* vrow = (bf16_t*)p.Vt + (long)head * p.hs_v + (long)d * p.S_pad + p.tok_off + t0 + tb;
+    bf16_t* vrow = (bf16_t*)p.Vt + hoff_v + (long)d * p.S_pad + p.tok_off + t0 + tb;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const int tl = tb + 8 * c;
@@ -105,8 +110,66 @@ extern "C" int utx_launch_qkv_post(const QkvPostParams* hp, hipStream_t stream) 
     QkvPostParams p = *hp;
     if (p.n_tok <= 0 || p.H <= 0) return -1;
     if ((p.tok_off & 7) || (p.S_pad & 7) || (p.ld & 7) || (p.q_col & 7) || (p.k_col & 7) || (p.v_col & 7)) return -2;   // 16-byte lanes
+    if (p.heads_per_group < 0 || (p.heads_per_group > 0 && ((p.H % p.heads_per_group) || (p.gs_qk & 7) || (p.gs_v & 7)))) return -2;
     dim3 grid((p.n_tok + 63) / 64, p.H);
     hipLaunchKernelGGL(qkv_post_kernel, grid, dim3(256), 0, stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sequence-parallel exchange, receive side (unitex_hip.h: utx_sp_unpack_qkv / utx_sp_unpack_o): relayout of what the
+// all-to-all delivered into the attention kernel's / the out-projection's operand layouts.  Pure copies: one 16-byte vector
+// per thread and step, sources and destinations in runs of >= 128 B (S_loc % 64 == 0), grid-stride.
+__global__ __launch_bounds__(256) void sp_unpack_qkv_kernel(const uint4* __restrict__ recv, int P, int Hp, int S_loc, uint4* __restrict__ q,
+                                                            uint4* __restrict__ k, uint4* __restrict__ vt) {
+    const long Ev = (long)S_loc * 16;                 // 16-byte vectors per (src, which, head) block: S_loc * 128 * 2 B / 16
+    const long S = (long)P * S_loc;
+    const long total = 3L * P * Hp * Ev;
+    const long slv = S_loc / 8;                       // vectors per V^T row segment
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long e = i % Ev;
+        long b = i / Ev;
+        const int hp = (int)(b % Hp); b /= Hp;
+        const int which = (int)(b % 3);
+        const int src = (int)(b / 3);
+        const uint4 v = recv[i];
+        if (which < 2) {
+            uint4* dst = which ? k : q;
+            dst[((long)hp * S + (long)src * S_loc) * 16 + e] = v;          // [hp][src*S_loc + tok][128]
+        } else {
+            const long d = e / slv, t8 = e - d * slv;
+            vt[((long)hp * 128 + d) * (S / 8) + (long)src * slv + t8] = v;  // [hp][d][src*S_loc + tok]
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void sp_unpack_o_kernel(const uint4* __restrict__ recv, int P, int Hp, int S_loc, bf16_t* __restrict__ out, long ld) {
+    const long Wv = (long)Hp * 16;                    // vectors per (src, tok) row: Hp * 128 * 2 B / 16
+    const long total = (long)P * S_loc * Wv;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long c = i % Wv;
+        long b = i / Wv;
+        const long tok = b % S_loc;
+        const long src = b / S_loc;
+        *reinterpret_cast<uint4*>(out + tok * ld + (src * Wv + c) * 8) = recv[i];
+    }
+}
+
+extern "C" int utx_launch_sp_unpack_qkv(const void* recv, int P, int Hp, int S_loc, void* q, void* k, void* vt, hipStream_t stream) {
+    if (P <= 0 || Hp <= 0 || S_loc <= 0 || (S_loc & 63)) return -2;
+    if ((((uintptr_t)recv) | ((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)vt)) & 15) return -2;
+    const long total = 3L * P * Hp * S_loc * 16;
+    long blocks = (total + 255) / 256; if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(sp_unpack_qkv_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const uint4*)recv, P, Hp, S_loc, (uint4*)q, (uint4*)k, (uint4*)vt);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+extern "C" int utx_launch_sp_unpack_o(const void* recv, int P, int Hp, int S_loc, void* out, long ld, hipStream_t stream) {
+    if (P <= 0 || Hp <= 0 || S_loc <= 0 || (ld & 7) || ld < (long)P * Hp * 128) return -2;
+    if ((((uintptr_t)recv) | ((uintptr_t)out)) & 15) return -2;
+    const long total = (long)P * S_loc * Hp * 16;
+    long blocks = (total + 255) / 256; if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(sp_unpack_o_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const uint4*)recv, P, Hp, S_loc, (bf16_t*)out, ld);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 

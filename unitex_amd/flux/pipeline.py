@@ -151,9 +151,20 @@ class PBRFluxPipeline:
         else:
             latents = noise_latents[0].to(self.device, BF16).contiguous()
             ids, cond = noise_ids, None
-        tr.set_positions(text_ids, ids)
+        tr.set_positions(text_ids, ids)          # full id tensors: a sequence-parallel transformer slices them itself
         tr.set_conditioning(prompt_embeds, pooled, guidance_scale)
-        use_graph = os.environ.get("UTX_HIP_GRAPH", "0") == "1" and num_inference_steps > 2 and hasattr(tr, "capture_graph")
+        # sequence parallel (one job over several GPUs, flux/ulysses.py): every rank drew the same latents from the same CPU
+        # generator; it keeps its contiguous slice of the image tokens, the Euler step / re-pin are per token, and one all-gather
+        # of the 64-channel latents (6.4 MB at 50 176 tokens) re-assembles the result for the VAE at the end
+        sp = getattr(tr, "sp", None)
+        n_noise_loc, S_img_full = n_noise, latents.shape[0]
+        if sp is not None and sp[1] > 1:
+            i0, i1 = tr.local_image_range(S_img_full)
+            cond = latents[max(i0, n_noise):i1].clone() if i1 > n_noise else None
+            n_noise_loc = min(max(n_noise - i0, 0), i1 - i0)
+            latents = latents[i0:i1].clone()
+        use_graph = os.environ.get("UTX_HIP_GRAPH", "0") == "1" and num_inference_steps > 2 and hasattr(tr, "capture_graph") \
+            and sp is None
         for i in range(num_inference_steps):
             # timestep = t.expand(B).to(latents.dtype); transformer(timestep=timestep / 1000)
             t_bf = torch.tensor(float(timesteps[i]), dtype=torch.float32).to(BF16)
@@ -162,9 +173,14 @@ class PBRFluxPipeline:
                 tr.capture_graph(warm=False)      # step 0 ran eagerly (first-use setup); the remaining steps replay one HIP graph
             v = tr.forward(latents, t_in)
             # Euler step on the noise tokens + re-pin of the clean condition tail, one fused kernel
-            ops.sched_step(latents, v, self.scheduler.dsigma(i), n_noise_tokens=n_noise, cond=cond)
+            ops.sched_step(latents, v, self.scheduler.dsigma(i), n_noise_tokens=n_noise_loc, cond=cond)
             if step_callback is not None:
                 step_callback(i, latents)
+        if sp is not None and sp[1] > 1:
+            from ..texturetools.distributed import _all_gather
+            full = torch.empty(S_img_full, latents.shape[1], dtype=latents.dtype, device=latents.device)
+            _all_gather(full, latents.contiguous(), sp[2])
+            latents = full
         return latents[:n_noise].unsqueeze(0)
 
     @torch.no_grad()

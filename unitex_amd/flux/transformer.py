@@ -318,15 +318,24 @@ class FluxDiT:
         d = QkvPostDesc()
         d.qkv, d.ld, d.q_col, d.k_col, d.v_col = ptr(qkv), qkv.stride(0), 0, D, 2 * D
         d.wq, d.wk, d.cosb, d.sinb = ptr(wq), ptr(wk), ptr(ws["cos"]), ptr(ws["sin"])
-        d.Qh, d.Kh, d.Vt = ptr(ws["Qh"]), ptr(ws["Kh"]), ptr(ws["Vt"])
-        d.hs_qk, d.hs_v, d.S_pad = ws["Qh"].stride(0), ws["Vt"].stride(0), ws["Vt"].shape[2]
+        if self.sp is not None:
+            # sequence parallel: write Q, K, V^T straight into the all-to-all send buffer [P][3][H/P][S_loc*128] (no pack pass)
+            ex = self.ex
+            d.Qh, d.Kh, d.Vt = ptr(ex.send_base(0)), ptr(ex.send_base(1)), ptr(ex.send_base(2))
+            d.hs_qk, d.hs_v, d.S_pad = ex.E, ex.E, ex.S_loc
+            d.heads_per_group, d.gs_qk, d.gs_v = ex.Hp, ex.group_stride, ex.group_stride
+        else:
+            d.Qh, d.Kh, d.Vt = ptr(ws["Qh"]), ptr(ws["Kh"]), ptr(ws["Vt"])
+            d.hs_qk, d.hs_v, d.S_pad = ws["Qh"].stride(0), ws["Vt"].stride(0), ws["Vt"].shape[2]
         d.n_tok, d.tok_off, d.H, d.eps = n_tok, tok_off, sh.num_heads, 1e-6
         d.q_scale = (1.0 / math.sqrt(128.0)) * 1.4426950408889634   # scores become base-2 exponents (attention scale=0)
         plan.append((self.lib.utx_qkv_post, d))
 
     def _attn(self, plan, ws, out, S):
         if self.sp is not None:
-            plan.append(("sp_attn", out[:, : self.shape.dim]))      # all-to-all in, attention over H/P heads x full sequence, all-to-all out
+            # exchange 1 was started by an earlier "sp_start" entry; here: wait + unpack, attention over H/P heads x the full
+            # sequence, exchange 2 + unpack into `out`
+            plan.append(("sp_attn", out[:, : self.shape.dim]))
             return
         sh = self.shape
         Qh, Kh, Vt = ws["Qh"], ws["Kh"], ws["Vt"]
@@ -354,10 +363,11 @@ class FluxDiT:
             "mod": z(1, self.n_mod),
             "h": z(S, D), "xn": z(S, D), "qkv": z(S, 3 * D), "cat": z(S, (1 + sh.mlp_ratio) * D),
             "attn": z(S, D),
-            "Qh": z(H, S_pad, 128), "Kh": z(H, S_pad, 128), "Vt": z(H, 128, S_pad),
             "cos": z(S, 64, dtype=torch.float32), "sin": z(S, 64, dtype=torch.float32),
             "out": z(S_img, sh.in_channels),
         }
+        if self.sp is None:
+            ws.update({"Qh": z(H, S_pad, 128), "Kh": z(H, S_pad, 128), "Vt": z(H, 128, S_pad)})
         if Rp:
             ws["T"] = z(S, 3 * Rp)
             ws["Tc"] = z(S_txt, 3 * Rp)     # LoRA-down temp of the text half (it runs concurrently with the image half)
@@ -365,7 +375,7 @@ class FluxDiT:
             from .ulysses import UlyssesExchange
             if S_pad != S:
                 raise ValueError("sequence parallel: the local token count %d must be a multiple of 64" % S)
-            self.ex = UlyssesExchange(H, S, group=self.sp[2], device=dev, dtype=BF16)
+            self.ex = UlyssesExchange(H, S, group=self.sp[2], device=dev, dtype=BF16, ctx=self.ctx)
         T = ws.get("T")
         Tc = ws.get("Tc") if self.overlap_text else T
         W, mod = self.W, ws["mod"][0]
@@ -408,6 +418,8 @@ class FluxDiT:
             self._qkvpost(px, qkv[S_txt:], b["nq"], b["nk"], ws, S_img, S_txt)
             self._qkvpost(pc, qkv[:S_txt], b["naq"], b["nak"], ws, S_txt, 0)
             self._par(plan, px, pc)
+            if self.sp is not None:
+                plan.append(("sp_start", None))
             self._attn(plan, ws, attn, S)
             px, pc = [], []
             self._gemm(px, attn[S_txt:], b["out_x.w"], h_x, bias=b["out_x.b"], lora=b.get("lora.out_x"), T=T,
@@ -426,10 +438,19 @@ class FluxDiT:
         for i, b in enumerate(self.single):
             sh_, sc_, g_ = chunks(("s", i), 3)
             self._lnmod(plan, h, xn, sh_, sc_)
-            # one GEMM for [q|k|v|proj_mlp]: qkv -> qkv buffer, GELU(mlp) -> cat[:, D:]
-            self._gemm(plan, xn, b["qkvm.w"], qkv, bias=b["qkvm.b"], lora=b.get("lora.qkvm"), lora_n_limit=3 * D,
-                       lora_seg_n=D, T=T, gelu_from=3 * D, n_split=3 * D, C1=cat[:, D:])
-            self._qkvpost(plan, qkv, b["nq"], b["nk"], ws, S, 0)
+            if self.sp is None:
+                # one GEMM for [q|k|v|proj_mlp]: qkv -> qkv buffer, GELU(mlp) -> cat[:, D:]
+                self._gemm(plan, xn, b["qkvm.w"], qkv, bias=b["qkvm.b"], lora=b.get("lora.qkvm"), lora_n_limit=3 * D,
+                           lora_seg_n=D, T=T, gelu_from=3 * D, n_split=3 * D, C1=cat[:, D:])
+                self._qkvpost(plan, qkv, b["nq"], b["nk"], ws, S, 0)
+            else:
+                # sequence parallel: the same GEMM cut at column 3D (identical arithmetic per column) so that the Q/K/V exchange
+                # starts as soon as q|k|v exist and the MLP half of the projection runs beside the all-to-all
+                self._gemm(plan, xn, b["qkvm.w"][: 3 * D], qkv, bias=b["qkvm.b"][: 3 * D], lora=b.get("lora.qkvm"),
+                           lora_n_limit=3 * D, lora_seg_n=D, T=T)
+                self._qkvpost(plan, qkv, b["nq"], b["nk"], ws, S, 0)
+                plan.append(("sp_start", None))
+                self._gemm(plan, xn, b["qkvm.w"][3 * D:], cat[:, D:], bias=b["qkvm.b"][3 * D:], gelu_from=0)
             self._attn(plan, ws, cat, S)  # attention output lands in cat[:, :D] (row stride 5D)
             self._gemm(plan, cat, b["out.w"], h, bias=b["out.b"], gate=g_, res=h)
         o = self.mod_off[("out",)]
@@ -504,9 +525,12 @@ class FluxDiT:
                 if self.shape.guidance_embeds:
                     t = t + ws["e_g"]
                 torch.add(t, ws["e_p"], out=ws["temb"])
+            elif fn == "sp_start":
+                self._sp_work = self.ex.start_heads_in()
             elif fn == "sp_attn":
                 ex = self.ex
-                q, k, vt = ex.heads_in(ws["Qh"], ws["Kh"], ws["Vt"])
+                q, k, vt = ex.finish_heads_in(self._sp_work)
+                self._sp_work = None
                 ev = getattr(self, "attn_events", None)
                 if ev is not None:
                     a = torch.cuda.Event(enable_timing=True)

@@ -19,9 +19,11 @@ from PIL import Image
 from .texturetools.timer import CPUTimer
 
 
-def build_pipeline(pretrain_models=None, pipeline_name="texture_plus", device="cuda:0", seed=0, lora_rank=64, shape=None):
+def build_pipeline(pretrain_models=None, pipeline_name="texture_plus", device="cuda:0", seed=0, lora_rank=64, shape=None,
+                   sequence_parallel=False, process_group=None):
     """FluxDiT + VAE + adapters.  With a `pretrain_models` directory holding diffusers-format safetensors the real
-    weights are loaded; otherwise (no checkpoints exist here) FLUX.1-dev-shaped synthetic weights are generated."""
+    weights are loaded; otherwise (no checkpoints exist here) FLUX.1-dev-shaped synthetic weights are generated.
+    sequence_parallel: ONE job over the ranks of `process_group` (flux/ulysses.py)."""
     from .flux.pipeline import PBRFluxPipeline
     from .flux.synthetic import SyntheticFluxStateDict, synthetic_lora
     from .flux.transformer import FluxDiT, FluxShape
@@ -39,7 +41,7 @@ def build_pipeline(pretrain_models=None, pipeline_name="texture_plus", device="c
         vae = AutoencoderKL.synthetic(seed=0, device=device)
         tex = synthetic_lora(sd, shape, rank=lora_rank, seed=1, device=device)
         dlt = synthetic_lora(sd, shape, rank=lora_rank, seed=2, device=device)
-    pipe = PBRFluxPipeline(FluxDiT(sd, shape, device=device), vae, device=device)
+    pipe = PBRFluxPipeline(FluxDiT(sd, shape, device=device, sequence_parallel=sequence_parallel, sp_group=process_group), vae, device=device)
     pipe.load_lora_weights(tex, adapter_name="texture")
     pipe.load_lora_weights(dlt, adapter_name="delight")
     pipe._num_inference_steps = 28
@@ -49,13 +51,28 @@ def build_pipeline(pretrain_models=None, pipeline_name="texture_plus", device="c
 class RGBTextureFullPipelineBase:
     def __init__(self, pretrain_models=None, pipeline_name="texture_plus", super_resolutions=False, seed=0, speedup_mode=None,
                  add_lora_path=None, add_lora_weights=None, enable_rembg=False, device="cuda:0", pipeline=None,
-                 num_inference_steps=None, atlas_size=2048, view_size=512):
+                 num_inference_steps=None, atlas_size=2048, view_size=512, multi_gpu=None, process_group=None):
+        """multi_gpu (beyond the reference, which is single-GPU): None = automatic -- when torch.distributed is initialised with
+        more than one rank, the ranks work on ONE mesh together: the DiT runs sequence-parallel (two all-to-alls per layer), the
+        geometry-condition render and the back-projection are sharded by view (`view_shard=(rank, world)`, ONE all-gather each;
+        SURVEY 8e).  Every rank executes the same orchestration and ends with the same atlas; rank 0 owns `save_dir`, the other
+        ranks keep their intermediate artefacts in `cache.rank<r>`.  False = each process is an independent single-GPU job."""
+        import torch.distributed as dist
         from .texturetools.renderer_inverse import NVDiffRendererInverse
         from .texturetools.video import VideoExporter
         if super_resolutions:
             raise NotImplementedError("TSD_SR super-resolution is off by default in the reference (run.py:4) and out of scope")
+        world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        if multi_gpu is None:
+            multi_gpu = world > 1
+        if multi_gpu and world < 2:
+            raise ValueError("multi_gpu=True needs an initialised torch.distributed group with more than one rank")
+        self.rank, self.world = (dist.get_rank(process_group), world) if multi_gpu else (0, 1)
+        self.process_group = process_group if multi_gpu else None
+        shard = (self.rank, self.world)
         if pipeline is None:
-            pipeline, wt, wd, names = build_pipeline(pretrain_models, pipeline_name, device=device)
+            pipeline, wt, wd, names = build_pipeline(pretrain_models, pipeline_name, device=device, sequence_parallel=bool(multi_gpu),
+                                                     process_group=self.process_group)
         else:
             wt, wd, names = [1.0, 0.0], [0.0, 1.0], ["texture", "delight"]
         if num_inference_steps is not None:
@@ -63,8 +80,8 @@ class RGBTextureFullPipelineBase:
         self.weights_for_texture, self.weights_for_delight, self.adapter_names = wt, wd, names
         self.pipeline_name = pipeline_name
         self.pipeline = pipeline
-        self.video_exporter = VideoExporter(device=device)
-        self.inverse_renderer = NVDiffRendererInverse(device=device)
+        self.video_exporter = VideoExporter(device=device, view_shard=shard, process_group=self.process_group)
+        self.inverse_renderer = NVDiffRendererInverse(device=device, view_shard=shard, process_group=self.process_group)
         self.generator = torch.Generator().manual_seed(seed)   # ONE CPU generator shared by all draws (A19)
         self.super_resolutions = super_resolutions
         self.atlas_size = atlas_size
@@ -186,13 +203,18 @@ class RGBTextureFullPipeline(RGBTextureFullPipelineBase):
 
     def __call__(self, save_dir: str, input_image_path: str, input_mesh_path: str, clear_cache=False) -> Tuple[str, str]:
         os.makedirs(save_dir, exist_ok=True)
-        cache_dir = os.path.join(os.path.abspath(save_dir), "cache")
+        rank = getattr(self, "rank", 0)
+        cache_dir = os.path.join(os.path.abspath(save_dir), "cache" if rank == 0 else "cache.rank%d" % rank)
         os.makedirs(cache_dir, exist_ok=True)
         for step in self.step_seq:
             getattr(self, step)(cache_dir=cache_dir, input_image_path=input_image_path, input_mesh_path=input_mesh_path,
                                 clear_cache=clear_cache)
-        for name in ("rembg_image.png", "mv_rgb.png", "textured_mesh.glb"):
-            shutil.copy(os.path.join(cache_dir, name), os.path.join(save_dir, name))
+        if rank == 0:
+            for name in ("rembg_image.png", "mv_rgb.png", "textured_mesh.glb"):
+                shutil.copy(os.path.join(cache_dir, name), os.path.join(save_dir, name))
+        if getattr(self, "world", 1) > 1:
+            import torch.distributed as dist
+            dist.barrier(group=self.process_group)      # rank 0's final artefacts exist when any rank returns
         if clear_cache:
             shutil.rmtree(cache_dir)
         return os.path.join(save_dir, "rembg_image.png"), os.path.join(save_dir, "textured_mesh.glb")

@@ -42,13 +42,19 @@ def smooth_views(n, H, W, seed=7):
     return out
 
 
-def time_backprojection(n_faces=50000, view_px=1024, atlas_px=2048, iters=3, warmup=1, device="cuda:0"):
-    """returns {"total_ms", "stages_ms": {...}, "stages_gbps": {...}, "faces", "texels", "covered_frac"} averaged over iters."""
+def time_backprojection(n_faces=50000, view_px=1024, atlas_px=2048, iters=3, warmup=1, device="cuda:0", view_shard=(0, 1),
+                        process_group=None, n_views=6):
+    """returns {"total_ms", "stages_ms": {...}, "stages_gbps": {...}, "faces", "texels", "covered_frac"} averaged over iters.
+    view_shard=(rank, world): this rank back-projects its block of the views; the stage list then carries "all_gather"."""
     verts, faces, uvs = meshes.sphere_with_faces(n_faces)
-    inv = NVDiffRendererInverse(device=device).update_from_arrays(verts, faces, uvs)
-    c2ws = camera.generate_box_views_c2ws(2.8)[[0, 1, 4, 2, 3, 5]]
+    inv = NVDiffRendererInverse(device=device, view_shard=view_shard, process_group=process_group).update_from_arrays(verts, faces, uvs)
+    if n_views == 6:
+        c2ws = camera.generate_box_views_c2ws(2.8)[[0, 1, 4, 2, 3, 5]]
+    else:
+        c2ws, order = camera.generate_views_c2ws(n_views, 2.8)
+        inv.index = order
     intr = camera.generate_intrinsics(1.0, 1.0, fov=False)
-    images = torch.from_numpy(smooth_views(6, view_px, view_px)).to(device)
+    images = torch.from_numpy(smooth_views(n_views, view_px, view_px)).to(device)
     acc, totals = {}, []
     covered = 0.0
     for it in range(warmup + iters):
@@ -69,7 +75,7 @@ def time_backprojection(n_faces=50000, view_px=1024, atlas_px=2048, iters=3, war
     inv.stage_events = None
     stages = {k: float(np.mean(v)) for k, v in acc.items()}
     T = float(atlas_px * atlas_px)
-    bpt = stage_bytes_per_texel(6)
+    bpt = stage_bytes_per_texel(n_views)
     gbps = {k: bpt[k] * T / (stages[k] * 1e-3) / 1e9 for k in stages if k in bpt and stages[k] > 0}
     return {"total_ms": float(np.mean(totals)), "stages_ms": stages, "stages_gbps": gbps, "faces": int(len(faces)),
             "texels": int(T), "covered_frac": covered, "view_px": view_px, "atlas_px": atlas_px}

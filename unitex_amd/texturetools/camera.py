@@ -71,6 +71,43 @@ def generate_box_views_c2ws(radius=2.8):
     return out
 
 
+def _axes_from_back(back):
+    """(right, up, back) of a camera at radius * back looking at the origin with world +y up -- the construction that yields
+    the four side views of _BOX_AXES when `back` is an axis."""
+    b = torch.nn.functional.normalize(torch.tensor(back, dtype=torch.float64), dim=0)
+    r = torch.nn.functional.normalize(torch.stack([b[2], torch.zeros((), dtype=torch.float64), -b[0]]), dim=0)   # (0,1,0) x back
+    u = torch.linalg.cross(b, r)
+    return r.float(), u.float(), b.float()
+
+
+# the two extra views of the 8-view set: upper diagonals over the front-right and the back-left corners (elevation 35.26 deg)
+_DIAGONAL_BACKS = [(1.0, 1.0, 1.0), (-1.0, 1.0, -1.0)]
+
+
+def generate_views_c2ws(n_views: int, radius=2.8):
+    """View sets of the texture path beyond the reference's hard-wired six, in the INVERSE RENDERER's view order, with the
+    composite priority (indices into that order, first = wins):
+      6 (the reference, pipeline.py:206, renderer_inverse.py:44): f, r, t, b, l, d          priority f, b, l, r, t, d
+      4 (export_nvdiffrast_video.py:931-932; BASELINE configs[0]):  f, r, b, l              priority f, b, l, r
+      8 (BASELINE configs[4]; builder-defined, the reference has no 8-view set): the six above + two upper diagonal views over
+        the (+x,+z) and (-x,-z) corners, orthographic like the others; they come LAST in priority, i.e. they only fill texels
+        that no axis view sees (the 54.7-degree grazing band around the cube corners and concavities).
+    Returns (c2ws [n,4,4], priority list)."""
+    box = generate_box_views_c2ws(radius)
+    if n_views == 6:
+        return box[[0, 1, 4, 2, 3, 5]], [0, 3, 4, 1, 2, 5]
+    if n_views == 4:
+        return box[[0, 1, 2, 3]], [0, 2, 3, 1]
+    if n_views == 8:
+        extra = torch.zeros(2, 4, 4, dtype=torch.float32)
+        for i, bk in enumerate(_DIAGONAL_BACKS):
+            r, u, b = _axes_from_back(bk)
+            extra[i, :3, 0], extra[i, :3, 1], extra[i, :3, 2], extra[i, :3, 3] = r, u, b, radius * b
+            extra[i, 3, 3] = 1.0
+        return torch.cat([box[[0, 1, 4, 2, 3, 5]], extra]), [0, 3, 4, 1, 2, 5, 6, 7]
+    raise ValueError("view sets exist for 4, 6 and 8 views")
+
+
 def lookat_to_matrix(lookat: torch.Tensor) -> torch.Tensor:
     """camera positions looking at the origin -> c2w (camera/generator.py:8-40).  World x forward / y right / z up is
     re-expressed as z forward / x right / y up by the fixed axis permutation applied on the left."""

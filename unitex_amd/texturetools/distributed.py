@@ -15,6 +15,17 @@ def view_range(rank, world, n_views):
     return min(rank * per, n_views), min((rank + 1) * per, n_views), per
 
 
+def _all_gather(out, inp, group):
+    """all_gather_into_tensor; gloo cannot take device tensors, so two ranks sharing one GPU in the tests stage through the
+    host (production: NCCL = RCCL, device to device)."""
+    if inp.is_cuda and dist.get_backend(group) == "gloo":
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(o, inp.cpu(), group=group)
+        out.copy_(o)
+    else:
+        dist.all_gather_into_tensor(out, inp, group=group)
+
+
 def gather_view_layers(color, vis, rank, world, group=None):
     """color [n,H,W,3] f32, vis [n,H,W] u8: rank r has valid data in its own view_range only.
     Returns the fully populated (color, vis) on every rank."""
@@ -26,7 +37,7 @@ def gather_view_layers(color, vis, rank, world, group=None):
         pay[j, : T * 12] = color[v0 + j].contiguous().reshape(-1).view(torch.uint8)
         pay[j, T * 12:] = vis[v0 + j].reshape(-1)
     allp = torch.empty(world * per, T * 13, dtype=torch.uint8, device=color.device)
-    dist.all_gather_into_tensor(allp, pay, group=group)
+    _all_gather(allp, pay, group)
     color_all = allp[:n, : T * 12].contiguous().view(torch.float32).view(n, H, W, 3)
     vis_all = allp[:n, T * 12:].contiguous().view(n, H, W)
     return color_all, vis_all
@@ -41,5 +52,5 @@ def gather_view_images(stack, rank, world, group=None):
     pay = torch.zeros(per, flat.shape[1], dtype=torch.uint8, device=stack.device)
     pay[: v1 - v0] = flat[v0:v1]
     allp = torch.empty(world * per, flat.shape[1], dtype=torch.uint8, device=stack.device)
-    dist.all_gather_into_tensor(allp, pay, group=group)
+    _all_gather(allp, pay, group)
     return allp[:n].reshape(stack.shape)

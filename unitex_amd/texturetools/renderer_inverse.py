@@ -261,7 +261,8 @@ class NVDiffRendererInverse:
         with self._stage("dilate_visibility"):
             vis = ops.dilate_visibility(rayvis, alphaok, rast2d)
         if world > 1:
-            color, vis = self._gather_layers(color, vis, per, n)
+            with self._stage("all_gather"):          # the one exchange step of the path
+                color, vis = self._gather_layers(color, vis, per, n)
         mask_u8 = (rast2d[..., 3] > 0).to(torch.uint8).contiguous()
         winner = seam = None
         if method == "reproject":
