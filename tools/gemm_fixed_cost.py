@@ -12,7 +12,8 @@ def timeit(fn, n=20):
         a.record(); fn(); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
     ts.sort(); return ts[len(ts) // 2]
 from unitex_amd import _lib
-_lib.set_option("UTX_GEMM_TILE", 256)
+_lib.set_option("UTX_GEMM_TILE", int(sys.argv[1]) if len(sys.argv) > 1 else 0)   # 0 = persistent kernel (default), 256 = per-tile 8-phase kernel
+print("UTX_GEMM_TILE =", _lib.get_options()["UTX_GEMM_TILE"])
 M, N = 50688, 3072     # 2376 tiles = 9.28 rounds of 256 CUs -> 10 rounds
 rounds = 10
 for kind in ("plain", "bias", "gate", "gelu"):

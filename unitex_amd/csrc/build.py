@@ -21,6 +21,7 @@ SOURCES = [
     ("attention_glds.hip", ["-fno-slp-vectorize"]),
     ("attention_q64.hip", []),
     ("gemm.hip", []),
+    ("gemm_pers.hip", []),
     ("dit_elementwise.hip", ["-ffp-contract=off"]),
     ("vae.hip", []),
     ("capi.cpp", []),

@@ -37,8 +37,9 @@ struct UtxOptions {
     int attn_tpb;         // tiles per barrier of the LDS-DMA kernel (1 | 2)
     int attn_tailsplit;   // 1 (default): key-split tail round
     int gemm_group_m;     // 0 = built-in GROUP_M
-    int gemm_tile;        // 0 auto, 128, 256, 2562 (2-barrier 256^2)
+    int gemm_tile;        // 0 auto, 128, 256 (per-tile 8-phase), 2560 (persistent), 2562 (2-barrier 256^2)
     int gemm_tailsplit;   // 1: K-split tail round of the 8-phase GEMM (off by default)
+    int gemm_pers_grid;   // persistent GEMM: number of workgroups (0 = one per CU)
     int attn_var_abl, attn_debug_abl, gemm_debug_abl;
 };
 extern UtxOptions g_utx_opt;
@@ -57,6 +58,7 @@ int utx_launch_attn_fwd(const void* q, const void* k, const void* vt, void* o,
 int utx_launch_attn_fwd_glds(const AttnParams* p, int presc, hipStream_t stream);
 int utx_launch_attn_fwd_q64(const AttnParams* p, int presc, hipStream_t stream);
 int utx_launch_gemm_bf16(const GemmParams* p, hipStream_t stream);
+int utx_launch_gemm_pers(GemmParams p, hipStream_t stream);   // gemm_pers.hip: persistent 256x256 kernel (large-M linears)
 int utx_launch_gemv_bf16(const GemvParams* p, hipStream_t stream);
 int utx_launch_qkv_post(const QkvPostParams* p, hipStream_t stream);
 int utx_launch_sp_unpack_qkv(const void* recv, int P, int Hp, int S_loc, void* q, void* k, void* vt, hipStream_t stream);
