@@ -302,10 +302,14 @@ def main():
 
     if rank == 0:
         from unitex_amd import _lib
-        fl, fl_attn = step_flops(S)
+        # text-token dedup (flux/transformer.py): the 512 identical text tokens of the reference are carried as 64 rows per rank
+        # whose keys count 8-fold -- FLOPs below are the EXECUTED ones (S_exec tokens), never the nominal 50 688-token figure
+        S_exec = S if model.text_rows is None else model.text_rows * (world if ulysses else 1) + S_img
+        fl, fl_attn = step_flops(S_exec)
+        fl_nominal, _ = step_flops(S)
         attn_ms = [a.elapsed_time(b) for a, b in events]
         attn_avg_ms = sum(attn_ms) / max(len(attn_ms), 1)
-        attn_launch_flops = 4.0 * S * S * 128 * HEADS / (world if ulysses else 1)
+        attn_launch_flops = 4.0 * S_exec * S_exec * 128 * HEADS / (world if ulysses else 1)
         achieved = attn_launch_flops / (attn_avg_ms * 1e-3) / 1e12
         value = (1 if ulysses else world) * args.steps / dt
         par = ("ulysses sp%d: ONE job, 2 all-to-alls / layer (RCCL) + view-sharded back-projection with one all-gather" % world) if ulysses \
@@ -317,7 +321,9 @@ def main():
             "config": {"workload": args.workload, "description": desc, "tokens": S, "text_tokens": S_txt,
                        "noise_tokens": n_noise, "control_tokens": n_ctrl, "dual_tokens": n_dual,
                        "lora_rank": args.lora_rank, "guidance": 3.5, "launch": "hip graph replay" if use_graph else "eager stream launches", "parallelism": par,
-                       "tflop_per_step": fl / 1e12, "achieved_tflops_per_gpu": fl / (dt / args.steps) / 1e12 / (world if ulysses else 1),
+                       "tokens_computed": S_exec, "text_dedup": None if model.text_rows is None else "512 identical text tokens carried as %d rows per rank, key weight 2^%.2f (SURVEY 7 last bullet; UTX_TEXT_DEDUP=0 disables)" % (model.text_rows, model.key_bias_log2),
+                       "tflop_per_step": fl / 1e12, "tflop_per_step_reference_semantics": fl_nominal / 1e12,
+                       "achieved_tflops_per_gpu": fl / (dt / args.steps) / 1e12 / (world if ulysses else 1),
                        "sec_per_mesh_texture_dit_only": 56.0 * dt / args.steps,
                        # every switch that could change what was measured: the library's launch options (all result-preserving; the
                        # wrong-result ablations do not exist in this library) and every UTX_* variable of the environment
@@ -399,7 +405,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             ncpu, phys = host_cores()
             try:
-                threads = max(1, min(ncpu, phys or ncpu))     # one thread per physical core when lscpu tells us; else what we may use
+                # one thread per physical core, capped at 64: on the 128-core hosts of the GPU boxes torch's fp32 GEMMs measured 0.14
+                # TFLOP/s with 128 threads against 0.36 with 64 (profiles/r02_bench_strip1024x6_v0.json.log vs BENCH_r01) -- the baseline
+                # is the faster setting; the host's physical core count is reported next to it
+                threads = max(1, min(ncpu, phys or ncpu, 64))
                 out["cpu_baseline"] = cpu_baseline(S, threads)
                 out["cpu_baseline"]["host"] = {"usable_threads": ncpu, "physical_cores_lscpu": phys}
                 try:

@@ -69,6 +69,14 @@ int utx_is_ablation_build(void);
 int utx_attn_fwd_bf16(utx_ctx* ctx, const void* q, const void* k, const void* vt, void* o,
                       long q_hs, long q_ss, long k_hs, long k_ss, long vt_hs, long vt_ds, long o_ss,
                       int H, int S, float softmax_scale, utx_stream stream);
+/* The same with KEY MULTIPLICITY: every key of tile 0 (keys 0..63) -- and, with key_bias_period = n > 0, of every 64-key tile
+ * whose index is a multiple of n -- stands for 2^key_bias_log2 identical keys: key_bias_log2 is added to its base-2 scores, which
+ * is exactly softmax over the repeated keys.  Used by the text-token dedup of unitex_amd/flux/transformer.py: the reference feeds
+ * 512 all-zero text embeddings with all-zero position ids (flux_piplines/texturing/pipeline.py:538-543), i.e. 512 IDENTICAL tokens
+ * at every layer (last bullet); 64 of them are carried, each counting 8-fold.  key_bias_log2 = 0 is utx_attn_fwd_bf16. */
+int utx_attn_fwd_bf16_kb(utx_ctx* ctx, const void* q, const void* k, const void* vt, void* o,
+                         long q_hs, long q_ss, long k_hs, long k_ss, long vt_hs, long vt_ds, long o_ss,
+                         int H, int S, float softmax_scale, float key_bias_log2, int key_bias_period, utx_stream stream);
 
 /* C = epi(alpha * (A B^T + A2 B2^T) + bias): bf16 GEMM, fp32 accumulate, fused epilogues.
  * Replaces every nn.Linear (+ peft LoRA branch, + GELU, + gated residual) inside the FLUX blocks

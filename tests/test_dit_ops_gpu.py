@@ -368,7 +368,7 @@ def test_sequence_parallel_plan_world1_matches_plain_forward():
             dist.destroy_process_group()
 
 
-def _sp_worker(rank, world, port, q):
+def _sp_worker(rank, world, port, q, zero_text=False):
     import os
     import sys
     import torch.distributed as dist
@@ -381,15 +381,18 @@ def _sp_worker(rank, world, port, q):
     cfg = R.tiny_config(heads=4, double=1, single=2, joint_dim=64, pooled_dim=64)
     sd = R.make_synthetic_state_dict(cfg, seed=3)
     shape = FluxShape(num_heads=4, num_double=1, num_single=2, joint_dim=64, pooled_dim=64)
-    S_txt, S_img = 64 * world, 192 * world
+    S_txt, S_img = (256 if zero_text else 64) * world, 192 * world
     g = torch.Generator().manual_seed(5)
     lat = torch.randn(S_img, 64, generator=g).to(torch.bfloat16).cuda()
     enc = (0.5 * torch.randn(S_txt, 64, generator=g)).to(torch.bfloat16).cuda()
     pooled = (0.5 * torch.randn(1, 64, generator=g)).to(torch.bfloat16).cuda()
+    if zero_text:      # the reference's conditioning: identical text tokens -> every rank carries 64 of them, keys weighted 256 / 64-fold,
+        enc.zero_()    # one text tile at the start of every rank's chunk of the gathered key sequence (key_bias_period)
     txt_ids, img_ids = torch.zeros(S_txt, 3), R.latent_image_ids(8 * world, 24)
     m = FluxDiT(sd, shape, device="cuda:0", sequence_parallel=True)
     m.set_positions(txt_ids, img_ids)
     m.set_conditioning(enc, pooled, 3.5)
+    assert (m.text_rows == 64 and m.key_bias_period == (64 + 192) // 64 and abs(m.key_bias_log2 - 2.0) < 1e-6) if zero_text else (m.text_rows is None)
     i0, i1 = m.local_image_range(S_img)
     out_loc = m.forward(lat[i0:i1].contiguous(), 0.5).float().cpu()
     torch.cuda.synchronize()
@@ -397,6 +400,7 @@ def _sp_worker(rank, world, port, q):
     dist.all_gather(parts, out_loc)
     if rank == 0:
         plain = FluxDiT(sd, shape, device="cuda:0")
+        plain.text_dedup = False           # the reference semantics: every text token processed
         plain.set_positions(txt_ids, img_ids)
         plain.set_conditioning(enc, pooled, 3.5)
         ref = plain.forward(lat, 0.5).float().cpu()
@@ -406,8 +410,8 @@ def _sp_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2])
-def test_sequence_parallel_two_ranks_match_unsharded_forward(world):
+@pytest.mark.parametrize("world,zero_text", [(2, False), (2, True)])
+def test_sequence_parallel_two_ranks_match_unsharded_forward(world, zero_text):
     """two processes share cuda:0 and exchange through gloo (host-staged all-to-all): the token-sharded /
     head-sharded FluxDiT plan -- real kernels, real slicing of ids / embeddings / latents -- against the plain forward.
     Differences can only come from the key order inside attention (fp32 summation order): a few bf16 ulps."""
@@ -416,7 +420,7 @@ def test_sequence_parallel_two_ranks_match_unsharded_forward(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29900 + (os.getpid() % 90)
-    procs = [ctx.Process(target=_sp_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_sp_worker, args=(r, world, port, q, zero_text)) for r in range(world)]
     for p in procs:
         p.start()
     err, mx, frac = q.get(timeout=300)
@@ -612,3 +616,81 @@ def test_sequence_parallel_relayout_kernels(P, Hp, S_loc):
     assert torch.equal(send[:, 0].view(P, Hp, S_loc, 128), Qh.view(P, Hp, S_loc, 128))
     assert torch.equal(send[:, 1].view(P, Hp, S_loc, 128), Kh.view(P, Hp, S_loc, 128))
     assert torch.equal(send[:, 2].view(P, Hp, 128, S_loc), Vt.view(P, Hp, 128, S_loc))
+
+
+@pytest.mark.parametrize("use_lora", [False, True])
+def test_text_token_dedup_matches_full_text_and_oracle(use_lora):
+    """the reference's text tokens are 512 copies of ONE token (zero embeddings, zero ids: pipeline.py:538-543; SURVEY 7 last
+    bullet).  With identical rows FluxDiT carries 64 of them and gives every key of the text tile the weight S_txt / 64 in the
+    softmax (utx_attn_fwd_bf16_kb): the image-token output must equal the full-text plan up to fp32 summation order / bf16
+    rounding, and both must match the oracle, which always processes all S_txt tokens.  Non-identical text rows must NOT dedup."""
+    from unitex_amd.flux.transformer import FluxDiT, FluxShape
+    cfg = dit_ref.tiny_config(heads=2, double=2, single=2, joint_dim=64, pooled_dim=64)
+    sd = dit_ref.make_synthetic_state_dict(cfg, seed=0)
+    shape = FluxShape(num_heads=2, num_double=2, num_single=2, joint_dim=64, pooled_dim=64)
+    S_txt, S_img = 256, 8 * 24 + 8 * 24 + 16
+    g = torch.Generator().manual_seed(21)
+    lat = torch.randn(S_img, 64, generator=g).to(BF)
+    enc = torch.zeros(S_txt, 64).to(BF)
+    pooled = torch.zeros(1, 64).to(BF)
+    txt_ids = torch.zeros(S_txt, 3)
+    img_ids = torch.cat([dit_ref.latent_image_ids(8, 24), dit_ref.latent_image_ids(8, 24, offset_y=8),
+                         dit_ref.latent_image_ids(4, 4, offset_x=24, offset_y=8)], 0)
+    loras = [(dit_ref.make_synthetic_lora(cfg, sd, rank=16, seed=2), 1.0)] if use_lora else None
+    ref, inter = dit_ref.flux_forward(sd, cfg, lat.float(), enc.float(), pooled.float(), 0.4375, 3.5, txt_ids, img_ids, loras=loras,
+                                      emulate_bf16=True, return_intermediates=True)
+    # the premise, on the oracle: the text rows stay identical through every double block
+    for k, v in inter.items():
+        if k.endswith("_ctx"):
+            assert torch.equal(v, v[:1].expand_as(v)), "text rows diverged in %s" % k
+    outs = {}
+    for dedup in (True, False):
+        m = FluxDiT(sd, shape, device="cuda:0")
+        m.text_dedup = dedup
+        if loras:
+            m.set_lora(loras)
+        m.set_positions(txt_ids, img_ids)
+        m.set_conditioning(enc.cuda(), pooled.cuda(), 3.5)
+        assert (m.text_rows == 64) == dedup and (abs(m.key_bias_log2 - 2.0) < 1e-6) == dedup        # 256 / 64 = 4-fold keys
+        outs[dedup] = m.forward(lat.cuda(), 0.4375).float().cpu()
+        torch.cuda.synchronize()
+    mx = max(ref.abs().max().item(), 1.0)
+    assert (outs[True] - outs[False]).abs().max().item() < 0.02 * mx
+    for d in (True, False):
+        assert (outs[d] - ref).abs().max().item() < 0.03 * mx
+    # a prompt with real (row-dependent) embeddings is never deduplicated
+    m = FluxDiT(sd, shape, device="cuda:0")
+    m.set_positions(txt_ids, img_ids)
+    m.set_conditioning((0.5 * torch.randn(S_txt, 64, generator=g)).to(BF).cuda(), pooled.cuda(), 3.5)
+    assert m.text_rows is None and m.key_bias_log2 == 0.0
+
+
+def test_attention_key_multiplicity_equals_repeated_keys():
+    """utx_attn_fwd_bf16_kb: 64 keys in tile 0 with key_bias_log2 = 3 must give the softmax over those keys repeated 8-fold (512
+    text keys) followed by the image keys -- checked against the fp32 oracle on the expanded sequence, including the periodic
+    form (a text tile at the start of every rank's chunk of the gathered sequence under sequence parallelism)."""
+    ops = _ops()
+    H, S_img = 4, 896            # two chunks of 64 + 448 = 512 keys = 8 tiles in the periodic case
+    g = torch.Generator().manual_seed(5)
+    qt, kt, vt_ = (torch.randn(H, 1, 128, generator=g) for _ in range(3))
+    qi, ki, vi = (torch.randn(H, S_img, 128, generator=g) for _ in range(3))
+    scale = (1.0 / math.sqrt(128.0))
+    for period_chunks in (0, 2):
+        if period_chunks == 0:
+            q = torch.cat([qt.expand(H, 64, 128), qi], 1); k = torch.cat([kt.expand(H, 64, 128), ki], 1); v = torch.cat([vt_.expand(H, 64, 128), vi], 1)
+            kf = torch.cat([kt.expand(H, 512, 128), ki], 1); vf = torch.cat([vt_.expand(H, 512, 128), vi], 1)
+            bias, period = 3.0, 0
+        else:      # two chunks [64 text | 448 image] each: 128 carried text keys stand for 512 -> 4-fold, bias 2
+            half = S_img // 2
+            q = torch.cat([qt.expand(H, 64, 128), qi[:, :half], qt.expand(H, 64, 128), qi[:, half:]], 1)
+            k = torch.cat([kt.expand(H, 64, 128), ki[:, :half], kt.expand(H, 64, 128), ki[:, half:]], 1)
+            v = torch.cat([vt_.expand(H, 64, 128), vi[:, :half], vt_.expand(H, 64, 128), vi[:, half:]], 1)
+            kf = torch.cat([kt.expand(H, 512, 128), ki], 1); vf = torch.cat([vt_.expand(H, 512, 128), vi], 1)
+            bias, period = 2.0, (64 + half) // 64
+        q, k, v, kf, vf = (t.to(BF) for t in (q, k, v, kf, vf))
+        S = q.shape[1]
+        out = ops.attention((q.float() * scale * 1.4426950408889634).to(BF).cuda().contiguous(), k.cuda().contiguous(),
+                            v.transpose(1, 2).contiguous().cuda(), S=S, scale=0.0, key_bias_log2=bias, key_bias_period=period)
+        out = out.float().cpu().view(S, H, 128).permute(1, 0, 2)
+        ref = dit_ref.sdpa(q.float(), kf.float(), vf.float(), em=False)          # queries of the carried rows, keys expanded
+        assert (out - ref).abs().max().item() < 4e-2, "key multiplicity (period %d)" % period

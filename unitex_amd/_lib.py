@@ -78,6 +78,7 @@ SYMBOLS = {
     "utx_get_option": (c_int, [C.c_char_p, C.POINTER(c_int)]),
     "utx_is_ablation_build": (c_int, []),
     "utx_attn_fwd_bf16": (c_int, [c_void_p] * 5 + [c_long] * 7 + [c_int, c_int, c_float, c_void_p]),
+    "utx_attn_fwd_bf16_kb": (c_int, [c_void_p] * 5 + [c_long] * 7 + [c_int, c_int, c_float, c_float, c_int, c_void_p]),
     "utx_gemm_bf16": (c_int, [c_void_p, C.POINTER(GemmDesc), c_void_p]),
     "utx_gemv_bf16": (c_int, [c_void_p, C.POINTER(GemvDesc), c_void_p]),
     "utx_group_norm_workspace_bytes": (c_long, []),

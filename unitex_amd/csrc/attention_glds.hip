@@ -156,6 +156,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
                 const bf16x8 kf_ = *reinterpret_cast<const bf16x8*>(kb + (kblk_) + kx[kk]);          \
                 sa_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf_, qf[kk], kk == 0 ? negm : sa_, 0, 0, 0); \
             }                                                                                        \
+            if (kbias) { _Pragma("unroll") for (int r = 0; r < 16; ++r) sa_[r] += kbv; }             \
             if (ragged) {                                                                            \
                 _Pragma("unroll") for (int r = 0; r < 16; ++r)                                       \
                     if ((boff_) + 16 * (r >> 3) + (r & 7) >= lim) sa_[r] = -INFINITY;                \
@@ -173,6 +174,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
                 _Pragma("unroll") for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha_;                 \
         }
         float ps0 = 0.f, ps1 = 0.f;
+        // key multiplicity: every key of this tile stands for 2^key_bias_log2 identical keys (text-token dedup) -> bias on its scores
+        const int tg = tb + t;                               // tile index in the whole sequence
+        const bool kbias = (p.key_bias_log2 != 0.f) && (p.key_bias_period > 0 ? (tg % p.key_bias_period == 0) : (tg == 0));
+        const float kbv = PRESC ? p.key_bias_log2 : p.key_bias_log2 / c2;
         // S0: QK(0); block-1 K fragments stream in behind the MFMAs
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) kfa[kk] = *reinterpret_cast<const bf16x8*>(kb + kx[kk]);
@@ -195,6 +200,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
             vfa[kk] = *reinterpret_cast<const bf16x8*>(vb + (kk & 3) * 4096 + vx[kk >> 2]);
             sa1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfb[kk], qf[kk], kk == 0 ? negm : sa1, 0, 0, 0);
         }
+        if (kbias) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sa0[r] += kbv;
+        }
         AG_EXPB(sa0, pb[0], pb[1], ps0)
 #pragma unroll
         for (int i_ = 0; i_ < (VAR == 2 ? 0 : 8); ++i_) {
@@ -213,6 +222,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
             if (VAR == 3) vfb[i] = vfa[i];   /* ablation: half of the V fragment reads removed (wrong results) */
             else vfb[i] = *reinterpret_cast<const bf16x8*>(vb + (i & 3) * 4096 + vx[2 + (i >> 2)]);
             oacc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfa[i], pb[i >> 2], oacc[i & 3], 0, 0, 0);
+        }
+        if (kbias) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sa1[r] += kbv;
         }
         AG_EXPB(sa1, pb[2], pb[3], ps1)
 #pragma unroll

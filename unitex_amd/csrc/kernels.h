@@ -25,6 +25,10 @@ struct AttnParams {
     int w_base, nsplit, tiles_per_split;
     bf16_t* part_o;        // [items][nsplit][256][128] bf16
     float* part_lse;       // [items][nsplit][256] f32: running maximum + log2(row sum)
+    // key multiplicity (text-token dedup, flux/transformer.py): the keys of tile 0 -- and of every tile whose index is a multiple of
+    // key_bias_period when that is > 0 -- stand for 2^key_bias_log2 identical keys each: key_bias_log2 is added to their scores
+    float key_bias_log2;
+    int key_bias_period;
 };
 // Launch options.  Every field is result-preserving (kernel selection / scheduling A/B): read ONCE from the environment by
 // the first utx_init (UTX_ATTN_*, UTX_GEMM_* variables of the same names), afterwards changed only through utx_set_option.
@@ -54,7 +58,7 @@ typedef utx_sched_desc SchedParams;
 extern "C" {
 int utx_launch_attn_fwd(const void* q, const void* k, const void* vt, void* o,
                         long q_hs, long q_ss, long k_hs, long k_ss, long vt_hs, long vt_ds,
-                        long o_ss, int H, int S, float scale, hipStream_t stream);
+                        long o_ss, int H, int S, float scale, float key_bias_log2, int key_bias_period, hipStream_t stream);
 int utx_launch_attn_fwd_glds(const AttnParams* p, int presc, hipStream_t stream);
 int utx_launch_attn_fwd_q64(const AttnParams* p, int presc, hipStream_t stream);
 int utx_launch_gemm_bf16(const GemmParams* p, hipStream_t stream);

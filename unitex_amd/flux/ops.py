@@ -27,8 +27,9 @@ def _bf(t):
     return t
 
 
-def attention(q, k, vt, S=None, scale=None, out=None, o_ss=None):
-    """q,k [H,S_pad,128]; vt [H,128,S_pad] (S_pad multiple of 64, zero padded) -> o [S, H*128]."""
+def attention(q, k, vt, S=None, scale=None, out=None, o_ss=None, key_bias_log2=0.0, key_bias_period=0):
+    """q,k [H,S_pad,128]; vt [H,128,S_pad] (S_pad multiple of 64, zero padded) -> o [S, H*128].
+    key_bias_log2 / key_bias_period: key multiplicity of tile 0 (and every period-th tile), see utx_attn_fwd_bf16_kb."""
     ctx = get_ctx(q.device.index)
     H, S_pad, D = q.shape
     assert D == 128 and vt.shape[1] == 128 and vt.shape[2] % 64 == 0
@@ -39,9 +40,10 @@ def attention(q, k, vt, S=None, scale=None, out=None, o_ss=None):
         out = torch.empty(S, H * D, dtype=torch.bfloat16, device=q.device)
     if o_ss is None:
         o_ss = out.stride(0)
-    rc = ctx.lib.utx_attn_fwd_bf16(ctx.handle, ptr(_bf(q)), ptr(_bf(k)), ptr(_bf(vt)), ptr(out),
-                                   q.stride(0), q.stride(1), k.stride(0), k.stride(1),
-                                   vt.stride(0), vt.stride(1), o_ss, H, S, float(scale), ctx.stream())
+    rc = ctx.lib.utx_attn_fwd_bf16_kb(ctx.handle, ptr(_bf(q)), ptr(_bf(k)), ptr(_bf(vt)), ptr(out),
+                                      q.stride(0), q.stride(1), k.stride(0), k.stride(1),
+                                      vt.stride(0), vt.stride(1), o_ss, H, S, float(scale), float(key_bias_log2), int(key_bias_period),
+                                      ctx.stream())
     ctx.check(rc)
     return out
 

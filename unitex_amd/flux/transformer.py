@@ -98,6 +98,13 @@ class FluxDiT:
         # image-token half, which fills CUs that the image GEMMs' tail rounds leave idle.  UTX_TXT_STREAM=0 keeps one stream.
         self.overlap_text = os.environ.get("UTX_TXT_STREAM", "1") != "0" and self.sp is None
         self._side = torch.cuda.Stream(device=self.device) if self.overlap_text else None
+        # text-token dedup (last bullet): the reference feeds 512 all-zero text embeddings with all-zero position ids
+        # (flux_piplines/texturing/pipeline.py:538-543) -- 512 IDENTICAL tokens at every layer.  When set_conditioning sees
+        # identical rows (and identical ids) it carries TEXT_KEEP of them and tells the attention kernel that each stands for
+        # S_txt / TEXT_KEEP keys (utx_attn_fwd_bf16_kb): the same softmax, up to fp32 summation order.  UTX_TEXT_DEDUP=0 disables.
+        self.text_dedup = os.environ.get("UTX_TEXT_DEDUP", "1") != "0"
+        self.key_bias_log2, self.key_bias_period, self.text_rows = 0.0, 0, None
+        self._ids = None
         self._pack(state_dict)
 
     # ------------------------------------------------------------------ weights
@@ -340,8 +347,8 @@ class FluxDiT:
         sh = self.shape
         Qh, Kh, Vt = ws["Qh"], ws["Kh"], ws["Vt"]
         args = (ptr(Qh), ptr(Kh), ptr(Vt), ptr(out), Qh.stride(0), Qh.stride(1), Kh.stride(0), Kh.stride(1),
-                Vt.stride(0), Vt.stride(1), out.stride(0), sh.num_heads, S, 0.0)
-        plan.append((self.lib.utx_attn_fwd_bf16, args))
+                Vt.stride(0), Vt.stride(1), out.stride(0), sh.num_heads, S, 0.0, float(self.key_bias_log2), int(self.key_bias_period))
+        plan.append((self.lib.utx_attn_fwd_bf16_kb, args))
 
     def _gemv(self, plan, x, W, b, y, silu_in=False, silu_out=False):
         d = GemvDesc()
@@ -459,15 +466,9 @@ class FluxDiT:
         self._gemm(plan, xn_x, W["proj_out.w"], ws["out"], bias=W["proj_out.b"])
         return {"ws": ws, "plan": plan, "S_txt": S_txt, "S_img": S_img}
 
-    def _get_plan(self, S_txt, S_img):
-        key = (S_txt, S_img, self._lora_version)
-        if key not in self._plans:
-            self._plans.clear()  # one live plan: workspaces are large
-            self._graphs = {}
-            self._plans[key] = self._build(S_txt, S_img)
-        return self._plans[key]
-
     # ------------------------------------------------------------------ forward
+    TEXT_KEEP = 64      # rows of the (identical) text tokens that are carried when the dedup applies: one 64-key attention tile
+
     def local_text_range(self, S_txt):
         from .ulysses import local_slice
         return (0, S_txt) if self.sp is None else local_slice(S_txt, self.sp[0], self.sp[1])
@@ -477,24 +478,44 @@ class FluxDiT:
         return (0, S_img) if self.sp is None else local_slice(S_img, self.sp[0], self.sp[1])
 
     def set_positions(self, txt_ids, img_ids):
-        """Upload the rotary tables for ids = cat(txt_ids, img_ids) (once per pipeline call)."""
-        if self.sp is not None:
-            t0, t1 = self.local_text_range(txt_ids.shape[0])
-            i0, i1 = self.local_image_range(img_ids.shape[0])
-            txt_ids, img_ids = txt_ids[t0:t1], img_ids[i0:i1]
-        p = self._get_plan(txt_ids.shape[0], img_ids.shape[0])
-        cos, sin = rope_tables(torch.cat([txt_ids.cpu().float(), img_ids.cpu().float()], dim=0),
-                               self.shape.axes_dim, self.shape.theta)
-        p["ws"]["cos"].copy_(cos, non_blocking=True)
-        p["ws"]["sin"].copy_(sin, non_blocking=True)
+        """Position ids of the joint sequence cat(txt_ids, img_ids) (FULL tensors, also under sequence parallelism).  The plan
+        and the rotary tables are built by set_conditioning, which knows whether the text tokens can be deduplicated."""
+        self._ids = (txt_ids.detach().to("cpu", torch.float32).contiguous(), img_ids.detach().to("cpu", torch.float32).contiguous())
 
     def set_conditioning(self, encoder_hidden_states, pooled_projections, guidance: float):
+        if self._ids is None:
+            raise RuntimeError("set_positions must be called before set_conditioning")
+        txt_ids, img_ids = self._ids
         S_txt = encoder_hidden_states.shape[-2]
-        p = next(iter(self._plans.values()))
+        assert txt_ids.shape[0] == S_txt, "txt_ids and encoder_hidden_states disagree on the number of text tokens"
+        enc = encoder_hidden_states.reshape(S_txt, -1)
+        world = 1 if self.sp is None else self.sp[1]
+        K = self.TEXT_KEEP
+        identical = bool(self.text_dedup and S_txt > K * world and S_txt % (K * world) == 0 and
+                         torch.equal(txt_ids, txt_ids[:1].expand_as(txt_ids)) and torch.equal(enc, enc[:1].expand_as(enc)))
+        if identical:
+            # every rank carries its own K copies; all keys of a text tile count S_txt / (K * world)-fold
+            t0, t1 = 0, K
+            self.key_bias_log2 = math.log2(S_txt / float(K * world))
+            self.text_rows = K
+        else:
+            t0, t1 = self.local_text_range(S_txt)
+            self.key_bias_log2, self.text_rows = 0.0, None
+        i0, i1 = self.local_image_range(img_ids.shape[0])
+        S_loc = (t1 - t0) + (i1 - i0)
+        # text tiles recur once per rank in the gathered key sequence (keys ordered (source rank, local token))
+        self.key_bias_period = (S_loc // 64) if (identical and world > 1) else 0
+        key = (t1 - t0, i1 - i0, self._lora_version, self.key_bias_log2, self.key_bias_period)
+        if key not in self._plans:
+            self._plans.clear()  # one live plan: workspaces are large
+            self._graphs = {}
+            self._plans[key] = self._build(t1 - t0, i1 - i0)
+        p = self._plans[key]
         ws = p["ws"]
-        t0, t1 = self.local_text_range(S_txt)
-        assert t1 - t0 == p["S_txt"]
-        ws["enc"].copy_(encoder_hidden_states.reshape(S_txt, -1)[t0:t1].to(BF16))
+        cos, sin = rope_tables(torch.cat([txt_ids[t0:t1], img_ids[i0:i1]], dim=0), self.shape.axes_dim, self.shape.theta)
+        ws["cos"].copy_(cos, non_blocking=True)
+        ws["sin"].copy_(sin, non_blocking=True)
+        ws["enc"].copy_(enc[t0:t1].to(BF16))
         ws["pooled"].copy_(pooled_projections.reshape(1, -1).to(BF16))
         g1000 = _bf16_scalar(_bf16_scalar(guidance) * 1000.0)  # guidance.to(dtype) * 1000 in bf16 [3p]
         ws["gproj"].copy_(_timestep_proj(g1000))
@@ -536,15 +557,16 @@ class FluxDiT:
                     a = torch.cuda.Event(enable_timing=True)
                     b = torch.cuda.Event(enable_timing=True)
                     a.record()
-                rc = lib.utx_attn_fwd_bf16(h, ptr(q), ptr(k), ptr(vt), ptr(ex.o), q.stride(0), q.stride(1), k.stride(0), k.stride(1),
-                                           vt.stride(0), vt.stride(1), ex.o.stride(0), ex.Hp, ex.S, 0.0, st)
+                rc = lib.utx_attn_fwd_bf16_kb(h, ptr(q), ptr(k), ptr(vt), ptr(ex.o), q.stride(0), q.stride(1), k.stride(0), k.stride(1),
+                                              vt.stride(0), vt.stride(1), ex.o.stride(0), ex.Hp, ex.S, 0.0, float(self.key_bias_log2),
+                                              int(self.key_bias_period), st)
                 if ev is not None:
                     b.record()
                     ev.append((a, b))
                 if rc:
                     self.ctx.check(rc)
                 ex.tokens_out(d)
-            elif fn is lib.utx_attn_fwd_bf16:
+            elif fn is lib.utx_attn_fwd_bf16_kb:
                 ev = getattr(self, "attn_events", None)
                 if ev is not None:  # bench.py: HIP events on the launch stream around the dominant kernel
                     a = torch.cuda.Event(enable_timing=True)
