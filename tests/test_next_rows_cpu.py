@@ -259,3 +259,48 @@ def test_vertex_normal_weightings_area_and_angle():
     exp /= np.linalg.norm(exp)
     assert np.allclose(ng, exp, atol=1e-6)
     assert np.linalg.norm(na - ng) > 0.5, "the skewed fan must separate the two weightings (area %s, angle %s)" % (na, ng)
+
+
+import pytest
+
+
+@pytest.mark.parametrize("n", [4, 6, 8])
+def test_view_grid_strip_round_trip_for_4_6_8_views(n, tmp_path):
+    """infer_mv's host permutations generalised from the reference's six views (pinned by fixture G3) to the 4-view set of
+    BASELINE configs[0] (export_nvdiffrast_video.py:931-932) and the builder-defined 8-view set of configs[4]: with an echo
+    pipeline, a grid of tagged tiles must come back as the same grid (strip order and the 180-degree turn of the 'down' view undone)
+    and the strip the DiT sees must hold the views in the order front, left, right, back, top, down (, diagonals)."""
+    import types
+    from PIL import Image as PI
+    from unitex_amd.pipeline import RGBTextureFullPipelineBase as B
+    lay = B.VIEW_LAYOUT[n]
+    V, R, Cc = 32, lay["rows"], lay["cols"]
+    rng = np.random.default_rng(n)
+    grid = np.zeros((R * V, Cc * V, 3), np.uint8)
+    for t in range(n):
+        tile = rng.integers(0, 255, (V, V, 3), dtype=np.uint8) // 2 * 2        # even values: 0.5 x + 0.5 x is exact
+        tile[..., 2] = 2 * t                                                    # tag
+        grid[(t // Cc) * V:(t // Cc + 1) * V, (t % Cc) * V:(t % Cc + 1) * V] = tile
+    PI.fromarray(grid).save(tmp_path / "n.png"); PI.fromarray(grid).save(tmp_path / "c.png")
+    PI.fromarray(np.zeros((V, V, 3), np.uint8)).save(tmp_path / "ref.png")
+    seen = {}
+
+    class Echo:
+        _num_inference_steps = 2
+
+        def set_adapters(s, adapter_names, adapter_weights):
+            pass
+
+        def __call__(s, **kw):
+            seen.setdefault("strips", []).append(np.asarray(kw["control_image"]).copy())
+            assert (kw["height"], kw["width"], kw["n_cols"]) == (V, n * V, n)
+            return types.SimpleNamespace(images=[kw["control_image"]])
+    me = types.SimpleNamespace(pipeline=Echo(), pipeline_name="texture_plus", view_size=V, n_views=n, generator=None,
+                               adapter_names=["texture", "delight"], weights_for_texture=[1.0, 0.0], weights_for_delight=[0.0, 1.0])
+    B.infer_mv(me, str(tmp_path), str(tmp_path / "ref.png"), str(tmp_path / "n.png"), str(tmp_path / "c.png"))
+    out = np.asarray(PI.open(tmp_path / "mv_rgb.png"))
+    assert np.array_equal(out, grid), "grid -> strip -> grid must be the identity for %d views" % n
+    order = [int(seen["strips"][0][V // 2, i * V + V // 2, 2]) // 2 for i in range(n)]
+    assert order == lay["strip"]
+    names = {4: "f r b l", 6: "f r t b l d", 8: "f r t b l d x1 x2"}[n].split()
+    assert [names[g] for g in order][:4] == ["f", "l", "r", "b"]

@@ -106,3 +106,60 @@ def test_full_pipeline_end_to_end_tiny(tmp_path):
     got = np.asarray(Image.open(os.path.join(cache, "wo_LTM/completed_uv.png")).convert("RGB")).astype(np.int32)
     ref8 = (np.clip(final, 0, 1) * 255 + 0.5).astype(np.int32)
     assert (np.abs(got - ref8) > 1).mean() < 1e-3, "completed atlas vs oracle"
+
+
+@pytest.mark.parametrize("n_views,view_px", [(4, 256), (8, 128)])
+def test_full_pipeline_4_and_8_view_variants(tmp_path, n_views, view_px):
+    """BASELINE configs[0] (four views f, r, b, l: the reference's export_condition supports them, export_nvdiffrast_video.py:931-932,
+    its infer_mv does not) and configs[4] (eight views, builder-defined set): the same call surface with n_views=4 / 8 must run the
+    whole chain -- condition grids of the right shape, a 1 x n control strip into the DiT, the n-view back-projection with the set's
+    composite priority -- and the union visibility mask must equal the oracle's for the same cameras."""
+    from unitex_amd.flux.pipeline import PBRFluxPipeline
+    from unitex_amd.flux.synthetic import SyntheticFluxStateDict, synthetic_lora
+    from unitex_amd.flux.transformer import FluxDiT, FluxShape
+    from unitex_amd.pipeline import CustomRGBTextureFullPipeline
+    from unitex_amd.texturetools import camera, meshes
+    dev = "cuda:0"
+    shape = FluxShape(num_heads=2, num_double=1, num_single=1, joint_dim=64, pooled_dim=64)
+    sd = SyntheticFluxStateDict(shape, seed=0, device=dev)
+    flux = PBRFluxPipeline(FluxDiT(sd, shape, device=dev), fakes.FakeVAE(), device=dev)
+    flux.load_lora_weights(synthetic_lora(sd, shape, rank=16, seed=1, device=dev), adapter_name="texture")
+    flux.load_lora_weights(synthetic_lora(sd, shape, rank=16, seed=2, device=dev), adapter_name="delight")
+    pipe = CustomRGBTextureFullPipeline(seed=63, pipeline=flux, num_inference_steps=2, atlas_size=256, device=dev, view_size=view_px,
+                                        n_views=n_views)
+    verts, faces, uvs = meshes.sphere_with_faces(3000)
+    mesh_path = str(tmp_path / "in.obj")
+    meshes.save_obj(mesh_path, verts, faces, uvs)
+    img_path = str(tmp_path / "ref.png")
+    yy, xx = np.mgrid[0:256, 0:256]
+    Image.fromarray(np.stack([xx, yy, (xx + yy) // 2], -1).astype(np.uint8)).save(img_path)
+    out_dir = str(tmp_path / "out")
+    png, glb = pipe(out_dir, img_path, mesh_path)
+    cache = os.path.join(out_dir, "cache")
+    lay = pipe.VIEW_LAYOUT[n_views]
+    V = view_px
+    assert np.asarray(Image.open(os.path.join(cache, "mv_rgb.png"))).shape == (lay["rows"] * V, lay["cols"] * V, 3)
+    assert np.asarray(Image.open(os.path.join(cache, "mv_rgb_w_light.png"))).shape == (V, n_views * V, 3)
+    assert open(glb, "rb").read(4) == b"glTF"
+    cam = torch.load(os.path.join(cache, "camera_info.pth"), weights_only=True)
+    c2ws_ref, order = camera.generate_views_c2ws(n_views, 2.8)
+    assert torch.equal(cam["c2ws"], c2ws_ref) and pipe.inverse_renderer.index == list(order)
+    # union visibility vs the oracle for these cameras
+    pv, pf, puv, pfuv = meshes.load_obj(os.path.join(cache, "processed_mesh.obj"))
+    vv, ff, uu = meshes.unify_uv_indexing(pv, pf, puv, pfuv)
+    mvp = G.mvp_matrices(cam["c2ws"].numpy(), cam["intrinsics"].numpy(), perspective=False)
+    clip = G.transform_points(vv, mvp)
+    vndc = (clip[..., :2] / clip[..., 3:4]).astype(np.float32)
+    img = np.asarray(Image.open(os.path.join(cache, "mv_rgb.png")).convert("RGB"), dtype=np.float32) / 255.0
+    views = img.reshape(lay["rows"], V, lay["cols"], V, 3).transpose(0, 2, 1, 3, 4).reshape(n_views, V, V, 3)
+    alphas = np.stack([(G.rasterize(clip[v], ff, V, V)[..., 3] > 0).astype(np.float32) for v in range(n_views)])
+    T = 256
+    uvclip = np.concatenate([uu * 2 - 1, np.zeros((len(uu), 1), np.float32), np.ones((len(uu), 1), np.float32)], -1)
+    rast2d = G.rasterize(uvclip, ff, T, T)
+    mask2d = rast2d[..., 3] > 0
+    col, rv, ao = G.backproject(rast2d, vv, ff, G.face_normals(vv, ff), vndc, (-cam["c2ws"].numpy()[:, :3, 2]).astype(np.float32),
+                                np.concatenate([views, alphas[..., None]], -1).astype(np.float32), G.BVH(vv, ff), angle_deg=100.0)
+    vis = G.dilate_visibility(rv, mask2d, ao)
+    visable = np.asarray(Image.open(os.path.join(cache, "wo_LTM/visable_uv_mask.png"))) > 127
+    assert np.array_equal(np.asarray(Image.open(os.path.join(cache, "wo_LTM/valid_uv_mask.png"))) > 127, mask2d)
+    assert np.array_equal(visable, vis.any(0)), "union visibility mask (%d views)" % n_views

@@ -139,10 +139,18 @@ class AutoencoderKL:
         q = ops.gemm(h, w[name + ".to_q.weight"], bias=w[name + ".to_q.bias"])
         k = ops.gemm(h, w[name + ".to_k.weight"], bias=w[name + ".to_k.bias"])
         vt = ops.gemm(w[name + ".to_v.weight"], h)                                   # V^T [C, S]; bias added after PV
-        s = ops.gemm(q, k, alpha=1.0 / math.sqrt(Cc))                                # scores [S, S]
-        self.ctx.check(self.ctx.lib.utx_softmax_rows(self.ctx.handle, ptr(s), S, s.stride(0), S, self.ctx.stream()))
-        a = ops.gemm(s, vt, bias=w[name + ".to_v.bias"])                             # P V + b_v
-        del s
+        # scores are materialised one block of query rows at a time ([QB, S] bf16, <= ~2 GiB): softmax and P V are row-wise, so the
+        # result is bit-identical to the whole [S, S] matrix (18.9 GB at 1024 x 6144, 550 GB at 2048^2 x 8 views)
+        QB = max(256, min(S, ((1 << 30) // S) // 256 * 256))
+        a = torch.empty(S, Cc, dtype=BF, device=self.device)
+        sbuf = torch.empty(min(QB, S), S, dtype=BF, device=self.device)
+        for r0 in range(0, S, QB):
+            r1 = min(S, r0 + QB)
+            sblk = sbuf[: r1 - r0]
+            ops.gemm(q[r0:r1], k, alpha=1.0 / math.sqrt(Cc), out=sblk)              # scores [QB, S]
+            self.ctx.check(self.ctx.lib.utx_softmax_rows(self.ctx.handle, ptr(sblk), r1 - r0, sblk.stride(0), S, self.ctx.stream()))
+            ops.gemm(sblk, vt, bias=w[name + ".to_v.bias"], out=a[r0:r1])            # P V + b_v
+        del sbuf
         return ops.gemm(a, w[name + ".to_out.0.weight"], bias=w[name + ".to_out.0.bias"], gate=self.ones[:Cc], res=x)
 
     def _mid(self, x, H, W, name):

@@ -51,7 +51,7 @@ def build_pipeline(pretrain_models=None, pipeline_name="texture_plus", device="c
 class RGBTextureFullPipelineBase:
     def __init__(self, pretrain_models=None, pipeline_name="texture_plus", super_resolutions=False, seed=0, speedup_mode=None,
                  add_lora_path=None, add_lora_weights=None, enable_rembg=False, device="cuda:0", pipeline=None,
-                 num_inference_steps=None, atlas_size=2048, view_size=512, multi_gpu=None, process_group=None):
+                 num_inference_steps=None, atlas_size=2048, view_size=512, multi_gpu=None, process_group=None, n_views=6):
         """multi_gpu (beyond the reference, which is single-GPU): None = automatic -- when torch.distributed is initialised with
         more than one rank, the ranks work on ONE mesh together: the DiT runs sequence-parallel (two all-to-alls per layer), the
         geometry-condition render and the back-projection are sharded by view (`view_shard=(rank, world)`, ONE all-gather each;
@@ -88,6 +88,18 @@ class RGBTextureFullPipelineBase:
         # per-view resolution: 512 is the reference's hard-wired operating point (pipeline.py:239-255); 1024 is
         # BASELINE.json's configs[1..2] (joint strip 1024 x 6144, 50 688 tokens)
         self.view_size = int(view_size)
+        # view count: 6 is the reference's hard-wired set (pipeline.py:206,239-255); 4 (f, r, b, l: export_nvdiffrast_video.py:931-932,
+        # BASELINE configs[0]) and 8 (six + two upper diagonals, BASELINE configs[4]) are the builder-defined generalisations SURVEY 8a's
+        # view-count caveat asks for -- same grid -> strip -> grid orchestration, cameras / priority from camera.generate_views_c2ws
+        if n_views not in self.VIEW_LAYOUT:
+            raise ValueError("n_views must be one of %s" % sorted(self.VIEW_LAYOUT))
+        self.n_views = int(n_views)
+
+    # view grid (rows x cols, tiles in the inverse renderer's view order) <-> 1 x n strip the DiT sees; `strip` lists the grid tiles in
+    # strip order, `rot` is the grid tile turned by 180 degrees on the way (the 'down' view).  6 = reference (pipeline.py:239-255,279-288)
+    VIEW_LAYOUT = {4: dict(rows=2, cols=2, strip=[0, 3, 1, 2], rot=None),
+                   6: dict(rows=2, cols=3, strip=[0, 4, 1, 3, 2, 5], rot=5),
+                   8: dict(rows=2, cols=4, strip=[0, 4, 1, 3, 2, 5, 6, 7], rot=5)}
 
     @CPUTimer("preprocess_blank_mesh")
     def preprocess_blank_mesh(self, save_dir, input_mesh_path, min_faces=20_000, max_faces=200_000, scale=0.95):
@@ -115,7 +127,8 @@ class RGBTextureFullPipelineBase:
 
     @CPUTimer("render_geometry_images")
     def render_geometry_images(self, save_dir, input_mesh_path, geometry_scale=0.95, scale=1.0, color="grey"):
-        out = self.video_exporter.export_condition(input_mesh_path, geometry_scale=geometry_scale, n_views=6, n_rows=2, n_cols=3,
+        lay = self.VIEW_LAYOUT[self.n_views]
+        out = self.video_exporter.export_condition(input_mesh_path, geometry_scale=geometry_scale, n_views=self.n_views, n_rows=lay["rows"], n_cols=lay["cols"],
                                                    H=self.view_size, W=self.view_size, fov_deg=49.1, scale=scale, perspective=False, orbit=False,
                                                    background=color, return_image=True, return_camera=True)
         out["alpha"].save(os.path.join(save_dir, "mv_alpha.png"))
@@ -135,20 +148,27 @@ class RGBTextureFullPipelineBase:
         if self.pipeline_name != "texture_plus":
             raise NotImplementedError("pipeline_name %s is not supported" % self.pipeline_name)
         V = getattr(self, "view_size", 512)
-        mix = (0.5 * normal.reshape(2, V, 3, V, -1) + 0.5 * ccm.reshape(2, V, 3, V, -1)).astype(np.uint8)
-        mix[1, :, 2] = mix[1, ::-1, 2, ::-1]
-        tiles = mix.transpose(0, 2, 1, 3, 4).reshape(6, V, V, -1)[[0, 4, 1, 3, 2, 5]]
-        control_image = Image.fromarray(tiles.transpose(1, 0, 2, 3).reshape(V, 6 * V, -1))
-        common = dict(prompt="[MVFLUX]", prompt_embeds=None, pooled_prompt_embeds=None, height=V, width=6 * V, n_rows=1,
-                      n_cols=6, num_inference_steps=steps, guidance_scale=3.5, max_sequence_length=512, generator=self.generator)
+        n = getattr(self, "n_views", 6)
+        lay = RGBTextureFullPipelineBase.VIEW_LAYOUT[n]
+        R, Cc, strip, rot = lay["rows"], lay["cols"], lay["strip"], lay["rot"]
+        mix = (0.5 * normal.reshape(R, V, Cc, V, -1) + 0.5 * ccm.reshape(R, V, Cc, V, -1)).astype(np.uint8)
+        if rot is not None:
+            mix[rot // Cc, :, rot % Cc] = mix[rot // Cc, ::-1, rot % Cc, ::-1]
+        tiles = mix.transpose(0, 2, 1, 3, 4).reshape(n, V, V, -1)[strip]
+        control_image = Image.fromarray(tiles.transpose(1, 0, 2, 3).reshape(V, n * V, -1))
+        common = dict(prompt="[MVFLUX]", prompt_embeds=None, pooled_prompt_embeds=None, height=V, width=n * V, n_rows=1,
+                      n_cols=n, num_inference_steps=steps, guidance_scale=3.5, max_sequence_length=512, generator=self.generator)
         self.pipeline.set_adapters(adapter_names=self.adapter_names, adapter_weights=self.weights_for_texture)
         out_image = self.pipeline(control_image=control_image, dual_image=reference_image, **common).images[0]
         out_image.save(os.path.join(save_dir, "mv_rgb_w_light.png"))
         self.pipeline.set_adapters(adapter_names=self.adapter_names, adapter_weights=self.weights_for_delight)
         delit = self.pipeline(control_image=out_image, **common).images[0]
-        t = np.array(delit).reshape(V, 6, V, -1)
-        t[:, 5] = t[::-1, 5, ::-1]
-        grid = t.transpose(1, 0, 2, 3)[[0, 2, 4, 3, 1, 5]].reshape(2, 3, V, V, -1).transpose(0, 2, 1, 3, 4).reshape(2 * V, 3 * V, -1)
+        t = np.array(delit).reshape(V, n, V, -1)
+        if rot is not None:
+            sp = strip.index(rot)                       # where the turned tile sits in the strip
+            t[:, sp] = t[::-1, sp, ::-1]
+        inv = [strip.index(g) for g in range(n)]        # strip position of every grid tile ([0, 2, 4, 3, 1, 5] for the reference's six)
+        grid = t.transpose(1, 0, 2, 3)[inv].reshape(R, Cc, V, V, -1).transpose(0, 2, 1, 3, 4).reshape(R * V, Cc * V, -1)
         Image.fromarray(grid).save(os.path.join(save_dir, "mv_rgb.png"))
 
     @CPUTimer("export_video")
@@ -164,10 +184,15 @@ class RGBTextureFullPipelineBase:
         assert method in ["kdtree", "reproject"] and not four_or_six and not flatten
         img = np.asarray(Image.open(input_mv_image_path).convert("RGB"), dtype=np.float32) / 255.0   # image_to_tensor
         Hh, Ww, Cc = img.shape
-        HP, WP = Hh // 2, Ww // 3
-        image_attrs = torch.from_numpy(img).reshape(2, HP, 3, WP, Cc).permute(0, 2, 1, 3, 4).reshape(6, HP, WP, Cc)
+        n = getattr(self, "n_views", 6)
+        lay = RGBTextureFullPipelineBase.VIEW_LAYOUT[n]
+        HP, WP = Hh // lay["rows"], Ww // lay["cols"]
+        image_attrs = torch.from_numpy(img).reshape(lay["rows"], HP, lay["cols"], WP, Cc).permute(0, 2, 1, 3, 4).reshape(n, HP, WP, Cc)
         cam = torch.load(camera_info_path, weights_only=True, map_location="cpu")
         self.inverse_renderer.update_from_file(input_mesh_path)
+        if n != 6:
+            from .texturetools import camera as _cam
+            self.inverse_renderer.index = list(_cam.generate_views_c2ws(n)[1])      # composite priority of the 4- / 8-view sets
         T = self.atlas_size
         textured, reprojected_uv, visable_mask, completed = self.inverse_renderer.infer(
             input_mesh_path, c2ws=cam["c2ws"], intrinsics=cam["intrinsics"], image_attrs=image_attrs, perspective=cam["perspective"],

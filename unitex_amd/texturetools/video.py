@@ -69,9 +69,12 @@ class VideoExporter:
         lo, hi = verts.min(0).values, verts.max(0).values
         s = (hi - lo).max() / (2.0 * geometry_scale)
         verts = ((verts - 0.5 * (lo + hi)) / s).contiguous()
-        c2ws = camera.generate_box_views_c2ws(radius=2.8)
-        sel = {1: [0], 2: [0, 2], 4: [0, 1, 2, 3], 6: [0, 1, 4, 2, 3, 5] if (n_rows, n_cols) == (2, 3) else list(range(6))}[n_views]
-        c2ws = c2ws[sel]
+        if n_views == 8:     # BASELINE configs[4]: the six axis views + two upper diagonals (camera.generate_views_c2ws; builder-defined)
+            c2ws, _ = camera.generate_views_c2ws(8, radius=2.8)
+        else:
+            c2ws = camera.generate_box_views_c2ws(radius=2.8)
+            sel = {1: [0], 2: [0, 2], 4: [0, 1, 2, 3], 6: [0, 1, 4, 2, 3, 5] if (n_rows, n_cols) == (2, 3) else list(range(6))}[n_views]
+            c2ws = c2ws[sel]
         intrinsics = camera.generate_intrinsics(scale, scale, fov=False, degree=False)
         bg = camera.parse_color(background)
         dev = self.device
