@@ -167,6 +167,9 @@ def main():
     ap.add_argument("--parallelism", default=os.environ.get("UTX_PARALLELISM", "ulysses"), choices=["replicas", "ulysses"],
                     help="N > 1: 'ulysses' (default) = ONE job, head-parallel sequence parallelism with two all-to-alls per layer "
                          "over RCCL (strong scaling) + view-sharded back-projection; 'replicas' = N independent jobs (weak scaling)")
+    ap.add_argument("--fp8", action="store_true",
+                    help="BASELINE configs[4] numerics: the five big linears on OCP MX fp8 operands (utx_gemm_desc.mx8); NOT the default "
+                         "bench line (the metric is quoted in bf16) -- reported with dtype 'mx-fp8 linears + bf16 attention'")
     ap.add_argument("--cpu-config1", action="store_true",
                     help="also run BASELINE configs[0] (512^2 x 4 views, S = 9728, 4 denoise steps, fp32) to COMPLETION on the host "
                          "cores with the oracle (~15-30 min): the one CPU number that is not extrapolated (SURVEY 8d)")
@@ -202,7 +205,7 @@ def main():
     shape = FluxShape()
     sd = SyntheticFluxStateDict(shape, seed=0, device=dev)
     ulysses = args.parallelism == "ulysses" and world > 1
-    model = FluxDiT(sd, shape, device=dev, sequence_parallel=ulysses)
+    model = FluxDiT(sd, shape, device=dev, sequence_parallel=ulysses, fp8_weights=args.fp8)
     tex = synthetic_lora(sd, shape, rank=args.lora_rank, seed=1, device=dev)
     dlt = synthetic_lora(sd, shape, rank=args.lora_rank, seed=2, device=dev)
     model.set_lora([(tex, 1.0), (dlt, 0.0)])  # reference: weights_for_texture = [1, 0] (pipeline.py:110)
@@ -317,7 +320,8 @@ def main():
         out = {
             "metric": "denoising-steps/sec", "value": value, "unit": "steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak" if (world > 1 and not ulysses) else "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak" if (world > 1 and not ulysses) else "strong", "vs_baseline": None,
+            "dtype": "mx-fp8 (e4m3 x E8M0/32) big linears + bf16 attention" if args.fp8 else "bf16", "data": "synthetic",
             "config": {"workload": args.workload, "description": desc, "tokens": S, "text_tokens": S_txt,
                        "noise_tokens": n_noise, "control_tokens": n_ctrl, "dual_tokens": n_dual,
                        "lora_rank": args.lora_rank, "guidance": 3.5, "launch": "hip graph replay" if use_graph else "eager stream launches", "parallelism": par,

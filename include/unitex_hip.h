@@ -105,8 +105,22 @@ typedef struct utx_gemm_desc {
      * F.pad(0,1,0,1) stride-2 downsampler and the nearest-2x upsampler) of the FLUX VAE [3p]. */
     int conv_Hi, conv_Wi, conv_Wo, conv_cin_log2, conv_stride, conv_pad, conv_up;
     const void* zero_page;
+    /* OCP MX fp8 base segment (mx8 = 1; BASELINE configs[4] "fp8 MFMA weights"): A [M,K] and B [N,K] hold e4m3 bytes (lda / ldb
+     * in bytes, K a multiple of 128) and a_scale [M][K/32] / b_scale [N][K/32] one E8M0 byte per 32 elements along K (row strides
+     * lds_a / lds_b bytes, multiples of 4); element value = e4m3 * 2^(scale - 127).  Accumulation in fp32 by
+     * v_mfma_scale_f32_32x32x64_f8f6f4; the LoRA segment (A2 / B2) stays bf16; epilogues unchanged.  Quantise activations with
+     * utx_quant_mx8; weights once at load (unitex_amd/flux/mx8.py).  Replaces the same nn.Linear as the bf16 form. */
+    const void* a_scale; long lds_a;
+    const void* b_scale; long lds_b;
+    int mx8;
 } utx_gemm_desc;
 int utx_gemm_bf16(utx_ctx* ctx, const utx_gemm_desc* d, utx_stream stream);
+
+/* OCP MX fp8 quantisation of a bf16 matrix along its rows (the activation operand of an mx8 GEMM):
+ *   per block of 32 consecutive elements: e = floor(log2(max|x|)) - 8 (clamped to [-127, 127]; -127 for an all-zero block),
+ *   scale byte = e + 127, q = e4m3_rne(clamp(x * 2^-e, -448, 448)).
+ * x [M][ldx] bf16 (K % 32 == 0, ldx % 8 == 0) -> q [M][ldq] bytes, s [M][lds] bytes (K/32 per row).  oracle/mx8_ref.py restates it. */
+int utx_quant_mx8(utx_ctx* ctx, const void* x, long ldx, void* q, long ldq, void* s, long lds, int M, int K, utx_stream stream);
 
 /* y[m,n] = act_out(sum_k act_in(x[m,k]) W[n,k] + b[n]) for M <= 8 (embedders, AdaLN modulation). */
 typedef struct utx_gemv_desc {

@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_dit_ops_gpu.py -x -q -k "multiplicity or dedup or sequence_parallel" 2>&1 | tail -8
+python tools/perf_fp8.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r02_perf_fp8_v0.log

@@ -22,7 +22,8 @@ class GemmDesc(C.Structure):
                 ("res", c_void_p), ("ldres", c_long), ("C", c_void_p), ("ldc", c_long),
                 ("n_split", c_int), ("C1", c_void_p), ("ldc1", c_long), ("ntn", c_int),
                 ("conv_Hi", c_int), ("conv_Wi", c_int), ("conv_Wo", c_int), ("conv_cin_log2", c_int),
-                ("conv_stride", c_int), ("conv_pad", c_int), ("conv_up", c_int), ("zero_page", c_void_p)]
+                ("conv_stride", c_int), ("conv_pad", c_int), ("conv_up", c_int), ("zero_page", c_void_p),
+                ("a_scale", c_void_p), ("lds_a", c_long), ("b_scale", c_void_p), ("lds_b", c_long), ("mx8", c_int)]
 
 
 class GemvDesc(C.Structure):
@@ -80,6 +81,7 @@ SYMBOLS = {
     "utx_attn_fwd_bf16": (c_int, [c_void_p] * 5 + [c_long] * 7 + [c_int, c_int, c_float, c_void_p]),
     "utx_attn_fwd_bf16_kb": (c_int, [c_void_p] * 5 + [c_long] * 7 + [c_int, c_int, c_float, c_float, c_int, c_void_p]),
     "utx_gemm_bf16": (c_int, [c_void_p, C.POINTER(GemmDesc), c_void_p]),
+    "utx_quant_mx8": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_void_p]),
     "utx_gemv_bf16": (c_int, [c_void_p, C.POINTER(GemvDesc), c_void_p]),
     "utx_group_norm_workspace_bytes": (c_long, []),
     "utx_group_norm": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p]),

@@ -117,6 +117,58 @@ extern "C" int utx_launch_qkv_post(const QkvPostParams* hp, hipStream_t stream) 
 }
 
 // ---------------------------------------------------------------------------------------------
+// OCP MX fp8 quantisation of the activation operand of an mx8 GEMM (unitex_hip.h: utx_quant_mx8).  One thread per block of 32
+// elements: 64 B read (4 x 16 B), 32 B + 1 scale byte written.  HBM-bound: 3.03 B per element.
+//   e = floor(log2(amax)) - 8  (exponent field of amax: bf16 inputs are exact in fp32), clamp [-127, 127]; amax == 0 -> -127
+//   q = e4m3_rne(clamp(x * 2^-e, -448, 448))            (v_cvt_pk_fp8_f32: OCP e4m3fn on gfx950)
+__global__ __launch_bounds__(256) void quant_mx8_kernel(const bf16_t* __restrict__ x, long ldx, uint8_t* __restrict__ q, long ldq,
+                                                        uint8_t* __restrict__ sc, long lds, int M, int nblk) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)M * nblk) return;
+    const int row = (int)(t / nblk), blk = (int)(t - (long)row * nblk);
+    const bf16_t* src = x + (long)row * ldx + blk * 32;
+    float v[32];
+    float amax = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(src + 8 * c);
+        const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[8 * c + 2 * j] = bf2f((uint16_t)(w[j] & 0xffff)); v[8 * c + 2 * j + 1] = bf2f((uint16_t)(w[j] >> 16));
+            amax = fmaxf(amax, fmaxf(fabsf(v[8 * c + 2 * j]), fabsf(v[8 * c + 2 * j + 1])));
+        }
+    }
+    int e = (int)((__float_as_uint(amax) >> 23) & 0xff) - 127 - 8;
+    if (amax == 0.f || e < -127) e = -127;
+    if (e > 127) e = 127;
+    const float inv = __uint_as_float((uint32_t)(127 - e) << 23);     // 2^-e, exact (e in [-127, 127] -> exponent field 0..254; 0 only for e = 127)
+    uint32_t out[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float a[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a[c] = fminf(fmaxf(v[4 * j + c] * inv, -448.f), 448.f);
+        int pk = 0;
+        pk = __builtin_amdgcn_cvt_pk_fp8_f32(a[0], a[1], pk, false);
+        pk = __builtin_amdgcn_cvt_pk_fp8_f32(a[2], a[3], pk, true);
+        out[j] = (uint32_t)pk;
+    }
+    uint4* dst = reinterpret_cast<uint4*>(q + (long)row * ldq + blk * 32);
+    dst[0] = make_uint4(out[0], out[1], out[2], out[3]);
+    dst[1] = make_uint4(out[4], out[5], out[6], out[7]);
+    sc[(long)row * lds + blk] = (uint8_t)(e + 127);
+}
+
+extern "C" int utx_launch_quant_mx8(const void* x, long ldx, void* q, long ldq, void* s, long lds, int M, int K, hipStream_t stream) {
+    if (M <= 0 || K <= 0 || (K & 31) || (ldx & 7) || (ldq & 15) || lds < K / 32) return -2;
+    const long total = (long)M * (K / 32);
+    hipLaunchKernelGGL(quant_mx8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)x, ldx, (uint8_t*)q, ldq,
+                       (uint8_t*)s, lds, M, K / 32);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Sequence-parallel exchange, receive side (unitex_hip.h: utx_sp_unpack_qkv / utx_sp_unpack_o): relayout of what the
 // all-to-all delivered into the attention kernel's / the out-projection's operand layouts.  Pure copies: one 16-byte vector
 // per thread and step, sources and destinations in runs of >= 128 B (S_loc % 64 == 0), grid-stride.

@@ -82,7 +82,13 @@ __device__ __forceinline__ void glds16(const bf16_t* g, char* lds) {
         }                                                                                                        \
     }
 
-template <int BM, int BN, int NWM, int NWN, bool CONV>
+// MX8: the base K-segment is OCP MX fp8 (e4m3 elements, one E8M0 scale per 32 elements along K) on BOTH operands, consumed by
+// v_mfma_scale_f32_32x32x64_f8f6f4 at twice the bf16 MFMA rate (BASELINE configs[4] "fp8 MFMA weights").  A 128-byte LDS row is
+// then 128 fp8 (one K-tile of 128) instead of 64 bf16: staging, swizzle and ring are byte-identical (the launcher passes K and the
+// leading dimensions in bf16 units, i.e. halved); only the fragment reads (32 bytes per lane and MFMA) and the per-lane scale
+// bytes differ.  The LoRA K-segment stays bf16 and feeds the same fp32 accumulators.
+typedef __attribute__((ext_vector_type(8))) int gm_i32x8;
+template <int BM, int BN, int NWM, int NWN, bool CONV, bool MX8 = false>
 __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_bf16_kernel(GemmParams p) {
     constexpr int NW = NWM * NWN, NT = 64 * NW;
     constexpr int WMR = BM / NWM, WNR = BN / NWN;   // rows of C per wave along m / n
@@ -179,6 +185,21 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_bf16_kernel(GemmParams
     const int ra0 = wm * WMR + l31, rb0 = wn * WNR + l31;
     const int aoff0 = ra0 * 128, aswz0 = (ra0 >> 1) & 7;
     const int boff0 = rb0 * 128 + A_BYTES, bswz0 = (rb0 >> 1) & 7;
+    // MX8: E8M0 scale bytes of this lane's fragment rows, one dword (4 blocks of 32 = one K-tile of 128) per row and K-tile,
+    // fetched one K-tile ahead; MFMA step kk spans blocks 2 kk (scale supplied by lanes 0-31) and 2 kk + 1 (lanes 32-63): byte 2 kk + lh
+    // of the dword -> pre-shifted by 8 lh, op_sel 2 kk
+    uint32_t sa_cur[MI], sb_cur[NI], sa_nxt[MI], sb_nxt[NI];
+    const uint8_t* sa_row[MI]; const uint8_t* sb_row[NI];
+    if constexpr (MX8) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) { int r = m0 + ra0 + 32 * i; if (r > p.M - 1) r = p.M - 1; sa_row[i] = (const uint8_t*)p.a_scale + (long)r * p.lds_a; }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) { int r = n0 + rb0 + 32 * i; if (r > p.N - 1) r = p.N - 1; sb_row[i] = (const uint8_t*)p.b_scale + (long)r * p.lds_b; }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) sa_nxt[i] = *reinterpret_cast<const uint32_t*>(sa_row[i]);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) sb_nxt[i] = *reinterpret_cast<const uint32_t*>(sb_row[i]);
+    }
     GM_STAGE(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
@@ -186,6 +207,45 @@ __global__ __launch_bounds__(64 * NWM * NWN, 2) void gemm_bf16_kernel(GemmParams
         __syncthreads();
         if (kt + 1 < nk) GM_STAGE(kt + 1, buf ^ 1);
         const char* st = smem + buf * STAGE;
+        if constexpr (MX8) {
+            if (kt < nk1) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) sa_cur[i] = sa_nxt[i] >> (8 * lh);
+#pragma unroll
+                for (int i = 0; i < NI; ++i) sb_cur[i] = sb_nxt[i] >> (8 * lh);
+                if (kt + 1 < nk1) {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) sa_nxt[i] = *reinterpret_cast<const uint32_t*>(sa_row[i] + 4 * (kt + 1));
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) sb_nxt[i] = *reinterpret_cast<const uint32_t*>(sb_row[i] + 4 * (kt + 1));
+                }
+#define GM_MX_STEP(kk_)                                                                                              \
+                {                                                                                                    \
+                    gm_i32x8 af8[MI], bf8[NI];                                                                       \
+                    /* operand layout of the instruction (tools/mx_probe.py): lane (row, h) holds k = 16h .. 16h+15 of scale   \
+                       block 0 in bytes 0-15 and k = 32 + 16h .. of scale block 1 in bytes 16-31; block 0's scale comes from   \
+                       lane row, block 1's from lane row + 32 */                                                     \
+                    const int c0_ = 4 * (kk_) + lh, c1_ = c0_ + 2;                                                   \
+                    _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                                 \
+                        const uint4 lo_ = *reinterpret_cast<const uint4*>(st + boff0 + i * 4096 + ((c0_ ^ bswz0) << 4));       \
+                        const uint4 hi_ = *reinterpret_cast<const uint4*>(st + boff0 + i * 4096 + ((c1_ ^ bswz0) << 4)); \
+                        bf8[i] = gm_i32x8{(int)lo_.x, (int)lo_.y, (int)lo_.z, (int)lo_.w, (int)hi_.x, (int)hi_.y, (int)hi_.z, (int)hi_.w}; \
+                    }                                                                                                \
+                    _Pragma("unroll") for (int i = 0; i < MI; ++i) {                                                 \
+                        const uint4 lo_ = *reinterpret_cast<const uint4*>(st + aoff0 + i * 4096 + ((c0_ ^ aswz0) << 4));       \
+                        const uint4 hi_ = *reinterpret_cast<const uint4*>(st + aoff0 + i * 4096 + ((c1_ ^ aswz0) << 4)); \
+                        af8[i] = gm_i32x8{(int)lo_.x, (int)lo_.y, (int)lo_.z, (int)lo_.w, (int)hi_.x, (int)hi_.y, (int)hi_.z, (int)hi_.w}; \
+                    }                                                                                                \
+                    _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                                \
+                        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                            \
+                            acc[ni][mi] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bf8[ni], af8[mi], acc[ni][mi], 0, 0, 2 * (kk_), \
+                                                                                          (int)sb_cur[ni], 2 * (kk_), (int)sa_cur[mi]);     \
+                }
+                GM_MX_STEP(0)
+                GM_MX_STEP(1)
+                continue;
+            }
+        }
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             bf16x8 af[MI], bfr[NI];
@@ -638,12 +698,12 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvParams p) {
     }
 }
 
-template <int BM, int BN, int NWM, int NWN, bool CONV = false>
+template <int BM, int BN, int NWM, int NWN, bool CONV = false, bool MX8 = false>
 static int launch_gemm(GemmParams p, hipStream_t stream, int group_env, int dbg_env) {
     constexpr int LDS = 2 * (BM + BN) * GM_BK * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<BM, BN, NWM, NWN, CONV>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<BM, BN, NWM, NWN, CONV, MX8>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
         attr_set = true;
     }
@@ -652,7 +712,7 @@ static int launch_gemm(GemmParams p, hipStream_t stream, int group_env, int dbg_
     int group_m = group_env > 0 ? group_env : GM_GROUP_M;
     if (group_m > ntm) group_m = ntm;
     p.ntn = ntn | (group_m << 16) | (dbg_env << 24);
-    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, NWM, NWN, CONV>), dim3(ntm * ntn), dim3(64 * NWM * NWN), LDS, stream, p);
+    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, NWM, NWN, CONV, MX8>), dim3(ntm * ntn), dim3(64 * NWM * NWN), LDS, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
@@ -712,6 +772,12 @@ static int launch_gemm8(GemmParams p, hipStream_t stream, int group_env, int dbg
 extern "C" int utx_launch_gemm_bf16(const GemmParams* hp, hipStream_t stream) {
     GemmParams p = *hp;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return -1;
+    if (p.mx8) {
+        // MX fp8 base segment: K counts fp8 elements (multiple of 128 = one K-tile), lda / ldb are bytes; scales [rows][K/32] bytes
+        if (!p.a_scale || !p.b_scale || (p.K % 128) || (p.lda & 15) || (p.ldb & 15) || (p.lds_a & 3) || (p.lds_b & 3) || p.conv_Wo > 0) return -2;
+        if (p.lds_a < p.K / 32 || p.lds_b < p.K / 32) return -2;
+        p.K /= 2; p.lda /= 2; p.ldb /= 2;          // bf16 units: the staging code is byte-identical
+    }
     if ((p.K % GM_BK) || (p.K2 % GM_BK) || (p.N % 8)) return -2;
     if ((p.lda & 7) || (p.ldb & 7) || (p.ldc & 7)) return -2;
     if (p.K2 > 0 && (!p.A2 || !p.B2 || (p.lda2 & 7) || (p.ldb2 & 7) || p.lora_seg_n <= 0 || (p.lora_seg_n % 128))) return -2;
@@ -724,6 +790,7 @@ extern "C" int utx_launch_gemm_bf16(const GemmParams* hp, hipStream_t stream) {
             return -2;
         return launch_gemm<128, 128, 2, 2, true>(p, stream, 0, 0);
     }
+    if (p.mx8) return launch_gemm<128, 128, 2, 2, false, true>(p, stream, group_env, 0);
     // 256^2 tiles need every column boundary on a 256 multiple and enough tiles to fill the chip
     const bool ok256 = (p.N % 256 == 0) && (p.n_split >= p.N || p.n_split % 256 == 0) &&
                        (p.gelu_from >= p.N || p.gelu_from % 256 == 0) &&

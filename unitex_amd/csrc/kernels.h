@@ -64,6 +64,7 @@ int utx_launch_attn_fwd_q64(const AttnParams* p, int presc, hipStream_t stream);
 int utx_launch_gemm_bf16(const GemmParams* p, hipStream_t stream);
 int utx_launch_gemm_pers(GemmParams p, hipStream_t stream);   // gemm_pers.hip: persistent 256x256 kernel (large-M linears)
 int utx_launch_gemv_bf16(const GemvParams* p, hipStream_t stream);
+int utx_launch_quant_mx8(const void* x, long ldx, void* q, long ldq, void* s, long lds, int M, int K, hipStream_t stream);
 int utx_launch_qkv_post(const QkvPostParams* p, hipStream_t stream);
 int utx_launch_sp_unpack_qkv(const void* recv, int P, int Hp, int S_loc, void* q, void* k, void* vt, hipStream_t stream);
 int utx_launch_sp_unpack_o(const void* recv, int P, int Hp, int S_loc, void* out, long ld, hipStream_t stream);

@@ -49,11 +49,15 @@ def attention(q, k, vt, S=None, scale=None, out=None, o_ss=None, key_bias_log2=0
 
 
 def make_gemm_desc(A, B, C_out, bias=None, A2=None, B2=None, lora_n_limit=None, lora_seg_n=None, alpha=1.0,
-                   gelu_from=None, gate=None, res=None, n_split=None, C1=None):
+                   gelu_from=None, gate=None, res=None, n_split=None, C1=None, a_scale=None, b_scale=None):
+    """a_scale / b_scale given: A and B are OCP MX fp8 operands (uint8 e4m3 bytes + E8M0 scales [rows, K/32], flux/mx8.py)."""
     M, K = A.shape
     N = B.shape[0]
     d = GemmDesc()
     d.A, d.lda, d.B, d.ldb = ptr(A), A.stride(0), ptr(B), B.stride(0)
+    if a_scale is not None:
+        assert A.dtype == torch.uint8 and B.dtype == torch.uint8 and b_scale is not None
+        d.a_scale, d.lds_a, d.b_scale, d.lds_b, d.mx8 = ptr(a_scale), a_scale.stride(0), ptr(b_scale), b_scale.stride(0), 1
     if A2 is not None:
         d.A2, d.lda2, d.B2, d.ldb2 = ptr(A2), A2.stride(0), ptr(B2), B2.stride(0)
         d.K2 = B2.shape[1]
@@ -82,7 +86,9 @@ def gemm(A, B, bias=None, out=None, **kw):
     n_split = kw.get("n_split")
     if out is None:
         out = torch.empty(M, N if n_split is None else n_split, dtype=torch.bfloat16, device=A.device)
-    d = make_gemm_desc(_bf(A), _bf(B), out, bias=bias, **kw)
+    if kw.get("a_scale") is None:
+        _bf(A), _bf(B)
+    d = make_gemm_desc(A, B, out, bias=bias, **kw)
     ctx.check(ctx.lib.utx_gemm_bf16(ctx.handle, C.byref(d), ctx.stream()))
     return out
 

@@ -74,8 +74,13 @@ def _bf16_scalar(x: float) -> float:
 
 
 class FluxDiT:
+    # the big linears that take OCP MX fp8 operands with fp8_weights=True (BASELINE configs[4]): image-side QKV and MLP of the double
+    # blocks, fused QKV|MLP projection and output projection of the single blocks -- 93 % of the linear FLOPs at S = 50 688
+    FP8_LINEARS_DOUBLE = ("qkv_x", "ff1_x", "ff2_x")
+    FP8_LINEARS_SINGLE = ("qkvm", "out")
+
     def __init__(self, state_dict: Dict[str, torch.Tensor], shape: Optional[FluxShape] = None, device="cuda:0",
-                 sequence_parallel=False, sp_group=None):
+                 sequence_parallel=False, sp_group=None, fp8_weights=False):
         """sequence_parallel: head-parallel ("Ulysses") sharding of ONE job over the ranks of `sp_group` (ulysses.py):
         set_positions / set_conditioning still take the FULL id / embedding tensors, forward() takes and returns this
         rank's slice of the image tokens (local_image_range)."""
@@ -102,6 +107,7 @@ class FluxDiT:
         # (flux_piplines/texturing/pipeline.py:538-543) -- 512 IDENTICAL tokens at every layer.  When set_conditioning sees
         # identical rows (and identical ids) it carries TEXT_KEEP of them and tells the attention kernel that each stands for
         # S_txt / TEXT_KEEP keys (utx_attn_fwd_bf16_kb): the same softmax, up to fp32 summation order.  UTX_TEXT_DEDUP=0 disables.
+        self.fp8_weights = bool(fp8_weights)
         self.text_dedup = os.environ.get("UTX_TEXT_DEDUP", "1") != "0"
         self.key_bias_log2, self.key_bias_period, self.text_rows = 0.0, 0, None
         self._ids = None
@@ -171,6 +177,14 @@ class FluxDiT:
         W["mod.b"] = torch.cat(mod_b, dim=0).contiguous()
         self.n_mod = off
         self.W = W
+        if self.fp8_weights:
+            # weights of the big linears once more as MX fp8 (e4m3 + E8M0 per 32 along K), quantised here at load
+            from .mx8 import quantize_weight
+            for blocks, names in ((self.double, self.FP8_LINEARS_DOUBLE), (self.single, self.FP8_LINEARS_SINGLE)):
+                for b in blocks:
+                    for nm in names:
+                        if b[nm + ".w"].shape[1] % 128 == 0:
+                            b[nm + ".q"], b[nm + ".s"] = quantize_weight(b[nm + ".w"], self.ctx)
 
     def num_params(self):
         n = sum(v.numel() for v in self.W.values())
@@ -293,17 +307,27 @@ class FluxDiT:
         self.lora_rank = max(rs) if rs else 0
 
     # ------------------------------------------------------------------ plan
-    def _gemm(self, plan, A, B, Cout, bias=None, lora=None, lora_n_limit=None, lora_seg_n=None, T=None, **kw):
-        """append (optional LoRA-down GEMM +) the main GEMM to the plan."""
+    def _gemm(self, plan, A, B, Cout, bias=None, lora=None, lora_n_limit=None, lora_seg_n=None, T=None, mx8=None, **kw):
+        """append (optional LoRA-down GEMM +) the main GEMM to the plan.  mx8 = (Wq, Ws, aq, as_): the base product runs on OCP MX fp8
+        operands -- the activation is quantised by utx_quant_mx8 into (aq, as_) first; the LoRA branch keeps its bf16 operands."""
+        if mx8 is not None:
+            Wq, Ws, aq, as_ = mx8
+            M, K = A.shape
+            aqv, asv = aq[:M, :K], as_[:M, : K // 32]
+            plan.append(("quant_mx8", (A, aqv, asv)))
+            kw = dict(kw, a_scale=asv, b_scale=Ws)
+            A_main, B_main = aqv, Wq
+        else:
+            A_main, B_main = A, B
         if lora is not None:
             A_cat, B_cat, alpha, Rp = lora
             Tv = T[: A.shape[0], : A_cat.shape[0]]
             d0 = ops.make_gemm_desc(A, A_cat, Tv, alpha=alpha)
             plan.append((self.lib.utx_gemm_bf16, d0))
-            d = ops.make_gemm_desc(A, B, Cout, bias=bias, A2=Tv, B2=B_cat, lora_n_limit=lora_n_limit,
+            d = ops.make_gemm_desc(A_main, B_main, Cout, bias=bias, A2=Tv, B2=B_cat, lora_n_limit=lora_n_limit,
                                    lora_seg_n=lora_seg_n, **kw)
         else:
-            d = ops.make_gemm_desc(A, B, Cout, bias=bias, **kw)
+            d = ops.make_gemm_desc(A_main, B_main, Cout, bias=bias, **kw)
         plan.append((self.lib.utx_gemm_bf16, d))
 
     def _par(self, plan, main_ops, side_ops):
@@ -375,6 +399,10 @@ class FluxDiT:
         }
         if self.sp is None:
             ws.update({"Qh": z(H, S_pad, 128), "Kh": z(H, S_pad, 128), "Vt": z(H, 128, S_pad)})
+        if self.fp8_weights:
+            Kmax = (1 + sh.mlp_ratio) * D
+            ws["aq"] = z(S, Kmax, dtype=torch.uint8)
+            ws["as"] = z(S, Kmax // 32, dtype=torch.uint8)
         if Rp:
             ws["T"] = z(S, 3 * Rp)
             ws["Tc"] = z(S_txt, 3 * Rp)     # LoRA-down temp of the text half (it runs concurrently with the image half)
@@ -385,6 +413,12 @@ class FluxDiT:
             self.ex = UlyssesExchange(H, S, group=self.sp[2], device=dev, dtype=BF16, ctx=self.ctx)
         T = ws.get("T")
         Tc = ws.get("Tc") if self.overlap_text else T
+
+        def mx(b, nm, row0=0):
+            """MX fp8 operands of linear `nm` of block b (None = bf16 path); the activation scratch rows start at row0."""
+            if not self.fp8_weights or (nm + ".q") not in b:
+                return None
+            return (b[nm + ".q"], b[nm + ".s"], ws["aq"][row0:], ws["as"][row0:])
         W, mod = self.W, ws["mod"][0]
         h, xn, qkv, cat, attn = ws["h"], ws["xn"], ws["qkv"], ws["cat"], ws["attn"]
         h_c, h_x = h[:S_txt], h[S_txt:]
@@ -419,7 +453,7 @@ class FluxDiT:
             self._lnmod(px, h_x, xn_x, sh_a, sc_a)
             self._lnmod(pc, h_c, xn_c, csh_a, csc_a)
             self._gemm(px, xn_x, b["qkv_x.w"], qkv[S_txt:], bias=b["qkv_x.b"], lora=b.get("lora.qkv_x"),
-                       lora_n_limit=3 * D, lora_seg_n=D, T=T)
+                       lora_n_limit=3 * D, lora_seg_n=D, T=T, mx8=mx(b, "qkv_x", S_txt))
             self._gemm(pc, xn_c, b["qkv_c.w"], qkv[:S_txt], bias=b["qkv_c.b"], lora=b.get("lora.qkv_c"),
                        lora_n_limit=3 * D, lora_seg_n=D, T=Tc)
             self._qkvpost(px, qkv[S_txt:], b["nq"], b["nk"], ws, S_img, S_txt)
@@ -434,9 +468,10 @@ class FluxDiT:
             self._gemm(pc, attn[:S_txt], b["out_c.w"], h_c, bias=b["out_c.b"], lora=b.get("lora.out_c"), T=Tc,
                        gate=cg_a, res=h_c)
             self._lnmod(px, h_x, xn_x, sh_m, sc_m)
-            self._gemm(px, xn_x, b["ff1_x.w"], ff[S_txt:], bias=b["ff1_x.b"], lora=b.get("lora.ff1_x"), T=T, gelu_from=0)
+            self._gemm(px, xn_x, b["ff1_x.w"], ff[S_txt:], bias=b["ff1_x.b"], lora=b.get("lora.ff1_x"), T=T, gelu_from=0,
+                       mx8=mx(b, "ff1_x", S_txt))
             self._gemm(px, ff[S_txt:], b["ff2_x.w"], h_x, bias=b["ff2_x.b"], lora=b.get("lora.ff2_x"), T=T,
-                       gate=g_m, res=h_x)
+                       gate=g_m, res=h_x, mx8=mx(b, "ff2_x", S_txt))
             self._lnmod(pc, h_c, xn_c, csh_m, csc_m)
             self._gemm(pc, xn_c, b["ff1_c.w"], ff[:S_txt], bias=b["ff1_c.b"], lora=b.get("lora.ff1_c"), T=Tc, gelu_from=0)
             self._gemm(pc, ff[:S_txt], b["ff2_c.w"], h_c, bias=b["ff2_c.b"], lora=b.get("lora.ff2_c"), T=Tc,
@@ -448,7 +483,7 @@ class FluxDiT:
             if self.sp is None:
                 # one GEMM for [q|k|v|proj_mlp]: qkv -> qkv buffer, GELU(mlp) -> cat[:, D:]
                 self._gemm(plan, xn, b["qkvm.w"], qkv, bias=b["qkvm.b"], lora=b.get("lora.qkvm"), lora_n_limit=3 * D,
-                           lora_seg_n=D, T=T, gelu_from=3 * D, n_split=3 * D, C1=cat[:, D:])
+                           lora_seg_n=D, T=T, gelu_from=3 * D, n_split=3 * D, C1=cat[:, D:], mx8=mx(b, "qkvm"))
                 self._qkvpost(plan, qkv, b["nq"], b["nk"], ws, S, 0)
             else:
                 # sequence parallel: the same GEMM cut at column 3D (identical arithmetic per column) so that the Q/K/V exchange
@@ -459,7 +494,7 @@ class FluxDiT:
                 plan.append(("sp_start", None))
                 self._gemm(plan, xn, b["qkvm.w"][3 * D:], cat[:, D:], bias=b["qkvm.b"][3 * D:], gelu_from=0)
             self._attn(plan, ws, cat, S)  # attention output lands in cat[:, :D] (row stride 5D)
-            self._gemm(plan, cat, b["out.w"], h, bias=b["out.b"], gate=g_, res=h)
+            self._gemm(plan, cat, b["out.w"], h, bias=b["out.b"], gate=g_, res=h, mx8=mx(b, "out"))
         o = self.mod_off[("out",)]
         scale, shift = mod[o: o + D], mod[o + D: o + 2 * D]  # AdaLayerNormContinuous: (scale, shift) [3p]
         self._lnmod(plan, h_x, xn_x, shift, scale)
@@ -520,6 +555,17 @@ class FluxDiT:
         g1000 = _bf16_scalar(_bf16_scalar(guidance) * 1000.0)  # guidance.to(dtype) * 1000 in bf16 [3p]
         ws["gproj"].copy_(_timestep_proj(g1000))
 
+    def _launch(self, fn, d, st):
+        """one stream-ordered launch of a plan entry that is a C-ABI call: (entry point, descriptor) or the MX fp8 quantiser"""
+        if fn == "quant_mx8":
+            x_, q_, s_ = d
+            rc = self.lib.utx_quant_mx8(self.ctx.handle, ptr(x_), x_.stride(0), ptr(q_), q_.stride(0), ptr(s_), s_.stride(0),
+                                        x_.shape[0], x_.shape[1], st)
+        else:
+            rc = fn(self.ctx.handle, C.byref(d), st)
+        if rc:
+            self.ctx.check(rc)
+
     def run_plan(self, p):
         h, st = self.ctx.handle, self.ctx.stream()
         lib, ws = self.lib, p["ws"]
@@ -531,15 +577,13 @@ class FluxDiT:
                 self._side.wait_event(ev_fork)
                 st2 = C.c_void_p(self._side.cuda_stream)
                 for f2, d2 in side_ops:
-                    rc = f2(h, C.byref(d2), st2)
-                    if rc:
-                        self.ctx.check(rc)
+                    self._launch(f2, d2, st2)
                 for f2, d2 in main_ops:
-                    rc = f2(h, C.byref(d2), st)
-                    if rc:
-                        self.ctx.check(rc)
+                    self._launch(f2, d2, st)
                 ev_join.record(self._side)
                 main.wait_event(ev_join)
+            elif fn == "quant_mx8":
+                self._launch(fn, d, st)
             elif fn == "temb_sum":
                 # conditioning = (timesteps_emb + guidance_emb) + pooled_projections, bf16 adds [3p]
                 t = ws["e_t"]
