@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-python tools/perf_fp8.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r02_perf_fp8_v0.log
+timeout 900 python -m pytest tests/test_geometry_gpu.py -x -q -k "chart_unwrap" 2>&1 | tail -15

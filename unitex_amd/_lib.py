@@ -117,6 +117,7 @@ SYMBOLS = {
     "utx_lens_blur_seam": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, C.POINTER(c_float), c_void_p, c_void_p]),
     "utx_pull_push_workspace_bytes": (c_long, [c_int, c_int]),
     "utx_pull_push": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "utx_chart_flood": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "utx_to_u8": (c_int, [c_void_p, c_void_p, c_long, c_long, c_int, c_void_p, c_void_p]),
 }
 

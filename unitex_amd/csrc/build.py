@@ -32,6 +32,7 @@ GEOM = [
     ("backproject.hip", ["-ffp-contract=off"]),
     ("texture_post.hip", ["-ffp-contract=off"]),
     ("knn.hip", ["-ffp-contract=off"]),
+    ("unwrap.hip", []),
 ]
 for s in GEOM:
     if os.path.exists(os.path.join(HERE, s[0])):

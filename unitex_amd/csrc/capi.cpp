@@ -268,6 +268,12 @@ int utx_pull_push(utx_ctx* ctx, const float* kd, const void* mask, int H, int W,
     if (!kd || !mask || !out || !work) return fail(ctx, -2, "utx_pull_push");
     UTX_CALL(ctx, "utx_pull_push", utx_launch_pull_push(kd, mask, H, W, out, work, (hipStream_t)stream));
 }
+int utx_chart_flood(utx_ctx* ctx, const int* adj, const int* bucket, int F, int* chart, int* flag, utx_stream stream) {
+    if (!adj || !bucket || !chart || !flag) return fail(ctx, -2, "utx_chart_flood");
+    const int rc = utx_launch_chart_flood(adj, bucket, F, chart, flag, (hipStream_t)stream);
+    if (rc < 0) return fail(ctx, rc, "utx_chart_flood");
+    return rc;
+}
 int utx_to_u8(utx_ctx* ctx, const float* src, long n_rows, long row_elems, int flip, void* dst, utx_stream stream) {
     if (!src || !dst) return fail(ctx, -2, "utx_to_u8");
     UTX_CALL(ctx, "utx_to_u8", utx_launch_to_u8(src, n_rows, row_elems, flip, dst, (hipStream_t)stream));

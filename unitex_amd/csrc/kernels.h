@@ -97,5 +97,6 @@ int utx_launch_nn_fill(const float* pos, const void* winner, const float* rast2d
 int utx_launch_lens_blur_seam(const float* src, const void* seam, int Hh, int Ww, const float* k49_host, float* dst, hipStream_t stream);
 size_t utx_pull_push_workspace_bytes_impl(int Hh, int Ww);
 int utx_launch_pull_push(const float* kd, const void* mask, int Hh, int Ww, float* out, void* work, hipStream_t stream);
+int utx_launch_chart_flood(const int* adj, const int* bucket, int F, int* chart, int* flag, hipStream_t stream);
 int utx_launch_to_u8(const float* src, long n_rows, long row_elems, int flip, void* dst, hipStream_t stream);
 }

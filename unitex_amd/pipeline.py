@@ -107,8 +107,11 @@ class RGBTextureFullPipelineBase:
         host-side equivalents of texturetools/meshes.py: .obj / .glb in, rescaled to bbox*scale; a mesh with UVs passes
         through, one without is cleaned, brought into [min_faces, max_faces] and unwrapped (builder-defined atlas)."""
         from .texturetools import meshes
+        # UV-less meshes get the chart unwrap: a handful of large charts at one texel density, as with the reference's UVAtlas charts
+        # (the per-triangle grid of round 1 spent most of the atlas on gutters and flat-shaded nothing but lost resolution)
         verts, faces, uvs, faces_uv = meshes.prepare_blank_mesh(input_mesh_path, min_faces=min_faces, max_faces=max_faces, scale=scale,
-                                                                atlas=self.atlas_size, gutter=4.0)
+                                                                atlas=self.atlas_size, gutter=4.0, unwrap="charts",
+                                                                device=str(self.inverse_renderer.device))
         # shared positions + per-corner UVs: the condition render smooths normals over position indices (export_condition reads
         # them through load_obj), the inverse renderer splits per (v, vt) pair (load_mesh)
         meshes.save_obj(os.path.join(save_dir, "processed_mesh.obj"), verts, faces, uvs, faces_uv=faces_uv)

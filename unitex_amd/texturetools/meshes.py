@@ -367,12 +367,130 @@ def unwrap_grid(verts, faces, atlas=2048, gutter=4.0):
     return verts.astype(np.float32), faces.astype(np.int32), tri_uv.reshape(-1, 2).astype(np.float32), f_uv
 
 
+# ---- chart-based unwrap (the reference: open3d compute_uvatlas(size=2048, gutter=4), uv_atlas.py:171-175 [3p]) ----
+# axis of projection bucket b and the in-plane basis (u, v) with u x v = axis, so that front-facing triangles keep positive area
+_BUCKET_AXES = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], np.float64)
+_BUCKET_UV = [(1, 2), (2, 1), (2, 0), (0, 2), (0, 1), (1, 0)]
+
+
+def face_adjacency(faces):
+    """adj [F,3] int32: the face across edge e = (v_e, v_{e+1}) of each face, -1 on a border; a non-manifold edge links its first
+    two faces only."""
+    F = len(faces)
+    e = np.stack([faces[:, [0, 1]], faces[:, [1, 2]], faces[:, [2, 0]]], 1).reshape(-1, 2).astype(np.int64)      # [3F,2], edge id = 3f + e
+    key = np.minimum(e[:, 0], e[:, 1]) * (int(faces.max()) + 1) + np.maximum(e[:, 0], e[:, 1])
+    order = np.argsort(key, kind="stable")
+    ks = key[order]
+    adj = -np.ones(3 * F, dtype=np.int32)
+    same = ks[1:] == ks[:-1]
+    first = np.ones(len(ks), bool); first[1:] = ~same                      # first edge of every run of equal keys
+    second = np.zeros(len(ks), bool); second[1:] = same & first[:-1]      # its immediate successor
+    i2 = np.nonzero(second)[0]
+    a, b = order[i2 - 1], order[i2]
+    adj[a] = (b // 3).astype(np.int32); adj[b] = (a // 3).astype(np.int32)
+    return adj.reshape(F, 3)
+
+
+def chart_buckets(verts, faces, adj, smooth_iters=2, cos_accept=0.45):
+    """projection bucket per face: the axis direction closest to the face normal, then a few majority-vote sweeps that move a face
+    into the bucket of >= 2 of its neighbours when its normal still faces that axis by more than acos(cos_accept) -- removes the
+    one-face islands along bucket borders (fewer, larger charts = less seam)."""
+    v = verts.astype(np.float64)
+    n = np.cross(v[faces[:, 1]] - v[faces[:, 0]], v[faces[:, 2]] - v[faces[:, 0]])
+    n /= np.maximum(np.linalg.norm(n, axis=1, keepdims=True), 1e-30)
+    dots = n @ _BUCKET_AXES.T                                    # [F,6]
+    bucket = np.argmax(dots, axis=1).astype(np.int32)
+    for _ in range(smooth_iters):
+        nb = np.where(adj >= 0, bucket[np.maximum(adj, 0)], -1)            # [F,3]
+        for b in range(6):
+            votes = (nb == b).sum(1)
+            move = (votes >= 2) & (bucket != b) & (dots[:, b] > cos_accept)
+            bucket = np.where(move, b, bucket).astype(np.int32)
+    return bucket
+
+
+def _shelf_pack(sizes, T):
+    """sizes [C,2] (w, h) in texels, sorted by the caller; returns offsets [C,2] or None when they do not fit a T x T atlas."""
+    x = y = shelf = 0.0
+    out = np.zeros_like(sizes)
+    for i, (w, h) in enumerate(sizes):
+        if w > T or h > T:
+            return None
+        if x + w > T:
+            x, y, shelf = 0.0, y + shelf, 0.0
+        if y + h > T:
+            return None
+        out[i] = (x, y)
+        x += w
+        shelf = max(shelf, h)
+    return out
+
+
+def unwrap_charts(verts, faces, atlas=2048, gutter=4.0, device="cuda:0", max_rounds=4):
+    """Chart unwrap: faces are bucketed by the axis their normal faces, charts are the connected same-bucket components (labelled on
+    the GPU: utx_chart_flood), every chart is projected orthographically along its axis (isometric up to the cosine of the facing
+    angle, <= 1/cos(63 deg) stretch) and the charts are shelf-packed at ONE texel density with `gutter` texels between them.  A
+    chart that folds over itself in projection is detected by rasterising the atlas with the product's own rasteriser and counting
+    texels per face; faces that lose their texels to another face of the same chart are split off into further charts (a few
+    rounds), so the result is bijective.  Returns verts [V,3] (shared positions), faces [F,3], uvs [3F,2] in [0,1], faces_uv [F,3]."""
+    import torch
+    from . import ops
+    F = len(faces)
+    faces = np.asarray(faces, np.int32)
+    adj = face_adjacency(faces)
+    bucket = chart_buckets(verts, faces, adj)
+    v64 = verts.astype(np.float64)
+    layer = np.zeros(F, np.int32)                     # fold-over layer: faces split off a chart get the next layer
+    dev = torch.device(device)
+    adj_d = torch.from_numpy(adj).to(dev)
+    for rnd in range(max_rounds):
+        key = (bucket + 6 * layer).astype(np.int32)
+        chart = ops.chart_flood(adj_d, torch.from_numpy(key).to(dev)).cpu().numpy()
+        ids, cidx = np.unique(chart, return_inverse=True)
+        C = len(ids)
+        # per-face 2-D coordinates in its chart's plane
+        ua = np.array([_BUCKET_UV[b][0] for b in bucket]); va = np.array([_BUCKET_UV[b][1] for b in bucket])
+        P = v64[faces]                                                  # [F,3,3]
+        fi = np.arange(F)[:, None]
+        uv3 = np.stack([P[fi, np.arange(3)[None, :], ua[:, None]], P[fi, np.arange(3)[None, :], va[:, None]]], -1)       # [F,3,2]
+        lo = np.full((C, 2), np.inf); hi = np.full((C, 2), -np.inf)
+        for k in range(3):
+            np.minimum.at(lo, cidx, uv3[:, k]); np.maximum.at(hi, cidx, uv3[:, k])
+        ext = hi - lo                                                   # chart extents in world units
+        order = np.argsort(-ext[:, 1], kind="stable")
+        # largest texel density at which the shelf packing fits
+        d_lo, d_hi, best = 0.0, atlas / max(float(ext.max()), 1e-9), None
+        for _ in range(40):
+            d = 0.5 * (d_lo + d_hi)
+            offs = _shelf_pack(ext[order] * d + gutter, atlas)
+            if offs is None:
+                d_hi = d
+            else:
+                d_lo, best = d, offs
+        if best is None:
+            raise ValueError("atlas %d cannot hold %d charts with a %g-texel gutter" % (atlas, C, gutter))
+        off = np.zeros((C, 2)); off[order] = best
+        uv = (off[cidx][:, None, :] + 0.5 * gutter + (uv3 - lo[cidx][:, None, :]) * d_lo) / float(atlas)                 # [F,3,2]
+        uvs = uv.reshape(-1, 2).astype(np.float32)
+        f_uv = np.arange(3 * F, dtype=np.int32).reshape(F, 3)
+        # bijectivity check on the GPU: texels owned per face vs the face's UV area
+        uvclip = np.concatenate([uvs * 2 - 1, np.zeros((3 * F, 1), np.float32), np.ones((3 * F, 1), np.float32)], -1)
+        rast = ops.rasterize(torch.from_numpy(uvclip).to(dev), torch.from_numpy(f_uv).to(dev), atlas, atlas)
+        owned = torch.bincount((rast[..., 3].long()).reshape(-1), minlength=F + 1)[1:].cpu().numpy()
+        a2 = np.abs((uv[:, 1, 0] - uv[:, 0, 0]) * (uv[:, 2, 1] - uv[:, 0, 1]) - (uv[:, 2, 0] - uv[:, 0, 0]) * (uv[:, 1, 1] - uv[:, 0, 1])) * 0.5 * atlas * atlas
+        lost = (a2 >= 3.0) & (owned < 0.5 * a2)
+        if not lost.any() or rnd == max_rounds - 1:
+            break
+        layer = np.where(lost, layer + 1, layer).astype(np.int32)
+    return verts.astype(np.float32), faces, uvs, f_uv
+
+
 def normalise_to_bbox(verts, scale):
     lo, hi = verts.min(0), verts.max(0)
     return ((verts - 0.5 * (lo + hi)) / ((hi - lo).max() / (2.0 * scale))).astype(np.float32)
 
 
-def prepare_blank_mesh(path, min_faces=20_000, max_faces=200_000, scale=1.0, atlas=2048, gutter=4.0, unwrap="grid"):
+def prepare_blank_mesh(path, min_faces=20_000, max_faces=200_000, scale=1.0, atlas=2048, gutter=4.0, unwrap="grid", device="cuda:0"):
     """preprocess_blank_mesh_o3d (uv_atlas.py:131-175) with the host-side equivalents above: rescale to the bbox;
     a mesh that already has UVs passes through; otherwise clean, bring the face count into [min_faces, max_faces],
     and unwrap.  Returns verts [V,3], faces [F,3], uvs [Vt,2], faces_uv [F,3]: positions stay shared, UVs are per corner
@@ -393,4 +511,6 @@ def prepare_blank_mesh(path, min_faces=20_000, max_faces=200_000, scale=1.0, atl
         verts, faces = subdivide_midpoint(verts, faces)
     if unwrap == "grid":
         return unwrap_grid(verts, faces, atlas=atlas, gutter=gutter)
+    if unwrap == "charts":
+        return unwrap_charts(verts, faces, atlas=atlas, gutter=gutter, device=device)
     raise ValueError("unknown unwrap method %r" % (unwrap,))

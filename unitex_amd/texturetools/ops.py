@@ -43,6 +43,19 @@ def rasterize(pos_clip, tri, H, W):
     return rast
 
 
+def chart_flood(adj, bucket):
+    """adj [F,3] int32 (face across each edge, -1 = border), bucket [F] int32 -> chart [F] int32: smallest face index of the
+    connected same-bucket component (utx_chart_flood; synchronises the stream)."""
+    ctx = get_ctx(adj.device.index)
+    F = adj.shape[0]
+    chart = torch.empty(F, dtype=torch.int32, device=adj.device)
+    flag = torch.zeros(1, dtype=torch.int32, device=adj.device)
+    rc = ctx.lib.utx_chart_flood(ctx.handle, ptr(_i(adj)), ptr(_i(bucket)), F, ptr(chart), ptr(flag), ctx.stream())
+    if rc < 0:
+        ctx.check(rc)
+    return chart
+
+
 def interpolate(attr, rast, tri):
     ctx = get_ctx(attr.device.index)
     H, W = rast.shape[:2]
