@@ -170,6 +170,16 @@ def test_gemm_persistent_kernel_edge_shapes_bit_identical_to_tiled_kernels(M, N,
     # repeated launches: the stream has no state that survives a launch
     again = gated()
     assert _same_bits(again, o["2560"])
+    # the alternative DMA placement of the persistent kernel (UTX_GEMM_PERS_SCHED) computes the same bits
+    from unitex_amd import _lib
+    try:
+        _set_tile("2560")
+        for forced in (1, 2):       # both DMA placements of the persistent kernel, whatever the shape heuristic picked above
+            _lib.set_option("UTX_GEMM_PERS_SCHED", forced)
+            assert _same_bits(gated(), o["2560"])
+    finally:
+        _lib.set_option("UTX_GEMM_PERS_SCHED", 0)
+        _set_tile(None)
 
 
 def test_full_width_dit_blocks_at_config1_shape_match_oracle():

@@ -24,10 +24,11 @@ for M, N, K, kind in shapes:
         kw.update(gate=torch.randn(N, device=dev).to(torch.bfloat16), res=C)
     if kind == "gelu":
         kw.update(gelu_from=0)
-    def run(tile):
+    def run(tile, sched=0):
         _lib.set_option("UTX_GEMM_TILE", tile)
+        _lib.set_option("UTX_GEMM_PERS_SCHED", sched)
         ops.gemm(A, B, out=C, **kw)
-    fns = {"pers": lambda: run(2560), "8ph": lambda: run(256), "lib": lambda: torch.nn.functional.linear(A, B, bias)}
+    fns = {"pers": lambda: run(2560, 1), "pers1": lambda: run(2560, 2), "8ph": lambda: run(256), "lib": lambda: torch.nn.functional.linear(A, B, bias)}
     ts = {k: [] for k in fns}
     for k, f in fns.items():
         f(); f()
@@ -36,7 +37,7 @@ for M, N, K, kind in shapes:
             ts[k].append(t1(f))
     fl = 2.0 * M * N * K
     med = {k: sorted(v)[len(v) // 2] for k, v in ts.items()}
-    print("M=%6d N=%6d K=%6d %-4s | pers %7.3f ms %6.0f TF | 8ph %7.3f ms %6.0f TF | lib %7.3f ms %6.0f TF | pers/8ph %.3f  pers/lib %.3f" % (
-        M, N, K, kind, med["pers"], fl / med["pers"] / 1e9, med["8ph"], fl / med["8ph"] / 1e9, med["lib"], fl / med["lib"] / 1e9,
-        med["8ph"] / med["pers"], med["lib"] / med["pers"]), flush=True)
-    _lib.set_option("UTX_GEMM_TILE", 0)
+    print("M=%6d N=%6d K=%6d %-4s | pers %7.3f ms %6.0f TF | pers(sched1) %7.3f ms %6.0f TF | 8ph %7.3f ms %6.0f TF | lib %7.3f ms %6.0f TF | pers/8ph %.3f  sched1/8ph %.3f  sched1/lib %.3f" % (
+        M, N, K, kind, med["pers"], fl / med["pers"] / 1e9, med["pers1"], fl / med["pers1"] / 1e9, med["8ph"], fl / med["8ph"] / 1e9, med["lib"], fl / med["lib"] / 1e9,
+        med["8ph"] / med["pers"], med["8ph"] / med["pers1"], med["lib"] / med["pers1"]), flush=True)
+    _lib.set_option("UTX_GEMM_TILE", 0); _lib.set_option("UTX_GEMM_PERS_SCHED", 0)

@@ -152,7 +152,7 @@ def load_library():
 
 
 OPTION_NAMES = ["UTX_ATTN_GLDS", "UTX_ATTN_FAST", "UTX_ATTN_Q64", "UTX_ATTN_TPB", "UTX_ATTN_TAILSPLIT",
-                "UTX_GEMM_GROUP_M", "UTX_GEMM_TILE", "UTX_GEMM_TAILSPLIT", "UTX_GEMM_PERS_GRID"]
+                "UTX_GEMM_GROUP_M", "UTX_GEMM_TILE", "UTX_GEMM_TAILSPLIT", "UTX_GEMM_PERS_GRID", "UTX_GEMM_PERS_SCHED"]
 
 
 def set_option(name, value):

@@ -801,10 +801,8 @@ extern "C" int utx_launch_gemm_bf16(const GemmParams* hp, hipStream_t stream) {
     if ((tile_env == 256 || tile_env == 2562 || tile_env == 2560) && ok256) use256 = true;   // 2562 = the 2-barrier 256^2 kernel, 2560 = force the persistent kernel (A/B testing)
     // default for the large-M linears: the persistent continuous-stream kernel (gemm_pers.hip); UTX_GEMM_TILE=256 keeps the
     // per-tile-launch 8-phase kernel for A/B (bit-identical outputs), and the timing ablations / tail split only exist there
-    // (same-process interleaved A/B, profiles/r02_gemm_ab_v3.log: +3..9 % on every K = 3072 shape; the gated long-K shapes
-    // -- K = 12288 / 15360, where the epilogue is < 2 % of a tile -- measure 1.5-4 % behind, so they stay on the per-tile kernel)
-    const bool pers_wins = !(p.gate && p.K + p.K2 > 6144);
-    if (use256 && (tile_env == 0 ? pers_wins : tile_env == 2560) && (dbg_env & 3) == 0 && g_utx_opt.gemm_tailsplit == 0)
+    // (same-process interleaved A/B against the per-tile 8-phase kernel and hipBLASLt: profiles/r02_gemm_ab_v3.log / _v4.log)
+    if (use256 && (tile_env == 0 || tile_env == 2560) && (dbg_env & 3) == 0 && g_utx_opt.gemm_tailsplit == 0)
         return utx_launch_gemm_pers(p, stream);
     if (use256 && tile_env != 2562) return launch_gemm8(p, stream, group_env, dbg_env);
     if (use256) return launch_gemm<256, 256, 2, 4>(p, stream, group_env, dbg_env);

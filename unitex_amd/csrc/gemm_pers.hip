@@ -68,7 +68,11 @@ __device__ __forceinline__ void gp_wait_res(gp_u32x4& a) {
 
 // GATED: the gated-residual epilogue (out = res + gate * y; no GELU, no column split in that mode) -- two instantiations keep each
 // epilogue's register footprint inside the 256-register budget of a 512-thread workgroup.
-template <bool GATED>
+// SCHED: where the eight DMAs of a K-tile are issued.  0 = two per phase (the schedule of gemm256_8ph_kernel); 1 = none in q0 (whose
+// twelve fragment reads make it the longest load phase), three in q1, one in q2, four in q3: a K-tile lasts 2 * sum_p max(load_p, 256
+// MFMA cycles), so the load phases should be EQUAL, not the DMA counts (profiles/r02_gemm_ab_v4.log).
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+template <bool GATED, int SCHED, bool M16 = false>
 __global__ __launch_bounds__(512, 2) void gemm256_pers_kernel(GemmParams p, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -155,6 +159,20 @@ __global__ __launch_bounds__(512, 2) void gemm256_pers_kernel(GemmParams p, int 
             gp_glds16(p0_ + 64 * (unsigned long)rs_ + vo_, l_ + 8192);                                      \
         }                                                                                                   \
     } while (0)
+    // one of the two DMAs (d_ = 0: rows 0-63 of the half-tile's slice, 1: rows 64-127) -- for schedules that spread them over phases
+#define GP_STAGE1(isb_, h_, d_, par_)                                                                       \
+    do {                                                                                                    \
+        const char* p0_ = (isb_) ? ((h_) ? s_pB1 : s_pB0) : ((h_) ? s_pA1 : s_pA0);                         \
+        const unsigned rs_ = (isb_) ? s_rB : s_rA;                                                          \
+        const unsigned vo_ = (isb_) ? voB : voA;                                                            \
+        const unsigned l_ = ldst + (2 * (isb_) + (h_)) * 32768 + (par_) * 16384 + 8192 * (d_);              \
+        if (!(isb_) && s_ragged) {                                                                          \
+            const int r_ = s_m0 + 8 * wave + 128 * (h_) + 64 * (d_) + srow_in;                              \
+            gp_glds16(p0_ + (d_) * 64 * (long)rs_ + vo_ - (long)((r_ > p.M - 1) ? r_ - (p.M - 1) : 0) * rs_, l_); \
+        } else {                                                                                            \
+            gp_glds16(p0_ + (d_) * 64 * (unsigned long)rs_ + vo_, l_);                                      \
+        }                                                                                                   \
+    } while (0)
 #define GP_STAGE_ADVANCE()                                                                 \
     do {                                                                                   \
         s_pA0 += GP_BK * 2; s_pA1 += GP_BK * 2; s_pB0 += GP_BK * 2; s_pB1 += GP_BK * 2;    \
@@ -203,17 +221,27 @@ __global__ __launch_bounds__(512, 2) void gemm256_pers_kernel(GemmParams p, int 
     a02 = GP_LD(fa2, (i_) * 32768 + (par_) * 16384);        a03 = GP_LD(fa3, (i_) * 32768 + (par_) * 16384);        \
     a10 = GP_LD(fa0, (i_) * 32768 + (par_) * 16384 + 4096); a11 = GP_LD(fa1, (i_) * 32768 + (par_) * 16384 + 4096); \
     a12 = GP_LD(fa2, (i_) * 32768 + (par_) * 16384 + 4096); a13 = GP_LD(fa3, (i_) * 32768 + (par_) * 16384 + 4096);
+    // M16 -- timing experiment (ablation build only, wrong results): every 32x32x16 MFMA replaced by two 16x16x32 MFMAs on the same
+    // operand registers: same FLOPs, same register / LDS traffic, the instruction shape hipBLASLt uses (tools/mfma_power_probe.py)
+#define GP_MM(acc_, b_, a_)                                                                                     \
+    if constexpr (M16) {                                                                                        \
+        f32x4_t lo_ = {acc_[0], acc_[1], acc_[2], acc_[3]}, hi_ = {acc_[4], acc_[5], acc_[6], acc_[7]};           \
+        lo_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_, a_, lo_, 0, 0, 0);                                    \
+        hi_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_, b_, hi_, 0, 0, 0);                                    \
+        acc_[0] = lo_[0]; acc_[1] = lo_[1]; acc_[2] = lo_[2]; acc_[3] = lo_[3];                                 \
+        acc_[4] = hi_[0]; acc_[5] = hi_[1]; acc_[6] = hi_[2]; acc_[7] = hi_[3];                                 \
+    } else acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_, a_, acc_, 0, 0, 0);
 #define GP_MFMA(b_, j_, i_)                                                                                     \
     do {                                                                                                        \
         __builtin_amdgcn_s_setprio(1);                                                                          \
-        acc[j_][2 * (i_)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_##0, a00, acc[j_][2 * (i_)], 0, 0, 0);          \
-        acc[j_][2 * (i_) + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_##0, a10, acc[j_][2 * (i_) + 1], 0, 0, 0);  \
-        acc[j_][2 * (i_)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_##1, a01, acc[j_][2 * (i_)], 0, 0, 0);          \
-        acc[j_][2 * (i_) + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_##1, a11, acc[j_][2 * (i_) + 1], 0, 0, 0);  \
-        acc[j_][2 * (i_)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_##2, a02, acc[j_][2 * (i_)], 0, 0, 0);          \
-        acc[j_][2 * (i_) + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_##2, a12, acc[j_][2 * (i_) + 1], 0, 0, 0);  \
-        acc[j_][2 * (i_)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_##3, a03, acc[j_][2 * (i_)], 0, 0, 0);          \
-        acc[j_][2 * (i_) + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_##3, a13, acc[j_][2 * (i_) + 1], 0, 0, 0);  \
+        GP_MM(acc[j_][2 * (i_)], b_##0, a00)                              \
+        GP_MM(acc[j_][2 * (i_) + 1], b_##0, a10)                      \
+        GP_MM(acc[j_][2 * (i_)], b_##1, a01)                              \
+        GP_MM(acc[j_][2 * (i_) + 1], b_##1, a11)                      \
+        GP_MM(acc[j_][2 * (i_)], b_##2, a02)                              \
+        GP_MM(acc[j_][2 * (i_) + 1], b_##2, a12)                      \
+        GP_MM(acc[j_][2 * (i_)], b_##3, a03)                              \
+        GP_MM(acc[j_][2 * (i_) + 1], b_##3, a13)                      \
         __builtin_amdgcn_s_setprio(0);                                                                          \
     } while (0)
     bf16x8 a00, a01, a02, a03, a10, a11, a12, a13;       // a{f}{kk}: current A piece (64 rows x 64 k)
@@ -254,7 +282,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_pers_kernel(GemmParams p, int 
         GP_LOAD_A(0, par_)                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                         \
         if (c_kt == 0) GP_EPI_FETCH();                                                             \
-        if (GP_SVALID) { GP_STAGE(0, 1, (par_) ^ 1); GP_STAGE_ADVANCE(); }                         \
+        if (SCHED == 0) { if (GP_SVALID) { GP_STAGE(0, 1, (par_) ^ 1); GP_STAGE_ADVANCE(); } }     \
         asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");                                         \
         GP_BAR();                                                                                  \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                         \
@@ -263,7 +291,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_pers_kernel(GemmParams p, int 
         /* q1 */                                                                                   \
         GP_LOAD_B(bo, 1, par_)                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                         \
-        if (GP_SVALID) GP_STAGE(1, 0, par_);                                                       \
+        if (SCHED == 0) { if (GP_SVALID) GP_STAGE(1, 0, par_); }                                   \
+        else {                                                                                     \
+            if (GP_SVALID) { GP_STAGE(0, 1, (par_) ^ 1); GP_STAGE_ADVANCE(); }                     \
+            if (GP_SVALID) GP_STAGE1(1, 0, 0, par_);                                               \
+        }                                                                                          \
         GP_BAR();                                                                                  \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                         \
         GP_MFMA(bo, 1, 0);                                                                         \
@@ -271,13 +303,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_pers_kernel(GemmParams p, int 
         /* q2 */                                                                                   \
         GP_LOAD_A(1, par_)                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                         \
-        if (GP_SVALID) GP_STAGE(0, 0, par_);                                                       \
+        if (SCHED == 0) { if (GP_SVALID) GP_STAGE(0, 0, par_); }                                   \
+        else { if (GP_SVALID) GP_STAGE1(1, 0, 1, par_); }                                          \
         GP_BAR();                                                                                  \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                         \
         GP_MFMA(bo, 1, 1);                                                                         \
         GP_BAR();                                                                                  \
         /* q3 */                                                                                   \
         if (GP_SVALID) {                                                                           \
+            if (SCHED != 0) GP_STAGE(0, 0, par_);                                                  \
             GP_STAGE(1, 1, par_);                                                                  \
             asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                       \
         } else {                                                                                   \
@@ -497,8 +531,10 @@ extern "C" int utx_launch_gemm_pers(GemmParams p, hipStream_t stream) {
     constexpr int LDS = 131072 + 8 * 1024;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_pers_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_pers_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
+        const void* ks[4] = {reinterpret_cast<const void*>(gemm256_pers_kernel<false, 0>), reinterpret_cast<const void*>(gemm256_pers_kernel<true, 0>),
+                             reinterpret_cast<const void*>(gemm256_pers_kernel<false, 1>), reinterpret_cast<const void*>(gemm256_pers_kernel<true, 1>)};
+        for (const void* k : ks)
+            if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
         attr_set = true;
     }
     static int ncu = 0;
@@ -510,11 +546,27 @@ extern "C" int utx_launch_gemm_pers(GemmParams p, hipStream_t stream) {
     const int tiles = ntm * ntn;
     int grid = tiles < ncu ? tiles : ncu;
     if (g_utx_opt.gemm_pers_grid > 0 && g_utx_opt.gemm_pers_grid < grid) grid = g_utx_opt.gemm_pers_grid;   // A/B: fewer workgroups than CUs
+    // DMA placement: 0 = two per phase, 1 = none beside the twelve fragment reads of q0 (3 / 1 / 4 in q1 / q2 / q3).  Interleaved A/B
+    // (profiles/r02_gemm_ab_v4.log): 1 wins +3.5...+6 % on the long-K shapes (K = 12288 / 15360) and +0.4...+0.8 % on N >= 12288,
+    // loses 1.5-2.7 % on the short narrow ones; UTX_GEMM_PERS_SCHED = 1 / 2 forces schedule 0 / 1.
+    int sched = (p.K + p.K2 >= 6144 || p.N >= 12288) ? 1 : 0;
+    if (g_utx_opt.gemm_pers_sched == 1) sched = 0;
+    if (g_utx_opt.gemm_pers_sched == 2) sched = 1;
+#ifdef UTX_ABLATION
+    if ((g_utx_opt.gemm_debug_abl & 16) && !p.gate) {
+        static bool a2 = false;
+        if (!a2) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_pers_kernel<false, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3; a2 = true; }
+        hipLaunchKernelGGL((gemm256_pers_kernel<false, 1, true>), dim3(grid), dim3(512), LDS, stream, p, tiles);
+        return hipGetLastError() == hipSuccess ? 0 : -4;
+    }
+#endif
     if (p.gate) {
         if (p.gelu_from < p.N || p.n_split < p.N) return -2;     // the gated epilogue carries neither GELU nor the column split
-        hipLaunchKernelGGL(gemm256_pers_kernel<true>, dim3(grid), dim3(512), LDS, stream, p, tiles);
+        if (sched == 0) hipLaunchKernelGGL((gemm256_pers_kernel<true, 0>), dim3(grid), dim3(512), LDS, stream, p, tiles);
+        else hipLaunchKernelGGL((gemm256_pers_kernel<true, 1>), dim3(grid), dim3(512), LDS, stream, p, tiles);
     } else {
-        hipLaunchKernelGGL(gemm256_pers_kernel<false>, dim3(grid), dim3(512), LDS, stream, p, tiles);
+        if (sched == 0) hipLaunchKernelGGL((gemm256_pers_kernel<false, 0>), dim3(grid), dim3(512), LDS, stream, p, tiles);
+        else hipLaunchKernelGGL((gemm256_pers_kernel<false, 1>), dim3(grid), dim3(512), LDS, stream, p, tiles);
     }
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }

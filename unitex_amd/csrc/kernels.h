@@ -44,6 +44,7 @@ struct UtxOptions {
     int gemm_tile;        // 0 auto, 128, 256 (per-tile 8-phase), 2560 (persistent), 2562 (2-barrier 256^2)
     int gemm_tailsplit;   // 1: K-split tail round of the 8-phase GEMM (off by default)
     int gemm_pers_grid;   // persistent GEMM: number of workgroups (0 = one per CU)
+    int gemm_pers_sched;  // persistent GEMM: DMA placement over the phases of a K-tile: 0 = by shape, 1 = force SCHED 0, 2 = force SCHED 1
     int attn_var_abl, attn_debug_abl, gemm_debug_abl;
 };
 extern UtxOptions g_utx_opt;
