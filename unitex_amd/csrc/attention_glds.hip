@@ -28,6 +28,19 @@ __device__ __forceinline__ void ag_glds16(const bf16_t* g, char* lds) {
                                      (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
 }
 
+// VAR == 5 (ablation build only, WRONG results): every 32x32x16 MFMA replaced by two 16x16x32 MFMAs on the same operand registers --
+// same FLOPs and register / LDS traffic; measures what the more power-efficient instruction shape (tools/mfma_power_probe.py) would
+// buy this kernel before paying for the re-layout of the softmax.
+#define AG_MM(acc_, a_, b_, c_)                                                                              \
+    if constexpr (VAR == 5) {                                                                                \
+        f32x4 lo_ = {c_[0], c_[1], c_[2], c_[3]}, hi_ = {c_[4], c_[5], c_[6], c_[7]};                        \
+        lo_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_, b_, lo_, 0, 0, 0);                                 \
+        hi_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_, a_, hi_, 0, 0, 0);                                 \
+        acc_ = c_;                                                                                           \
+        acc_[0] = lo_[0]; acc_[1] = lo_[1]; acc_[2] = lo_[2]; acc_[3] = lo_[3];                              \
+        acc_[4] = hi_[0]; acc_[5] = hi_[1]; acc_[6] = hi_[2]; acc_[7] = hi_[3];                              \
+    } else acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b_, c_, 0, 0, 0);
+
 template <int PRESC, int TPB, int VAR>
 __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -186,7 +199,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
         for (int kk = 0; kk < 8; ++kk) {
             if (VAR == 3) kfb[kk] = kfa[kk];   /* ablation: half of the K fragment reads removed (wrong results) */
             else kfb[kk] = *reinterpret_cast<const bf16x8*>(kb + 8192 + kx[kk]);
-            sa0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfa[kk], qf[kk], kk == 0 ? negm : sa0, 0, 0, 0);
+            if (kk == 0) { AG_MM(sa0, kfa[kk], qf[kk], negm) } else { AG_MM(sa0, kfa[kk], qf[kk], sa0) }
         }
         __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
 #pragma unroll
@@ -198,7 +211,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
             vfa[kk] = *reinterpret_cast<const bf16x8*>(vb + (kk & 3) * 4096 + vx[kk >> 2]);
-            sa1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfb[kk], qf[kk], kk == 0 ? negm : sa1, 0, 0, 0);
+            if (kk == 0) { AG_MM(sa1, kfb[kk], qf[kk], negm) } else { AG_MM(sa1, kfb[kk], qf[kk], sa1) }
         }
         if (kbias) {
 #pragma unroll
@@ -221,7 +234,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
         for (int i = 0; i < 8; ++i) {
             if (VAR == 3) vfb[i] = vfa[i];   /* ablation: half of the V fragment reads removed (wrong results) */
             else vfb[i] = *reinterpret_cast<const bf16x8*>(vb + (i & 3) * 4096 + vx[2 + (i >> 2)]);
-            oacc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfa[i], pb[i >> 2], oacc[i & 3], 0, 0, 0);
+            AG_MM(oacc[i & 3], vfa[i], pb[i >> 2], oacc[i & 3])
         }
         if (kbias) {
 #pragma unroll
@@ -242,7 +255,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
         // S3: PV(1)
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-            oacc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfb[i], pb[2 + (i >> 2)], oacc[i & 3], 0, 0, 0);
+            AG_MM(oacc[i & 3], vfb[i], pb[2 + (i >> 2)], oacc[i & 3])
         if (VAR != 1) __builtin_amdgcn_s_setprio(0);
       }
       __syncthreads();     // this group fully read by every wave; the next group (DMA) retired by the vmcnt(0) of this fence
@@ -382,7 +395,8 @@ extern "C" int utx_launch_attn_fwd_glds(const AttnParams* p, int presc, hipStrea
       if (var == 1 && presc) return launch_glds<1, 1, 1>(*p, stream);
       if (var == 2 && presc) return launch_glds<1, 1, 2>(*p, stream);
       if (var == 3 && presc) return launch_glds<1, 1, 3>(*p, stream);
-      if (var == 4 && presc) return launch_glds<1, 1, 4>(*p, stream); }
+      if (var == 4 && presc) return launch_glds<1, 1, 4>(*p, stream);
+      if (var == 5 && presc) return launch_glds<1, 1, 5>(*p, stream); }
 #endif
     return presc ? launch_glds<1, 1>(*p, stream) : launch_glds<0, 1>(*p, stream);
 }
