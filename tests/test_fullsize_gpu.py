@@ -63,7 +63,7 @@ def _set_tile(v):
 def _gemm_variants(fn):
     outs = {}
     try:
-        for tile in ("128", "2562", "256", "2560"):     # 2560 = the persistent kernel (gemm_pers.hip), the default for most large shapes
+        for tile in ("128", "2562", "256", "2560", "2564"):     # 2560 = the persistent kernel (gemm_pers.hip), the default for most large shapes; 2564 = one wave per SIMD (gemm_w4.hip)
             _set_tile(tile)
             outs[tile] = fn()
             torch.cuda.synchronize()
@@ -96,7 +96,7 @@ def test_gemm_full_size_kernels_agree_bitwise_and_match_oracle_rows(M):
         ops.gemm(x, W, bias=bias, out=c0, A2=T, B2=Bl, lora_n_limit=3 * D, lora_seg_n=D, gelu_from=3 * D, n_split=3 * D, C1=c1)
         return torch.cat([c0, c1], 1)
     o = _gemm_variants(fused)
-    assert _same_bits(o["256"], o["128"]) and _same_bits(o["2562"], o["128"]) and _same_bits(o["2560"], o["128"]), "fused qkv|mlp: kernels disagree"
+    assert all(_same_bits(o[k], o["128"]) for k in ("2562", "256", "2560", "2564")), "fused qkv|mlp: kernels disagree"
     rows = torch.tensor([0, 255, 256, 1000, M // 2 + 17, M - 1])
     # oracle arithmetic (fp32 on the CPU, bf16 rounding at the same tensor boundaries) on the sampled rows
     y = x[rows].float().cpu() @ W.float().cpu().t()
@@ -119,7 +119,7 @@ def test_gemm_full_size_kernels_agree_bitwise_and_match_oracle_rows(M):
         ops.gemm(cat, Wo, bias=bo, out=r, gate=gate, res=r)
         return r
     o = _gemm_variants(gated)
-    assert _same_bits(o["256"], o["128"]) and _same_bits(o["2562"], o["128"]) and _same_bits(o["2560"], o["128"]), "gated residual: kernels disagree"
+    assert all(_same_bits(o[k], o["128"]) for k in ("2562", "256", "2560", "2564")), "gated residual: kernels disagree"
     yy = ((cat[rows].float().cpu() @ Wo.float().cpu().t()) + bo.float().cpu()).to(BF).float()
     yy = (res[rows].float().cpu() + (gate.float().cpu() * yy).to(BF).float()).to(BF).float()
     rel = ((o["256"][rows].float().cpu() - yy).abs() / yy.abs().clamp_min(1.0)).max().item()
@@ -132,7 +132,8 @@ def test_gemm_persistent_kernel_edge_shapes_bit_identical_to_tiled_kernels(M, N,
     boundary logic: ragged M (rows >= M in the last tile row, including waves with no valid row), an ODD number of K-tiles per
     tile (K = 192, and 48 + 1 style LoRA segments: the stream re-enters at odd LDS parity), a single K-tile per tile (K = 64:
     every K-tile is first and last), tiles with and without the LoRA segment in one launch, GELU / column split on a tile
-    boundary, and the gated residual updated IN PLACE (res aliases C).  All four kernels must agree bit for bit."""
+    boundary, and the gated residual updated IN PLACE (res aliases C).  All five kernels (incl. the one-wave-per-SIMD kernel of
+    gemm_w4.hip, whose stream unit is 32 k: K = 64 is two sub-stages per tile, its ragged-M gated slow path) must agree bit for bit."""
     ops = _ops()
     g = torch.Generator(device="cuda").manual_seed(M + N + K)
     A = (torch.randn(M, K, device="cuda", generator=g) / 2).to(BF)
@@ -153,7 +154,7 @@ def test_gemm_persistent_kernel_edge_shapes_bit_identical_to_tiled_kernels(M, N,
         ops.gemm(A, W, bias=bias, out=c0, gelu_from=split, n_split=split, C1=c1, alpha=0.75, **kw)
         return torch.cat([c0, c1], 1)
     o = _gemm_variants(plain)
-    assert all(_same_bits(o[k], o["128"]) for k in ("2562", "256", "2560")), "plain / GELU / split epilogue: kernels disagree"
+    assert all(_same_bits(o[k], o["128"]) for k in ("2562", "256", "2560", "2564")), "plain / GELU / split epilogue: kernels disagree"
     ref = (0.75 * (A.float() @ W.float().t() + ((kw["A2"].float() @ kw["B2"].float().t()) if K2 else 0.0)) + bias.float()).to(BF).float()
     ref[:, split:] = dit_ref.gelu_tanh(ref[:, split:].cpu()).to(BF).float().cuda()
     rel = ((o["2560"].float() - ref).abs() / ref.abs().clamp_min(1.0)).max().item()
@@ -166,7 +167,7 @@ def test_gemm_persistent_kernel_edge_shapes_bit_identical_to_tiled_kernels(M, N,
         ops.gemm(A, W, bias=bias, out=r, gate=gate, res=r, **kw)
         return r
     o = _gemm_variants(gated)
-    assert all(_same_bits(o[k], o["128"]) for k in ("2562", "256", "2560")), "gated residual (in place): kernels disagree"
+    assert all(_same_bits(o[k], o["128"]) for k in ("2562", "256", "2560", "2564")), "gated residual (in place): kernels disagree"
     # repeated launches: the stream has no state that survives a launch
     again = gated()
     assert _same_bits(again, o["2560"])

@@ -63,6 +63,7 @@ int utx_launch_attn_fwd(const void* q, const void* k, const void* vt, void* o,
 int utx_launch_attn_fwd_glds(const AttnParams* p, int presc, hipStream_t stream);
 int utx_launch_attn_fwd_q64(const AttnParams* p, int presc, hipStream_t stream);
 int utx_launch_gemm_bf16(const GemmParams* p, hipStream_t stream);
+int utx_launch_gemm_w4(GemmParams p, hipStream_t stream);     // gemm_w4.hip: persistent 256x256 kernel, one wave per SIMD
 int utx_launch_gemm_pers(GemmParams p, hipStream_t stream);   // gemm_pers.hip: persistent 256x256 kernel (large-M linears)
 int utx_launch_gemv_bf16(const GemvParams* p, hipStream_t stream);
 int utx_launch_quant_mx8(const void* x, long ldx, void* q, long ldq, void* s, long lds, int M, int K, hipStream_t stream);
