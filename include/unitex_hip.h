@@ -241,6 +241,12 @@ void utx_bvh_free(utx_bvh* bvh);
 int utx_bvh_arrays(utx_bvh* bvh, int** info, float** aabb, unsigned** codes_sorted, int** idx_sorted);
 /* intersects_closest (rt_aprmis/__init__.py:40-86): tid [R] int32, -1 = miss. */
 int utx_bvh_trace(utx_ctx* ctx, utx_bvh* bvh, const float* rays_o, const float* rays_d, long R, int* tid, utx_stream stream);
+/* the same trace + the number of tree nodes the rays visited, ADDED to *visited (device counter; measurement of SURVEY 8d's
+ * nodes-visited-per-ray, bench.py); longest root-to-leaf path of the tree (the stackless packed traversal is used up to 60, the
+ * reference's 64-entry stack walk above: intersect_test2.slang:63-146). */
+int utx_bvh_trace_count(utx_ctx* ctx, utx_bvh* bvh, const float* rays_o, const float* rays_d, long R, int* tid,
+                        unsigned long long* visited, utx_stream stream);
+int utx_bvh_depth(utx_bvh* bvh);
 
 /* fused per-(view, texel) gather + visibility of uv_to_pcd (renderer_inverse.py:277-298,316-325) */
 typedef struct utx_backproject_desc {

@@ -92,10 +92,20 @@ def test_bvh_build_and_trace_bit_exact():
         rd = np.tile(np.array([[0, 0, -1]], np.float32), (R, 1))
         d2 = rng.normal(size=(R, 3)).astype(np.float32)
         o2 = (-3.0 * d2 / np.linalg.norm(d2, axis=1, keepdims=True)).astype(np.float32) + rng.uniform(-0.3, 0.3, (R, 3)).astype(np.float32)
+        from unitex_amd import _lib
+        assert 0 <= b.depth() <= 60, "these trees take the stackless packed traversal"
         for o, d in ((ro, rd), (o2, d2)):
             t_ref = ref.trace(o, d)
-            t = b.trace(_cu(o), _cu(d)).cpu().numpy()
+            t = b.trace(_cu(o), _cu(d)).cpu().numpy()          # product path: stackless walk over the packed tree
             assert np.array_equal(t, t_ref)
+            try:                                                # the reference's 64-entry stack walk over the unpacked arrays: same ids
+                _lib.set_option("UTX_BVH_STACK_WALK", 1)
+                t_stack = b.trace(_cu(o), _cu(d)).cpu().numpy()
+            finally:
+                _lib.set_option("UTX_BVH_STACK_WALK", 0)
+            assert np.array_equal(t_stack, t_ref)
+            t_cnt, visited = b.trace_count(_cu(o), _cu(d))      # counting variant: same ids, every ray visits at least the root
+            assert np.array_equal(t_cnt.cpu().numpy(), t_ref) and visited >= len(o)
         if nf >= 500:
             assert (t_ref >= 0).mean() > 0.3
 

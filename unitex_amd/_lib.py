@@ -104,6 +104,8 @@ SYMBOLS = {
     "utx_bvh_free": (None, [c_void_p]),
     "utx_bvh_arrays": (c_int, [c_void_p, C.POINTER(c_void_p), C.POINTER(c_void_p), C.POINTER(c_void_p), C.POINTER(c_void_p)]),
     "utx_bvh_trace": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_void_p]),
+    "utx_bvh_trace_count": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_void_p]),
+    "utx_bvh_depth": (c_int, [c_void_p]),
     "utx_backproject": (c_int, [c_void_p, C.POINTER(BackprojectDesc), c_void_p, c_void_p]),
     "utx_dilate_visibility": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "utx_composite": (c_int, [c_void_p, c_void_p, c_void_p, C.POINTER(c_int), c_int, c_long, c_void_p, c_void_p, c_void_p]),
@@ -152,7 +154,8 @@ def load_library():
 
 
 OPTION_NAMES = ["UTX_ATTN_GLDS", "UTX_ATTN_FAST", "UTX_ATTN_Q64", "UTX_ATTN_TPB", "UTX_ATTN_TAILSPLIT",
-                "UTX_GEMM_GROUP_M", "UTX_GEMM_TILE", "UTX_GEMM_TAILSPLIT", "UTX_GEMM_PERS_GRID", "UTX_GEMM_PERS_SCHED"]
+                "UTX_GEMM_GROUP_M", "UTX_GEMM_TILE", "UTX_GEMM_TAILSPLIT", "UTX_GEMM_PERS_GRID", "UTX_GEMM_PERS_SCHED",
+                "UTX_BVH_STACK_WALK"]
 
 
 def set_option(name, value):

@@ -18,7 +18,10 @@ __device__ __forceinline__ float4 tap4(const float4* img, int H, int W, int x, i
     return img[(long)y * W + x];
 }
 
-__global__ __launch_bounds__(256) void backproject_kernel(utx_backproject_desc p, const int* info, const float* aabb) {
+// PACKED: stackless walk over the packed tree (bvh_device.h) -- the product path; !PACKED: the reference's 64-entry stack walk, kept for
+// trees deeper than UTX_BVH_PACKED_MAX_DEPTH (where the reference's stack overflow quirk could matter) and for A/B tests
+template <bool PACKED>
+__global__ __launch_bounds__(256) void backproject_kernel(utx_backproject_desc p, const int* info, const float* aabb, const float4* nodes, const float4* tris) {
     const long T = (long)p.T_h * p.T_w;
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int vw = p.view_begin + blockIdx.y;
@@ -64,7 +67,7 @@ __global__ __launch_bounds__(256) void backproject_kernel(utx_backproject_desc p
     oc[2] = ((a.z * w00 + b.z * w01) + c.z * w10) + e.z * w11;
     const float sa = ((a.w * w00 + b.w * w01) + c.w * w10) + e.w * w11;
     *ao = sa > 0.999f ? 1 : 0;
-    const int hit = bvh_trace_one(info, aabb, vert, faces, ro, d);
+    const int hit = PACKED ? bvh_trace_packed(nodes, tris, ro, d, nullptr) : bvh_trace_one(info, aabb, vert, faces, ro, d);
     *rv = (hit == id && hit != -1 && cs < p.cos_thresh) ? 1 : 0;
 }
 
@@ -73,7 +76,10 @@ extern "C" int utx_launch_backproject(const utx_backproject_desc* hp, const utx_
     if (!bvh || p.T_h <= 0 || p.T_w <= 0 || p.view_count <= 0) return -2;
     const long T = (long)p.T_h * p.T_w;
     dim3 grid((unsigned)((T + 255) / 256), p.view_count);
-    hipLaunchKernelGGL(backproject_kernel, grid, dim3(256), 0, stream, p, bvh->info, bvh->aabb);
+    if (bvh->depth <= UTX_BVH_PACKED_MAX_DEPTH && !g_utx_opt.bvh_stack_walk)
+        hipLaunchKernelGGL(backproject_kernel<true>, grid, dim3(256), 0, stream, p, bvh->info, bvh->aabb, bvh->nodes, bvh->tris);
+    else
+        hipLaunchKernelGGL(backproject_kernel<false>, grid, dim3(256), 0, stream, p, bvh->info, bvh->aabb, bvh->nodes, bvh->tris);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 

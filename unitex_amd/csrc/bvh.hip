@@ -154,9 +154,52 @@ __global__ __launch_bounds__(256) void bvh_refit_kernel(int n, const int* info, 
     }
 }
 
+// packed tree for the stackless traversal (bvh_device.h): one thread per node; esc by walking up until the node is a second child
+__global__ __launch_bounds__(256) void bvh_pack_kernel(int n, const int* info, const float* aabb, const int* parent, const float* vert,
+                                                       const int* faces, float4* nodes, float4* tris, int* depth) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nn = 2 * n - 1;
+    if (g >= nn) return;
+    const int L = info[3 * (long)g], R = info[3 * (long)g + 1];
+    const bool leaf = (L == 0 && R == 0);
+    int esc = -1, steps = 0;
+    for (int cur = g; cur != 0; ++steps) {
+        const int P = parent[cur];
+        if (cur == info[3 * (long)P + 1]) { esc = info[3 * (long)P]; break; }
+        cur = P;
+    }
+    if (leaf) {
+        int d = 0;
+        for (int cur = g; cur != 0; cur = parent[cur]) ++d;
+        atomicMax(depth, d);
+        const int prim = info[3 * (long)g + 2];
+        const int* f = faces + 3 * (long)prim;
+        for (int k = 0; k < 3; ++k)
+            tris[3 * (long)prim + k] = make_float4(vert[3 * (long)f[k]], vert[3 * (long)f[k] + 1], vert[3 * (long)f[k] + 2], 0.f);
+    }
+    const int link = leaf ? ~info[3 * (long)g + 2] : R;
+    nodes[2 * (long)g] = make_float4(aabb[6 * (long)g], aabb[6 * (long)g + 1], aabb[6 * (long)g + 2], aabb[6 * (long)g + 3]);
+    nodes[2 * (long)g + 1] = make_float4(aabb[6 * (long)g + 4], aabb[6 * (long)g + 5], __int_as_float(link), __int_as_float(esc));
+}
+
 // ---------------------------------------------------------------------------------------------
 // traversal
 // ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bvh_trace_packed_kernel(const float4* nodes, const float4* tris, const float* ro, const float* rd, long R,
+                                                               int* tid, unsigned long long* visited) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned nv = 0;
+    if (i < R) {
+        const float o[3] = {ro[3 * i], ro[3 * i + 1], ro[3 * i + 2]};
+        const float d[3] = {rd[3 * i], rd[3 * i + 1], rd[3 * i + 2]};
+        tid[i] = bvh_trace_packed(nodes, tris, o, d, visited ? &nv : nullptr);
+    }
+    if (visited) {      // diagnostics (bench: nodes visited per ray): wave sum, one atomic per wave
+        for (int o = 32; o > 0; o >>= 1) nv += __shfl_xor(nv, o, 64);
+        if ((threadIdx.x & 63) == 0) atomicAdd(visited, (unsigned long long)nv);
+    }
+}
+
 __global__ __launch_bounds__(256) void bvh_trace_kernel(const int* info, const float* aabb, const float* vert, const int* faces,
                                                         const float* ro, const float* rd, long R, int* tid) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -186,6 +229,10 @@ extern "C" int utx_bvh_build_impl(const float* verts, int V, const int* faces, i
     HCHK(hipMalloc(&b->parent, nn * sizeof(int)));
     HCHK(hipMalloc(&b->counter, (long)(F > 1 ? F - 1 : 1) * sizeof(int)));
     HCHK(hipMalloc(&b->extent, 8 * sizeof(unsigned)));
+    HCHK(hipMalloc(&b->nodes, nn * 2 * sizeof(float4)));
+    HCHK(hipMalloc(&b->tris, (long)F * 3 * sizeof(float4)));
+    HCHK(hipMalloc(&b->depth_dev, sizeof(int)));
+    HCHK(hipMemsetAsync(b->depth_dev, 0, sizeof(int), stream));
     b->sort_tmp_bytes = 0;
     HCHK(rocprim::radix_sort_pairs(nullptr, b->sort_tmp_bytes, b->codes, b->codes_sorted, b->idx, b->idx_sorted, (size_t)F, 0, 32, stream));
     HCHK(hipMalloc(&b->sort_tmp, b->sort_tmp_bytes ? b->sort_tmp_bytes : 16));
@@ -196,14 +243,20 @@ extern "C" int utx_bvh_build_impl(const float* verts, int V, const int* faces, i
     HCHK(rocprim::radix_sort_pairs(b->sort_tmp, b->sort_tmp_bytes, b->codes, b->codes_sorted, b->idx, b->idx_sorted, (size_t)F, 0, 32, stream));
     hipLaunchKernelGGL(bvh_hierarchy_kernel, dim3(nb), dim3(256), 0, stream, F, b->codes_sorted, b->idx_sorted, b->ebox, b->info, b->aabb, b->parent);
     hipLaunchKernelGGL(bvh_refit_kernel, dim3(nb), dim3(256), 0, stream, F, b->info, b->aabb, b->parent, b->counter);
+    hipLaunchKernelGGL(bvh_pack_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, stream, F, b->info, b->aabb, b->parent, verts, faces,
+                       b->nodes, b->tris, b->depth_dev);
     if (hipGetLastError() != hipSuccess) return -4;
+    // the tree depth decides, once per mesh, which traversal the launches use (the build is not part of any captured graph)
+    HCHK(hipMemcpyAsync(&b->depth, b->depth_dev, sizeof(int), hipMemcpyDeviceToHost, stream));
+    HCHK(hipStreamSynchronize(stream));
     *out = b;
     return 0;
 }
 
 extern "C" void utx_bvh_free_impl(utx_bvh* b) {
     if (!b) return;
-    void* ps[] = {b->info, b->aabb, b->ebox, b->codes, b->codes_sorted, b->idx, b->idx_sorted, b->parent, b->counter, b->extent, b->sort_tmp};
+    void* ps[] = {b->info, b->aabb, b->ebox, b->codes, b->codes_sorted, b->idx, b->idx_sorted, b->parent, b->counter, b->extent, b->sort_tmp,
+                  b->nodes, b->tris, b->depth_dev};
     for (void* p : ps) if (p) (void)hipFree(p);
     delete b;
 }
@@ -217,8 +270,16 @@ extern "C" int utx_bvh_arrays_impl(utx_bvh* b, int** info, float** aabb, unsigne
     return b->F;
 }
 
-extern "C" int utx_bvh_trace_impl(utx_bvh* b, const float* ro, const float* rd, long R, int* tid, hipStream_t stream) {
+extern "C" int utx_bvh_depth_impl(utx_bvh* b) { return b->depth; }
+
+extern "C" int utx_bvh_trace_impl(utx_bvh* b, const float* ro, const float* rd, long R, int* tid, unsigned long long* visited, int force_stack,
+                                  hipStream_t stream) {
     if (!b || R <= 0) return -2;
+    if (b->depth <= UTX_BVH_PACKED_MAX_DEPTH && !force_stack) {
+        hipLaunchKernelGGL(bvh_trace_packed_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, stream, b->nodes, b->tris, ro, rd, R, tid, visited);
+        return hipGetLastError() == hipSuccess ? 0 : -4;
+    }
+    if (visited) return -2;     // the node count is a diagnostic of the packed traversal
     hipLaunchKernelGGL(bvh_trace_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, stream, b->info, b->aabb, b->verts, b->faces, ro, rd, R, tid);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }

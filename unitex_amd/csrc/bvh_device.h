@@ -72,6 +72,45 @@ __device__ __forceinline__ int bvh_trace_one(const int* __restrict__ info, const
 }
 
 
+// ---- the same traversal over the PACKED tree (built by bvh_pack_kernel; used whenever the tree is shallow enough that the
+// reference's 64-entry stack can never overflow, i.e. always in practice):
+//   node  = two 16-byte words  {bb[0..3]} {bb[4], bb[5], link, esc}      (the reference reads 6 + 3 scalar dwords from two arrays)
+//           link > 0: internal node, link = its SECOND child (the reference pushes first, second and pops the second first);
+//           link < 0: leaf of primitive ~link.  esc = the node the reference would pop after this node's subtree is done:
+//           the first child of the parent for a second child, the parent's esc for a first child, -1 at the root.
+//   tri   = three 16-byte words {v0, 0} {v1, 0} {v2, 0}                  (the reference chases faces[] then three vertices)
+// No stack, so no scratch memory and no dependent index load between "pop" and the next box test.  The order in which nodes and
+// triangles are visited -- and with it the quirk that the LAST triangle hit wins, not the closest -- is the reference's exactly:
+// miss -> esc; internal hit -> second child (whose esc is the first child); leaf -> test, esc.
+__device__ __forceinline__ int bvh_trace_packed(const float4* __restrict__ nodes, const float4* __restrict__ tris, const float* ro,
+                                                const float* rd_in, unsigned* visited) {
+    const float nrm = sqrtf(dot3(rd_in, rd_in));
+    const float rd[3] = {rd_in[0] / nrm, rd_in[1] / nrm, rd_in[2] / nrm};
+    float closest = 1e9f;
+    int hit_tid = -1;
+    int nd = 0;
+    unsigned nv = 0;
+    while (nd >= 0) {
+        const float4 a = nodes[2 * (long)nd], b = nodes[2 * (long)nd + 1];
+        const float bb[6] = {a.x, a.y, a.z, a.w, b.x, b.y};
+        const int link = __float_as_int(b.z), esc = __float_as_int(b.w);
+        ++nv;
+        if (!aabb_hit(ro, rd, 0.f, closest, bb)) { nd = esc; continue; }
+        if (link > 0) { nd = link; continue; }
+        const int prim = ~link;
+        const float4 t0 = tris[3 * (long)prim], t1 = tris[3 * (long)prim + 1], t2 = tris[3 * (long)prim + 2];
+        const float v0[3] = {t0.x, t0.y, t0.z}, v1[3] = {t1.x, t1.y, t1.z}, v2[3] = {t2.x, t2.y, t2.z};
+        float t;
+        if (tri_hit(ro, rd, v0, v1, v2, t)) {
+            closest = t < closest ? t : closest;
+            hit_tid = prim;
+        }
+        nd = esc;
+    }
+    if (visited) *visited = nv;
+    return hit_tid;
+}
+
 struct utx_bvh {
     int F;
     int* info;       // [2F-1][3]
@@ -85,4 +124,9 @@ struct utx_bvh {
     int* counter;    // [F-1]
     unsigned* extent;  // 6 ordered-uint min/max
     void* sort_tmp; size_t sort_tmp_bytes;
+    float4* nodes;   // [2F-1][2] packed tree (bvh_trace_packed)
+    float4* tris;    // [F][3]
+    int* depth_dev;  // max number of ancestors of a leaf
+    int depth;       // host copy; the packed traversal is used when depth <= UTX_BVH_PACKED_MAX_DEPTH
 };
+#define UTX_BVH_PACKED_MAX_DEPTH 60   // the reference's stack holds 64 entries and the walk keeps at most depth + 1 of them

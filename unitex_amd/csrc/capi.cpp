@@ -7,7 +7,7 @@
 #include <stdlib.h>
 #include "kernels.h"
 
-UtxOptions g_utx_opt = {1, 2, 0, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0};
+UtxOptions g_utx_opt = {1, 2, 0, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
 struct OptName { const char* name; int UtxOptions::*field; bool ablation; };
 static const OptName kOptions[] = {
@@ -16,7 +16,7 @@ static const OptName kOptions[] = {
     {"UTX_ATTN_TAILSPLIT", &UtxOptions::attn_tailsplit, false},
     {"UTX_GEMM_GROUP_M", &UtxOptions::gemm_group_m, false}, {"UTX_GEMM_TILE", &UtxOptions::gemm_tile, false},
     {"UTX_GEMM_TAILSPLIT", &UtxOptions::gemm_tailsplit, false}, {"UTX_GEMM_PERS_GRID", &UtxOptions::gemm_pers_grid, false},
-    {"UTX_GEMM_PERS_SCHED", &UtxOptions::gemm_pers_sched, false},
+    {"UTX_GEMM_PERS_SCHED", &UtxOptions::gemm_pers_sched, false}, {"UTX_BVH_STACK_WALK", &UtxOptions::bvh_stack_walk, false},
     {"UTX_ATTN_VAR", &UtxOptions::attn_var_abl, true},      {"UTX_ATTN_DEBUG", &UtxOptions::attn_debug_abl, true},
     {"UTX_GEMM_DEBUG", &UtxOptions::gemm_debug_abl, true},
 };
@@ -222,8 +222,13 @@ int utx_bvh_arrays(utx_bvh* bvh, int** info, float** aabb, unsigned** codes_sort
 }
 int utx_bvh_trace(utx_ctx* ctx, utx_bvh* bvh, const float* ro, const float* rd, long R, int* tid, utx_stream stream) {
     if (!bvh || !ro || !rd || !tid) return fail(ctx, -2, "utx_bvh_trace");
-    UTX_CALL(ctx, "utx_bvh_trace", utx_bvh_trace_impl(bvh, ro, rd, R, tid, (hipStream_t)stream));
+    UTX_CALL(ctx, "utx_bvh_trace", utx_bvh_trace_impl(bvh, ro, rd, R, tid, nullptr, g_utx_opt.bvh_stack_walk, (hipStream_t)stream));
 }
+int utx_bvh_trace_count(utx_ctx* ctx, utx_bvh* bvh, const float* ro, const float* rd, long R, int* tid, unsigned long long* visited, utx_stream stream) {
+    if (!bvh || !ro || !rd || !tid || !visited) return fail(ctx, -2, "utx_bvh_trace_count");
+    UTX_CALL(ctx, "utx_bvh_trace_count", utx_bvh_trace_impl(bvh, ro, rd, R, tid, visited, 0, (hipStream_t)stream));
+}
+int utx_bvh_depth(utx_bvh* bvh) { return bvh ? utx_bvh_depth_impl(bvh) : -2; }
 int utx_backproject(utx_ctx* ctx, const utx_backproject_desc* d, utx_bvh* bvh, utx_stream stream) {
     if (!d || !bvh || !d->rast2d || !d->verts || !d->faces || !d->fnormal || !d->vndc || !d->dirs || !d->images ||
         !d->color || !d->rayvis || !d->alphaok || d->view_begin < 0 || d->view_begin + d->view_count > d->n_views)

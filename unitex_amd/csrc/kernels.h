@@ -41,10 +41,11 @@ struct UtxOptions {
     int attn_tpb;         // tiles per barrier of the LDS-DMA kernel (1 | 2)
     int attn_tailsplit;   // 1 (default): key-split tail round
     int gemm_group_m;     // 0 = built-in GROUP_M
-    int gemm_tile;        // 0 auto, 128, 256 (per-tile 8-phase), 2560 (persistent), 2562 (2-barrier 256^2)
+    int gemm_tile;        // 0 auto, 128, 256 (per-tile 8-phase), 2560 (persistent), 2562 (2-barrier 256^2), 2564 (one wave per SIMD)
     int gemm_tailsplit;   // 1: K-split tail round of the 8-phase GEMM (off by default)
     int gemm_pers_grid;   // persistent GEMM: number of workgroups (0 = one per CU)
     int gemm_pers_sched;  // persistent GEMM: DMA placement over the phases of a K-tile: 0 = by shape, 1 = force SCHED 0, 2 = force SCHED 1
+    int bvh_stack_walk;   // 1: the reference's stack walk over the unpacked tree instead of the stackless packed walk (A/B; same results)
     int attn_var_abl, attn_debug_abl, gemm_debug_abl;
 };
 extern UtxOptions g_utx_opt;
@@ -89,7 +90,8 @@ int utx_launch_texture_shade(const float* rast, const float* uv, const int* tri,
 int utx_bvh_build_impl(const float* verts, int V, const int* faces, int F, utx_bvh** out, hipStream_t stream);
 void utx_bvh_free_impl(utx_bvh* b);
 int utx_bvh_arrays_impl(utx_bvh* b, int** info, float** aabb, unsigned** codes_sorted, int** idx_sorted);
-int utx_bvh_trace_impl(utx_bvh* b, const float* ro, const float* rd, long R, int* tid, hipStream_t stream);
+int utx_bvh_trace_impl(utx_bvh* b, const float* ro, const float* rd, long R, int* tid, unsigned long long* visited, int force_stack, hipStream_t stream);
+int utx_bvh_depth_impl(utx_bvh* b);
 int utx_launch_backproject(const utx_backproject_desc* p, const utx_bvh* bvh, hipStream_t stream);
 int utx_launch_dilate_visibility(const void* rayvis, const void* alphaok, const void* rast2d, int n_views, int Hh, int Ww, void* tmp, void* vis_out, hipStream_t stream);
 int utx_launch_composite(const float* colors, const void* vis, const int* order, int n_order, long T, float* atlas, void* winner, hipStream_t stream);

@@ -8,7 +8,7 @@ compulsory reads + writes of that stage's tensors (each counted once), stated be
 import numpy as np
 import torch
 
-from . import camera, meshes
+from . import camera, meshes, ops
 from .renderer_inverse import NVDiffRendererInverse
 
 # compulsory bytes per atlas texel (T texels, n views), fp32 unless noted:
@@ -73,9 +73,24 @@ def time_backprojection(n_faces=50000, view_px=1024, atlas_px=2048, iters=3, war
             acc.setdefault(name, []).append(a.elapsed_time(b))
         covered = float(out[2].float().mean())
     inv.stage_events = None
+    # nodes visited per ray -- the visibility rays of the first view of this rank, re-cast through the counting trace
+    nodes_per_ray, depth = None, None
+    try:
+        m, rast2d = inv.pbr_mesh, inv.last["rast2d"]
+        cov = rast2d[..., 3] > 0
+        pos = ops.interpolate(m.vertices, rast2d, m.faces)[cov]
+        from .distributed import view_range
+        v0 = view_range(view_shard[0], view_shard[1], n_views)[0]
+        d = (-torch.as_tensor(c2ws)[min(v0, n_views - 1), :3, 2]).to(pos.device, torch.float32)
+        ro = pos - 2.0 * (3.0 ** 0.5) * d
+        bvh = m.optix
+        _, visited = bvh.trace_count(ro, d.expand_as(ro).contiguous())
+        nodes_per_ray, depth = visited / max(1, ro.shape[0]), bvh.depth()
+    except Exception as e:  # noqa: BLE001 -- a diagnostic must not break the timing
+        nodes_per_ray = "error: %r" % (e,)
     stages = {k: float(np.mean(v)) for k, v in acc.items()}
     T = float(atlas_px * atlas_px)
     bpt = stage_bytes_per_texel(n_views)
     gbps = {k: bpt[k] * T / (stages[k] * 1e-3) / 1e9 for k in stages if k in bpt and stages[k] > 0}
     return {"total_ms": float(np.mean(totals)), "stages_ms": stages, "stages_gbps": gbps, "faces": int(len(faces)),
-            "texels": int(T), "covered_frac": covered, "view_px": view_px, "atlas_px": atlas_px}
+            "texels": int(T), "covered_frac": covered, "view_px": view_px, "atlas_px": atlas_px, "nodes_per_ray": nodes_per_ray, "bvh_depth": depth}

@@ -140,6 +140,19 @@ class BVH:
         self.ctx.check(self.ctx.lib.utx_bvh_trace(self.ctx.handle, self.handle, ptr(ro), ptr(rd), ro.shape[0], ptr(tid), self.ctx.stream()))
         return tid
 
+    def trace_count(self, rays_o, rays_d):
+        """(tid, number of tree nodes the rays visited in total) -- the measurement behind bench.py's nodes_visited_per_ray"""
+        ro, rd = _f(rays_o.reshape(-1, 3)), _f(rays_d.reshape(-1, 3))
+        tid = torch.empty(ro.shape[0], dtype=I32, device=ro.device)
+        visited = torch.zeros(1, dtype=torch.int64, device=ro.device)
+        self.ctx.check(self.ctx.lib.utx_bvh_trace_count(self.ctx.handle, self.handle, ptr(ro), ptr(rd), ro.shape[0], ptr(tid), ptr(visited),
+                                                        self.ctx.stream()))
+        return tid, int(visited.item())
+
+    def depth(self):
+        """longest root-to-leaf path of the tree (<= 60: the stackless packed traversal is in use)"""
+        return int(self.ctx.lib.utx_bvh_depth(self.handle))
+
 
 def backproject(rast2d, verts, faces, fnormal, vndc, dirs, images, bvh, angle_deg=100.0, view_begin=0, view_count=None,
                 out=None):
