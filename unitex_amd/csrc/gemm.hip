@@ -751,20 +751,34 @@ static int launch_gemm8(GemmParams p, hipStream_t stream, int group_env, int dbg
         hipLaunchKernelGGL(gemm256_8ph_kernel, dim3(tiles), dim3(512), LDS, stream, p, sp);
         return hipGetLastError() == hipSuccess ? 0 : -4;
     }
-    static float* ws_part[16] = {nullptr}; static int* ws_tick[16] = {nullptr}; static size_t ws_cap[16] = {0};
-    int dev = 0; if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return -5;
+    // Workspace: one (partials, tickets) pair PER STREAM -- FluxDiT launches GEMMs on two streams at once and a shared pair would race
+    // between them -- grown outside of any capture: a launch that would have to allocate while its stream is being captured into a
+    // graph falls back to the unsplit launch (same bits: the split changes only who sums the K ranges).
+    struct TailWs { int dev; hipStream_t stream; float* part; int* tick; size_t cap; };
+    static TailWs ws_tab[32] = {};
+    static int ws_n = 0;
+    int dev = 0; if (hipGetDevice(&dev) != hipSuccess) return -5;
     const size_t need = (size_t)r * best_ks;
-    if (ws_cap[dev] < need) {
-        if (ws_part[dev]) (void)hipFree(ws_part[dev]);
-        if (ws_tick[dev]) (void)hipFree(ws_tick[dev]);
-        ws_part[dev] = nullptr; ws_tick[dev] = nullptr; ws_cap[dev] = 0;
-        if (hipMalloc((void**)&ws_part[dev], need * 65536 * sizeof(float)) != hipSuccess) return -5;
-        if (hipMalloc((void**)&ws_tick[dev], 1024 * sizeof(int)) != hipSuccess) return -5;
-        ws_cap[dev] = need;
+    TailWs* ws = nullptr;
+    for (int i = 0; i < ws_n; ++i) if (ws_tab[i].dev == dev && ws_tab[i].stream == stream) ws = &ws_tab[i];
+    if (!ws || ws->cap < need) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        const bool capturing = hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+        if (capturing || (!ws && ws_n == 32)) {
+            hipLaunchKernelGGL(gemm256_8ph_kernel, dim3(tiles), dim3(512), LDS, stream, p, sp);
+            return hipGetLastError() == hipSuccess ? 0 : -4;
+        }
+        if (!ws) { ws = &ws_tab[ws_n++]; *ws = TailWs{dev, stream, nullptr, nullptr, 0}; }
+        if (ws->part) (void)hipFree(ws->part);        // hipFree waits for the launches that still read it
+        if (ws->tick) (void)hipFree(ws->tick);
+        ws->part = nullptr; ws->tick = nullptr; ws->cap = 0;
+        if (hipMalloc((void**)&ws->part, need * 65536 * sizeof(float)) != hipSuccess) return -5;
+        if (hipMalloc((void**)&ws->tick, 1024 * sizeof(int)) != hipSuccess) return -5;
+        ws->cap = need;
     }
-    if (hipMemsetAsync(ws_tick[dev], 0, (size_t)r * sizeof(int), stream) != hipSuccess) return -5;
+    if (hipMemsetAsync(ws->tick, 0, (size_t)r * sizeof(int), stream) != hipSuccess) return -5;
     hipLaunchKernelGGL(gemm256_8ph_kernel, dim3(nfull), dim3(512), LDS, stream, p, sp);
-    G8Split st = {best_ks, nfull, ws_part[dev], ws_tick[dev]};
+    G8Split st = {best_ks, nfull, ws->part, ws->tick};
     hipLaunchKernelGGL(gemm256_8ph_kernel, dim3(r * best_ks), dim3(512), LDS, stream, p, st);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
