@@ -25,9 +25,10 @@ def _ops():
     return ops
 
 
-def test_attention_full_size_sampled_rows_and_properties():
+@pytest.mark.parametrize("S", [S_FULL, 49664])     # BASELINE configs[1] texture pass (50 688 joint tokens) and configs[2] delight pass (49 664: no dual image)
+def test_attention_full_size_sampled_rows_and_properties(S):
     ops = _ops()
-    S, H = S_FULL, 4          # 4 of the 24 heads: same per-head work, 1/6 of the memory
+    H = 4                     # 4 of the 24 heads: same per-head work, 1/6 of the memory
     g = torch.Generator(device="cuda").manual_seed(11)
     q = torch.randn(H, S, 128, device="cuda", generator=g).to(BF)
     k = torch.randn(H, S, 128, device="cuda", generator=g).to(BF)
@@ -37,7 +38,7 @@ def test_attention_full_size_sampled_rows_and_properties():
     out = ops.attention(q, k, vt, S=S)                      # [S, H*128]
     torch.cuda.synchronize()
     assert torch.isfinite(out.float()).all()
-    rows = torch.tensor([0, 1, 31, 123, 255, 256, 4097, 25000, 40000, 50687])
+    rows = torch.tensor([0, 1, 31, 123, 255, 256, 4097, 25000, 40000, S - 1])
     for h in range(H):
         ref = dit_ref.sdpa(q[h:h + 1, rows].float().cpu(), k[h:h + 1].float().cpu(), v[h:h + 1].float().cpu(), em=False)[0]
         got = out[rows][:, h * 128:(h + 1) * 128].float().cpu()
@@ -53,6 +54,26 @@ def test_attention_full_size_sampled_rows_and_properties():
     torch.cuda.synchronize()
     d = (o2.float() - out.float()).abs().max().item()
     assert d < 2e-2, "permutation changed the result by %g" % d
+
+
+def test_attention_full_size_key_multiplicity_equals_the_expanded_sequence():
+    """text-token de-duplication at the bench's size: 64 text rows whose keys carry weight 2^3 + 50 176 image rows (S = 50 240 executed) must give
+    what the literal sequence gives (each text key 8 times: S = 50 688) -- for the image queries and for the text queries (softmax over n
+    identical keys = one key with weight n; the reference feeds identical prompt embeddings, pipeline.py:556-567)."""
+    ops = _ops()
+    H, S_d, n_txt, mult = 2, 50240, 64, 8
+    g = torch.Generator(device="cuda").manual_seed(5)
+    q = torch.randn(H, S_d, 128, device="cuda", generator=g).to(BF)
+    k = torch.randn(H, S_d, 128, device="cuda", generator=g).to(BF)
+    v = torch.randn(H, S_d, 128, device="cuda", generator=g).to(BF)
+    out_d = ops.attention(q, k, v.transpose(1, 2).contiguous(), S=S_d, key_bias_log2=math.log2(mult))
+    exp = lambda t: torch.cat([t[:, :n_txt].repeat(1, mult, 1), t[:, n_txt:]], dim=1).contiguous()
+    qe, ke, ve = exp(q), exp(k), exp(v)
+    out_e = ops.attention(qe, ke, ve.transpose(1, 2).contiguous(), S=S_d + n_txt * (mult - 1))
+    torch.cuda.synchronize()
+    d_img = (out_d[n_txt:].float() - out_e[n_txt * mult:].float()).abs().max().item()
+    d_txt = (out_d[:n_txt].float() - out_e[:n_txt].float()).abs().max().item()
+    assert d_img < 2e-2 and d_txt < 2e-2, "de-duplicated vs expanded sequence: image rows %g, text rows %g" % (d_img, d_txt)
 
 
 def _set_tile(v):
