@@ -13,16 +13,16 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _inputs(n_views, view_px):
+def _inputs(n_views, view_px, n_faces=20000):
     from unitex_amd.texturetools import camera, meshes
     from unitex_amd.texturetools.benchmarks import smooth_views
-    verts, faces, uvs = meshes.sphere_with_faces(20000)
+    verts, faces, uvs = meshes.sphere_with_faces(n_faces)
     c2ws, order = camera.generate_views_c2ws(n_views, 2.8)
     intr = camera.generate_intrinsics(1.0, 1.0, fov=False)
     return verts, faces, uvs, c2ws, order, intr, torch.from_numpy(smooth_views(n_views, view_px, view_px))
 
 
-def _backproject_worker(rank, world, port, n_views, q):
+def _backproject_worker(rank, world, port, n_views, q, n_faces=20000, view_px=256, atlas_px=512):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     import torch.distributed as dist
@@ -32,8 +32,8 @@ def _backproject_worker(rank, world, port, n_views, q):
         from unitex_amd.texturetools.video import VideoExporter
         dev = "cuda:0"
         torch.cuda.set_device(0)
-        verts, faces, uvs, c2ws, order, intr, images = _inputs(n_views, 256)
-        kw = dict(c2ws=c2ws, intrinsics=intr, image_attrs=images.to(dev), perspective=False, H=256, W=256, H2D=512, W2D=512,
+        verts, faces, uvs, c2ws, order, intr, images = _inputs(n_views, view_px, n_faces)
+        kw = dict(c2ws=c2ws, intrinsics=intr, image_attrs=images.to(dev), perspective=False, H=view_px, W=view_px, H2D=atlas_px, W2D=atlas_px,
                   filt_gradient_points=False, ray_normal_angle_threhold=100.0, return_layers=True)
         inv = NVDiffRendererInverse(device=dev, view_shard=(rank, world)).update_from_arrays(verts, faces, uvs)
         inv.index = list(order)
@@ -68,17 +68,18 @@ def _backproject_worker(rank, world, port, n_views, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_views", [(2, 6), (3, 8)])
-def test_view_sharded_backprojection_on_gpu_is_bit_identical_to_one_rank(world, n_views):
+@pytest.mark.parametrize("world,n_views,n_faces,view_px,atlas_px", [(2, 6, 20000, 256, 512), (3, 8, 20000, 256, 512), (2, 6, 50000, 1024, 2048)])
+def test_view_sharded_backprojection_on_gpu_is_bit_identical_to_one_rank(world, n_views, n_faces, view_px, atlas_px):
     """NVDiffRendererInverse.infer(view_shard=(rank, world)): each rank back-projects its block of the views with the HIP kernels,
     ONE all-gather of the 13 B/texel/view layers, composite + post-processing replicated -- the atlas, the per-view layers, the
     composite winner and the uint8 texture must equal the one-rank run bit for bit (reference renderer_inverse.py:44,
-    599-602 for the priority composite the gather feeds).  world 3 over the 8-view set covers the ragged split (3 + 3 + 2)."""
+    599-602 for the priority composite the gather feeds).  world 3 over the 8-view set covers the ragged split (3 + 3 + 2); the last
+    case is BASELINE configs[3]'s geometry (50 k-face mesh, six 1024^2 views, 2048^2 atlas) on two ranks."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29950 + (os.getpid() % 40) + world
-    procs = [ctx.Process(target=_backproject_worker, args=(r, world, port, n_views, q)) for r in range(world)]
+    procs = [ctx.Process(target=_backproject_worker, args=(r, world, port, n_views, q, n_faces, view_px, atlas_px)) for r in range(world)]
     for p in procs:
         p.start()
     res = q.get(timeout=600)
