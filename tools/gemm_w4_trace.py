@@ -12,11 +12,19 @@ M, N, K = 50688, 3072, 3072
 A = (torch.randn(M, K, device=dev) / math.sqrt(K)).to(torch.bfloat16); B = torch.randn(N, K, device=dev).to(torch.bfloat16)
 bias = torch.randn(N, device=dev).to(torch.bfloat16); C = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
 _lib.set_option("UTX_GEMM_TILE", 2564)
-for wg, abl in ((0, 144), (0, 400)):
-    print("ABL", abl); _lib.set_option("UTX_GEMM_DEBUG", abl << 5); _lib.set_option("UTX_GEMM_PERS_SCHED", 100 + wg)
+from unitex_amd.flux.ops import make_gemm_desc, ptr
+import ctypes as C_
+lib = _lib.load_library(); ctx = ops.get_ctx(0)
+trace = torch.zeros(3 * 4000, dtype=torch.int64, device=dev)
+for wg, abl in ((0, 128), (0, 144), (100, 128)):
+    print("ABL", abl, "workgroup", wg); _lib.set_option("UTX_GEMM_DEBUG", abl << 5); _lib.set_option("UTX_GEMM_PERS_SCHED", 100 + wg)
+    d = make_gemm_desc(A, B, C, bias=bias)
+    d.zero_page = ptr(trace)
     for _ in range(3):
-        C.zero_(); ops.gemm(A, B, out=C, bias=bias); torch.cuda.synchronize()
-    t = C.view(torch.int64).flatten()[:3 * 4000].cpu().numpy().reshape(-1, 3)
+        trace.zero_()
+        rc = lib.utx_gemm_bf16(ctx.handle, C_.byref(d), ctx.stream()); assert rc == 0, rc
+        torch.cuda.synchronize()
+    t = trace.cpu().numpy().reshape(-1, 3)
     n = int(np.argmax((t[:, 1] == 0)) if (t[:, 1] == 0).any() else len(t))
     t = t[:n]
     tag, wall, cyc = t[:, 0], (t[:, 1] - t[0, 1]) * 0.01, t[:, 2] - t[0, 2]
@@ -28,5 +36,5 @@ for wg, abl in ((0, 144), (0, 400)):
         ss = np.diff(wall[start:i + 1])          # sub-stage durations of this tile (last = up to the epilogue start)
         cc = np.diff(cyc[start:i + 1])
         epi = wall[i + 1] - wall[i]
-        print("  tile %d: %3d sub-stages, mean %.3f us (first 4: %s, last 4: %s), cycles/sub-stage mean %.0f -> %.2f GHz | epilogue %.2f us (%d cycles)" % (
+        print("  tile %d: %3d K-tiles, mean %.3f us (first 4: %s, last 4: %s), cycles/K-tile mean %.0f -> %.2f GHz | epilogue %.2f us (%d cycles)" % (
             k, len(ss), ss.mean(), " ".join("%.2f" % x for x in ss[:4]), " ".join("%.2f" % x for x in ss[-4:]), cc.mean(), cc.sum() / ss.sum() * 1e-3, epi, cyc[i + 1] - cyc[i]))

@@ -813,11 +813,12 @@ extern "C" int utx_launch_gemm_bf16(const GemmParams* hp, hipStream_t stream) {
     bool use256 = ok256 && tiles256 >= 192;
     if (tile_env == 128) use256 = false;
     if ((tile_env == 256 || tile_env == 2562 || tile_env == 2560 || tile_env == 2564) && ok256) use256 = true;   // 2562 = the 2-barrier 256^2 kernel, 2560 = force the persistent kernel (A/B testing)
-    // default for the large-M linears: the persistent continuous-stream kernel (gemm_pers.hip); UTX_GEMM_TILE=256 keeps the
-    // per-tile-launch 8-phase kernel for A/B (bit-identical outputs), and the timing ablations / tail split only exist there
-    // (same-process interleaved A/B against the per-tile 8-phase kernel and hipBLASLt: profiles/r02_gemm_ab_v3.log / _v4.log)
-    if (use256 && tile_env == 2564) return utx_launch_gemm_w4(p, stream);   // one wave per SIMD (gemm_w4.hip)
-    if (use256 && (tile_env == 0 || tile_env == 2560) && (dbg_env & 3) == 0 && g_utx_opt.gemm_tailsplit == 0)
+    // default for the large-M linears: the persistent one-wave-per-SIMD kernel (gemm_w4.hip; +5...10 % over the persistent 8-wave kernel on the FLUX
+    // shapes, profiles/r02_gemm_w4_check_v7.log); UTX_GEMM_TILE=2560 keeps the persistent 8-wave kernel (gemm_pers.hip), 256 the per-tile-launch
+    // 8-phase kernel, for A/B (all bit-identical); the timing ablations / tail split only exist in the latter.
+    if (use256 && (tile_env == 0 || tile_env == 2564) && (dbg_env & 3) == 0 && g_utx_opt.gemm_tailsplit == 0)
+        return utx_launch_gemm_w4(p, stream);
+    if (use256 && tile_env == 2560 && (dbg_env & 3) == 0 && g_utx_opt.gemm_tailsplit == 0)
         return utx_launch_gemm_pers(p, stream);
     if (use256 && tile_env != 2562) return launch_gemm8(p, stream, group_env, dbg_env);
     if (use256) return launch_gemm<256, 256, 2, 4>(p, stream, group_env, dbg_env);

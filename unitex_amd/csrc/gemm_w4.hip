@@ -44,7 +44,7 @@
 #include "common.h"
 #include "kernels.h"
 
-#define W4_SUB 32768
+#define W4_STAGE 65536      // one K-tile of 64 k: A[256][64] at +0, B[256][64] at +32768, bf16, 128-byte rows
 
 __device__ __forceinline__ float w4_gelu_tanh(float x) {   // same expression as gemm.hip
     const float k0 = 0.7978845608028654f, k1 = 0.044715f;
@@ -63,6 +63,14 @@ __device__ __forceinline__ void w4_dma_m0(unsigned voff, const char* sbase) {
 
 #define W4_FENCE() __builtin_amdgcn_sched_barrier(0)
 
+// a wave-uniform pointer the compiler computed with vector instructions (it has no scalar 64-bit multiply) back into SGPRs: the DMA takes
+// its base as an "s" operand
+__device__ __forceinline__ const char* w4_uniform(const char* p) {
+    const unsigned long v = (unsigned long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const char*)(((unsigned long)hi << 32) | lo);
+}
+
 // ABL (ablation build only, wrong results): 1 = no DMA in the loop, 2 = no fragment reads in the loop, 4 = no vmcnt wait / barrier, 8 = no epilogue,
 // 16 = epilogue without its C stores, 32 = the DMA cursor parked from the start (every DMA re-reads the same bytes)
 template <bool GATED, int ABL = 0>
@@ -75,16 +83,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int l31 = lane & 31, lh = lane >> 5;
     const int G = gridDim.x;
     const int wid = xcd_remap(blockIdx.x, G);
-    // ABL 128 (ablation build): workgroup 0 / wave 0 writes a timeline into the C buffer instead of C (use with ABL 16 = no C stores):
+    // ABL 128 (ablation build): one workgroup's wave 0 writes a timeline into the buffer passed in the descriptor's (otherwise unused) zero_page field:
     // per sub-stage the 100 MHz wall clock and the shader clock, a negative marker pair around every epilogue
-    long* const trace = ((ABL & 128) && blockIdx.x == (unsigned)trace_wg && tid == 0) ? (long*)p.C : nullptr;
+    long* const trace = ((ABL & 128) && blockIdx.x == (unsigned)trace_wg && tid == 0) ? (long*)p.zero_page : nullptr;
     int trace_n = 0;
 #define W4_TRACE(tag_) do { if ((ABL & 128) && trace && trace_n < 4000) { trace[3 * trace_n] = (tag_); trace[3 * trace_n + 1] = wall_clock64(); trace[3 * trace_n + 2] = __builtin_readcyclecounter(); ++trace_n; } } while (0)
 
     const int ntn = p.ntn & 0xffff, group_m = (p.ntn >> 16) & 0xff;
     const int ntm_ = (p.M + 255) / 256;
     const int per_group = group_m * ntn;
-    const int nss1 = p.K / 32, nss2 = p.K2 / 32;
+    const int nss1 = p.K / 64, nss2 = p.K2 / 64;      // K-tiles of the base / LoRA segment
     const unsigned ldaB = (unsigned)p.lda * 2, ldbB = (unsigned)p.ldb * 2, lda2B = (unsigned)p.lda2 * 2, ldb2B = (unsigned)p.ldb2 * 2;
 
 #define W4_TILE_ORIGIN(w_, m0_, n0_)                                                       \
@@ -97,31 +105,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         (n0_) = tn_ * 256;                                                                 \
     } while (0)
 
-    // ---- staging cursor.  DMA piece pc = wave + 4 d (d = 0..3) of an operand = rows 16 pc .. 16 pc + 15; lane -> row lane >> 2,
-    // LDS slot lane & 3 <- global chunk (lane & 3) ^ f(row).  One scalar base per operand (advanced 64 B per sub-stage), four per-lane
-    // byte offsets per operand (recomputed per tile / K-segment: strides change with the LoRA segment, rows >= M re-read row M-1).
-    const int drow = lane >> 2;
-    const unsigned dchunk = (unsigned)(((lane & 3) ^ (((drow >> 2) & 3) ^ (3 * (wave & 1)))) << 4);
+    // ---- staging cursor.  A K-tile (64 k) of an operand = 256 rows x 128 B = 32 DMA pieces of 8 rows; wave w issues pieces w, w + 4, ...,
+    // w + 28: lane -> row lane >> 3 of the piece, LDS chunk lane & 7 <- global chunk (lane & 7) ^ ((row >> 1) & 7) (the swizzle of gemm.hip's
+    // 128-byte rows; (row >> 1) & 7 = (4 (piece & 1) + (lane >> 4)) & 7 and piece & 1 = wave & 1).  FULL 128-byte row segments per request:
+    // tools/l2_fill_probe.hip measures 87-100 GB/s per CU for this pattern with every CU streaming from L2 and 34-44 for 64-byte segments
+    // (the first version of this kernel staged 32-k sub-stages and was bound by exactly that: profiles/r02_l2_fill_probe.log).
+    // One scalar base per operand (advanced 128 B per K-tile), eight per-lane byte offsets per operand (recomputed per tile / K-segment:
+    // strides change with the LoRA segment, rows >= M re-read row M-1).
+    const int drow = lane >> 3;
+    const unsigned dchunk = (unsigned)(((lane & 7) ^ ((4 * (wave & 1) + (drow >> 1)) & 7)) << 4);
     const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
     int s_tile = wid, s_ss = 0, s_seg_end = 0, s_seg = 1, s_m0 = 0, s_n0 = 0, s_slot = 0;
     bool s_lora = false;
     const char *s_pA = nullptr, *s_pB = nullptr;
-    unsigned voA0 = 0, voA1 = 0, voA2 = 0, voA3 = 0, voB0 = 0, voB1 = 0, voB2 = 0, voB3 = 0;
-#define W4_ROWOFF_A(d_, stride_) ((unsigned)(((s_m0 + 16 * (wave + 4 * (d_)) + drow > p.M - 1) ? p.M - 1 - s_m0 : 16 * (wave + 4 * (d_)) + drow)) * (stride_) + dchunk)
-#define W4_ROWOFF_B(d_, stride_) ((unsigned)(16 * (wave + 4 * (d_)) + drow) * (stride_) + dchunk)
+    unsigned voA0 = 0, voA1 = 0, voA2 = 0, voA3 = 0, voA4 = 0, voA5 = 0, voA6 = 0, voA7 = 0;
+    unsigned voB0 = 0, voB1 = 0, voB2 = 0, voB3 = 0, voB4 = 0, voB5 = 0, voB6 = 0, voB7 = 0;
+#define W4_ROWOFF_A(d_, stride_) ((unsigned)(((s_m0 + 8 * (wave + 4 * (d_)) + drow > p.M - 1) ? p.M - 1 - s_m0 : 8 * (wave + 4 * (d_)) + drow)) * (stride_) + dchunk)
+#define W4_ROWOFF_B(d_, stride_) ((unsigned)(8 * (wave + 4 * (d_)) + drow) * (stride_) + dchunk)
+#define W4_SET_OFFS(sa_, sb_)                                                                              \
+    do {                                                                                                   \
+        voA0 = W4_ROWOFF_A(0, sa_); voA1 = W4_ROWOFF_A(1, sa_); voA2 = W4_ROWOFF_A(2, sa_); voA3 = W4_ROWOFF_A(3, sa_); \
+        voA4 = W4_ROWOFF_A(4, sa_); voA5 = W4_ROWOFF_A(5, sa_); voA6 = W4_ROWOFF_A(6, sa_); voA7 = W4_ROWOFF_A(7, sa_); \
+        voB0 = W4_ROWOFF_B(0, sb_); voB1 = W4_ROWOFF_B(1, sb_); voB2 = W4_ROWOFF_B(2, sb_); voB3 = W4_ROWOFF_B(3, sb_); \
+        voB4 = W4_ROWOFF_B(4, sb_); voB5 = W4_ROWOFF_B(5, sb_); voB6 = W4_ROWOFF_B(6, sb_); voB7 = W4_ROWOFF_B(7, sb_); \
+    } while (0)
 #define W4_SEG1_SETUP()                                                                                    \
     do {                                                                                                   \
-        s_pA = (const char*)p.A + (long)s_m0 * ldaB;  s_pB = (const char*)p.B + (long)s_n0 * ldbB;         \
-        voA0 = W4_ROWOFF_A(0, ldaB); voA1 = W4_ROWOFF_A(1, ldaB); voA2 = W4_ROWOFF_A(2, ldaB); voA3 = W4_ROWOFF_A(3, ldaB); \
-        voB0 = W4_ROWOFF_B(0, ldbB); voB1 = W4_ROWOFF_B(1, ldbB); voB2 = W4_ROWOFF_B(2, ldbB); voB3 = W4_ROWOFF_B(3, ldbB); \
+        s_pA = w4_uniform((const char*)p.A + (long)s_m0 * ldaB);  s_pB = w4_uniform((const char*)p.B + (long)s_n0 * ldbB); \
+        W4_SET_OFFS(ldaB, ldbB);                                                                           \
         s_ss = 0; s_seg_end = nss1; s_seg = 1;                                                             \
     } while (0)
 #define W4_SEG2_SETUP()                                                                                    \
     do {                                                                                                   \
-        s_pA = (const char*)p.A2 + (long)((s_n0 / p.lora_seg_n) * p.K2) * 2 + (long)s_m0 * lda2B;          \
-        s_pB = (const char*)p.B2 + (long)s_n0 * ldb2B;                                                     \
-        voA0 = W4_ROWOFF_A(0, lda2B); voA1 = W4_ROWOFF_A(1, lda2B); voA2 = W4_ROWOFF_A(2, lda2B); voA3 = W4_ROWOFF_A(3, lda2B); \
-        voB0 = W4_ROWOFF_B(0, ldb2B); voB1 = W4_ROWOFF_B(1, ldb2B); voB2 = W4_ROWOFF_B(2, ldb2B); voB3 = W4_ROWOFF_B(3, ldb2B); \
+        s_pA = w4_uniform((const char*)p.A2 + (long)((s_n0 / p.lora_seg_n) * p.K2) * 2 + (long)s_m0 * lda2B); \
+        s_pB = w4_uniform((const char*)p.B2 + (long)s_n0 * ldb2B);                                         \
+        W4_SET_OFFS(lda2B, ldb2B);                                                                         \
         s_ss = 0; s_seg_end = nss2; s_seg = 2;                                                             \
     } while (0)
 #define W4_STAGE_SETUP()                                                                   \
@@ -131,21 +149,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         W4_SEG1_SETUP();                                                                   \
     } while (0)
 #define W4_SVALID (s_tile < ntiles)
-    // the four DMAs of operand A (isb_ = 0) / B (1) of the cursor's sub-stage, one at a time (d_ literal)
-#define W4_DMA_LDS(isb_, d_) (lds0 + (unsigned)s_slot * W4_SUB + (isb_) * 16384u + (unsigned)(wave + 4 * (d_)) * 1024u)
-#define W4_DMA_M0(isb_, d_)                                                                                \
-    w4_dma_m0((isb_) ? ((d_) == 0 ? voB0 : (d_) == 1 ? voB1 : (d_) == 2 ? voB2 : voB3)                     \
-                     : ((d_) == 0 ? voA0 : (d_) == 1 ? voA1 : (d_) == 2 ? voA2 : voA3),                    \
-              (isb_) ? s_pB : s_pA)
-#define W4_DMA(isb_, d_)                                                                                   \
-    w4_dma(lds0 + (unsigned)s_slot * W4_SUB + (isb_) * 16384u + (unsigned)(wave + 4 * (d_)) * 1024u,       \
-           (isb_) ? ((d_) == 0 ? voB0 : (d_) == 1 ? voB1 : (d_) == 2 ? voB2 : voB3)                        \
-                  : ((d_) == 0 ? voA0 : (d_) == 1 ? voA1 : (d_) == 2 ? voA2 : voA3),                       \
-           (isb_) ? s_pB : s_pA)
+    // DMA d_ (0..7, literal) of operand A (isb_ = 0) / B (1) of the cursor's K-tile
+#define W4_VO(isb_, d_) ((isb_) ? ((d_) == 0 ? voB0 : (d_) == 1 ? voB1 : (d_) == 2 ? voB2 : (d_) == 3 ? voB3 : (d_) == 4 ? voB4 : (d_) == 5 ? voB5 : (d_) == 6 ? voB6 : voB7) \
+                                : ((d_) == 0 ? voA0 : (d_) == 1 ? voA1 : (d_) == 2 ? voA2 : (d_) == 3 ? voA3 : (d_) == 4 ? voA4 : (d_) == 5 ? voA5 : (d_) == 6 ? voA6 : voA7))
+#define W4_DMA_LDS(isb_, d_) (lds0 + (unsigned)s_slot * W4_STAGE + (isb_) * 32768u + (unsigned)(wave + 4 * (d_)) * 1024u)
+#define W4_DMA_M0(isb_, d_) w4_dma_m0(W4_VO(isb_, d_), (isb_) ? s_pB : s_pA)
+#define W4_DMA(isb_, d_) w4_dma(W4_DMA_LDS(isb_, d_), W4_VO(isb_, d_), (isb_) ? s_pB : s_pA)
 #define W4_STAGE_ADVANCE()                                                                 \
     do {                                                                                   \
-        s_pA += 64; s_pB += 64;                                                            \
-        s_slot = (s_slot + 1) & 3;                                                         \
+        s_pA += 128; s_pB += 128;                                                          \
+        s_slot ^= 1;                                                                       \
         ++s_ss;                                                                            \
         if (s_ss == s_seg_end) {                                                           \
             if (s_seg == 1 && s_lora) {                                                    \
@@ -156,12 +169,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }                                                                              \
         }                                                                                  \
     } while (0)
-    // past the last tile the cursor keeps issuing (the loop has no conditional DMA and one vmcnt count): it re-reads the first 64 bytes
-    // of the first rows of A and B into ring slots nobody reads any more
+    // past the last tile the cursor keeps issuing (the loop has no conditional DMA): it re-reads the first 128 bytes of the first rows
+    // of A and B into ring slots nobody reads any more
 #define W4_PARK()                                                                          \
     do {                                                                                   \
         s_pA = (const char*)p.A; s_pB = (const char*)p.B;                                  \
-        voA0 = voA1 = voA2 = voA3 = voB0 = voB1 = voB2 = voB3 = dchunk;                    \
+        voA0 = voA1 = voA2 = voA3 = voA4 = voA5 = voA6 = voA7 = dchunk;                    \
+        voB0 = voB1 = voB2 = voB3 = voB4 = voB5 = voB6 = voB7 = dchunk;                    \
         s_ss = 0; s_seg_end = 0x7fffffff; s_seg = 2;                                       \
     } while (0)
 
@@ -190,10 +204,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                                 else asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x_) : "a"(acc[jn_][im_][r_])); x_; })
     W4_ZERO_ACC()
 
-    // fragment read offsets inside a sub-stage: row * 64 + ((2 kk + lh) ^ f(row)) * 16; f depends on l31 only (row blocks are multiples of 32)
-    const int fsw = ((l31 >> 2) & 3) ^ (3 * ((l31 >> 4) & 1));
-    const int xk0 = ((0 + lh) ^ fsw) << 4, xk1 = ((2 + lh) ^ fsw) << 4;
-    const int arow = (wm * 128 + l31) * 64, brow = 16384 + (wn * 128 + l31) * 64;
+    // fragment read offsets inside a stage: row * 128 + ((2 kk + lh) ^ swz) * 16, swz = (row >> 1) & 7 = (l31 >> 1) & 7 (row blocks are multiples of 32)
+    const int fsw = (l31 >> 1) & 7;
+    const int xk0 = ((0 + lh) ^ fsw) << 4, xk1 = ((2 + lh) ^ fsw) << 4, xk2 = ((4 + lh) ^ fsw) << 4, xk3 = ((6 + lh) ^ fsw) << 4;
+    const int arow = (wm * 128 + l31) * 128, brow = 32768 + (wn * 128 + l31) * 128;
     bf16x8 fa0[4], fb0[4], fa1[4], fb1[4];
 #define W4_LD(off_) (*reinterpret_cast<const bf16x8*>(smem + (off_)))
     // read number r_ (0..7) of a K-step: B0 A0 A1 B1 A2 A3 B2 B3 -- the first MFMAs of the next K-step need B0, A0, A1 first
@@ -201,12 +215,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     do {                                                                                                   \
         if ((r_) == 0) FB_[0] = W4_LD((base_) + brow + (xk_));                                             \
         if ((r_) == 1) FA_[0] = W4_LD((base_) + arow + (xk_));                                             \
-        if ((r_) == 2) FA_[1] = W4_LD((base_) + arow + 2048 + (xk_));                                      \
-        if ((r_) == 3) FB_[1] = W4_LD((base_) + brow + 2048 + (xk_));                                      \
-        if ((r_) == 4) FA_[2] = W4_LD((base_) + arow + 4096 + (xk_));                                      \
-        if ((r_) == 5) FA_[3] = W4_LD((base_) + arow + 6144 + (xk_));                                      \
-        if ((r_) == 6) FB_[2] = W4_LD((base_) + brow + 4096 + (xk_));                                      \
-        if ((r_) == 7) FB_[3] = W4_LD((base_) + brow + 6144 + (xk_));                                      \
+        if ((r_) == 2) FA_[1] = W4_LD((base_) + arow + 4096 + (xk_));                                      \
+        if ((r_) == 3) FB_[1] = W4_LD((base_) + brow + 4096 + (xk_));                                      \
+        if ((r_) == 4) FA_[2] = W4_LD((base_) + arow + 8192 + (xk_));                                      \
+        if ((r_) == 5) FA_[3] = W4_LD((base_) + arow + 12288 + (xk_));                                     \
+        if ((r_) == 6) FB_[2] = W4_LD((base_) + brow + 8192 + (xk_));                                      \
+        if ((r_) == 7) FB_[3] = W4_LD((base_) + brow + 12288 + (xk_));                                     \
     } while (0)
     // MFMA number i_ (0..15) of a K-step: (jn, im) in the order that touches the fragments as they arrive
 #define W4_MF(i_, FA_, FB_)                                                                                \
@@ -241,13 +255,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // 16 dwords (32 bf16 = the columns of one jn block) through the scalar cache; hipcc would use vector loads (it cannot prove
     // the array is not written by this kernel), whose vmcnt waits would drain the staging pipeline
 #define W4_SLOAD16(dst_, ptr_) asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dst_) : "s"(ptr_) : "memory")
+    // the bias of the wave's 128 columns (4 x 16 dwords) in ONE request burst and one wait per tile: sixteen loads waited for one by one (one per
+    // 32-row block and jn) cost ~3k of the epilogue's 10k cycles (tools/gemm_w4_trace.py)
+#define W4_SLOAD64(d0_, d1_, d2_, d3_, ptr_)                                                                           \
+    asm volatile("s_load_dwordx16 %0, %4, 0x0\n\ts_load_dwordx16 %1, %4, 0x40\n\ts_load_dwordx16 %2, %4, 0x80\n\ts_load_dwordx16 %3, %4, 0xc0\n\t" \
+                 "s_waitcnt lgkmcnt(0)" : "=&s"(d0_), "=&s"(d1_), "=&s"(d2_), "=&s"(d3_) : "s"(ptr_) : "memory")
     // C leaves through a per-wave 8 KB LDS buffer (the 32 KB of LDS above the ring), one 32-row block at a time: in accumulator layout
     // a lane owns 16 bytes of ONE row per store and a store instruction touches 32 rows x 32 B -- measured 10-12 us per tile against
     // 3 us when every store instruction writes 4 rows x 256 contiguous bytes (profiles/r02_gemm_w4_probe_v4.log).  Written [32 rows]
     // [16 chunks of 16 B] with chunk ^= row & 15 (ds_write_b128 lane groups are 8 consecutive lanes = 8 rows of one chunk column),
     // read back as lane -> (row 4t + lane/16, chunk lane%16): both conflict-free.  The residual of the gated epilogue is read in the
     // same lane -> (row, chunk) layout, so its loads are coalesced the same way.
-    char* const stg = smem + 4 * W4_SUB + wave * 8192;
+    char* const stg = smem + 2 * W4_STAGE + wave * 8192;
     // residual / gate loads hipcc does not see (a visible load would be waited for with vmcnt(0): a drain of the staging pipeline)
 #define W4_LOAD16_ASM(dst_, ptr_) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst_) : "v"(ptr_) : "memory")
 #define W4_WAIT_RES(n_, r_) do { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r_) : "n"(n_) : "memory"); W4_FENCE(); } while (0)
@@ -258,7 +277,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define W4_EPI_WRITE(im_, GELU_)                                                                                       \
         _Pragma("unroll") for (int jn_ = 0; jn_ < 4; ++jn_) {                                                          \
             w4_u32x16 bw_;                                                                                             \
-            W4_SLOAD16(bw_, ebias + 32 * jn_);                                                                         \
+            if constexpr (GATED) W4_SLOAD16(bw_, ebias + 32 * jn_);     /* the gated kernel has no SGPRs to spare for the burst */ \
+            else bw_ = jn_ == 0 ? bq0 : jn_ == 1 ? bq1 : jn_ == 2 ? bq2 : bq3;                                         \
             _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_) {                                                         \
                 float b8_[8];                                                                                          \
                 _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_)                                                       \
@@ -377,8 +397,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const unsigned cvo = (unsigned)((elane >> 4) * (unsigned)ldc * 2u + (unsigned)(elane & 15) * 16u);              \
         const char* const rub = (const char*)pres + ((long)(c_m0 + wm * 128) * p.ldres + c_n0 + wn * 128) * 2;         \
         const unsigned rvo = (unsigned)((elane >> 4) * (unsigned)p.ldres * 2u + (unsigned)(elane & 15) * 16u);          \
+        w4_u32x16 bq0, bq1, bq2, bq3;                                                                                  \
+        if constexpr (!GATED) W4_SLOAD64(bq0, bq1, bq2, bq3, ebias);                                                   \
         if constexpr (GATED) {                                                                                         \
-            W4_WAIT_RES(12, gq);      /* >= 16 DMAs are younger than the gate request of this tile (K >= 64) */          \
+            W4_WAIT_RES(8, gq);       /* the eight DMAs of the tile's last K-step 3 are younger than the gate request (and every K-tile drains vmcnt) */ \
             if (full) {                                                                                                \
                 w4_u32x4 ra0, ra1, ra2, ra3, ra4, ra5, ra6, ra7, rb0, rb1, rb2, rb3, rb4, rb5, rb6, rb7;               \
                 W4_RES_LOAD(ra0, 0, 0); W4_RES_LOAD(ra1, 0, 1); W4_RES_LOAD(ra2, 0, 2); W4_RES_LOAD(ra3, 0, 3);         \
@@ -400,17 +422,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         W4_ZERO_ACC()                                                                                                  \
     } while (0)
 
-    // ---- prologue: sub-stages 0, 1, 2 of the stream requested; sub-stage 0 landed; F0 of sub-stage 0 resident
-#define W4_STAGE_ALL()                                                                     \
-    do {                                                                                   \
-        W4_DMA(0, 0); W4_DMA(0, 1); W4_DMA(0, 2); W4_DMA(0, 3);                            \
-        W4_DMA(1, 0); W4_DMA(1, 1); W4_DMA(1, 2); W4_DMA(1, 3);                            \
-        W4_STAGE_ADVANCE();                                                                \
-    } while (0)
+    // ---- prologue: K-tile 0 complete and landed, operand A of K-tile 1 requested; F0 = fragments of K-step 0 of K-tile 0
+#define W4_STAGE_HALF(isb_) do { W4_DMA(isb_, 0); W4_DMA(isb_, 1); W4_DMA(isb_, 2); W4_DMA(isb_, 3); W4_DMA(isb_, 4); W4_DMA(isb_, 5); W4_DMA(isb_, 6); W4_DMA(isb_, 7); } while (0)
     if (W4_SVALID && !(ABL & 32)) W4_STAGE_SETUP(); else W4_PARK();      // ABL 32: every DMA re-reads the same 1 KB (issue + LDS write, no memory traffic)
-    constexpr int LEAD = (ABL & 256) ? 2 : 3;          // sub-stages the DMA cursor runs ahead (ABL 256: timing experiment with 2)
-    for (int i = 0; i < LEAD; ++i) W4_STAGE_ALL();
-    if (LEAD == 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    W4_STAGE_HALF(0); W4_STAGE_HALF(1); W4_STAGE_ADVANCE();
+    W4_DMA(0, 0); W4_DMA(0, 1); W4_DMA(0, 2); W4_DMA(0, 3);         // what K-step 3 of a K-tile -1 would have requested
+#ifdef W4_SPREAD3
+    W4_DMA(0, 4); W4_DMA(0, 5);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+#else
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#endif
     W4_COMPUTE_SETUP();
     W4_GATE_FETCH();
     __builtin_amdgcn_s_barrier();
@@ -420,49 +442,68 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     W4_FENCE();
 
-    int post_epi = 0;          // > 0: this many of the coming sub-stages still have the last epilogue's 32 stores inside their vmcnt window
+    // One K-tile = four K-steps of 16 MFMAs.  Slot i (behind MFMA i) of a K-step carries one fragment read (i < 8: the K-step after this one)
+    // or one DMA (i >= 8, K-steps 0 and 3 only); the LDS address of a DMA is put into M0 in front of the MFMA before it (the wait state M0 needs).
+    //   K-step 0: MFMAs on F0 | reads -> F1 (kk 1) | 8 DMAs: operand B of the cursor's K-tile (= compute K-tile + 1), cursor advances
+    //   K-step 1: MFMAs on F1 | reads -> F0 (kk 2)
+    //   K-step 2: MFMAs on F0 | reads -> F1 (kk 3); lgkmcnt(0) [every read of this stage retired]; vmcnt(0) [K-tile + 1 landed]; s_barrier
+    //   K-step 3: MFMAs on F1 | reads -> F0 (kk 0 of the NEXT stage) | 8 DMAs: operand A of K-tile + 2 into THIS stage (free since the barrier)
+    // Every DMA is issued >= 2 K-steps (~0.65 us) before the wait that needs it; tools/l2_fill_probe.hip: 0.3-0.4 us loaded L2 latency.
     for (;;) {
         W4_TRACE(c_ss);
-        const int cb = c_slot * W4_SUB, nb = ((c_slot + 1) & 3) * W4_SUB;
-        // slot i (behind MFMA i) of a K-step: the DMAs at 3, 7, 11, 15 -- spread evenly: the four waves run in step, and 4 x 1 KB per 64
-        // cycles is all the CU's vector-memory path takes (profiles/r02_gemm_w4_probe_v0.log: bunched, a DMA cost ~50 MFMA-pipe cycles) --
-        // the eight fragment reads in the other slots from 0 on (read r in slot r + r / 3)
-#define W4_RIDX(i_) ((i_) - ((i_) >> 2))
-        // ---- K-step A
-#define W4_KA(i_)                                                                          \
-        if (((i_) & 3) == 3 && !(ABL & 1)) W4_MF_M0(i_, fa0, fb0, W4_DMA_LDS(0, (i_) >> 2)); else W4_MF(i_, fa0, fb0); \
-        W4_FENCE();                                                                        \
-        if (((i_) & 3) != 3 && W4_RIDX(i_) < 8 && !(ABL & 2)) W4_READ(W4_RIDX(i_), fa1, fb1, cb, xk1); \
-        if (((i_) & 3) == 3 && !(ABL & 1)) W4_DMA_M0(0, (i_) >> 2);                         \
+        const int cb = c_slot * W4_STAGE, nb = (c_slot ^ 1) * W4_STAGE;
+        // DMA schedule: piece p = 0..15 of the cursor's K-tile (p < 8: operand A piece p, else operand B piece p - 8), never more than one DMA per two
+        // MFMAs (a burst of eight 1 KB requests per wave backs the vector-memory path up into the issuing wave, which has no partner wave to hide behind):
+        //   K-step 3: p 0..3 behind MFMAs 9, 11, 13, 15 | K-step 0: p 4..11 behind the odd MFMAs | K-step 1: p 12..15 behind MFMAs 1, 3, 5, 7, then the cursor advances
+#ifdef W4_SPREAD3      /* experiment: one DMA per three MFMAs over K-steps 3, 0, 1 (6 + 5 + 5); the last piece then has 0.37 us to land */
+#define W4_PIECE_OF(ks_, i_) ((ks_) == 3 ? (((i_) % 3) == 0 ? (i_) / 3 : -1) : (ks_) == 0 ? (((i_) % 3) == 2 ? 6 + (i_) / 3 : -1) \
+                              : (ks_) == 1 ? ((((i_) % 3) == 1 && (i_) < 15) ? 11 + (i_) / 3 : -1) : -1)
+#else
+#define W4_PIECE_OF(ks_, i_) ((ks_) == 3 ? (((i_) >= 9 && ((i_) & 1)) ? ((i_) - 9) / 2 : -1) : (ks_) == 0 ? (((i_) & 1) ? 4 + ((i_) - 1) / 2 : -1) \
+                              : (ks_) == 1 ? ((((i_) & 1) && (i_) < 8) ? 12 + ((i_) - 1) / 2 : -1) : -1)
+#endif
+#define W4_KSTEP(i_, ks_, FA_, FB_, FAn_, FBn_, base_, xk_)                                                \
+        {                                                                                                  \
+            constexpr int pc_ = (ABL & 1) ? -1 : W4_PIECE_OF(ks_, i_);                                     \
+            constexpr int isb_ = pc_ >= 8 ? 1 : 0, d_ = pc_ < 0 ? 0 : (pc_ & 7);                           \
+            if constexpr (pc_ >= 0) W4_MF_M0(i_, FA_, FB_, W4_DMA_LDS(isb_, d_)); else W4_MF(i_, FA_, FB_); \
+            W4_FENCE();                                                                                    \
+            if ((i_) < 8 && !(ABL & 2)) W4_READ(i_, FAn_, FBn_, base_, xk_);                               \
+            if constexpr (pc_ >= 0) W4_DMA_M0(isb_, d_);                                                   \
+            W4_FENCE();                                                                                    \
+        }
+#define W4_KSTEP16(ks_, FA_, FB_, FAn_, FBn_, base_, xk_)                                                  \
+        W4_KSTEP(0, ks_, FA_, FB_, FAn_, FBn_, base_, xk_) W4_KSTEP(1, ks_, FA_, FB_, FAn_, FBn_, base_, xk_)   \
+        W4_KSTEP(2, ks_, FA_, FB_, FAn_, FBn_, base_, xk_) W4_KSTEP(3, ks_, FA_, FB_, FAn_, FBn_, base_, xk_)   \
+        W4_KSTEP(4, ks_, FA_, FB_, FAn_, FBn_, base_, xk_) W4_KSTEP(5, ks_, FA_, FB_, FAn_, FBn_, base_, xk_)   \
+        W4_KSTEP(6, ks_, FA_, FB_, FAn_, FBn_, base_, xk_) W4_KSTEP(7, ks_, FA_, FB_, FAn_, FBn_, base_, xk_)   \
+        W4_KSTEP(8, ks_, FA_, FB_, FAn_, FBn_, base_, xk_) W4_KSTEP(9, ks_, FA_, FB_, FAn_, FBn_, base_, xk_)   \
+        W4_KSTEP(10, ks_, FA_, FB_, FAn_, FBn_, base_, xk_) W4_KSTEP(11, ks_, FA_, FB_, FAn_, FBn_, base_, xk_) \
+        W4_KSTEP(12, ks_, FA_, FB_, FAn_, FBn_, base_, xk_) W4_KSTEP(13, ks_, FA_, FB_, FAn_, FBn_, base_, xk_) \
+        W4_KSTEP(14, ks_, FA_, FB_, FAn_, FBn_, base_, xk_) W4_KSTEP(15, ks_, FA_, FB_, FAn_, FBn_, base_, xk_)
+        // ---- K-step 0
+        W4_KSTEP16(0, fa0, fb0, fa1, fb1, cb, xk1)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         W4_FENCE();
-        W4_KA(0) W4_KA(1) W4_KA(2) W4_KA(3) W4_KA(4) W4_KA(5) W4_KA(6) W4_KA(7)
-        W4_KA(8) W4_KA(9) W4_KA(10) W4_KA(11) W4_KA(12) W4_KA(13) W4_KA(14) W4_KA(15)
+        // ---- K-step 1
+        W4_KSTEP16(1, fa1, fb1, fa0, fb0, cb, xk2)
+        if (!(ABL & 1)) W4_STAGE_ADVANCE();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        W4_FENCE();
+        // ---- K-step 2
+        W4_KSTEP16(2, fa0, fb0, fa1, fb1, cb, xk3)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (!(ABL & 4)) {
-            if (LEAD == 3) {
-                if (post_epi > 0) asm volatile("s_waitcnt vmcnt(44)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // K-tile + 1 landed (its last piece was requested 1.5 K-steps ago)
             W4_FENCE();
             __builtin_amdgcn_s_barrier();
         }
         W4_FENCE();
-        // ---- K-step B
-#define W4_KB(i_)                                                                          \
-        if (((i_) & 3) == 3 && !(ABL & 1)) W4_MF_M0(i_, fa1, fb1, W4_DMA_LDS(1, (i_) >> 2)); else W4_MF(i_, fa1, fb1); \
-        W4_FENCE();                                                                        \
-        if (((i_) & 3) != 3 && W4_RIDX(i_) < 8 && !(ABL & 2)) W4_READ(W4_RIDX(i_), fa0, fb0, nb, xk0); \
-        if (((i_) & 3) == 3 && !(ABL & 1)) W4_DMA_M0(1, (i_) >> 2);                         \
-        if ((i_) == 15) W4_STAGE_ADVANCE();                                                \
-        W4_FENCE();
-        W4_KB(0) W4_KB(1) W4_KB(2) W4_KB(3) W4_KB(4) W4_KB(5) W4_KB(6) W4_KB(7)
-        W4_KB(8) W4_KB(9) W4_KB(10) W4_KB(11) W4_KB(12) W4_KB(13) W4_KB(14) W4_KB(15)
+        // ---- K-step 3
+        W4_KSTEP16(3, fa1, fb1, fa0, fb0, nb, xk0)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         W4_FENCE();
-        c_slot = (c_slot + 1) & 3;
-        if (post_epi > 0) --post_epi;
+        c_slot ^= 1;
         ++c_ss;
         if (c_ss != c_nss) continue;
         // ---- tile boundary
@@ -471,7 +512,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         W4_TRACE(-1);
         if (!(ABL & 8)) W4_EPILOGUE();
         W4_TRACE(-2);
-        post_epi = full ? 2 : 0;
         c_tile += G;
         if (c_tile >= ntiles) break;
         W4_COMPUTE_SETUP();
@@ -481,7 +521,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 }
 
 extern "C" int utx_launch_gemm_w4(GemmParams p, hipStream_t stream) {
-    constexpr int LDS = 4 * W4_SUB + 4 * 8192;       // the ring + the four waves' C staging buffers = all 160 KB
+    constexpr int LDS = 2 * W4_STAGE + 4 * 8192;     // the ring + the four waves' C staging buffers = all 160 KB
     static bool attr_set = false;
     if (!attr_set) {
         const void* ks[2] = {reinterpret_cast<const void*>(gemm256_w4_kernel<false>), reinterpret_cast<const void*>(gemm256_w4_kernel<true>)};
@@ -505,7 +545,7 @@ extern "C" int utx_launch_gemm_w4(GemmParams p, hipStream_t stream) {
         if (abl && !p.gate) {
 #define W4_ABL_CASE(a_) if (abl == (a_)) { hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_w4_kernel<false, (a_)>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
                                            hipLaunchKernelGGL((gemm256_w4_kernel<false, (a_)>), dim3(grid), dim3(256), LDS, stream, p, tiles, trace_wg); return 0; }
-            W4_ABL_CASE(1) W4_ABL_CASE(2) W4_ABL_CASE(3) W4_ABL_CASE(4) W4_ABL_CASE(7) W4_ABL_CASE(8) W4_ABL_CASE(15) W4_ABL_CASE(16) W4_ABL_CASE(32) W4_ABL_CASE(64) W4_ABL_CASE(144) W4_ABL_CASE(256) W4_ABL_CASE(400)
+            W4_ABL_CASE(1) W4_ABL_CASE(2) W4_ABL_CASE(3) W4_ABL_CASE(4) W4_ABL_CASE(7) W4_ABL_CASE(8) W4_ABL_CASE(15) W4_ABL_CASE(16) W4_ABL_CASE(32) W4_ABL_CASE(64) W4_ABL_CASE(128) W4_ABL_CASE(144)
         }
     }
 #endif
