@@ -44,6 +44,9 @@
 #include "common.h"
 #include "kernels.h"
 
+#ifndef W4_ZERO_BY_MFMA
+#define W4_ZERO_BY_MFMA 1
+#endif
 #define W4_STAGE 65536      // one K-tile of 64 k: A[256][64] at +0, B[256][64] at +32768, bf16, 128-byte rows
 
 __device__ __forceinline__ float w4_gelu_tanh(float x) {   // same expression as gemm.hip
@@ -188,6 +191,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         c_ss = 0;                                                                          \
     } while (0)
 
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
     f32x16 acc[4][4];   // [jn][im], swapped MFMA: rows = n, cols = m
     typedef __attribute__((ext_vector_type(4))) float w4_f32x4;
     w4_f32x4 acc4[4][4][2];   // ABL 64 only (timing experiment, wrong results): every 32x32x16 MFMA replaced by two 16x16x32 on the same operands
@@ -198,7 +202,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     _Pragma("unroll") for (int b_ = 0; b_ < 4; ++b_)                        \
     _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) {                     \
         if constexpr ((ABL & 64) != 0) { if (r_ < 8) asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(acc4[a_][b_][r_ >> 2][r_ & 3])); } \
-        else asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(acc[a_][b_][r_]));  \
+        else if (W4_ZERO_BY_MFMA && r_ == 0) asm volatile("s_nop 2\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %1, 0" : "=a"(acc[a_][b_]) : "v"(zero8));   /* 0 x 0 + 0: one MFMA zeroes 16 registers (32 cycles; sixteen v_accvgpr_write take 80).  s_nop: hipcc may materialise the zero operand with a v_mov right in front of the asm and does not see the MFMA inside it (VALU write -> MFMA read needs wait states) */ \
+        else if (!W4_ZERO_BY_MFMA) asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(acc[a_][b_][r_]));    \
     }
 #define W4_ACC(jn_, im_, r_) ({ float x_; if constexpr ((ABL & 64) != 0) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x_) : "a"(acc4[jn_][im_][((r_) >> 2) & 1][(r_) & 3])); \
                                 else asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x_) : "a"(acc[jn_][im_][r_])); x_; })
@@ -278,12 +283,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         _Pragma("unroll") for (int jn_ = 0; jn_ < 4; ++jn_) {                                                          \
             w4_u32x16 bw_;                                                                                             \
             if constexpr (GATED) W4_SLOAD16(bw_, ebias + 32 * jn_);     /* the gated kernel has no SGPRs to spare for the burst */ \
-            else bw_ = jn_ == 0 ? bq0 : jn_ == 1 ? bq1 : jn_ == 2 ? bq2 : bq3;                                         \
             _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_) {                                                         \
                 float b8_[8];                                                                                          \
                 _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_)                                                       \
                     _Pragma("unroll") for (int d_ = 0; d_ < 2; ++d_) {                                                 \
-                        const uint32_t w_ = (bw_[8 * q_ + 4 * h_ + 2 + d_] & hm) | (bw_[8 * q_ + 4 * h_ + d_] & ~hm);     \
+                        /* plain kernel: the lane's words were selected once per tile (bsel); gated: per block from the scalar load */ \
+                        uint32_t w_;                                                                                   \
+                        if constexpr (GATED) w_ = (bw_[8 * q_ + 4 * h_ + 2 + d_] & hm) | (bw_[8 * q_ + 4 * h_ + d_] & ~hm); \
+                        else w_ = bsel[jn_][q_][2 * h_ + d_];                                                          \
                         b8_[4 * h_ + 2 * d_] = p.bias ? bf2f((uint16_t)(w_ & 0xffff)) : 0.f;                           \
                         b8_[4 * h_ + 2 * d_ + 1] = p.bias ? bf2f((uint16_t)(w_ >> 16)) : 0.f;                          \
                     }                                                                                                  \
@@ -398,7 +405,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const char* const rub = (const char*)pres + ((long)(c_m0 + wm * 128) * p.ldres + c_n0 + wn * 128) * 2;         \
         const unsigned rvo = (unsigned)((elane >> 4) * (unsigned)p.ldres * 2u + (unsigned)(elane & 15) * 16u);          \
         w4_u32x16 bq0, bq1, bq2, bq3;                                                                                  \
-        if constexpr (!GATED) W4_SLOAD64(bq0, bq1, bq2, bq3, ebias);                                                   \
+        uint32_t bsel[4][2][4];          /* plain kernel: this lane's bias words (packed bf16 pairs) of every (jn, q) piece */ \
+        if constexpr (!GATED) {                                                                                        \
+            W4_SLOAD64(bq0, bq1, bq2, bq3, ebias);                                                                     \
+            _Pragma("unroll") for (int jn_ = 0; jn_ < 4; ++jn_) {                                                      \
+                const w4_u32x16 bw_ = jn_ == 0 ? bq0 : jn_ == 1 ? bq1 : jn_ == 2 ? bq2 : bq3;                          \
+                _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_)                                                       \
+                    _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_)                                                   \
+                        bsel[jn_][q_][e_] = (bw_[8 * q_ + 4 * (e_ >> 1) + 2 + (e_ & 1)] & hm) | (bw_[8 * q_ + 4 * (e_ >> 1) + (e_ & 1)] & ~hm); \
+            }                                                                                                          \
+        }                                                                                                              \
         if constexpr (GATED) {                                                                                         \
             W4_WAIT_RES(8, gq);       /* the eight DMAs of the tile's last K-step 3 are younger than the gate request (and every K-tile drains vmcnt) */ \
             if (full) {                                                                                                \
