@@ -84,7 +84,7 @@ def _set_tile(v):
 def _gemm_variants(fn):
     outs = {}
     try:
-        for tile in ("128", "2562", "256", "2560", "2564"):     # 2560 = the persistent kernel (gemm_pers.hip), the default for most large shapes; 2564 = one wave per SIMD (gemm_w4.hip)
+        for tile in ("128", "2562", "256", "2560", "2564"):     # 2564 = the persistent one-wave-per-SIMD kernel (gemm_w4.hip), the default for the large shapes; 2560 = the persistent 8-wave kernel (gemm_pers.hip)
             _set_tile(tile)
             outs[tile] = fn()
             torch.cuda.synchronize()
@@ -149,7 +149,7 @@ def test_gemm_full_size_kernels_agree_bitwise_and_match_oracle_rows(M):
 
 @pytest.mark.parametrize("M,N,K,K2", [(3500, 3584, 192, 64), (3584, 3584, 64, 0), (7000, 2048, 320, 128), (4096, 12544, 128, 64)])
 def test_gemm_persistent_kernel_edge_shapes_bit_identical_to_tiled_kernels(M, N, K, K2):
-    """the persistent continuous-stream kernel (default for >= 192 tiles of 256 x 256) at the shapes that stress its tile
+    """the persistent continuous-stream kernels (gemm_w4.hip: default for >= 192 tiles of 256 x 256; gemm_pers.hip) at the shapes that stress their tile
     boundary logic: ragged M (rows >= M in the last tile row, including waves with no valid row), an ODD number of K-tiles per
     tile (K = 192, and 48 + 1 style LoRA segments: the stream re-enters at odd LDS parity), a single K-tile per tile (K = 64:
     every K-tile is first and last), tiles with and without the LoRA segment in one launch, GELU / column split on a tile

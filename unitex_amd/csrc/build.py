@@ -22,7 +22,7 @@ SOURCES = [
     ("attention_q64.hip", []),
     ("gemm.hip", []),
     ("gemm_pers.hip", []),
-    ("gemm_w4.hip", ["-DW4_SPREAD3"]),
+    ("gemm_w4.hip", []),
     ("dit_elementwise.hip", ["-ffp-contract=off"]),
     ("vae.hip", []),
     ("capi.cpp", []),

@@ -1,46 +1,44 @@
-// bf16 MFMA GEMM for the large-M FLUX linears, ONE wave per SIMD (gfx950): 256x256 tile, four waves of 128x128, the accumulators
-// of a wave (256 registers) in the upper half of its 512-entry register file, every K-step's LDS reads and LDS-DMA issued in the
-// shadow of the previous K-step's MFMAs by the SAME wave.
+// bf16 MFMA GEMM for the large-M FLUX linears, ONE wave per SIMD (gfx950) -- the default for >= 192 tiles of 256 x 256 (gemm.hip dispatch).
+// 256x256 tile, four waves of 128x128, the accumulators of a wave (256 registers) in the AGPR half of its 512-entry register file, every
+// K-step's LDS reads and LDS-DMA issued in the shadow of the previous K-step's MFMAs by the SAME wave; persistent workgroups (one per CU)
+// walk tiles w, w + G, ... and the DMA cursor runs on across tile boundaries.
 //
-//   C[M,N] = epi( alpha * ( A[M,K] . B[N,K]^T  +  A2[M,K2] . B2[N,K2]^T ) + bias[N] )      (same contract as gemm.hip)
+//   C[M,N] = epi( alpha * ( A[M,K] . B[N,K]^T  +  A2[M,K2] . B2[N,K2]^T ) + bias[N] )      (same contract as gemm.hip; bit-identical outputs)
 //
-// STATUS: opt-in (UTX_GEMM_TILE = 2564), not the default.  Built to test whether the vendor library's 4-wave structure is what its lead
-// comes from (profiles/r02_gemm_clock_probe.log: on M = 50688, N = 21504, K = 3072 its MT256x256x64 kernel keeps the matrix pipe 81 %
-// busy at 1.73 GHz against 70 % at 1.63 GHz for gemm256_pers_kernel).  Result (profiles/r02_gemm_w4_*.log): bit-identical to the other
-// kernels; 0.94-0.99 x the speed of gemm256_pers_kernel on the FLUX shapes.  What the instrumented runs say:
-//   * with the DMA cursor parked (every DMA re-reads one KB: same instruction stream, no memory traffic) a K-tile of 64 costs 1.01 us
-//     = the matrix pipe's own 2048 cycles at 2.03 GHz -- the schedule below has no bubble of its own;
-//   * with real traffic the in-kernel timeline (tools/gemm_w4_trace.py) shows 1385-1390 shader cycles per sub-stage (1024 are MFMA) at a
-//     shader clock of 1.3-1.5 GHz: the kernel is POWER-limited (the chip holds 2.4 GHz only on idle data), and a third of its cycles go
-//     to vector-memory issue back-pressure that no placement of the eight DMAs per sub-stage removes (bunched, spread, lead 2 or 3);
-//   * replacing every 32x32x16 MFMA by two 16x16x32 (the shape the library uses; ablation, wrong results) is worth 5-9 % here (0.4-3.6 %
-//     in the 8-wave kernel): the next step if this kernel is taken further, together with a leaner epilogue (10-11k cycles per tile).
-// Structure: a wave owns 128x128 (a third fewer fragment bytes per FLOP than 8 waves of 128x64: 32 ds_read_b128 per 64 MFMAs instead of
-// 24 per 32), reads the fragments of K-step k+1 while the MFMAs of K-step k execute, and meets the other three waves at ONE barrier
-// per 32 MFMAs; there is no compute / load phase pair to balance.
+// Why this structure (profiles/r02_gemm_clock_probe.log): on M = 50688, N = 21504, K = 3072 the vendor library's hand-scheduled 4-wave kernel
+// keeps the matrix pipe 81 % busy against 70 % for the 8-wave kernel of gemm_pers.hip at identical MFMA work -- there a compute wave and a load
+// wave alternate per SIMD behind two barriers per phase and the load phase (~350 cycles) outlasts the 256-cycle MFMA phase it should hide
+// behind.  With one wave per SIMD there is no phase to balance: a wave owns 128x128 (a third fewer fragment bytes per FLOP: 32 ds_read_b128 per
+// 64 MFMAs instead of 24 per 32), reads the fragments of K-step k+1 under the MFMAs of K-step k and meets the other three waves at ONE barrier
+// per 64 MFMAs.  What the measurements say (profiles/r02_gemm_w4_*.log, r02_l2_fill_probe.log):
+//   * the instruction stream has no bubble of its own: with the DMA cursor parked (every DMA re-reads one KB) a 64-k K-tile costs 0.97 us = the
+//     matrix pipe's 2048 cycles at 2.1 GHz;
+//   * with real operand traffic the kernel is bound by how the L2 -> LDS path is fed.  A first version staged 32-k sub-stages (64-byte row
+//     segments, ring of four): tools/l2_fill_probe.hip shows that path delivers 34-44 GB/s per CU for 64-byte segments and 87-100 for 128-byte
+//     ones with every CU streaming; that version ran at exactly 35 GB/s per CU (1.48 us per K-tile, 0.94-0.99 x the 8-wave kernel).  This
+//     version stages 64-k K-tiles on 128-byte rows (two 64 KB stages) -- 1.33 us per K-tile;
+//   * a burst of DMAs backs the vector-memory path up into the issuing wave, which has no partner wave to hide behind: eight in a row cost
+//     ~30 cycles each beyond their MFMA shadow; one per three MFMAs (below) is worth +3-4 % over one per MFMA;
+//   * the epilogue (8.5k cycles per tile: 256 v_accvgpr_read + fma + pack + LDS transpose) is exposed -- nothing overlaps it with one wave
+//     per SIMD: bias through ONE scalar-load burst, accumulators re-zeroed by 16 MFMAs (0 x 0 + 0), C stores coalesced through LDS.
+// Result: +8-11 % over gemm256_pers_kernel on the FLUX shapes, 2-13 % behind the vendor kernel (profiles/r02_gemm_w4_check_v8.log); bench A/B
+// profiles/r02_bench_gemm_w4_ab.log.  Replacing every 32x32x16 MFMA by two 16x16x32 (the vendor kernel's shape; ablation) is worth 1-4 % more.
 //
-// Stream: the unit is a SUB-STAGE = 32 k of the 256x256 tile (A[256][32] + B[256][32] bf16 = 32 KB).  LDS holds a ring of four
-// (128 KB); the LDS-DMA cursor runs three sub-stages ahead of the MFMA cursor and continues across tile boundaries (persistent
-// workgroups, tiles w, w + G, ...).  Per sub-stage and wave: 2 K-steps x 16 MFMA 32x32x16, 16 ds_read_b128, 8 LDS-DMA (1 KB each).
-//   K-step A (fragments F0 of this sub-stage resident): 16 MFMAs | 8 reads -> F1 (same slot, k 16..31) | 4 DMAs (A of sub-stage u+3)
-//     s_waitcnt lgkmcnt(0); s_waitcnt vmcnt(12) [own DMAs of sub-stage u+1 landed]; s_barrier
-//   K-step B: 16 MFMAs on F1 | 8 reads -> F0 (slot u+1, k 0..15) | 4 DMAs (B of sub-stage u+3); s_waitcnt lgkmcnt(0)
-// Hazards: RAW -- a slot is read only after every wave's counted vmcnt for it and the barrier behind that; WAR -- the DMA of
-// sub-stage u+3 overwrites the slot of sub-stage u-1, whose last reads (F1, K-step A of u-1) every wave retired (lgkmcnt(0)) before
-// the barrier of sub-stage u-1, which every wave has passed before any wave issues a DMA in sub-stage u.
-// vmcnt: loads and stores retire in order; behind the DMAs of sub-stage u+1 there are the 8 of u+2 and the 4 just issued = 12; for
-// the two sub-stages that follow an epilogue the wave's 32 C stores sit in between (12 + 32 = 44; only when the tile was not ragged,
-// otherwise the smaller count simply waits for more).
+// Stream: K-tile = 64 k of the 256x256 tile = A[256][64] + B[256][64] bf16 = 64 KB, two stages in LDS (128 KB) + 8 KB of C staging per wave
+// = all 160 KB.  Per K-tile and wave: 4 K-steps x 16 MFMA 32x32x16, 32 ds_read_b128, 16 LDS-DMA pieces of 1 KB (8 rows x 128 B).
+//   K-step 0: MFMAs on F0 | reads -> F1 (kk 1) | pieces 6..10 of the cursor's K-tile (= compute K-tile + 1)
+//   K-step 1: MFMAs on F1 | reads -> F0 (kk 2) | pieces 11..15, cursor advances
+//   K-step 2: MFMAs on F0 | reads -> F1 (kk 3); s_waitcnt lgkmcnt(0) [every read of this stage retired]; vmcnt(0) [K-tile + 1 landed]; s_barrier
+//   K-step 3: MFMAs on F1 | reads -> F0 (kk 0 of the NEXT stage) | pieces 0..5 of K-tile + 2 into THIS stage (free since the barrier)
+// Hazards: RAW -- a stage is read only after every wave's vmcnt(0) for it and the barrier behind that; WAR -- the pieces of K-tile + 2 overwrite
+// this K-tile's stage, whose last reads (K-step 3's fragments, read in K-step 2) every wave retired before that barrier.  Loads, DMAs and stores
+// retire in order through one counter, so vmcnt(0) also waits for the C stores of an epilogue just behind; they have had a K-tile to retire.
+// The MFMAs are inline asm (AGPR accumulators by constraint): hipcc's hazard recogniser does not see them -- the two places where a VALU result
+// feeds an asm MFMA or an asm MFMA result feeds a VALU read carry their own s_nop (W4_ZERO_ACC, W4_MFMA_DRAIN).
 //
-// LDS sub-stage layout: operand X at X * 16 KB, row r (64 B) at r * 64, its four 16-byte chunks XOR-swizzled:
-//   slot = chunk ^ f(r),  f(r) = ((r >> 2) & 3) ^ (3 * ((r >> 4) & 1))
-// A ds_read_b128 is served in lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31} (MI355X_MICROARCH.md, LDS): with 64-byte rows
-// four rows share a 256-byte bank row; in both groups the four lanes whose rows agree mod 4 get four different f -> no conflicts.
-// The swizzle is applied on the DMA SOURCE (which global chunk a lane fetches; the LDS image of a DMA is lane-linear) and on the
-// fragment read address.
-//
-// Arithmetic: same K order per output element, same MFMA, same epilogue rounding points as gemm.hip / gemm_pers.hip -> bit-identical
-// outputs (tests/test_fullsize_gpu.py).
+// LDS stage layout: operand X at X * 32 KB, row r (128 B) at r * 128, its eight 16-byte chunks XOR-swizzled: slot = chunk ^ ((r >> 1) & 7)
+// (conflict-free for the ds_read_b128 lane groups, as in gemm.hip); applied on the DMA source (which global chunk a lane fetches; the LDS image
+// of a DMA is lane-linear) and on the fragment read address.
 #include "common.h"
 #include "kernels.h"
 
@@ -442,13 +440,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define W4_STAGE_HALF(isb_) do { W4_DMA(isb_, 0); W4_DMA(isb_, 1); W4_DMA(isb_, 2); W4_DMA(isb_, 3); W4_DMA(isb_, 4); W4_DMA(isb_, 5); W4_DMA(isb_, 6); W4_DMA(isb_, 7); } while (0)
     if (W4_SVALID && !(ABL & 32)) W4_STAGE_SETUP(); else W4_PARK();      // ABL 32: every DMA re-reads the same 1 KB (issue + LDS write, no memory traffic)
     W4_STAGE_HALF(0); W4_STAGE_HALF(1); W4_STAGE_ADVANCE();
-    W4_DMA(0, 0); W4_DMA(0, 1); W4_DMA(0, 2); W4_DMA(0, 3);         // what K-step 3 of a K-tile -1 would have requested
-#ifdef W4_SPREAD3
-    W4_DMA(0, 4); W4_DMA(0, 5);
+    W4_DMA(0, 0); W4_DMA(0, 1); W4_DMA(0, 2); W4_DMA(0, 3); W4_DMA(0, 4); W4_DMA(0, 5);      // what K-step 3 of a K-tile -1 would have requested
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-#else
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-#endif
     W4_COMPUTE_SETUP();
     W4_GATE_FETCH();
     __builtin_amdgcn_s_barrier();
@@ -458,26 +451,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     W4_FENCE();
 
-    // One K-tile = four K-steps of 16 MFMAs.  Slot i (behind MFMA i) of a K-step carries one fragment read (i < 8: the K-step after this one)
-    // or one DMA (i >= 8, K-steps 0 and 3 only); the LDS address of a DMA is put into M0 in front of the MFMA before it (the wait state M0 needs).
-    //   K-step 0: MFMAs on F0 | reads -> F1 (kk 1) | 8 DMAs: operand B of the cursor's K-tile (= compute K-tile + 1), cursor advances
-    //   K-step 1: MFMAs on F1 | reads -> F0 (kk 2)
-    //   K-step 2: MFMAs on F0 | reads -> F1 (kk 3); lgkmcnt(0) [every read of this stage retired]; vmcnt(0) [K-tile + 1 landed]; s_barrier
-    //   K-step 3: MFMAs on F1 | reads -> F0 (kk 0 of the NEXT stage) | 8 DMAs: operand A of K-tile + 2 into THIS stage (free since the barrier)
-    // Every DMA is issued >= 2 K-steps (~0.65 us) before the wait that needs it; tools/l2_fill_probe.hip: 0.3-0.4 us loaded L2 latency.
+    // One K-tile = four K-steps of 16 MFMAs (schedule in the file header).  Slot i (behind MFMA i) of a K-step carries one fragment read (i < 8: the
+    // fragments of the K-step after this one) and / or one DMA; the LDS address of a DMA is put into M0 in front of the MFMA before it (the wait state
+    // M0 needs).
     for (;;) {
         W4_TRACE(c_ss);
         const int cb = c_slot * W4_STAGE, nb = (c_slot ^ 1) * W4_STAGE;
-        // DMA schedule: piece p = 0..15 of the cursor's K-tile (p < 8: operand A piece p, else operand B piece p - 8), never more than one DMA per two
-        // MFMAs (a burst of eight 1 KB requests per wave backs the vector-memory path up into the issuing wave, which has no partner wave to hide behind):
-        //   K-step 3: p 0..3 behind MFMAs 9, 11, 13, 15 | K-step 0: p 4..11 behind the odd MFMAs | K-step 1: p 12..15 behind MFMAs 1, 3, 5, 7, then the cursor advances
-#ifdef W4_SPREAD3      /* experiment: one DMA per three MFMAs over K-steps 3, 0, 1 (6 + 5 + 5); the last piece then has 0.37 us to land */
+        // DMA schedule: piece p = 0..15 of the cursor's K-tile (p < 8: operand A piece p, else operand B piece p - 8), ONE DMA PER THREE MFMAs over
+        // K-steps 3, 0, 1 (a burst of 1 KB requests backs the vector-memory path up into the issuing wave, which has no partner wave to hide behind;
+        // measured: one per MFMA -> one per two +2 %, -> one per three +3-4 % more; the last piece then has 18 MFMAs ~ 0.37 us to land, against
+        // 0.3-0.4 us of loaded L2 latency -- tools/l2_fill_probe.hip):
+        //   K-step 3: p 0..5 behind MFMAs 0, 3, ..., 15 | K-step 0: p 6..10 behind MFMAs 2, 5, ..., 14 | K-step 1: p 11..15 behind MFMAs 1, 4, ..., 13, then the cursor advances
 #define W4_PIECE_OF(ks_, i_) ((ks_) == 3 ? (((i_) % 3) == 0 ? (i_) / 3 : -1) : (ks_) == 0 ? (((i_) % 3) == 2 ? 6 + (i_) / 3 : -1) \
                               : (ks_) == 1 ? ((((i_) % 3) == 1 && (i_) < 15) ? 11 + (i_) / 3 : -1) : -1)
-#else
-#define W4_PIECE_OF(ks_, i_) ((ks_) == 3 ? (((i_) >= 9 && ((i_) & 1)) ? ((i_) - 9) / 2 : -1) : (ks_) == 0 ? (((i_) & 1) ? 4 + ((i_) - 1) / 2 : -1) \
-                              : (ks_) == 1 ? ((((i_) & 1) && (i_) < 8) ? 12 + ((i_) - 1) / 2 : -1) : -1)
-#endif
 #define W4_KSTEP(i_, ks_, FA_, FB_, FAn_, FBn_, base_, xk_)                                                \
         {                                                                                                  \
             constexpr int pc_ = (ABL & 1) ? -1 : W4_PIECE_OF(ks_, i_);                                     \
