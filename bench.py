@@ -227,6 +227,9 @@ def main():
         t[..., 1] += torch.arange(oy, oy + t.shape[0])[:, None]
         t[..., 2] += torch.arange(ox, ox + t.shape[1])[None, :]
     img_ids = torch.cat([t.reshape(-1, 3) for t in ids], 0)
+    prune = os.environ.get("UTX_PRUNE_LAST", "1") != "0" and not ulysses and not args.fp8
+    if prune:
+        model.set_output_rows(n_noise)    # as the texturing pipeline does: only the noise tokens' prediction is consumed (sched_step reads no other row)
     model.set_positions(torch.zeros(S_txt, 3), img_ids)
     model.set_conditioning(torch.zeros(S_txt, shape.joint_dim, device=dev), torch.zeros(1, shape.pooled_dim, device=dev), 3.5)
     sched = FlowMatchEulerScheduler()
@@ -313,6 +316,15 @@ def main():
         attn_ms = [a.elapsed_time(b) for a, b in events]
         attn_avg_ms = sum(attn_ms) / max(len(attn_ms), 1)
         attn_launch_flops = 4.0 * S_exec * S_exec * 128 * HEADS / (world if ulysses else 1)
+        n_attn = 57
+        if prune:
+            # last-block pruning (FluxDiT.set_output_rows): the last of the 57 attention calls has n_noise queries instead of S_exec, and the
+            # last block's q / MLP / output projections run on n_noise rows -- the FLOP figures are the EXECUTED ones
+            dead = S_exec - n_noise
+            attn_last = 4.0 * n_noise * S_exec * 128 * HEADS
+            fl -= (attn_launch_flops - attn_last) + 2.0 * dead * 3072 * (3072 + 4 * 3072) + 2.0 * dead * (5 * 3072) * 3072
+            fl_attn -= (attn_launch_flops - attn_last)
+            attn_launch_flops = (attn_launch_flops * (n_attn - 1) + attn_last) / n_attn      # mean over the step's calls, as attn_avg_ms is
         achieved = attn_launch_flops / (attn_avg_ms * 1e-3) / 1e12
         value = (1 if ulysses else world) * args.steps / dt
         par = ("ulysses sp%d: ONE job, 2 all-to-alls / layer (RCCL) + view-sharded back-projection with one all-gather" % world) if ulysses \
@@ -326,6 +338,8 @@ def main():
                        "noise_tokens": n_noise, "control_tokens": n_ctrl, "dual_tokens": n_dual,
                        "lora_rank": args.lora_rank, "guidance": 3.5, "launch": "hip graph replay" if use_graph else "eager stream launches", "parallelism": par,
                        "tokens_computed": S_exec, "text_dedup": None if model.text_rows is None else "512 identical text tokens carried as %d rows per rank, key weight 2^%.2f (SURVEY 7 last bullet; UTX_TEXT_DEDUP=0 disables)" % (model.text_rows, model.key_bias_log2),
+                       "last_block_pruning": ("last block: queries / MLP / out-projection for the %d noise tokens only (the prediction of the condition tail is never read: "
+                                              "flux_piplines/texturing/pipeline.py:645,660,684; UTX_PRUNE_LAST=0 disables)" % n_noise) if prune else None,
                        "tflop_per_step": fl / 1e12, "tflop_per_step_reference_semantics": fl_nominal / 1e12,
                        "achieved_tflops_per_gpu": fl / (dt / args.steps) / 1e12 / (world if ulysses else 1),
                        "sec_per_mesh_texture_dit_only": 56.0 * dt / args.steps,

@@ -77,6 +77,13 @@ int utx_attn_fwd_bf16(utx_ctx* ctx, const void* q, const void* k, const void* vt
 int utx_attn_fwd_bf16_kb(utx_ctx* ctx, const void* q, const void* k, const void* vt, void* o,
                          long q_hs, long q_ss, long k_hs, long k_ss, long vt_hs, long vt_ds, long o_ss,
                          int H, int S, float softmax_scale, float key_bias_log2, int key_bias_period, utx_stream stream);
+/* The same with FEWER QUERIES THAN KEYS: rows 0 .. S_q-1 of q are the queries (o gets S_q rows), keys / values are all S_kv tokens.  Used by
+ * the last transformer block: the pipeline discards the prediction of the condition tokens (flux_piplines/texturing/pipeline.py:645,660,684:
+ * the condition tail of the latents is re-pinned before every transformer call and cut off at the end), so only the noise tokens need
+ * a query in the block whose output nobody attends to any more (unitex_amd/flux/transformer.py, `set_output_rows`). */
+int utx_attn_fwd_bf16_kbq(utx_ctx* ctx, const void* q, const void* k, const void* vt, void* o,
+                          long q_hs, long q_ss, long k_hs, long k_ss, long vt_hs, long vt_ds, long o_ss,
+                          int H, int S_q, int S_kv, float softmax_scale, float key_bias_log2, int key_bias_period, utx_stream stream);
 
 /* C = epi(alpha * (A B^T + A2 B2^T) + bias): bf16 GEMM, fp32 accumulate, fused epilogues.
  * Replaces every nn.Linear (+ peft LoRA branch, + GELU, + gated residual) inside the FLUX blocks

@@ -56,6 +56,9 @@ class FakeDiT:
     def set_positions(self, txt_ids, img_ids):
         self.txt_ids, self.img_ids = txt_ids, img_ids
 
+    def set_output_rows(self, n):
+        self.out_rows = n         # the real FluxDiT prunes its last block to these rows; the fake computes every row
+
     def set_conditioning(self, enc, pooled, guidance):
         self.cond_absmax = max(float(enc.abs().max()), float(pooled.abs().max()))
         self.guidance = guidance

@@ -287,6 +287,45 @@ def test_tiny_dit_forward_matches_oracle(use_lora):
         assert (base - ref).abs().max().item() > 5 * err, "LoRA branch must matter in this test"
 
 
+@pytest.mark.parametrize("use_lora", [False, True])
+def test_last_block_pruning_keeps_the_consumed_rows_bit_identical(use_lora):
+    """FluxDiT.set_output_rows(n): the texturing pipeline reads only the noise tokens' prediction (the condition tail of the latents is
+    re-pinned before every transformer call: flux_piplines/texturing/pipeline.py:645,660,684), so the last block computes query / MLP /
+    output projection for those rows only and the final norm + proj_out likewise.  The rows that are read must equal the unpruned
+    forward BIT FOR BIT (same weights, same K order, same attention arithmetic per query row), with and without the LoRA K-segment."""
+    from unitex_amd.flux.transformer import FluxDiT, FluxShape
+    from unitex_amd import _lib
+    cfg = dit_ref.tiny_config(heads=2, double=1, single=2, joint_dim=64, pooled_dim=64)
+    sd = dit_ref.make_synthetic_state_dict(cfg, seed=0)
+    shape = FluxShape(num_heads=2, num_double=1, num_single=2, joint_dim=64, pooled_dim=64)
+    S_txt, n_noise, S_img = 64, 8 * 24, 8 * 24 + 8 * 24 + 16
+    g = torch.Generator().manual_seed(7)
+    lat = torch.randn(S_img, 64, generator=g).to(BF)
+    enc = (0.5 * torch.randn(S_txt, 64, generator=g)).to(BF)
+    pooled = (0.5 * torch.randn(1, 64, generator=g)).to(BF)
+    txt_ids = torch.zeros(S_txt, 3)
+    img_ids = torch.cat([dit_ref.latent_image_ids(8, 24), dit_ref.latent_image_ids(8, 24, offset_y=8),
+                         dit_ref.latent_image_ids(4, 4, offset_x=24, offset_y=8)], 0)
+    m = FluxDiT(sd, shape, device="cuda:0")
+    if use_lora:
+        m.set_lora([(dit_ref.make_synthetic_lora(cfg, sd, rank=16, seed=2), 1.0)])
+    outs = {}
+    try:
+        _lib.set_option("UTX_ATTN_TAILSPLIT", 0)      # the key-split tail round picks different query blocks for the two launches
+        for rows in (None, n_noise, 100):
+            m.set_output_rows(rows)
+            m.set_positions(txt_ids, img_ids)
+            m.set_conditioning(enc.cuda(), pooled.cuda(), 3.5)
+            outs[rows] = m.forward(lat.cuda(), 0.4375).clone()
+            torch.cuda.synchronize()
+    finally:
+        _lib.set_option("UTX_ATTN_TAILSPLIT", 1)
+        m.set_output_rows(None)
+    for rows in (n_noise, 100):
+        assert torch.equal(outs[rows][:rows].view(torch.int16), outs[None][:rows].view(torch.int16)), "pruned forward differs on rows < %d" % rows
+    assert outs[None].float().abs().max() > 0.1
+
+
 def test_adapter_switching_module_copies_and_all_zero_weights():
     """(i) an adapter that carries a full x_embedder copy (peft modules_to_save, trainer.py:297-304) swaps it in while it is
     switched on, and the other adapter's copy when the weights flip (texture pass / delight pass, pipeline.py:245,263);

@@ -17,11 +17,11 @@ for M, N, K in shapes:
     def run(tile, abl):
         _lib.set_option("UTX_GEMM_TILE", tile); _lib.set_option("UTX_GEMM_DEBUG", abl << 5)
         ops.gemm(A, B, out=C, bias=bias)
-    fns = {"pers": lambda: run(2560, 0), "w4": lambda: run(2564, 0), "w4/16x16": lambda: run(2564, 64), "lib": lambda: torch.nn.functional.linear(A, B, bias)}
+    fns = {"pers": lambda: run(2560, 0), "w4": lambda: run(2564, 0), "w4/16x16": lambda: run(2564, 64), "w4/stagger40us": lambda: run(2564, 256), "lib": lambda: torch.nn.functional.linear(A, B, bias)}
     ts = {k: [] for k in fns}
     for k, f in fns.items(): f(); f()
     for r in range(7):
         for k, f in fns.items(): ts[k].append(t1(f))
     med = {k: sorted(v)[len(v) // 2] for k, v in ts.items()}
-    print("M=%6d N=%6d K=%6d | " % (M, N, K) + " | ".join("%s %.3f" % (k, med[k]) for k in fns) + " | (w4/16x16)/pers %.3f  /lib %.3f" % (med["pers"] / med["w4/16x16"], med["lib"] / med["w4/16x16"]), flush=True)
+    print("M=%6d N=%6d K=%6d | " % (M, N, K) + " | ".join("%s %.3f" % (k, med[k]) for k in fns) + " | w4/pers %.3f  w4/lib %.3f  stagger/w4 %.3f" % (med["pers"] / med["w4"], med["lib"] / med["w4"], med["w4"] / med["w4/stagger40us"]), flush=True)
 _lib.set_option("UTX_GEMM_TILE", 0); _lib.set_option("UTX_GEMM_DEBUG", 0)

@@ -422,21 +422,22 @@ static int attn_fast() { return g_utx_opt.attn_fast; }
 // already base-2 exponents and a probability is a single v_exp_f32.
 extern "C" int utx_launch_attn_fwd(const void* q, const void* k, const void* vt, void* o,
                                    long q_hs, long q_ss, long k_hs, long k_ss, long vt_hs, long vt_ds,
-                                   long o_ss, int H, int S, float scale, float key_bias_log2, int key_bias_period, hipStream_t stream) {
-    if (S <= 0 || H <= 0 || scale < 0.f || key_bias_period < 0) return -1;
+                                   long o_ss, int H, int S, int Sq, float scale, float key_bias_log2, int key_bias_period, hipStream_t stream) {
+    if (S <= 0 || H <= 0 || scale < 0.f || key_bias_period < 0 || Sq < 0 || Sq > S) return -1;
+    if (Sq == S) Sq = 0;
     if ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)vt)) & 15) return -2;                       // 16-byte aligned bases (LDS-DMA / b128 loads)
     if ((vt_ds & 7) || (q_ss & 7) || (k_ss & 7) || (o_ss & 3) || (q_hs & 7) || (k_hs & 7) || (vt_hs & 7)) return -2;   // 16-byte rows
     AttnParams p;
     p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.vt = (const bf16_t*)vt; p.o = (bf16_t*)o;
     p.q_hs = q_hs; p.q_ss = q_ss; p.k_hs = k_hs; p.k_ss = k_ss; p.vt_hs = vt_hs; p.vt_ds = vt_ds;
-    p.o_ss = o_ss; p.H = H; p.S = S; p.nqb = 0;
+    p.o_ss = o_ss; p.H = H; p.S = S; p.nqb = 0; p.Sq = Sq;
     p.dbg = g_utx_opt.attn_debug_abl;   // always 0 in the product library (capi.cpp)
     p.scale_log2 = scale * 1.4426950408889634f;
     const bool presc = (scale == 0.f);
     p.flags = nullptr; p.flag_hs = 0;
     p.key_bias_log2 = key_bias_log2; p.key_bias_period = key_bias_period;
-    // key multiplicity exists in the default (LDS-DMA staged) kernel only
-    if (key_bias_log2 != 0.f && (g_utx_opt.attn_glds == 0 || g_utx_opt.attn_q64 == 1 || g_utx_opt.attn_tpb != 1)) return -2;
+    // key multiplicity and a query count below the key count exist in the default (LDS-DMA staged) kernel only
+    if ((key_bias_log2 != 0.f || Sq != 0) && (g_utx_opt.attn_glds == 0 || g_utx_opt.attn_q64 == 1 || g_utx_opt.attn_tpb != 1)) return -2;
     // opt-in: the 4 x 64 kernel (attention_q64.hip) followed by its repair pass; it needs whole 64-key tiles
     { if (g_utx_opt.attn_q64 == 1 && (S & 63) == 0) {
           static unsigned char* flag_buf[16] = {nullptr}; static size_t flag_cap[16] = {0};

@@ -58,7 +58,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
     const int w = p.w_base + item;
     const int head = w / p.nqb;
     const int qb = w - head * p.nqb;
-    const int S = p.S;
+    const int S = p.S;                                // keys
+    const int Sq = p.Sq > 0 ? p.Sq : p.S;             // query rows (Sq < S: only the first Sq rows of q are queries -- last-block pruning, flux/transformer.py)
     // keys of this workgroup: all of them, or tiles [tb, tb + tiles_per_split) of the sequence (base pointers are advanced, Sk counts from there)
     const int tb = nsp > 1 ? split * p.tiles_per_split : 0;
     const int Sk = nsp > 1 ? ((S - tb * AG_KVB < p.tiles_per_split * AG_KVB) ? S - tb * AG_KVB : p.tiles_per_split * AG_KVB) : S;
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
     bf16x8 qf[8];
     {
         int qrow = q0 + lq;
-        if (qrow > S - 1) qrow = S - 1;
+        if (qrow > Sq - 1) qrow = Sq - 1;
         const bf16_t* qp = p.q + (long)head * p.q_hs + (long)qrow * p.q_ss + lh * 8;
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(qp + kk * 16);
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
     if (nsp > 1) {
         // partial result of this key range: normalised rows (bf16) + log2-sum-exp; attn_merge_kernel combines the ranges
         const long prow = ((long)item * nsp + split) * 256 + wave * 32 + lq;
-        if (qrow < S) {
+        if (qrow < Sq) {
             bf16_t* op = p.part_o + prow * 128 + 4 * lh;
 #pragma unroll
             for (int db = 0; db < 4; ++db)
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
         }
         return;
     }
-    if (qrow < S) {
+    if (qrow < Sq) {
         bf16_t* op = p.o + (long)qrow * p.o_ss + head * 128 + 4 * lh;
 #pragma unroll
         for (int db = 0; db < 4; ++db)
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(AttnParams p, int n_ite
     const int w = p.w_base + item;
     const int head = w / p.nqb, qb = w - head * p.nqb;
     const int qrow = qb * 256 + ql;
-    if (qrow >= p.S) return;
+    if (qrow >= (p.Sq > 0 ? p.Sq : p.S)) return;
     const int nsp = p.nsplit;
     float M = -INFINITY;
     for (int i = 0; i < nsp; ++i) M = fmaxf(M, p.part_lse[((long)item * nsp + i) * 256 + ql]);
@@ -340,7 +341,7 @@ static int launch_glds(AttnParams p, hipStream_t stream) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, AG_LDS(TPB)) != hipSuccess) return -3;
         attr_set = true;
     }
-    p.nqb = (p.S + 255) / 256;
+    p.nqb = ((p.Sq > 0 ? p.Sq : p.S) + 255) / 256;
     p.w_base = 0; p.nsplit = 1; p.tiles_per_split = 0; p.part_o = nullptr; p.part_lse = nullptr;
     const int nwg = p.nqb * p.H;
     // Tail split: the workgroups of the last, partly filled round are cut along the keys so that the round costs a fraction

@@ -108,7 +108,7 @@ int utx_attn_fwd_bf16(utx_ctx* ctx, const void* q, const void* k, const void* vt
                       int H, int S, float softmax_scale, utx_stream stream) {
     if (!q || !k || !vt || !o) return fail(ctx, -2, "utx_attn_fwd_bf16");
     UTX_CALL(ctx, "utx_attn_fwd_bf16",
-             utx_launch_attn_fwd(q, k, vt, o, q_hs, q_ss, k_hs, k_ss, vt_hs, vt_ds, o_ss, H, S,
+             utx_launch_attn_fwd(q, k, vt, o, q_hs, q_ss, k_hs, k_ss, vt_hs, vt_ds, o_ss, H, S, S,
                                  softmax_scale, 0.f, 0, (hipStream_t)stream));
 }
 
@@ -117,7 +117,16 @@ int utx_attn_fwd_bf16_kb(utx_ctx* ctx, const void* q, const void* k, const void*
                          int H, int S, float softmax_scale, float key_bias_log2, int key_bias_period, utx_stream stream) {
     if (!q || !k || !vt || !o) return fail(ctx, -2, "utx_attn_fwd_bf16_kb");
     UTX_CALL(ctx, "utx_attn_fwd_bf16_kb",
-             utx_launch_attn_fwd(q, k, vt, o, q_hs, q_ss, k_hs, k_ss, vt_hs, vt_ds, o_ss, H, S,
+             utx_launch_attn_fwd(q, k, vt, o, q_hs, q_ss, k_hs, k_ss, vt_hs, vt_ds, o_ss, H, S, S,
+                                 softmax_scale, key_bias_log2, key_bias_period, (hipStream_t)stream));
+}
+
+int utx_attn_fwd_bf16_kbq(utx_ctx* ctx, const void* q, const void* k, const void* vt, void* o,
+                          long q_hs, long q_ss, long k_hs, long k_ss, long vt_hs, long vt_ds, long o_ss,
+                          int H, int S_q, int S_kv, float softmax_scale, float key_bias_log2, int key_bias_period, utx_stream stream) {
+    if (!q || !k || !vt || !o) return fail(ctx, -2, "utx_attn_fwd_bf16_kbq");
+    UTX_CALL(ctx, "utx_attn_fwd_bf16_kbq",
+             utx_launch_attn_fwd(q, k, vt, o, q_hs, q_ss, k_hs, k_ss, vt_hs, vt_ds, o_ss, H, S_kv, S_q,
                                  softmax_scale, key_bias_log2, key_bias_period, (hipStream_t)stream));
 }
 

@@ -88,6 +88,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // per sub-stage the 100 MHz wall clock and the shader clock, a negative marker pair around every epilogue
     long* const trace = ((ABL & 128) && blockIdx.x == (unsigned)trace_wg && tid == 0) ? (long*)p.zero_page : nullptr;
     int trace_n = 0;
+    if constexpr ((ABL & 256) != 0) {      // ABL 256 (correct results): workgroups start up to 40 us apart, so tile boundaries (C store bursts) of different CUs stop coinciding
+        const long t0 = wall_clock64(), wait = (long)((blockIdx.x >> 3) & 15) * 4000 / 16;
+        while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+    }
 #define W4_TRACE(tag_) do { if ((ABL & 128) && trace && trace_n < 4000) { trace[3 * trace_n] = (tag_); trace[3 * trace_n + 1] = wall_clock64(); trace[3 * trace_n + 2] = __builtin_readcyclecounter(); ++trace_n; } } while (0)
 
     const int ntn = p.ntn & 0xffff, group_m = (p.ntn >> 16) & 0xff;
@@ -543,11 +547,11 @@ extern "C" int utx_launch_gemm_w4(GemmParams p, hipStream_t stream) {
     const int trace_wg = g_utx_opt.gemm_pers_sched >= 100 ? g_utx_opt.gemm_pers_sched - 100 : 0;   // ablation build: which workgroup writes the ABL 128 timeline
 #ifdef UTX_ABLATION
     {
-        const int abl = (g_utx_opt.gemm_debug_abl >> 5) & 511;     // UTX_GEMM_DEBUG bits 5..8
+        const int abl = (g_utx_opt.gemm_debug_abl >> 5) & 511;   // (ABL 256 = start-time stagger: results stay correct)     // UTX_GEMM_DEBUG bits 5..8
         if (abl && !p.gate) {
 #define W4_ABL_CASE(a_) if (abl == (a_)) { hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_w4_kernel<false, (a_)>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
                                            hipLaunchKernelGGL((gemm256_w4_kernel<false, (a_)>), dim3(grid), dim3(256), LDS, stream, p, tiles, trace_wg); return 0; }
-            W4_ABL_CASE(1) W4_ABL_CASE(2) W4_ABL_CASE(3) W4_ABL_CASE(4) W4_ABL_CASE(7) W4_ABL_CASE(8) W4_ABL_CASE(15) W4_ABL_CASE(16) W4_ABL_CASE(32) W4_ABL_CASE(64) W4_ABL_CASE(128) W4_ABL_CASE(144)
+            W4_ABL_CASE(1) W4_ABL_CASE(2) W4_ABL_CASE(3) W4_ABL_CASE(4) W4_ABL_CASE(7) W4_ABL_CASE(8) W4_ABL_CASE(15) W4_ABL_CASE(16) W4_ABL_CASE(32) W4_ABL_CASE(64) W4_ABL_CASE(128) W4_ABL_CASE(144) W4_ABL_CASE(256)
         }
     }
 #endif

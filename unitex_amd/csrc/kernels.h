@@ -16,6 +16,7 @@ struct AttnParams {
     bf16_t* o;
     long q_hs, q_ss, k_hs, k_ss, vt_hs, vt_ds, o_ss;  // element strides
     int H, S, nqb;
+    int Sq;            // query rows (0 = S): attention_glds.hip only
     int dbg;           // perf ablation only (UTX_ATTN_DEBUG bits): 1 no staging, 2 no exp, 4 no barrier, 8 no PV, 16 no QK
     float scale_log2;  // softmax_scale * log2(e)
     unsigned char* flags;  // per (head, 64-query group) overflow marks: written by the 4 x 64 kernel, read by the repair pass (else null)
@@ -60,7 +61,7 @@ typedef utx_sched_desc SchedParams;
 extern "C" {
 int utx_launch_attn_fwd(const void* q, const void* k, const void* vt, void* o,
                         long q_hs, long q_ss, long k_hs, long k_ss, long vt_hs, long vt_ds,
-                        long o_ss, int H, int S, float scale, float key_bias_log2, int key_bias_period, hipStream_t stream);
+                        long o_ss, int H, int S, int Sq, float scale, float key_bias_log2, int key_bias_period, hipStream_t stream);
 int utx_launch_attn_fwd_glds(const AttnParams* p, int presc, hipStream_t stream);
 int utx_launch_attn_fwd_q64(const AttnParams* p, int presc, hipStream_t stream);
 int utx_launch_gemm_bf16(const GemmParams* p, hipStream_t stream);

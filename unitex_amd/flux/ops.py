@@ -27,23 +27,25 @@ def _bf(t):
     return t
 
 
-def attention(q, k, vt, S=None, scale=None, out=None, o_ss=None, key_bias_log2=0.0, key_bias_period=0):
+def attention(q, k, vt, S=None, scale=None, out=None, o_ss=None, key_bias_log2=0.0, key_bias_period=0, S_q=None):
     """q,k [H,S_pad,128]; vt [H,128,S_pad] (S_pad multiple of 64, zero padded) -> o [S, H*128].
-    key_bias_log2 / key_bias_period: key multiplicity of tile 0 (and every period-th tile), see utx_attn_fwd_bf16_kb."""
+    key_bias_log2 / key_bias_period: key multiplicity of tile 0 (and every period-th tile), see utx_attn_fwd_bf16_kb.
+    S_q < S: only rows 0..S_q-1 of q are queries (o gets S_q rows), see utx_attn_fwd_bf16_kbq."""
     ctx = get_ctx(q.device.index)
     H, S_pad, D = q.shape
     assert D == 128 and vt.shape[1] == 128 and vt.shape[2] % 64 == 0
     S = S_pad if S is None else S
     if scale is None:
         scale = 1.0 / math.sqrt(D)   # pass scale=0.0 when Q was pre-scaled by scale*log2(e) in qkv_post
+    S_q = S if S_q is None else S_q
     if out is None:
-        out = torch.empty(S, H * D, dtype=torch.bfloat16, device=q.device)
+        out = torch.empty(S_q, H * D, dtype=torch.bfloat16, device=q.device)
     if o_ss is None:
         o_ss = out.stride(0)
-    rc = ctx.lib.utx_attn_fwd_bf16_kb(ctx.handle, ptr(_bf(q)), ptr(_bf(k)), ptr(_bf(vt)), ptr(out),
-                                      q.stride(0), q.stride(1), k.stride(0), k.stride(1),
-                                      vt.stride(0), vt.stride(1), o_ss, H, S, float(scale), float(key_bias_log2), int(key_bias_period),
-                                      ctx.stream())
+    rc = ctx.lib.utx_attn_fwd_bf16_kbq(ctx.handle, ptr(_bf(q)), ptr(_bf(k)), ptr(_bf(vt)), ptr(out),
+                                       q.stride(0), q.stride(1), k.stride(0), k.stride(1),
+                                       vt.stride(0), vt.stride(1), o_ss, H, S_q, S, float(scale), float(key_bias_log2), int(key_bias_period),
+                                       ctx.stream())
     ctx.check(rc)
     return out
 

@@ -152,6 +152,7 @@ class PBRFluxPipeline:
             latents = noise_latents[0].to(self.device, BF16).contiguous()
             ids, cond = noise_ids, None
         tr.set_positions(text_ids, ids)          # full id tensors: a sequence-parallel transformer slices them itself
+        tr.set_output_rows(n_noise)     # the prediction of the condition tail is never read (re-pinned every step, cut off at the end)
         tr.set_conditioning(prompt_embeds, pooled, guidance_scale)
         # sequence parallel (one job over several GPUs, flux/ulysses.py): every rank drew the same latents from the same CPU
         # generator; it keeps its contiguous slice of the image tokens, the Euler step / re-pin are per token, and one all-gather

@@ -96,6 +96,7 @@ class FluxDiT:
         self.lib = self.ctx.lib
         self._plans = {}
         self._graphs = {}
+        self.out_rows = None       # set_output_rows: image rows whose prediction the caller consumes (None = all)
         self._lora_active: List[Tuple[Dict, float]] = []
         self._lora_version = 0
         self.attn_events = None
@@ -362,7 +363,7 @@ class FluxDiT:
         d.q_scale = (1.0 / math.sqrt(128.0)) * 1.4426950408889634   # scores become base-2 exponents (attention scale=0)
         plan.append((self.lib.utx_qkv_post, d))
 
-    def _attn(self, plan, ws, out, S):
+    def _attn(self, plan, ws, out, S, q_rows=None):
         if self.sp is not None:
             # exchange 1 was started by an earlier "sp_start" entry; here: wait + unpack, attention over H/P heads x the full
             # sequence, exchange 2 + unpack into `out`
@@ -370,8 +371,16 @@ class FluxDiT:
             return
         sh = self.shape
         Qh, Kh, Vt = ws["Qh"], ws["Kh"], ws["Vt"]
-        args = (ptr(Qh), ptr(Kh), ptr(Vt), ptr(out), Qh.stride(0), Qh.stride(1), Kh.stride(0), Kh.stride(1),
-                Vt.stride(0), Vt.stride(1), out.stride(0), sh.num_heads, S, 0.0, float(self.key_bias_log2), int(self.key_bias_period))
+        if q_rows is None:
+            args = (ptr(Qh), ptr(Kh), ptr(Vt), ptr(out), Qh.stride(0), Qh.stride(1), Kh.stride(0), Kh.stride(1),
+                    Vt.stride(0), Vt.stride(1), out.stride(0), sh.num_heads, S, 0.0, float(self.key_bias_log2), int(self.key_bias_period))
+        else:       # queries = token rows [r0, r1) only (last-block pruning); `out` starts at row r0 as well
+            r0, r1 = q_rows
+            Qs = Qh[:, r0:]
+            args = (ptr(Qs), ptr(Kh), ptr(Vt), ptr(out), Qh.stride(0), Qh.stride(1), Kh.stride(0), Kh.stride(1),
+                    Vt.stride(0), Vt.stride(1), out.stride(0), sh.num_heads, r1 - r0, S, 0.0, float(self.key_bias_log2), int(self.key_bias_period))
+            plan.append((self.lib.utx_attn_fwd_bf16_kbq, args))
+            return
         plan.append((self.lib.utx_attn_fwd_bf16_kb, args))
 
     def _gemv(self, plan, x, W, b, y, silu_in=False, silu_out=False):
@@ -477,9 +486,32 @@ class FluxDiT:
             self._gemm(pc, ff[:S_txt], b["ff2_c.w"], h_c, bias=b["ff2_c.b"], lora=b.get("lora.ff2_c"), T=Tc,
                        gate=cg_m, res=h_c)
             self._par(plan, px, pc)
+        n_out = S_img if (self.out_rows is None or self.sp is not None or self.fp8_weights) else max(1, min(int(self.out_rows), S_img))
         for i, b in enumerate(self.single):
             sh_, sc_, g_ = chunks(("s", i), 3)
             self._lnmod(plan, h, xn, sh_, sc_)
+            if i == len(self.single) - 1 and n_out < S_img:
+                # LAST block, only rows [r0, r1) of its output are consumed (set_output_rows): keys / values for every token, but query,
+                # MLP and output projection for those rows only.  Same weights, same K order per output element: the rows that are
+                # computed equal the unpruned block's bit for bit (up to which query blocks the attention tail split picks).
+                r0, r1 = S_txt, S_txt + n_out
+                Wm, bm = b["qkvm.w"], b["qkvm.b"]
+                lora = b.get("lora.qkvm")
+                kw_kv, kw_q = {}, {}
+                if lora is not None:
+                    A_cat, B_cat, alpha, _rp = lora
+                    R = A_cat.shape[0] // 3
+                    Tv = T[:S, : 3 * R]
+                    plan.append((self.lib.utx_gemm_bf16, ops.make_gemm_desc(xn, A_cat, Tv, alpha=alpha)))
+                    kw_kv = dict(A2=Tv[:, R:], B2=B_cat[D: 3 * D], lora_n_limit=2 * D, lora_seg_n=D)
+                    kw_q = dict(A2=Tv[r0:r1, :R], B2=B_cat[:D], lora_n_limit=D, lora_seg_n=D)
+                plan.append((self.lib.utx_gemm_bf16, ops.make_gemm_desc(xn, Wm[D: 3 * D], qkv[:, D: 3 * D], bias=bm[D: 3 * D], **kw_kv)))
+                plan.append((self.lib.utx_gemm_bf16, ops.make_gemm_desc(xn[r0:r1], Wm[:D], qkv[r0:r1, :D], bias=bm[:D], **kw_q)))
+                plan.append((self.lib.utx_gemm_bf16, ops.make_gemm_desc(xn[r0:r1], Wm[3 * D:], cat[r0:r1, D:], bias=bm[3 * D:], gelu_from=0)))
+                self._qkvpost(plan, qkv, b["nq"], b["nk"], ws, S, 0)      # Q rows outside [r0, r1) are stale (finite) and never read
+                self._attn(plan, ws, cat[r0:], S, q_rows=(r0, r1))
+                plan.append((self.lib.utx_gemm_bf16, ops.make_gemm_desc(cat[r0:r1], b["out.w"], h[r0:r1], bias=b["out.b"], gate=g_, res=h[r0:r1])))
+                continue
             if self.sp is None:
                 # one GEMM for [q|k|v|proj_mlp]: qkv -> qkv buffer, GELU(mlp) -> cat[:, D:]
                 self._gemm(plan, xn, b["qkvm.w"], qkv, bias=b["qkvm.b"], lora=b.get("lora.qkvm"), lora_n_limit=3 * D,
@@ -497,8 +529,8 @@ class FluxDiT:
             self._gemm(plan, cat, b["out.w"], h, bias=b["out.b"], gate=g_, res=h, mx8=mx(b, "out"))
         o = self.mod_off[("out",)]
         scale, shift = mod[o: o + D], mod[o + D: o + 2 * D]  # AdaLayerNormContinuous: (scale, shift) [3p]
-        self._lnmod(plan, h_x, xn_x, shift, scale)
-        self._gemm(plan, xn_x, W["proj_out.w"], ws["out"], bias=W["proj_out.b"])
+        self._lnmod(plan, h_x[:n_out], xn_x[:n_out], shift, scale)
+        self._gemm(plan, xn_x[:n_out], W["proj_out.w"], ws["out"][:n_out], bias=W["proj_out.b"])
         return {"ws": ws, "plan": plan, "S_txt": S_txt, "S_img": S_img}
 
     # ------------------------------------------------------------------ forward
@@ -511,6 +543,15 @@ class FluxDiT:
     def local_image_range(self, S_img):
         from .ulysses import local_slice
         return (0, S_img) if self.sp is None else local_slice(S_img, self.sp[0], self.sp[1])
+
+    def set_output_rows(self, n):
+        """Only the first n image tokens' prediction will be read from forward()'s result (None = all; call before set_conditioning).
+        The texturing pipeline discards the prediction of the condition tokens: the condition tail of the latents is re-pinned before
+        every transformer call and cut off at the end (flux_piplines/texturing/pipeline.py:645,660,684), so in the LAST block -- whose
+        output no later block attends to -- only the noise tokens need a query, an MLP row and an output projection, and the final
+        norm / proj_out only those rows.  Keys and values of every token are still computed.  Rows >= n of the result are undefined.
+        Exact for the rows that are read; not applied under sequence parallelism or with fp8 weights (the full block runs)."""
+        self.out_rows = None if n is None else int(n)
 
     def set_positions(self, txt_ids, img_ids):
         """Position ids of the joint sequence cat(txt_ids, img_ids) (FULL tensors, also under sequence parallelism).  The plan
@@ -540,7 +581,7 @@ class FluxDiT:
         S_loc = (t1 - t0) + (i1 - i0)
         # text tiles recur once per rank in the gathered key sequence (keys ordered (source rank, local token))
         self.key_bias_period = (S_loc // 64) if (identical and world > 1) else 0
-        key = (t1 - t0, i1 - i0, self._lora_version, self.key_bias_log2, self.key_bias_period)
+        key = (t1 - t0, i1 - i0, self._lora_version, self.key_bias_log2, self.key_bias_period, self.out_rows)
         if key not in self._plans:
             self._plans.clear()  # one live plan: workspaces are large
             self._graphs = {}
@@ -610,7 +651,7 @@ class FluxDiT:
                 if rc:
                     self.ctx.check(rc)
                 ex.tokens_out(d)
-            elif fn is lib.utx_attn_fwd_bf16_kb:
+            elif fn is lib.utx_attn_fwd_bf16_kb or fn is lib.utx_attn_fwd_bf16_kbq:
                 ev = getattr(self, "attn_events", None)
                 if ev is not None:  # bench.py: HIP events on the launch stream around the dominant kernel
                     a = torch.cuda.Event(enable_timing=True)
