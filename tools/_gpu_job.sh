@@ -1,14 +1,4 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-: > gpurun_out/r02_bench_prune_ab.log
-for rep in 1 2; do
-  for t in 0 1; do
-    echo "== UTX_PRUNE_LAST=$t strip1024x6" >> gpurun_out/r02_bench_prune_ab.log
-    UTX_PRUNE_LAST=$t python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | grep '^{' | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['roofline']['achieved'], d['roofline']['avg_launch_ms'], d['config']['tflop_per_step'])" >> gpurun_out/r02_bench_prune_ab.log
-  done
-done
-for t in 0 1 0 1; do
-  echo "== UTX_PRUNE_LAST=$t ref512x6" >> gpurun_out/r02_bench_prune_ab.log
-  UTX_PRUNE_LAST=$t python bench.py --workload ref512x6 --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | grep '^{' | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['roofline']['achieved'], d['roofline']['avg_launch_ms'], d['config']['tflop_per_step'])" >> gpurun_out/r02_bench_prune_ab.log
-done
-cat gpurun_out/r02_bench_prune_ab.log
+timeout 900 python tools/run_full_pipeline.py --view 1024 --reps 1 > gpurun_out/r02_full_pipeline_e2e_1024.log 2>&1
+grep -v amdgpu.ids gpurun_out/r02_full_pipeline_e2e_1024.log | tail -12
