@@ -1,4 +1,4 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 900 python tools/run_full_pipeline.py --view 1024 --reps 1 > gpurun_out/r02_full_pipeline_e2e_1024.log 2>&1
-grep -v amdgpu.ids gpurun_out/r02_full_pipeline_e2e_1024.log | tail -12
+timeout 1500 python -m pytest tests/test_dit_ops_gpu.py tests/test_fullsize_gpu.py tests/test_pipeline_gpu.py tests/test_vae_gpu.py -x -q -m gpu > gpurun_out/r02_gpu_tests_lnmod.log 2>&1
+grep -E "passed|failed|Error|assert" gpurun_out/r02_gpu_tests_lnmod.log | tail -5

@@ -227,52 +227,50 @@ extern "C" int utx_launch_sp_unpack_o(const void* recv, int P, int Hp, int S_loc
 
 // ---------------------------------------------------------------------------------------------
 // LayerNorm (no affine, eps) + AdaLN modulation:  y = bf16( bf16( bf16(LN(x)) * bf16(1+scale) ) + shift )
-// AdaLayerNormZero / ZeroSingle / Continuous of the FLUX blocks [3p, SURVEY 3.4].  One block per token.
+// AdaLayerNormZero / ZeroSingle / Continuous of the FLUX blocks [3p, SURVEY 3.4].
 
+// One WAVE per token (four tokens per 256-thread block): a lane holds up to 8 chunks of 8 channels (D <= 4096) -- all its loads are in flight at
+// once, both reductions are wave-level (no LDS, no block barrier).  (Round 1 used one 256-thread block per token with two __syncthreads
+// reductions: 3.0 TB/s at D = 3072; the per-block latency chain, not HBM, set the time.)
 __global__ __launch_bounds__(256) void ln_mod_kernel(LnModParams p) {
-    __shared__ float red[8];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tok = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tok >= p.n_tok) return;
     const bf16_t* xr = (const bf16_t*)p.x + (long)tok * p.ldx;
     const int nchunk = p.D >> 3;
-    float v[2][8];
+    uint4 raw[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int c = lane + 64 * it;
+        raw[it] = (c < nchunk) ? *reinterpret_cast<const uint4*>(xr + c * 8) : make_uint4(0u, 0u, 0u, 0u);
+    }
+    float v[8][8];
     float s = 0.f;
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int c = tid + 256 * it;
-        if (c < nchunk) {
-            const uint4 raw = *reinterpret_cast<const uint4*>(xr + c * 8);
-            const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+    for (int it = 0; it < 8; ++it) {
+        const uint32_t w[4] = {raw[it].x, raw[it].y, raw[it].z, raw[it].w};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                v[it][2 * j] = bf2f((uint16_t)(w[j] & 0xffff));
-                v[it][2 * j + 1] = bf2f((uint16_t)(w[j] >> 16));
-                s += v[it][2 * j] + v[it][2 * j + 1];
-            }
+        for (int j = 0; j < 4; ++j) {
+            v[it][2 * j] = bf2f((uint16_t)(w[j] & 0xffff));
+            v[it][2 * j + 1] = bf2f((uint16_t)(w[j] >> 16));
+            s += v[it][2 * j] + v[it][2 * j + 1];          // chunks beyond D are zeros
         }
     }
-    s = wave_sum(s);
-    if (lane == 0) red[wave] = s;
-    __syncthreads();
-    const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)p.D;
+    const float mean = wave_sum(s) / (float)p.D;
     float q = 0.f;
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int c = tid + 256 * it;
-        if (c < nchunk) {
+    for (int it = 0; it < 8; ++it) {
+        if (lane + 64 * it < nchunk) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) { const float dlt = v[it][j] - mean; q += dlt * dlt; }
         }
     }
-    q = wave_sum(q);
-    if (lane == 0) red[4 + wave] = q;
-    __syncthreads();
-    const float var = (red[4] + red[5] + red[6] + red[7]) / (float)p.D;
+    const float var = wave_sum(q) / (float)p.D;
     const float rstd = 1.0f / sqrtf(var + p.eps);
     bf16_t* yr = (bf16_t*)p.y + (long)tok * p.ldy;
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int c = tid + 256 * it;
+    for (int it = 0; it < 8; ++it) {
+        const int c = lane + 64 * it;
         if (c < nchunk) {
             const uint4 sh = *reinterpret_cast<const uint4*>((const bf16_t*)p.shift + c * 8);
             const uint4 sc = *reinterpret_cast<const uint4*>((const bf16_t*)p.scale + c * 8);
@@ -299,7 +297,7 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(LnModParams p) {
 extern "C" int utx_launch_ln_mod(const LnModParams* hp, hipStream_t stream) {
     LnModParams p = *hp;
     if (p.n_tok <= 0 || p.D <= 0 || (p.D & 7) || p.D > 4096 || (p.ldx & 7) || (p.ldy & 7)) return -2;
-    hipLaunchKernelGGL(ln_mod_kernel, dim3(p.n_tok), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(ln_mod_kernel, dim3((p.n_tok + 3) / 4), dim3(256), 0, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
