@@ -172,7 +172,7 @@ def main():
                          "bench line (the metric is quoted in bf16) -- reported with dtype 'mx-fp8 linears + bf16 attention'")
     ap.add_argument("--cpu-config1", action="store_true",
                     help="also run BASELINE configs[0] (512^2 x 4 views, S = 9728, 4 denoise steps, fp32) to COMPLETION on the host "
-                         "cores with the oracle (~15-30 min): the one CPU number that is not extrapolated (SURVEY 8d)")
+                         "cores with the oracle (~35 min on the GPU box's 64 threads; 50 min on the 8-core build container: profiles/r02_cpu_config1_container.json): the one CPU number that is not extrapolated (SURVEY 8d)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
