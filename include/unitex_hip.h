@@ -120,6 +120,18 @@ typedef struct utx_gemm_desc {
     const void* a_scale; long lds_a;
     const void* b_scale; long lds_b;
     int mx8;
+    /* Fused q / k post-processing (qk_cols > 0; the "fused QKV + RMSNorm + RoPE" of the hot path; one-wave-per-SIMD kernel only -- a wave owns
+     * a whole 128-column head there): output columns n < qk_cols are NOT written to C; each 128-column head slab gets what utx_qkv_post does
+     * to q (columns < qk_cols / 2) or k (the rest): per-head RMSNorm with qk_wq / qk_wk, RoPE from qk_cos / qk_sin ([tok][64] fp32, token =
+     * qk_tok_off + row), q scaled by qk_q_scale, head-major store to qk_Qh / qk_Kh ([H][S_pad][128], head stride qk_hs elements) -- same
+     * arithmetic, same rounding points, same summation order, bit-identical to GEMM -> utx_qkv_post (attention_processor.py:42-87).  Columns
+     * >= qk_cols (v, the MLP half of a single block) take the plain epilogue; v is transposed by utx_qkv_post with skip_qk = 1. */
+    int qk_cols;                       /* 0 = off; else 2 * H * 128 */
+    int qk_tok_off;
+    float qk_eps, qk_q_scale;
+    const void* qk_wq; const void* qk_wk;
+    const float* qk_cos; const float* qk_sin;
+    void* qk_Qh; void* qk_Kh; long qk_hs;
 } utx_gemm_desc;
 int utx_gemm_bf16(utx_ctx* ctx, const utx_gemm_desc* d, utx_stream stream);
 
@@ -170,6 +182,7 @@ typedef struct utx_qkv_post_desc {
      * [P][3][H/P][...] (one group per destination rank) and no pack pass exists.  0 = plain [H][...] layout. */
     int heads_per_group;
     long gs_qk, gs_v;
+    int skip_qk;                             /* 1: q and k were produced by the GEMM's fused epilogue (utx_gemm_desc.qk_cols): only V is transposed */
 } utx_qkv_post_desc;
 int utx_qkv_post(utx_ctx* ctx, const utx_qkv_post_desc* d, utx_stream stream);
 

@@ -287,6 +287,47 @@ def test_tiny_dit_forward_matches_oracle(use_lora):
         assert (base - ref).abs().max().item() > 5 * err, "LoRA branch must matter in this test"
 
 
+@pytest.mark.parametrize("M,tok_off,lora", [(16384, 0, False), (16384 + 100, 64, True)])
+def test_gemm_fused_qk_post_is_bit_identical_to_gemm_then_qkv_post(M, tok_off, lora):
+    """utx_gemm_desc.qk_cols: the QKV projection's epilogue applies per-head RMSNorm + RoPE (+ the q scale) and writes head-major Q / K itself
+    (one-wave-per-SIMD kernel: a wave owns a whole 128-column head); V columns take the plain epilogue and utx_qkv_post(skip_qk) transposes
+    them.  Same arithmetic in the same order as GEMM -> utx_qkv_post (attention_processor.py:42-87): Q, K, V^T must be BIT-IDENTICAL,
+    with a ragged last row tile, a token offset, and the LoRA K-segment in the accumulators."""
+    ops = _ops()
+    H, K, R = 2, 256, 64
+    D = H * 128
+    g = torch.Generator(device="cuda").manual_seed(M)
+    x = (torch.randn(M, K, device="cuda", generator=g) / 2).to(BF)
+    W = (torch.randn(3 * D, K, device="cuda", generator=g) / math.sqrt(K)).to(BF)
+    bias = torch.randn(3 * D, device="cuda", generator=g).to(BF)
+    wq = (1 + 0.1 * torch.randn(128, device="cuda", generator=g)).to(BF)
+    wk = (1 + 0.1 * torch.randn(128, device="cuda", generator=g)).to(BF)
+    S = tok_off + M
+    S_pad = (S + 63) // 64 * 64
+    ids = torch.stack([torch.zeros(S), torch.arange(S) // 97, torch.arange(S) % 97], 1).float()
+    cos, sin = [t.cuda().contiguous() for t in dit_ref.rope_tables(ids)]
+    kw = {}
+    if lora:
+        T = (torch.randn(M, 3 * R, device="cuda", generator=g) / 8).to(BF)
+        Bl = (torch.randn(3 * D, R, device="cuda", generator=g) / 4).to(BF)
+        kw = dict(A2=T, B2=Bl, lora_n_limit=3 * D, lora_seg_n=D)
+    qs = 0.1275
+    outs = []
+    for fused in (False, True):
+        qkv = torch.full((M, 3 * D), 3.0, dtype=BF, device="cuda")
+        Qh = torch.zeros(H, S_pad, 128, dtype=BF, device="cuda"); Kh = torch.zeros_like(Qh); Vt = torch.zeros(H, 128, S_pad, dtype=BF, device="cuda")
+        qk = dict(cols=2 * D, tok_off=tok_off, eps=1e-6, q_scale=qs, wq=wq, wk=wk, cos=cos, sin=sin, Qh=Qh, Kh=Kh) if fused else None
+        ops.gemm(x, W, bias=bias, out=qkv, qk_post=qk, **kw)
+        ops.qkv_post(qkv, 0, D, 2 * D, wq, wk, cos, sin, Qh, Kh, Vt, M, tok_off, H, q_scale=qs, skip_qk=fused)
+        torch.cuda.synchronize()
+        if fused:
+            assert bool((qkv[:, : 2 * D] == 3.0).all()), "the fused epilogue must not write the q / k columns of C"
+        outs.append((Qh, Kh, Vt))
+    for name, a, b in zip("QKV", outs[0], outs[1]):
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16)), "%s differs between GEMM -> qkv_post and the fused epilogue" % name
+    assert outs[0][0].float().abs().max() > 0.05
+
+
 @pytest.mark.parametrize("use_lora", [False, True])
 def test_last_block_pruning_keeps_the_consumed_rows_bit_identical(use_lora):
     """FluxDiT.set_output_rows(n): the texturing pipeline reads only the noise tokens' prediction (the condition tail of the latents is

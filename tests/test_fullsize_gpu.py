@@ -228,6 +228,7 @@ def test_full_width_dit_blocks_at_config1_shape_match_oracle():
     lb = dit_ref.make_synthetic_lora(cfg, sd, rank=64, seed=3)
     loras = [(la, 1.0), (lb, 0.0)]
     m = FluxDiT(sd, shape, device="cuda:0")
+    m.fuse_qk = True            # opt-in (UTX_FUSE_QK=1): q / k post-processing inside the QKV projections' epilogue
     m.set_lora(loras)
     m.set_positions(txt_ids, img_ids)
     m.set_conditioning(enc.cuda(), pooled.cuda(), 3.5)
@@ -241,3 +242,23 @@ def test_full_width_dit_blocks_at_config1_shape_match_oracle():
     assert torch.isfinite(out).all()
     assert err < 0.03 * max(mx, 1.0), "full-width DiT blocks: err %g (ref max %g)" % (err, mx)
     assert (out - ref).abs().mean().item() < 0.004 * max(mx, 1.0)
+    # the forward above ran with q / k post-processing fused into the QKV projections (these shapes take the one-wave-per-SIMD GEMM);
+    # GEMM -> utx_qkv_post must give the same bits
+    fused_gemms = sum(1 for fn, d in _flat_plan(m) if fn is m.lib.utx_gemm_bf16 and d.qk_cols > 0)
+    assert fused_gemms == 2, "expected the image-stream QKV projection of the double block and the single block's projection to be fused, got %d" % fused_gemms
+    m.fuse_qk = False
+    m._plans.clear()
+    m.set_conditioning(enc.cuda(), pooled.cuda(), 3.5)
+    assert sum(1 for fn, d in _flat_plan(m) if fn is m.lib.utx_gemm_bf16 and d.qk_cols > 0) == 0
+    out2 = m.forward(lat.cuda(), 0.4375).float().cpu()
+    assert torch.equal(out2, out), "fused q / k epilogue changed the forward: max |d| %g" % (out2 - out).abs().max().item()
+
+
+def _flat_plan(m):
+    def walk(ops_):
+        for fn, d in ops_:
+            if fn == "par":
+                yield from walk(d[0]); yield from walk(d[1])
+            else:
+                yield fn, d
+    return list(walk(next(iter(m._plans.values()))["plan"]))

@@ -23,7 +23,10 @@ class GemmDesc(C.Structure):
                 ("n_split", c_int), ("C1", c_void_p), ("ldc1", c_long), ("ntn", c_int),
                 ("conv_Hi", c_int), ("conv_Wi", c_int), ("conv_Wo", c_int), ("conv_cin_log2", c_int),
                 ("conv_stride", c_int), ("conv_pad", c_int), ("conv_up", c_int), ("zero_page", c_void_p),
-                ("a_scale", c_void_p), ("lds_a", c_long), ("b_scale", c_void_p), ("lds_b", c_long), ("mx8", c_int)]
+                ("a_scale", c_void_p), ("lds_a", c_long), ("b_scale", c_void_p), ("lds_b", c_long), ("mx8", c_int),
+                ("qk_cols", c_int), ("qk_tok_off", c_int), ("qk_eps", c_float), ("qk_q_scale", c_float),
+                ("qk_wq", c_void_p), ("qk_wk", c_void_p), ("qk_cos", c_void_p), ("qk_sin", c_void_p),
+                ("qk_Qh", c_void_p), ("qk_Kh", c_void_p), ("qk_hs", c_long)]
 
 
 class GemvDesc(C.Structure):
@@ -38,7 +41,7 @@ class QkvPostDesc(C.Structure):
                 ("Qh", c_void_p), ("Kh", c_void_p), ("Vt", c_void_p),
                 ("hs_qk", c_long), ("hs_v", c_long), ("S_pad", c_long),
                 ("n_tok", c_int), ("tok_off", c_int), ("H", c_int), ("eps", c_float), ("q_scale", c_float),
-                ("heads_per_group", c_int), ("gs_qk", c_long), ("gs_v", c_long)]
+                ("heads_per_group", c_int), ("gs_qk", c_long), ("gs_v", c_long), ("skip_qk", c_int)]
 
 
 class LnModDesc(C.Structure):

@@ -49,12 +49,13 @@ __global__ __launch_bounds__(256) void qkv_post_kernel(QkvPostParams p) {
         }
         const bf16_t* row = (const bf16_t*)p.qkv + (long)tok * p.ld + head * 128 + 8 * sub;
         const long srow = (long)(p.tok_off + tok);
+        const uint4 vraw = *reinterpret_cast<const uint4*>(row + p.v_col);
+        if (!p.skip_qk) {      // skip_qk: q / k came out of the GEMM's fused epilogue (utx_gemm_desc.qk_cols); only V is transposed here
         const float4 cs = *reinterpret_cast<const float4*>(p.cosb + srow * 64 + 4 * sub);
         const float4 sn = *reinterpret_cast<const float4*>(p.sinb + srow * 64 + 4 * sub);
         const float csv[4] = {cs.x, cs.y, cs.z, cs.w}, snv[4] = {sn.x, sn.y, sn.z, sn.w};
         const uint4 qraw = *reinterpret_cast<const uint4*>(row + p.q_col);
         const uint4 kraw = *reinterpret_cast<const uint4*>(row + p.k_col);
-        const uint4 vraw = *reinterpret_cast<const uint4*>(row + p.v_col);
 #pragma unroll
         for (int which = 0; which < 2; ++which) {
             const uint4 raw = which ? kraw : qraw;
@@ -82,6 +83,7 @@ __global__ __launch_bounds__(256) void qkv_post_kernel(QkvPostParams p) {
             }
             bf16_t* dst = (bf16_t*)(which ? p.Kh : p.Qh) + hoff_qk + srow * 128 + 8 * sub;
             *reinterpret_cast<uint4*>(dst) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+        }
         }
         *reinterpret_cast<uint4*>(&sv[tl][8 * sub]) = vraw;
     }

@@ -816,6 +816,12 @@ extern "C" int utx_launch_gemm_bf16(const GemmParams* hp, hipStream_t stream) {
     // default for the large-M linears: the persistent one-wave-per-SIMD kernel (gemm_w4.hip; +5...10 % over the persistent 8-wave kernel on the FLUX
     // shapes, profiles/r02_gemm_w4_check_v7.log); UTX_GEMM_TILE=2560 keeps the persistent 8-wave kernel (gemm_pers.hip), 256 the per-tile-launch
     // 8-phase kernel, for A/B (all bit-identical); the timing ablations / tail split only exist in the latter.
+    if (p.qk_cols > 0) {
+        // fused q / k post-processing: only the one-wave-per-SIMD kernel has it (a wave owns a whole head there); refuse instead of dropping it
+        if (p.mx8 || p.conv_Wo > 0 || p.gate || (p.qk_cols % 256) || p.qk_cols > p.N || p.qk_cols > p.n_split || p.qk_cols > p.gelu_from ||
+            !p.qk_wq || !p.qk_wk || !p.qk_cos || !p.qk_sin || !p.qk_Qh || !p.qk_Kh || p.qk_hs <= 0 || p.qk_tok_off < 0) return -2;
+        if (!(use256 && (tile_env == 0 || tile_env == 2564) && (dbg_env & 3) == 0 && g_utx_opt.gemm_tailsplit == 0)) return -2;
+    }
     if (use256 && (tile_env == 0 || tile_env == 2564) && (dbg_env & 3) == 0 && g_utx_opt.gemm_tailsplit == 0)
         return utx_launch_gemm_w4(p, stream);
     if (use256 && tile_env == 2560 && (dbg_env & 3) == 0 && g_utx_opt.gemm_tailsplit == 0)

@@ -74,7 +74,8 @@ __device__ __forceinline__ const char* w4_uniform(const char* p) {
 
 // ABL (ablation build only, wrong results): 1 = no DMA in the loop, 2 = no fragment reads in the loop, 4 = no vmcnt wait / barrier, 8 = no epilogue,
 // 16 = epilogue without its C stores, 32 = the DMA cursor parked from the start (every DMA re-reads the same bytes)
-template <bool GATED, int ABL = 0>
+// QKF: the fused q / k post-processing of utx_gemm_desc.qk_cols (plain kernel only)
+template <bool GATED, int ABL = 0, bool QKF = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm256_w4_kernel(GemmParams p, int ntiles, int trace_wg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -278,7 +279,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define W4_LOAD16_ASM(dst_, ptr_) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst_) : "v"(ptr_) : "memory")
 #define W4_WAIT_RES(n_, r_) do { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r_) : "n"(n_) : "memory"); W4_FENCE(); } while (0)
     w4_u32x4 gq = {0u, 0u, 0u, 0u};      // gate of this lane's 8 output columns (store layout), requested when the tile starts
-#define W4_GATE_FETCH() do { if (GATED) W4_LOAD16_ASM(gq, (const bf16_t*)p.gate + c_n0 + wn * 128 + 8 * (lane & 15)); } while (0)
+    // fused q / k tiles (QKF): the same register carries the RMSNorm weight of this wave's head (q or k), eight channels per lane in store layout
+#define W4_GATE_FETCH()                                                                                                        \
+    do {                                                                                                                       \
+        if (GATED) W4_LOAD16_ASM(gq, (const bf16_t*)p.gate + c_n0 + wn * 128 + 8 * (lane & 15));                                \
+        if (QKF && c_n0 < p.qk_cols)                                                                                           \
+            W4_LOAD16_ASM(gq, (const bf16_t*)((c_n0 + wn * 128) * 2 >= p.qk_cols ? p.qk_wk : p.qk_wq) + 8 * (lane & 15));      \
+    } while (0)
 
     // y of one 32-row block im_ -> staging buffer
 #define W4_EPI_WRITE(im_, GELU_)                                                                                       \
@@ -332,6 +339,66 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     W4_STORE_M(im_, 4, y4_) W4_STORE_M(im_, 5, y5_) W4_STORE_M(im_, 6, y6_) W4_STORE_M(im_, 7, y7_)    \
                 }                                                                                                      \
             }                                                                                                          \
+        }
+    // ---- fused q / k post-processing (QKF; utx_gemm_desc.qk_cols): after the LDS transpose a lane holds 8 consecutive channels of one token's
+    // head row and 16 lanes share the row -- exactly the decomposition of qkv_post_kernel (dit_elementwise.hip), so its arithmetic is repeated
+    // verbatim: same sum order (in-lane pairs, then xor 8, 4, 2, 1 over the 16 lanes), same bf16 rounding points, IEEE div / sqrt, no contraction.
+    // cos / sin (2 x float4 per piece and lane) are requested ahead in a rolling window of four pieces, the first window before the block's write
+    // phase; the waits are literal counts of younger operations (full tiles; a ragged tile waits for everything).
+    typedef __attribute__((ext_vector_type(4))) float w4_f32x4v;
+    // all addresses of this path are (kernel-argument base in SGPRs) + (32-bit VGPR offset): a 64-bit per-piece address would be computed with
+    // vector multiplies, hoisted out of the tile loop and spilled inside the K loop
+#define W4_QK_ROWOFF(im_, t_) ((unsigned)(qsrow0 + 32 * (im_) + 4 * (t_) > qsrow_max ? qsrow_max : qsrow0 + 32 * (im_) + 4 * (t_)) * 256u)
+#define W4_QK_CS_LOAD(dst_, tab_, im_, t_)                                                                             \
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst_) : "v"(qvo + W4_QK_ROWOFF(im_, t_)), "s"(tab_) : "memory")
+#define W4_QK_PIECE(im_, t_, Y_, CS_, SN_, n_)                                                                         \
+        {                                                                                                              \
+            if (full) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(CS_), "+v"(SN_) : "n"(n_) : "memory"); }            \
+            else { asm volatile("s_waitcnt vmcnt(0)" : "+v"(CS_), "+v"(SN_) : : "memory"); }                           \
+            W4_FENCE();                                                                                                \
+            {                                                                                                          \
+            _Pragma("clang fp contract(off)")                                                                          \
+            const uint32_t rw_[4] = {Y_.x, Y_.y, Y_.z, Y_.w};                                                          \
+            float x_[8];                                                                                               \
+            float ss_ = 0.f;                                                                                           \
+            _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) {                                                         \
+                x_[2 * c_] = bf2f((uint16_t)(rw_[c_] & 0xffff)); x_[2 * c_ + 1] = bf2f((uint16_t)(rw_[c_] >> 16));     \
+                ss_ += x_[2 * c_] * x_[2 * c_] + x_[2 * c_ + 1] * x_[2 * c_ + 1];                                      \
+            }                                                                                                          \
+            _Pragma("unroll") for (int o_ = 8; o_ > 0; o_ >>= 1) ss_ += __shfl_xor(ss_, o_, 64);                       \
+            const float rstd_ = 1.0f / sqrtf(ss_ / 128.0f + p.qk_eps);                                                 \
+            uint32_t ow_[4];                                                                                           \
+            _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) {                                                         \
+                const float w0_ = bf2f((uint16_t)(gq[c_] & 0xffff)), w1_ = bf2f((uint16_t)(gq[c_] >> 16));             \
+                const float a0_ = rbf(rbf(x_[2 * c_] * rstd_) * w0_);                                                  \
+                const float a1_ = rbf(rbf(x_[2 * c_ + 1] * rstd_) * w1_);                                              \
+                const float r0_ = (a0_ * CS_[c_] + (-a1_) * SN_[c_]) * qs;                                             \
+                const float r1_ = (a1_ * CS_[c_] + a0_ * SN_[c_]) * qs;                                                \
+                ow_[c_] = pack2bf(r0_, r1_);                                                                           \
+            }                                                                                                          \
+            if (full || W4_ROW(im_, t_) < p.M) {                                                                       \
+                w4_u32x4 od_ = {ow_[0], ow_[1], ow_[2], ow_[3]};                                                       \
+                asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"(qvo + qhead + (unsigned)(qsrow0 + 32 * (im_) + 4 * (t_)) * 256u), "v"(od_), "s"(qdst) : "memory"); \
+            }                                                                                                          \
+            }                                                                                                          \
+            W4_FENCE();                                                                                                \
+        }
+#define W4_QK_BLOCK(im_)                                                                                               \
+        {                                                                                                              \
+            /* rolling window of four pieces of cos / sin (16 registers): piece t + 4 is requested into the registers of piece t as soon as that is done. \
+               Literal waits (full tiles): t < 4: 2 (3 - t) older-window loads + 3 t (store + 2 loads per finished piece) = 6 + t;                   \
+               t = 4 + j: 3 (3 - j) + j = 9 - 2 j */                                                                    \
+            w4_f32x4v c0_, s0_, c1_, s1_, c2_, s2_, c3_, s3_;                                                           \
+            W4_QK_CS_LOAD(c0_, p.qk_cos, im_, 0); W4_QK_CS_LOAD(s0_, p.qk_sin, im_, 0); W4_QK_CS_LOAD(c1_, p.qk_cos, im_, 1); W4_QK_CS_LOAD(s1_, p.qk_sin, im_, 1); \
+            W4_QK_CS_LOAD(c2_, p.qk_cos, im_, 2); W4_QK_CS_LOAD(s2_, p.qk_sin, im_, 2); W4_QK_CS_LOAD(c3_, p.qk_cos, im_, 3); W4_QK_CS_LOAD(s3_, p.qk_sin, im_, 3); \
+            W4_FENCE();                                                                                                \
+            W4_EPI_WRITE(im_, false)                                                                                   \
+            W4_EPI_READ8()                                                                                             \
+            W4_QK_PIECE(im_, 0, y0_, c0_, s0_, 6) W4_QK_CS_LOAD(c0_, p.qk_cos, im_, 4); W4_QK_CS_LOAD(s0_, p.qk_sin, im_, 4); W4_FENCE(); \
+            W4_QK_PIECE(im_, 1, y1_, c1_, s1_, 7) W4_QK_CS_LOAD(c1_, p.qk_cos, im_, 5); W4_QK_CS_LOAD(s1_, p.qk_sin, im_, 5); W4_FENCE(); \
+            W4_QK_PIECE(im_, 2, y2_, c2_, s2_, 8) W4_QK_CS_LOAD(c2_, p.qk_cos, im_, 6); W4_QK_CS_LOAD(s2_, p.qk_sin, im_, 6); W4_FENCE(); \
+            W4_QK_PIECE(im_, 3, y3_, c3_, s3_, 9) W4_QK_CS_LOAD(c3_, p.qk_cos, im_, 7); W4_QK_CS_LOAD(s3_, p.qk_sin, im_, 7); W4_FENCE(); \
+            W4_QK_PIECE(im_, 4, y4_, c0_, s0_, 9) W4_QK_PIECE(im_, 5, y5_, c1_, s1_, 7) W4_QK_PIECE(im_, 6, y6_, c2_, s2_, 5) W4_QK_PIECE(im_, 7, y7_, c3_, s3_, 3) \
         }
     // gated: out = res + bf16(gate * y), the rounding points of gemm.hip
 #define W4_GATE_OUT(Y_, R_, O_)                                                                                        \
@@ -433,6 +500,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             } else {                                                                                                   \
                 W4_GATE_SLOW_BLOCK(0) W4_GATE_SLOW_BLOCK(1) W4_GATE_SLOW_BLOCK(2) W4_GATE_SLOW_BLOCK(3)                \
             }                                                                                                          \
+        } else if (QKF && c_n0 < p.qk_cols) {                                                                         \
+            /* this wave's 128 columns = one head of q (columns < qk_cols / 2) or k */                                 \
+            const int col0 = c_n0 + wn * 128, dq = p.qk_cols >> 1;                                                      \
+            const bool isk = col0 >= dq;                                                                               \
+            const int head = (isk ? col0 - dq : col0) >> 7;                                                            \
+            const float qs = isk ? 1.0f : p.qk_q_scale;                                                                \
+            const int qsrow0 = p.qk_tok_off + c_m0 + wm * 128, qsrow_max = p.qk_tok_off + p.M - 1;                      \
+            const unsigned qvo = (unsigned)((elane >> 4) * 256 + (elane & 15) * 16);                                    \
+            const char* const qdst = (const char*)(isk ? p.qk_Kh : p.qk_Qh);                                          \
+            const unsigned qhead = (unsigned)head * (unsigned)p.qk_hs * 2u;        /* byte offset of this head: < 4 GB for any S this library sizes for */ \
+            asm volatile("s_waitcnt vmcnt(6)" : "+v"(gq) : : "memory");      /* the head's norm weight, requested at the tile's start: every K-tile's vmcnt(0) has drained it; only the six pieces of the last K-step 3 are younger */ \
+            W4_QK_BLOCK(0) W4_QK_BLOCK(1) W4_QK_BLOCK(2) W4_QK_BLOCK(3)                                                \
         } else {                                                                                                       \
             if (do_gelu) { W4_PLAIN_BLOCK(0, true) W4_PLAIN_BLOCK(1, true) W4_PLAIN_BLOCK(2, true) W4_PLAIN_BLOCK(3, true) } \
             else { W4_PLAIN_BLOCK(0, false) W4_PLAIN_BLOCK(1, false) W4_PLAIN_BLOCK(2, false) W4_PLAIN_BLOCK(3, false) } \
@@ -518,6 +597,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         W4_TRACE(-1);
         if (!(ABL & 8)) W4_EPILOGUE();
         W4_TRACE(-2);
+        {   // F0 of the next tile's first K-step was prefetched by K-step 3 -- re-read it here instead of keeping 32 registers alive across the
+            // epilogue (its stage is intact; one exposed LDS latency per tile buys the epilogue a quarter more VGPRs)
+            const int rb = c_slot * W4_STAGE;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) W4_READ(r, fa0, fb0, rb, xk0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            W4_FENCE();
+        }
         c_tile += G;
         if (c_tile >= ntiles) break;
         W4_COMPUTE_SETUP();
@@ -559,6 +646,11 @@ extern "C" int utx_launch_gemm_w4(GemmParams p, hipStream_t stream) {
         if (p.gelu_from < p.N || p.n_split < p.N) return -2;
         hipLaunchKernelGGL((gemm256_w4_kernel<true>), dim3(grid), dim3(256), LDS, stream, p, tiles, trace_wg);
     } else {
+        if (p.qk_cols > 0) {
+            static bool aq = false;
+            if (!aq) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_w4_kernel<false, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3; aq = true; }
+            hipLaunchKernelGGL((gemm256_w4_kernel<false, 0, true>), dim3(grid), dim3(256), LDS, stream, p, tiles, trace_wg);
+        } else
         hipLaunchKernelGGL((gemm256_w4_kernel<false>), dim3(grid), dim3(256), LDS, stream, p, tiles, trace_wg);
     }
     return hipGetLastError() == hipSuccess ? 0 : -4;

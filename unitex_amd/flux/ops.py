@@ -51,7 +51,7 @@ def attention(q, k, vt, S=None, scale=None, out=None, o_ss=None, key_bias_log2=0
 
 
 def make_gemm_desc(A, B, C_out, bias=None, A2=None, B2=None, lora_n_limit=None, lora_seg_n=None, alpha=1.0,
-                   gelu_from=None, gate=None, res=None, n_split=None, C1=None, a_scale=None, b_scale=None):
+                   gelu_from=None, gate=None, res=None, n_split=None, C1=None, a_scale=None, b_scale=None, qk_post=None):
     """a_scale / b_scale given: A and B are OCP MX fp8 operands (uint8 e4m3 bytes + E8M0 scales [rows, K/32], flux/mx8.py)."""
     M, K = A.shape
     N = B.shape[0]
@@ -68,6 +68,12 @@ def make_gemm_desc(A, B, C_out, bias=None, A2=None, B2=None, lora_n_limit=None, 
     else:
         d.K2, d.lora_n_limit, d.lora_seg_n = 0, 0, 128
     d.M, d.N, d.K = M, N, K
+    if qk_post is not None:
+        # fused q / k post-processing (utx_gemm_desc.qk_cols): dict(cols, tok_off, eps, q_scale, wq, wk, cos, sin, Qh, Kh)
+        q = qk_post
+        d.qk_cols, d.qk_tok_off, d.qk_eps, d.qk_q_scale = int(q["cols"]), int(q["tok_off"]), float(q["eps"]), float(q["q_scale"])
+        d.qk_wq, d.qk_wk, d.qk_cos, d.qk_sin = ptr(q["wq"]), ptr(q["wk"]), ptr(q["cos"]), ptr(q["sin"])
+        d.qk_Qh, d.qk_Kh, d.qk_hs = ptr(q["Qh"]), ptr(q["Kh"]), q["Qh"].stride(0)
     d.alpha = alpha
     d.bias = ptr(bias)
     d.gelu_from = N if gelu_from is None else gelu_from
@@ -79,6 +85,19 @@ def make_gemm_desc(A, B, C_out, bias=None, A2=None, B2=None, lora_n_limit=None, 
     if C1 is not None:
         d.C1, d.ldc1 = ptr(C1), C1.stride(0)
     return d
+
+
+def gemm_takes_w4(M, N, n_split=None, gelu_from=None, K2=0, lora_seg_n=None, lora_n_limit=None):
+    """True when utx_gemm_bf16 dispatches this shape to the one-wave-per-SIMD 256 x 256 kernel (gemm_w4.hip) -- the kernel that carries the
+    fused q / k epilogue; mirrors the rule in gemm.hip (`ok256`, >= 192 tiles, default UTX_GEMM_TILE / no tail split)."""
+    opt = _lib.get_options()
+    if opt.get("UTX_GEMM_TILE", 0) not in (0, 2564) or opt.get("UTX_GEMM_TAILSPLIT", 0) != 0:
+        return False
+    ok = (N % 256 == 0) and (n_split is None or n_split >= N or n_split % 256 == 0) and (gelu_from is None or gelu_from >= N or gelu_from % 256 == 0)
+    if K2:
+        ok = ok and (lora_seg_n or N) % 256 == 0 and (lora_n_limit if lora_n_limit is not None else N) % 256 == 0
+    tiles = ((M + 255) // 256) * ((N + 255) // 256)
+    return bool(ok and (tiles >= 192 or opt.get("UTX_GEMM_TILE", 0) == 2564))
 
 
 def gemm(A, B, bias=None, out=None, **kw):
@@ -110,7 +129,7 @@ def gemv(x, W, bias=None, silu_in=False, silu_out=False, out=None):
 
 
 def qkv_post(qkv, q_col, k_col, v_col, wq, wk, cos, sin, Qh, Kh, Vt, n_tok, tok_off, H, eps=1e-6, q_scale=1.0,
-             heads_per_group=0, group_stride=0, head_stride=None, row_stride_v=None):
+             heads_per_group=0, group_stride=0, head_stride=None, row_stride_v=None, skip_qk=False):
     """heads_per_group > 0: Qh / Kh / Vt are flat bases of a grouped layout (the sequence-parallel send buffer, ulysses.py):
     head h at (h // g) * group_stride + (h % g) * head_stride, V^T rows row_stride_v apart."""
     ctx = get_ctx(qkv.device.index)
@@ -127,6 +146,7 @@ def qkv_post(qkv, q_col, k_col, v_col, wq, wk, cos, sin, Qh, Kh, Vt, n_tok, tok_
     else:
         d.hs_qk, d.hs_v, d.S_pad = Qh.stride(0), Vt.stride(0), Vt.shape[2]
     d.n_tok, d.tok_off, d.H, d.eps, d.q_scale = n_tok, tok_off, H, eps, q_scale
+    d.skip_qk = int(bool(skip_qk))      # q / k came out of the GEMM's fused epilogue (make_gemm_desc(qk_post=...)): V transpose only
     ctx.check(ctx.lib.utx_qkv_post(ctx.handle, C.byref(d), ctx.stream()))
 
 

@@ -96,6 +96,11 @@ class FluxDiT:
         self.lib = self.ctx.lib
         self._plans = {}
         self._graphs = {}
+        # q / k post-processing (RMSNorm + RoPE + head-major store) fused into the QKV projection's epilogue where the GEMM runs on the
+        # one-wave-per-SIMD kernel (utx_gemm_desc.qk_cols): UTX_FUSE_QK=1.  Bit-identical to GEMM -> utx_qkv_post, but OFF by default: that
+        # kernel's epilogue is exposed (nothing overlaps it with one wave per SIMD) and the per-piece RMSNorm / RoPE arithmetic costs it more
+        # than the saved pass over qkv -- 2045.2 -> 2052.1 ms per step at S = 50 688, equal at S = 13 824 (profiles/r02_bench_fuse_qk_ab.log)
+        self.fuse_qk = os.environ.get("UTX_FUSE_QK", "0") == "1"
         self.out_rows = None       # set_output_rows: image rows whose prediction the caller consumes (None = all)
         self._lora_active: List[Tuple[Dict, float]] = []
         self._lora_version = 0
@@ -345,7 +350,7 @@ class FluxDiT:
         d.y, d.ldy, d.n_tok, d.D, d.eps = ptr(y), y.stride(0), x.shape[0], x.shape[1], 1e-6
         plan.append((self.lib.utx_ln_mod, d))
 
-    def _qkvpost(self, plan, qkv, wq, wk, ws, n_tok, tok_off):
+    def _qkvpost(self, plan, qkv, wq, wk, ws, n_tok, tok_off, skip_qk=False):
         sh, D = self.shape, self.shape.dim
         d = QkvPostDesc()
         d.qkv, d.ld, d.q_col, d.k_col, d.v_col = ptr(qkv), qkv.stride(0), 0, D, 2 * D
@@ -361,6 +366,7 @@ class FluxDiT:
             d.hs_qk, d.hs_v, d.S_pad = ws["Qh"].stride(0), ws["Vt"].stride(0), ws["Vt"].shape[2]
         d.n_tok, d.tok_off, d.H, d.eps = n_tok, tok_off, sh.num_heads, 1e-6
         d.q_scale = (1.0 / math.sqrt(128.0)) * 1.4426950408889634   # scores become base-2 exponents (attention scale=0)
+        d.skip_qk = int(bool(skip_qk))
         plan.append((self.lib.utx_qkv_post, d))
 
     def _attn(self, plan, ws, out, S, q_rows=None):
@@ -429,6 +435,13 @@ class FluxDiT:
                 return None
             return (b[nm + ".q"], b[nm + ".s"], ws["aq"][row0:], ws["as"][row0:])
         W, mod = self.W, ws["mod"][0]
+
+        def qk_fused(M, N, tok_off, wq, wk, **shape_kw):
+            """qk_post argument of the QKV projection when its GEMM takes the kernel that has the fused epilogue, else None."""
+            if not (self.fuse_qk and self.sp is None and not self.fp8_weights and ops.gemm_takes_w4(M, N, **shape_kw)):
+                return None
+            return dict(cols=2 * D, tok_off=tok_off, eps=1e-6, q_scale=(1.0 / math.sqrt(128.0)) * 1.4426950408889634,
+                        wq=wq, wk=wk, cos=ws["cos"], sin=ws["sin"], Qh=ws["Qh"], Kh=ws["Kh"])
         h, xn, qkv, cat, attn = ws["h"], ws["xn"], ws["qkv"], ws["cat"], ws["attn"]
         h_c, h_x = h[:S_txt], h[S_txt:]
         xn_c, xn_x = xn[:S_txt], xn[S_txt:]
@@ -461,11 +474,13 @@ class FluxDiT:
             px, pc = [], []
             self._lnmod(px, h_x, xn_x, sh_a, sc_a)
             self._lnmod(pc, h_c, xn_c, csh_a, csc_a)
+            has_l = b.get("lora.qkv_x") is not None
+            qkx = qk_fused(S_img, 3 * D, S_txt, b["nq"], b["nk"], K2=(Rp if has_l else 0), lora_seg_n=D, lora_n_limit=3 * D)
             self._gemm(px, xn_x, b["qkv_x.w"], qkv[S_txt:], bias=b["qkv_x.b"], lora=b.get("lora.qkv_x"),
-                       lora_n_limit=3 * D, lora_seg_n=D, T=T, mx8=mx(b, "qkv_x", S_txt))
+                       lora_n_limit=3 * D, lora_seg_n=D, T=T, mx8=mx(b, "qkv_x", S_txt), qk_post=qkx)
             self._gemm(pc, xn_c, b["qkv_c.w"], qkv[:S_txt], bias=b["qkv_c.b"], lora=b.get("lora.qkv_c"),
                        lora_n_limit=3 * D, lora_seg_n=D, T=Tc)
-            self._qkvpost(px, qkv[S_txt:], b["nq"], b["nk"], ws, S_img, S_txt)
+            self._qkvpost(px, qkv[S_txt:], b["nq"], b["nk"], ws, S_img, S_txt, skip_qk=qkx is not None)
             self._qkvpost(pc, qkv[:S_txt], b["naq"], b["nak"], ws, S_txt, 0)
             self._par(plan, px, pc)
             if self.sp is not None:
@@ -514,9 +529,12 @@ class FluxDiT:
                 continue
             if self.sp is None:
                 # one GEMM for [q|k|v|proj_mlp]: qkv -> qkv buffer, GELU(mlp) -> cat[:, D:]
+                has_l = b.get("lora.qkvm") is not None
+                qkm = qk_fused(S, (3 + sh.mlp_ratio) * D, 0, b["nq"], b["nk"], n_split=3 * D, gelu_from=3 * D, K2=(Rp if has_l else 0),
+                               lora_seg_n=D, lora_n_limit=3 * D)
                 self._gemm(plan, xn, b["qkvm.w"], qkv, bias=b["qkvm.b"], lora=b.get("lora.qkvm"), lora_n_limit=3 * D,
-                           lora_seg_n=D, T=T, gelu_from=3 * D, n_split=3 * D, C1=cat[:, D:], mx8=mx(b, "qkvm"))
-                self._qkvpost(plan, qkv, b["nq"], b["nk"], ws, S, 0)
+                           lora_seg_n=D, T=T, gelu_from=3 * D, n_split=3 * D, C1=cat[:, D:], mx8=mx(b, "qkvm"), qk_post=qkm)
+                self._qkvpost(plan, qkv, b["nq"], b["nk"], ws, S, 0, skip_qk=qkm is not None)
             else:
                 # sequence parallel: the same GEMM cut at column 3D (identical arithmetic per column) so that the Q/K/V exchange
                 # starts as soon as q|k|v exist and the MLP half of the projection runs beside the all-to-all
