@@ -597,8 +597,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         W4_TRACE(-1);
         if (!(ABL & 8)) W4_EPILOGUE();
         W4_TRACE(-2);
-        {   // F0 of the next tile's first K-step was prefetched by K-step 3 -- re-read it here instead of keeping 32 registers alive across the
-            // epilogue (its stage is intact; one exposed LDS latency per tile buys the epilogue a quarter more VGPRs)
+        if constexpr (QKF) {   // F0 of the next tile's first K-step was prefetched by K-step 3 -- the fused q / k variant re-reads it here instead of
+            // keeping 32 registers alive across its larger epilogue (the stage is intact; one exposed LDS latency per tile)
             const int rb = c_slot * W4_STAGE;
 #pragma unroll
             for (int r = 0; r < 8; ++r) W4_READ(r, fa0, fb0, rb, xk0);
