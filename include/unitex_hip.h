@@ -132,8 +132,15 @@ typedef struct utx_gemm_desc {
     const void* qk_wq; const void* qk_wk;
     const float* qk_cos; const float* qk_sin;
     void* qk_Qh; void* qk_Kh; long qk_hs;
+    /* Optional scratch for the balanced tail of the one-wave-per-SIMD kernel (UTX_GEMM_STREAMK, default on): when the 256 x 256 tiles do not
+     * fill the last round of workgroups, the K loops of that round's tiles are cut into equal ranges over all CUs, the fp32 partial tiles
+     * pass through sk_work and a second small kernel sums them in K order and runs the epilogue (deterministic; differs from the unsplit
+     * result only by fp32 summation order).  Caller-owned, >= utx_gemm_streamk_workspace_bytes(), one buffer per stream that launches
+     * GEMMs concurrently; NULL = never split. */
+    void* sk_work; size_t sk_work_bytes;
 } utx_gemm_desc;
 int utx_gemm_bf16(utx_ctx* ctx, const utx_gemm_desc* d, utx_stream stream);
+size_t utx_gemm_streamk_workspace_bytes(utx_ctx* ctx);   /* size of utx_gemm_desc.sk_work for this device (2 partial tiles per CU) */
 
 /* OCP MX fp8 quantisation of a bf16 matrix along its rows (the activation operand of an mx8 GEMM):
  *   per block of 32 consecutive elements: e = floor(log2(max|x|)) - 8 (clamped to [-127, 127]; -127 for an all-zero block),

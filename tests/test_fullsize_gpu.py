@@ -82,7 +82,11 @@ def _set_tile(v):
 
 
 def _gemm_variants(fn):
+    """one result per GEMM kernel.  The kernels promise identical bits for the same summation order, so the split tail round of the
+    default kernel (UTX_GEMM_STREAMK: fp32 partial sums over K ranges, its own test below) is off here."""
+    from unitex_amd import _lib
     outs = {}
+    _lib.set_option("UTX_GEMM_STREAMK", 0)
     try:
         for tile in ("128", "2562", "256", "2560", "2564"):     # 2564 = the persistent one-wave-per-SIMD kernel (gemm_w4.hip), the default for the large shapes; 2560 = the persistent 8-wave kernel (gemm_pers.hip)
             _set_tile(tile)
@@ -90,11 +94,93 @@ def _gemm_variants(fn):
             torch.cuda.synchronize()
     finally:
         _set_tile(None)
+        _lib.set_option("UTX_GEMM_STREAMK", 1)
     return outs
 
 
 def _same_bits(a, b):
     return torch.equal(a.view(torch.int16), b.view(torch.int16))
+
+
+@pytest.mark.parametrize("M,N,K,K2,kind", [(50240, 3072, 15360, 64, "gate"), (13376, 3072, 12288, 64, "gate"), (13001, 3072, 12288, 64, "gelu"),
+                                           (6144, 3072, 15360, 0, "gate"), (13376, 9216, 3072, 64, "split")])
+def test_gemm_split_tail_round_matches_unsplit_launch_and_oracle_rows(M, N, K, K2, kind):
+    """UTX_GEMM_STREAMK (default on; gemm_w4.hip "split tail"): when the 256 x 256 tiles leave the last round of workgroups less than half full,
+    the tiles of that round are cut along K, fp32 partial tiles go through utx_gemm_desc.sk_work and gemm_w4_fixup_kernel sums them in K order
+    and runs the epilogue.  Shapes: the single-block out-projection of BASELINE's strip (9.23 rounds -> 4 ranges per tail tile), the reference
+    strip's MLP down-projection (2.48 rounds -> 2 ranges), a ragged M with GELU, the pruned last block (1.12 rounds -> 8 ranges) and a
+    column-split QKV projection.  Contract: every tile of the whole rounds has the bits of the unsplit launch; tail tiles differ by fp32
+    summation order only (<= 1 bf16 ulp of the pre-residual value); two launches give the same bits; sampled rows match the oracle."""
+    from unitex_amd import _lib
+    ops = _ops()
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    A = (torch.randn(M, K, device="cuda", generator=g) / 2).to(BF)
+    W = (torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K)).to(BF)
+    bias = torch.randn(N, device="cuda", generator=g).to(BF)
+    kw = {}
+    if K2:
+        kw.update(A2=(torch.randn(M, K2, device="cuda", generator=g) / 8).to(BF), B2=(torch.randn(N, K2, device="cuda", generator=g) / 4).to(BF))
+    res = torch.randn(M, N, device="cuda", generator=g).to(BF)
+    gate = torch.randn(N, device="cuda", generator=g).to(BF)
+
+    def run():
+        if kind == "gate":
+            r = res.clone()
+            ops.gemm(A, W, bias=bias, out=r, gate=gate, res=r, **kw)        # in place, as the DiT uses it
+            return r
+        if kind == "gelu":
+            return ops.gemm(A, W, bias=bias, gelu_from=0, **kw)
+        c0 = torch.empty(M, N - 3072, dtype=BF, device="cuda")
+        c1 = torch.empty(M, 3072, dtype=BF, device="cuda")
+        ops.gemm(A, W, bias=bias, out=c0, n_split=N - 3072, C1=c1, **kw)
+        return torch.cat([c0, c1], 1)
+    try:
+        _lib.set_option("UTX_GEMM_STREAMK", 0)
+        base = run()
+        _lib.set_option("UTX_GEMM_STREAMK", 1)
+        s1 = run()
+        s2 = run()
+    finally:
+        _lib.set_option("UTX_GEMM_STREAMK", 1)
+    torch.cuda.synchronize()
+    assert _same_bits(s1, s2), "split tail round is not deterministic"
+    ntn, tiles = N // 256, ((M + 255) // 256) * (N // 256)
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    T = tiles % ncu
+    assert tiles > ncu and 0 < T <= ncu // 2, "shape does not exercise the split (tiles %d, CUs %d)" % (tiles, ncu)
+    diff = (s1 != base)
+    assert bool(diff.any()), "the split launch has the bits of the unsplit one everywhere: the tail round was not split"
+    # tiles are numbered in groups of 4 row-tiles x all column tiles, column-major inside a group (gemm_w4.hip W4_TILE_ORIGIN); the tail tiles are the
+    # last T of that order.  Everything else must be untouched.
+    ntm, gm = (M + 255) // 256, 4
+    tail = torch.zeros(ntm, ntn, dtype=torch.bool)
+    for w in range(tiles - T, tiles):
+        grp, rem = divmod(w, gm * ntn)
+        gs = min(gm, ntm - grp * gm)
+        tn, tm = divmod(rem, gs)
+        tail[grp * gm + tm, tn] = True
+    dt = diff.cpu()
+    dt = torch.nn.functional.pad(dt, (0, 0, 0, ntm * 256 - M)).view(ntm, 256, ntn, 256).any(3).any(1)
+    assert not bool((dt & ~tail).any()), "a tile outside the last round changed"
+    # rounding only: the GEMM value moves by at most one bf16 ulp (2^-7 relative; x |gate|, GELU' <= 1.13 on top -> 2^-6 of the pre-residual
+    # value), and the gated residual sum is rounded once more (2^-7 of the output)
+    y0 = (base.float() - res.float()) if kind == "gate" else base.float()
+    y1 = (s1.float() - res.float()) if kind == "gate" else s1.float()
+    bound = 2.0 ** -6 * torch.maximum(y0.abs(), y1.abs()).clamp_min(1.0)
+    if kind == "gate":
+        bound = bound + 2.0 ** -7 * torch.maximum(base.float().abs(), s1.float().abs())
+    assert bool(((s1.float() - base.float()).abs() <= bound).all()), "split tail differs from the unsplit launch by more than rounding"
+    rows = torch.tensor([0, 255, M // 2 + 17, M - 300, M - 2, M - 1])
+    y = A[rows].float().cpu() @ W.float().cpu().t()
+    if K2:
+        y += kw["A2"][rows].float().cpu() @ kw["B2"].float().cpu().t()
+    y = (y + bias.float().cpu()).to(BF).float()
+    if kind == "gelu":
+        y = dit_ref.gelu_tanh(y).to(BF).float()
+    if kind == "gate":
+        y = (res[rows].float().cpu() + (gate.float().cpu() * y).to(BF).float()).to(BF).float()
+    rel = ((s1[rows].float().cpu() - y).abs() / y.abs().clamp_min(1.0)).max().item()
+    assert rel < 1.6e-2, "split tail vs oracle rows: %g" % rel
 
 
 @pytest.mark.parametrize("M", [S_FULL, 13824, 6336])   # 6336 = 50688 / 8: ragged last 256-row tile (sequence-parallel shard)
@@ -229,6 +315,8 @@ def test_full_width_dit_blocks_at_config1_shape_match_oracle():
     loras = [(la, 1.0), (lb, 0.0)]
     m = FluxDiT(sd, shape, device="cuda:0")
     m.fuse_qk = True            # opt-in (UTX_FUSE_QK=1): q / k post-processing inside the QKV projections' epilogue
+    from unitex_amd import _lib
+    _lib.set_option("UTX_GEMM_STREAMK", 0)      # the bit-comparison below spans a fused (never split) and an unfused (tail round split) QKV projection
     m.set_lora(loras)
     m.set_positions(txt_ids, img_ids)
     m.set_conditioning(enc.cuda(), pooled.cuda(), 3.5)
@@ -251,7 +339,13 @@ def test_full_width_dit_blocks_at_config1_shape_match_oracle():
     m.set_conditioning(enc.cuda(), pooled.cuda(), 3.5)
     assert sum(1 for fn, d in _flat_plan(m) if fn is m.lib.utx_gemm_bf16 and d.qk_cols > 0) == 0
     out2 = m.forward(lat.cuda(), 0.4375).float().cpu()
+    _lib.set_option("UTX_GEMM_STREAMK", 1)
     assert torch.equal(out2, out), "fused q / k epilogue changed the forward: max |d| %g" % (out2 - out).abs().max().item()
+    # and with the split tail round of the large GEMMs (the default): same forward up to fp32 summation order in the tail tiles
+    m._plans.clear()
+    m.set_conditioning(enc.cuda(), pooled.cuda(), 3.5)
+    out3 = m.forward(lat.cuda(), 0.4375).float().cpu()
+    assert (out3 - ref).abs().max().item() < 0.03 * max(mx, 1.0) and (out3 - out).abs().max().item() < 0.02 * max(mx, 1.0)
 
 
 def _flat_plan(m):

@@ -26,7 +26,8 @@ class GemmDesc(C.Structure):
                 ("a_scale", c_void_p), ("lds_a", c_long), ("b_scale", c_void_p), ("lds_b", c_long), ("mx8", c_int),
                 ("qk_cols", c_int), ("qk_tok_off", c_int), ("qk_eps", c_float), ("qk_q_scale", c_float),
                 ("qk_wq", c_void_p), ("qk_wk", c_void_p), ("qk_cos", c_void_p), ("qk_sin", c_void_p),
-                ("qk_Qh", c_void_p), ("qk_Kh", c_void_p), ("qk_hs", c_long)]
+                ("qk_Qh", c_void_p), ("qk_Kh", c_void_p), ("qk_hs", c_long),
+                ("sk_work", c_void_p), ("sk_work_bytes", C.c_size_t)]
 
 
 class GemvDesc(C.Structure):
@@ -85,6 +86,7 @@ SYMBOLS = {
     "utx_attn_fwd_bf16_kb": (c_int, [c_void_p] * 5 + [c_long] * 7 + [c_int, c_int, c_float, c_float, c_int, c_void_p]),
     "utx_attn_fwd_bf16_kbq": (c_int, [c_void_p] * 5 + [c_long] * 7 + [c_int, c_int, c_int, c_float, c_float, c_int, c_void_p]),
     "utx_gemm_bf16": (c_int, [c_void_p, C.POINTER(GemmDesc), c_void_p]),
+    "utx_gemm_streamk_workspace_bytes": (C.c_size_t, [c_void_p]),
     "utx_quant_mx8": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_void_p]),
     "utx_gemv_bf16": (c_int, [c_void_p, C.POINTER(GemvDesc), c_void_p]),
     "utx_group_norm_workspace_bytes": (c_long, []),
@@ -159,7 +161,7 @@ def load_library():
 
 OPTION_NAMES = ["UTX_ATTN_GLDS", "UTX_ATTN_FAST", "UTX_ATTN_Q64", "UTX_ATTN_TPB", "UTX_ATTN_TAILSPLIT",
                 "UTX_GEMM_GROUP_M", "UTX_GEMM_TILE", "UTX_GEMM_TAILSPLIT", "UTX_GEMM_PERS_GRID", "UTX_GEMM_PERS_SCHED",
-                "UTX_BVH_STACK_WALK"]
+                "UTX_GEMM_STREAMK", "UTX_BVH_STACK_WALK"]
 
 
 def set_option(name, value):

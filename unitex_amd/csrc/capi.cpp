@@ -7,7 +7,7 @@
 #include <stdlib.h>
 #include "kernels.h"
 
-UtxOptions g_utx_opt = {1, 2, 0, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+UtxOptions g_utx_opt = {1, 2, 0, 1, 1, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0};
 
 struct OptName { const char* name; int UtxOptions::*field; bool ablation; };
 static const OptName kOptions[] = {
@@ -16,7 +16,8 @@ static const OptName kOptions[] = {
     {"UTX_ATTN_TAILSPLIT", &UtxOptions::attn_tailsplit, false},
     {"UTX_GEMM_GROUP_M", &UtxOptions::gemm_group_m, false}, {"UTX_GEMM_TILE", &UtxOptions::gemm_tile, false},
     {"UTX_GEMM_TAILSPLIT", &UtxOptions::gemm_tailsplit, false}, {"UTX_GEMM_PERS_GRID", &UtxOptions::gemm_pers_grid, false},
-    {"UTX_GEMM_PERS_SCHED", &UtxOptions::gemm_pers_sched, false}, {"UTX_BVH_STACK_WALK", &UtxOptions::bvh_stack_walk, false},
+    {"UTX_GEMM_PERS_SCHED", &UtxOptions::gemm_pers_sched, false}, {"UTX_GEMM_STREAMK", &UtxOptions::gemm_streamk, false},
+    {"UTX_BVH_STACK_WALK", &UtxOptions::bvh_stack_walk, false},
     {"UTX_ATTN_VAR", &UtxOptions::attn_var_abl, true},      {"UTX_ATTN_DEBUG", &UtxOptions::attn_debug_abl, true},
     {"UTX_GEMM_DEBUG", &UtxOptions::gemm_debug_abl, true},
 };
@@ -130,6 +131,7 @@ int utx_attn_fwd_bf16_kbq(utx_ctx* ctx, const void* q, const void* k, const void
                                  softmax_scale, key_bias_log2, key_bias_period, (hipStream_t)stream));
 }
 
+size_t utx_gemm_streamk_workspace_bytes(utx_ctx*) { return utx_gemm_streamk_workspace_bytes_impl(); }
 int utx_gemm_bf16(utx_ctx* ctx, const utx_gemm_desc* d, utx_stream stream) {
     if (!d || !d->A || !d->B || !d->C) return fail(ctx, -2, "utx_gemm_bf16");
     UTX_CALL(ctx, "utx_gemm_bf16", utx_launch_gemm_bf16(d, (hipStream_t)stream));

@@ -21,6 +21,9 @@
 //     ~30 cycles each beyond their MFMA shadow; one per three MFMAs (below) is worth +3-4 % over one per MFMA;
 //   * the epilogue (8.5k cycles per tile: 256 v_accvgpr_read + fma + pack + LDS transpose) is exposed -- nothing overlaps it with one wave
 //     per SIMD: bias through ONE scalar-load burst, accumulators re-zeroed by 16 MFMAs (0 x 0 + 0), C stores coalesced through LDS.
+//   * whole rounds of 256 tiles are the unit of time of a persistent kernel: 636 tiles (the reference strip's N = 3072 linears) are 2.48 rounds and
+//     cost 3.  The last, partly filled round is cut along K instead ("split tail" below, gemm_w4_fixup_kernel): -13 / -14 % on the K = 12288 /
+//     15360 linears of the reference strip, -7 % on BASELINE's strip, -35 % on the pruned last block (profiles/r02_gemm_streamk_check_v4.log).
 // Result: +8-11 % over gemm256_pers_kernel on the FLUX shapes, 2-13 % behind the vendor kernel (profiles/r02_gemm_w4_check_v8.log); bench A/B
 // profiles/r02_bench_gemm_w4_ab.log.  Replacing every 32x32x16 MFMA by two 16x16x32 (the vendor kernel's shape; ablation) is worth 1-4 % more.
 //
@@ -76,7 +79,7 @@ __device__ __forceinline__ const char* w4_uniform(const char* p) {
 // 16 = epilogue without its C stores, 32 = the DMA cursor parked from the start (every DMA re-reads the same bytes)
 // QKF: the fused q / k post-processing of utx_gemm_desc.qk_cols (plain kernel only)
 template <bool GATED, int ABL = 0, bool QKF = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm256_w4_kernel(GemmParams p, int ntiles, int trace_wg) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm256_w4_kernel(GemmParams p, int ntiles, int trace_wg, int sk_T, int sk_S) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -100,6 +103,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int per_group = group_m * ntn;
     const int nss1 = p.K / 64, nss2 = p.K2 / 64;      // K-tiles of the base / LoRA segment
     const unsigned ldaB = (unsigned)p.lda * 2, ldbB = (unsigned)p.ldb * 2, lda2B = (unsigned)p.lda2 * 2, ldb2B = (unsigned)p.ldb2 * 2;
+    // ---- split tail (sk_T > 0; launcher: utx_launch_gemm_w4).  The ntiles - sk_T tiles of the whole rounds are walked as before; each of the sk_T
+    // tiles of the last, partly filled round is cut along K into sk_S equal ranges (sk_T * sk_S <= G) and workgroup w < sk_T * sk_S takes range
+    // j = w / sk_T of tail tile w % sk_T -- workgroups with neighbouring indices (one XCD) then work on neighbouring tiles at the SAME K offsets,
+    // the lockstep that lets them share operand panels in L2 during a whole round (a first version cut the tail's K-tiles into G exactly equal
+    // ranges that straddled tiles: every workgroup at its own K offset, and a third of the gain gone).  A range ends with its fp32
+    // accumulators written as they lie in the registers to slot w of p.sk_work (W4_DUMP); gemm_w4_fixup_kernel sums a tile's sk_S slots in K
+    // order and runs the epilogue.  nssu = K-tiles per tail tile, the same for every tail tile (the launcher checks).
+    const int nfull_tiles = ntiles - sk_T;
+    const int nssu = nss1 + ((p.K2 > 0 && p.lora_n_limit > 0) ? nss2 : 0);
+    // the segment after the current one of a cursor (tj_, tile_): the next whole tile of this workgroup, then its tail range.  Scalar work only.
+    // tj_: -1 whole tiles, 0 tail range not yet taken, 2 taken / none.  k1_ < 0 stands for "the whole tile" (its K extent depends on its columns)
+#define W4_NEXT_SEG(tj_, tile_, ok_, k0_, k1_)                                                     \
+    do {                                                                                           \
+        ok_ = false; k0_ = 0; k1_ = -1;                                                            \
+        if (tj_ < 0) {                                                                             \
+            tile_ += G;                                                                            \
+            if (tile_ < nfull_tiles) ok_ = true; else tj_ = sk_T > 0 ? 0 : 2;                      \
+        }                                                                                          \
+        if (!ok_ && tj_ == 0) {                                                                    \
+            tj_ = 2;                                                                               \
+            if (wid < sk_T * sk_S) {                                                               \
+                const int j_ = wid / sk_T;                                                         \
+                ok_ = true; tile_ = nfull_tiles + wid - j_ * sk_T;                                 \
+                k0_ = (j_ * nssu) / sk_S; k1_ = ((j_ + 1) * nssu) / sk_S;                          \
+            }                                                                                      \
+        }                                                                                          \
+    } while (0)
 
 #define W4_TILE_ORIGIN(w_, m0_, n0_)                                                       \
     do {                                                                                   \
@@ -122,7 +152,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const unsigned dchunk = (unsigned)(((lane & 7) ^ ((4 * (wave & 1) + (drow >> 1)) & 7)) << 4);
     const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
     int s_tile = wid, s_ss = 0, s_seg_end = 0, s_seg = 1, s_m0 = 0, s_n0 = 0, s_slot = 0;
-    bool s_lora = false;
+    int s_l2 = 0;       // K-tiles of the LoRA segment that follow the base segment of the cursor's tile (0: none)
+    int s_tj = -1;      // W4_NEXT_SEG
     const char *s_pA = nullptr, *s_pB = nullptr;
     unsigned voA0 = 0, voA1 = 0, voA2 = 0, voA3 = 0, voA4 = 0, voA5 = 0, voA6 = 0, voA7 = 0;
     unsigned voB0 = 0, voB1 = 0, voB2 = 0, voB3 = 0, voB4 = 0, voB5 = 0, voB6 = 0, voB7 = 0;
@@ -135,24 +166,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         voB0 = W4_ROWOFF_B(0, sb_); voB1 = W4_ROWOFF_B(1, sb_); voB2 = W4_ROWOFF_B(2, sb_); voB3 = W4_ROWOFF_B(3, sb_); \
         voB4 = W4_ROWOFF_B(4, sb_); voB5 = W4_ROWOFF_B(5, sb_); voB6 = W4_ROWOFF_B(6, sb_); voB7 = W4_ROWOFF_B(7, sb_); \
     } while (0)
-#define W4_SEG1_SETUP()                                                                                    \
+    // ONE piece of code places the cursor: K-tile kk_ of [.., k1_) of tile s_tile (K-tiles 0 .. nss1 - 1 = base segment, then the LoRA segment) --
+    // the start of a tile, the switch to its LoRA segment, the start of a tail segment and parking all come through here, so the sixteen
+    // per-lane offsets have one writer inside the loop (several writers under runtime branches cost registers in the K loop).
+    // park_: past its last segment the cursor keeps issuing (the loop has no conditional DMA): strides 0 -> every DMA re-reads the first 128 B
+    // of row 0 of A and B into ring slots nobody reads any more.
+#define W4_STAGE_AT(kk_, k1_, park_)                                                                       \
     do {                                                                                                   \
-        s_pA = w4_uniform((const char*)p.A + (long)s_m0 * ldaB);  s_pB = w4_uniform((const char*)p.B + (long)s_n0 * ldbB); \
-        W4_SET_OFFS(ldaB, ldbB);                                                                           \
-        s_ss = 0; s_seg_end = nss1; s_seg = 1;                                                             \
-    } while (0)
-#define W4_SEG2_SETUP()                                                                                    \
-    do {                                                                                                   \
-        s_pA = w4_uniform((const char*)p.A2 + (long)((s_n0 / p.lora_seg_n) * p.K2) * 2 + (long)s_m0 * lda2B); \
-        s_pB = w4_uniform((const char*)p.B2 + (long)s_n0 * ldb2B);                                         \
-        W4_SET_OFFS(lda2B, ldb2B);                                                                         \
-        s_ss = 0; s_seg_end = nss2; s_seg = 2;                                                             \
-    } while (0)
-#define W4_STAGE_SETUP()                                                                   \
-    do {                                                                                   \
-        W4_TILE_ORIGIN(s_tile, s_m0, s_n0);                                                \
-        s_lora = (p.K2 > 0) && (s_n0 < p.lora_n_limit);                                    \
-        W4_SEG1_SETUP();                                                                   \
+        W4_TILE_ORIGIN(s_tile, s_m0, s_n0);                                                                \
+        const int k1r_ = (k1_) < 0 ? nss1 + (((p.K2 > 0) && (s_n0 < p.lora_n_limit)) ? nss2 : 0) : (k1_); \
+        const bool in2_ = (kk_) >= nss1;                                                                   \
+        const int kk2_ = in2_ ? (kk_) - nss1 : (kk_);                                                      \
+        const unsigned sa_ = (park_) ? 0u : in2_ ? lda2B : ldaB, sb_ = (park_) ? 0u : in2_ ? ldb2B : ldbB; \
+        const char* const a_ = in2_ ? (const char*)p.A2 + (long)((s_n0 / p.lora_seg_n) * p.K2) * 2 : (const char*)p.A; \
+        const char* const b_ = in2_ ? (const char*)p.B2 : (const char*)p.B;                                \
+        s_pA = w4_uniform(a_ + (long)s_m0 * sa_ + (long)kk2_ * 128);                                       \
+        s_pB = w4_uniform(b_ + (long)s_n0 * sb_ + (long)kk2_ * 128);                                       \
+        W4_SET_OFFS(sa_, sb_);                                                                             \
+        s_ss = kk2_; s_seg = in2_ ? 2 : 1;                                                                 \
+        s_seg_end = (park_) ? 0x7fffffff : in2_ ? k1r_ - nss1 : (k1r_ < nss1 ? k1r_ : nss1);               \
+        s_l2 = in2_ ? 0 : (k1r_ > nss1 ? k1r_ - nss1 : 0);                                                 \
     } while (0)
 #define W4_SVALID (s_tile < ntiles)
     // DMA d_ (0..7, literal) of operand A (isb_ = 0) / B (1) of the cursor's K-tile
@@ -167,16 +200,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         s_slot ^= 1;                                                                       \
         ++s_ss;                                                                            \
         if (s_ss == s_seg_end) {                                                           \
-            if (s_seg == 1 && s_lora) {                                                    \
-                W4_SEG2_SETUP();                                                           \
-            } else {                                                                       \
-                s_tile += G;                                                               \
-                if (s_tile < ntiles) W4_STAGE_SETUP(); else W4_PARK();                     \
-            }                                                                              \
+            bool ok_; int kk_, k1_;                                                        \
+            if (s_seg == 1 && s_l2 > 0) { ok_ = true; kk_ = nss1; k1_ = nss1 + s_l2; }     \
+            else W4_NEXT_SEG(s_tj, s_tile, ok_, kk_, k1_);                                 \
+            if (!ok_) { s_tile = 0; kk_ = 0; k1_ = 1; }                                    \
+            W4_STAGE_AT(kk_, k1_, !ok_);                                                   \
         }                                                                                  \
     } while (0)
-    // past the last tile the cursor keeps issuing (the loop has no conditional DMA): it re-reads the first 128 bytes of the first rows
-    // of A and B into ring slots nobody reads any more
+    // ABL 32 only: parked from the start
 #define W4_PARK()                                                                          \
     do {                                                                                   \
         s_pA = (const char*)p.A; s_pB = (const char*)p.B;                                  \
@@ -187,11 +218,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // ---- compute cursor
     int c_tile = wid, c_ss = 0, c_nss = 0, c_m0 = 0, c_n0 = 0, c_slot = 0;
-#define W4_COMPUTE_SETUP()                                                                 \
+    int c_tj = -1;      // as s_tj; > 0 while the cursor is in its tail range
+#define W4_COMPUTE_AT(k0_, k1_)                                                            \
     do {                                                                                   \
         W4_TILE_ORIGIN(c_tile, c_m0, c_n0);                                                \
-        c_nss = nss1 + (((p.K2 > 0) && (c_n0 < p.lora_n_limit)) ? nss2 : 0);               \
+        c_nss = (k1_) < 0 ? nss1 + (((p.K2 > 0) && (c_n0 < p.lora_n_limit)) ? nss2 : 0) : (k1_) - (k0_); \
         c_ss = 0;                                                                          \
+    } while (0)
+#define W4_COMPUTE_NEXT(done_)                                                             \
+    do {                                                                                   \
+        bool ok_; int k0_, k1_;                                                            \
+        W4_NEXT_SEG(c_tj, c_tile, ok_, k0_, k1_);                                          \
+        (done_) = !ok_;                                                                    \
+        if (ok_) W4_COMPUTE_AT(k0_, k1_);                                                  \
     } while (0)
 
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -278,8 +317,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // residual / gate loads hipcc does not see (a visible load would be waited for with vmcnt(0): a drain of the staging pipeline)
 #define W4_LOAD16_ASM(dst_, ptr_) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst_) : "v"(ptr_) : "memory")
 #define W4_WAIT_RES(n_, r_) do { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r_) : "n"(n_) : "memory"); W4_FENCE(); } while (0)
-    w4_u32x4 gq = {0u, 0u, 0u, 0u};      // gate of this lane's 8 output columns (store layout), requested when the tile starts
-    // fused q / k tiles (QKF): the same register carries the RMSNorm weight of this wave's head (q or k), eight channels per lane in store layout
+    // gate of this lane's 8 output columns (store layout); fused q / k tiles (QKF): the RMSNorm weight of this wave's head (q or k), eight
+    // channels per lane in store layout.  Requested at the START OF THE EPILOGUE by a load hipcc does not see, and older than every residual /
+    // cos-sin load behind it: the first counted wait of the epilogue covers it (in-order retirement).  It must not be requested earlier (say at
+    // the tile's start, its latency hidden by the K loop): the compiler believes the register is defined when the asm statement ends and is
+    // free to copy it -- across the loop's back edge it did, before the data had landed.
 #define W4_GATE_FETCH()                                                                                                        \
     do {                                                                                                                       \
         if (GATED) W4_LOAD16_ASM(gq, (const bf16_t*)p.gate + c_n0 + wn * 128 + 8 * (lane & 15));                                \
@@ -473,6 +515,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const unsigned cvo = (unsigned)((elane >> 4) * (unsigned)ldc * 2u + (unsigned)(elane & 15) * 16u);              \
         const char* const rub = (const char*)pres + ((long)(c_m0 + wm * 128) * p.ldres + c_n0 + wn * 128) * 2;         \
         const unsigned rvo = (unsigned)((elane >> 4) * (unsigned)p.ldres * 2u + (unsigned)(elane & 15) * 16u);          \
+        w4_u32x4 gq = {0u, 0u, 0u, 0u};                                                                                \
+        W4_GATE_FETCH();                                                                                               \
         w4_u32x16 bq0, bq1, bq2, bq3;                                                                                  \
         uint32_t bsel[4][2][4];          /* plain kernel: this lane's bias words (packed bf16 pairs) of every (jn, q) piece */ \
         if constexpr (!GATED) {                                                                                        \
@@ -485,7 +529,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }                                                                                                          \
         }                                                                                                              \
         if constexpr (GATED) {                                                                                         \
-            W4_WAIT_RES(8, gq);       /* the eight DMAs of the tile's last K-step 3 are younger than the gate request (and every K-tile drains vmcnt) */ \
             if (full) {                                                                                                \
                 w4_u32x4 ra0, ra1, ra2, ra3, ra4, ra5, ra6, ra7, rb0, rb1, rb2, rb3, rb4, rb5, rb6, rb7;               \
                 W4_RES_LOAD(ra0, 0, 0); W4_RES_LOAD(ra1, 0, 1); W4_RES_LOAD(ra2, 0, 2); W4_RES_LOAD(ra3, 0, 3);         \
@@ -510,23 +553,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const unsigned qvo = (unsigned)((elane >> 4) * 256 + (elane & 15) * 16);                                    \
             const char* const qdst = (const char*)(isk ? p.qk_Kh : p.qk_Qh);                                          \
             const unsigned qhead = (unsigned)head * (unsigned)p.qk_hs * 2u;        /* byte offset of this head: < 4 GB for any S this library sizes for */ \
-            asm volatile("s_waitcnt vmcnt(6)" : "+v"(gq) : : "memory");      /* the head's norm weight, requested at the tile's start: every K-tile's vmcnt(0) has drained it; only the six pieces of the last K-step 3 are younger */ \
             W4_QK_BLOCK(0) W4_QK_BLOCK(1) W4_QK_BLOCK(2) W4_QK_BLOCK(3)                                                \
         } else {                                                                                                       \
             if (do_gelu) { W4_PLAIN_BLOCK(0, true) W4_PLAIN_BLOCK(1, true) W4_PLAIN_BLOCK(2, true) W4_PLAIN_BLOCK(3, true) } \
             else { W4_PLAIN_BLOCK(0, false) W4_PLAIN_BLOCK(1, false) W4_PLAIN_BLOCK(2, false) W4_PLAIN_BLOCK(3, false) } \
         }                                                                                                              \
-        W4_ZERO_ACC()                                                                                                  \
+    } while (0)
+
+    // ---- end of a tail range: the accumulators as they lie in the registers -> slot wid of the workspace, [wave][jn][im][a][lane] x 16 B:
+    // every store instruction writes one contiguous KB
+#define W4_DUMP(slot_)                                                                                                 \
+    do {                                                                                                               \
+        int dlane = lane;                                                                                              \
+        asm volatile("" : "+v"(dlane));                                                                                \
+        float* const wsb = (float*)p.sk_work + ((long)(slot_) * 4 + wave) * 16384 + dlane * 4;                         \
+        _Pragma("unroll") for (int jn_ = 0; jn_ < 4; ++jn_)                                                            \
+        _Pragma("unroll") for (int im_ = 0; im_ < 4; ++im_)                                                            \
+        _Pragma("unroll") for (int a_ = 0; a_ < 4; ++a_) {                                                             \
+            const w4_f32x4 v_ = {W4_ACC(jn_, im_, 4 * a_), W4_ACC(jn_, im_, 4 * a_ + 1), W4_ACC(jn_, im_, 4 * a_ + 2), W4_ACC(jn_, im_, 4 * a_ + 3)}; \
+            *reinterpret_cast<w4_f32x4*>(wsb + ((jn_ * 4 + im_) * 4 + a_) * 256) = v_;                                 \
+        }                                                                                                              \
     } while (0)
 
     // ---- prologue: K-tile 0 complete and landed, operand A of K-tile 1 requested; F0 = fragments of K-step 0 of K-tile 0
 #define W4_STAGE_HALF(isb_) do { W4_DMA(isb_, 0); W4_DMA(isb_, 1); W4_DMA(isb_, 2); W4_DMA(isb_, 3); W4_DMA(isb_, 4); W4_DMA(isb_, 5); W4_DMA(isb_, 6); W4_DMA(isb_, 7); } while (0)
-    if (W4_SVALID && !(ABL & 32)) W4_STAGE_SETUP(); else W4_PARK();      // ABL 32: every DMA re-reads the same 1 KB (issue + LDS write, no memory traffic)
+    if constexpr ((ABL & 32) != 0) { W4_PARK(); s_tj = 2; } else { W4_STAGE_AT(0, -1, false); }      // ABL 32: every DMA re-reads the same 1 KB (issue + LDS write, no memory traffic)
     W4_STAGE_HALF(0); W4_STAGE_HALF(1); W4_STAGE_ADVANCE();
     W4_DMA(0, 0); W4_DMA(0, 1); W4_DMA(0, 2); W4_DMA(0, 3); W4_DMA(0, 4); W4_DMA(0, 5);      // what K-step 3 of a K-tile -1 would have requested
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    W4_COMPUTE_SETUP();
-    W4_GATE_FETCH();
+    W4_COMPUTE_AT(0, -1);
     __builtin_amdgcn_s_barrier();
     W4_FENCE();
 #pragma unroll
@@ -595,7 +650,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const bool full = (c_m0 + 256 <= p.M);
         W4_MFMA_DRAIN();
         W4_TRACE(-1);
-        if (!(ABL & 8)) W4_EPILOGUE();
+        if (c_tj > 0) { W4_DUMP(wid); }
+        else if (!(ABL & 8)) W4_EPILOGUE();
+        if (!(ABL & 8)) { W4_ZERO_ACC() }      // one zeroing behind both paths: the accumulator tile has a single definition at the join
         W4_TRACE(-2);
         if constexpr (QKF) {   // F0 of the next tile's first K-step was prefetched by K-step 3 -- the fused q / k variant re-reads it here instead of
             // keeping 32 registers alive across its larger epilogue (the stage is intact; one exposed LDS latency per tile)
@@ -605,12 +662,73 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             W4_FENCE();
         }
-        c_tile += G;
-        if (c_tile >= ntiles) break;
-        W4_COMPUTE_SETUP();
-        W4_GATE_FETCH();
+        bool done;
+        W4_COMPUTE_NEXT(done);
+        if (done) break;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the parked cursor's DMAs target this workgroup's LDS: retire them before it is released
+}
+
+// Second kernel of the split tail: tail tile t = ntiles - sk_T + blockIdx.x / 16; workgroup (t, wave quadrant wv, 32-row block im) sums the tile's sk_S
+// slots (j sk_T + t, ascending j = ascending K: a fixed order) and runs the epilogue of the main kernel (same expressions, same rounding points).
+// A thread owns what a lane of the main kernel owned: (jn = tid / 64, lane) x a = 0..3 x 4 columns.
+template <bool GATED>
+__global__ __launch_bounds__(256) void gemm_w4_fixup_kernel(GemmParams p, int ntiles, int sk_T, int sk_S) {
+    typedef __attribute__((ext_vector_type(4))) float f32x4v;
+    const int t = blockIdx.x >> 4, wv = (blockIdx.x >> 2) & 3, im = blockIdx.x & 3;
+    const int tid = threadIdx.x, lane = tid & 63, jn = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+    const int wm = wv >> 1, wn = wv & 1;
+    const int ntn = p.ntn & 0xffff, group_m = (p.ntn >> 16) & 0xff, ntm = (p.M + 255) / 256, per_group = group_m * ntn;
+    const int w = ntiles - sk_T + t;
+    const int grp = w / per_group, rem = w - grp * per_group, ftm = grp * group_m;
+    const int gs = (ntm - ftm < group_m) ? ntm - ftm : group_m;
+    const int tn = rem / gs;
+    const int m0 = (ftm + rem - tn * gs) * 256, n0 = tn * 256;
+    f32x4v acc[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) acc[a] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < sk_S; ++j) {
+        const float* src = (const float*)p.sk_work + ((long)(j * sk_T + t) * 4 + wv) * 16384 + (jn * 4 + im) * 1024 + lane * 4;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) acc[a] += *reinterpret_cast<const f32x4v*>(src + a * 256);
+    }
+    const int m = m0 + wm * 128 + im * 32 + l31;
+    if (m >= p.M) return;
+    const bool do_gelu = !GATED && n0 >= p.gelu_from, to_c1 = !GATED && n0 >= p.n_split;
+    bf16_t* const crow = to_c1 ? (bf16_t*)p.C1 + (long)m * p.ldc1 - p.n_split : (bf16_t*)p.C + (long)m * p.ldc;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int n = n0 + wn * 128 + jn * 32 + 8 * a + 4 * lh;
+        float v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float b = p.bias ? bf2f(((const bf16_t*)p.bias)[n + c]) : 0.f;
+            v[c] = acc[a][c] * p.alpha + b;
+            if (do_gelu) v[c] = w4_gelu_tanh(rbf(v[c]));
+        }
+        uint32_t o0 = pack2bf(v[0], v[1]), o1 = pack2bf(v[2], v[3]);
+        if constexpr (GATED) {
+            const uint2 r = *reinterpret_cast<const uint2*>((const bf16_t*)p.res + (long)m * p.ldres + n);
+            const uint2 gt = *reinterpret_cast<const uint2*>((const bf16_t*)p.gate + n);
+            const uint32_t yy[2] = {o0, o1}, rr[2] = {r.x, r.y}, gg[2] = {gt.x, gt.y};
+            uint32_t oo[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const float y0f = bf2f((uint16_t)(yy[c] & 0xffff)), y1f = bf2f((uint16_t)(yy[c] >> 16));
+                const float r0f = bf2f((uint16_t)(rr[c] & 0xffff)), r1f = bf2f((uint16_t)(rr[c] >> 16));
+                const float g0f = bf2f((uint16_t)(gg[c] & 0xffff)), g1f = bf2f((uint16_t)(gg[c] >> 16));
+                oo[c] = pack2bf(r0f + rbf(g0f * y0f), r1f + rbf(g1f * y1f));
+            }
+            o0 = oo[0]; o1 = oo[1];
+        }
+        *reinterpret_cast<uint2*>(crow + n) = make_uint2(o0, o1);
+    }
+}
+
+extern "C" size_t utx_gemm_streamk_workspace_bytes_impl(void) {
+    int dev = 0; hipDeviceProp_t pr;
+    const int ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256;
+    return (size_t)ncu * 262144;      // one fp32 256 x 256 partial tile per workgroup
 }
 
 extern "C" int utx_launch_gemm_w4(GemmParams p, hipStream_t stream) {
@@ -632,26 +750,46 @@ extern "C" int utx_launch_gemm_w4(GemmParams p, hipStream_t stream) {
     int grid = tiles < ncu ? tiles : ncu;
     if (g_utx_opt.gemm_pers_grid > 0 && g_utx_opt.gemm_pers_grid < grid) grid = g_utx_opt.gemm_pers_grid;
     const int trace_wg = g_utx_opt.gemm_pers_sched >= 100 ? g_utx_opt.gemm_pers_sched - 100 : 0;   // ablation build: which workgroup writes the ABL 128 timeline
+    // Split tail (kernel: "split tail"): when the last round holds T < grid / 2 tiles, each is cut along K into S = grid / T ranges, so that round
+    // takes 1 / S of a tile's K loop instead of a whole one while most CUs idle.  Worth it when the K-tiles it saves outweigh the partial dump +
+    // the fix-up kernel (~cost K-tiles, measured: profiles/r02_gemm_streamk_check_v*.log).
+    int sk_T = 0, sk_S = 0;
+    {
+        const int T = tiles % grid;
+        const int nss2 = p.K2 / 64, nssu = p.K / 64 + ((p.K2 > 0 && p.lora_n_limit > 0) ? nss2 : 0);
+        const bool uniform = p.K2 == 0 || p.lora_n_limit <= 0 || p.lora_n_limit >= p.N;      // every tail tile has the same K extent
+        const int cost = g_utx_opt.gemm_streamk > 1 ? g_utx_opt.gemm_streamk : 16;             // values > 1 set the threshold (tuning)
+        if (g_utx_opt.gemm_streamk > 0 && p.sk_work && tiles > grid && T > 0 && uniform && p.qk_cols == 0) {
+            int S = grid / T;
+            if (S > 8) S = 8;
+            while (S > 1 && nssu / S < 8) --S;        // at least 8 K-tiles per range
+            if (S >= 2 && p.sk_work_bytes >= (size_t)T * S * 262144 && (nssu + S - 1) / S + cost < nssu) { sk_T = T; sk_S = S; }
+        }
+    }
 #ifdef UTX_ABLATION
     {
         const int abl = (g_utx_opt.gemm_debug_abl >> 5) & 511;   // (ABL 256 = start-time stagger: results stay correct)     // UTX_GEMM_DEBUG bits 5..8
         if (abl && !p.gate) {
 #define W4_ABL_CASE(a_) if (abl == (a_)) { hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_w4_kernel<false, (a_)>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
-                                           hipLaunchKernelGGL((gemm256_w4_kernel<false, (a_)>), dim3(grid), dim3(256), LDS, stream, p, tiles, trace_wg); return 0; }
+                                           hipLaunchKernelGGL((gemm256_w4_kernel<false, (a_)>), dim3(grid), dim3(256), LDS, stream, p, tiles, trace_wg, 0, 0); return 0; }
             W4_ABL_CASE(1) W4_ABL_CASE(2) W4_ABL_CASE(3) W4_ABL_CASE(4) W4_ABL_CASE(7) W4_ABL_CASE(8) W4_ABL_CASE(15) W4_ABL_CASE(16) W4_ABL_CASE(32) W4_ABL_CASE(64) W4_ABL_CASE(128) W4_ABL_CASE(144) W4_ABL_CASE(256)
         }
     }
 #endif
     if (p.gate) {
         if (p.gelu_from < p.N || p.n_split < p.N) return -2;
-        hipLaunchKernelGGL((gemm256_w4_kernel<true>), dim3(grid), dim3(256), LDS, stream, p, tiles, trace_wg);
+        hipLaunchKernelGGL((gemm256_w4_kernel<true>), dim3(grid), dim3(256), LDS, stream, p, tiles, trace_wg, sk_T, sk_S);
     } else {
         if (p.qk_cols > 0) {
             static bool aq = false;
             if (!aq) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_w4_kernel<false, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3; aq = true; }
-            hipLaunchKernelGGL((gemm256_w4_kernel<false, 0, true>), dim3(grid), dim3(256), LDS, stream, p, tiles, trace_wg);
+            hipLaunchKernelGGL((gemm256_w4_kernel<false, 0, true>), dim3(grid), dim3(256), LDS, stream, p, tiles, trace_wg, sk_T, sk_S);
         } else
-        hipLaunchKernelGGL((gemm256_w4_kernel<false>), dim3(grid), dim3(256), LDS, stream, p, tiles, trace_wg);
+        hipLaunchKernelGGL((gemm256_w4_kernel<false>), dim3(grid), dim3(256), LDS, stream, p, tiles, trace_wg, sk_T, sk_S);
+    }
+    if (sk_T > 0) {
+        if (p.gate) hipLaunchKernelGGL((gemm_w4_fixup_kernel<true>), dim3(sk_T * 16), dim3(256), 0, stream, p, tiles, sk_T, sk_S);
+        else hipLaunchKernelGGL((gemm_w4_fixup_kernel<false>), dim3(sk_T * 16), dim3(256), 0, stream, p, tiles, sk_T, sk_S);
     }
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }

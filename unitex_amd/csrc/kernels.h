@@ -46,6 +46,7 @@ struct UtxOptions {
     int gemm_tailsplit;   // 1: K-split tail round of the 8-phase GEMM (off by default)
     int gemm_pers_grid;   // persistent GEMM: number of workgroups (0 = one per CU)
     int gemm_pers_sched;  // persistent GEMM: DMA placement over the phases of a K-tile: 0 = by shape, 1 = force SCHED 0, 2 = force SCHED 1
+    int gemm_streamk;     // 1 (default): one-wave-per-SIMD GEMM balances the K loops of its last, partly filled round over all CUs (needs utx_gemm_desc.sk_work)
     int bvh_stack_walk;   // 1: the reference's stack walk over the unpacked tree instead of the stackless packed walk (A/B; same results)
     int attn_var_abl, attn_debug_abl, gemm_debug_abl;
 };
@@ -65,6 +66,7 @@ int utx_launch_attn_fwd(const void* q, const void* k, const void* vt, void* o,
 int utx_launch_attn_fwd_glds(const AttnParams* p, int presc, hipStream_t stream);
 int utx_launch_attn_fwd_q64(const AttnParams* p, int presc, hipStream_t stream);
 int utx_launch_gemm_bf16(const GemmParams* p, hipStream_t stream);
+size_t utx_gemm_streamk_workspace_bytes_impl(void);
 int utx_launch_gemm_w4(GemmParams p, hipStream_t stream);     // gemm_w4.hip: persistent 256x256 kernel, one wave per SIMD
 int utx_launch_gemm_pers(GemmParams p, hipStream_t stream);   // gemm_pers.hip: persistent 256x256 kernel (large-M linears)
 int utx_launch_gemv_bf16(const GemvParams* p, hipStream_t stream);

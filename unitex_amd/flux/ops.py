@@ -51,8 +51,10 @@ def attention(q, k, vt, S=None, scale=None, out=None, o_ss=None, key_bias_log2=0
 
 
 def make_gemm_desc(A, B, C_out, bias=None, A2=None, B2=None, lora_n_limit=None, lora_seg_n=None, alpha=1.0,
-                   gelu_from=None, gate=None, res=None, n_split=None, C1=None, a_scale=None, b_scale=None, qk_post=None):
-    """a_scale / b_scale given: A and B are OCP MX fp8 operands (uint8 e4m3 bytes + E8M0 scales [rows, K/32], flux/mx8.py)."""
+                   gelu_from=None, gate=None, res=None, n_split=None, C1=None, a_scale=None, b_scale=None, qk_post=None, sk_work=None):
+    """a_scale / b_scale given: A and B are OCP MX fp8 operands (uint8 e4m3 bytes + E8M0 scales [rows, K/32], flux/mx8.py).
+    sk_work: uint8 scratch tensor of streamk_workspace() bytes for the balanced tail of the large-M kernel (utx_gemm_desc.sk_work); one per
+    stream that launches GEMMs concurrently.  None = the tail round is never split."""
     M, K = A.shape
     N = B.shape[0]
     d = GemmDesc()
@@ -84,7 +86,27 @@ def make_gemm_desc(A, B, C_out, bias=None, A2=None, B2=None, lora_n_limit=None, 
     d.n_split = N if n_split is None else n_split
     if C1 is not None:
         d.C1, d.ldc1 = ptr(C1), C1.stride(0)
+    if sk_work is not None:
+        d.sk_work, d.sk_work_bytes = ptr(sk_work), sk_work.numel() * sk_work.element_size()
     return d
+
+
+_SK_WS = {}
+
+
+def streamk_workspace(device, stream=None, shared=True):
+    """scratch for utx_gemm_desc.sk_work on `device`.  shared=True: one cached buffer per (device, stream) -- GEMMs launched on the same
+    stream are ordered, so they can share it; shared=False: a fresh buffer (a model that owns its plan)."""
+    dev = torch.device(device)
+    ctx = get_ctx(dev.index)
+    nbytes = int(ctx.lib.utx_gemm_streamk_workspace_bytes(ctx.handle))
+    if not shared:
+        return torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream(dev) if stream is None else stream
+    key = (dev.index, st.cuda_stream)
+    if key not in _SK_WS:
+        _SK_WS[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    return _SK_WS[key]
 
 
 def gemm_takes_w4(M, N, n_split=None, gelu_from=None, K2=0, lora_seg_n=None, lora_n_limit=None):
@@ -109,6 +131,8 @@ def gemm(A, B, bias=None, out=None, **kw):
         out = torch.empty(M, N if n_split is None else n_split, dtype=torch.bfloat16, device=A.device)
     if kw.get("a_scale") is None:
         _bf(A), _bf(B)
+    if "sk_work" not in kw and M >= 4096:
+        kw = dict(kw, sk_work=streamk_workspace(A.device))
     d = make_gemm_desc(A, B, out, bias=bias, **kw)
     ctx.check(ctx.lib.utx_gemm_bf16(ctx.handle, C.byref(d), ctx.stream()))
     return out

@@ -549,7 +549,25 @@ class FluxDiT:
         scale, shift = mod[o: o + D], mod[o + D: o + 2 * D]  # AdaLayerNormContinuous: (scale, shift) [3p]
         self._lnmod(plan, h_x[:n_out], xn_x[:n_out], shift, scale)
         self._gemm(plan, xn_x[:n_out], W["proj_out.w"], ws["out"][:n_out], bias=W["proj_out.b"])
+        self._assign_streamk(plan, ws)
         return {"ws": ws, "plan": plan, "S_txt": S_txt, "S_img": S_img}
+
+    def _assign_streamk(self, plan, ws):
+        """scratch of the large-M GEMM's balanced tail round (utx_gemm_desc.sk_work): one buffer for the GEMMs of the main stream -- they
+        are ordered among themselves; the text-side ops of a "par" entry run beside them on the second stream and get none (their GEMMs are
+        far below the size where the tail is split).  UTX_GEMM_STREAMK=0 at library level switches the split off."""
+        if self.fp8_weights:
+            return
+        if "sk" not in ws:
+            ws["sk"] = ops.streamk_workspace(self.device, shared=False)
+        sk = ws["sk"]
+        def assign(entries):
+            for e in entries:
+                if e[0] is self.lib.utx_gemm_bf16:
+                    e[1].sk_work, e[1].sk_work_bytes = ptr(sk), sk.numel()
+                elif e[0] == "par":
+                    assign(e[1][0])
+        assign(plan)
 
     # ------------------------------------------------------------------ forward
     TEXT_KEEP = 64      # rows of the (identical) text tokens that are carried when the dedup applies: one 64-key attention tile
