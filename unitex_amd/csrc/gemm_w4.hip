@@ -104,28 +104,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int nss1 = p.K / 64, nss2 = p.K2 / 64;      // K-tiles of the base / LoRA segment
     const unsigned ldaB = (unsigned)p.lda * 2, ldbB = (unsigned)p.ldb * 2, lda2B = (unsigned)p.lda2 * 2, ldb2B = (unsigned)p.ldb2 * 2;
     // ---- split tail (sk_T > 0; launcher: utx_launch_gemm_w4).  The ntiles - sk_T tiles of the whole rounds are walked as before; each of the sk_T
-    // tiles of the last, partly filled round is cut along K into sk_S equal ranges (sk_T * sk_S <= G) and workgroup w < sk_T * sk_S takes range
-    // j = w / sk_T of tail tile w % sk_T -- workgroups with neighbouring indices (one XCD) then work on neighbouring tiles at the SAME K offsets,
-    // the lockstep that lets them share operand panels in L2 during a whole round (a first version cut the tail's K-tiles into G exactly equal
-    // ranges that straddled tiles: every workgroup at its own K offset, and a third of the gain gone).  A range ends with its fp32
-    // accumulators written as they lie in the registers to slot w of p.sk_work (W4_DUMP); gemm_w4_fixup_kernel sums a tile's sk_S slots in K
-    // order and runs the epilogue.  nssu = K-tiles per tail tile, the same for every tail tile (the launcher checks).
+    // tiles of the last, partly filled round is cut along K into sk_S equal ranges: range r = 0 .. sk_T sk_S - 1 is part r / sk_T of tail tile
+    // r % sk_T, and workgroup w takes ranges w, w + G, ... after its whole tiles (one range each when sk_T sk_S <= G, the usual case).  Workgroups
+    // with neighbouring indices (one XCD) then work on neighbouring tiles at the SAME K offsets -- the lockstep that lets them share operand
+    // panels in L2 during a whole round (a first version cut the tail's K-tiles into G exactly equal ranges that straddled tiles: every
+    // workgroup at its own K offset, and a third of the gain gone).  A range ends with its fp32 accumulators written as they lie in the
+    // registers to slot r of p.sk_work (W4_DUMP); gemm_w4_fixup_kernel sums a tile's sk_S slots in K order and runs the epilogue.
+    // nssu = K-tiles per tail tile, the same for every tail tile (the launcher checks).
     const int nfull_tiles = ntiles - sk_T;
     const int nssu = nss1 + ((p.K2 > 0 && p.lora_n_limit > 0) ? nss2 : 0);
-    // the segment after the current one of a cursor (tj_, tile_): the next whole tile of this workgroup, then its tail range.  Scalar work only.
-    // tj_: -1 whole tiles, 0 tail range not yet taken, 2 taken / none.  k1_ < 0 stands for "the whole tile" (its K extent depends on its columns)
+    // the segment after the current one of a cursor (tj_, tile_): the next whole tile of this workgroup, then its tail ranges.  Scalar work only.
+    // tj_: -1 whole tiles, else the number of tail ranges taken so far.  k1_ < 0 stands for "the whole tile" (its K extent depends on its columns)
 #define W4_NEXT_SEG(tj_, tile_, ok_, k0_, k1_)                                                     \
     do {                                                                                           \
         ok_ = false; k0_ = 0; k1_ = -1;                                                            \
         if (tj_ < 0) {                                                                             \
             tile_ += G;                                                                            \
-            if (tile_ < nfull_tiles) ok_ = true; else tj_ = sk_T > 0 ? 0 : 2;                      \
+            if (tile_ < nfull_tiles) ok_ = true; else tj_ = 0;                                     \
         }                                                                                          \
-        if (!ok_ && tj_ == 0) {                                                                    \
-            tj_ = 2;                                                                               \
-            if (wid < sk_T * sk_S) {                                                               \
-                const int j_ = wid / sk_T;                                                         \
-                ok_ = true; tile_ = nfull_tiles + wid - j_ * sk_T;                                 \
+        if (!ok_) {                                                                                \
+            const int r_ = wid + tj_ * G;                                                          \
+            if (r_ < sk_T * sk_S) {                                                                \
+                const int j_ = r_ / sk_T;                                                          \
+                ok_ = true; tile_ = nfull_tiles + r_ - j_ * sk_T; ++tj_;                           \
                 k0_ = (j_ * nssu) / sk_S; k1_ = ((j_ + 1) * nssu) / sk_S;                          \
             }                                                                                      \
         }                                                                                          \
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // ---- compute cursor
     int c_tile = wid, c_ss = 0, c_nss = 0, c_m0 = 0, c_n0 = 0, c_slot = 0;
-    int c_tj = -1;      // as s_tj; > 0 while the cursor is in its tail range
+    int c_tj = -1;      // as s_tj; > 0 while the cursor is in a tail range (its c_tj-th)
 #define W4_COMPUTE_AT(k0_, k1_)                                                            \
     do {                                                                                   \
         W4_TILE_ORIGIN(c_tile, c_m0, c_n0);                                                \
@@ -560,7 +561,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }                                                                                                              \
     } while (0)
 
-    // ---- end of a tail range: the accumulators as they lie in the registers -> slot wid of the workspace, [wave][jn][im][a][lane] x 16 B:
+    // ---- end of a tail range: the accumulators as they lie in the registers -> slot r (= the range's number) of the workspace, [wave][jn][im][a][lane] x 16 B:
     // every store instruction writes one contiguous KB
 #define W4_DUMP(slot_)                                                                                                 \
     do {                                                                                                               \
@@ -577,7 +578,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // ---- prologue: K-tile 0 complete and landed, operand A of K-tile 1 requested; F0 = fragments of K-step 0 of K-tile 0
 #define W4_STAGE_HALF(isb_) do { W4_DMA(isb_, 0); W4_DMA(isb_, 1); W4_DMA(isb_, 2); W4_DMA(isb_, 3); W4_DMA(isb_, 4); W4_DMA(isb_, 5); W4_DMA(isb_, 6); W4_DMA(isb_, 7); } while (0)
-    if constexpr ((ABL & 32) != 0) { W4_PARK(); s_tj = 2; } else { W4_STAGE_AT(0, -1, false); }      // ABL 32: every DMA re-reads the same 1 KB (issue + LDS write, no memory traffic)
+    if constexpr ((ABL & 32) != 0) { W4_PARK(); } else { W4_STAGE_AT(0, -1, false); }      // ABL 32: every DMA re-reads the same 1 KB (issue + LDS write, no memory traffic)
     W4_STAGE_HALF(0); W4_STAGE_HALF(1); W4_STAGE_ADVANCE();
     W4_DMA(0, 0); W4_DMA(0, 1); W4_DMA(0, 2); W4_DMA(0, 3); W4_DMA(0, 4); W4_DMA(0, 5);      // what K-step 3 of a K-tile -1 would have requested
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -650,7 +651,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const bool full = (c_m0 + 256 <= p.M);
         W4_MFMA_DRAIN();
         W4_TRACE(-1);
-        if (c_tj > 0) { W4_DUMP(wid); }
+        if (c_tj > 0) { W4_DUMP(wid + (c_tj - 1) * G); }
         else if (!(ABL & 8)) W4_EPILOGUE();
         if (!(ABL & 8)) { W4_ZERO_ACC() }      // one zeroing behind both paths: the accumulator tile has a single definition at the join
         W4_TRACE(-2);
@@ -728,7 +729,7 @@ __global__ __launch_bounds__(256) void gemm_w4_fixup_kernel(GemmParams p, int nt
 extern "C" size_t utx_gemm_streamk_workspace_bytes_impl(void) {
     int dev = 0; hipDeviceProp_t pr;
     const int ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256;
-    return (size_t)ncu * 262144;      // one fp32 256 x 256 partial tile per workgroup
+    return (size_t)ncu * 2 * 262144;      // up to two fp32 256 x 256 partial tiles per workgroup
 }
 
 extern "C" int utx_launch_gemm_w4(GemmParams p, hipStream_t stream) {
@@ -750,20 +751,25 @@ extern "C" int utx_launch_gemm_w4(GemmParams p, hipStream_t stream) {
     int grid = tiles < ncu ? tiles : ncu;
     if (g_utx_opt.gemm_pers_grid > 0 && g_utx_opt.gemm_pers_grid < grid) grid = g_utx_opt.gemm_pers_grid;
     const int trace_wg = g_utx_opt.gemm_pers_sched >= 100 ? g_utx_opt.gemm_pers_sched - 100 : 0;   // ablation build: which workgroup writes the ABL 128 timeline
-    // Split tail (kernel: "split tail"): when the last round holds T < grid / 2 tiles, each is cut along K into S = grid / T ranges, so that round
-    // takes 1 / S of a tile's K loop instead of a whole one while most CUs idle.  Worth it when the K-tiles it saves outweigh the partial dump +
-    // the fix-up kernel (~cost K-tiles, measured: profiles/r02_gemm_streamk_check_v*.log).
+    // Split tail (kernel: "split tail"): the T < grid tiles of the last round are cut along K into S ranges each, T S ranges over the grid in
+    // ceil(T S / grid) passes, instead of T workgroups running a whole tile while the others idle.  S by a cost model in K-tiles (1.3 us), fitted to
+    // profiles/r02_gemm_streamk_check_v*.log: a range costs its K-tiles + 4 (dump), the fix-up kernel 6 + 8 per 256 partial tiles; unsplit, the
+    // round costs a tile's K-tiles.  UTX_GEMM_STREAMK = n > 1 sets the margin the saving has to exceed (default 4).
     int sk_T = 0, sk_S = 0;
     {
         const int T = tiles % grid;
         const int nss2 = p.K2 / 64, nssu = p.K / 64 + ((p.K2 > 0 && p.lora_n_limit > 0) ? nss2 : 0);
         const bool uniform = p.K2 == 0 || p.lora_n_limit <= 0 || p.lora_n_limit >= p.N;      // every tail tile has the same K extent
-        const int cost = g_utx_opt.gemm_streamk > 1 ? g_utx_opt.gemm_streamk : 16;             // values > 1 set the threshold (tuning)
+        const int margin = g_utx_opt.gemm_streamk > 1 ? g_utx_opt.gemm_streamk : 4;
         if (g_utx_opt.gemm_streamk > 0 && p.sk_work && tiles > grid && T > 0 && uniform && p.qk_cols == 0) {
-            int S = grid / T;
-            if (S > 8) S = 8;
-            while (S > 1 && nssu / S < 8) --S;        // at least 8 K-tiles per range
-            if (S >= 2 && p.sk_work_bytes >= (size_t)T * S * 262144 && (nssu + S - 1) / S + cost < nssu) { sk_T = T; sk_S = S; }
+            int best = nssu - margin, bestS = 0;
+            for (int S = 2; S <= 8; ++S) {
+                if (nssu / S < 8 || T * S > 2 * grid || (size_t)T * S * 262144 > p.sk_work_bytes) break;
+                const int passes = (T * S + grid - 1) / grid;
+                const int est = passes * ((nssu + S - 1) / S + 4) + 6 + (8 * T * S) / 256;
+                if (est < best) { best = est; bestS = S; }
+            }
+            if (bestS) { sk_T = T; sk_S = bestS; }
         }
     }
 #ifdef UTX_ABLATION
