@@ -304,3 +304,39 @@ def test_view_grid_strip_round_trip_for_4_6_8_views(n, tmp_path):
     assert order == lay["strip"]
     names = {4: "f r b l", 6: "f r t b l d", 8: "f r t b l d x1 x2"}[n].split()
     assert [names[g] for g in order][:4] == ["f", "l", "r", "b"]
+
+
+def test_obj_reader_fast_path_equals_the_line_reader_and_falls_back(tmp_path):
+    """load_obj parses the all-triangle files this package writes with whole-file numpy conversions (the pipeline re-reads processed_mesh.obj in
+    every stage, io/mesh_loader.py in the reference); every other spelling must go through -- and equal -- the line-by-line reader."""
+    v, f, uv = meshes.make_bumpy_sphere(24, 12)[:3]
+    v, f, uv = np.asarray(v, dtype=np.float32), np.asarray(f, dtype=np.int32), np.asarray(uv, dtype=np.float32)
+
+    def same(a, b):
+        assert len(a) == len(b)
+        for x, y in zip(a, b):
+            assert (x is None and y is None) or (x.dtype == y.dtype and x.shape == y.shape and np.array_equal(x, y))
+    p = str(tmp_path / "a.obj")
+    meshes.save_obj(p, v, f, uv, f)                    # v / vt / f a/b a/b a/b
+    got = meshes.load_obj(p)
+    same(got, meshes._load_obj_generic(p))
+    assert got[0].shape == v.shape and np.array_equal(got[1], f) and np.array_equal(got[3], f) and np.allclose(got[2], uv, atol=1e-6)
+    meshes.save_obj(p, v, f)                           # no uvs: f a b c
+    same(meshes.load_obj(p), meshes._load_obj_generic(p))
+    assert meshes.load_obj(p)[2] is None
+    body = "".join("v %r %r %r\n" % tuple(float(c) for c in r) for r in v) + "".join("vt %r %r\n" % tuple(float(c) for c in r) for r in uv)
+    variants = {
+        "normals": body + "vn 0 0 1\n" + "".join("f %d/%d/1 %d/%d/1 %d/%d/1\n" % (a + 1, a + 1, b + 1, b + 1, c + 1, c + 1) for a, b, c in f),
+        "quad": body + "f 1/1 2/2 3/3 4/4\n" + "".join("f %d/%d %d/%d %d/%d\n" % (a + 1, a + 1, b + 1, b + 1, c + 1, c + 1) for a, b, c in f),
+        "negative": body + "".join("f %d/%d %d/%d %d/%d\n" % (a - len(v), a - len(uv), b - len(v), b - len(uv), c - len(v), c - len(uv)) for a, b, c in f),
+        "no_vt_ref": body + "vn 0 0 1\n" + "".join("f %d//1 %d//1 %d//1\n" % (a + 1, b + 1, c + 1) for a, b, c in f),
+        "vertex_colours": "".join("v %r %r %r 1 0 0\n" % tuple(float(c) for c in r) for r in v) + "".join("f %d %d %d\n" % (a + 1, b + 1, c + 1) for a, b, c in f),
+        "comments_and_groups": "# c\no x\n" + body + "g part\ns off\n" + "".join("f %d/%d %d/%d %d/%d\n" % (a + 1, a + 1, b + 1, b + 1, c + 1, c + 1) for a, b, c in f),
+    }
+    for name, text in variants.items():
+        q = str(tmp_path / (name + ".obj"))
+        with open(q, "w") as fh:
+            fh.write(text)
+        same(meshes.load_obj(q), meshes._load_obj_generic(q))
+    assert np.array_equal(meshes.load_obj(str(tmp_path / "negative.obj"))[1], f)
+    assert len(meshes.load_obj(str(tmp_path / "quad.obj"))[1]) == len(f) + 2

@@ -16,7 +16,11 @@ import numpy as np
 import torch
 from PIL import Image
 
-from .texturetools.timer import CPUTimer
+from .texturetools.timer import CPUTimer, Encoders
+
+# zlib level of the stage hand-off PNGs.  PNG is lossless: the level changes the file size (+15 % at 1 against PIL's default 6), never a pixel --
+# and the encoder's time: a 2048^2 RGB atlas costs 0.3-0.5 s at level 6 on the GPU box's host, several times the whole back-projection chain.
+PNG_LEVEL = int(os.environ.get("UTX_PNG_LEVEL", "1"))
 
 
 def build_pipeline(pretrain_models=None, pipeline_name="texture_plus", device="cuda:0", seed=0, lora_rank=64, shape=None,
@@ -125,8 +129,8 @@ class RGBTextureFullPipelineBase:
         src = Image.open(input_image_path)
         src = src.resize((1024, 1024)) if src.mode == "RGBA" else src.convert("RGB").resize((1024, 1024))
         out = preprocess(src, alpha=None, H=1024, W=1024, scale=scale, color=color)
-        out.save(os.path.join(save_dir, "rembg_image.png"))
-        out.convert("RGB").resize((512, 512)).save(os.path.join(save_dir, "processed_image.png"))
+        out.save(os.path.join(save_dir, "rembg_image.png"), compress_level=PNG_LEVEL)
+        out.convert("RGB").resize((512, 512)).save(os.path.join(save_dir, "processed_image.png"), compress_level=PNG_LEVEL)
 
     @CPUTimer("render_geometry_images")
     def render_geometry_images(self, save_dir, input_mesh_path, geometry_scale=0.95, scale=1.0, color="grey"):
@@ -134,9 +138,9 @@ class RGBTextureFullPipelineBase:
         out = self.video_exporter.export_condition(input_mesh_path, geometry_scale=geometry_scale, n_views=self.n_views, n_rows=lay["rows"], n_cols=lay["cols"],
                                                    H=self.view_size, W=self.view_size, fov_deg=49.1, scale=scale, perspective=False, orbit=False,
                                                    background=color, return_image=True, return_camera=True)
-        out["alpha"].save(os.path.join(save_dir, "mv_alpha.png"))
-        out["ccm"].save(os.path.join(save_dir, "mv_ccm.png"))
-        out["normal"].save(os.path.join(save_dir, "mv_normal.png"))
+        with Encoders() as enc:
+            for key in ("alpha", "ccm", "normal"):
+                enc.submit(out[key].save, os.path.join(save_dir, "mv_%s.png" % key), compress_level=PNG_LEVEL)
         torch.save({"c2ws": out["c2ws"], "intrinsics": out["intrinsics"], "perspective": out["perspective"]},
                    os.path.join(save_dir, "camera_info.pth"))
 
@@ -163,16 +167,17 @@ class RGBTextureFullPipelineBase:
                       n_cols=n, num_inference_steps=steps, guidance_scale=3.5, max_sequence_length=512, generator=self.generator)
         self.pipeline.set_adapters(adapter_names=self.adapter_names, adapter_weights=self.weights_for_texture)
         out_image = self.pipeline(control_image=control_image, dual_image=reference_image, **common).images[0]
-        out_image.save(os.path.join(save_dir, "mv_rgb_w_light.png"))
-        self.pipeline.set_adapters(adapter_names=self.adapter_names, adapter_weights=self.weights_for_delight)
-        delit = self.pipeline(control_image=out_image, **common).images[0]
+        with Encoders(1) as enc:     # the lit strip is encoded while the delight pass runs (it reads the image, not the file)
+            enc.submit(out_image.copy().save, os.path.join(save_dir, "mv_rgb_w_light.png"), compress_level=PNG_LEVEL)
+            self.pipeline.set_adapters(adapter_names=self.adapter_names, adapter_weights=self.weights_for_delight)
+            delit = self.pipeline(control_image=out_image, **common).images[0]
         t = np.array(delit).reshape(V, n, V, -1)
         if rot is not None:
             sp = strip.index(rot)                       # where the turned tile sits in the strip
             t[:, sp] = t[::-1, sp, ::-1]
         inv = [strip.index(g) for g in range(n)]        # strip position of every grid tile ([0, 2, 4, 3, 1, 5] for the reference's six)
         grid = t.transpose(1, 0, 2, 3)[inv].reshape(R, Cc, V, V, -1).transpose(0, 2, 1, 3, 4).reshape(R * V, Cc * V, -1)
-        Image.fromarray(grid).save(os.path.join(save_dir, "mv_rgb.png"))
+        Image.fromarray(grid).save(os.path.join(save_dir, "mv_rgb.png"), compress_level=PNG_LEVEL)
 
     @CPUTimer("export_video")
     def export_video(self, save_dir, input_mesh_path, output_video_name):
@@ -202,14 +207,15 @@ class RGBTextureFullPipelineBase:
             H=HP, W=WP, H2D=T, W2D=T, method=method, kdtree_n_neighbors=8, kdtree_n_neighbors_visiable=4, kdtree_inpainting=inpainting,
             reproject_inpainting=inpainting, grad_norm_threhold=0.15, ray_normal_angle_threhold=100,
             filt_gradient_points=inpainting)   # keyword set of the reference call, pipeline.py:333-348
-        textured.export(os.path.join(save_dir, "textured_mesh.glb"))
+        with Encoders() as enc:
+            enc.submit(textured.export, os.path.join(save_dir, "textured_mesh.glb"))
 
-        def save_mask(t, name):   # torchvision save_image: *255 + 0.5, clamp, uint8 [3p]
-            a = (t.float().clamp(0, 1) * 255 + 0.5).clamp(0, 255).to(torch.uint8).cpu().numpy()
-            Image.fromarray(a if a.ndim == 2 else a).save(os.path.join(save_dir, name))
-        save_mask(reprojected_uv.any(dim=0)[..., 0], "visable_uv_mask.png")
-        save_mask(visable_mask[0, ..., 0], "valid_uv_mask.png")
-        save_mask(completed[0], "completed_uv.png")
+            def save_mask(t, name):   # torchvision save_image: *255 + 0.5, clamp, uint8 [3p]
+                a = (t.float().clamp(0, 1) * 255 + 0.5).clamp(0, 255).to(torch.uint8).cpu().numpy()
+                enc.submit(Image.fromarray(a).save, os.path.join(save_dir, name), compress_level=PNG_LEVEL)
+            save_mask(reprojected_uv.any(dim=0)[..., 0], "visable_uv_mask.png")
+            save_mask(visable_mask[0, ..., 0], "valid_uv_mask.png")
+            save_mask(completed[0], "completed_uv.png")
         self.inverse_renderer.clear()
         torch.cuda.empty_cache()
 

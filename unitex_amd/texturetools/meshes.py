@@ -6,6 +6,7 @@ own UV atlas (SURVEY 8d "Synthetic inputs"): a bumpy lat-long sphere (self-occlu
 a seam) at any face count.  OBJ I/O mirrors what the reference round-trips through
 cache/processed_mesh.obj (pipeline.py:171-179, 330)."""
 import json
+import os
 import struct
 
 import numpy as np
@@ -83,8 +84,47 @@ def save_obj(path, verts, faces, uvs=None, faces_uv=None, mtl=None):
 
 
 def load_obj(path):
-    """Minimal OBJ reader: v / vt / f (triangles or fan-triangulated polygons).
-    Returns verts [V,3], faces [F,3], uvs [Vt,2] | None, faces_uv [F,3] | None."""
+    """OBJ reader: v / vt / f (triangles or fan-triangulated polygons).
+    Returns verts [V,3], faces [F,3], uvs [Vt,2] | None, faces_uv [F,3] | None.
+    The pipeline re-reads processed_mesh.obj in every stage (as the reference does), so the plain all-triangle file this package writes is
+    parsed with a few whole-file numpy conversions; anything else (polygons, negative indices, `a//c` references, extra vertex columns) goes
+    through the line-by-line reader.  Same values either way: decimal text -> float64 -> float32."""
+    with open(path, "rb") as f:
+        lines = f.read().split(b"\n")
+    vl = [l[2:] for l in lines if l[:2] == b"v "]
+    tl = [l[3:] for l in lines if l[:3] == b"vt "]
+    fl = [l[2:] for l in lines if l[:2] == b"f "]
+    try:
+        if not vl or not fl:
+            raise ValueError
+        vt_ = np.fromstring(b" ".join(vl), dtype=np.float64, sep=" ")
+        if vt_.size != 3 * len(vl):
+            raise ValueError
+        verts = vt_.astype(np.float32).reshape(-1, 3)
+        ref0 = fl[0].split()[0]
+        nfield = ref0.count(b"/") + 1
+        joined = b" ".join(fl)
+        if b"//" in joined or b"-" in joined:
+            raise ValueError
+        ft_ = np.fromstring(joined.replace(b"/", b" "), dtype=np.int64, sep=" ")
+        if ft_.size != 3 * nfield * len(fl):
+            raise ValueError
+        idx = ft_.reshape(len(fl), 3, nfield) - 1
+        if idx.min() < 0:
+            raise ValueError
+        faces = np.ascontiguousarray(idx[:, :, 0]).astype(np.int32)
+        if tl and nfield >= 2:
+            tt_ = np.fromstring(b" ".join(tl), dtype=np.float64, sep=" ")
+            if tt_.size % len(tl) or tt_.size // len(tl) < 2:
+                raise ValueError
+            uvs = tt_.astype(np.float32).reshape(len(tl), -1)[:, :2]
+            return verts, faces, np.ascontiguousarray(uvs), np.ascontiguousarray(idx[:, :, 1]).astype(np.int32)
+        return verts, faces, None, None
+    except ValueError:
+        return _load_obj_generic(path)
+
+
+def _load_obj_generic(path):
     vs, vts, fv, ft = [], [], [], []
     with open(path) as f:
         for line in f:
@@ -130,7 +170,7 @@ def save_glb(path, verts, faces, uvs, texture_rgb_u8):
     import io
     from PIL import Image
     buf = io.BytesIO()
-    Image.fromarray(texture_rgb_u8).save(buf, format="PNG")
+    Image.fromarray(texture_rgb_u8).save(buf, format="PNG", compress_level=int(os.environ.get("UTX_PNG_LEVEL", "1")))      # lossless either way; level 6 costs 5x the time
     png = buf.getvalue()
     v = np.ascontiguousarray(verts, dtype=np.float32)
     t = np.ascontiguousarray(np.stack([uvs[:, 0], 1.0 - uvs[:, 1]], -1), dtype=np.float32)  # glTF v is top-down

@@ -78,7 +78,7 @@ class TexturedMesh:
         else:
             from PIL import Image
             base = os.path.splitext(path)[0]
-            Image.fromarray(self.texture).save(base + ".png")
+            Image.fromarray(self.texture).save(base + ".png", compress_level=int(os.environ.get("UTX_PNG_LEVEL", "1")))
             with open(base + ".mtl", "w") as f:
                 f.write("newmtl material_0\nmap_Kd %s\n" % os.path.basename(base + ".png"))
             meshes.save_obj(path, self.vertices, self.faces, self.uv, mtl=os.path.basename(base + ".mtl"))
