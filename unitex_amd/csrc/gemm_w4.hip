@@ -744,7 +744,9 @@ extern "C" int utx_launch_gemm_w4(GemmParams p, hipStream_t stream) {
     static int ncu = 0;
     if (!ncu) { int dev = 0; hipDeviceProp_t pr; ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
     const int ntm = (p.M + 255) / 256, ntn = p.N / 256;
-    int group_m = g_utx_opt.gemm_group_m > 0 ? g_utx_opt.gemm_group_m : 4;
+    // tile rows per L2 block of the tile order: wide outputs want narrow blocks (the B panel of a block is ntn tiles wide), mid-width ones taller
+    // blocks; +1...2 % against a fixed 4 (profiles/r02_gemm_group_m_sweep.log)
+    int group_m = g_utx_opt.gemm_group_m > 0 ? g_utx_opt.gemm_group_m : (ntn >= 64 ? 2 : ntn >= 32 ? 8 : 4);
     if (group_m > ntm) group_m = ntm;
     p.ntn = ntn | (group_m << 16);
     const int tiles = ntm * ntn;
