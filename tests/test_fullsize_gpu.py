@@ -183,6 +183,52 @@ def test_gemm_split_tail_round_matches_unsplit_launch_and_oracle_rows(M, N, K, K
     assert rel < 1.6e-2, "split tail vs oracle rows: %g" % rel
 
 
+@pytest.mark.parametrize("M,N,K,K2,S,kind", [(13376, 3072, 512, 512, 2, "gate"), (13376, 3072, 512, 512, 3, "gate"), (13001, 3072, 192, 64, 4, "plain"),
+                                             (13376, 3072, 320, 128, 4, "gate"), (13824, 3072, 576, 0, 3, "plain")])
+def test_gemm_split_tail_forced_range_shapes(M, N, K, K2, S, kind):
+    """UTX_GEMM_STREAMK = 1000 + S forces S ranges per tail tile on shapes the launcher's cost model never splits -- the range geometries of
+    gemm_w4.hip's staging cursor: a range that IS the LoRA segment (K = K2 = 512, S = 2), ranges that straddle the base -> LoRA switch and start
+    inside the LoRA segment at an odd K-tile (S = 3), ranges of ONE K-tile (K = 192 + 64, S = 4), four ranges of unequal length over 7 K-tiles in two passes of the grid, and
+    136 tail tiles x 3 ranges in two passes of the grid (M = 13 824).  Same contract as the test below."""
+    from unitex_amd import _lib
+    ops = _ops()
+    g = torch.Generator(device="cuda").manual_seed(M + N + K + S)
+    A = (torch.randn(M, K, device="cuda", generator=g) / 2).to(BF)
+    W = (torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K)).to(BF)
+    bias = torch.randn(N, device="cuda", generator=g).to(BF)
+    kw = {}
+    if K2:
+        kw.update(A2=(torch.randn(M, K2, device="cuda", generator=g) / 8).to(BF), B2=(torch.randn(N, K2, device="cuda", generator=g) / 4).to(BF))
+    res = torch.randn(M, N, device="cuda", generator=g).to(BF)
+    gate = torch.randn(N, device="cuda", generator=g).to(BF)
+
+    def run():
+        if kind == "gate":
+            r = res.clone()
+            ops.gemm(A, W, bias=bias, out=r, gate=gate, res=r, **kw)
+            return r
+        return ops.gemm(A, W, bias=bias, **kw)
+    try:
+        _lib.set_option("UTX_GEMM_STREAMK", 0)
+        base = run()
+        _lib.set_option("UTX_GEMM_STREAMK", 1000 + S)
+        s1 = run()
+        s2 = run()
+    finally:
+        _lib.set_option("UTX_GEMM_STREAMK", 1)
+    torch.cuda.synchronize()
+    assert _same_bits(s1, s2), "forced split is not deterministic"
+    assert bool((s1 != base).any()), "the forced split has the bits of the unsplit launch everywhere: nothing was split"
+    y0 = (base.float() - res.float()) if kind == "gate" else base.float()
+    y1 = (s1.float() - res.float()) if kind == "gate" else s1.float()
+    bound = 2.0 ** -6 * torch.maximum(y0.abs(), y1.abs()).clamp_min(1.0)
+    if kind == "gate":
+        bound = bound + 2.0 ** -7 * torch.maximum(base.float().abs(), s1.float().abs())
+    assert bool(((s1.float() - base.float()).abs() <= bound).all()), "forced split differs from the unsplit launch by more than rounding"
+    frac = float((s1 != base).float().mean())
+    assert frac < 0.02, "a forced split changes rounding in a few elements of the tail tiles only, not %.3f of the output" % frac
+
+
 @pytest.mark.parametrize("M", [S_FULL, 13824, 6336])   # 6336 = 50688 / 8: ragged last 256-row tile (sequence-parallel shard)
 def test_gemm_full_size_kernels_agree_bitwise_and_match_oracle_rows(M):
     ops = _ops()

@@ -762,8 +762,13 @@ extern "C" int utx_launch_gemm_w4(GemmParams p, hipStream_t stream) {
         const int T = tiles % grid;
         const int nss2 = p.K2 / 64, nssu = p.K / 64 + ((p.K2 > 0 && p.lora_n_limit > 0) ? nss2 : 0);
         const bool uniform = p.K2 == 0 || p.lora_n_limit <= 0 || p.lora_n_limit >= p.N;      // every tail tile has the same K extent
-        const int margin = g_utx_opt.gemm_streamk > 1 ? g_utx_opt.gemm_streamk : 4;
-        if (g_utx_opt.gemm_streamk > 0 && p.sk_work && tiles > grid && T > 0 && uniform && p.qk_cols == 0) {
+        const int margin = (g_utx_opt.gemm_streamk > 1 && g_utx_opt.gemm_streamk < 1000) ? g_utx_opt.gemm_streamk : 4;
+        if (g_utx_opt.gemm_streamk >= 1000 && p.sk_work && tiles > grid && T > 0 && uniform && p.qk_cols == 0) {
+            // tests: UTX_GEMM_STREAMK = 1000 + S forces S ranges wherever the structure allows it (ranges of one K-tile, ranges that start inside
+            // the LoRA segment, odd range lengths -- shapes the cost model would never split)
+            const int S = g_utx_opt.gemm_streamk - 1000;
+            if (S >= 2 && S <= 8 && nssu >= S && T * S <= 2 * grid && (size_t)T * S * 262144 <= p.sk_work_bytes) { sk_T = T; sk_S = S; }
+        } else if (g_utx_opt.gemm_streamk > 0 && p.sk_work && tiles > grid && T > 0 && uniform && p.qk_cols == 0) {
             int best = nssu - margin, bestS = 0;
             for (int S = 2; S <= 8; ++S) {
                 if (nssu / S < 8 || T * S > 2 * grid || (size_t)T * S * 262144 > p.sk_work_bytes) break;
