@@ -35,12 +35,14 @@ int utx_init(int device, utx_ctx** ctx);
 void utx_free(utx_ctx* ctx);
 const char* utx_last_error(utx_ctx* ctx);
 
-/* Launch options (kernel selection / scheduling A/B; every one is RESULT-PRESERVING).  The first utx_init reads the
- * environment variables of the same names once; later changes go through utx_set_option only (no getenv on the launch
- * path).  Names: UTX_ATTN_GLDS, UTX_ATTN_FAST, UTX_ATTN_Q64, UTX_ATTN_TPB, UTX_ATTN_TAILSPLIT, UTX_GEMM_GROUP_M,
- * UTX_GEMM_TILE, UTX_GEMM_TAILSPLIT, UTX_GEMM_PERS_GRID, UTX_GEMM_PERS_SCHED.  The timing-ablation switches that compute wrong results (UTX_ATTN_VAR,
- * UTX_ATTN_DEBUG, UTX_GEMM_DEBUG) exist only in the separately built libunitex_hip_ablate.so (tools/ only): in this
- * library they return -7 and the environment variables are ignored.  Returns -2 for an unknown name. */
+/* Launch options (kernel selection / scheduling A/B).  Every one is RESULT-PRESERVING: identical bits, except that the three
+ * tail-split switches (UTX_ATTN_TAILSPLIT, UTX_GEMM_TAILSPLIT, UTX_GEMM_STREAMK) change the fp32 summation order inside the tiles
+ * they split -- the same result up to rounding, deterministic from launch to launch.  The first utx_init reads the environment
+ * variables of the same names once; later changes go through utx_set_option only (no getenv on the launch path).  Names:
+ * UTX_ATTN_GLDS, UTX_ATTN_FAST, UTX_ATTN_Q64, UTX_ATTN_TPB, UTX_ATTN_TAILSPLIT, UTX_GEMM_GROUP_M, UTX_GEMM_TILE, UTX_GEMM_TAILSPLIT,
+ * UTX_GEMM_STREAMK, UTX_GEMM_PERS_GRID, UTX_GEMM_PERS_SCHED, UTX_BVH_STACK_WALK.  The timing-ablation switches that compute wrong
+ * results (UTX_ATTN_VAR, UTX_ATTN_DEBUG, UTX_GEMM_DEBUG) exist only in the separately built libunitex_hip_ablate.so (tools/ only): in
+ * this library they return -7 and the environment variables are ignored.  Returns -2 for an unknown name. */
 int utx_set_option(const char* name, int value);
 int utx_get_option(const char* name, int* value);
 int utx_is_ablation_build(void);
