@@ -286,7 +286,8 @@ def test_gemm_persistent_kernel_edge_shapes_bit_identical_to_tiled_kernels(M, N,
     tile (K = 192, and 48 + 1 style LoRA segments: the stream re-enters at odd LDS parity), a single K-tile per tile (K = 64:
     every K-tile is first and last), tiles with and without the LoRA segment in one launch, GELU / column split on a tile
     boundary, and the gated residual updated IN PLACE (res aliases C).  All five kernels (incl. the one-wave-per-SIMD kernel of
-    gemm_w4.hip, whose stream unit is 32 k: K = 64 is two sub-stages per tile, its ragged-M gated slow path) must agree bit for bit."""
+    gemm_w4.hip, whose stream unit is a 64-k K-tile: K = 64 is ONE K-tile per tile -- every K-tile first and last --, and its ragged-M gated slow
+    path) must agree bit for bit."""
     ops = _ops()
     g = torch.Generator(device="cuda").manual_seed(M + N + K)
     A = (torch.randn(M, K, device="cuda", generator=g) / 2).to(BF)
