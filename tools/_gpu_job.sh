@@ -1,5 +1,4 @@
-R=$GRAFT_REPO_ROOT
-mkdir -p $R/gpurun_out
-cd /tmp && export TMPDIR=/tmp
-timeout 100 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_ref512 -- python $R/bench.py --workload ref512x6 --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof_ref512.log 2>&1
-find $R/gpurun_out/prof_ref512 -name "*kernel_stats.csv" | head -2
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+timeout 75 python -m pytest tests/test_fullsize_gpu.py tests/test_dit_ops_gpu.py -x -q -k "split_tail or forced_range or edge_shapes or gemm" > gpurun_out/r02_gemm_tests_i.log 2>&1
+tail -3 gpurun_out/r02_gemm_tests_i.log

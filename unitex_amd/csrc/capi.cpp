@@ -132,6 +132,12 @@ int utx_attn_fwd_bf16_kbq(utx_ctx* ctx, const void* q, const void* k, const void
 }
 
 size_t utx_gemm_streamk_workspace_bytes(utx_ctx*) { return utx_gemm_streamk_workspace_bytes_impl(); }
+int utx_gemm_plan(const utx_gemm_desc* d, int n_cus, int out[4]) {
+    if (!d || !out || n_cus <= 0 || d->M <= 0 || d->N <= 0 || d->K <= 0) return -2;
+    options_from_env_once();
+    utx_gemm_plan_impl(d, n_cus, d->sk_work != nullptr, out);
+    return 0;
+}
 int utx_gemm_bf16(utx_ctx* ctx, const utx_gemm_desc* d, utx_stream stream) {
     if (!d || !d->A || !d->B || !d->C) return fail(ctx, -2, "utx_gemm_bf16");
     UTX_CALL(ctx, "utx_gemm_bf16", utx_launch_gemm_bf16(d, (hipStream_t)stream));

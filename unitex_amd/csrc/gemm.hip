@@ -783,6 +783,39 @@ static int launch_gemm8(GemmParams p, hipStream_t stream, int group_env, int dbg
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
+// Which kernel a descriptor goes to, and how the one-wave-per-SIMD kernel would cut its last round -- pure host arithmetic (no HIP call), shared by
+// the launcher below and by utx_gemm_plan (C ABI: the host side and the CPU tests read the decision instead of restating it).
+// kernel: 0 = 128^2 (incl. the implicit convolution / MX fp8 forms), 1 = one wave per SIMD (gemm_w4.hip), 2 = persistent 8-wave, 3 = per-tile 8-phase,
+// 4 = 2-barrier 256^2.  Shape validation stays in the launcher.
+extern "C" void utx_gemm_plan_impl(const GemmParams* pp, int ncu, int sk_has_work, int out[4]) {
+    const GemmParams& p = *pp;
+    const int dbg_env = g_utx_opt.gemm_debug_abl, tile_env = g_utx_opt.gemm_tile;
+    out[0] = 0; out[1] = ((p.M + 127) / 128) * ((p.N + 127) / 128); out[2] = 0; out[3] = 0;
+    if (p.conv_Wo > 0 || p.mx8) return;
+    // 256^2 tiles need every column boundary on a 256 multiple and enough tiles to fill the chip
+    const bool ok256 = (p.N % 256 == 0) && (p.n_split >= p.N || p.n_split % 256 == 0) &&
+                       (p.gelu_from >= p.N || p.gelu_from % 256 == 0) &&
+                       (p.K2 == 0 || (p.lora_seg_n % 256 == 0 && p.lora_n_limit % 256 == 0));
+    const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+    bool use256 = ok256 && tiles256 >= 192;
+    if (tile_env == 128) use256 = false;
+    if ((tile_env == 256 || tile_env == 2562 || tile_env == 2560 || tile_env == 2564) && ok256) use256 = true;   // 2562 = the 2-barrier 256^2 kernel, 2560 = force the persistent kernel (A/B testing)
+    if (!use256) return;
+    out[1] = (int)tiles256;
+    // default for the large-M linears: the persistent one-wave-per-SIMD kernel (gemm_w4.hip; +5...10 % over the persistent 8-wave kernel on the FLUX
+    // shapes, profiles/r02_gemm_w4_check_v7.log); UTX_GEMM_TILE=2560 keeps the persistent 8-wave kernel (gemm_pers.hip), 256 the per-tile-launch
+    // 8-phase kernel, for A/B (all bit-identical); the timing ablations / the 8-phase tail split only exist in the latter.
+    const bool plain_opts = (dbg_env & 3) == 0 && g_utx_opt.gemm_tailsplit == 0;
+    if ((tile_env == 0 || tile_env == 2564) && plain_opts) {
+        out[0] = 1;
+        int grid = tiles256 < ncu ? (int)tiles256 : ncu;
+        if (g_utx_opt.gemm_pers_grid > 0 && g_utx_opt.gemm_pers_grid < grid) grid = g_utx_opt.gemm_pers_grid;
+        utx_gemm_w4_split_plan(&p, (int)tiles256, grid, sk_has_work, &out[2], &out[3]);
+    } else if (tile_env == 2560 && plain_opts) out[0] = 2;
+    else if (tile_env != 2562) out[0] = 3;
+    else out[0] = 4;
+}
+
 extern "C" int utx_launch_gemm_bf16(const GemmParams* hp, hipStream_t stream) {
     GemmParams p = *hp;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return -1;
@@ -805,29 +838,18 @@ extern "C" int utx_launch_gemm_bf16(const GemmParams* hp, hipStream_t stream) {
         return launch_gemm<128, 128, 2, 2, true>(p, stream, 0, 0);
     }
     if (p.mx8) return launch_gemm<128, 128, 2, 2, false, true>(p, stream, group_env, 0);
-    // 256^2 tiles need every column boundary on a 256 multiple and enough tiles to fill the chip
-    const bool ok256 = (p.N % 256 == 0) && (p.n_split >= p.N || p.n_split % 256 == 0) &&
-                       (p.gelu_from >= p.N || p.gelu_from % 256 == 0) &&
-                       (p.K2 == 0 || (p.lora_seg_n % 256 == 0 && p.lora_n_limit % 256 == 0));
-    const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
-    bool use256 = ok256 && tiles256 >= 192;
-    if (tile_env == 128) use256 = false;
-    if ((tile_env == 256 || tile_env == 2562 || tile_env == 2560 || tile_env == 2564) && ok256) use256 = true;   // 2562 = the 2-barrier 256^2 kernel, 2560 = force the persistent kernel (A/B testing)
-    // default for the large-M linears: the persistent one-wave-per-SIMD kernel (gemm_w4.hip; +5...10 % over the persistent 8-wave kernel on the FLUX
-    // shapes, profiles/r02_gemm_w4_check_v7.log); UTX_GEMM_TILE=2560 keeps the persistent 8-wave kernel (gemm_pers.hip), 256 the per-tile-launch
-    // 8-phase kernel, for A/B (all bit-identical); the timing ablations / tail split only exist in the latter.
+    int plan[4];
+    utx_gemm_plan_impl(&p, 256, 1, plan);      // the kernel choice does not depend on the CU count (only the split of the last round does)
     if (p.qk_cols > 0) {
         // fused q / k post-processing: only the one-wave-per-SIMD kernel has it (a wave owns a whole head there); refuse instead of dropping it
         if (p.mx8 || p.conv_Wo > 0 || p.gate || (p.qk_cols % 256) || p.qk_cols > p.N || p.qk_cols > p.n_split || p.qk_cols > p.gelu_from ||
             !p.qk_wq || !p.qk_wk || !p.qk_cos || !p.qk_sin || !p.qk_Qh || !p.qk_Kh || p.qk_hs <= 0 || p.qk_tok_off < 0) return -2;
-        if (!(use256 && (tile_env == 0 || tile_env == 2564) && (dbg_env & 3) == 0 && g_utx_opt.gemm_tailsplit == 0)) return -2;
+        if (plan[0] != 1) return -2;
     }
-    if (use256 && (tile_env == 0 || tile_env == 2564) && (dbg_env & 3) == 0 && g_utx_opt.gemm_tailsplit == 0)
-        return utx_launch_gemm_w4(p, stream);
-    if (use256 && tile_env == 2560 && (dbg_env & 3) == 0 && g_utx_opt.gemm_tailsplit == 0)
-        return utx_launch_gemm_pers(p, stream);
-    if (use256 && tile_env != 2562) return launch_gemm8(p, stream, group_env, dbg_env);
-    if (use256) return launch_gemm<256, 256, 2, 4>(p, stream, group_env, dbg_env);
+    if (plan[0] == 1) return utx_launch_gemm_w4(p, stream);
+    if (plan[0] == 2) return utx_launch_gemm_pers(p, stream);
+    if (plan[0] == 3) return launch_gemm8(p, stream, group_env, dbg_env);
+    if (plan[0] == 4) return launch_gemm<256, 256, 2, 4>(p, stream, group_env, dbg_env);
     return launch_gemm<128, 128, 2, 2>(p, stream, group_env, dbg_env);
 }
 

@@ -732,6 +732,38 @@ extern "C" size_t utx_gemm_streamk_workspace_bytes_impl(void) {
     return (size_t)ncu * 2 * 262144;      // up to two fp32 256 x 256 partial tiles per workgroup
 }
 
+// Split tail (kernel: "split tail"), the plan: the T = tiles % grid tiles of the last round are cut along K into S ranges each, T S ranges over the grid
+// in ceil(T S / grid) passes, instead of T workgroups running a whole tile while the others idle.  S by a cost model in K-tiles (1.3 us), fitted to
+// profiles/r02_gemm_streamk_check_v*.log: a range costs its K-tiles + 4 (dump), the fix-up kernel 6 + 8 per 256 partial tiles; unsplit, the round
+// costs a tile's K-tiles.  UTX_GEMM_STREAMK: 0 never, 1 the model with a margin of 4 K-tiles, 2..999 that margin, 1000 + S force S ranges wherever
+// the structure allows it (tests: ranges of one K-tile, ranges that start inside the LoRA segment, odd range lengths -- shapes the model never
+// splits).  Pure host arithmetic; *T = *S = 0 when the last round stays whole.  At most 2 grid partial tiles (the workspace of
+// utx_gemm_streamk_workspace_bytes).
+extern "C" void utx_gemm_w4_split_plan(const GemmParams* pp, int tiles, int grid, int has_work, int* T_out, int* S_out) {
+    const GemmParams& p = *pp;
+    *T_out = 0; *S_out = 0;
+    const int opt = g_utx_opt.gemm_streamk;
+    if (opt <= 0 || !has_work || grid <= 0 || tiles <= grid || p.qk_cols != 0) return;
+    const int T = tiles % grid;
+    if (T == 0) return;
+    if (!(p.K2 == 0 || p.lora_n_limit <= 0 || p.lora_n_limit >= p.N)) return;       // every tail tile must have the same K extent
+    const int nssu = p.K / 64 + ((p.K2 > 0 && p.lora_n_limit > 0) ? p.K2 / 64 : 0);
+    if (opt >= 1000) {
+        const int S = opt - 1000;
+        if (S >= 2 && S <= 8 && nssu >= S && T * S <= 2 * grid) { *T_out = T; *S_out = S; }
+        return;
+    }
+    const int margin = opt > 1 ? opt : 4;
+    int best = nssu - margin, bestS = 0;
+    for (int S = 2; S <= 8; ++S) {
+        if (nssu / S < 8 || T * S > 2 * grid) break;
+        const int passes = (T * S + grid - 1) / grid;
+        const int est = passes * ((nssu + S - 1) / S + 4) + 6 + (8 * T * S) / 256;
+        if (est < best) { best = est; bestS = S; }
+    }
+    if (bestS) { *T_out = T; *S_out = bestS; }
+}
+
 extern "C" int utx_launch_gemm_w4(GemmParams p, hipStream_t stream) {
     constexpr int LDS = 2 * W4_STAGE + 4 * 8192;     // the ring + the four waves' C staging buffers = all 160 KB
     static bool attr_set = false;
@@ -753,32 +785,8 @@ extern "C" int utx_launch_gemm_w4(GemmParams p, hipStream_t stream) {
     int grid = tiles < ncu ? tiles : ncu;
     if (g_utx_opt.gemm_pers_grid > 0 && g_utx_opt.gemm_pers_grid < grid) grid = g_utx_opt.gemm_pers_grid;
     const int trace_wg = g_utx_opt.gemm_pers_sched >= 100 ? g_utx_opt.gemm_pers_sched - 100 : 0;   // ablation build: which workgroup writes the ABL 128 timeline
-    // Split tail (kernel: "split tail"): the T < grid tiles of the last round are cut along K into S ranges each, T S ranges over the grid in
-    // ceil(T S / grid) passes, instead of T workgroups running a whole tile while the others idle.  S by a cost model in K-tiles (1.3 us), fitted to
-    // profiles/r02_gemm_streamk_check_v*.log: a range costs its K-tiles + 4 (dump), the fix-up kernel 6 + 8 per 256 partial tiles; unsplit, the
-    // round costs a tile's K-tiles.  UTX_GEMM_STREAMK = n > 1 sets the margin the saving has to exceed (default 4).
     int sk_T = 0, sk_S = 0;
-    {
-        const int T = tiles % grid;
-        const int nss2 = p.K2 / 64, nssu = p.K / 64 + ((p.K2 > 0 && p.lora_n_limit > 0) ? nss2 : 0);
-        const bool uniform = p.K2 == 0 || p.lora_n_limit <= 0 || p.lora_n_limit >= p.N;      // every tail tile has the same K extent
-        const int margin = (g_utx_opt.gemm_streamk > 1 && g_utx_opt.gemm_streamk < 1000) ? g_utx_opt.gemm_streamk : 4;
-        if (g_utx_opt.gemm_streamk >= 1000 && p.sk_work && tiles > grid && T > 0 && uniform && p.qk_cols == 0) {
-            // tests: UTX_GEMM_STREAMK = 1000 + S forces S ranges wherever the structure allows it (ranges of one K-tile, ranges that start inside
-            // the LoRA segment, odd range lengths -- shapes the cost model would never split)
-            const int S = g_utx_opt.gemm_streamk - 1000;
-            if (S >= 2 && S <= 8 && nssu >= S && T * S <= 2 * grid && (size_t)T * S * 262144 <= p.sk_work_bytes) { sk_T = T; sk_S = S; }
-        } else if (g_utx_opt.gemm_streamk > 0 && p.sk_work && tiles > grid && T > 0 && uniform && p.qk_cols == 0) {
-            int best = nssu - margin, bestS = 0;
-            for (int S = 2; S <= 8; ++S) {
-                if (nssu / S < 8 || T * S > 2 * grid || (size_t)T * S * 262144 > p.sk_work_bytes) break;
-                const int passes = (T * S + grid - 1) / grid;
-                const int est = passes * ((nssu + S - 1) / S + 4) + 6 + (8 * T * S) / 256;
-                if (est < best) { best = est; bestS = S; }
-            }
-            if (bestS) { sk_T = T; sk_S = bestS; }
-        }
-    }
+    utx_gemm_w4_split_plan(&p, tiles, grid, (p.sk_work && p.sk_work_bytes >= (size_t)2 * grid * 262144) ? 1 : 0, &sk_T, &sk_S);     // a plan holds at most 2 grid partial tiles
 #ifdef UTX_ABLATION
     {
         const int abl = (g_utx_opt.gemm_debug_abl >> 5) & 511;   // (ABL 256 = start-time stagger: results stay correct)     // UTX_GEMM_DEBUG bits 5..8

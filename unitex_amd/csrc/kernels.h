@@ -67,6 +67,8 @@ int utx_launch_attn_fwd_glds(const AttnParams* p, int presc, hipStream_t stream)
 int utx_launch_attn_fwd_q64(const AttnParams* p, int presc, hipStream_t stream);
 int utx_launch_gemm_bf16(const GemmParams* p, hipStream_t stream);
 size_t utx_gemm_streamk_workspace_bytes_impl(void);
+void utx_gemm_plan_impl(const GemmParams* p, int ncu, int sk_has_work, int out[4]);          // gemm.hip: kernel choice + split of the last round (pure)
+void utx_gemm_w4_split_plan(const GemmParams* p, int tiles, int grid, int has_work, int* T, int* S);   // gemm_w4.hip (pure)
 int utx_launch_gemm_w4(GemmParams p, hipStream_t stream);     // gemm_w4.hip: persistent 256x256 kernel, one wave per SIMD
 int utx_launch_gemm_pers(GemmParams p, hipStream_t stream);   // gemm_pers.hip: persistent 256x256 kernel (large-M linears)
 int utx_launch_gemv_bf16(const GemvParams* p, hipStream_t stream);

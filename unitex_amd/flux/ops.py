@@ -109,17 +109,33 @@ def streamk_workspace(device, stream=None, shared=True):
     return _SK_WS[key]
 
 
+GEMM_KERNELS = ("128x128", "w4", "pers8", "8phase", "2barrier")
+
+
+def gemm_plan(M, N, K=3072, K2=0, n_split=None, gelu_from=None, lora_seg_n=None, lora_n_limit=None, sk=True, n_cus=256):
+    """what utx_gemm_bf16 does with this shape under the current launch options (utx_gemm_plan: the library's own dispatch arithmetic, no device
+    needed): dict(kernel=one of GEMM_KERNELS, tiles, tail_tiles, ranges) -- tail_tiles > 0 when the one-wave-per-SIMD kernel cuts its last round
+    along K into `ranges` ranges per tile (needs scratch: sk)."""
+    lib = _lib.load_library()
+    d = GemmDesc()
+    d.A = d.B = d.C = 1                       # never dereferenced by the plan
+    d.M, d.N, d.K, d.K2 = int(M), int(N), int(K), int(K2)
+    d.lora_n_limit = (N if lora_n_limit is None else lora_n_limit) if K2 else 0
+    d.lora_seg_n = (N if lora_seg_n is None else lora_seg_n) if K2 else 128
+    d.n_split = N if n_split is None else n_split
+    d.gelu_from = N if gelu_from is None else gelu_from
+    d.sk_work = 1 if sk else None
+    out = (C.c_int * 4)()
+    rc = lib.utx_gemm_plan(C.byref(d), int(n_cus), C.byref(out))
+    if rc != 0:
+        raise ValueError("utx_gemm_plan -> %d" % rc)
+    return {"kernel": GEMM_KERNELS[out[0]], "tiles": out[1], "tail_tiles": out[2], "ranges": out[3]}
+
+
 def gemm_takes_w4(M, N, n_split=None, gelu_from=None, K2=0, lora_seg_n=None, lora_n_limit=None):
     """True when utx_gemm_bf16 dispatches this shape to the one-wave-per-SIMD 256 x 256 kernel (gemm_w4.hip) -- the kernel that carries the
-    fused q / k epilogue; mirrors the rule in gemm.hip (`ok256`, >= 192 tiles, default UTX_GEMM_TILE / no tail split)."""
-    opt = _lib.get_options()
-    if opt.get("UTX_GEMM_TILE", 0) not in (0, 2564) or opt.get("UTX_GEMM_TAILSPLIT", 0) != 0:
-        return False
-    ok = (N % 256 == 0) and (n_split is None or n_split >= N or n_split % 256 == 0) and (gelu_from is None or gelu_from >= N or gelu_from % 256 == 0)
-    if K2:
-        ok = ok and (lora_seg_n or N) % 256 == 0 and (lora_n_limit if lora_n_limit is not None else N) % 256 == 0
-    tiles = ((M + 255) // 256) * ((N + 255) // 256)
-    return bool(ok and (tiles >= 192 or opt.get("UTX_GEMM_TILE", 0) == 2564))
+    fused q / k epilogue.  Asked of the library (utx_gemm_plan), not restated here."""
+    return gemm_plan(M, N, K2=K2, n_split=n_split, gelu_from=gelu_from, lora_seg_n=lora_seg_n, lora_n_limit=lora_n_limit)["kernel"] == "w4"
 
 
 def gemm(A, B, bias=None, out=None, **kw):
