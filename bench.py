@@ -153,6 +153,13 @@ def cpu_baseline_backprojection():
             "sample": "oracle/geom_ref.c + numpy, 20k faces, 6 x 256^2 views, 512^2 atlas (x16 texels -> 2048^2)"}
 
 
+def _gemm_census(model):
+    try:
+        return model.gemm_census()
+    except Exception as e:  # noqa: BLE001 -- a reporting extra must never cost the bench line
+        return {"error": repr(e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -345,7 +352,7 @@ def main():
                        "sec_per_mesh_texture_dit_only": 56.0 * dt / args.steps,
                        # every switch that could change what was measured: the library's launch options (all result-preserving; the
                        # wrong-result ablations do not exist in this library) and every UTX_* variable of the environment
-                       "launch_options": _lib.get_options(), "ablation_build": bool(_lib.load_library().utx_is_ablation_build()),
+                       "launch_options": _lib.get_options(), "gemm_launches_per_step": _gemm_census(model), "ablation_build": bool(_lib.load_library().utx_is_ablation_build()),
                        "env_UTX": {k: v for k, v in sorted(os.environ.items()) if k.startswith("UTX_")}},
             "roofline": {"bound": "mfma", "kernel": "attn_fwd_glds_kernel", "launches_per_call": "full rounds + key-split tail round (same kernel) + attn_merge_kernel; a 'launch' below is one utx_attn_fwd_bf16 call", "achieved": achieved, "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,

@@ -552,6 +552,30 @@ class FluxDiT:
         self._assign_streamk(plan, ws)
         return {"ws": ws, "plan": plan, "S_txt": S_txt, "S_img": S_img}
 
+    def gemm_census(self, n_cus=None):
+        """{kernel name: launches per forward} of the current plan, as the library's own dispatch (utx_gemm_plan) sees each descriptor, plus
+        "w4_split_tail": the launches whose partly filled last round is cut along K (what bench.py reports in `config`)."""
+        if not self._plans:
+            return {}
+        if n_cus is None:
+            n_cus = torch.cuda.get_device_properties(self.device).multi_processor_count
+        out = {}
+        arr = (C.c_int * 4)()
+
+        def walk(entries):
+            for e in entries:
+                if e[0] == "par":
+                    walk(e[1][0]); walk(e[1][1])
+                elif e[0] is self.lib.utx_gemm_bf16:
+                    if self.lib.utx_gemm_plan(C.byref(e[1]), int(n_cus), C.byref(arr)) != 0:
+                        continue
+                    k = ops.GEMM_KERNELS[arr[0]]
+                    out[k] = out.get(k, 0) + 1
+                    if arr[2] > 0:
+                        out["w4_split_tail"] = out.get("w4_split_tail", 0) + 1
+        walk(next(iter(self._plans.values()))["plan"])
+        return out
+
     def _assign_streamk(self, plan, ws):
         """scratch of the large-M GEMM's balanced tail round (utx_gemm_desc.sk_work): one buffer for the GEMMs of the main stream -- they
         are ordered among themselves; the text-side ops of a "par" entry run beside them on the second stream and get none (their GEMMs are
