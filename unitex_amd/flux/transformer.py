@@ -582,16 +582,23 @@ class FluxDiT:
         far below the size where the tail is split).  UTX_GEMM_STREAMK=0 at library level switches the split off."""
         if self.fp8_weights:
             return
+        ncu = torch.cuda.get_device_properties(self.device).multi_processor_count
+
+        def main_gemms(entries):
+            for e in entries:
+                if e[0] is self.lib.utx_gemm_bf16:
+                    yield e[1]
+                elif e[0] == "par":
+                    yield from main_gemms(e[1][0])
+        descs = list(main_gemms(plan))
+        # only launches with more 256 x 256 tiles than CUs can have a partly filled LAST round (small models never pay for the buffer)
+        if not any(((d.M + 255) // 256) * (d.N // 256) > ncu for d in descs):
+            return
         if "sk" not in ws:
             ws["sk"] = ops.streamk_workspace(self.device, shared=False)
         sk = ws["sk"]
-        def assign(entries):
-            for e in entries:
-                if e[0] is self.lib.utx_gemm_bf16:
-                    e[1].sk_work, e[1].sk_work_bytes = ptr(sk), sk.numel()
-                elif e[0] == "par":
-                    assign(e[1][0])
-        assign(plan)
+        for d in descs:
+            d.sk_work, d.sk_work_bytes = ptr(sk), sk.numel()
 
     # ------------------------------------------------------------------ forward
     TEXT_KEEP = 64      # rows of the (identical) text tokens that are carried when the dedup applies: one 64-key attention tile
