@@ -367,7 +367,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define W4_CPTR(im_, t_) (cub + (long)(32 * (im_) + 4 * (t_)) * ldc * 2 + cvo)
 #define W4_RPTR_U(im_, t_) (rub + (long)(32 * (im_) + 4 * (t_)) * p.ldres * 2)
 #define W4_ROW(im_, t_) (rowg + 32 * (im_) + 4 * (t_))
-#define W4_STORE_U(im_, t_, O_) *reinterpret_cast<uint4*>(W4_CPTR(im_, t_)) = O_;
+    // ABL 512 (ablation build; correct results): the C stores carry the nontemporal hint.  One round of tiles writes 4 MB of C per XCD -- the size of
+    // its L2 -- so write-allocated C lines may be what evicts the operand panels the next K-tiles stream (the 14 us of operand traffic per K = 3072
+    // tile, profiles/r02_gemm_w4_probe_v10.log); to be measured with tools/gemm_w4_probe.py
+#define W4_STORE_U(im_, t_, O_) { if constexpr ((ABL & 512) != 0) { const uint4 o4_ = O_; const w4_u32x4 ov_ = {o4_.x, o4_.y, o4_.z, o4_.w};                  \
+                                      __builtin_nontemporal_store(ov_, reinterpret_cast<w4_u32x4*>(W4_CPTR(im_, t_))); }                       \
+                                  else *reinterpret_cast<uint4*>(W4_CPTR(im_, t_)) = O_; }
 #define W4_STORE_M(im_, t_, O_) if (W4_ROW(im_, t_) < p.M) { W4_STORE_U(im_, t_, O_) }
 #define W4_PLAIN_BLOCK(im_, GELU_)                                                                                     \
         W4_EPI_WRITE(im_, GELU_)                                                                                       \
@@ -789,11 +794,11 @@ extern "C" int utx_launch_gemm_w4(GemmParams p, hipStream_t stream) {
     utx_gemm_w4_split_plan(&p, tiles, grid, (p.sk_work && p.sk_work_bytes >= (size_t)2 * grid * 262144) ? 1 : 0, &sk_T, &sk_S);     // a plan holds at most 2 grid partial tiles
 #ifdef UTX_ABLATION
     {
-        const int abl = (g_utx_opt.gemm_debug_abl >> 5) & 511;   // (ABL 256 = start-time stagger: results stay correct)     // UTX_GEMM_DEBUG bits 5..8
+        const int abl = (g_utx_opt.gemm_debug_abl >> 5) & 1023;   // (ABL 256 = start-time stagger, 512 = nontemporal C stores: results stay correct)     // UTX_GEMM_DEBUG bits 5..14
         if (abl && !p.gate) {
 #define W4_ABL_CASE(a_) if (abl == (a_)) { hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_w4_kernel<false, (a_)>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
                                            hipLaunchKernelGGL((gemm256_w4_kernel<false, (a_)>), dim3(grid), dim3(256), LDS, stream, p, tiles, trace_wg, 0, 0); return 0; }
-            W4_ABL_CASE(1) W4_ABL_CASE(2) W4_ABL_CASE(3) W4_ABL_CASE(4) W4_ABL_CASE(7) W4_ABL_CASE(8) W4_ABL_CASE(15) W4_ABL_CASE(16) W4_ABL_CASE(32) W4_ABL_CASE(64) W4_ABL_CASE(128) W4_ABL_CASE(144) W4_ABL_CASE(256)
+            W4_ABL_CASE(1) W4_ABL_CASE(2) W4_ABL_CASE(3) W4_ABL_CASE(4) W4_ABL_CASE(7) W4_ABL_CASE(8) W4_ABL_CASE(15) W4_ABL_CASE(16) W4_ABL_CASE(32) W4_ABL_CASE(64) W4_ABL_CASE(128) W4_ABL_CASE(144) W4_ABL_CASE(256) W4_ABL_CASE(512)
         }
     }
 #endif
