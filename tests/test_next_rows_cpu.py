@@ -340,3 +340,23 @@ def test_obj_reader_fast_path_equals_the_line_reader_and_falls_back(tmp_path):
         same(meshes.load_obj(q), meshes._load_obj_generic(q))
     assert np.array_equal(meshes.load_obj(str(tmp_path / "negative.obj"))[1], f)
     assert len(meshes.load_obj(str(tmp_path / "quad.obj"))[1]) == len(f) + 2
+
+
+def test_stage_encoders_finish_inside_the_stage_and_surface_errors(tmp_path):
+    """texturetools/timer.py::Encoders: the codecs of one stage run side by side on host threads, but the stage's files are on disk when its
+    `with` block ends (the stages hand over PATHS, reference pipeline.py:594-632) and an encoder's exception is raised in the stage that owns it."""
+    from unitex_amd.texturetools.timer import Encoders
+    imgs = [Image.fromarray(np.full((64, 64, 3), 10 * i, np.uint8)) for i in range(6)]
+    with Encoders() as enc:
+        for i, im in enumerate(imgs):
+            enc.submit(im.save, str(tmp_path / ("a%d.png" % i)), compress_level=1)
+    for i in range(6):
+        assert np.array_equal(np.asarray(Image.open(str(tmp_path / ("a%d.png" % i)))), np.asarray(imgs[i]))
+    with pytest.raises(FileNotFoundError):
+        with Encoders() as enc:
+            enc.submit(imgs[0].save, str(tmp_path / "no_such_dir" / "x.png"))
+    # level-1 hand-off PNGs are lossless: same pixels as PIL's default level
+    a = (np.random.default_rng(0).random((128, 96, 3)) * 255).astype(np.uint8)
+    Image.fromarray(a).save(str(tmp_path / "l1.png"), compress_level=1)
+    Image.fromarray(a).save(str(tmp_path / "l6.png"))
+    assert np.array_equal(np.asarray(Image.open(str(tmp_path / "l1.png"))), np.asarray(Image.open(str(tmp_path / "l6.png"))))
