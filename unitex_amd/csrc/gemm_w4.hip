@@ -367,10 +367,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define W4_CPTR(im_, t_) (cub + (long)(32 * (im_) + 4 * (t_)) * ldc * 2 + cvo)
 #define W4_RPTR_U(im_, t_) (rub + (long)(32 * (im_) + 4 * (t_)) * p.ldres * 2)
 #define W4_ROW(im_, t_) (rowg + 32 * (im_) + 4 * (t_))
-    // ABL 512 (ablation build; correct results): the C stores carry the nontemporal hint.  One round of tiles writes 4 MB of C per XCD -- the size of
-    // its L2 -- so write-allocated C lines may be what evicts the operand panels the next K-tiles stream (the 14 us of operand traffic per K = 3072
-    // tile, profiles/r02_gemm_w4_probe_v10.log); to be measured with tools/gemm_w4_probe.py
-#define W4_STORE_U(im_, t_, O_) { if constexpr ((ABL & 512) != 0) { const uint4 o4_ = O_; const w4_u32x4 ov_ = {o4_.x, o4_.y, o4_.z, o4_.w};                  \
+    // The C stores carry the NONTEMPORAL hint.  One round of tiles writes 4 MB of C per XCD -- the size of its L2 -- and write-allocated C lines
+    // evicted the operand panels the next K-tiles stream: per tile of M = 50 688, N = 3072 (us; profiles/r02_gemm_w4_probe_nt.log)
+    //   K = 1024: 37.3 -> 29.2 (no C stores at all: 27.7) | K = 3072: 82.7 -> 77.7 (75.1) | K = 6144: 150.0 -> 146.8 (145.0)
+    // i.e. the hint recovers 70-85 % of what the stores cost.  ABL 512 (ablation build, correct results) = plain stores, for the A/B.
+#define W4_STORE_U(im_, t_, O_) { if constexpr ((ABL & 512) == 0) { const uint4 o4_ = O_; const w4_u32x4 ov_ = {o4_.x, o4_.y, o4_.z, o4_.w};                  \
                                       __builtin_nontemporal_store(ov_, reinterpret_cast<w4_u32x4*>(W4_CPTR(im_, t_))); }                       \
                                   else *reinterpret_cast<uint4*>(W4_CPTR(im_, t_)) = O_; }
 #define W4_STORE_M(im_, t_, O_) if (W4_ROW(im_, t_) < p.M) { W4_STORE_U(im_, t_, O_) }
@@ -794,7 +795,7 @@ extern "C" int utx_launch_gemm_w4(GemmParams p, hipStream_t stream) {
     utx_gemm_w4_split_plan(&p, tiles, grid, (p.sk_work && p.sk_work_bytes >= (size_t)2 * grid * 262144) ? 1 : 0, &sk_T, &sk_S);     // a plan holds at most 2 grid partial tiles
 #ifdef UTX_ABLATION
     {
-        const int abl = (g_utx_opt.gemm_debug_abl >> 5) & 1023;   // (ABL 256 = start-time stagger, 512 = nontemporal C stores: results stay correct)     // UTX_GEMM_DEBUG bits 5..14
+        const int abl = (g_utx_opt.gemm_debug_abl >> 5) & 1023;   // (ABL 256 = start-time stagger, 512 = plain instead of nontemporal C stores: results stay correct)     // UTX_GEMM_DEBUG bits 5..14
         if (abl && !p.gate) {
 #define W4_ABL_CASE(a_) if (abl == (a_)) { hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_w4_kernel<false, (a_)>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
                                            hipLaunchKernelGGL((gemm256_w4_kernel<false, (a_)>), dim3(grid), dim3(256), LDS, stream, p, tiles, trace_wg, 0, 0); return 0; }
