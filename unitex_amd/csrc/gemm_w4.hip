@@ -21,6 +21,8 @@
 //     ~30 cycles each beyond their MFMA shadow; one per three MFMAs (below) is worth +3-4 % over one per MFMA;
 //   * the epilogue (8.5k cycles per tile: 256 v_accvgpr_read + fma + pack + LDS transpose) is exposed -- nothing overlaps it with one wave
 //     per SIMD: bias through ONE scalar-load burst, accumulators re-zeroed by 16 MFMAs (0 x 0 + 0), C stores coalesced through LDS.
+//   * the C stores carry the nontemporal hint: one round of tiles writes 4 MB of C per XCD, the size of its L2, and write-allocated C lines evicted the
+//     operand panels the next K-tiles stream (-6 % per K = 3072 tile, -22 % at K = 1024: profiles/r02_gemm_w4_probe_nt.log; W4_STORE_U);
 //   * whole rounds of 256 tiles are the unit of time of a persistent kernel: 636 tiles (the reference strip's N = 3072 linears) are 2.48 rounds and
 //     cost 3.  The last, partly filled round is cut along K instead ("split tail" below, gemm_w4_fixup_kernel): -13 / -14 % on the K = 12288 /
 //     15360 linears of the reference strip, -7 % on BASELINE's strip, -35 % on the pruned last block (profiles/r02_gemm_streamk_check_v4.log).
