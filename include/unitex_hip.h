@@ -118,7 +118,10 @@ typedef struct utx_gemm_desc {
      * in bytes, K a multiple of 128) and a_scale [M][K/32] / b_scale [N][K/32] one E8M0 byte per 32 elements along K (row strides
      * lds_a / lds_b bytes, multiples of 4); element value = e4m3 * 2^(scale - 127).  Accumulation in fp32 by
      * v_mfma_scale_f32_32x32x64_f8f6f4; the LoRA segment (A2 / B2) stays bf16; epilogues unchanged.  Quantise activations with
-     * utx_quant_mx8; weights once at load (unitex_amd/flux/mx8.py).  Replaces the same nn.Linear as the bf16 form. */
+     * utx_quant_mx8; weights once at load (unitex_amd/flux/mx8.py).  Replaces the same nn.Linear as the bf16 form.
+     * mx8 = 2: the same operands with TILE-PACKED scales (utx_quant_mx8_packed; lds_a / lds_b = row blocks of 128 per K-tile slab of a_scale /
+     * b_scale) on the persistent one-wave-per-SIMD kernel: N and every column boundary (n_split, gelu_from) multiples of 256, no LoRA segment
+     * (K2 = 0: merge the adapters into the weight before quantising), no fused q / k epilogue; anything else is refused (-2), never dropped. */
     const void* a_scale; long lds_a;
     const void* b_scale; long lds_b;
     int mx8;
@@ -149,6 +152,12 @@ size_t utx_gemm_streamk_workspace_bytes(utx_ctx* ctx);   /* size of utx_gemm_des
  *   scale byte = e + 127, q = e4m3_rne(clamp(x * 2^-e, -448, 448)).
  * x [M][ldx] bf16 (K % 32 == 0, ldx % 8 == 0) -> q [M][ldq] bytes, s [M][lds] bytes (K/32 per row).  oracle/mx8_ref.py restates it. */
 int utx_quant_mx8(utx_ctx* ctx, const void* x, long ldx, void* q, long ldq, void* s, long lds, int M, int K, utx_stream stream);
+/* The same quantiser (identical q bytes and scale values) with the scales TILE-PACKED for utx_gemm_desc.mx8 == 2 (the one-wave-per-SIMD kernel,
+ * unitex_amd/csrc/gemm_w4.hip): s is an array of dwords [K/128][row_blocks][32][4]; dword [kt][rb][l][im] holds the four E8M0 bytes of the
+ * 32-element blocks 4 kt .. 4 kt + 3 of row 128 rb + 32 im + l (byte j = block 4 kt + j).  row_blocks >= ceil(M / 128); K % 128 == 0; s 16-byte
+ * aligned, K/128 * row_blocks * 512 bytes.  Rows >= M of the last row block are not written.  A lane of the GEMM then fetches the scale dwords of
+ * its four fragment rows for a K-tile with ONE 16-byte load (512 contiguous bytes per wave) instead of four strided dword gathers. */
+int utx_quant_mx8_packed(utx_ctx* ctx, const void* x, long ldx, void* q, long ldq, void* s, long row_blocks, int M, int K, utx_stream stream);
 
 /* y[m,n] = act_out(sum_k act_in(x[m,k]) W[n,k] + b[n]) for M <= 8 (embedders, AdaLN modulation). */
 typedef struct utx_gemv_desc {

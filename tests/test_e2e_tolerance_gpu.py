@@ -1,0 +1,124 @@
+"""The floating-point end of the contract, measured end to end.
+
+Reference loop: /root/reference/flux_piplines/texturing/pipeline.py:633-692 -- K denoise steps (transformer -> flow-match Euler
+step, condition tail re-pinned before every call), cut off the condition tail, unpack, VAE decode, postprocess to uint8.
+
+Product: PBRFluxPipeline.denoise (HIP FluxDiT + fused utx_sched_step) -> HIP AutoencoderKL.decode -> uint8.
+Oracle : oracle/dit_ref.denoise_loop(emulate_bf16=True) (fp32 arithmetic, rounded to bf16 at every tensor boundary of the bf16
+         reference) -> oracle/vae_ref (fp32) -> the same postprocess.
+
+STATED TOLERANCE (asserted below, measured values printed and quoted in DESIGN.md section 3):
+  * latents after K = 4 steps: max |d| <= 0.05 max|latent|, mean |d| <= 0.006 max|latent|
+  * decoded uint8 image: >= 97 % of the pixels within 2 LSB, >= 99.5 % within 4 LSB, no pixel further than 16 LSB
+BASELINE's "1e-3 max-abs" is below half a bf16 ulp at 1.0 (3.9e-3) and cannot be met by ANY bf16 evaluation order that differs from
+the reference's own (the reference itself is not reproducible to 1e-3 across GPU kernels libraries); what can be stated is the
+drift of this implementation's bf16 kernels against an fp32-accumulating restatement with the reference's rounding points.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dit_ref, vae_ref
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+DEV = "cuda:0"
+
+
+def _postprocess_u8(img):
+    x = (img.float() / 2 + 0.5).clamp(0, 1).cpu().permute(0, 2, 3, 1).numpy()
+    return (x * 255).round().astype(np.uint8)
+
+
+def _run_both(cfg, shape, S_txt, zero_text, lat_hw, dual_hw, K, lora_rank, n_threads=None):
+    from unitex_amd.flux.pipeline import PBRFluxPipeline
+    from unitex_amd.flux.synthetic import synthetic_vae_state_dict
+    from unitex_amd.flux.transformer import FluxDiT
+    from unitex_amd.flux.vae_hip import AutoencoderKL
+    hl, wl = lat_hw                              # packed token grid of the noise strip (latent = 2 hl x 2 wl, image = 16 hl x 16 wl)
+    sd = dit_ref.make_synthetic_state_dict(cfg, seed=0)
+    la = dit_ref.make_synthetic_lora(cfg, sd, rank=lora_rank, seed=2)
+    loras = [(la, 1.0)]
+    g = torch.Generator().manual_seed(63)
+    n_noise = hl * wl
+    noise = torch.randn(n_noise, 64, generator=g).to(BF)
+    ids = [dit_ref.latent_image_ids(hl, wl), dit_ref.latent_image_ids(hl, wl, offset_y=hl)]
+    n_cond = hl * wl
+    if dual_hw:
+        ids.append(dit_ref.latent_image_ids(dual_hw[0], dual_hw[1], offset_x=wl, offset_y=hl))
+        n_cond += dual_hw[0] * dual_hw[1]
+    cond = torch.randn(n_cond, 64, generator=g).to(BF)
+    noise_ids, cond_ids = ids[0], torch.cat(ids[1:], 0)
+    if zero_text:       # what the reference feeds (pipeline.py:538-543): the text-token de-duplication path of FluxDiT
+        enc = torch.zeros(S_txt, cfg.joint_dim).to(BF); pooled = torch.zeros(1, cfg.pooled_dim).to(BF)
+    else:
+        enc = (0.5 * torch.randn(S_txt, cfg.joint_dim, generator=g)).to(BF); pooled = (0.5 * torch.randn(1, cfg.pooled_dim, generator=g)).to(BF)
+    txt_ids = torch.zeros(S_txt, 3)
+    vsd = synthetic_vae_state_dict(1)
+    # ---- product
+    tr = FluxDiT(sd, shape, device=DEV)
+    vae = AutoencoderKL(vsd, device=DEV)
+    pipe = PBRFluxPipeline(tr, vae, device=DEV)
+    pipe.load_lora_weights(la, "texture")
+    pipe.set_adapters(["texture"], [1.0])
+    lat = pipe.denoise(noise[None], noise_ids, cond[None], cond_ids, enc.to(DEV)[None], pooled.to(DEV), txt_ids, K, 3.5)
+    H, W = 16 * hl, 16 * wl
+    z = pipe._unpack_latents(lat, H, W, 8)
+    z = (z / vae.scaling_factor) + vae.shift_factor
+    img = vae.decode(z.to(BF))
+    torch.cuda.synchronize()
+    got_lat = lat[0].float().cpu()
+    got_u8 = _postprocess_u8(img)
+    # ---- oracle
+    if n_threads:
+        torch.set_num_threads(n_threads)
+    ref_lat = dit_ref.denoise_loop(sd, cfg, noise.float(), cond.float(), enc.float(), pooled.float(), txt_ids,
+                                   torch.cat([noise_ids, cond_ids], 0), K, guidance=3.5, loras=loras, emulate_bf16=True)
+    rz = dit_ref.unpack_latents(ref_lat[None], H, W, 8)
+    rz = dit_ref._rb(dit_ref._rb(rz / vae_ref.AutoencoderKL.scaling_factor, True) + vae_ref.AutoencoderKL.shift_factor, True)
+    ref_img = vae_ref.AutoencoderKL.from_state_dict(vsd).decode(rz)
+    ref_u8 = _postprocess_u8(ref_img)
+    return got_lat, ref_lat, got_u8, ref_u8
+
+
+def _report(tag, got_lat, ref_lat, got_u8, ref_u8):
+    mx = ref_lat.abs().max().item()
+    d = (got_lat - ref_lat).abs()
+    du = np.abs(got_u8.astype(np.int32) - ref_u8.astype(np.int32))
+    hist = {k: float((du <= k).mean()) for k in (0, 1, 2, 4, 8)}
+    # a decoded image that is constant (saturated) would make the uint8 comparison vacuous
+    spread = float(ref_u8.std())
+    print("\n[e2e tolerance] %s: latents max|d| %.4g = %.4g of max|lat| %.3g, mean|d| %.4g = %.4g of max; uint8: ==0 %.4f, <=1 %.4f, <=2 %.4f, "
+          "<=4 %.4f, <=8 %.4f, max %d LSB (image std %.1f LSB)" % (tag, d.max().item(), d.max().item() / mx, mx, d.mean().item(), d.mean().item() / mx,
+                                                                   hist[0], hist[1], hist[2], hist[4], hist[8], int(du.max()), spread))
+    return mx, d, du, hist, spread
+
+
+@pytest.mark.parametrize("zero_text", [True, False])
+def test_k_step_denoise_and_vae_decode_tiny_full_depth_pattern(zero_text):
+    """2 double + 4 single blocks (the depth pattern: double blocks feeding single blocks, both more than once), 2 heads, rank-16 LoRA, 4 real
+    steps with re-pin, 128 x 384 strip + control + 64 x 64 dual; zero text embeddings (128 tokens: the de-duplicated path) and random ones."""
+    from unitex_amd.flux.transformer import FluxShape
+    cfg = dit_ref.tiny_config(heads=2, double=2, single=4, joint_dim=64, pooled_dim=64)
+    shape = FluxShape(num_heads=2, num_double=2, num_single=4, joint_dim=64, pooled_dim=64)
+    got_lat, ref_lat, got_u8, ref_u8 = _run_both(cfg, shape, 128 if zero_text else 64, zero_text, (8, 24), (4, 4), 4, 16)
+    mx, d, du, hist, spread = _report("tiny 2+4 blocks, %s text" % ("zero" if zero_text else "random"), got_lat, ref_lat, got_u8, ref_u8)
+    assert torch.isfinite(got_lat).all() and spread > 4.0
+    assert d.max().item() <= 0.05 * mx and d.mean().item() <= 0.006 * mx
+    assert hist[2] >= 0.97 and hist[4] >= 0.995 and du.max() <= 16
+
+
+def test_k_step_denoise_and_vae_decode_full_width_at_config1_shape():
+    """BASELINE configs[0] shape at the real FLUX width: D = 3072, 24 heads, rank-64 LoRA, 512 zero text tokens, 512 x 2048 strip (4096 noise
+    tokens) + control + 512^2 dual = 9728 joint tokens; depth cut to 1 + 1 blocks so the fp32 oracle does the 4 steps in about two minutes."""
+    from unitex_amd.flux.transformer import FluxShape
+    cfg = dit_ref.FluxConfig(num_double=1, num_single=1)
+    shape = FluxShape(num_double=1, num_single=1)
+    nt = max(1, min(len(os.sched_getaffinity(0)), 64))
+    got_lat, ref_lat, got_u8, ref_u8 = _run_both(cfg, shape, 512, True, (32, 128), (32, 32), 4, 64, n_threads=nt)
+    mx, d, du, hist, spread = _report("full width 1+1 blocks, S = 9728", got_lat, ref_lat, got_u8, ref_u8)
+    assert torch.isfinite(got_lat).all() and spread > 4.0
+    assert d.max().item() <= 0.05 * mx and d.mean().item() <= 0.006 * mx
+    assert hist[2] >= 0.97 and hist[4] >= 0.995 and du.max() <= 16

@@ -121,3 +121,155 @@ def test_fp8_path_tolerance_against_bf16_path():
     assert (outs[False] - ref).abs().max().item() < 0.03 * mx
     d = (outs[True] - ref).abs().max().item()
     assert 1e-4 * mx < d < 0.15 * mx, "fp8-weight DiT vs bf16 oracle: %g of max|out| %g" % (d, mx)
+
+
+def test_fp8_full_width_blocks_at_config5_per_view_shape():
+    """BASELINE configs[4]: 2048^2 per view -> 16 384 noise + 16 384 control + 1024 dual + 512 text = 34 304 joint tokens, real FLUX width
+    (D = 3072, 24 heads, rank-64 LoRA), the five big linears of every block on MX fp8 operands; depth cut to 1 + 1 blocks.
+    The fp32 oracle needs minutes at this size, so the chain is: bf16 HIP path vs oracle at full width (tests/test_fullsize_gpu.py, S = 9728,
+    3e-2 max|out|) + fp8 HIP path vs bf16 HIP path HERE, with the bound derived from the measured error of ONE fp8 linear on this data:
+    a block output passes through at most 5 fp8 linears whose relative errors e_lin add in quadrature at unit gain -> relative Frobenius
+    error of the forward <= 4 e_lin (sqrt(5) = 2.2 with a factor ~2 for the gains of the gates / the LayerNorm), and max |d| <= 0.15 max|out|
+    (the stated fp8 tolerance of test_fp8_path_tolerance_against_bf16_path)."""
+    from unitex_amd.flux import mx8
+    from unitex_amd.flux.transformer import FluxDiT, FluxShape
+    ops = _ops()
+    ctx = ops.get_ctx(0)
+    cfg = dit_ref.FluxConfig(num_double=1, num_single=1)
+    sd = dit_ref.make_synthetic_state_dict(cfg, seed=0)
+    shape = FluxShape(num_double=1, num_single=1)
+    S_txt = 512
+    img_ids = torch.cat([dit_ref.latent_image_ids(128, 128), dit_ref.latent_image_ids(128, 128, offset_y=128),
+                         dit_ref.latent_image_ids(32, 32, offset_x=128, offset_y=128)], 0)
+    S_img = img_ids.shape[0]
+    assert S_txt + S_img == 34304
+    g = torch.Generator().manual_seed(5)
+    lat = torch.randn(S_img, 64, generator=g).to(BF)
+    enc = torch.zeros(S_txt, cfg.joint_dim).to(BF); pooled = torch.zeros(1, cfg.pooled_dim).to(BF)
+    txt_ids = torch.zeros(S_txt, 3)
+    la = dit_ref.make_synthetic_lora(cfg, sd, rank=64, seed=2)
+    outs, census = {}, {}
+    for fp8 in (False, True):
+        m = FluxDiT(sd, shape, device="cuda:0", fp8_weights=fp8)
+        m.set_lora([(la, 1.0)])
+        m.set_positions(txt_ids, img_ids)
+        m.set_conditioning(enc.cuda(), pooled.cuda(), 3.5)
+        outs[fp8] = m.forward(lat.cuda(), 0.4375).float()
+        torch.cuda.synchronize()
+        census[fp8] = m.gemm_census()
+        if fp8:
+            # e_lin on the live activation of the first fp8 linear (LayerNorm-modulated hidden states x the QKV weight of the double block)
+            ws = next(iter(m._plans.values()))["ws"]
+            A = ws["xn"][S_txt:].clone(); W = m.double[0]["qkv_x.w"]
+            ref = ops.gemm(A, W).float()
+            aq, a_s = mx8.quantize_act(A, ctx); wq, w_s = mx8.quantize_weight(W, ctx)
+            e_lin = ((ops.gemm(aq, wq, a_scale=a_s, b_scale=w_s).float() - ref).norm() / ref.norm()).item()
+        del m
+        torch.cuda.empty_cache()
+    assert torch.isfinite(outs[True]).all()
+    mxo = max(outs[False].abs().max().item(), 1.0)
+    d = outs[True] - outs[False]
+    rel_f = (d.norm() / outs[False].norm()).item()
+    print("\n[fp8 full width, S = 34304] e_lin %.4f | forward fp8 vs bf16: rel Frobenius %.4f (bound 4 e_lin = %.4f), max|d| %.4g = %.4f of max|out| %.3g, "
+          "mean|d| %.4g | GEMM kernels bf16 %s fp8 %s" % (e_lin, rel_f, 4 * e_lin, d.abs().max().item(), d.abs().max().item() / mxo, mxo,
+                                                         d.abs().mean().item(), census[False], census[True]))
+    assert 0.005 < e_lin < 0.06
+    assert rel_f < 4 * e_lin, "fp8 forward vs bf16 forward: relative Frobenius error %g against 4 e_lin = %g" % (rel_f, 4 * e_lin)
+    assert 1e-4 * mxo < d.abs().max().item() < 0.15 * mxo
+
+
+def test_mx8_packed_scale_quantiser_matches_the_rowmajor_one():
+    """utx_quant_mx8_packed: the same q bytes and the same E8M0 values as utx_quant_mx8 (= oracle/mx8_ref.quantize, bit for bit), scale bytes in
+    the tile-packed order [K/128][row block][32][4] x 4 bytes; ragged row count (the last row block partly filled), strided rows, a scratch
+    buffer larger than the matrix in both directions."""
+    from unitex_amd.flux import mx8
+    ops = _ops()
+    ctx = ops.get_ctx(0)
+    g = torch.Generator().manual_seed(1)
+    for M, K in ((300, 1024), (256, 128), (1000, 3072)):
+        x = (torch.randn(M, K, generator=g) * torch.exp(3 * torch.randn(M, 1, generator=g))).to(BF)
+        x[0, :64] = 0
+        q_ref, s_ref = mx8_ref.quantize(x)
+        q, sp = mx8.quantize_act(x.cuda(), ctx, packed=True)
+        torch.cuda.synchronize()
+        assert torch.equal(q.cpu(), q_ref)
+        assert torch.equal(sp.rowmajor().cpu(), s_ref), "packed scales, M=%d K=%d" % (M, K)
+        big = torch.zeros(M, K + 512, dtype=BF); big[:, 256:256 + K] = x
+        buf = mx8.PackedScales(mx8.packed_scale_buffer(M + 700, K + 256, "cuda"), M, K)
+        q2 = torch.empty(M + 5, K + 128, dtype=torch.uint8, device="cuda")
+        mx8.quantize_act(big.cuda()[:, 256:256 + K], ctx, out=(q2[:M, :K], buf))
+        assert torch.equal(q2[:M, :K].cpu(), q_ref) and torch.equal(buf.rowmajor().cpu(), s_ref)
+
+
+@pytest.mark.parametrize("M,N,K", [(1100, 512, 512), (4096, 3072, 3072), (13376, 3072, 3072), (6400, 9216, 1024), (2048, 256, 128)])
+def test_mx8_one_wave_per_simd_kernel_bit_identical_to_the_tiled_mx_kernel_and_exact_on_sampled_rows(M, N, K):
+    """utx_gemm_desc.mx8 = 2 (gemm_w4.hip, MX): 256 x 256 persistent tiles, 32 scaled MFMAs per 128-k K-tile, tile-packed scales.  Both MX kernels
+    accumulate every output element over ascending K with the same instruction -> BIT-IDENTICAL results on every epilogue (bias + GELU + column
+    split; gated residual), ragged M included; sampled rows against the exact MX dot products (oracle/mx8_ref.py).  With the split tail round
+    (13376 x 3072 = 636 tiles = 2.48 rounds) the tail tiles differ by fp32 summation order only."""
+    from unitex_amd import _lib
+    from unitex_amd.flux import mx8
+    ops = _ops()
+    ctx = ops.get_ctx(0)
+    g = torch.Generator().manual_seed(M + N + K)
+    A = (torch.randn(M, K, generator=g) * 0.7).to(BF).cuda()
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(BF).cuda()
+    bias = torch.randn(N, generator=g).to(BF).cuda()
+    gate = torch.randn(N, generator=g).to(BF).cuda()
+    res = torch.randn(M, N, generator=g).to(BF).cuda()
+    aq, a_s = mx8.quantize_act(A, ctx); wq, w_s = mx8.quantize_weight(W, ctx)
+    _, a_p = mx8.quantize_act(A, ctx, packed=True); _, w_p = mx8.quantize_weight(W, ctx, packed=True)
+    split = N // 2 if (N // 2) % 256 == 0 else N
+    outs = {}
+    _lib.set_option("UTX_GEMM_STREAMK", 0)
+    try:
+        for tag, sa, sb in (("tiled", a_s, w_s), ("w4", a_p, w_p)):
+            c0 = torch.zeros(M, split, dtype=BF, device="cuda"); c1 = torch.zeros(M, max(N - split, 1), dtype=BF, device="cuda")
+            kw = dict(a_scale=sa, b_scale=sb)
+            if split < N:
+                ops.gemm(aq, wq, bias=bias, out=c0, gelu_from=split, n_split=split, C1=c1, **kw)
+            else:
+                ops.gemm(aq, wq, bias=bias, out=c0, **kw)
+            r = res.clone()
+            ops.gemm(aq, wq, bias=bias, out=r, gate=gate, res=r, **kw)
+            torch.cuda.synchronize()
+            outs[tag] = (c0, c1, r)
+    finally:
+        _lib.set_option("UTX_GEMM_STREAMK", 1)
+    for i, nm in enumerate(("bias / GELU / split: C", "C1", "gated residual")):
+        a, b = outs["tiled"][i], outs["w4"][i]
+        assert torch.equal(a, b), "%s: one-wave-per-SIMD MX kernel differs from the tiled MX kernel: max |d| %g in %d elements" % (
+            nm, (a.float() - b.float()).abs().max().item(), (a != b).sum().item())
+    # the default launch (split tail round where the model splits): same up to fp32 summation order in the tail tiles
+    r2 = res.clone()
+    ops.gemm(aq, wq, bias=bias, out=r2, gate=gate, res=r2, a_scale=a_p, b_scale=w_p)
+    torch.cuda.synchronize()
+    dd = (r2.float() - outs["w4"][2].float()).abs()
+    assert (dd / outs["w4"][2].float().abs().clamp_min(1.0)).max().item() <= 3.2e-2 and (dd > 0).float().mean().item() < 0.02
+    # sampled rows vs the exact MX dot products
+    rows = torch.randperm(M, generator=g)[:96].sort().values
+    acc = mx8_ref.gemm(aq.cpu()[rows], a_s.cpu()[rows], wq.cpu(), w_s.cpu())
+    y = (acc + bias.float().cpu()).to(BF).float()
+    if split < N:
+        y[:, split:] = dit_ref.gelu_tanh(y[:, split:]).to(BF).float()
+        got = torch.cat([outs["w4"][0], outs["w4"][1]], 1).float().cpu()[rows]
+    else:
+        got = outs["w4"][0].float().cpu()[rows]
+    rel = ((got - y).abs() / y.abs().clamp_min(1.0)).max().item()
+    assert rel < 1.6e-2, "MX one-wave-per-SIMD GEMM vs exact MX reference: %g" % rel
+
+
+def test_mx8_packed_form_refuses_what_it_cannot_do():
+    """mx8 = 2 has no LoRA K-segment and no 128-column boundaries: the library refuses (-2 -> exception) instead of dropping them."""
+    from unitex_amd.flux import mx8
+    ops = _ops()
+    ctx = ops.get_ctx(0)
+    A = torch.randn(512, 256).to(BF).cuda(); W = torch.randn(512, 256).to(BF).cuda()
+    aq, a_p = mx8.quantize_act(A, ctx, packed=True); wq, w_p = mx8.quantize_weight(W, ctx, packed=True)
+    T = torch.randn(512, 64).to(BF).cuda(); Bl = torch.randn(512, 64).to(BF).cuda()
+    with pytest.raises(Exception):
+        ops.gemm(aq, wq, a_scale=a_p, b_scale=w_p, A2=T, B2=Bl)
+    with pytest.raises(Exception):
+        c1 = torch.empty(512, 384, dtype=BF, device="cuda")
+        ops.gemm(aq, wq, out=torch.empty(512, 128, dtype=BF, device="cuda"), a_scale=a_p, b_scale=w_p, n_split=128, C1=c1)
+    torch.cuda.synchronize()

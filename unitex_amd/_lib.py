@@ -89,6 +89,7 @@ SYMBOLS = {
     "utx_gemm_streamk_workspace_bytes": (C.c_size_t, [c_void_p]),
     "utx_gemm_plan": (c_int, [C.POINTER(GemmDesc), c_int, C.POINTER(c_int * 4)]),
     "utx_quant_mx8": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_void_p]),
+    "utx_quant_mx8_packed": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_void_p]),
     "utx_gemv_bf16": (c_int, [c_void_p, C.POINTER(GemvDesc), c_void_p]),
     "utx_group_norm_workspace_bytes": (c_long, []),
     "utx_group_norm": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p]),

@@ -148,6 +148,11 @@ int utx_quant_mx8(utx_ctx* ctx, const void* x, long ldx, void* q, long ldq, void
     UTX_CALL(ctx, "utx_quant_mx8", utx_launch_quant_mx8(x, ldx, q, ldq, sc, lds, M, K, (hipStream_t)stream));
 }
 
+int utx_quant_mx8_packed(utx_ctx* ctx, const void* x, long ldx, void* q, long ldq, void* sc, long row_blocks, int M, int K, utx_stream stream) {
+    if (!x || !q || !sc) return fail(ctx, -2, "utx_quant_mx8_packed");
+    UTX_CALL(ctx, "utx_quant_mx8_packed", utx_launch_quant_mx8_packed(x, ldx, q, ldq, sc, row_blocks, M, K, (hipStream_t)stream));
+}
+
 int utx_gemv_bf16(utx_ctx* ctx, const utx_gemv_desc* d, utx_stream stream) {
     if (!d || !d->x || !d->W || !d->y) return fail(ctx, -2, "utx_gemv_bf16");
     UTX_CALL(ctx, "utx_gemv_bf16", utx_launch_gemv_bf16(d, (hipStream_t)stream));

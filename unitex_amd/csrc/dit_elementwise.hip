@@ -123,10 +123,15 @@ extern "C" int utx_launch_qkv_post(const QkvPostParams* hp, hipStream_t stream) 
 // elements: 64 B read (4 x 16 B), 32 B + 1 scale byte written.  HBM-bound: 3.03 B per element.
 //   e = floor(log2(amax)) - 8  (exponent field of amax: bf16 inputs are exact in fp32), clamp [-127, 127]; amax == 0 -> -127
 //   q = e4m3_rne(clamp(x * 2^-e, -448, 448))            (v_cvt_pk_fp8_f32: OCP e4m3fn on gfx950)
+// PACKED (utx_quant_mx8_packed): the scale bytes in the tile-packed order the one-wave-per-SIMD GEMM reads (gemm_w4.hip, MX): dword
+// [K-tile kt = blk / 4][row block rb = row / 128][l = row % 32][im = (row % 128) / 32] holds the four scale bytes blk % 4 = 0..3 of the K-tile; the four
+// threads of a K-tile (consecutive lanes: nblk % 4 == 0) assemble the dword with two DPP-class shuffles and lane 0 of them stores it.  lds = row blocks
+// per K-tile slab.  Same bytes, same q: only the scale addressing differs.
+template <bool PACKED>
 __global__ __launch_bounds__(256) void quant_mx8_kernel(const bf16_t* __restrict__ x, long ldx, uint8_t* __restrict__ q, long ldq,
                                                         uint8_t* __restrict__ sc, long lds, int M, int nblk) {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (long)M * nblk) return;
+    if (t >= (long)M * nblk) return;      // PACKED: M * nblk is a multiple of 4, so the four lanes of a K-tile leave together
     const int row = (int)(t / nblk), blk = (int)(t - (long)row * nblk);
     const bf16_t* src = x + (long)row * ldx + blk * 32;
     float v[32];
@@ -159,14 +164,28 @@ __global__ __launch_bounds__(256) void quant_mx8_kernel(const bf16_t* __restrict
     uint4* dst = reinterpret_cast<uint4*>(q + (long)row * ldq + blk * 32);
     dst[0] = make_uint4(out[0], out[1], out[2], out[3]);
     dst[1] = make_uint4(out[4], out[5], out[6], out[7]);
-    sc[(long)row * lds + blk] = (uint8_t)(e + 127);
+    if constexpr (PACKED) {
+        uint32_t w = (uint32_t)(e + 127) << (8 * (blk & 3));
+        w |= (uint32_t)__shfl_xor((int)w, 1, 64);
+        w |= (uint32_t)__shfl_xor((int)w, 2, 64);
+        if ((blk & 3) == 0)
+            reinterpret_cast<uint32_t*>(sc)[(((long)(blk >> 2) * lds + (row >> 7)) * 32 + (row & 31)) * 4 + ((row >> 5) & 3)] = w;
+    } else sc[(long)row * lds + blk] = (uint8_t)(e + 127);
 }
 
 extern "C" int utx_launch_quant_mx8(const void* x, long ldx, void* q, long ldq, void* s, long lds, int M, int K, hipStream_t stream) {
     if (M <= 0 || K <= 0 || (K & 31) || (ldx & 7) || (ldq & 15) || lds < K / 32) return -2;
     const long total = (long)M * (K / 32);
-    hipLaunchKernelGGL(quant_mx8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)x, ldx, (uint8_t*)q, ldq,
+    hipLaunchKernelGGL(quant_mx8_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)x, ldx, (uint8_t*)q, ldq,
                        (uint8_t*)s, lds, M, K / 32);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+extern "C" int utx_launch_quant_mx8_packed(const void* x, long ldx, void* q, long ldq, void* s, long row_blocks, int M, int K, hipStream_t stream) {
+    if (M <= 0 || K <= 0 || (K & 127) || (ldx & 7) || (ldq & 15) || row_blocks < (M + 127) / 128 || ((uintptr_t)s & 15)) return -2;
+    const long total = (long)M * (K / 32);
+    hipLaunchKernelGGL(quant_mx8_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)x, ldx, (uint8_t*)q, ldq,
+                       (uint8_t*)s, row_blocks, M, K / 32);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 

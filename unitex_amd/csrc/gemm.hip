@@ -791,7 +791,14 @@ extern "C" void utx_gemm_plan_impl(const GemmParams* pp, int ncu, int sk_has_wor
     const GemmParams& p = *pp;
     const int dbg_env = g_utx_opt.gemm_debug_abl, tile_env = g_utx_opt.gemm_tile;
     out[0] = 0; out[1] = ((p.M + 127) / 128) * ((p.N + 127) / 128); out[2] = 0; out[3] = 0;
-    if (p.conv_Wo > 0 || p.mx8) return;
+    if (p.conv_Wo > 0 || p.mx8 == 1) return;
+    if (p.mx8 == 2) {     // MX fp8 with tile-packed scales: the one-wave-per-SIMD kernel only (gemm_w4.hip, MX); the launcher refuses other shapes
+        out[0] = 1; out[1] = ((p.M + 255) / 256) * (p.N / 256);
+        int grid = out[1] < ncu ? out[1] : ncu;
+        if (g_utx_opt.gemm_pers_grid > 0 && g_utx_opt.gemm_pers_grid < grid) grid = g_utx_opt.gemm_pers_grid;
+        utx_gemm_w4_split_plan(&p, out[1], grid, sk_has_work, &out[2], &out[3]);
+        return;
+    }
     // 256^2 tiles need every column boundary on a 256 multiple and enough tiles to fill the chip
     const bool ok256 = (p.N % 256 == 0) && (p.n_split >= p.N || p.n_split % 256 == 0) &&
                        (p.gelu_from >= p.N || p.gelu_from % 256 == 0) &&
@@ -821,8 +828,8 @@ extern "C" int utx_launch_gemm_bf16(const GemmParams* hp, hipStream_t stream) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return -1;
     if (p.mx8) {
         // MX fp8 base segment: K counts fp8 elements (multiple of 128 = one K-tile), lda / ldb are bytes; scales [rows][K/32] bytes
-        if (!p.a_scale || !p.b_scale || (p.K % 128) || (p.lda & 15) || (p.ldb & 15) || (p.lds_a & 3) || (p.lds_b & 3) || p.conv_Wo > 0) return -2;
-        if (p.lds_a < p.K / 32 || p.lds_b < p.K / 32) return -2;
+        if (!p.a_scale || !p.b_scale || (p.K % 128) || (p.lda & 15) || (p.ldb & 15) || p.conv_Wo > 0 || p.mx8 > 2) return -2;
+        if (p.mx8 == 1 && ((p.lds_a & 3) || (p.lds_b & 3) || p.lds_a < p.K / 32 || p.lds_b < p.K / 32)) return -2;
         p.K /= 2; p.lda /= 2; p.ldb /= 2;          // bf16 units: the staging code is byte-identical
     }
     if ((p.K % GM_BK) || (p.K2 % GM_BK) || (p.N % 8)) return -2;
@@ -831,18 +838,27 @@ extern "C" int utx_launch_gemm_bf16(const GemmParams* hp, hipStream_t stream) {
     if (p.gate && (!p.res || (p.ldres & 7))) return -2;
     if (p.n_split < p.N && (!p.C1 || (p.n_split % 128) || (p.ldc1 & 7))) return -2;
     const int group_env = g_utx_opt.gemm_group_m, dbg_env = g_utx_opt.gemm_debug_abl, tile_env = g_utx_opt.gemm_tile;
+    // fused q / k post-processing exists only in the bf16 one-wave-per-SIMD kernel: refuse every other form here, in front of the early returns of
+    // the convolution / MX forms, instead of silently dropping it
+    if (p.qk_cols > 0 && (p.mx8 || p.conv_Wo > 0 || p.gate)) return -2;
     if (p.conv_Wo > 0) {   // implicit 3x3 convolution: 128^2 kernel, A rows gathered per tap
         if (p.K2 > 0 || !p.zero_page || p.conv_cin_log2 < 6 || p.K != (9 << p.conv_cin_log2) || p.conv_Hi <= 0 || p.conv_Wi <= 0 ||
             p.conv_stride < 1 || p.conv_stride > 2 || p.conv_pad < 0 || p.conv_pad > 1 || (p.conv_up & ~1) || (p.M % p.conv_Wo))
             return -2;
         return launch_gemm<128, 128, 2, 2, true>(p, stream, 0, 0);
     }
+    if (p.mx8 == 2) {
+        // tile-packed scales: 256 x 256 tiles only (every column boundary on a 256 multiple), no LoRA segment (merge the adapters into the weights
+        // before quantising: unitex_amd/flux/transformer.py), no fused q / k epilogue
+        if ((p.N % 256) || (p.n_split < p.N && p.n_split % 256) || (p.gelu_from < p.N && p.gelu_from % 256) || p.K2 > 0 || p.qk_cols > 0) return -2;
+        return utx_launch_gemm_w4(p, stream);
+    }
     if (p.mx8) return launch_gemm<128, 128, 2, 2, false, true>(p, stream, group_env, 0);
     int plan[4];
     utx_gemm_plan_impl(&p, 256, 1, plan);      // the kernel choice does not depend on the CU count (only the split of the last round does)
     if (p.qk_cols > 0) {
         // fused q / k post-processing: only the one-wave-per-SIMD kernel has it (a wave owns a whole head there); refuse instead of dropping it
-        if (p.mx8 || p.conv_Wo > 0 || p.gate || (p.qk_cols % 256) || p.qk_cols > p.N || p.qk_cols > p.n_split || p.qk_cols > p.gelu_from ||
+        if ((p.qk_cols % 256) || p.qk_cols > p.N || p.qk_cols > p.n_split || p.qk_cols > p.gelu_from ||
             !p.qk_wq || !p.qk_wk || !p.qk_cos || !p.qk_sin || !p.qk_Qh || !p.qk_Kh || p.qk_hs <= 0 || p.qk_tok_off < 0) return -2;
         if (plan[0] != 1) return -2;
     }

@@ -80,7 +80,9 @@ __device__ __forceinline__ const char* w4_uniform(const char* p) {
 // ABL (ablation build only, wrong results): 1 = no DMA in the loop, 2 = no fragment reads in the loop, 4 = no vmcnt wait / barrier, 8 = no epilogue,
 // 16 = epilogue without its C stores, 32 = the DMA cursor parked from the start (every DMA re-reads the same bytes)
 // QKF: the fused q / k post-processing of utx_gemm_desc.qk_cols (plain kernel only)
-template <bool GATED, int ABL = 0, bool QKF = false>
+// MX: OCP MX fp8 operands with tile-packed E8M0 scales (utx_gemm_desc.mx8 == 2; "MX fp8" below): same staging, ring and epilogues, a K-tile is
+// 128 fp8 = the same 128-byte rows, 32 v_mfma_scale_f32_32x32x64_f8f6f4 per K-tile instead of 64 v_mfma_f32_32x32x16_bf16
+template <bool GATED, int ABL = 0, bool QKF = false, bool MX = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm256_w4_kernel(GemmParams p, int ntiles, int trace_wg, int sk_T, int sk_S) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -158,6 +160,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     int s_l2 = 0;       // K-tiles of the LoRA segment that follow the base segment of the cursor's tile (0: none)
     int s_tj = -1;      // W4_NEXT_SEG
     const char *s_pA = nullptr, *s_pB = nullptr;
+    // MX fp8: the E8M0 scales of the cursor's K-tile, tile-packed [K/128][row blocks of 128][l31 = 32][im = 4] dwords (4 scale bytes = the four
+    // 32-element blocks of the K-tile of row 128 rb + 32 im + l31): ONE 16-byte load per lane, operand and K-tile gives a lane the scale dwords of its
+    // four fragment rows (512 contiguous bytes per wave; lanes 32-63 fetch the same bytes as lanes 0-31).  p.lds_a / p.lds_b = row blocks per K-tile slab.
+    const char *s_pSA = nullptr, *s_pSB = nullptr;
+    unsigned s_sstA = 0, s_sstB = 0;
     unsigned voA0 = 0, voA1 = 0, voA2 = 0, voA3 = 0, voA4 = 0, voA5 = 0, voA6 = 0, voA7 = 0;
     unsigned voB0 = 0, voB1 = 0, voB2 = 0, voB3 = 0, voB4 = 0, voB5 = 0, voB6 = 0, voB7 = 0;
 #define W4_ROWOFF_A(d_, stride_) ((unsigned)(((s_m0 + 8 * (wave + 4 * (d_)) + drow > p.M - 1) ? p.M - 1 - s_m0 : 8 * (wave + 4 * (d_)) + drow)) * (stride_) + dchunk)
@@ -185,6 +192,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const char* const b_ = in2_ ? (const char*)p.B2 : (const char*)p.B;                                \
         s_pA = w4_uniform(a_ + (long)s_m0 * sa_ + (long)kk2_ * 128);                                       \
         s_pB = w4_uniform(b_ + (long)s_n0 * sb_ + (long)kk2_ * 128);                                       \
+        if constexpr (MX) {                                                                                \
+            const int rba_ = ((s_m0 >> 7) + wm < (int)p.lds_a) ? (s_m0 >> 7) + wm : (int)p.lds_a - 1;     /* a wave half beyond M: any block (rows never stored) */ \
+            const int rbb_ = (s_n0 >> 7) + wn;                                                             \
+            s_sstA = (park_) ? 0u : (unsigned)p.lds_a * 512u; s_sstB = (park_) ? 0u : (unsigned)p.lds_b * 512u; \
+            s_pSA = w4_uniform((const char*)p.a_scale + ((long)kk2_ * p.lds_a + rba_) * 512);              \
+            s_pSB = w4_uniform((const char*)p.b_scale + ((long)kk2_ * p.lds_b + rbb_) * 512);              \
+        }                                                                                                  \
         W4_SET_OFFS(sa_, sb_);                                                                             \
         s_ss = kk2_; s_seg = in2_ ? 2 : 1;                                                                 \
         s_seg_end = (park_) ? 0x7fffffff : in2_ ? k1r_ - nss1 : (k1r_ < nss1 ? k1r_ : nss1);               \
@@ -200,6 +214,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define W4_STAGE_ADVANCE()                                                                 \
     do {                                                                                   \
         s_pA += 128; s_pB += 128;                                                          \
+        if constexpr (MX) { s_pSA += s_sstA; s_pSB += s_sstB; }                            \
         s_slot ^= 1;                                                                       \
         ++s_ss;                                                                            \
         if (s_ss == s_seg_end) {                                                           \
@@ -239,6 +254,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
     f32x16 acc[4][4];   // [jn][im], swapped MFMA: rows = n, cols = m
     typedef __attribute__((ext_vector_type(4))) float w4_f32x4;
+    typedef __attribute__((ext_vector_type(4))) unsigned int w4_u32x4s;
     w4_f32x4 acc4[4][4][2];   // ABL 64 only (timing experiment, wrong results): every 32x32x16 MFMA replaced by two 16x16x32 on the same operands
     // every use of the accumulators is an "a"-constrained asm operand (MFMA, zeroing, the epilogue's reads): the register class of the
     // tile is then AGPR by construction and the allocator has nothing to split
@@ -288,6 +304,55 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             asm volatile("s_mov_b32 m0, %4\n\tv_mfma_f32_16x16x32_bf16 %0, %2, %3, %0\n\tv_mfma_f32_16x16x32_bf16 %1, %3, %2, %1" \
                          : "+a"(acc4[jn_][im_][0]), "+a"(acc4[jn_][im_][1]) : "v"(FB_[jn_]), "v"(FA_[im_]), "s"(m0_)); \
         else asm volatile("s_mov_b32 m0, %3\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[jn_][im_]) : "v"(FB_[jn_]), "v"(FA_[im_]), "s"(m0_)); \
+    } while (0)
+    // ---- MX fp8 (MX): fragments of 32 bytes per lane and MFMA -- lane (row, h) holds k = 16h .. 16h+15 of the MFMA's first 32-element scale block
+    // in bytes 0-15 and k = 32 + 16h .. of its second block in bytes 16-31 (tools/mx_probe.hip), i.e. chunks 4 ks + h and 4 ks + 2 + h of the
+    // 128-byte row for K-step ks = 0, 1: the same four swizzled chunk offsets xk0..xk3 as the bf16 form, two ds_read_b128 per fragment.  Block 0's scale
+    // is taken from lane `row`, block 1's from lane `row + 32`, byte op_sel of the scale register: the lane's dword of four scale bytes is
+    // pre-shifted by 8 h, K-step ks reads byte 2 ks (op_sel_hi, the instruction's second op_sel bit).
+    typedef __attribute__((ext_vector_type(8))) int w4_i32x8;
+    typedef __attribute__((ext_vector_type(4))) int w4_i32x4;
+    w4_i32x8 xa0[4], xb0[4], xa1[4], xb1[4];
+    w4_u32x4s sa_cur = {0u, 0u, 0u, 0u}, sb_cur = {0u, 0u, 0u, 0u}, sa_nxt = {0u, 0u, 0u, 0u}, sb_nxt = {0u, 0u, 0u, 0u};
+    const unsigned svo = (unsigned)l31 * 16u;
+    const unsigned lds_w = lds0 + (unsigned)wave * 1024u;
+#define W4_LD4(off_) (*reinterpret_cast<const w4_i32x4*>(smem + (off_)))
+    // read number r_ (0..15) of an MX K-step: fragment r_ / 2 in the order B0 A0 A1 B1 A2 A3 B2 B3, low half then high half
+#define W4_XREAD(r_, FA_, FB_, base_, xlo_, xhi_)                                                          \
+    do {                                                                                                   \
+        constexpr int f_ = (r_) >> 1;                                                                      \
+        const int xo_ = ((r_) & 1) ? (xhi_) : (xlo_);                                                      \
+        constexpr int isb_ = (f_ == 0 || f_ == 3 || f_ == 6 || f_ == 7) ? 1 : 0;                           \
+        constexpr int ix_ = f_ == 0 ? 0 : f_ == 1 ? 0 : f_ == 2 ? 1 : f_ == 3 ? 1 : f_ == 4 ? 2 : f_ == 5 ? 3 : f_ == 6 ? 2 : 3; \
+        if constexpr (isb_) { if constexpr (((r_) & 1) == 0) FB_[ix_].lo = W4_LD4((base_) + brow + ix_ * 4096 + xo_); else FB_[ix_].hi = W4_LD4((base_) + brow + ix_ * 4096 + xo_); } \
+        else                { if constexpr (((r_) & 1) == 0) FA_[ix_].lo = W4_LD4((base_) + arow + ix_ * 4096 + xo_); else FA_[ix_].hi = W4_LD4((base_) + arow + ix_ * 4096 + xo_); } \
+    } while (0)
+    // MFMA number i_ (0..15) of MX K-step ks_ (literal 0 / 1): scale byte 2 ks_
+#define W4_XMF(i_, ks_, FA_, FB_)                                                                          \
+    do {                                                                                                   \
+        constexpr int jn_ = ((i_) >> 2), im_ = ((i_) & 3);                                                 \
+        if constexpr ((ks_) == 0) asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]"   \
+                                               : "+a"(acc[jn_][im_]) : "v"(FB_[jn_]), "v"(FA_[im_]), "v"(sb_cur[jn_]), "v"(sa_cur[im_])); \
+        else asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[1,1,0]"      \
+                          : "+a"(acc[jn_][im_]) : "v"(FB_[jn_]), "v"(FA_[im_]), "v"(sb_cur[jn_]), "v"(sa_cur[im_])); \
+    } while (0)
+#define W4_XMF_M0(i_, ks_, FA_, FB_, m0_)                                                                  \
+    do {                                                                                                   \
+        constexpr int jn_ = ((i_) >> 2), im_ = ((i_) & 3);                                                 \
+        if constexpr ((ks_) == 0) asm volatile("s_mov_b32 m0, %5\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" \
+                                               : "+a"(acc[jn_][im_]) : "v"(FB_[jn_]), "v"(FA_[im_]), "v"(sb_cur[jn_]), "v"(sa_cur[im_]), "s"(m0_)); \
+        else asm volatile("s_mov_b32 m0, %5\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[1,1,0]" \
+                          : "+a"(acc[jn_][im_]) : "v"(FB_[jn_]), "v"(FA_[im_]), "v"(sb_cur[jn_]), "v"(sa_cur[im_]), "s"(m0_)); \
+    } while (0)
+    // the scale dwords of the staging cursor's K-tile (a load hipcc does not see: its data is first touched behind the counted wait that names it)
+#define W4_XSCALE_LOAD(dst_, base_) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst_) : "v"(svo), "s"(base_) : "memory")
+    // next -> current: the lane's byte lane: lanes 32-63 supply the scale of the second block of every MFMA.  s_nop: the MFMAs behind it are asm
+    // (VALU write -> MFMA read needs wait states hipcc cannot insert)
+#define W4_XSCALE_TAKE()                                                                                   \
+    do {                                                                                                   \
+        const unsigned sh_ = 8u * (unsigned)lh;                                                            \
+        _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) { sa_cur[e_] = sa_nxt[e_] >> sh_; sb_cur[e_] = sb_nxt[e_] >> sh_; } \
+        asm volatile("s_nop 4" : "+v"(sa_cur), "+v"(sb_cur));                                              \
     } while (0)
     // The MFMAs are inline asm so that the 256 accumulator registers are AGPRs by constraint (left to itself hipcc keeps part of the
     // accumulator tile in VGPRs and shuttles it through v_accvgpr_write around every MFMA, spilling the fragments); the price is that
@@ -587,6 +652,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // ---- prologue: K-tile 0 complete and landed, operand A of K-tile 1 requested; F0 = fragments of K-step 0 of K-tile 0
 #define W4_STAGE_HALF(isb_) do { W4_DMA(isb_, 0); W4_DMA(isb_, 1); W4_DMA(isb_, 2); W4_DMA(isb_, 3); W4_DMA(isb_, 4); W4_DMA(isb_, 5); W4_DMA(isb_, 6); W4_DMA(isb_, 7); } while (0)
     if constexpr ((ABL & 32) != 0) { W4_PARK(); } else { W4_STAGE_AT(0, -1, false); }      // ABL 32: every DMA re-reads the same 1 KB (issue + LDS write, no memory traffic)
+    // the sixteen fragment reads of an MX K-step, literal read numbers (W4_XREAD)
+#define W4_XREAD16(FA_, FB_, base_, xlo_, xhi_)                                                            \
+    W4_XREAD(0, FA_, FB_, base_, xlo_, xhi_); W4_XREAD(1, FA_, FB_, base_, xlo_, xhi_); W4_XREAD(2, FA_, FB_, base_, xlo_, xhi_); W4_XREAD(3, FA_, FB_, base_, xlo_, xhi_);     \
+    W4_XREAD(4, FA_, FB_, base_, xlo_, xhi_); W4_XREAD(5, FA_, FB_, base_, xlo_, xhi_); W4_XREAD(6, FA_, FB_, base_, xlo_, xhi_); W4_XREAD(7, FA_, FB_, base_, xlo_, xhi_);     \
+    W4_XREAD(8, FA_, FB_, base_, xlo_, xhi_); W4_XREAD(9, FA_, FB_, base_, xlo_, xhi_); W4_XREAD(10, FA_, FB_, base_, xlo_, xhi_); W4_XREAD(11, FA_, FB_, base_, xlo_, xhi_);   \
+    W4_XREAD(12, FA_, FB_, base_, xlo_, xhi_); W4_XREAD(13, FA_, FB_, base_, xlo_, xhi_); W4_XREAD(14, FA_, FB_, base_, xlo_, xhi_); W4_XREAD(15, FA_, FB_, base_, xlo_, xhi_);
+    if constexpr (MX) {
+        // K-tile 0 complete with its scales, pieces 0..10 of K-tile 1 requested (what K-step 1 of a K-tile -1 would have requested)
+        W4_STAGE_HALF(0); W4_STAGE_HALF(1);
+        W4_XSCALE_LOAD(sa_nxt, s_pSA); W4_XSCALE_LOAD(sb_nxt, s_pSB);
+        W4_STAGE_ADVANCE();
+        W4_DMA(0, 0); W4_DMA(0, 1); W4_DMA(0, 2); W4_DMA(0, 3); W4_DMA(0, 4); W4_DMA(0, 5); W4_DMA(0, 6); W4_DMA(0, 7); W4_DMA(1, 0); W4_DMA(1, 1); W4_DMA(1, 2);
+        asm volatile("s_waitcnt vmcnt(11)" : "+v"(sa_nxt), "+v"(sb_nxt) : : "memory");
+        W4_FENCE();
+        W4_XSCALE_TAKE();
+        W4_COMPUTE_AT(0, -1);
+        __builtin_amdgcn_s_barrier();
+        W4_FENCE();
+        W4_XREAD16(xa0, xb0, 0, xk0, xk1)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        W4_FENCE();
+    } else {
     W4_STAGE_HALF(0); W4_STAGE_HALF(1); W4_STAGE_ADVANCE();
     W4_DMA(0, 0); W4_DMA(0, 1); W4_DMA(0, 2); W4_DMA(0, 3); W4_DMA(0, 4); W4_DMA(0, 5);      // what K-step 3 of a K-tile -1 would have requested
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -597,6 +684,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int r = 0; r < 8; ++r) W4_READ(r, fa0, fb0, 0, xk0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     W4_FENCE();
+    }
 
     // One K-tile = four K-steps of 16 MFMAs (schedule in the file header).  Slot i (behind MFMA i) of a K-step carries one fragment read (i < 8: the
     // fragments of the K-step after this one) and / or one DMA; the LDS address of a DMA is put into M0 in front of the MFMA before it (the wait state
@@ -630,6 +718,51 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         W4_KSTEP(10, ks_, FA_, FB_, FAn_, FBn_, base_, xk_) W4_KSTEP(11, ks_, FA_, FB_, FAn_, FBn_, base_, xk_) \
         W4_KSTEP(12, ks_, FA_, FB_, FAn_, FBn_, base_, xk_) W4_KSTEP(13, ks_, FA_, FB_, FAn_, FBn_, base_, xk_) \
         W4_KSTEP(14, ks_, FA_, FB_, FAn_, FBn_, base_, xk_) W4_KSTEP(15, ks_, FA_, FB_, FAn_, FBn_, base_, xk_)
+        // ---- MX fp8: a K-tile (128 k) is TWO K-steps of 16 scaled MFMAs (64 cycles each: the same 2048 matrix-pipe cycles as the 64 bf16 MFMAs
+        // of a 64-k K-tile, on twice the k).  Slot i carries one 16-byte fragment read (the next K-step's) and at most one DMA:
+        //   K-step 0: MFMAs on X0 | reads -> X1 (second half of this stage) | pieces 11..15 of the cursor's K-tile (= compute K-tile + 1) in slots
+        //             0, 1, 3, 4, 6, its scale dwords in slots 8, 9, the cursor advances; lgkmcnt(0), vmcnt(0) [9 MFMAs = 576 cycles for the last piece
+        //             to land: the bf16 schedule's 18 x 32], s_barrier
+        //   K-step 1: MFMAs on X1 | reads -> X0 (first half of the NEXT stage) | pieces 0..10 of K-tile + 2 into THIS stage (two per three slots:
+        //             one DMA per 96 matrix-pipe cycles, the spacing the bf16 schedule settled on); scales next -> current
+#define W4_XPIECE_OF(ks_, i_) ((ks_) == 1 ? ((((i_) % 3) != 2) ? ((i_) / 3) * 2 + ((i_) % 3) : -1) : (((((i_) % 3) != 2) && (i_) < 7) ? 11 + ((i_) / 3) * 2 + ((i_) % 3) : -1))
+#define W4_XKSTEP(i_, ks_, FA_, FB_, FAn_, FBn_, base_, xlo_, xhi_)                                        \
+        {                                                                                                  \
+            constexpr int pc_ = W4_XPIECE_OF(ks_, i_);                                                     \
+            constexpr int isb_ = pc_ >= 8 ? 1 : 0, d_ = pc_ < 0 ? 0 : (pc_ & 7);                           \
+            if constexpr (pc_ >= 0) W4_XMF_M0(i_, ks_, FA_, FB_, xlds + (unsigned)(isb_ * 32768 + d_ * 4096)); else W4_XMF(i_, ks_, FA_, FB_); \
+            W4_FENCE();                                                                                    \
+            W4_XREAD(i_, FAn_, FBn_, base_, xlo_, xhi_);                                                   \
+            if constexpr (pc_ >= 0) W4_DMA_M0(isb_, d_);                                                   \
+            if constexpr ((ks_) == 0 && (i_) == 8) W4_XSCALE_LOAD(sa_nxt, s_pSA);                          \
+            if constexpr ((ks_) == 0 && (i_) == 9) W4_XSCALE_LOAD(sb_nxt, s_pSB);                          \
+            W4_FENCE();                                                                                    \
+        }
+#define W4_XKSTEP16(ks_, FA_, FB_, FAn_, FBn_, base_, xlo_, xhi_)                                          \
+        W4_XKSTEP(0, ks_, FA_, FB_, FAn_, FBn_, base_, xlo_, xhi_) W4_XKSTEP(1, ks_, FA_, FB_, FAn_, FBn_, base_, xlo_, xhi_)   \
+        W4_XKSTEP(2, ks_, FA_, FB_, FAn_, FBn_, base_, xlo_, xhi_) W4_XKSTEP(3, ks_, FA_, FB_, FAn_, FBn_, base_, xlo_, xhi_)   \
+        W4_XKSTEP(4, ks_, FA_, FB_, FAn_, FBn_, base_, xlo_, xhi_) W4_XKSTEP(5, ks_, FA_, FB_, FAn_, FBn_, base_, xlo_, xhi_)   \
+        W4_XKSTEP(6, ks_, FA_, FB_, FAn_, FBn_, base_, xlo_, xhi_) W4_XKSTEP(7, ks_, FA_, FB_, FAn_, FBn_, base_, xlo_, xhi_)   \
+        W4_XKSTEP(8, ks_, FA_, FB_, FAn_, FBn_, base_, xlo_, xhi_) W4_XKSTEP(9, ks_, FA_, FB_, FAn_, FBn_, base_, xlo_, xhi_)   \
+        W4_XKSTEP(10, ks_, FA_, FB_, FAn_, FBn_, base_, xlo_, xhi_) W4_XKSTEP(11, ks_, FA_, FB_, FAn_, FBn_, base_, xlo_, xhi_) \
+        W4_XKSTEP(12, ks_, FA_, FB_, FAn_, FBn_, base_, xlo_, xhi_) W4_XKSTEP(13, ks_, FA_, FB_, FAn_, FBn_, base_, xlo_, xhi_) \
+        W4_XKSTEP(14, ks_, FA_, FB_, FAn_, FBn_, base_, xlo_, xhi_) W4_XKSTEP(15, ks_, FA_, FB_, FAn_, FBn_, base_, xlo_, xhi_)
+        if constexpr (MX) {
+            unsigned xlds = lds_w + (unsigned)s_slot * W4_STAGE;     // one scalar base per K-step, a literal add per DMA (sixteen precomputed piece addresses do not fit the SGPR file beside the cursor)
+            W4_XKSTEP16(0, xa0, xb0, xa1, xb1, cb, xk2, xk3)
+            W4_STAGE_ADVANCE();
+            xlds = lds_w + (unsigned)s_slot * W4_STAGE;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(sa_nxt), "+v"(sb_nxt) : : "memory");      // K-tile + 1 and its scales landed
+            W4_FENCE();
+            __builtin_amdgcn_s_barrier();
+            W4_FENCE();
+            W4_XKSTEP16(1, xa1, xb1, xa0, xb0, nb, xk0, xk1)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            W4_FENCE();
+            W4_XSCALE_TAKE();
+            W4_FENCE();
+        } else {
         // ---- K-step 0
         W4_KSTEP16(0, fa0, fb0, fa1, fb1, cb, xk1)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -652,6 +785,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         W4_KSTEP16(3, fa1, fb1, fa0, fb0, nb, xk0)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         W4_FENCE();
+        }
         c_slot ^= 1;
         ++c_ss;
         if (c_ss != c_nss) continue;
@@ -663,6 +797,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         else if (!(ABL & 8)) W4_EPILOGUE();
         if (!(ABL & 8)) { W4_ZERO_ACC() }      // one zeroing behind both paths: the accumulator tile has a single definition at the join
         W4_TRACE(-2);
+        if constexpr (MX) {    // as QKF below: X0 (64 registers) is not kept alive across the epilogue, the stage is intact
+            const int rb = c_slot * W4_STAGE;
+            W4_XREAD16(xa0, xb0, rb, xk0, xk1)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            W4_FENCE();
+        }
         if constexpr (QKF) {   // F0 of the next tile's first K-step was prefetched by K-step 3 -- the fused q / k variant re-reads it here instead of
             // keeping 32 registers alive across its larger epilogue (the stage is intact; one exposed LDS latency per tile)
             const int rb = c_slot * W4_STAGE;
@@ -805,7 +945,20 @@ extern "C" int utx_launch_gemm_w4(GemmParams p, hipStream_t stream) {
         }
     }
 #endif
-    if (p.gate) {
+    if (p.mx8 == 2) {
+        // MX fp8 operands, tile-packed scales (K, lda, ldb arrive in bf16 units = halved, as for the 128^2 form: the staging code is byte-identical)
+        if (p.K2 > 0 || p.qk_cols > 0 || (p.K % 64) || !p.a_scale || !p.b_scale || p.lds_a < (p.M + 127) / 128 || p.lds_b < p.N / 128 ||
+            ((uintptr_t)p.a_scale & 15) || ((uintptr_t)p.b_scale & 15)) return -2;
+        if (p.gate && (p.gelu_from < p.N || p.n_split < p.N)) return -2;
+        static bool ax = false;
+        if (!ax) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_w4_kernel<false, 0, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_w4_kernel<true, 0, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
+            ax = true;
+        }
+        if (p.gate) hipLaunchKernelGGL((gemm256_w4_kernel<true, 0, false, true>), dim3(grid), dim3(256), LDS, stream, p, tiles, trace_wg, sk_T, sk_S);
+        else hipLaunchKernelGGL((gemm256_w4_kernel<false, 0, false, true>), dim3(grid), dim3(256), LDS, stream, p, tiles, trace_wg, sk_T, sk_S);
+    } else if (p.gate) {
         if (p.gelu_from < p.N || p.n_split < p.N) return -2;
         hipLaunchKernelGGL((gemm256_w4_kernel<true>), dim3(grid), dim3(256), LDS, stream, p, tiles, trace_wg, sk_T, sk_S);
     } else {

@@ -73,6 +73,7 @@ int utx_launch_gemm_w4(GemmParams p, hipStream_t stream);     // gemm_w4.hip: pe
 int utx_launch_gemm_pers(GemmParams p, hipStream_t stream);   // gemm_pers.hip: persistent 256x256 kernel (large-M linears)
 int utx_launch_gemv_bf16(const GemvParams* p, hipStream_t stream);
 int utx_launch_quant_mx8(const void* x, long ldx, void* q, long ldq, void* s, long lds, int M, int K, hipStream_t stream);
+int utx_launch_quant_mx8_packed(const void* x, long ldx, void* q, long ldq, void* s, long row_blocks, int M, int K, hipStream_t stream);
 int utx_launch_qkv_post(const QkvPostParams* p, hipStream_t stream);
 int utx_launch_sp_unpack_qkv(const void* recv, int P, int Hp, int S_loc, void* q, void* k, void* vt, hipStream_t stream);
 int utx_launch_sp_unpack_o(const void* recv, int P, int Hp, int S_loc, void* out, long ld, hipStream_t stream);

@@ -61,7 +61,11 @@ def make_gemm_desc(A, B, C_out, bias=None, A2=None, B2=None, lora_n_limit=None, 
     d.A, d.lda, d.B, d.ldb = ptr(A), A.stride(0), ptr(B), B.stride(0)
     if a_scale is not None:
         assert A.dtype == torch.uint8 and B.dtype == torch.uint8 and b_scale is not None
-        d.a_scale, d.lds_a, d.b_scale, d.lds_b, d.mx8 = ptr(a_scale), a_scale.stride(0), ptr(b_scale), b_scale.stride(0), 1
+        if hasattr(a_scale, "row_blocks"):     # mx8.PackedScales on both operands: the one-wave-per-SIMD MX kernel (mx8 = 2)
+            assert hasattr(b_scale, "row_blocks"), "packed activation scales need packed weight scales"
+            d.a_scale, d.lds_a, d.b_scale, d.lds_b, d.mx8 = ptr(a_scale.data), a_scale.row_blocks, ptr(b_scale.data), b_scale.row_blocks, 2
+        else:
+            d.a_scale, d.lds_a, d.b_scale, d.lds_b, d.mx8 = ptr(a_scale), a_scale.stride(0), ptr(b_scale), b_scale.stride(0), 1
     if A2 is not None:
         d.A2, d.lda2, d.B2, d.ldb2 = ptr(A2), A2.stride(0), ptr(B2), B2.stride(0)
         d.K2 = B2.shape[1]
@@ -136,6 +140,14 @@ def gemm_takes_w4(M, N, n_split=None, gelu_from=None, K2=0, lora_seg_n=None, lor
     """True when utx_gemm_bf16 dispatches this shape to the one-wave-per-SIMD 256 x 256 kernel (gemm_w4.hip) -- the kernel that carries the
     fused q / k epilogue.  Asked of the library (utx_gemm_plan), not restated here."""
     return gemm_plan(M, N, K2=K2, n_split=n_split, gelu_from=gelu_from, lora_seg_n=lora_seg_n, lora_n_limit=lora_n_limit)["kernel"] == "w4"
+
+
+def mx8_uses_packed(M, N, n_split=None, gelu_from=None):
+    """MX fp8 GEMM of this shape on the one-wave-per-SIMD kernel (tile-packed scales, utx_gemm_desc.mx8 = 2)?  The kernel's own constraints (N and
+    every column boundary on 256) and the bf16 dispatch's fill rule (>= 192 tiles of 256 x 256); smaller shapes keep the 128 x 128-tile MX kernel."""
+    if N % 256 or (n_split is not None and n_split < N and n_split % 256) or (gelu_from is not None and gelu_from < N and gelu_from % 256):
+        return False
+    return ((M + 255) // 256) * (N // 256) >= 192
 
 
 def gemm(A, B, bias=None, out=None, **kw):

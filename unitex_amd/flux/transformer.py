@@ -184,13 +184,35 @@ class FluxDiT:
         self.n_mod = off
         self.W = W
         if self.fp8_weights:
-            # weights of the big linears once more as MX fp8 (e4m3 + E8M0 per 32 along K), quantised here at load
-            from .mx8 import quantize_weight
-            for blocks, names in ((self.double, self.FP8_LINEARS_DOUBLE), (self.single, self.FP8_LINEARS_SINGLE)):
-                for b in blocks:
-                    for nm in names:
-                        if b[nm + ".w"].shape[1] % 128 == 0:
-                            b[nm + ".q"], b[nm + ".s"] = quantize_weight(b[nm + ".w"], self.ctx)
+            self._quantize_fp8_weights()
+
+    def _quantize_fp8_weights(self):
+        """weights of the big linears once more as MX fp8 (e4m3 + E8M0 per 32 along K), quantised at load and again by set_lora: in fp8 mode the
+        switched-on adapters are MERGED into the weight before it is quantised, W' = W + sum_i s_i B_i A_i (fp32 sum, rounded to bf16, then MX
+        fp8) -- a LoRA update is far below the e4m3 quantisation step of the base weight, so carrying it as a separate bf16 K-segment buys no
+        accuracy, and the merged form needs neither the LoRA-down GEMM nor a second K-segment in the fp8 kernel.  (The bf16 path keeps the
+        adapters un-merged, as peft does.)  Off the denoise path: twice per mesh (texture pass, delight pass), ~12 G parameters re-quantised.
+        Scales in both layouts: row-major for the 128^2-tile kernel (small / ragged shapes), tile-packed for the one-wave-per-SIMD kernel."""
+        from .mx8 import quantize_weight
+        for blocks, names in ((self.double, self.FP8_LINEARS_DOUBLE), (self.single, self.FP8_LINEARS_SINGLE)):
+            for b in blocks:
+                for nm in names:
+                    W = b[nm + ".w"]
+                    if W.shape[1] % 128:
+                        continue
+                    lora = b.get("lora." + nm)
+                    if lora is not None:
+                        A_cat, B_cat, alpha, Rp = lora
+                        nseg = A_cat.shape[0] // Rp
+                        seg = B_cat.shape[0] // nseg
+                        Wf = W.to(torch.float32)
+                        for si in range(nseg):
+                            Wf[si * seg:(si + 1) * seg] += float(alpha) * (B_cat[si * seg:(si + 1) * seg].float() @ A_cat[si * Rp:(si + 1) * Rp].float())
+                        W = Wf.to(BF16)
+                        del Wf
+                    b[nm + ".q"], b[nm + ".s"] = quantize_weight(W, self.ctx)
+                    if W.shape[0] % 256 == 0:
+                        _, b[nm + ".sp"] = quantize_weight(W, self.ctx, packed=True)
 
     def num_params(self):
         n = sum(v.numel() for v in self.W.values())
@@ -209,6 +231,8 @@ class FluxDiT:
         self._graphs = {}
         self._pack_full_overrides()
         self._pack_lora()
+        if self.fp8_weights:
+            self._quantize_fp8_weights()
 
     FULL_OVERRIDE_MODULES = ("x_embedder",)   # the only parameterised entry of the trainer's modules_to_save (trainer.py:297-304)
 
@@ -319,10 +343,16 @@ class FluxDiT:
         if mx8 is not None:
             Wq, Ws, aq, as_ = mx8
             M, K = A.shape
-            aqv, asv = aq[:M, :K], as_[:M, : K // 32]
+            aqv = aq[:M, :K]
+            if hasattr(Ws, "row_blocks"):      # tile-packed scales: the scratch buffer is shared by every fp8 GEMM of the plan (>= K/128 slabs, >= M/128 row blocks)
+                from .mx8 import PackedScales
+                asv = PackedScales(as_, M, K)
+            else:
+                asv = as_[:M, : K // 32]
             plan.append(("quant_mx8", (A, aqv, asv)))
             kw = dict(kw, a_scale=asv, b_scale=Ws)
             A_main, B_main = aqv, Wq
+            lora = None     # merged into the fp8 weight (_quantize_fp8_weights)
         else:
             A_main, B_main = A, B
         if lora is not None:
@@ -415,9 +445,11 @@ class FluxDiT:
         if self.sp is None:
             ws.update({"Qh": z(H, S_pad, 128), "Kh": z(H, S_pad, 128), "Vt": z(H, 128, S_pad)})
         if self.fp8_weights:
+            from .mx8 import packed_scale_buffer
             Kmax = (1 + sh.mlp_ratio) * D
             ws["aq"] = z(S, Kmax, dtype=torch.uint8)
             ws["as"] = z(S, Kmax // 32, dtype=torch.uint8)
+            ws["asp"] = packed_scale_buffer(S, Kmax, dev)
         if Rp:
             ws["T"] = z(S, 3 * Rp)
             ws["Tc"] = z(S_txt, 3 * Rp)     # LoRA-down temp of the text half (it runs concurrently with the image half)
@@ -429,10 +461,13 @@ class FluxDiT:
         T = ws.get("T")
         Tc = ws.get("Tc") if self.overlap_text else T
 
-        def mx(b, nm, row0=0):
-            """MX fp8 operands of linear `nm` of block b (None = bf16 path); the activation scratch rows start at row0."""
+        def mx(b, nm, row0=0, M=None, **shape_kw):
+            """MX fp8 operands of linear `nm` of block b (None = bf16 path); the activation scratch rows start at row0.  Shapes that fill the
+            chip with 256 x 256 tiles take the one-wave-per-SIMD kernel (tile-packed scales), the rest the 128 x 128-tile kernel (row-major)."""
             if not self.fp8_weights or (nm + ".q") not in b:
                 return None
+            if (nm + ".sp") in b and ops.mx8_uses_packed(S if M is None else M, b[nm + ".q"].shape[0], **shape_kw):
+                return (b[nm + ".q"], b[nm + ".sp"], ws["aq"][row0:], ws["asp"])
             return (b[nm + ".q"], b[nm + ".s"], ws["aq"][row0:], ws["as"][row0:])
         W, mod = self.W, ws["mod"][0]
 
@@ -477,7 +512,7 @@ class FluxDiT:
             has_l = b.get("lora.qkv_x") is not None
             qkx = qk_fused(S_img, 3 * D, S_txt, b["nq"], b["nk"], K2=(Rp if has_l else 0), lora_seg_n=D, lora_n_limit=3 * D)
             self._gemm(px, xn_x, b["qkv_x.w"], qkv[S_txt:], bias=b["qkv_x.b"], lora=b.get("lora.qkv_x"),
-                       lora_n_limit=3 * D, lora_seg_n=D, T=T, mx8=mx(b, "qkv_x", S_txt), qk_post=qkx)
+                       lora_n_limit=3 * D, lora_seg_n=D, T=T, mx8=mx(b, "qkv_x", S_txt, S_img), qk_post=qkx)
             self._gemm(pc, xn_c, b["qkv_c.w"], qkv[:S_txt], bias=b["qkv_c.b"], lora=b.get("lora.qkv_c"),
                        lora_n_limit=3 * D, lora_seg_n=D, T=Tc)
             self._qkvpost(px, qkv[S_txt:], b["nq"], b["nk"], ws, S_img, S_txt, skip_qk=qkx is not None)
@@ -493,9 +528,9 @@ class FluxDiT:
                        gate=cg_a, res=h_c)
             self._lnmod(px, h_x, xn_x, sh_m, sc_m)
             self._gemm(px, xn_x, b["ff1_x.w"], ff[S_txt:], bias=b["ff1_x.b"], lora=b.get("lora.ff1_x"), T=T, gelu_from=0,
-                       mx8=mx(b, "ff1_x", S_txt))
+                       mx8=mx(b, "ff1_x", S_txt, S_img))
             self._gemm(px, ff[S_txt:], b["ff2_x.w"], h_x, bias=b["ff2_x.b"], lora=b.get("lora.ff2_x"), T=T,
-                       gate=g_m, res=h_x, mx8=mx(b, "ff2_x", S_txt))
+                       gate=g_m, res=h_x, mx8=mx(b, "ff2_x", S_txt, S_img))
             self._lnmod(pc, h_c, xn_c, csh_m, csc_m)
             self._gemm(pc, xn_c, b["ff1_c.w"], ff[:S_txt], bias=b["ff1_c.b"], lora=b.get("lora.ff1_c"), T=Tc, gelu_from=0)
             self._gemm(pc, ff[:S_txt], b["ff2_c.w"], h_c, bias=b["ff2_c.b"], lora=b.get("lora.ff2_c"), T=Tc,
@@ -533,7 +568,7 @@ class FluxDiT:
                 qkm = qk_fused(S, (3 + sh.mlp_ratio) * D, 0, b["nq"], b["nk"], n_split=3 * D, gelu_from=3 * D, K2=(Rp if has_l else 0),
                                lora_seg_n=D, lora_n_limit=3 * D)
                 self._gemm(plan, xn, b["qkvm.w"], qkv, bias=b["qkvm.b"], lora=b.get("lora.qkvm"), lora_n_limit=3 * D,
-                           lora_seg_n=D, T=T, gelu_from=3 * D, n_split=3 * D, C1=cat[:, D:], mx8=mx(b, "qkvm"), qk_post=qkm)
+                           lora_seg_n=D, T=T, gelu_from=3 * D, n_split=3 * D, C1=cat[:, D:], mx8=mx(b, "qkvm", n_split=3 * D, gelu_from=3 * D), qk_post=qkm)
                 self._qkvpost(plan, qkv, b["nq"], b["nk"], ws, S, 0, skip_qk=qkm is not None)
             else:
                 # sequence parallel: the same GEMM cut at column 3D (identical arithmetic per column) so that the Q/K/V exchange
@@ -580,8 +615,6 @@ class FluxDiT:
         """scratch of the large-M GEMM's balanced tail round (utx_gemm_desc.sk_work): one buffer for the GEMMs of the main stream -- they
         are ordered among themselves; the text-side ops of a "par" entry run beside them on the second stream and get none (their GEMMs are
         far below the size where the tail is split).  UTX_GEMM_STREAMK=0 at library level switches the split off."""
-        if self.fp8_weights:
-            return
         ncu = torch.cuda.get_device_properties(self.device).multi_processor_count
 
         def main_gemms(entries):
@@ -667,8 +700,12 @@ class FluxDiT:
         """one stream-ordered launch of a plan entry that is a C-ABI call: (entry point, descriptor) or the MX fp8 quantiser"""
         if fn == "quant_mx8":
             x_, q_, s_ = d
-            rc = self.lib.utx_quant_mx8(self.ctx.handle, ptr(x_), x_.stride(0), ptr(q_), q_.stride(0), ptr(s_), s_.stride(0),
-                                        x_.shape[0], x_.shape[1], st)
+            if hasattr(s_, "row_blocks"):
+                rc = self.lib.utx_quant_mx8_packed(self.ctx.handle, ptr(x_), x_.stride(0), ptr(q_), q_.stride(0), ptr(s_.data), s_.row_blocks,
+                                                   x_.shape[0], x_.shape[1], st)
+            else:
+                rc = self.lib.utx_quant_mx8(self.ctx.handle, ptr(x_), x_.stride(0), ptr(q_), q_.stride(0), ptr(s_), s_.stride(0),
+                                            x_.shape[0], x_.shape[1], st)
         else:
             rc = fn(self.ctx.handle, C.byref(d), st)
         if rc:
