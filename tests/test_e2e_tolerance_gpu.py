@@ -8,8 +8,10 @@ Oracle : oracle/dit_ref.denoise_loop(emulate_bf16=True) (fp32 arithmetic, rounde
          reference) -> oracle/vae_ref (fp32) -> the same postprocess.
 
 STATED TOLERANCE (asserted below, measured values printed and quoted in DESIGN.md section 3):
-  * latents after K = 4 steps: max |d| <= 0.05 max|latent|, mean |d| <= 0.006 max|latent|
-  * decoded uint8 image: >= 97 % of the pixels within 2 LSB, >= 99.5 % within 4 LSB, no pixel further than 16 LSB
+  * latents after K = 4 steps: max |d| <= 0.02 max|latent|, mean |d| <= 0.0015 max|latent|
+  * decoded uint8 image: >= 99 % of the pixels within 2 LSB, >= 99.9 % within 4 LSB, no pixel further than 8 LSB
+  (measured on MI355X, profiles/r03_e2e_tol_a.log: max 0.005-0.008, mean 0.0004-0.0005 of max|latent|; 54 % of the pixels equal, 94 % within 1 LSB,
+  99.7 % within 2, none beyond 4 -- the same for the tiny 2 + 4-block network and the full-width 1 + 1-block one at 9728 tokens)
 BASELINE's "1e-3 max-abs" is below half a bf16 ulp at 1.0 (3.9e-3) and cannot be met by ANY bf16 evaluation order that differs from
 the reference's own (the reference itself is not reproducible to 1e-3 across GPU kernels libraries); what can be stated is the
 drift of this implementation's bf16 kernels against an fp32-accumulating restatement with the reference's rounding points.
@@ -106,8 +108,8 @@ def test_k_step_denoise_and_vae_decode_tiny_full_depth_pattern(zero_text):
     got_lat, ref_lat, got_u8, ref_u8 = _run_both(cfg, shape, 128 if zero_text else 64, zero_text, (8, 24), (4, 4), 4, 16)
     mx, d, du, hist, spread = _report("tiny 2+4 blocks, %s text" % ("zero" if zero_text else "random"), got_lat, ref_lat, got_u8, ref_u8)
     assert torch.isfinite(got_lat).all() and spread > 4.0
-    assert d.max().item() <= 0.05 * mx and d.mean().item() <= 0.006 * mx
-    assert hist[2] >= 0.97 and hist[4] >= 0.995 and du.max() <= 16
+    assert d.max().item() <= 0.02 * mx and d.mean().item() <= 0.0015 * mx
+    assert hist[2] >= 0.99 and hist[4] >= 0.999 and du.max() <= 8
 
 
 def test_k_step_denoise_and_vae_decode_full_width_at_config1_shape():
@@ -120,5 +122,5 @@ def test_k_step_denoise_and_vae_decode_full_width_at_config1_shape():
     got_lat, ref_lat, got_u8, ref_u8 = _run_both(cfg, shape, 512, True, (32, 128), (32, 32), 4, 64, n_threads=nt)
     mx, d, du, hist, spread = _report("full width 1+1 blocks, S = 9728", got_lat, ref_lat, got_u8, ref_u8)
     assert torch.isfinite(got_lat).all() and spread > 4.0
-    assert d.max().item() <= 0.05 * mx and d.mean().item() <= 0.006 * mx
-    assert hist[2] >= 0.97 and hist[4] >= 0.995 and du.max() <= 16
+    assert d.max().item() <= 0.02 * mx and d.mean().item() <= 0.0015 * mx
+    assert hist[2] >= 0.99 and hist[4] >= 0.999 and du.max() <= 8

@@ -17,12 +17,19 @@ class PackedScales:
 
     def __init__(self, data, rows, K):
         self.data, self.rows, self.K = data, rows, K
-        self.row_blocks = data.shape[1]
+        assert data.dim() == 3 and data.shape[2] == 512 and data.stride(2) == 1 and data.stride(1) == 512 and data.stride(0) % 512 == 0
+        self.row_blocks = data.stride(0) // 512       # row blocks per K-tile slab = the slab stride the kernels address with (a row-sliced view keeps it)
 
     def rowmajor(self):
         """[rows, K/32] uint8 (tests): byte (r, b) = dword [b / 4][r / 128][r % 32][(r % 128) / 32] byte b % 4"""
-        d = self.data.view(self.K // 128, self.row_blocks, 32, 4, 4)            # kt, rb, l, im, j
-        return d.permute(1, 3, 2, 0, 4).reshape(self.row_blocks * 128, self.K // 32)[: self.rows].contiguous()
+        nb = (self.rows + 127) // 128
+        d = self.data[: self.K // 128, :nb].reshape(self.K // 128, nb, 32, 4, 4)            # kt, rb, l, im, j
+        return d.permute(1, 3, 2, 0, 4).reshape(nb * 128, self.K // 32)[: self.rows].contiguous()
+
+    def row_slice(self, r0, r1):
+        """the scales of rows [r0, r1) as an operand of their own (r0 % 128 == 0: weight rows of a fused projection)"""
+        assert r0 % 128 == 0
+        return PackedScales(self.data[:, r0 // 128: (r1 + 127) // 128], r1 - r0, self.K)
 
 
 def packed_scale_buffer(rows, K, device):
