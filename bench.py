@@ -55,32 +55,50 @@ def step_flops(S):
     return attn + lin, attn
 
 
-def cpu_baseline(S_full, threads):
-    """Oracle (oracle/dit_ref.py, fp32 torch CPU) on a bounded sample: NB double + NB single FLUX blocks at
-    full width (D=3072, 24 heads), S_txt=512 + S_img=2560 tokens; extrapolated by algorithmic FLOPs."""
+def cpu_baseline(S_full, threads, full_depth=False):
+    """Oracle (oracle/dit_ref.py, fp32 torch CPU) at BASELINE configs[0]'s shape -- full width (D = 3072, 24 heads), 512 text + 4096 noise +
+    4096 control + 1024 dual = 9728 tokens -- on a bounded sample of its depth: 1 double + 1 single block (2 / 57 of a configs[0] step; every
+    block has the same attention : linear ratio, 34.5 % : 65.5 % at this length, so the sample has the step's own mix), about 20-30 s on the
+    GPU box's host.  The attention core is timed once more on its own (oracle sdpa, 24 heads x 9728 tokens), which gives separate attention and
+    linear rates; the S_full-token step (attention share 73 %) is extrapolated with THOSE two rates, not with one blended FLOP rate.
+    full_depth=True (bench.py --cpu-full-step, ~9 min): the whole 57-block step at 9728 tokens, nothing about depth extrapolated."""
     from oracle import dit_ref
     torch.set_num_threads(threads)
-    NB = 3
-    cfg = dit_ref.FluxConfig(num_double=NB, num_single=NB)
+    nd, ns = (N_DOUBLE, N_SINGLE) if full_depth else (1, 1)
+    cfg = dit_ref.FluxConfig(num_double=nd, num_single=ns)
     sd = dit_ref.make_synthetic_state_dict(cfg, seed=0, dtype=torch.float32)
-    S_txt, S_img = 512, 2560
+    HL, WL, DL, S_txt = 32, 128, 32, 512
     g = torch.Generator().manual_seed(63)
+    img_ids = torch.cat([dit_ref.latent_image_ids(HL, WL), dit_ref.latent_image_ids(HL, WL, offset_y=HL),
+                         dit_ref.latent_image_ids(DL, DL, offset_x=WL, offset_y=HL)], 0)
+    S_img = img_ids.shape[0]
     lat = torch.randn(S_img, 64, generator=g)
     enc = torch.zeros(S_txt, cfg.joint_dim)
     pooled = torch.zeros(1, cfg.pooled_dim)
     txt_ids = torch.zeros(S_txt, 3)
-    img_ids = dit_ref.latent_image_ids(40, 64)
     t0 = time.perf_counter()
     dit_ref.flux_forward(sd, cfg, lat, enc, pooled, 0.5, 3.5, txt_ids, img_ids, emulate_bf16=False)
     dt = time.perf_counter() - t0
     S = S_txt + S_img
-    fl = (4.0 * S * S * D + 24.0 * D * D * S) * 2 * NB
-    rate = fl / dt  # FLOP/s
-    full, _ = step_flops(S_full)
-    return {"value": rate / full, "unit": "steps/s", "cores": threads, "kind": "port",
-            "sample": "oracle/dit_ref.py fp32 torch-CPU: %d double + %d single FLUX blocks, D=3072, S=%d, %.1f s measured "
-                      "(%.2f TFLOP/s); extrapolated by FLOPs to the %d-token 57-block step" % (NB, NB, S, dt, rate / 1e12, S_full),
-            "measured_seconds": dt}
+    q = torch.randn(HEADS, S, 128, generator=g)
+    t1 = time.perf_counter()
+    dit_ref.sdpa(q, q, q, False)
+    dt_attn1 = time.perf_counter() - t1                      # one attention call of the sample
+    nb = nd + ns
+    fl_attn1, fl_lin1 = 4.0 * S * S * D, 24.0 * D * D * S
+    t_attn = min(dt_attn1 * nb, 0.9 * dt)
+    rate_attn, rate_lin = fl_attn1 * nb / t_attn, fl_lin1 * nb / (dt - t_attn)
+    full, full_attn = step_flops(S_full)
+    t_full = full_attn / rate_attn + (full - full_attn) / rate_lin
+    return {"value": 1.0 / t_full, "unit": "steps/s", "cores": threads, "kind": "port",
+            "sample": "oracle/dit_ref.py fp32 torch-CPU at BASELINE configs[0]'s shape (D=3072, 24 heads, S=%d): %d double + %d single FLUX blocks%s, "
+                      "%.1f s measured = %.2f TFLOP/s blended; attention core alone %.2f s per call -> %.2f TFLOP/s attention, %.2f TFLOP/s linears + "
+                      "elementwise; the %d-token 57-block step (attention %.0f %% of its FLOPs) extrapolated with those two rates"
+                      % (S, nd, ns, " = one COMPLETE 57-block step, depth not extrapolated" if full_depth else " (2/57 of a step)", dt,
+                         (fl_attn1 + fl_lin1) * nb / dt / 1e12, dt_attn1, rate_attn / 1e12, rate_lin / 1e12, S_full, 100.0 * full_attn / full),
+            "measured_seconds": dt, "config0_step_seconds": dt * (N_DOUBLE + N_SINGLE) / nb, "config0_step_is_measured": bool(full_depth),
+            "attention_tflops": rate_attn / 1e12, "linear_tflops": rate_lin / 1e12,
+            "full_step_reference": "profiles/r03_cpu_full_step.json (bench.py --cpu-full-step on a GPU box's host), when present"}
 
 
 def host_cores():
@@ -177,6 +195,9 @@ def main():
     ap.add_argument("--fp8", action="store_true",
                     help="BASELINE configs[4] numerics: the five big linears on OCP MX fp8 operands (utx_gemm_desc.mx8); NOT the default "
                          "bench line (the metric is quoted in bf16) -- reported with dtype 'mx-fp8 linears + bf16 attention'")
+    ap.add_argument("--cpu-full-step", action="store_true",
+                    help="CPU baseline on ONE COMPLETE 57-block step at BASELINE configs[0]'s shape (S = 9728) instead of 1 + 1 blocks: ~9 min of "
+                         "host time, so not the default")
     ap.add_argument("--cpu-config1", action="store_true",
                     help="also run BASELINE configs[0] (512^2 x 4 views, S = 9728, 4 denoise steps, fp32) to COMPLETION on the host "
                          "cores with the oracle (~35 min on the GPU box's 64 threads; 50 min on the 8-core build container: profiles/r02_cpu_config1_container.json): the one CPU number that is not extrapolated (SURVEY 8d)")
@@ -235,9 +256,9 @@ def main():
         t[..., 2] += torch.arange(ox, ox + t.shape[1])[None, :]
     img_ids = torch.cat([t.reshape(-1, 3) for t in ids], 0)
     prune = os.environ.get("UTX_PRUNE_LAST", "1") != "0" and not ulysses and not args.fp8
+    model.set_positions(torch.zeros(S_txt, 3), img_ids)
     if prune:
         model.set_output_rows(n_noise)    # as the texturing pipeline does: only the noise tokens' prediction is consumed (sched_step reads no other row)
-    model.set_positions(torch.zeros(S_txt, 3), img_ids)
     model.set_conditioning(torch.zeros(S_txt, shape.joint_dim, device=dev), torch.zeros(1, shape.pooled_dim, device=dev), 3.5)
     sched = FlowMatchEulerScheduler()
     total = args.warmup + args.steps
@@ -278,6 +299,13 @@ def main():
         model.release_graph()
         one_step(total - 1, events)
         torch.cuda.synchronize()
+    # GEMM-only roofline: ONE extra eager step behind the timed region with HIP events around every large-M GEMM of the main stream
+    # (the text-side GEMMs of the double blocks run beside them on the second stream, as in the timed steps)
+    gemm_ev = []
+    model.gemm_events = gemm_ev
+    one_step(total - 1, None)
+    torch.cuda.synchronize()
+    model.gemm_events = None
     if world > 1:
         import torch.distributed as dist
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -364,6 +392,18 @@ def main():
                          "sustained_mfma_only_tflops": 1730.0, "frac_of_sustained": achieved / 1730.0,
                          "attention_share_of_step_time": (attn_avg_ms * (N_DOUBLE + N_SINGLE)) / (dt / args.steps * 1e3)},
         }
+        if gemm_ev:
+            g_ms = sum(a.elapsed_time(b) for a, b, _ in gemm_ev)
+            g_fl = sum(f for _, _, f in gemm_ev)
+            peak = 5000.0 if args.fp8 else PEAK_BF16_TFLOPS
+            lin_nominal = 24.0 * D * D * S_exec * (N_DOUBLE + N_SINGLE) / (world if ulysses else 1)
+            out["roofline_gemm"] = {"bound": "mfma", "kernel": "gemm256_w4_kernel (+ gemm_w4_fixup_kernel; MX form with --fp8)", "achieved": g_fl / (g_ms * 1e-3) / 1e12,
+                                    "peak": peak, "unit": "TFLOP/s", "frac": g_fl / (g_ms * 1e-3) / 1e12 / peak,
+                                    "launches_timed": len(gemm_ev), "sum_ms_per_step": g_ms, "flops_timed": g_fl,
+                                    "flops_linears_nominal_24D2S57": lin_nominal, "share_of_linear_flops_timed": g_fl / lin_nominal,
+                                    "timed_in": "one eager step after the timed region: HIP events on the launch stream around every GEMM with M >= 4096 "
+                                                "(2 M N (K + K2) FLOP each: the LoRA K-segment counts, LoRA-down products and the text-side GEMMs on the second stream do not)",
+                                    "share_of_step_time": g_ms / (dt / args.steps * 1e3)}
         if exchange:
             out["config"]["exchange"] = exchange
         # HBM traffic of the dominant kernel: PMC passes cannot run inside the timed run (they serialise kernels), so
@@ -434,7 +474,7 @@ def main():
                 # TFLOP/s with 128 threads against 0.36 with 64 (profiles/r02_bench_strip1024x6_v0.json.log vs BENCH_r01) -- the baseline
                 # is the faster setting; the host's physical core count is reported next to it
                 threads = max(1, min(ncpu, phys or ncpu, 64))
-                out["cpu_baseline"] = cpu_baseline(S, threads)
+                out["cpu_baseline"] = cpu_baseline(S, threads, full_depth=args.cpu_full_step)
                 out["cpu_baseline"]["host"] = {"usable_threads": ncpu, "physical_cores_lscpu": phys}
                 try:
                     out["cpu_baseline"]["backprojection"] = cpu_baseline_backprojection()

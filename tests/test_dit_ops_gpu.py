@@ -354,8 +354,8 @@ def test_last_block_pruning_keeps_the_consumed_rows_bit_identical(use_lora):
     try:
         _lib.set_option("UTX_ATTN_TAILSPLIT", 0)      # the key-split tail round picks different query blocks for the two launches
         for rows in (None, n_noise, 100):
-            m.set_output_rows(rows)
             m.set_positions(txt_ids, img_ids)
+            m.set_output_rows(rows)
             m.set_conditioning(enc.cuda(), pooled.cuda(), 3.5)
             outs[rows] = m.forward(lat.cuda(), 0.4375).clone()
             torch.cuda.synchronize()

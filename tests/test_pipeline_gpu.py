@@ -73,11 +73,16 @@ def test_full_pipeline_end_to_end_tiny(tmp_path):
     cam = torch.load(os.path.join(cache, "camera_info.pth"), weights_only=True)
     c2ws, intr = cam["c2ws"].numpy(), cam["intrinsics"].numpy()
     mvp = G.mvp_matrices(c2ws, intr, perspective=False)
-    clip = G.transform_points(pv, mvp)
+    # the conditions are rendered from the RAW input mesh (reference pipeline.py:573), normalised by export_condition's own scale_to_bbox(0.95)
+    rv_, rf_, _, _ = meshes.load_obj(mesh_path)
+    rv_ = rv_.astype(np.float32)
+    lo, hi = rv_.min(0), rv_.max(0)
+    rv_ = ((rv_ - np.float32(0.5) * (lo + hi)) / ((hi - lo).max() / np.float32(2.0 * 0.95))).astype(np.float32)
+    clip = G.transform_points(rv_, mvp)
     alpha_img = np.asarray(Image.open(os.path.join(cache, "mv_alpha.png")))
     for v in range(6):
         r, c = divmod(v, 3)
-        ref = (G.rasterize(clip[v], pf, 512, 512)[..., 3] > 0)
+        ref = (G.rasterize(clip[v], rf_, 512, 512)[..., 3] > 0)
         got = alpha_img[r * 512:(r + 1) * 512, c * 512:(c + 1) * 512] > 0
         assert np.array_equal(got, ref), "condition alpha view %d" % v
     # ---- back-projection stage vs the CPU oracle on the same mv_rgb.png
@@ -163,3 +168,44 @@ def test_full_pipeline_4_and_8_view_variants(tmp_path, n_views, view_px):
     visable = np.asarray(Image.open(os.path.join(cache, "wo_LTM/visable_uv_mask.png"))) > 127
     assert np.array_equal(np.asarray(Image.open(os.path.join(cache, "wo_LTM/valid_uv_mask.png"))) > 127, mask2d)
     assert np.array_equal(visable, vis.any(0)), "union visibility mask (%d views)" % n_views
+
+
+def test_condition_render_uses_the_raw_input_mesh_not_the_processed_one(tmp_path):
+    """/root/reference/pipeline.py:573: step_1_1 renders the geometry conditions (the DiT's control image) from `input_mesh_path`, not from
+    cache/processed_mesh.obj.  A UV-less 3000-face input is subdivided by preprocess_blank_mesh (min_faces = 20 000), so the two differ: the
+    alpha grid must be the oracle's coverage of the RAW mesh (bbox-normalised by export_condition itself)."""
+    from unitex_amd.flux.pipeline import PBRFluxPipeline
+    from unitex_amd.flux.synthetic import SyntheticFluxStateDict
+    from unitex_amd.flux.transformer import FluxDiT, FluxShape
+    from unitex_amd.pipeline import CustomRGBTextureFullPipeline
+    from unitex_amd.texturetools import meshes
+    dev = "cuda:0"
+    shape = FluxShape(num_heads=2, num_double=1, num_single=1, joint_dim=64, pooled_dim=64)
+    flux = PBRFluxPipeline(FluxDiT(SyntheticFluxStateDict(shape, seed=0, device=dev), shape, device=dev), fakes.FakeVAE(), device=dev)
+    pipe = CustomRGBTextureFullPipeline(seed=63, pipeline=flux, num_inference_steps=2, atlas_size=256, device=dev, view_size=256)
+    verts, faces, _ = meshes.sphere_with_faces(3000)
+    verts = (verts * np.array([1.0, 0.6, 0.8], np.float32) + 0.25).astype(np.float32)       # an ellipsoid, off-centre
+    mesh_path = str(tmp_path / "raw.obj")
+    meshes.save_obj(mesh_path, verts, faces, None)
+    cache = str(tmp_path / "cache"); os.makedirs(cache)
+    calls = []
+    real = pipe.render_geometry_images
+    pipe.render_geometry_images = lambda d, p, *a, **k: (calls.append(p), real(d, p, *a, **k))[1]
+    pipe.infer_mv = lambda *a, **k: None                       # the DiT is not the subject here
+    pipe.preprocess_reference_image = lambda *a, **k: None
+    pipe.step_1_1(cache_dir=cache, input_image_path=None, input_mesh_path=mesh_path)
+    assert calls == [mesh_path]
+    pv, pf, _, _ = meshes.load_obj(os.path.join(cache, "processed_mesh.obj"))
+    assert len(pf) >= 20000 > len(faces)                       # the processed mesh IS a different mesh
+    cam = torch.load(os.path.join(cache, "camera_info.pth"), weights_only=True)
+    mvp = G.mvp_matrices(cam["c2ws"].numpy(), cam["intrinsics"].numpy(), perspective=False)
+    rv_, rf_, _, _ = meshes.load_obj(mesh_path)
+    rv_ = rv_.astype(np.float32)
+    lo, hi = rv_.min(0), rv_.max(0)
+    rv_ = ((rv_ - np.float32(0.5) * (lo + hi)) / ((hi - lo).max() / np.float32(2.0 * 0.95))).astype(np.float32)
+    clip = G.transform_points(rv_, mvp)
+    alpha_img = np.asarray(Image.open(os.path.join(cache, "mv_alpha.png")))
+    for v in range(6):
+        r, c = divmod(v, 3)
+        ref = G.rasterize(clip[v], rf_, 256, 256)[..., 3] > 0
+        assert np.array_equal(alpha_img[r * 256:(r + 1) * 256, c * 256:(c + 1) * 256] > 0, ref), "condition alpha of the raw mesh, view %d" % v

@@ -402,11 +402,10 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(AttnParams p) {
 template <int NW, int PRESC, int FAST>
 static int launch_variant(const AttnParams& p0, hipStream_t stream) {
     constexpr int lds = ATT_LDS_BYTES(2);
-    static bool attr_set = false;
-    if (!attr_set) {
+    UTX_ONCE_PER_DEVICE(attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<NW, PRESC, FAST>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -3;
-        attr_set = true;
+        UTX_ONCE_DONE(attr_set);
     }
     AttnParams p = p0;
     p.nqb = (p.S + 32 * NW - 1) / (32 * NW);

@@ -335,11 +335,10 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(AttnParams p, int n_ite
 
 template <int PRESC, int TPB, int VAR = 0>
 static int launch_glds(AttnParams p, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    UTX_ONCE_PER_DEVICE(attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_glds_kernel<PRESC, TPB, VAR>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, AG_LDS(TPB)) != hipSuccess) return -3;
-        attr_set = true;
+        UTX_ONCE_DONE(attr_set);
     }
     p.nqb = ((p.Sq > 0 ? p.Sq : p.S) + 255) / 256;
     p.w_base = 0; p.nsplit = 1; p.tiles_per_split = 0; p.part_o = nullptr; p.part_lse = nullptr;
@@ -347,9 +346,8 @@ static int launch_glds(AttnParams p, hipStream_t stream) {
     // Tail split: the workgroups of the last, partly filled round are cut along the keys so that the round costs a fraction
     // of a workgroup's duration instead of a whole one (S = 13 824: 1296 workgroups = 5 rounds of 256 CUs + 16 -> the 16 run
     // as 256 sixteenths; S = 50 688: 18 rounds + 144 -> 1008 sevenths).  UTX_ATTN_TAILSPLIT=0 disables it.
-    static int ncu = 0;
+    const int ncu = utx_ncu();
     const int enabled = g_utx_opt.attn_tailsplit != 0;
-    if (!ncu) { int dev = 0; hipDeviceProp_t pr; ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
     const int nfull = (nwg / ncu) * ncu, r = nwg - nfull;
     const int nt_all = (p.S + AG_KVB - 1) / AG_KVB;
     int best_ns = 1;

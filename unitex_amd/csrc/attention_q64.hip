@@ -339,11 +339,10 @@ __global__ __launch_bounds__(256) void attn_fwd_q64_kernel(AttnParams p) {
 
 template <int PRESC, int ABL>
 static int launch_q64(AttnParams p, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    UTX_ONCE_PER_DEVICE(attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_q64_kernel<PRESC, ABL>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, AQ_LDS) != hipSuccess) return -3;
-        attr_set = true;
+        UTX_ONCE_DONE(attr_set);
     }
     p.nqb = (p.S + 255) / 256;
     hipLaunchKernelGGL((attn_fwd_q64_kernel<PRESC, ABL>), dim3(p.nqb * p.H), dim3(256), AQ_LDS, stream, p);

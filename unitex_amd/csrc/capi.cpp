@@ -5,6 +5,7 @@
 #include <string.h>
 #include <string>
 #include <stdlib.h>
+#include <mutex>
 #include "kernels.h"
 
 UtxOptions g_utx_opt = {1, 2, 0, 1, 1, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0};
@@ -27,15 +28,17 @@ static const bool kAblationBuild = true;
 static const bool kAblationBuild = false;
 #endif
 
+// The environment is read exactly once, by whichever entry point touches the options first (utx_init, utx_set_option, utx_get_option,
+// utx_gemm_plan): a utx_set_option made before the first utx_init must not be overwritten by a later read of the same UTX_* variable.
 static void options_from_env_once() {
-    static bool done = false;
-    if (done) return;
-    done = true;
-    for (const OptName& o : kOptions) {
-        if (o.ablation && !kAblationBuild) continue;      // wrong-result switches do not exist in the product library
-        const char* e = getenv(o.name);
-        if (e && *e) g_utx_opt.*(o.field) = atoi(e);
-    }
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const OptName& o : kOptions) {
+            if (o.ablation && !kAblationBuild) continue;      // wrong-result switches do not exist in the product library
+            const char* e = getenv(o.name);
+            if (e && *e) g_utx_opt.*(o.field) = atoi(e);
+        }
+    });
 }
 
 struct utx_ctx {
@@ -78,6 +81,7 @@ int utx_init(int device, utx_ctx** out) {
 
 int utx_set_option(const char* name, int value) {
     if (!name) return -2;
+    options_from_env_once();
     for (const OptName& o : kOptions)
         if (strcmp(name, o.name) == 0) {
             if (o.ablation && !kAblationBuild) return -7;
@@ -89,6 +93,7 @@ int utx_set_option(const char* name, int value) {
 
 int utx_get_option(const char* name, int* value) {
     if (!name || !value) return -2;
+    options_from_env_once();
     for (const OptName& o : kOptions)
         if (strcmp(name, o.name) == 0) {
             if (o.ablation && !kAblationBuild) return -7;

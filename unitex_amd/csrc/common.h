@@ -54,3 +54,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + j;
 }
+
+// ---- host side: one-time launch setup is PER DEVICE (hipFuncSetAttribute applies to the current device; CU counts may differ between
+// partitions): call sites keep a bit mask indexed by device instead of a process-wide flag
+static inline int utx_device() { int d = 0; return (hipGetDevice(&d) == hipSuccess && d >= 0 && d < 64) ? d : 0; }
+static inline int utx_ncu() {
+    static int tab[64] = {};
+    const int d = utx_device();
+    if (!tab[d]) { hipDeviceProp_t pr; tab[d] = (hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; }
+    return tab[d];
+}
+#define UTX_ONCE_PER_DEVICE(flag_) static unsigned long long flag_ = 0; const int flag_##_dev = utx_device(); if (!((flag_ >> flag_##_dev) & 1ull))
+#define UTX_ONCE_DONE(flag_) flag_ |= 1ull << flag_##_dev

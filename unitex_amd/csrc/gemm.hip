@@ -701,11 +701,10 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvParams p) {
 template <int BM, int BN, int NWM, int NWN, bool CONV = false, bool MX8 = false>
 static int launch_gemm(GemmParams p, hipStream_t stream, int group_env, int dbg_env) {
     constexpr int LDS = 2 * (BM + BN) * GM_BK * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
+    UTX_ONCE_PER_DEVICE(attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<BM, BN, NWM, NWN, CONV, MX8>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
-        attr_set = true;
+        UTX_ONCE_DONE(attr_set);
     }
     const int ntm = (p.M + BM - 1) / BM;
     const int ntn = (p.N + BN - 1) / BN;
@@ -718,11 +717,10 @@ static int launch_gemm(GemmParams p, hipStream_t stream, int group_env, int dbg_
 
 static int launch_gemm8(GemmParams p, hipStream_t stream, int group_env, int dbg_env) {
     constexpr int LDS = 131072;
-    static bool attr_set = false;
-    if (!attr_set) {
+    UTX_ONCE_PER_DEVICE(attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_8ph_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
-        attr_set = true;
+        UTX_ONCE_DONE(attr_set);
     }
     const int ntm = (p.M + 255) / 256, ntn = p.N / 256;
     int group_m = group_env > 0 ? group_env : GM_GROUP_M;
@@ -732,8 +730,7 @@ static int launch_gemm8(GemmParams p, hipStream_t stream, int group_env, int dbg
     const int tiles = ntm * ntn;
     // Tail split, opt-in (UTX_GEMM_TAILSPLIT=1): see G8Split.  Candidate when the last round is sparsely filled and K is long
     // enough that a tile's fixed cost (prologue + epilogue, ~10 us against ~1.4 us per K-tile) does not dominate.
-    static int ncu = 0;
-    if (!ncu) { int dev = 0; hipDeviceProp_t pr; ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
+    const int ncu = utx_ncu();
     const bool enabled = g_utx_opt.gemm_tailsplit == 1 && dbg_env == 0;
     const int nfull = (tiles / ncu) * ncu, r = tiles - nfull;
     int best_ks = 1;

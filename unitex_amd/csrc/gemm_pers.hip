@@ -529,16 +529,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_pers_kernel(GemmParams p, int 
 
 extern "C" int utx_launch_gemm_pers(GemmParams p, hipStream_t stream) {
     constexpr int LDS = 131072 + 8 * 1024;
-    static bool attr_set = false;
-    if (!attr_set) {
+    UTX_ONCE_PER_DEVICE(attr_set) {
         const void* ks[4] = {reinterpret_cast<const void*>(gemm256_pers_kernel<false, 0>), reinterpret_cast<const void*>(gemm256_pers_kernel<true, 0>),
                              reinterpret_cast<const void*>(gemm256_pers_kernel<false, 1>), reinterpret_cast<const void*>(gemm256_pers_kernel<true, 1>)};
         for (const void* k : ks)
             if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
-        attr_set = true;
+        UTX_ONCE_DONE(attr_set);
     }
-    static int ncu = 0;
-    if (!ncu) { int dev = 0; hipDeviceProp_t pr; ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
+    const int ncu = utx_ncu();
     const int ntm = (p.M + 255) / 256, ntn = p.N / 256;
     int group_m = g_utx_opt.gemm_group_m > 0 ? g_utx_opt.gemm_group_m : 4;
     if (group_m > ntm) group_m = ntm;
@@ -554,8 +552,7 @@ extern "C" int utx_launch_gemm_pers(GemmParams p, hipStream_t stream) {
     if (g_utx_opt.gemm_pers_sched == 2) sched = 1;
 #ifdef UTX_ABLATION
     if ((g_utx_opt.gemm_debug_abl & 16) && !p.gate) {
-        static bool a2 = false;
-        if (!a2) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_pers_kernel<false, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3; a2 = true; }
+        UTX_ONCE_PER_DEVICE(a2) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_pers_kernel<false, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3; UTX_ONCE_DONE(a2); }
         hipLaunchKernelGGL((gemm256_pers_kernel<false, 1, true>), dim3(grid), dim3(512), LDS, stream, p, tiles);
         return hipGetLastError() == hipSuccess ? 0 : -4;
     }

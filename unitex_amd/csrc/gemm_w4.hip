@@ -914,15 +914,13 @@ extern "C" void utx_gemm_w4_split_plan(const GemmParams* pp, int tiles, int grid
 
 extern "C" int utx_launch_gemm_w4(GemmParams p, hipStream_t stream) {
     constexpr int LDS = 2 * W4_STAGE + 4 * 8192;     // the ring + the four waves' C staging buffers = all 160 KB
-    static bool attr_set = false;
-    if (!attr_set) {
+    UTX_ONCE_PER_DEVICE(attr_set) {
         const void* ks[2] = {reinterpret_cast<const void*>(gemm256_w4_kernel<false>), reinterpret_cast<const void*>(gemm256_w4_kernel<true>)};
         for (const void* k : ks)
             if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
-        attr_set = true;
+        UTX_ONCE_DONE(attr_set);
     }
-    static int ncu = 0;
-    if (!ncu) { int dev = 0; hipDeviceProp_t pr; ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
+    const int ncu = utx_ncu();
     const int ntm = (p.M + 255) / 256, ntn = p.N / 256;
     // tile rows per L2 block of the tile order: wide outputs want narrow blocks (the B panel of a block is ntn tiles wide), mid-width ones taller
     // blocks; +1...2 % against a fixed 4 (profiles/r02_gemm_group_m_sweep.log)
@@ -950,11 +948,10 @@ extern "C" int utx_launch_gemm_w4(GemmParams p, hipStream_t stream) {
         if (p.K2 > 0 || p.qk_cols > 0 || (p.K % 64) || !p.a_scale || !p.b_scale || p.lds_a < (p.M + 127) / 128 || p.lds_b < p.N / 128 ||
             ((uintptr_t)p.a_scale & 15) || ((uintptr_t)p.b_scale & 15)) return -2;
         if (p.gate && (p.gelu_from < p.N || p.n_split < p.N)) return -2;
-        static bool ax = false;
-        if (!ax) {
+        UTX_ONCE_PER_DEVICE(ax) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_w4_kernel<false, 0, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess ||
                 hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_w4_kernel<true, 0, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
-            ax = true;
+            UTX_ONCE_DONE(ax);
         }
         if (p.gate) hipLaunchKernelGGL((gemm256_w4_kernel<true, 0, false, true>), dim3(grid), dim3(256), LDS, stream, p, tiles, trace_wg, sk_T, sk_S);
         else hipLaunchKernelGGL((gemm256_w4_kernel<false, 0, false, true>), dim3(grid), dim3(256), LDS, stream, p, tiles, trace_wg, sk_T, sk_S);
@@ -963,8 +960,7 @@ extern "C" int utx_launch_gemm_w4(GemmParams p, hipStream_t stream) {
         hipLaunchKernelGGL((gemm256_w4_kernel<true>), dim3(grid), dim3(256), LDS, stream, p, tiles, trace_wg, sk_T, sk_S);
     } else {
         if (p.qk_cols > 0) {
-            static bool aq = false;
-            if (!aq) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_w4_kernel<false, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3; aq = true; }
+            UTX_ONCE_PER_DEVICE(aq) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_w4_kernel<false, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3; UTX_ONCE_DONE(aq); }
             hipLaunchKernelGGL((gemm256_w4_kernel<false, 0, true>), dim3(grid), dim3(256), LDS, stream, p, tiles, trace_wg, sk_T, sk_S);
         } else
         hipLaunchKernelGGL((gemm256_w4_kernel<false>), dim3(grid), dim3(256), LDS, stream, p, tiles, trace_wg, sk_T, sk_S);

@@ -105,6 +105,7 @@ class FluxDiT:
         self._lora_active: List[Tuple[Dict, float]] = []
         self._lora_version = 0
         self.attn_events = None
+        self.gemm_events = None    # bench.py: list that receives (start event, end event, FLOPs) of every large-M GEMM launched on the main stream
         # double blocks: the text-token half (M = 512: a fraction of one round of tiles) runs on a second HIP stream beside the
         # image-token half, which fills CUs that the image GEMMs' tail rounds leave idle.  UTX_TXT_STREAM=0 keeps one stream.
         self.overlap_text = os.environ.get("UTX_TXT_STREAM", "1") != "0" and self.sp is None
@@ -234,6 +235,12 @@ class FluxDiT:
         if self.fp8_weights:
             self._quantize_fp8_weights()
 
+    # what to do with whole-module copies an adapter file carries beside its LoRA pairs (peft modules_to_save): "swap" = the switched-on adapter's
+    # copy replaces the base module for the pass (what peft's ModulesToSaveWrapper does for the ACTIVE adapter when the checkpoint is loaded
+    # through peft), "ignore" = keep the base module (what a loader that drops non-LoRA keys does), "error".  The reference loads adapters with
+    # diffusers' load_lora_weights of an unpinned version (pipeline.py:108-109, env.sh:12) [3p]: which of the two it does cannot be pinned here,
+    # so the choice is explicit, and applying a copy is logged loudly once per set_lora.
+    adapter_module_copies = os.environ.get("UTX_ADAPTER_MODULE_COPIES", "swap")
     FULL_OVERRIDE_MODULES = ("x_embedder",)   # the only parameterised entry of the trainer's modules_to_save (trainer.py:297-304)
 
     def _pack_full_overrides(self):
@@ -245,6 +252,15 @@ class FluxDiT:
         owners = {}
         for idx, (d, s) in enumerate(self._lora_active):
             full = d.get("__full__") if isinstance(d, dict) else None
+            if full and self.adapter_module_copies == "ignore":
+                continue
+            if full and self.adapter_module_copies == "error":
+                raise ValueError("adapter %d carries whole-module copies %s (adapter_module_copies='error')" % (idx, sorted(full)))
+            if full:
+                import warnings
+                warnings.warn("FluxDiT.set_lora: adapter %d replaces base module tensors %s with its own copies for this pass (peft modules_to_save "
+                              "semantics; FluxDiT.adapter_module_copies / UTX_ADAPTER_MODULE_COPIES = 'ignore' keeps the base module)" % (idx, sorted(full)),
+                              RuntimeWarning, stacklevel=3)
             for k, v in (full or {}).items():
                 mod, kind = k.rsplit(".", 1)
                 if mod not in self.FULL_OVERRIDE_MODULES:
@@ -645,7 +661,9 @@ class FluxDiT:
         return (0, S_img) if self.sp is None else local_slice(S_img, self.sp[0], self.sp[1])
 
     def set_output_rows(self, n):
-        """Only the first n image tokens' prediction will be read from forward()'s result (None = all; call before set_conditioning).
+        """Only the first n image tokens' prediction will be read from forward()'s result (None = all).  Call it BETWEEN set_positions and
+        set_conditioning: set_positions starts a new job and resets it to None, so a later user of the same FluxDiT never inherits a previous
+        caller's pruning (rows >= n of the result are undefined).
         The texturing pipeline discards the prediction of the condition tokens: the condition tail of the latents is re-pinned before
         every transformer call and cut off at the end (flux_piplines/texturing/pipeline.py:645,660,684), so in the LAST block -- whose
         output no later block attends to -- only the noise tokens need a query, an MLP row and an output projection, and the final
@@ -657,6 +675,7 @@ class FluxDiT:
         """Position ids of the joint sequence cat(txt_ids, img_ids) (FULL tensors, also under sequence parallelism).  The plan
         and the rotary tables are built by set_conditioning, which knows whether the text tokens can be deduplicated."""
         self._ids = (txt_ids.detach().to("cpu", torch.float32).contiguous(), img_ids.detach().to("cpu", torch.float32).contiguous())
+        self.out_rows = None          # sticky pruning would hand the next caller stale condition-token rows (set_output_rows)
 
     def set_conditioning(self, encoder_hidden_states, pooled_projections, guidance: float):
         if self._ids is None:
@@ -696,8 +715,19 @@ class FluxDiT:
         g1000 = _bf16_scalar(_bf16_scalar(guidance) * 1000.0)  # guidance.to(dtype) * 1000 in bf16 [3p]
         ws["gproj"].copy_(_timestep_proj(g1000))
 
-    def _launch(self, fn, d, st):
+    def _launch(self, fn, d, st, timed=True):
         """one stream-ordered launch of a plan entry that is a C-ABI call: (entry point, descriptor) or the MX fp8 quantiser"""
+        gev = self.gemm_events
+        if gev is not None and timed and fn is self.lib.utx_gemm_bf16 and d.M >= 4096:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            rc = fn(self.ctx.handle, C.byref(d), st)
+            b.record()
+            k2 = d.K2 * min(d.lora_n_limit, d.N) / d.N if (d.K2 > 0 and d.lora_n_limit > 0) else 0.0     # the LoRA K-segment runs on the columns < lora_n_limit
+            gev.append((a, b, 2.0 * d.M * d.N * (d.K + k2)))
+            if rc:
+                self.ctx.check(rc)
+            return
         if fn == "quant_mx8":
             x_, q_, s_ = d
             if hasattr(s_, "row_blocks"):
@@ -722,7 +752,7 @@ class FluxDiT:
                 self._side.wait_event(ev_fork)
                 st2 = C.c_void_p(self._side.cuda_stream)
                 for f2, d2 in side_ops:
-                    self._launch(f2, d2, st2)
+                    self._launch(f2, d2, st2, timed=False)
                 for f2, d2 in main_ops:
                     self._launch(f2, d2, st)
                 ev_join.record(self._side)
@@ -769,9 +799,7 @@ class FluxDiT:
                 if rc:
                     self.ctx.check(rc)
             else:
-                rc = fn(h, C.byref(d), st)
-                if rc:
-                    self.ctx.check(rc)
+                self._launch(fn, d, st)
 
     def forward(self, hidden_states, timestep: float, out: Optional[torch.Tensor] = None):
         """One transformer evaluation.  hidden_states [S_img, 64] bf16 (noise ++ condition tokens);

@@ -225,13 +225,18 @@ class RGBTextureFullPipeline(RGBTextureFullPipelineBase):
         print("step_1_1: %s, %s" % (input_image_path, input_mesh_path))
         self.preprocess_blank_mesh(cache_dir, input_mesh_path)
         self.preprocess_reference_image(cache_dir, input_image_path)
-        self.render_geometry_images(cache_dir, os.path.join(cache_dir, "processed_mesh.obj"))
+        # the geometry conditions (normal + CCM control image of the DiT) are rendered from the RAW input mesh, as the reference does
+        # (pipeline.py:573): export_condition normalises it to the same bbox itself, and a mesh that preprocess_blank_mesh decimates or
+        # subdivides still conditions the DiT on its original surface
+        self.render_geometry_images(cache_dir, input_mesh_path)
         self.infer_mv(cache_dir, os.path.join(cache_dir, "processed_image.png"), os.path.join(cache_dir, "mv_normal.png"),
                       os.path.join(cache_dir, "mv_ccm.png"))
 
     def step_2_1(self, cache_dir, input_image_path, input_mesh_path, clear_cache=False, *args, **kwargs):
         self.reproject_and_query_field(cache_dir, os.path.join(cache_dir, "processed_mesh.obj"), os.path.join(cache_dir, "mv_rgb.png"),
                                        os.path.join(cache_dir, "camera_info.pth"), inpainting=False)
+        if not clear_cache:     # pipeline.py:579-580
+            self.export_video(cache_dir, os.path.join(cache_dir, "textured_mesh.glb"), "textured_mesh.mp4")
 
     step_seq = ["step_1_1", "step_2_1"]
 

@@ -472,7 +472,11 @@ def unwrap_charts(verts, faces, atlas=2048, gutter=4.0, device="cuda:0", max_rou
     angle, <= 1/cos(63 deg) stretch) and the charts are shelf-packed at ONE texel density with `gutter` texels between them.  A
     chart that folds over itself in projection is detected by rasterising the atlas with the product's own rasteriser and counting
     texels per face; faces that lose their texels to another face of the same chart are split off into further charts (a few
-    rounds), so the result is bijective.  Returns verts [V,3] (shared positions), faces [F,3], uvs [3F,2] in [0,1], faces_uv [F,3]."""
+    rounds); faces that are STILL overlapped after `max_rounds` become one-triangle charts of their own in a final round (a single
+    triangle projected along its dominant axis cannot fold), so the atlas that is returned is bijective for every face the check can
+    see -- faces under 3 texels of UV area own too few texel centres to be counted and are not checked.  Should even the final round
+    leave overlapped faces (it cannot by construction) a RuntimeWarning says so instead of returning the atlas silently.
+    Returns verts [V,3] (shared positions), faces [F,3], uvs [3F,2] in [0,1], faces_uv [F,3]."""
     import torch
     from . import ops
     F = len(faces)
@@ -483,7 +487,7 @@ def unwrap_charts(verts, faces, atlas=2048, gutter=4.0, device="cuda:0", max_rou
     layer = np.zeros(F, np.int32)                     # fold-over layer: faces split off a chart get the next layer
     dev = torch.device(device)
     adj_d = torch.from_numpy(adj).to(dev)
-    for rnd in range(max_rounds):
+    for rnd in range(max_rounds + 1):
         key = (bucket + 6 * layer).astype(np.int32)
         chart = ops.chart_flood(adj_d, torch.from_numpy(key).to(dev)).cpu().numpy()
         ids, cidx = np.unique(chart, return_inverse=True)
@@ -519,9 +523,17 @@ def unwrap_charts(verts, faces, atlas=2048, gutter=4.0, device="cuda:0", max_rou
         owned = torch.bincount((rast[..., 3].long()).reshape(-1), minlength=F + 1)[1:].cpu().numpy()
         a2 = np.abs((uv[:, 1, 0] - uv[:, 0, 0]) * (uv[:, 2, 1] - uv[:, 0, 1]) - (uv[:, 2, 0] - uv[:, 0, 0]) * (uv[:, 1, 1] - uv[:, 0, 1])) * 0.5 * atlas * atlas
         lost = (a2 >= 3.0) & (owned < 0.5 * a2)
-        if not lost.any() or rnd == max_rounds - 1:
+        if not lost.any():
             break
-        layer = np.where(lost, layer + 1, layer).astype(np.int32)
+        if rnd == max_rounds:
+            import warnings
+            warnings.warn("unwrap_charts: %d faces still share texels with another face after the one-triangle fallback" % int(lost.sum()), RuntimeWarning)
+            break
+        if rnd == max_rounds - 1:       # last resort: every face that is still overlapped becomes a chart of its own (unique key -> no same-key neighbour)
+            layer = layer.copy()
+            layer[lost] = max_rounds + 1 + np.arange(int(lost.sum()), dtype=np.int32)
+        else:
+            layer = np.where(lost, layer + 1, layer).astype(np.int32)
     return verts.astype(np.float32), faces, uvs, f_uv
 
 

@@ -60,7 +60,12 @@ class VideoExporter:
         assert n_views == n_rows * n_cols, "Value Error: (n_views, n_rows, n_cols)=%s" % ((n_views, n_rows, n_cols),)
         assert not orbit and not perspective, "the texture pipeline renders orthographic box views (pipeline.py:200-214)"
         if isinstance(mesh_path, str):
-            verts, faces, _, _ = meshes.load_obj(mesh_path)
+            # the reference renders the conditions from the RAW input mesh (pipeline.py:573 -> export_nvdiffrast_video.py:900-999), any format its
+            # loader reads; here .obj (shared positions: normals are smoothed over position indices) and .glb
+            if mesh_path.lower().endswith(".obj"):
+                verts, faces, _, _ = meshes.load_obj(mesh_path)
+            else:
+                verts, faces, _, _ = meshes.load_mesh(mesh_path)
         else:
             verts, faces = mesh_path
         verts = torch.as_tensor(verts, dtype=torch.float32)
