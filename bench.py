@@ -402,7 +402,7 @@ def main():
                                     "launches_timed": len(gemm_ev), "sum_ms_per_step": g_ms, "flops_timed": g_fl,
                                     "flops_linears_nominal_24D2S57": lin_nominal, "share_of_linear_flops_timed": g_fl / lin_nominal,
                                     "timed_in": "one eager step after the timed region: HIP events on the launch stream around every GEMM with M >= 4096 "
-                                                "(2 M N (K + K2) FLOP each: the LoRA K-segment counts, LoRA-down products and the text-side GEMMs on the second stream do not)",
+                                                "(2 M N (K + K2) FLOP each, the LoRA K-segment and the LoRA-down products x A^T included; the text-side GEMMs on the second stream are not timed)",
                                     "share_of_step_time": g_ms / (dt / args.steps * 1e3)}
         if exchange:
             out["config"]["exchange"] = exchange

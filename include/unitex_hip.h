@@ -65,9 +65,10 @@ int utx_is_ablation_build(void);
  * softmax_scale > 0: the reference's scale (1/sqrt(128)); softmax_scale == 0: Q was pre-multiplied by
  * scale*log2(e) by utx_qkv_post (q_scale) and scores are used as base-2 exponents directly.
  * One call may issue up to three stream-ordered launches (full rounds of workgroups, the key-split tail round, its merge).
- * The tail round uses a library-owned scratch buffer per device, grown with hipMalloc on the first call that needs it:
- * make one eager call per (H, S) before capturing the stream into a HIP graph.  Calls on the same device must not run
- * concurrently on different streams (the scratch is shared). */
+ * The tail round needs scratch.  utx_attn_fwd_bf16_ws takes it from the caller (utx_attn_workspace_bytes: nothing is allocated on the
+ * launch path, re-entrant per stream / buffer).  The entry points without a workspace argument use a buffer owned by the CONTEXT, grown
+ * with hipMalloc by the first call that needs more (never while the stream is being captured: such a launch stays unsplit -- same
+ * result up to one bf16 rounding of the tail rows); calls through one context must not run concurrently on different streams. */
 int utx_attn_fwd_bf16(utx_ctx* ctx, const void* q, const void* k, const void* vt, void* o,
                       long q_hs, long q_ss, long k_hs, long k_ss, long vt_hs, long vt_ds, long o_ss,
                       int H, int S, float softmax_scale, utx_stream stream);
@@ -86,6 +87,15 @@ int utx_attn_fwd_bf16_kb(utx_ctx* ctx, const void* q, const void* k, const void*
 int utx_attn_fwd_bf16_kbq(utx_ctx* ctx, const void* q, const void* k, const void* vt, void* o,
                           long q_hs, long q_ss, long k_hs, long k_ss, long vt_hs, long vt_ds, long o_ss,
                           int H, int S_q, int S_kv, float softmax_scale, float key_bias_log2, int key_bias_period, utx_stream stream);
+/* The same with CALLER-OWNED scratch for the key-split tail round: work >= utx_attn_workspace_bytes(ctx, H, S_q, S_kv) bytes, 16-byte aligned, used only
+ * by the launches of this call (stream-ordered).  work == NULL or too small: the tail round is not split.  utx_attn_plan (pure host arithmetic,
+ * no device): out = {workgroups, workgroups in full rounds of n_cus, key ranges per tail workgroup (1 = not split), 64-key tiles per range}. */
+int utx_attn_fwd_bf16_ws(utx_ctx* ctx, const void* q, const void* k, const void* vt, void* o,
+                         long q_hs, long q_ss, long k_hs, long k_ss, long vt_hs, long vt_ds, long o_ss,
+                         int H, int S_q, int S_kv, float softmax_scale, float key_bias_log2, int key_bias_period,
+                         void* work, size_t work_bytes, utx_stream stream);
+size_t utx_attn_workspace_bytes(utx_ctx* ctx, int H, int S_q, int S_kv);
+int utx_attn_plan(int H, int S_q, int S_kv, int n_cus, int out[4]);
 
 /* C = epi(alpha * (A B^T + A2 B2^T) + bias): bf16 GEMM, fp32 accumulate, fused epilogues.
  * Replaces every nn.Linear (+ peft LoRA branch, + GELU, + gated residual) inside the FLUX blocks

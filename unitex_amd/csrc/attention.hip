@@ -421,7 +421,8 @@ static int attn_fast() { return g_utx_opt.attn_fast; }
 // already base-2 exponents and a probability is a single v_exp_f32.
 extern "C" int utx_launch_attn_fwd(const void* q, const void* k, const void* vt, void* o,
                                    long q_hs, long q_ss, long k_hs, long k_ss, long vt_hs, long vt_ds,
-                                   long o_ss, int H, int S, int Sq, float scale, float key_bias_log2, int key_bias_period, hipStream_t stream) {
+                                   long o_ss, int H, int S, int Sq, float scale, float key_bias_log2, int key_bias_period, void* work, size_t work_bytes,
+                                   hipStream_t stream) {
     if (S <= 0 || H <= 0 || scale < 0.f || key_bias_period < 0 || Sq < 0 || Sq > S) return -1;
     if (Sq == S) Sq = 0;
     if ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)vt)) & 15) return -2;                       // 16-byte aligned bases (LDS-DMA / b128 loads)
@@ -435,6 +436,7 @@ extern "C" int utx_launch_attn_fwd(const void* q, const void* k, const void* vt,
     const bool presc = (scale == 0.f);
     p.flags = nullptr; p.flag_hs = 0;
     p.key_bias_log2 = key_bias_log2; p.key_bias_period = key_bias_period;
+    p.work = work; p.work_bytes = work_bytes;
     // key multiplicity and a query count below the key count exist in the default (LDS-DMA staged) kernel only
     if ((key_bias_log2 != 0.f || Sq != 0) && (g_utx_opt.attn_glds == 0 || g_utx_opt.attn_q64 == 1 || g_utx_opt.attn_tpb != 1)) return -2;
     // opt-in: the 4 x 64 kernel (attention_q64.hip) followed by its repair pass; it needs whole 64-key tiles

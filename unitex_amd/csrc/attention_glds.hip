@@ -135,6 +135,12 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) asm volatile("" : "+v"(qf[kk]));
 
+    // VAR 6 (ablation build, correct results): STATIC priority -- the second-dispatched half of the workgroup (waves 4-7) is the arbitration loser of
+    // every segment (MI355X_MICROARCH.md, "Two waves per SIMD", item 4): one s_setprio 1 for that half, no per-segment flips.  MEASURED AND NOT
+    // ADOPTED (profiles/r03_attn_variants_v0.log): 25.580 vs 25.380 ms at S = 50 240 (-0.8 %), equal at S = 13 376 -- that lever belongs to a loop whose
+    // halves alternate compute and load segments behind barriers; here all eight waves run the same interleaved stream and the per-tile flips
+    // (prio 1 while computing, 0 at the barrier) already are the better arbitration
+    if (VAR == 6 && wave >= 4) __builtin_amdgcn_s_setprio(1);
     for (int u = 0; u < ngrp; ++u) {
       const int gs = (u & 1) * TPB;                      // first ring slot of this group
 #pragma unroll
@@ -195,7 +201,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
         // S0: QK(0); block-1 K fragments stream in behind the MFMAs
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) kfa[kk] = *reinterpret_cast<const bf16x8*>(kb + kx[kk]);
-        if (VAR != 1) __builtin_amdgcn_s_setprio(1);
+        if (VAR != 1 && VAR != 6) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
             if (VAR == 3) kfb[kk] = kfa[kk];   /* ablation: half of the K fragment reads removed (wrong results) */
@@ -257,45 +263,53 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
             AG_MM(oacc[i & 3], vfb[i], pb[2 + (i >> 2)], oacc[i & 3])
-        if (VAR != 1) __builtin_amdgcn_s_setprio(0);
+        if (VAR != 1 && VAR != 6) __builtin_amdgcn_s_setprio(0);
       }
       __syncthreads();     // this group fully read by every wave; the next group (DMA) retired by the vmcnt(0) of this fence
     }
 
-    // ---- epilogue: lane (q, h) holds O[q][32db + 8a + 4h + c], r = 4a + c
+    // ---- epilogue: lane (q, h) holds O[q][32db + 8a + 4h + c], r = 4a + c -- 8 bytes of a row per (db, a), the other half-wave the neighbouring 8.
+    // Packed pairs of the groups a = 2j / 2j+1 are exchanged between the half-waves (v_permlane32_swap): lanes 0-31 then hold columns 16j .. 16j+7
+    // of the 32-column block, lanes 32-63 columns 16j+8 .. 16j+15 -> ONE 16-byte store instead of two 8-byte ones (MI355X_MICROARCH.md T21: the
+    // store tail of this layout is store-ISSUE-bound; the same exchange as the GEMM epilogue's).  MEASURED AND NOT ADOPTED (round 3,
+    // profiles/r03_attn_variants_v0.log, same process, interleaved): 25.380 vs 25.380 ms at S = 50 240, 1.889 vs 1.867 ms at S = 13 376 (-1.1 %) --
+    // with 785 key tiles per workgroup the epilogue is ~1 % of a workgroup's life and the 16 swaps cost what the 8 saved stores bought.  The
+    // default keeps the 8-byte stores; VAR 7 (ablation build) is the widened form, bit-identical.
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
     const int qrow = q0 + lq;
+#define AG_STORE_ROW(dst_, wide_)                                                                            \
+    do {                                                                                                     \
+        if (wide_) {                                                                                         \
+            bf16_t* const o16_ = (dst_) + 8 * lh;                                                            \
+            _Pragma("unroll") for (int db = 0; db < 4; ++db)                                                 \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                  \
+                const uint32_t w00_ = pack2bf(oacc[db][8 * j + 0] * inv, oacc[db][8 * j + 1] * inv), w01_ = pack2bf(oacc[db][8 * j + 2] * inv, oacc[db][8 * j + 3] * inv); \
+                const uint32_t w10_ = pack2bf(oacc[db][8 * j + 4] * inv, oacc[db][8 * j + 5] * inv), w11_ = pack2bf(oacc[db][8 * j + 6] * inv, oacc[db][8 * j + 7] * inv); \
+                auto s0_ = __builtin_amdgcn_permlane32_swap(w00_, w10_, false, false);                       \
+                auto s1_ = __builtin_amdgcn_permlane32_swap(w01_, w11_, false, false);                       \
+                if (qrow < Sq) *reinterpret_cast<uint4*>(o16_ + 32 * db + 16 * j) = make_uint4(s0_[0], s1_[0], s0_[1], s1_[1]); \
+            }                                                                                                \
+        } else if (qrow < Sq) {                                                                              \
+            bf16_t* const o8_ = (dst_) + 4 * lh;                                                             \
+            _Pragma("unroll") for (int db = 0; db < 4; ++db)                                                 \
+            _Pragma("unroll") for (int a = 0; a < 4; ++a) {                                                  \
+                uint2 v;                                                                                     \
+                v.x = pack2bf(oacc[db][4 * a + 0] * inv, oacc[db][4 * a + 1] * inv);                         \
+                v.y = pack2bf(oacc[db][4 * a + 2] * inv, oacc[db][4 * a + 3] * inv);                         \
+                *reinterpret_cast<uint2*>(o8_ + 32 * db + 8 * a) = v;                                        \
+            }                                                                                                \
+        }                                                                                                    \
+    } while (0)
     if (nsp > 1) {
         // partial result of this key range: normalised rows (bf16) + log2-sum-exp; attn_merge_kernel combines the ranges
         const long prow = ((long)item * nsp + split) * 256 + wave * 32 + lq;
-        if (qrow < Sq) {
-            bf16_t* op = p.part_o + prow * 128 + 4 * lh;
-#pragma unroll
-            for (int db = 0; db < 4; ++db)
-#pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    uint2 v;
-                    v.x = pack2bf(oacc[db][4 * a + 0] * inv, oacc[db][4 * a + 1] * inv);
-                    v.y = pack2bf(oacc[db][4 * a + 2] * inv, oacc[db][4 * a + 3] * inv);
-                    *reinterpret_cast<uint2*>(op + 32 * db + 8 * a) = v;
-                }
-            if (lh == 0) p.part_lse[prow] = (PRESC ? m_run : m_run * c2) + __builtin_amdgcn_logf(l_tot);
-        }
+        AG_STORE_ROW(p.part_o + prow * 128, VAR == 7);
+        if (qrow < Sq && lh == 0) p.part_lse[prow] = (PRESC ? m_run : m_run * c2) + __builtin_amdgcn_logf(l_tot);
         return;
     }
-    if (qrow < Sq) {
-        bf16_t* op = p.o + (long)qrow * p.o_ss + head * 128 + 4 * lh;
-#pragma unroll
-        for (int db = 0; db < 4; ++db)
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                uint2 v;
-                v.x = pack2bf(oacc[db][4 * a + 0] * inv, oacc[db][4 * a + 1] * inv);
-                v.y = pack2bf(oacc[db][4 * a + 2] * inv, oacc[db][4 * a + 3] * inv);
-                *reinterpret_cast<uint2*>(op + 32 * db + 8 * a) = v;
-            }
-    }
+    const bool wide = VAR == 7 && ((p.o_ss & 7) == 0) && ((((uintptr_t)p.o) & 15) == 0);     // wave-uniform
+    AG_STORE_ROW(p.o + (long)(qrow < Sq ? qrow : 0) * p.o_ss + head * 128, wide);
 }
 
 // combine the key ranges of the tail items: out = sum_i 2^(lse_i - M) O_i / sum_i 2^(lse_i - M).  One thread per (query, 8 channels).
@@ -333,6 +347,41 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(AttnParams p, int n_ite
     *reinterpret_cast<uint4*>(p.o + (long)qrow * p.o_ss + head * 128 + 8 * c8) = o;
 }
 
+// Tail split, the plan (pure host arithmetic; C ABI: utx_attn_plan): nwg = ceil(Sq / 256) * H workgroups; the r = nwg % ncu workgroups of the last, partly
+// filled round are cut along the keys into ns ranges of tps 64-key tiles so that the round costs a fraction of a workgroup's duration instead of a
+// whole one (S = 13 824: 1296 workgroups = 5 rounds of 256 CUs + 16 -> the 16 run as 256 sixteenths; S = 50 688: 18 rounds + 144 -> 1008 sevenths;
+// sequence parallel over 8 ranks, 3 heads x 198 query blocks = 594 = 2 rounds + 82 -> 246 thirds).  UTX_ATTN_TAILSPLIT=0 disables it.
+// out = {nwg, nfull, ns (1 = not split), tps}
+extern "C" void utx_attn_split_plan_impl(int H, int Sq, int S, int ncu, int out[4]) {
+    const int nqb = ((Sq > 0 ? Sq : S) + 255) / 256;
+    const int nwg = nqb * H;
+    const int nfull = (nwg / ncu) * ncu, r = nwg - nfull;
+    const int nt_all = (S + AG_KVB - 1) / AG_KVB;
+    int best_ns = 1;
+    if (g_utx_opt.attn_tailsplit != 0 && nfull > 0 && r > 0) {
+        double best = 0.92;                                    // worth it only below ~0.9 of a round
+        for (int ns = 2; ns <= 16; ++ns) {
+            if (r * ns > 2048 || (nt_all + ns - 1) / ns < 12) break;      // workspace bound; >= 12 tiles per split
+            const double cost = (double)((r * ns + ncu - 1) / ncu) * (1.0 / ns + 0.02);   // rounds x (share + fixed cost of a workgroup)
+            if (cost < best) { best = cost; best_ns = ns; }
+        }
+    }
+    out[0] = nwg; out[1] = nfull; out[2] = 1; out[3] = nt_all;
+    if (best_ns > 1) {
+        const int tps = (nt_all + best_ns - 1) / best_ns;
+        out[2] = (nt_all + tps - 1) / tps;                     // every split owns at least one tile
+        out[3] = tps;
+    }
+}
+// bytes of caller-owned scratch the tail split of this shape needs (0: the launch is never split): normalised partial rows (bf16) + log2-sum-exp (f32)
+extern "C" size_t utx_attn_workspace_bytes_impl(int H, int Sq, int S, int ncu) {
+    int pl[4];
+    utx_attn_split_plan_impl(H, Sq, S, ncu, pl);
+    if (pl[2] <= 1) return 0;
+    const size_t rows = (size_t)(pl[0] - pl[1]) * pl[2] * 256;
+    return rows * 128 * sizeof(bf16_t) + rows * sizeof(float);
+}
+
 template <int PRESC, int TPB, int VAR = 0>
 static int launch_glds(AttnParams p, hipStream_t stream) {
     UTX_ONCE_PER_DEVICE(attr_set) {
@@ -342,43 +391,21 @@ static int launch_glds(AttnParams p, hipStream_t stream) {
     }
     p.nqb = ((p.Sq > 0 ? p.Sq : p.S) + 255) / 256;
     p.w_base = 0; p.nsplit = 1; p.tiles_per_split = 0; p.part_o = nullptr; p.part_lse = nullptr;
-    const int nwg = p.nqb * p.H;
-    // Tail split: the workgroups of the last, partly filled round are cut along the keys so that the round costs a fraction
-    // of a workgroup's duration instead of a whole one (S = 13 824: 1296 workgroups = 5 rounds of 256 CUs + 16 -> the 16 run
-    // as 256 sixteenths; S = 50 688: 18 rounds + 144 -> 1008 sevenths).  UTX_ATTN_TAILSPLIT=0 disables it.
-    const int ncu = utx_ncu();
-    const int enabled = g_utx_opt.attn_tailsplit != 0;
-    const int nfull = (nwg / ncu) * ncu, r = nwg - nfull;
-    const int nt_all = (p.S + AG_KVB - 1) / AG_KVB;
-    int best_ns = 1;
-    if (enabled && TPB == 1 && VAR == 0 && !p.flags && nfull > 0 && r > 0) {
-        double best = 0.92;                                    // worth it only below ~0.9 of a round
-        for (int ns = 2; ns <= 16; ++ns) {
-            if (r * ns > 2048 || (nt_all + ns - 1) / ns < 12) break;      // workspace bound; >= 12 tiles per split
-            const double cost = (double)((r * ns + ncu - 1) / ncu) * (1.0 / ns + 0.02);   // rounds x (share + fixed cost of a workgroup)
-            if (cost < best) { best = cost; best_ns = ns; }
-        }
-    }
-    if (best_ns == 1) {
+    int pl[4] = {p.nqb * p.H, 0, 1, 0};
+    if (TPB == 1 && (VAR == 0 || VAR == 6 || VAR == 7) && !p.flags) utx_attn_split_plan_impl(p.H, p.Sq, p.S, utx_ncu(), pl);
+    const int nwg = pl[0], nfull = pl[1], ns = pl[2], tps = pl[3], r = nwg - nfull;
+    // the scratch of the split is CALLER-OWNED (utx_attn_fwd_bf16_ws; the legacy entry points pass the context's own buffer, grown outside of any
+    // capture): nothing is allocated here, a launch whose scratch is missing or too small runs unsplit -- same result up to one bf16 rounding of the
+    // tail rows, a fraction of a round slower
+    const size_t rows = (size_t)r * ns * 256;
+    if (ns <= 1 || !p.work || p.work_bytes < rows * (128 * sizeof(bf16_t) + sizeof(float))) {
         hipLaunchKernelGGL((attn_fwd_glds_kernel<PRESC, TPB, VAR>), dim3(nwg), dim3(512), AG_LDS(TPB), stream, p);
         return hipGetLastError() == hipSuccess ? 0 : -4;
     }
-    const int tps = (nt_all + best_ns - 1) / best_ns;
-    const int ns = (nt_all + tps - 1) / tps;                   // every split owns at least one tile
-    static bf16_t* ws_o[16] = {nullptr}; static float* ws_l[16] = {nullptr}; static size_t ws_cap[16] = {0};
-    int dev = 0; if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return -5;
-    const size_t rows = (size_t)r * ns * 256;
-    if (ws_cap[dev] < rows) {
-        if (ws_o[dev]) (void)hipFree(ws_o[dev]);
-        if (ws_l[dev]) (void)hipFree(ws_l[dev]);
-        ws_o[dev] = nullptr; ws_l[dev] = nullptr; ws_cap[dev] = 0;
-        if (hipMalloc((void**)&ws_o[dev], rows * 128 * sizeof(bf16_t)) != hipSuccess) return -5;
-        if (hipMalloc((void**)&ws_l[dev], rows * sizeof(float)) != hipSuccess) return -5;
-        ws_cap[dev] = rows;
-    }
     hipLaunchKernelGGL((attn_fwd_glds_kernel<PRESC, TPB, VAR>), dim3(nfull), dim3(512), AG_LDS(TPB), stream, p);
     AttnParams t = p;
-    t.w_base = nfull; t.nsplit = ns; t.tiles_per_split = tps; t.part_o = ws_o[dev]; t.part_lse = ws_l[dev];
+    t.w_base = nfull; t.nsplit = ns; t.tiles_per_split = tps;
+    t.part_o = (bf16_t*)p.work; t.part_lse = (float*)((char*)p.work + rows * 128 * sizeof(bf16_t));
     hipLaunchKernelGGL((attn_fwd_glds_kernel<PRESC, TPB, VAR>), dim3(r * ns), dim3(512), AG_LDS(TPB), stream, t);
     const long mt = (long)r * 256 * 16;
     hipLaunchKernelGGL(attn_merge_kernel, dim3((unsigned)((mt + 255) / 256)), dim3(256), 0, stream, t, r);
@@ -395,7 +422,9 @@ extern "C" int utx_launch_attn_fwd_glds(const AttnParams* p, int presc, hipStrea
       if (var == 2 && presc) return launch_glds<1, 1, 2>(*p, stream);
       if (var == 3 && presc) return launch_glds<1, 1, 3>(*p, stream);
       if (var == 4 && presc) return launch_glds<1, 1, 4>(*p, stream);
-      if (var == 5 && presc) return launch_glds<1, 1, 5>(*p, stream); }
+      if (var == 5 && presc) return launch_glds<1, 1, 5>(*p, stream);
+      if (var == 6 && presc) return launch_glds<1, 1, 6>(*p, stream);      // static priority for waves 4-7 (correct results)
+      if (var == 7 && presc) return launch_glds<1, 1, 7>(*p, stream); }    // 16-byte epilogue stores through v_permlane32_swap (correct results)
 #endif
     return presc ? launch_glds<1, 1>(*p, stream) : launch_glds<0, 1>(*p, stream);
 }

@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <mutex>
 #include "kernels.h"
+#include "common.h"
 
 UtxOptions g_utx_opt = {1, 2, 0, 1, 1, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0};
 
@@ -44,7 +45,30 @@ static void options_from_env_once() {
 struct utx_ctx {
     int device;
     std::string err;
+    // scratch of the attention tail split for the entry points that take no workspace argument: owned by THIS context (not process-static), grown
+    // only outside of a stream capture; callers that want no allocation at all on the launch path use utx_attn_fwd_bf16_ws with their own buffer
+    void* attn_ws = nullptr;
+    size_t attn_ws_cap = 0;
 };
+
+// the context's attention scratch for one launch: grown when too small (hipFree + hipMalloc: a device sync, on growth only, never under capture --
+// a capturing stream gets no scratch and the launch stays unsplit)
+static void* ctx_attn_ws(utx_ctx* ctx, int H, int Sq, int S, hipStream_t stream, size_t* bytes) {
+    *bytes = 0;
+    if (!ctx) return nullptr;
+    const size_t need = utx_attn_workspace_bytes_impl(H, Sq == S ? 0 : Sq, S, utx_ncu());
+    if (need == 0) return nullptr;
+    if (ctx->attn_ws_cap < need) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+        if (ctx->attn_ws) (void)hipFree(ctx->attn_ws);
+        ctx->attn_ws = nullptr; ctx->attn_ws_cap = 0;
+        if (hipMalloc(&ctx->attn_ws, need) != hipSuccess) { ctx->attn_ws = nullptr; return nullptr; }
+        ctx->attn_ws_cap = need;
+    }
+    *bytes = ctx->attn_ws_cap;
+    return ctx->attn_ws;
+}
 
 static int fail(utx_ctx* ctx, int code, const char* what) {
     if (ctx) {
@@ -105,7 +129,10 @@ int utx_get_option(const char* name, int* value) {
 
 int utx_is_ablation_build(void) { return kAblationBuild ? 1 : 0; }
 
-void utx_free(utx_ctx* ctx) { delete ctx; }
+void utx_free(utx_ctx* ctx) {
+    if (ctx && ctx->attn_ws) (void)hipFree(ctx->attn_ws);
+    delete ctx;
+}
 
 const char* utx_last_error(utx_ctx* ctx) { return ctx ? ctx->err.c_str() : "no context"; }
 
@@ -113,27 +140,53 @@ int utx_attn_fwd_bf16(utx_ctx* ctx, const void* q, const void* k, const void* vt
                       long q_hs, long q_ss, long k_hs, long k_ss, long vt_hs, long vt_ds, long o_ss,
                       int H, int S, float softmax_scale, utx_stream stream) {
     if (!q || !k || !vt || !o) return fail(ctx, -2, "utx_attn_fwd_bf16");
+    size_t wsb = 0; void* const ws = ctx_attn_ws(ctx, H, S, S, (hipStream_t)stream, &wsb);
     UTX_CALL(ctx, "utx_attn_fwd_bf16",
              utx_launch_attn_fwd(q, k, vt, o, q_hs, q_ss, k_hs, k_ss, vt_hs, vt_ds, o_ss, H, S, S,
-                                 softmax_scale, 0.f, 0, (hipStream_t)stream));
+                                 softmax_scale, 0.f, 0, ws, wsb, (hipStream_t)stream));
 }
 
 int utx_attn_fwd_bf16_kb(utx_ctx* ctx, const void* q, const void* k, const void* vt, void* o,
                          long q_hs, long q_ss, long k_hs, long k_ss, long vt_hs, long vt_ds, long o_ss,
                          int H, int S, float softmax_scale, float key_bias_log2, int key_bias_period, utx_stream stream) {
     if (!q || !k || !vt || !o) return fail(ctx, -2, "utx_attn_fwd_bf16_kb");
+    size_t wsb = 0; void* const ws = ctx_attn_ws(ctx, H, S, S, (hipStream_t)stream, &wsb);
     UTX_CALL(ctx, "utx_attn_fwd_bf16_kb",
              utx_launch_attn_fwd(q, k, vt, o, q_hs, q_ss, k_hs, k_ss, vt_hs, vt_ds, o_ss, H, S, S,
-                                 softmax_scale, key_bias_log2, key_bias_period, (hipStream_t)stream));
+                                 softmax_scale, key_bias_log2, key_bias_period, ws, wsb, (hipStream_t)stream));
 }
 
 int utx_attn_fwd_bf16_kbq(utx_ctx* ctx, const void* q, const void* k, const void* vt, void* o,
                           long q_hs, long q_ss, long k_hs, long k_ss, long vt_hs, long vt_ds, long o_ss,
                           int H, int S_q, int S_kv, float softmax_scale, float key_bias_log2, int key_bias_period, utx_stream stream) {
     if (!q || !k || !vt || !o) return fail(ctx, -2, "utx_attn_fwd_bf16_kbq");
+    size_t wsb = 0; void* const ws = (S_q > 0 && S_q <= S_kv) ? ctx_attn_ws(ctx, H, S_q, S_kv, (hipStream_t)stream, &wsb) : nullptr;
     UTX_CALL(ctx, "utx_attn_fwd_bf16_kbq",
              utx_launch_attn_fwd(q, k, vt, o, q_hs, q_ss, k_hs, k_ss, vt_hs, vt_ds, o_ss, H, S_kv, S_q,
-                                 softmax_scale, key_bias_log2, key_bias_period, (hipStream_t)stream));
+                                 softmax_scale, key_bias_log2, key_bias_period, ws, wsb, (hipStream_t)stream));
+}
+
+int utx_attn_fwd_bf16_ws(utx_ctx* ctx, const void* q, const void* k, const void* vt, void* o,
+                         long q_hs, long q_ss, long k_hs, long k_ss, long vt_hs, long vt_ds, long o_ss,
+                         int H, int S_q, int S_kv, float softmax_scale, float key_bias_log2, int key_bias_period,
+                         void* work, size_t work_bytes, utx_stream stream) {
+    if (!q || !k || !vt || !o) return fail(ctx, -2, "utx_attn_fwd_bf16_ws");
+    UTX_CALL(ctx, "utx_attn_fwd_bf16_ws",
+             utx_launch_attn_fwd(q, k, vt, o, q_hs, q_ss, k_hs, k_ss, vt_hs, vt_ds, o_ss, H, S_kv, S_q,
+                                 softmax_scale, key_bias_log2, key_bias_period, work, work_bytes, (hipStream_t)stream));
+}
+
+size_t utx_attn_workspace_bytes(utx_ctx* ctx, int H, int S_q, int S_kv) {
+    (void)ctx;
+    if (H <= 0 || S_kv <= 0 || S_q <= 0 || S_q > S_kv) return 0;
+    return utx_attn_workspace_bytes_impl(H, S_q == S_kv ? 0 : S_q, S_kv, utx_ncu());
+}
+
+int utx_attn_plan(int H, int S_q, int S_kv, int n_cus, int out[4]) {
+    if (!out || H <= 0 || S_kv <= 0 || S_q <= 0 || S_q > S_kv || n_cus <= 0) return -2;
+    options_from_env_once();
+    utx_attn_split_plan_impl(H, S_q == S_kv ? 0 : S_q, S_kv, n_cus, out);
+    return 0;
 }
 
 size_t utx_gemm_streamk_workspace_bytes(utx_ctx*) { return utx_gemm_streamk_workspace_bytes_impl(); }

@@ -30,6 +30,9 @@ struct AttnParams {
     // key_bias_period when that is > 0 -- stand for 2^key_bias_log2 identical keys each: key_bias_log2 is added to their scores
     float key_bias_log2;
     int key_bias_period;
+    // caller-owned scratch of the tail split (utx_attn_workspace_bytes); null / too small: the launch stays unsplit
+    void* work;
+    size_t work_bytes;
 };
 // Launch options.  Every field is result-preserving (kernel selection / scheduling A/B): read ONCE from the environment by
 // the first utx_init (UTX_ATTN_*, UTX_GEMM_* variables of the same names), afterwards changed only through utx_set_option.
@@ -62,7 +65,9 @@ typedef utx_sched_desc SchedParams;
 extern "C" {
 int utx_launch_attn_fwd(const void* q, const void* k, const void* vt, void* o,
                         long q_hs, long q_ss, long k_hs, long k_ss, long vt_hs, long vt_ds,
-                        long o_ss, int H, int S, int Sq, float scale, float key_bias_log2, int key_bias_period, hipStream_t stream);
+                        long o_ss, int H, int S, int Sq, float scale, float key_bias_log2, int key_bias_period, void* work, size_t work_bytes, hipStream_t stream);
+void utx_attn_split_plan_impl(int H, int Sq, int S, int ncu, int out[4]);     // attention_glds.hip (pure): {workgroups, in full rounds, key ranges per tail workgroup, tiles per range}
+size_t utx_attn_workspace_bytes_impl(int H, int Sq, int S, int ncu);
 int utx_launch_attn_fwd_glds(const AttnParams* p, int presc, hipStream_t stream);
 int utx_launch_attn_fwd_q64(const AttnParams* p, int presc, hipStream_t stream);
 int utx_launch_gemm_bf16(const GemmParams* p, hipStream_t stream);

@@ -423,17 +423,27 @@ class FluxDiT:
             return
         sh = self.shape
         Qh, Kh, Vt = ws["Qh"], ws["Kh"], ws["Vt"]
-        if q_rows is None:
-            args = (ptr(Qh), ptr(Kh), ptr(Vt), ptr(out), Qh.stride(0), Qh.stride(1), Kh.stride(0), Kh.stride(1),
-                    Vt.stride(0), Vt.stride(1), out.stride(0), sh.num_heads, S, 0.0, float(self.key_bias_log2), int(self.key_bias_period))
-        else:       # queries = token rows [r0, r1) only (last-block pruning); `out` starts at row r0 as well
-            r0, r1 = q_rows
-            Qs = Qh[:, r0:]
-            args = (ptr(Qs), ptr(Kh), ptr(Vt), ptr(out), Qh.stride(0), Qh.stride(1), Kh.stride(0), Kh.stride(1),
-                    Vt.stride(0), Vt.stride(1), out.stride(0), sh.num_heads, r1 - r0, S, 0.0, float(self.key_bias_log2), int(self.key_bias_period))
-            plan.append((self.lib.utx_attn_fwd_bf16_kbq, args))
-            return
-        plan.append((self.lib.utx_attn_fwd_bf16_kb, args))
+        r0, r1 = (0, S) if q_rows is None else q_rows     # q_rows: queries = token rows [r0, r1) only (last-block pruning); `out` starts at row r0 as well
+        Qs = Qh[:, r0:]
+        wk = self._attn_work(ws, sh.num_heads, r1 - r0, S)
+        args = (ptr(Qs), ptr(Kh), ptr(Vt), ptr(out), Qh.stride(0), Qh.stride(1), Kh.stride(0), Kh.stride(1),
+                Vt.stride(0), Vt.stride(1), out.stride(0), sh.num_heads, r1 - r0, S, 0.0, float(self.key_bias_log2), int(self.key_bias_period),
+                ptr(wk), 0 if wk is None else wk.numel())
+        plan.append((self.lib.utx_attn_fwd_bf16_ws, args))
+
+    def _attn_work(self, ws, H, S_q, S_kv):
+        """scratch of the attention tail split (utx_attn_fwd_bf16_ws: caller-owned, nothing allocated on the launch path, capture-safe): one buffer per
+        plan, sized for its largest attention launch; the launches of a plan are ordered on one stream."""
+        need = int(self.lib.utx_attn_workspace_bytes(self.ctx.handle, int(H), int(S_q), int(S_kv)))
+        if need == 0:
+            return None
+        cur = ws.get("attn_ws")
+        if cur is None or cur.numel() < need:
+            # earlier plan entries hold the old buffer's pointer AND its (smaller, sufficient for them) size: keep it alive beside the new one
+            if cur is not None:
+                ws.setdefault("attn_ws_old", []).append(cur)
+            ws["attn_ws"] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return ws["attn_ws"]
 
     def _gemv(self, plan, x, W, b, y, silu_in=False, silu_out=False):
         d = GemvDesc()
@@ -776,16 +786,17 @@ class FluxDiT:
                     a = torch.cuda.Event(enable_timing=True)
                     b = torch.cuda.Event(enable_timing=True)
                     a.record()
-                rc = lib.utx_attn_fwd_bf16_kb(h, ptr(q), ptr(k), ptr(vt), ptr(ex.o), q.stride(0), q.stride(1), k.stride(0), k.stride(1),
-                                              vt.stride(0), vt.stride(1), ex.o.stride(0), ex.Hp, ex.S, 0.0, float(self.key_bias_log2),
-                                              int(self.key_bias_period), st)
+                wk = self._attn_work(ws, ex.Hp, ex.S, ex.S)
+                rc = lib.utx_attn_fwd_bf16_ws(h, ptr(q), ptr(k), ptr(vt), ptr(ex.o), q.stride(0), q.stride(1), k.stride(0), k.stride(1),
+                                              vt.stride(0), vt.stride(1), ex.o.stride(0), ex.Hp, ex.S, ex.S, 0.0, float(self.key_bias_log2),
+                                              int(self.key_bias_period), ptr(wk), 0 if wk is None else wk.numel(), st)
                 if ev is not None:
                     b.record()
                     ev.append((a, b))
                 if rc:
                     self.ctx.check(rc)
                 ex.tokens_out(d)
-            elif fn is lib.utx_attn_fwd_bf16_kb or fn is lib.utx_attn_fwd_bf16_kbq:
+            elif fn is lib.utx_attn_fwd_bf16_ws:
                 ev = getattr(self, "attn_events", None)
                 if ev is not None:  # bench.py: HIP events on the launch stream around the dominant kernel
                     a = torch.cuda.Event(enable_timing=True)
