@@ -330,7 +330,7 @@ def main():
             torch.cuda.synchronize()
             t_in += e[0].elapsed_time(e[1]); t_out += e[1].elapsed_time(e[2])
         exchange = {"qkv_all_to_all_plus_unpack_ms": t_in / reps, "out_all_to_all_plus_unpack_ms": t_out / reps,
-                    "bytes_per_rank_per_layer": ex.bytes_per_layer, "layers": N_DOUBLE + N_SINGLE,
+                    "bytes_per_rank_per_layer": ex.bytes_per_layer, "layers": N_DOUBLE + N_SINGLE, "head_groups": ex.G,
                     "note": "measured back to back without compute; in the step the Q/K/V exchange of the 38 single blocks runs beside the MLP half of the projection GEMM"}
     bp = None
     if world > 1:
@@ -350,8 +350,8 @@ def main():
         fl_nominal, _ = step_flops(S)
         attn_ms = [a.elapsed_time(b) for a, b in events]
         attn_avg_ms = sum(attn_ms) / max(len(attn_ms), 1)
-        attn_launch_flops = 4.0 * S_exec * S_exec * 128 * HEADS / (world if ulysses else 1)
-        n_attn = 57
+        attn_launch_flops = 4.0 * S_exec * S_exec * 128 * (model.ex.Hg if ulysses else HEADS)     # sequence parallel: one launch per head group of Hg heads
+        n_attn = 57 * (model.ex.G if ulysses else 1)
         if prune:
             # last-block pruning (FluxDiT.set_output_rows): the last of the 57 attention calls has n_noise queries instead of S_exec, and the
             # last block's q / MLP / output projections run on n_noise rows -- the FLOP figures are the EXECUTED ones
@@ -390,7 +390,7 @@ def main():
                          # context, not the judged fraction: an MFMA-only stream of the same shape sustains 1.73 PF on random operands
                          # on this board (power-limited clock, profiles/r01_perf_attn_q64.log)
                          "sustained_mfma_only_tflops": 1730.0, "frac_of_sustained": achieved / 1730.0,
-                         "attention_share_of_step_time": (attn_avg_ms * (N_DOUBLE + N_SINGLE)) / (dt / args.steps * 1e3)},
+                         "attention_share_of_step_time": (attn_avg_ms * n_attn) / (dt / args.steps * 1e3)},
         }
         if gemm_ev:
             g_ms = sum(a.elapsed_time(b) for a, b, _ in gemm_ev)

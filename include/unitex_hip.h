@@ -211,6 +211,11 @@ typedef struct utx_qkv_post_desc {
     int heads_per_group;
     long gs_qk, gs_v;
     int skip_qk;                             /* 1: q and k were produced by the GEMM's fused epilogue (utx_gemm_desc.qk_cols): only V is transposed */
+    /* second level of the grouped addressing (0 = off): the g heads of a destination rank are cut into head groups of sub_heads heads whose
+     * exchanges are pipelined with attention (send layout [group][P][3][sub_heads][...]): head hi = h % g of a rank lives at
+     * (h / g) * gs + (hi / sub_heads) * gs2 + (hi % sub_heads) * hs.  g % sub_heads == 0. */
+    int sub_heads;
+    long gs2_qk, gs2_v;
 } utx_qkv_post_desc;
 int utx_qkv_post(utx_ctx* ctx, const utx_qkv_post_desc* d, utx_stream stream);
 
@@ -219,9 +224,12 @@ int utx_qkv_post(utx_ctx* ctx, const utx_qkv_post_desc* d, utx_stream stream);
  * Both are pure 16-byte-vector copies (HBM-bound), one launch each; S = P * S_loc, S_loc % 64 == 0, E = S_loc * 128.
  *   utx_sp_unpack_qkv: recv [P src][3][Hp][E]  ->  q, k [Hp][S][128] (row = src*S_loc + tok),  vt [Hp][128][S]
  *                      (recv[src][0|1][hp] is [S_loc][128]; recv[src][2][hp] is [128][S_loc])
- *   utx_sp_unpack_o  : recv [P src][S_loc][Hp*128]  ->  out [S_loc][ld]: columns src*Hp*128 .. of row tok */
+ *   utx_sp_unpack_o  : recv [P src][S_loc][Hp*128]  ->  out [S_loc][ld]: columns src*Hp*128 .. of row tok
+ *   utx_sp_unpack_o_cols: the same for ONE head group of several (Hp = heads of the group): source rank src lands at column src * src_cols
+ *                      of `out` (src_cols = all heads of a rank x 128; `out` points at the group's first column) */
 int utx_sp_unpack_qkv(utx_ctx* ctx, const void* recv, int P, int Hp, int S_loc, void* q, void* k, void* vt, utx_stream stream);
 int utx_sp_unpack_o(utx_ctx* ctx, const void* recv, int P, int Hp, int S_loc, void* out, long ld, utx_stream stream);
+int utx_sp_unpack_o_cols(utx_ctx* ctx, const void* recv, int P, int Hp, int S_loc, void* out, long ld, long src_cols, utx_stream stream);
 
 /* LayerNorm(no affine) + AdaLN modulation (AdaLayerNormZero/ZeroSingle/Continuous [3p]). */
 typedef struct utx_ln_mod_desc {

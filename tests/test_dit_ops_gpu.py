@@ -448,13 +448,14 @@ def test_sequence_parallel_plan_world1_matches_plain_forward():
             dist.destroy_process_group()
 
 
-def _sp_worker(rank, world, port, q, zero_text=False):
+def _sp_worker(rank, world, port, q, zero_text=False, groups=1):
     import os
     import sys
     import torch.distributed as dist
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["UTX_SP_GROUPS"] = str(groups)      # head groups per rank whose exchanges are pipelined with attention (ulysses.pick_head_groups)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import dit_ref as R
     from unitex_amd.flux.transformer import FluxDiT, FluxShape
@@ -473,6 +474,7 @@ def _sp_worker(rank, world, port, q, zero_text=False):
     m.set_positions(txt_ids, img_ids)
     m.set_conditioning(enc, pooled, 3.5)
     assert (m.text_rows == 64 and m.key_bias_period == (64 + 192) // 64 and abs(m.key_bias_log2 - 2.0) < 1e-6) if zero_text else (m.text_rows is None)
+    assert m.ex.G == groups and m.ex.Hg * groups * world == 4 and m.overlap_text      # two streams in the double blocks under sequence parallelism as well
     i0, i1 = m.local_image_range(S_img)
     out_loc = m.forward(lat[i0:i1].contiguous(), 0.5).float().cpu()
     torch.cuda.synchronize()
@@ -490,17 +492,19 @@ def _sp_worker(rank, world, port, q, zero_text=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,zero_text", [(2, False), (2, True)])
-def test_sequence_parallel_two_ranks_match_unsharded_forward(world, zero_text):
+@pytest.mark.parametrize("world,zero_text,groups", [(2, False, 1), (2, True, 1), (2, False, 2), (2, True, 2)])
+def test_sequence_parallel_two_ranks_match_unsharded_forward(world, zero_text, groups):
     """two processes share cuda:0 and exchange through gloo (host-staged all-to-all): the token-sharded /
     head-sharded FluxDiT plan -- real kernels, real slicing of ids / embeddings / latents -- against the plain forward.
-    Differences can only come from the key order inside attention (fp32 summation order): a few bf16 ulps."""
+    Differences can only come from the key order inside attention (fp32 summation order): a few bf16 ulps.
+    groups = 2: the two heads of a rank as two head groups -- send buffer written through the two-level grouped addressing of
+    utx_qkv_post, one all-to-all + unpack + attention launch + return exchange per group (the pipelined form, ulysses.py)."""
     import os
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29900 + (os.getpid() % 90)
-    procs = [ctx.Process(target=_sp_worker, args=(r, world, port, q, zero_text)) for r in range(world)]
+    procs = [ctx.Process(target=_sp_worker, args=(r, world, port, q, zero_text, groups)) for r in range(world)]
     for p in procs:
         p.start()
     err, mx, frac = q.get(timeout=300)
@@ -656,6 +660,43 @@ def test_gemm_tail_split_matches_unsplit_launch_and_oracle(M, N, K, lora):
     assert torch.equal(s1.view(torch.int16), s2.view(torch.int16)), "split launch is not deterministic"
     changed = (s1 != plain).float().mean().item()
     assert 0.0 < changed < 0.02, "only roundings inside the tail tiles may move: %g of the elements differ" % changed
+
+
+@pytest.mark.parametrize("P,G,Hg,S_loc", [(4, 3, 2, 128), (2, 2, 3, 64), (3, 1, 2, 64)])
+def test_sequence_parallel_head_group_layouts(P, G, Hg, S_loc):
+    """the pipelined exchanges' group-major buffers (ulysses.py, round 3): utx_qkv_post's TWO-LEVEL grouped addressing writes
+    send [G][P][3][Hg][E] in place, utx_sp_unpack_o_cols puts one head group's return block at its columns of the consumer's rows;
+    both against torch index arithmetic, bit-exact."""
+    import ctypes as C
+    ops = _ops()
+    ctx = ops.get_ctx(0)
+    g = torch.Generator().manual_seed(P * 100 + G * 10 + Hg)
+    Hp, E = G * Hg, S_loc * 128
+    H, D = P * Hp, P * Hp * 128
+    qkv = torch.randn(S_loc, 3 * D, generator=g).to(BF).cuda()
+    wq = (1 + 0.1 * torch.randn(128, generator=g)).to(BF).cuda(); wk = (1 + 0.1 * torch.randn(128, generator=g)).to(BF).cuda()
+    ang = torch.rand(S_loc, 64, generator=g) * 6.28
+    cos, sin = torch.cos(ang).cuda().contiguous(), torch.sin(ang).cuda().contiguous()
+    Qh = torch.zeros(H, S_loc, 128, dtype=BF, device="cuda"); Kh = torch.zeros_like(Qh); Vt = torch.zeros(H, 128, S_loc, dtype=BF, device="cuda")
+    ops.qkv_post(qkv, 0, D, 2 * D, wq, wk, cos, sin, Qh, Kh, Vt, S_loc, 0, H, q_scale=0.1275)
+    send = torch.zeros(G, P, 3, Hg, E, dtype=BF, device="cuda")
+    flat = send.view(-1)
+    ops.qkv_post(qkv, 0, D, 2 * D, wq, wk, cos, sin, flat, flat[Hg * E:], flat[2 * Hg * E:], S_loc, 0, H, q_scale=0.1275,
+                 heads_per_group=Hp, group_stride=3 * Hg * E, head_stride=E, row_stride_v=S_loc, sub_heads=Hg, sub_stride=P * 3 * Hg * E)
+    torch.cuda.synchronize()
+    assert torch.equal(send[:, :, 0].reshape(G, P, Hg, S_loc, 128), Qh.view(P, G, Hg, S_loc, 128).transpose(0, 1))
+    assert torch.equal(send[:, :, 1].reshape(G, P, Hg, S_loc, 128), Kh.view(P, G, Hg, S_loc, 128).transpose(0, 1))
+    assert torch.equal(send[:, :, 2].reshape(G, P, Hg, 128, S_loc), Vt.view(P, G, Hg, 128, S_loc).transpose(0, 1))
+    # return side: group by group into strided rows
+    out = torch.zeros(S_loc, 5 * D, dtype=BF, device="cuda")
+    orecv = torch.randn(G, P, S_loc, Hg * 128, generator=g).to(BF).cuda()
+    for gi in range(G):
+        dst = out[:, gi * Hg * 128:]
+        ctx.check(ctx.lib.utx_sp_unpack_o_cols(ctx.handle, C.c_void_p(orecv[gi].data_ptr()), P, Hg, S_loc, C.c_void_p(dst.data_ptr()), out.stride(0),
+                                               Hp * 128, ctx.stream()))
+    torch.cuda.synchronize()
+    exp = orecv.permute(2, 1, 0, 3).reshape(S_loc, P * G * Hg * 128)          # row tok: [src][group][Hg*128] = head (src*Hp + g*Hg + hg)
+    assert torch.equal(out[:, :D], exp) and out[:, D:].abs().max().item() == 0
 
 
 @pytest.mark.parametrize("P,Hp,S_loc", [(4, 3, 128), (8, 3, 64), (2, 1, 192)])

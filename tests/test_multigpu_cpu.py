@@ -72,14 +72,29 @@ def _ulysses_worker(rank, world, port, q):
     t0, t1 = local_slice(S_txt, rank, world)
     i0, i1 = local_slice(S_img, rank, world)
     own = torch.cat([torch.arange(t0, t1), S_txt + torch.arange(i0, i1)])          # this rank's tokens: [txt_loc | img_loc]
-    ex = UlyssesExchange(H, own.numel(), device="cpu", dtype=torch.float32)
-    q_h, k_h, vt_h = ex.heads_in(qf[:, own].contiguous(), kf[:, own].contiguous(), vf[:, own].transpose(1, 2).contiguous())
-    o = dit_ref.sdpa(q_h, k_h, vt_h.transpose(1, 2), em=False)                     # [H/P, S, 128], rows = (src rank, local token)
-    ex.o.copy_(o.permute(1, 0, 2).reshape(S, -1))
-    out = torch.empty(own.numel(), 5 * H * 128)[:, : H * 128]                      # strided rows, like the single-block cat buffer
-    ex.tokens_out(out)
     ref = dit_ref.sdpa(qf, kf, vf, em=False)[:, own].permute(1, 0, 2).reshape(own.numel(), -1)
-    err = (out - ref).abs().max().item()
+    err = 0.0
+    for G in [g for g in (1, 2, 3) if (H // world) % g == 0]:     # head groups whose exchanges are pipelined with attention (round 3)
+        ex = UlyssesExchange(H, own.numel(), device="cpu", dtype=torch.float32, head_groups=G)
+        assert ex.bytes_per_layer == 4 * own.numel() * H * 128 * 4
+        ex.pack(qf[:, own].contiguous(), kf[:, own].contiguous(), vf[:, own].transpose(1, 2).contiguous())
+        works = ex.start_heads_in()
+        out = torch.full((own.numel(), 5 * H * 128), float("nan"))[:, : H * 128]       # strided rows, like the single-block cat buffer
+        back = []
+        for g in range(G):                                     # the product's order: group by group, return exchange started per group
+            q_h, k_h, vt_h = ex.finish_heads_in_group(g, works[g])
+            o = dit_ref.sdpa(q_h, k_h, vt_h.transpose(1, 2), em=False)              # [Hg, S, 128], rows = (src rank, local token)
+            ex.o[g].copy_(o.permute(1, 0, 2).reshape(S, -1))
+            back.append(ex.start_tokens_out_group(g))
+        for g in range(G):
+            ex.finish_tokens_out_group(g, back[g], out)
+        err = max(err, (out - ref).abs().max().item())
+        # the blocking forms (bench.py's exchange timing) do the same
+        q2, k2, v2 = ex.heads_in(qf[:, own].contiguous(), kf[:, own].contiguous(), vf[:, own].transpose(1, 2).contiguous())
+        ex.set_attention_output(dit_ref.sdpa(q2, k2, v2.transpose(1, 2), em=False))
+        out2 = torch.empty(own.numel(), H * 128)
+        ex.tokens_out(out2)
+        err = max(err, (out2 - ref).abs().max().item())
     q.put((rank, err < 1e-5, err))
     dist.barrier()
     dist.destroy_process_group()
@@ -98,3 +113,41 @@ def test_ulysses_exchange_matches_unsharded_attention(world):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res), res
+
+
+def test_sequence_parallel_model_bytes_overlap_window_and_predicted_scaling():
+    """the arithmetic the first multi-GPU run is to be compared with (unitex_amd/flux/sp_model.py): bytes per rank and layer
+    equal what UlyssesExchange moves; the exchanges of the G - 1 later head groups fit behind a group's attention at every P (so only the
+    first-in / last-out share is exposed); with PER-DIRECTION xGMI bandwidth (76.5 GB/s per link x 65 %) the predicted speed-up at 4 ranks
+    is >= 3.5 (BASELINE's target), and the un-pipelined round-2 form would not have reached it."""
+    import ctypes as C
+    from unitex_amd import _lib
+    from unitex_amd.flux import sp_model
+    from unitex_amd.flux.ulysses import UlyssesExchange, pick_head_groups
+    lib = _lib.load_library()
+
+    def plan(H, Sq, S, ncu):
+        out = (C.c_int * 4)()
+        assert lib.utx_attn_plan(H, Sq, S, ncu, C.byref(out)) == 0
+        return list(out)
+    rows = {r["P"]: r for r in sp_model.table(plan=plan)}
+    for P in (2, 4, 8):
+        r = rows[P]
+        ex = UlyssesExchange(24, r["S_loc"], device="cpu", dtype=torch.bfloat16, head_groups=r["groups"])
+        assert ex.P == 1                      # no process group here: the buffer arithmetic is what is checked
+        # a rank keeps 1 / P of what it produces: (P - 1) / P of 4 S_loc D 2 B leaves it, 3 / 4 of that in exchange 1
+        assert abs(r["bytes_per_rank_per_layer_on_fabric"] - 4 * r["S_loc"] * 3072 * 2 * (P - 1) / P) < 1
+        assert r["bytes_per_peer_in"] == 3 * r["S_loc"] * (3072 // P) * 2
+        assert r["groups"] == pick_head_groups(24 // P, r["S_loc"] * P, 256)
+        # overlap window: the fabric time of a layer (both exchanges, all groups) is below the attention time of the layer
+        assert r["exchange_in_ms"] + r["exchange_out_ms"] < r["attention_ms_per_layer"]
+        assert r["exposed_comm_frac"] < 0.05
+    assert rows[2]["groups"] == 4 and rows[4]["groups"] == 3 and rows[8]["groups"] == 1
+    assert rows[4]["speedup"] >= 3.5, rows[4]
+    assert rows[2]["speedup"] >= 1.8 and rows[8]["speedup"] >= 6.5
+    # round 2's form (G = 1: both exchanges exposed in the double blocks, the return exchange everywhere) at 4 ranks
+    unpip = sp_model.predict(4, groups=1, plan=plan)
+    assert unpip["exposed_comm_ms"] > 3.5 * rows[4]["exposed_comm_ms"]
+    # the attention launch of 3 heads at P = 8 is ONE launch whose third round is cut along the keys (utx_attn_plan), not 2.32 -> 3 whole rounds
+    nwg, nfull, ns, tps = plan(3, 50688, 50688, 256)
+    assert (nwg, nfull) == (594, 512) and ns == 3 and (nwg - nfull) * ns <= 256

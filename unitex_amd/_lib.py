@@ -42,7 +42,8 @@ class QkvPostDesc(C.Structure):
                 ("Qh", c_void_p), ("Kh", c_void_p), ("Vt", c_void_p),
                 ("hs_qk", c_long), ("hs_v", c_long), ("S_pad", c_long),
                 ("n_tok", c_int), ("tok_off", c_int), ("H", c_int), ("eps", c_float), ("q_scale", c_float),
-                ("heads_per_group", c_int), ("gs_qk", c_long), ("gs_v", c_long), ("skip_qk", c_int)]
+                ("heads_per_group", c_int), ("gs_qk", c_long), ("gs_v", c_long), ("skip_qk", c_int),
+                ("sub_heads", c_int), ("gs2_qk", c_long), ("gs2_v", c_long)]
 
 
 class LnModDesc(C.Structure):
@@ -101,6 +102,7 @@ SYMBOLS = {
     "utx_qkv_post": (c_int, [c_void_p, C.POINTER(QkvPostDesc), c_void_p]),
     "utx_sp_unpack_qkv": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "utx_sp_unpack_o": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_long, c_void_p]),
+    "utx_sp_unpack_o_cols": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_long, c_long, c_void_p]),
     "utx_ln_mod": (c_int, [c_void_p, C.POINTER(LnModDesc), c_void_p]),
     "utx_sched_step": (c_int, [c_void_p, C.POINTER(SchedDesc), c_void_p]),
     # geometry

@@ -248,7 +248,12 @@ int utx_sp_unpack_qkv(utx_ctx* ctx, const void* recv, int P, int Hp, int S_loc, 
 
 int utx_sp_unpack_o(utx_ctx* ctx, const void* recv, int P, int Hp, int S_loc, void* out, long ld, utx_stream stream) {
     if (!recv || !out) return fail(ctx, -2, "utx_sp_unpack_o");
-    UTX_CALL(ctx, "utx_sp_unpack_o", utx_launch_sp_unpack_o(recv, P, Hp, S_loc, out, ld, (hipStream_t)stream));
+    UTX_CALL(ctx, "utx_sp_unpack_o", utx_launch_sp_unpack_o(recv, P, Hp, S_loc, out, ld, 0, (hipStream_t)stream));
+}
+
+int utx_sp_unpack_o_cols(utx_ctx* ctx, const void* recv, int P, int Hp, int S_loc, void* out, long ld, long src_cols, utx_stream stream) {
+    if (!recv || !out || src_cols <= 0) return fail(ctx, -2, "utx_sp_unpack_o_cols");
+    UTX_CALL(ctx, "utx_sp_unpack_o_cols", utx_launch_sp_unpack_o(recv, P, Hp, S_loc, out, ld, src_cols, (hipStream_t)stream));
 }
 
 int utx_ln_mod(utx_ctx* ctx, const utx_ln_mod_desc* d, utx_stream stream) {

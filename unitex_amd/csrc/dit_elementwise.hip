@@ -24,10 +24,13 @@ __global__ __launch_bounds__(256) void qkv_post_kernel(QkvPostParams p) {
     const int head = blockIdx.y;
     const int t0 = blockIdx.x * 64;
     // head -> offset: plain [H][...] or grouped (sequence-parallel send layout: one group of heads per destination rank)
+    // (a second level -- sub_heads: the heads of a destination rank cut into head groups whose exchanges are pipelined with attention -- puts head
+    // hi of a rank at (hi / sub_heads) * gs2 + (hi % sub_heads) * hs)
     const int hg = p.heads_per_group > 0 ? head / p.heads_per_group : 0;
-    const int hi = p.heads_per_group > 0 ? head - hg * p.heads_per_group : head;
-    const long hoff_qk = (long)hg * p.gs_qk + (long)hi * p.hs_qk;
-    const long hoff_v = (long)hg * p.gs_v + (long)hi * p.hs_v;
+    int hi = p.heads_per_group > 0 ? head - hg * p.heads_per_group : head;
+    long hoff_qk = (long)hg * p.gs_qk, hoff_v = (long)hg * p.gs_v;
+    if (p.sub_heads > 0) { const int sg = hi / p.sub_heads; hi -= sg * p.sub_heads; hoff_qk += (long)sg * p.gs2_qk; hoff_v += (long)sg * p.gs2_v; }
+    hoff_qk += (long)hi * p.hs_qk; hoff_v += (long)hi * p.hs_v;
     float wq[8], wk[8];
     {
         const uint4 a = *reinterpret_cast<const uint4*>((const bf16_t*)p.wq + 8 * sub);
@@ -113,6 +116,7 @@ extern "C" int utx_launch_qkv_post(const QkvPostParams* hp, hipStream_t stream) 
     if (p.n_tok <= 0 || p.H <= 0) return -1;
     if ((p.tok_off & 7) || (p.S_pad & 7) || (p.ld & 7) || (p.q_col & 7) || (p.k_col & 7) || (p.v_col & 7)) return -2;   // 16-byte lanes
     if (p.heads_per_group < 0 || (p.heads_per_group > 0 && ((p.H % p.heads_per_group) || (p.gs_qk & 7) || (p.gs_v & 7)))) return -2;
+    if (p.sub_heads < 0 || (p.sub_heads > 0 && (p.heads_per_group <= 0 || (p.heads_per_group % p.sub_heads) || (p.gs2_qk & 7) || (p.gs2_v & 7)))) return -2;
     dim3 grid((p.n_tok + 63) / 64, p.H);
     hipLaunchKernelGGL(qkv_post_kernel, grid, dim3(256), 0, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -4;
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(256) void sp_unpack_qkv_kernel(const uint4* __restr
     }
 }
 
-__global__ __launch_bounds__(256) void sp_unpack_o_kernel(const uint4* __restrict__ recv, int P, int Hp, int S_loc, bf16_t* __restrict__ out, long ld) {
+__global__ __launch_bounds__(256) void sp_unpack_o_kernel(const uint4* __restrict__ recv, int P, int Hp, int S_loc, bf16_t* __restrict__ out, long ld, long src_cols) {
     const long Wv = (long)Hp * 16;                    // vectors per (src, tok) row: Hp * 128 * 2 B / 16
     const long total = (long)P * S_loc * Wv;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(256) void sp_unpack_o_kernel(const uint4* __restric
         long b = i / Wv;
         const long tok = b % S_loc;
         const long src = b / S_loc;
-        *reinterpret_cast<uint4*>(out + tok * ld + (src * Wv + c) * 8) = recv[i];
+        *reinterpret_cast<uint4*>(out + tok * ld + src * src_cols + c * 8) = recv[i];       // src_cols = Hp * 128 unless this is one head group of several
     }
 }
 
@@ -237,12 +241,13 @@ extern "C" int utx_launch_sp_unpack_qkv(const void* recv, int P, int Hp, int S_l
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
-extern "C" int utx_launch_sp_unpack_o(const void* recv, int P, int Hp, int S_loc, void* out, long ld, hipStream_t stream) {
-    if (P <= 0 || Hp <= 0 || S_loc <= 0 || (ld & 7) || ld < (long)P * Hp * 128) return -2;
+extern "C" int utx_launch_sp_unpack_o(const void* recv, int P, int Hp, int S_loc, void* out, long ld, long src_cols, hipStream_t stream) {
+    if (src_cols <= 0) src_cols = (long)Hp * 128;
+    if (P <= 0 || Hp <= 0 || S_loc <= 0 || (ld & 7) || (src_cols & 7) || src_cols < (long)Hp * 128 || ld < (long)(P - 1) * src_cols + (long)Hp * 128) return -2;
     if ((((uintptr_t)recv) | ((uintptr_t)out)) & 15) return -2;
     const long total = (long)P * S_loc * Hp * 16;
     long blocks = (total + 255) / 256; if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(sp_unpack_o_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const uint4*)recv, P, Hp, S_loc, (bf16_t*)out, ld);
+    hipLaunchKernelGGL(sp_unpack_o_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const uint4*)recv, P, Hp, S_loc, (bf16_t*)out, ld, src_cols);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 

@@ -181,9 +181,10 @@ def gemv(x, W, bias=None, silu_in=False, silu_out=False, out=None):
 
 
 def qkv_post(qkv, q_col, k_col, v_col, wq, wk, cos, sin, Qh, Kh, Vt, n_tok, tok_off, H, eps=1e-6, q_scale=1.0,
-             heads_per_group=0, group_stride=0, head_stride=None, row_stride_v=None, skip_qk=False):
+             heads_per_group=0, group_stride=0, head_stride=None, row_stride_v=None, skip_qk=False, sub_heads=0, sub_stride=0):
     """heads_per_group > 0: Qh / Kh / Vt are flat bases of a grouped layout (the sequence-parallel send buffer, ulysses.py):
-    head h at (h // g) * group_stride + (h % g) * head_stride, V^T rows row_stride_v apart."""
+    head h at (h // g) * group_stride + (h % g) * head_stride, V^T rows row_stride_v apart; with sub_heads = s > 0 the heads of a
+    group are cut once more: (h // g) * group_stride + ((h % g) // s) * sub_stride + (h % s) * head_stride."""
     ctx = get_ctx(qkv.device.index)
     d = QkvPostDesc()
     d.qkv, d.ld = ptr(_bf(qkv)), qkv.stride(0)
@@ -195,6 +196,7 @@ def qkv_post(qkv, q_col, k_col, v_col, wq, wk, cos, sin, Qh, Kh, Vt, n_tok, tok_
     if heads_per_group:
         d.hs_qk, d.hs_v, d.S_pad = head_stride, head_stride, row_stride_v
         d.heads_per_group, d.gs_qk, d.gs_v = heads_per_group, group_stride, group_stride
+        d.sub_heads, d.gs2_qk, d.gs2_v = sub_heads, sub_stride, sub_stride
     else:
         d.hs_qk, d.hs_v, d.S_pad = Qh.stride(0), Vt.stride(0), Vt.shape[2]
     d.n_tok, d.tok_off, d.H, d.eps, d.q_scale = n_tok, tok_off, H, eps, q_scale

@@ -108,7 +108,7 @@ class FluxDiT:
         self.gemm_events = None    # bench.py: list that receives (start event, end event, FLOPs) of every large-M GEMM launched on the main stream
         # double blocks: the text-token half (M = 512: a fraction of one round of tiles) runs on a second HIP stream beside the
         # image-token half, which fills CUs that the image GEMMs' tail rounds leave idle.  UTX_TXT_STREAM=0 keeps one stream.
-        self.overlap_text = os.environ.get("UTX_TXT_STREAM", "1") != "0" and self.sp is None
+        self.overlap_text = os.environ.get("UTX_TXT_STREAM", "1") != "0"      # also under sequence parallelism (the fork / join events end before "sp_start")
         self._side = torch.cuda.Stream(device=self.device) if self.overlap_text else None
         # text-token dedup (last bullet): the reference feeds 512 all-zero text embeddings with all-zero position ids
         # (flux_piplines/texturing/pipeline.py:538-543) -- 512 IDENTICAL tokens at every layer.  When set_conditioning sees
@@ -402,11 +402,12 @@ class FluxDiT:
         d.qkv, d.ld, d.q_col, d.k_col, d.v_col = ptr(qkv), qkv.stride(0), 0, D, 2 * D
         d.wq, d.wk, d.cosb, d.sinb = ptr(wq), ptr(wk), ptr(ws["cos"]), ptr(ws["sin"])
         if self.sp is not None:
-            # sequence parallel: write Q, K, V^T straight into the all-to-all send buffer [P][3][H/P][S_loc*128] (no pack pass)
+            # sequence parallel: write Q, K, V^T straight into the all-to-all send buffer [G][P][3][Hg][S_loc*128] (no pack pass)
             ex = self.ex
             d.Qh, d.Kh, d.Vt = ptr(ex.send_base(0)), ptr(ex.send_base(1)), ptr(ex.send_base(2))
             d.hs_qk, d.hs_v, d.S_pad = ex.E, ex.E, ex.S_loc
-            d.heads_per_group, d.gs_qk, d.gs_v = ex.Hp, ex.group_stride, ex.group_stride
+            d.heads_per_group, d.gs_qk, d.gs_v = ex.Hp, ex.dest_stride, ex.dest_stride       # level 1: destination rank
+            d.sub_heads, d.gs2_qk, d.gs2_v = ex.Hg, ex.group_stride, ex.group_stride        # level 2: head group (pipelined exchanges)
         else:
             d.Qh, d.Kh, d.Vt = ptr(ws["Qh"]), ptr(ws["Kh"]), ptr(ws["Vt"])
             d.hs_qk, d.hs_v, d.S_pad = ws["Qh"].stride(0), ws["Vt"].stride(0), ws["Vt"].shape[2]
@@ -417,8 +418,8 @@ class FluxDiT:
 
     def _attn(self, plan, ws, out, S, q_rows=None):
         if self.sp is not None:
-            # exchange 1 was started by an earlier "sp_start" entry; here: wait + unpack, attention over H/P heads x the full
-            # sequence, exchange 2 + unpack into `out`
+            # exchange 1 was started by an earlier "sp_start" entry; here, head group by head group: wait + unpack, attention over the group's
+            # heads x the full sequence, start its return exchange -- the fabric works beside the next group's attention (ulysses.py)
             plan.append(("sp_attn", out[:, : self.shape.dim]))
             return
         sh = self.shape
@@ -483,7 +484,8 @@ class FluxDiT:
             from .ulysses import UlyssesExchange
             if S_pad != S:
                 raise ValueError("sequence parallel: the local token count %d must be a multiple of 64" % S)
-            self.ex = UlyssesExchange(H, S, group=self.sp[2], device=dev, dtype=BF16, ctx=self.ctx)
+            self.ex = UlyssesExchange(H, S, group=self.sp[2], device=dev, dtype=BF16, ctx=self.ctx,
+                                      n_cus=torch.cuda.get_device_properties(dev).multi_processor_count)
         T = ws.get("T")
         Tc = ws.get("Tc") if self.overlap_text else T
 
@@ -779,23 +781,28 @@ class FluxDiT:
                 self._sp_work = self.ex.start_heads_in()
             elif fn == "sp_attn":
                 ex = self.ex
-                q, k, vt = ex.finish_heads_in(self._sp_work)
-                self._sp_work = None
+                works, self._sp_work = self._sp_work, None
                 ev = getattr(self, "attn_events", None)
-                if ev is not None:
-                    a = torch.cuda.Event(enable_timing=True)
-                    b = torch.cuda.Event(enable_timing=True)
-                    a.record()
-                wk = self._attn_work(ws, ex.Hp, ex.S, ex.S)
-                rc = lib.utx_attn_fwd_bf16_ws(h, ptr(q), ptr(k), ptr(vt), ptr(ex.o), q.stride(0), q.stride(1), k.stride(0), k.stride(1),
-                                              vt.stride(0), vt.stride(1), ex.o.stride(0), ex.Hp, ex.S, ex.S, 0.0, float(self.key_bias_log2),
-                                              int(self.key_bias_period), ptr(wk), 0 if wk is None else wk.numel(), st)
-                if ev is not None:
-                    b.record()
-                    ev.append((a, b))
-                if rc:
-                    self.ctx.check(rc)
-                ex.tokens_out(d)
+                wk = self._attn_work(ws, ex.Hg, ex.S, ex.S)
+                back = []
+                for g in range(ex.G):
+                    q, k, vt = ex.finish_heads_in_group(g, None if works is None else works[g])
+                    og = ex.o[g]
+                    if ev is not None:
+                        a = torch.cuda.Event(enable_timing=True)
+                        b = torch.cuda.Event(enable_timing=True)
+                        a.record()
+                    rc = lib.utx_attn_fwd_bf16_ws(h, ptr(q), ptr(k), ptr(vt), ptr(og), q.stride(0), q.stride(1), k.stride(0), k.stride(1),
+                                                  vt.stride(0), vt.stride(1), og.stride(0), ex.Hg, ex.S, ex.S, 0.0, float(self.key_bias_log2),
+                                                  int(self.key_bias_period), ptr(wk), 0 if wk is None else wk.numel(), st)
+                    if ev is not None:
+                        b.record()
+                        ev.append((a, b))
+                    if rc:
+                        self.ctx.check(rc)
+                    back.append(ex.start_tokens_out_group(g))
+                for g in range(ex.G):
+                    ex.finish_tokens_out_group(g, back[g], d)
             elif fn is lib.utx_attn_fwd_bf16_ws:
                 ev = getattr(self, "attn_events", None)
                 if ev is not None:  # bench.py: HIP events on the launch stream around the dominant kernel
