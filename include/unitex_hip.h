@@ -376,6 +376,14 @@ int utx_to_u8(utx_ctx* ctx, const float* src, long n_rows, long row_elems, int f
  * (convergence test).  Returns the number of sweeps (> 0) or a negative error. */
 int utx_chart_flood(utx_ctx* ctx, const int* adj, const int* bucket, int F, int* chart, int* flag, utx_stream stream);
 
+/* HOST-side mesh preparation (no device work, no context): quadric-error-metric edge-collapse decimation to at most target_faces triangles.
+ * Replaces open3d's simplify_quadric_decimation in preprocess_blank_mesh_o3d (uv_atlas.py:155-163; open3d / VTK [3p]) with the published
+ * algorithm (Garland & Heckbert 1997): area-weighted face quadrics, boundary edges held by perpendicular constraint planes
+ * (boundary_weight, 1.0 in the reference's legacy call), optimal placement, flip rejection.  verts [V][3] f32, faces [F][3] i32 ->
+ * verts_out (capacity V), faces_out (capacity F), counts in *V_out / *F_out.  Deterministic. */
+int utx_mesh_decimate_qem(const float* verts, int V, const int* faces, int F, int target_faces, double boundary_weight,
+                          float* verts_out, int* faces_out, int* V_out, int* F_out);
+
 int utx_abi_sizes(int* out, int n);
 
 #ifdef __cplusplus

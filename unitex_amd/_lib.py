@@ -80,6 +80,7 @@ SYMBOLS = {
     "utx_free": (None, [c_void_p]),
     "utx_last_error": (C.c_char_p, [c_void_p]),
     "utx_abi_sizes": (c_int, [C.POINTER(c_int), c_int]),
+    "utx_mesh_decimate_qem": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, C.c_double, c_void_p, c_void_p, C.POINTER(c_int), C.POINTER(c_int)]),
     "utx_set_option": (c_int, [C.c_char_p, c_int]),
     "utx_get_option": (c_int, [C.c_char_p, C.POINTER(c_int)]),
     "utx_is_ablation_build": (c_int, []),

@@ -26,6 +26,7 @@ SOURCES = [
     ("dit_elementwise.hip", ["-ffp-contract=off"]),
     ("vae.hip", []),
     ("capi.cpp", []),
+    ("meshproc.cpp", []),
 ]
 GEOM = [
     ("raster.hip", ["-ffp-contract=off"]),

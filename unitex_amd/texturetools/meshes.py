@@ -359,6 +359,72 @@ def subdivide_midpoint(verts, faces):
     return np.concatenate([verts, mid]).astype(np.float32), nf.astype(np.int32)
 
 
+def subdivide_loop(verts, faces, iterations=1):
+    """Loop subdivision (C. Loop 1987), what open3d's TriangleMesh.subdivide_loop computes [3p] and the reference applies twice to meshes under
+    min_faces (uv_atlas.py:164-165): every triangle is split 1:4; a new vertex on an INTERIOR edge (a, b) with opposite corners (c, d) is
+    3/8 (a + b) + 1/8 (c + d), on a boundary edge the midpoint; an old interior vertex of valence n moves to (1 - n beta) v + beta sum(neighbours),
+    beta = 3/16 for n = 3 and 3/(8 n) otherwise; an old boundary vertex to 3/4 v + 1/8 (its two boundary neighbours).  Vectorised, float64."""
+    v = np.asarray(verts, np.float64)
+    f = np.asarray(faces, np.int64)
+    for _ in range(int(iterations)):
+        F, V = len(f), len(v)
+        e = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]])                    # edge k of face i at row k * F + i
+        opp = np.concatenate([f[:, 2], f[:, 0], f[:, 1]])                                   # the corner opposite to that edge
+        es = np.sort(e, axis=1)
+        ue, inv, cnt = np.unique(es, axis=0, return_inverse=True, return_counts=True)
+        inv = inv.reshape(-1)
+        interior = cnt == 2                                                                 # (non-manifold edges with > 2 faces are treated as boundary)
+        osum = np.zeros((len(ue), 3)); np.add.at(osum, inv, v[opp])
+        mid = v[ue[:, 0]] + v[ue[:, 1]]
+        newv = np.where(interior[:, None], 0.375 * mid + 0.125 * osum, 0.5 * mid)
+        # old vertices
+        nsum = np.zeros((V, 3)); val = np.zeros(V)
+        np.add.at(nsum, ue[:, 0], v[ue[:, 1]]); np.add.at(nsum, ue[:, 1], v[ue[:, 0]])
+        np.add.at(val, ue[:, 0], 1.0); np.add.at(val, ue[:, 1], 1.0)
+        bedge = ue[~interior]
+        on_b = np.zeros(V, bool); on_b[bedge.reshape(-1)] = True
+        bsum = np.zeros((V, 3)); np.add.at(bsum, bedge[:, 0], v[bedge[:, 1]]); np.add.at(bsum, bedge[:, 1], v[bedge[:, 0]])
+        beta = np.where(val == 3, 3.0 / 16.0, 3.0 / (8.0 * np.maximum(val, 1.0)))
+        moved = (1.0 - val * beta)[:, None] * v + beta[:, None] * nsum
+        moved = np.where(on_b[:, None], 0.75 * v + 0.125 * bsum, moved)
+        moved = np.where((val == 0)[:, None], v, moved)                                     # unreferenced vertices stay
+        m01, m12, m20 = inv[:F] + V, inv[F:2 * F] + V, inv[2 * F:] + V
+        a, b, c = f[:, 0], f[:, 1], f[:, 2]
+        f = np.concatenate([np.stack([a, m01, m20], 1), np.stack([m01, b, m12], 1), np.stack([m20, m12, c], 1), np.stack([m01, m12, m20], 1)])
+        v = np.concatenate([moved, newv])
+    return v.astype(np.float32), f.astype(np.int32)
+
+
+def smooth_simple(verts, faces, iterations=3):
+    """open3d filter_smooth_simple(FilterScope.Vertex) [3p] (uv_atlas.py:169: three iterations on the COPY of the mesh that is unwrapped -- the UVs
+    are computed on the smoothed surface and carried by the original one): v <- (v + sum of its edge neighbours) / (1 + valence) per iteration."""
+    v = np.asarray(verts, np.float64)
+    f = np.asarray(faces, np.int64)
+    ue = np.unique(np.sort(np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]]), axis=1), axis=0)
+    val = np.zeros(len(v)); np.add.at(val, ue[:, 0], 1.0); np.add.at(val, ue[:, 1], 1.0)
+    for _ in range(int(iterations)):
+        acc = v.copy()
+        np.add.at(acc, ue[:, 0], v[ue[:, 1]]); np.add.at(acc, ue[:, 1], v[ue[:, 0]])
+        v = acc / (1.0 + val)[:, None]
+    return v.astype(np.float32)
+
+
+def decimate_qem(verts, faces, max_faces, boundary_weight=1.0):
+    """quadric-error-metric edge-collapse decimation to <= max_faces triangles (utx_mesh_decimate_qem: host C++ in libunitex_hip.so, the published
+    Garland-Heckbert algorithm; the reference calls open3d's simplify_quadric_decimation, uv_atlas.py:155-163 [3p])."""
+    import ctypes as C
+    from .._lib import load_library
+    lib = load_library()
+    v = np.ascontiguousarray(verts, np.float32); f = np.ascontiguousarray(faces, np.int32)
+    vo = np.empty_like(v); fo = np.empty_like(f)
+    nv, nf = C.c_int(0), C.c_int(0)
+    rc = lib.utx_mesh_decimate_qem(v.ctypes.data_as(C.c_void_p), len(v), f.ctypes.data_as(C.c_void_p), len(f), int(max_faces), float(boundary_weight),
+                                   vo.ctypes.data_as(C.c_void_p), fo.ctypes.data_as(C.c_void_p), C.byref(nv), C.byref(nf))
+    if rc != 0:
+        raise RuntimeError("utx_mesh_decimate_qem -> %d" % rc)
+    return vo[: nv.value].copy(), fo[: nf.value].copy()
+
+
 def decimate_cluster(verts, faces, max_faces):
     """vertex-clustering decimation until F <= max_faces (the reference uses open3d quadric decimation,
     uv_atlas.py:154-160): vertices are snapped to a uniform grid, cells collapse to their mean."""
@@ -413,6 +479,25 @@ _BUCKET_AXES = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1]
 _BUCKET_UV = [(1, 2), (2, 1), (2, 0), (0, 2), (0, 1), (1, 0)]
 
 
+def projection_frames(n_dirs=26):
+    """projection directions of the chart unwrap and an orthonormal in-plane basis (u, v) with u x v = d for each: [n,3] x 3.
+    6  = the coordinate axes (round 2): a face may lie up to 54.7 degrees off its axis -> up to 73 % area stretch in projection;
+    26 = axes + the 12 edge and 8 corner diagonals of the cube: every unit normal is within 27.6 degrees of one of them, i.e. the planar
+         projection stretches a face's area by at most 1 / cos(27.6 deg) - 1 = 12.8 % -- inside the reference's UVAtlas bound max_stretch = 0.1667
+         (uv_atlas.py:171) BY CONSTRUCTION (UVAtlas itself is [3p]: its own stretch metric is not restated, the bound is)."""
+    if n_dirs == 6:
+        d = _BUCKET_AXES.copy()
+    elif n_dirs == 26:
+        d = np.array([(x, y, z) for x in (-1, 0, 1) for y in (-1, 0, 1) for z in (-1, 0, 1) if (x, y, z) != (0, 0, 0)], np.float64)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+    else:
+        raise ValueError("projection direction sets exist for 6 and 26 directions")
+    ref = np.where(np.abs(d[:, 2:3]) < 0.9, np.array([[0.0, 0.0, 1.0]]), np.array([[1.0, 0.0, 0.0]]))
+    u = np.cross(ref, d); u /= np.linalg.norm(u, axis=1, keepdims=True)
+    v = np.cross(d, u)
+    return d, u, v
+
+
 def face_adjacency(faces):
     """adj [F,3] int32: the face across edge e = (v_e, v_{e+1}) of each face, -1 on a border; a non-manifold edge links its first
     two faces only."""
@@ -431,18 +516,20 @@ def face_adjacency(faces):
     return adj.reshape(F, 3)
 
 
-def chart_buckets(verts, faces, adj, smooth_iters=2, cos_accept=0.45):
-    """projection bucket per face: the axis direction closest to the face normal, then a few majority-vote sweeps that move a face
-    into the bucket of >= 2 of its neighbours when its normal still faces that axis by more than acos(cos_accept) -- removes the
-    one-face islands along bucket borders (fewer, larger charts = less seam)."""
+def chart_buckets(verts, faces, adj, smooth_iters=2, cos_accept=6.0 / 7.0, dirs=None):
+    """projection bucket per face: the projection direction closest to the face normal, then a few majority-vote sweeps that move a face
+    into the bucket of >= 2 of its neighbours when its normal still faces that direction by more than acos(cos_accept) -- removes the
+    one-face islands along bucket borders (fewer, larger charts = less seam).  cos_accept = 6/7: a face is never put into a bucket that
+    would stretch it by more than 1/6 (the reference's max_stretch, uv_atlas.py:171)."""
     v = verts.astype(np.float64)
     n = np.cross(v[faces[:, 1]] - v[faces[:, 0]], v[faces[:, 2]] - v[faces[:, 0]])
     n /= np.maximum(np.linalg.norm(n, axis=1, keepdims=True), 1e-30)
-    dots = n @ _BUCKET_AXES.T                                    # [F,6]
+    dirs = _BUCKET_AXES if dirs is None else dirs
+    dots = n @ dirs.T                                            # [F, n_dirs]
     bucket = np.argmax(dots, axis=1).astype(np.int32)
     for _ in range(smooth_iters):
         nb = np.where(adj >= 0, bucket[np.maximum(adj, 0)], -1)            # [F,3]
-        for b in range(6):
+        for b in range(len(dirs)):
             votes = (nb == b).sum(1)
             move = (votes >= 2) & (bucket != b) & (dots[:, b] > cos_accept)
             bucket = np.where(move, b, bucket).astype(np.int32)
@@ -466,10 +553,11 @@ def _shelf_pack(sizes, T):
     return out
 
 
-def unwrap_charts(verts, faces, atlas=2048, gutter=4.0, device="cuda:0", max_rounds=4):
-    """Chart unwrap: faces are bucketed by the axis their normal faces, charts are the connected same-bucket components (labelled on
-    the GPU: utx_chart_flood), every chart is projected orthographically along its axis (isometric up to the cosine of the facing
-    angle, <= 1/cos(63 deg) stretch) and the charts are shelf-packed at ONE texel density with `gutter` texels between them.  A
+def unwrap_charts(verts, faces, atlas=2048, gutter=4.0, device="cuda:0", max_rounds=4, n_dirs=26):
+    """Chart unwrap: faces are bucketed by the projection direction their normal faces (26 directions: area stretch <= 12.8 %, inside the
+    reference's max_stretch = 1/6; `projection_frames`), charts are the connected same-bucket components (labelled on
+    the GPU: utx_chart_flood), every chart is projected orthographically along its direction (isometric up to the cosine of the facing
+    angle) and the charts are shelf-packed at ONE texel density with `gutter` texels between them.  A
     chart that folds over itself in projection is detected by rasterising the atlas with the product's own rasteriser and counting
     texels per face; faces that lose their texels to another face of the same chart are split off into further charts (a few
     rounds); faces that are STILL overlapped after `max_rounds` become one-triangle charts of their own in a final round (a single
@@ -482,21 +570,20 @@ def unwrap_charts(verts, faces, atlas=2048, gutter=4.0, device="cuda:0", max_rou
     F = len(faces)
     faces = np.asarray(faces, np.int32)
     adj = face_adjacency(faces)
-    bucket = chart_buckets(verts, faces, adj)
+    dirs, bu, bv = projection_frames(n_dirs)
+    bucket = chart_buckets(verts, faces, adj, dirs=dirs)
     v64 = verts.astype(np.float64)
     layer = np.zeros(F, np.int32)                     # fold-over layer: faces split off a chart get the next layer
     dev = torch.device(device)
     adj_d = torch.from_numpy(adj).to(dev)
     for rnd in range(max_rounds + 1):
-        key = (bucket + 6 * layer).astype(np.int32)
+        key = (bucket + len(dirs) * layer).astype(np.int32)
         chart = ops.chart_flood(adj_d, torch.from_numpy(key).to(dev)).cpu().numpy()
         ids, cidx = np.unique(chart, return_inverse=True)
         C = len(ids)
         # per-face 2-D coordinates in its chart's plane
-        ua = np.array([_BUCKET_UV[b][0] for b in bucket]); va = np.array([_BUCKET_UV[b][1] for b in bucket])
         P = v64[faces]                                                  # [F,3,3]
-        fi = np.arange(F)[:, None]
-        uv3 = np.stack([P[fi, np.arange(3)[None, :], ua[:, None]], P[fi, np.arange(3)[None, :], va[:, None]]], -1)       # [F,3,2]
+        uv3 = np.stack([(P * bu[bucket][:, None, :]).sum(-1), (P * bv[bucket][:, None, :]).sum(-1)], -1)               # [F,3,2]: corners in the chart's plane
         lo = np.full((C, 2), np.inf); hi = np.full((C, 2), -np.inf)
         for k in range(3):
             np.minimum.at(lo, cidx, uv3[:, k]); np.maximum.at(hi, cidx, uv3[:, k])
@@ -557,12 +644,18 @@ def prepare_blank_mesh(path, min_faces=20_000, max_faces=200_000, scale=1.0, atl
     if uvs is not None:
         return verts, faces, uvs, faces_uv
     verts, faces = clean_mesh(verts, faces)
+    # the reference's branches (uv_atlas.py:154-168): quadric decimation above max_faces, exactly TWO Loop subdivisions below min_faces, clean again
     if len(faces) > max_faces:
-        verts, faces = decimate_cluster(verts, faces, max_faces)
-    while len(faces) < min_faces and 4 * len(faces) <= max_faces:
-        verts, faces = subdivide_midpoint(verts, faces)
+        verts, faces = decimate_qem(verts, faces, max_faces)
+        verts, faces = clean_mesh(verts, faces)
+    elif len(faces) < min_faces:
+        verts, faces = subdivide_loop(verts, faces, iterations=2)
+        verts, faces = clean_mesh(verts, faces)
     if unwrap == "grid":
         return unwrap_grid(verts, faces, atlas=atlas, gutter=gutter)
     if unwrap == "charts":
-        return unwrap_charts(verts, faces, atlas=atlas, gutter=gutter, device=device)
+        # the atlas is computed on a COPY smoothed three times (uv_atlas.py:169-175) and carried by the unsmoothed mesh
+        sm = smooth_simple(verts, faces, iterations=3)
+        _, f2, uvs, f_uv = unwrap_charts(sm, faces, atlas=atlas, gutter=gutter, device=device)
+        return verts.astype(np.float32), f2, uvs, f_uv
     raise ValueError("unknown unwrap method %r" % (unwrap,))
