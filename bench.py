@@ -255,7 +255,7 @@ def main():
         t[..., 1] += torch.arange(oy, oy + t.shape[0])[:, None]
         t[..., 2] += torch.arange(ox, ox + t.shape[1])[None, :]
     img_ids = torch.cat([t.reshape(-1, 3) for t in ids], 0)
-    prune = os.environ.get("UTX_PRUNE_LAST", "1") != "0" and not ulysses and not args.fp8
+    prune = os.environ.get("UTX_PRUNE_LAST", "1") != "0" and not ulysses
     model.set_positions(torch.zeros(S_txt, 3), img_ids)
     if prune:
         model.set_output_rows(n_noise)    # as the texturing pipeline does: only the noise tokens' prediction is consumed (sched_step reads no other row)

@@ -176,6 +176,30 @@ def test_fp8_full_width_blocks_at_config5_per_view_shape():
     assert 0.005 < e_lin < 0.06
     assert rel_f < 4 * e_lin, "fp8 forward vs bf16 forward: relative Frobenius error %g against 4 e_lin = %g" % (rel_f, 4 * e_lin)
     assert 1e-4 * mxo < d.abs().max().item() < 0.15 * mxo
+    # last-block pruning on the fp8 path (set_output_rows: queries / MLP / out-projection of the last block for the 16 384 noise tokens only, their
+    # activations quantised as a matrix of their own): MX quantisation is row-local and every output element is accumulated over ascending K by the
+    # same instruction, so the rows that are read must not change by a single bit (tail splits off: they pick different tiles for the two shapes)
+    from unitex_amd import _lib
+    n_noise = 16384
+    _lib.set_option("UTX_ATTN_TAILSPLIT", 0); _lib.set_option("UTX_GEMM_STREAMK", 0)
+    try:
+        res = {}
+        for rows in (None, n_noise):
+            m = FluxDiT(sd, shape, device="cuda:0", fp8_weights=True)
+            m.set_lora([(la, 1.0)])
+            m.set_positions(txt_ids, img_ids)
+            m.set_output_rows(rows)
+            m.set_conditioning(enc.cuda(), pooled.cuda(), 3.5)
+            res[rows] = m.forward(lat.cuda(), 0.4375).clone()
+            torch.cuda.synchronize()
+            if rows:
+                ws = next(iter(m._plans.values()))["ws"]
+                assert "aq2" in ws, "the pruned last block did not take the fp8 path"
+            del m
+            torch.cuda.empty_cache()
+    finally:
+        _lib.set_option("UTX_ATTN_TAILSPLIT", 1); _lib.set_option("UTX_GEMM_STREAMK", 1)
+    assert torch.equal(res[n_noise][:n_noise].view(torch.int16), res[None][:n_noise].view(torch.int16)), "fp8 pruned forward differs on the consumed rows"
 
 
 def test_mx8_packed_scale_quantiser_matches_the_rowmajor_one():

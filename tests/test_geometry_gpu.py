@@ -401,13 +401,18 @@ def test_chart_unwrap_labels_and_bijectivity():
         vv, ff, uu, fu = meshes.unwrap_charts(v, f, atlas=T, gutter=3.0)
         assert np.array_equal(vv, v.astype(np.float32)) and np.array_equal(ff, f) and uu.min() >= 0 and uu.max() <= 1
         uvclip = np.concatenate([uu * 2 - 1, np.zeros((len(uu), 1), np.float32), np.ones((len(uu), 1), np.float32)], -1)
+        # no texel centre is claimed by two faces: the ORACLE rasteriser with the faces in order and reversed (all triangles at z = 0: the smaller id
+        # wins a shared texel, the other one in the reversed pass) must name the same face everywhere
         ids = G.rasterize(uvclip, fu, T, T)[..., 3].astype(np.int64)
+        idr = G.rasterize(uvclip, np.ascontiguousarray(fu[::-1]), T, T)[..., 3].astype(np.int64)
+        idr = np.where(idr > 0, len(f) + 1 - idr, idr)
+        assert np.array_equal(ids, idr), "%s: %d texels are claimed by two faces" % (name, int((ids != idr).sum()))
         owned = np.bincount(ids.reshape(-1), minlength=len(f) + 1)[1:]
         t = uu.reshape(-1, 3, 2).astype(np.float64)
         area = np.abs((t[:, 1, 0] - t[:, 0, 0]) * (t[:, 2, 1] - t[:, 0, 1]) - (t[:, 2, 0] - t[:, 0, 0]) * (t[:, 1, 1] - t[:, 0, 1])) * 0.5 * T * T
         big = area >= 4.0
-        assert big.mean() > 0.5, name
-        assert (owned[big] >= 0.45 * area[big]).all(), "%s: %d faces hidden under other faces" % (name, int((owned[big] < 0.45 * area[big]).sum()))
+        assert big.mean() > 0.4, name
+        assert abs(owned.sum() - area.sum()) < 0.02 * area.sum(), "%s: texels owned %.0f vs UV area %.0f" % (name, owned.sum(), area.sum())
         # UV triangles keep their orientation (no mirrored charts)
         sgn = (t[:, 1, 0] - t[:, 0, 0]) * (t[:, 2, 1] - t[:, 0, 1]) - (t[:, 2, 0] - t[:, 0, 0]) * (t[:, 1, 1] - t[:, 0, 1])
         assert (sgn[big] > 0).all(), name

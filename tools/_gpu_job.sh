@@ -1,14 +1,10 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 export PYTHONUNBUFFERED=1
-# round 3, job 2: MX w4 kernel tests, attention epilogue / workspace changes, attention variants A/B, raw-mesh condition render, bench with roofline_gemm + new CPU baseline
-timeout 900 python -m pytest tests/test_fp8_gpu.py -x -q -s -m gpu > gpurun_out/r03_fp8_tests_b.log 2>&1; echo "fp8 tests rc=$?"
-grep -v amdgpu gpurun_out/r03_fp8_tests_b.log | tail -n 12
-timeout 900 python -m pytest tests/test_dit_ops_gpu.py tests/test_fullsize_gpu.py -x -q -m gpu -k "attention or pruning or tail_split or sharded or sequence" > gpurun_out/r03_attn_tests_b.log 2>&1; echo "attn tests rc=$?"
-tail -n 6 gpurun_out/r03_attn_tests_b.log
-timeout 300 python tools/attn_variants_r03.py > gpurun_out/r03_attn_variants_v0.log 2>&1; echo "variants rc=$?"
-grep -v amdgpu gpurun_out/r03_attn_variants_v0.log
-timeout 900 python -m pytest tests/test_pipeline_gpu.py -x -q -m gpu > gpurun_out/r03_pipeline_tests_b.log 2>&1; echo "pipeline rc=$?"
-tail -n 6 gpurun_out/r03_pipeline_tests_b.log
-timeout 600 python bench.py --steps 4 --warmup 1 > gpurun_out/r03_bench_strip1024x6_v1.json.log 2>&1; echo "bench rc=$?"
-tail -n 2 gpurun_out/r03_bench_strip1024x6_v1.json.log | cut -c 1-3000
+# round 3, job 3: pipelined sequence-parallel exchanges (2 processes on one GPU), 26-direction chart unwrap, mesh preparation, 2-rank bench control flow
+timeout 900 python -m pytest tests/test_dit_ops_gpu.py -x -q -m gpu -k "sequence or head_group or relayout" > gpurun_out/r03_sp_tests_c.log 2>&1; echo "sp tests rc=$?"
+tail -n 8 gpurun_out/r03_sp_tests_c.log
+timeout 900 python -m pytest tests/test_geometry_gpu.py tests/test_pipeline_gpu.py tests/test_multigpu_gpu.py -x -q -m gpu > gpurun_out/r03_geom_pipe_tests_c.log 2>&1; echo "geom/pipe/multigpu rc=$?"
+tail -n 12 gpurun_out/r03_geom_pipe_tests_c.log
+UTX_DIST_BACKEND=gloo timeout 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/r03_bench_strip1024x6_2ranks_1gpu.json.log 2>&1; echo "bench 2 ranks rc=$?"
+tail -n 2 gpurun_out/r03_bench_strip1024x6_2ranks_1gpu.json.log | cut -c 1-1500

@@ -564,7 +564,7 @@ class FluxDiT:
             self._gemm(pc, ff[:S_txt], b["ff2_c.w"], h_c, bias=b["ff2_c.b"], lora=b.get("lora.ff2_c"), T=Tc,
                        gate=cg_m, res=h_c)
             self._par(plan, px, pc)
-        n_out = S_img if (self.out_rows is None or self.sp is not None or self.fp8_weights) else max(1, min(int(self.out_rows), S_img))
+        n_out = S_img if (self.out_rows is None or self.sp is not None) else max(1, min(int(self.out_rows), S_img))
         for i, b in enumerate(self.single):
             sh_, sc_, g_ = chunks(("s", i), 3)
             self._lnmod(plan, h, xn, sh_, sc_)
@@ -574,6 +574,33 @@ class FluxDiT:
                 # computed equal the unpruned block's bit for bit (up to which query blocks the attention tail split picks).
                 r0, r1 = S_txt, S_txt + n_out
                 Wm, bm = b["qkvm.w"], b["qkvm.b"]
+                if self.fp8_weights and (("qkvm.sp") in b) and ops.mx8_uses_packed(n_out, D) and ops.mx8_uses_packed(S, 2 * D):
+                    # the same block on MX fp8 operands (adapters merged into the weights): x_n quantised once for the k | v projection over all rows
+                    # and once more, as a matrix of its own, for the rows that keep a query (tile-packed scales are addressed from a 128-row-aligned
+                    # origin; r0 = the text rows is not one) -- second activation scratch `aq2`
+                    from .mx8 import PackedScales, packed_scale_buffer
+                    Kmax = (1 + sh.mlp_ratio) * D
+                    if "aq2" not in ws:
+                        ws["aq2"] = torch.zeros(n_out, Kmax, dtype=torch.uint8, device=dev)
+                        ws["asp2"] = packed_scale_buffer(n_out, Kmax, dev)
+                    Wq, Wsp = b["qkvm.q"], b["qkvm.sp"]
+                    a_all = PackedScales(ws["asp"], S, D)
+                    plan.append(("quant_mx8", (xn, ws["aq"][:S, :D], a_all)))
+                    plan.append((self.lib.utx_gemm_bf16, ops.make_gemm_desc(ws["aq"][:S, :D], Wq[D: 3 * D], qkv[:, D: 3 * D], bias=bm[D: 3 * D],
+                                                                            a_scale=a_all, b_scale=Wsp.row_slice(D, 3 * D))))
+                    a_q = PackedScales(ws["asp2"], n_out, D)
+                    plan.append(("quant_mx8", (xn[r0:r1], ws["aq2"][:, :D], a_q)))
+                    plan.append((self.lib.utx_gemm_bf16, ops.make_gemm_desc(ws["aq2"][:, :D], Wq[:D], qkv[r0:r1, :D], bias=bm[:D],
+                                                                            a_scale=a_q, b_scale=Wsp.row_slice(0, D))))
+                    plan.append((self.lib.utx_gemm_bf16, ops.make_gemm_desc(ws["aq2"][:, :D], Wq[3 * D:], cat[r0:r1, D:], bias=bm[3 * D:], gelu_from=0,
+                                                                            a_scale=a_q, b_scale=Wsp.row_slice(3 * D, Wq.shape[0]))))
+                    self._qkvpost(plan, qkv, b["nq"], b["nk"], ws, S, 0)
+                    self._attn(plan, ws, cat[r0:], S, q_rows=(r0, r1))
+                    a_o = PackedScales(ws["asp2"], n_out, Kmax)
+                    plan.append(("quant_mx8", (cat[r0:r1], ws["aq2"], a_o)))
+                    plan.append((self.lib.utx_gemm_bf16, ops.make_gemm_desc(ws["aq2"], b["out.q"], h[r0:r1], bias=b["out.b"], gate=g_, res=h[r0:r1],
+                                                                            a_scale=a_o, b_scale=b["out.sp"])))
+                    continue
                 lora = b.get("lora.qkvm")
                 kw_kv, kw_q = {}, {}
                 if lora is not None:

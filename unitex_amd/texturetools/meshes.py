@@ -562,7 +562,7 @@ def unwrap_charts(verts, faces, atlas=2048, gutter=4.0, device="cuda:0", max_rou
     texels per face; faces that lose their texels to another face of the same chart are split off into further charts (a few
     rounds); faces that are STILL overlapped after `max_rounds` become one-triangle charts of their own in a final round (a single
     triangle projected along its dominant axis cannot fold), so the atlas that is returned is bijective for every face the check can
-    see -- faces under 3 texels of UV area own too few texel centres to be counted and are not checked.  Should even the final round
+    see (texel-centre resolution: a face that covers no texel centre at all has nothing to lose).  Should even the final round
     leave overlapped faces (it cannot by construction) a RuntimeWarning says so instead of returning the atlas silently.
     Returns verts [V,3] (shared positions), faces [F,3], uvs [3F,2] in [0,1], faces_uv [F,3]."""
     import torch
@@ -604,12 +604,18 @@ def unwrap_charts(verts, faces, atlas=2048, gutter=4.0, device="cuda:0", max_rou
         uv = (off[cidx][:, None, :] + 0.5 * gutter + (uv3 - lo[cidx][:, None, :]) * d_lo) / float(atlas)                 # [F,3,2]
         uvs = uv.reshape(-1, 2).astype(np.float32)
         f_uv = np.arange(3 * F, dtype=np.int32).reshape(F, 3)
-        # bijectivity check on the GPU: texels owned per face vs the face's UV area
+        # bijectivity check on the GPU, exact at texel-centre resolution: the atlas is rasterised twice with the product's rasteriser, once with
+        # the faces in order and once reversed.  All UV triangles lie at z = 0, so a texel centre covered by two faces goes to the smaller face
+        # id -- the other one in the reversed pass: any texel whose two winners differ is claimed twice, and the faces that lose it in the first
+        # pass are the ones split off.  (Round 2 compared texels owned with the UV area, which also flagged slivers that overlap nothing.)
         uvclip = np.concatenate([uvs * 2 - 1, np.zeros((3 * F, 1), np.float32), np.ones((3 * F, 1), np.float32)], -1)
-        rast = ops.rasterize(torch.from_numpy(uvclip).to(dev), torch.from_numpy(f_uv).to(dev), atlas, atlas)
-        owned = torch.bincount((rast[..., 3].long()).reshape(-1), minlength=F + 1)[1:].cpu().numpy()
-        a2 = np.abs((uv[:, 1, 0] - uv[:, 0, 0]) * (uv[:, 2, 1] - uv[:, 0, 1]) - (uv[:, 2, 0] - uv[:, 0, 0]) * (uv[:, 1, 1] - uv[:, 0, 1])) * 0.5 * atlas * atlas
-        lost = (a2 >= 3.0) & (owned < 0.5 * a2)
+        uvc_d = torch.from_numpy(uvclip).to(dev)
+        ida = ops.rasterize(uvc_d, torch.from_numpy(f_uv).to(dev), atlas, atlas)[..., 3].long()
+        idb = ops.rasterize(uvc_d, torch.from_numpy(np.ascontiguousarray(f_uv[::-1])).to(dev), atlas, atlas)[..., 3].long()
+        idb = torch.where(idb > 0, F + 1 - idb, idb)
+        twice = ida != idb
+        lost = np.zeros(F, bool)
+        lost[(idb[twice] - 1).unique().cpu().numpy()] = True
         if not lost.any():
             break
         if rnd == max_rounds:
