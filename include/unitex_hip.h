@@ -153,6 +153,14 @@ typedef struct utx_gemm_desc {
      * result only by fp32 summation order).  Caller-owned, >= utx_gemm_streamk_workspace_bytes(), one buffer per stream that launches
      * GEMMs concurrently; NULL = never split. */
     void* sk_work; size_t sk_work_bytes;
+    /* mx8 == 2 only, optional: the GELU part of the output (columns n >= gelu_from) leaves as OCP MX fp8 -- the A operand of the NEXT mx8 = 2 GEMM
+     * (FLUX: GELU(ff.net.0) feeds ff.net.2; GELU(proj_mlp) feeds proj_out) -- instead of bf16: bytes q_out [M][ldq_out] at column n - gelu_from,
+     * tile-packed scales qs_out (qs_out_rb row blocks per K-tile slab), K-tile q_out_kt0 + (n - gelu_from) / 128.  Bit-identical to the bf16
+     * epilogue followed by utx_quant_mx8_packed (rounded to bf16, then quantised per block of 32 columns); C / C1 are not written for those
+     * columns.  (N - gelu_from) % 128 == 0, ldq_out % 8 == 0.  The split tail round is not used by such a launch. */
+    void* q_out; long ldq_out;
+    void* qs_out; long qs_out_rb;
+    int q_out_kt0;
 } utx_gemm_desc;
 int utx_gemm_bf16(utx_ctx* ctx, const utx_gemm_desc* d, utx_stream stream);
 size_t utx_gemm_streamk_workspace_bytes(utx_ctx* ctx);   /* size of utx_gemm_desc.sk_work for this device (2 partial tiles per CU) */
@@ -238,6 +246,12 @@ typedef struct utx_ln_mod_desc {
     void* y; long ldy;
     int n_tok, D;
     float eps;
+    /* q != NULL (D % 128 == 0): the result leaves as OCP MX fp8 instead of bf16 -- exactly what utx_quant_mx8_packed makes of the bf16 result
+     * (the value is rounded to bf16 first, then quantised per block of 32): bytes q [n_tok][ldq], tile-packed scales qs (qs_row_blocks row
+     * blocks per K-tile slab, see utx_quant_mx8_packed).  The activation operand of an mx8 = 2 GEMM without the bf16 round trip through HBM;
+     * y is not written. */
+    void* q; long ldq;
+    void* qs; long qs_row_blocks;
 } utx_ln_mod_desc;
 int utx_ln_mod(utx_ctx* ctx, const utx_ln_mod_desc* d, utx_stream stream);
 

@@ -176,6 +176,30 @@ def test_fp8_full_width_blocks_at_config5_per_view_shape():
     assert 0.005 < e_lin < 0.06
     assert rel_f < 4 * e_lin, "fp8 forward vs bf16 forward: relative Frobenius error %g against 4 e_lin = %g" % (rel_f, 4 * e_lin)
     assert 1e-4 * mxo < d.abs().max().item() < 0.15 * mxo
+    # fused quantisation (default): LayerNorm-modulation and the GELU epilogues write the next GEMM's activation AS fp8 (utx_ln_mod_desc.q,
+    # utx_gemm_desc.q_out) -- the same bytes as bf16 + utx_quant_mx8_packed, so the forward must not change by a single bit
+    import os
+    os.environ["UTX_FP8_FUSE_QUANT"] = "0"
+    try:
+        m = FluxDiT(sd, shape, device="cuda:0", fp8_weights=True)
+        m.set_lora([(la, 1.0)])
+        m.set_positions(txt_ids, img_ids)
+        m.set_conditioning(enc.cuda(), pooled.cuda(), 3.5)
+        unfused = m.forward(lat.cuda(), 0.4375).float()
+        torch.cuda.synchronize()
+        n_quant = sum(1 for fn, _ in _flat(m) if fn == "quant_mx8")
+        del m
+    finally:
+        del os.environ["UTX_FP8_FUSE_QUANT"]
+    m = FluxDiT(sd, shape, device="cuda:0", fp8_weights=True)
+    m.set_lora([(la, 1.0)])
+    m.set_positions(txt_ids, img_ids)
+    m.set_conditioning(enc.cuda(), pooled.cuda(), 3.5)
+    n_quant_fused = sum(1 for fn, _ in _flat(m) if fn == "quant_mx8")
+    del m
+    torch.cuda.empty_cache()
+    assert n_quant == 5 and n_quant_fused == 1, (n_quant, n_quant_fused)      # only the attention output of the single block keeps a quantiser pass
+    assert torch.equal(unfused, outs[True]), "fused fp8 quantisation changed the forward: max |d| %g" % (unfused - outs[True]).abs().max().item()
     # last-block pruning on the fp8 path (set_output_rows: queries / MLP / out-projection of the last block for the 16 384 noise tokens only, their
     # activations quantised as a matrix of their own): MX quantisation is row-local and every output element is accumulated over ascending K by the
     # same instruction, so the rows that are read must not change by a single bit (tail splits off: they pick different tiles for the two shapes)
@@ -297,3 +321,13 @@ def test_mx8_packed_form_refuses_what_it_cannot_do():
         c1 = torch.empty(512, 384, dtype=BF, device="cuda")
         ops.gemm(aq, wq, out=torch.empty(512, 128, dtype=BF, device="cuda"), a_scale=a_p, b_scale=w_p, n_split=128, C1=c1)
     torch.cuda.synchronize()
+
+
+def _flat(m):
+    def walk(ops_):
+        for fn, d in ops_:
+            if isinstance(fn, str) and fn == "par":
+                yield from walk(d[0]); yield from walk(d[1])
+            else:
+                yield fn, d
+    return list(walk(next(iter(m._plans.values()))["plan"]))

@@ -27,7 +27,8 @@ class GemmDesc(C.Structure):
                 ("qk_cols", c_int), ("qk_tok_off", c_int), ("qk_eps", c_float), ("qk_q_scale", c_float),
                 ("qk_wq", c_void_p), ("qk_wk", c_void_p), ("qk_cos", c_void_p), ("qk_sin", c_void_p),
                 ("qk_Qh", c_void_p), ("qk_Kh", c_void_p), ("qk_hs", c_long),
-                ("sk_work", c_void_p), ("sk_work_bytes", C.c_size_t)]
+                ("sk_work", c_void_p), ("sk_work_bytes", C.c_size_t),
+                ("q_out", c_void_p), ("ldq_out", c_long), ("qs_out", c_void_p), ("qs_out_rb", c_long), ("q_out_kt0", c_int)]
 
 
 class GemvDesc(C.Structure):
@@ -48,7 +49,8 @@ class QkvPostDesc(C.Structure):
 
 class LnModDesc(C.Structure):
     _fields_ = [("x", c_void_p), ("ldx", c_long), ("shift", c_void_p), ("scale", c_void_p),
-                ("y", c_void_p), ("ldy", c_long), ("n_tok", c_int), ("D", c_int), ("eps", c_float)]
+                ("y", c_void_p), ("ldy", c_long), ("n_tok", c_int), ("D", c_int), ("eps", c_float),
+                ("q", c_void_p), ("ldq", c_long), ("qs", c_void_p), ("qs_row_blocks", c_long)]
 
 
 class SchedDesc(C.Structure):

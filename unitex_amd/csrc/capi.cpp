@@ -257,7 +257,7 @@ int utx_sp_unpack_o_cols(utx_ctx* ctx, const void* recv, int P, int Hp, int S_lo
 }
 
 int utx_ln_mod(utx_ctx* ctx, const utx_ln_mod_desc* d, utx_stream stream) {
-    if (!d || !d->x || !d->y || !d->shift || !d->scale) return fail(ctx, -2, "utx_ln_mod");
+    if (!d || !d->x || (!d->y && !d->q) || !d->shift || !d->scale) return fail(ctx, -2, "utx_ln_mod");
     UTX_CALL(ctx, "utx_ln_mod", utx_launch_ln_mod(d, (hipStream_t)stream));
 }
 

@@ -258,6 +258,10 @@ extern "C" int utx_launch_sp_unpack_o(const void* recv, int P, int Hp, int S_loc
 // One WAVE per token (four tokens per 256-thread block): a lane holds up to 8 chunks of 8 channels (D <= 4096) -- all its loads are in flight at
 // once, both reductions are wave-level (no LDS, no block barrier).  (Round 1 used one 256-thread block per token with two __syncthreads
 // reductions: 3.0 TB/s at D = 3072; the per-block latency chain, not HBM, set the time.)
+// MXQ (utx_ln_mod_desc.q): the result leaves as OCP MX fp8 -- a block of 32 channels = the 4 consecutive chunks of lanes 4k .. 4k+3 (block maximum by
+// two shuffles), a K-tile of 128 = 16 lanes (its four scale bytes assembled into one dword by two more shuffles, stored by the first of them at its
+// tile-packed place); the bf16 rounding of the unfused path is kept in front of the quantisation, so the bytes equal utx_ln_mod -> utx_quant_mx8_packed.
+template <bool MXQ>
 __global__ __launch_bounds__(256) void ln_mod_kernel(LnModParams p) {
     const int lane = threadIdx.x & 63;
     const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -315,7 +319,33 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(LnModParams p) {
                 }
                 ow[j] = pack2bf(o[0], o[1]);
             }
-            *reinterpret_cast<uint4*>(yr + c * 8) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+            if constexpr (!MXQ) *reinterpret_cast<uint4*>(yr + c * 8) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+            else {
+                float f[8], amax = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f[2 * j] = bf2f((uint16_t)(ow[j] & 0xffff)); f[2 * j + 1] = bf2f((uint16_t)(ow[j] >> 16));
+                    amax = fmaxf(amax, fmaxf(fabsf(f[2 * j]), fabsf(f[2 * j + 1])));
+                }
+                amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+                amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+                int e = (int)((__float_as_uint(amax) >> 23) & 0xff) - 127 - 8;
+                if (amax == 0.f || e < -127) e = -127;
+                if (e > 127) e = 127;
+                const float inv = __uint_as_float((uint32_t)(127 - e) << 23);
+                float a[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[j] = fminf(fmaxf(f[j] * inv, -448.f), 448.f);
+                int p0 = 0, p1 = 0;
+                p0 = __builtin_amdgcn_cvt_pk_fp8_f32(a[0], a[1], p0, false); p0 = __builtin_amdgcn_cvt_pk_fp8_f32(a[2], a[3], p0, true);
+                p1 = __builtin_amdgcn_cvt_pk_fp8_f32(a[4], a[5], p1, false); p1 = __builtin_amdgcn_cvt_pk_fp8_f32(a[6], a[7], p1, true);
+                *reinterpret_cast<uint2*>((uint8_t*)p.q + (long)tok * p.ldq + c * 8) = make_uint2((uint32_t)p0, (uint32_t)p1);
+                uint32_t w = (uint32_t)(e + 127) << (8 * ((lane >> 2) & 3));
+                w |= (uint32_t)__shfl_xor((int)w, 4, 64);
+                w |= (uint32_t)__shfl_xor((int)w, 8, 64);
+                if ((lane & 15) == 0)
+                    reinterpret_cast<uint32_t*>(p.qs)[(((long)(c >> 4) * p.qs_row_blocks + (tok >> 7)) * 32 + (tok & 31)) * 4 + ((tok >> 5) & 3)] = w;
+            }
         }
     }
 }
@@ -323,7 +353,13 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(LnModParams p) {
 extern "C" int utx_launch_ln_mod(const LnModParams* hp, hipStream_t stream) {
     LnModParams p = *hp;
     if (p.n_tok <= 0 || p.D <= 0 || (p.D & 7) || p.D > 4096 || (p.ldx & 7) || (p.ldy & 7)) return -2;
-    hipLaunchKernelGGL(ln_mod_kernel, dim3((p.n_tok + 3) / 4), dim3(256), 0, stream, p);
+    if (p.q) {
+        if (!p.qs || (p.D & 127) || (p.ldq & 7) || p.qs_row_blocks < (p.n_tok + 127) / 128 || ((uintptr_t)p.qs & 15) || ((uintptr_t)p.q & 7)) return -2;
+        hipLaunchKernelGGL(ln_mod_kernel<true>, dim3((p.n_tok + 3) / 4), dim3(256), 0, stream, p);
+        return hipGetLastError() == hipSuccess ? 0 : -4;
+    }
+    if (!p.y) return -2;
+    hipLaunchKernelGGL(ln_mod_kernel<false>, dim3((p.n_tok + 3) / 4), dim3(256), 0, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 

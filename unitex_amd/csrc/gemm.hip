@@ -838,6 +838,7 @@ extern "C" int utx_launch_gemm_bf16(const GemmParams* hp, hipStream_t stream) {
     // fused q / k post-processing exists only in the bf16 one-wave-per-SIMD kernel: refuse every other form here, in front of the early returns of
     // the convolution / MX forms, instead of silently dropping it
     if (p.qk_cols > 0 && (p.mx8 || p.conv_Wo > 0 || p.gate)) return -2;
+    if (p.q_out && p.mx8 != 2) return -2;      // fp8 output of the GELU tiles exists in the MX one-wave-per-SIMD kernel only: refused elsewhere, never dropped
     if (p.conv_Wo > 0) {   // implicit 3x3 convolution: 128^2 kernel, A rows gathered per tap
         if (p.K2 > 0 || !p.zero_page || p.conv_cin_log2 < 6 || p.K != (9 << p.conv_cin_log2) || p.conv_Hi <= 0 || p.conv_Wi <= 0 ||
             p.conv_stride < 1 || p.conv_stride > 2 || p.conv_pad < 0 || p.conv_pad > 1 || (p.conv_up & ~1) || (p.M % p.conv_Wo))

@@ -456,6 +456,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 }                                                                                                      \
             }                                                                                                          \
         }
+    // ---- MX fp8 OUTPUT of the GELU tiles (MX kernel, utx_gemm_desc.q_out): after the LDS transpose a lane holds 8 consecutive columns of one row and 16
+    // lanes share the row's 128 columns -- one K-tile of the NEXT GEMM, four blocks of 32 = four lanes each.  Block maximum by two shuffles, the four
+    // scale bytes of the row's K-tile assembled into one dword by two more, stored by the first lane of the 16 at its tile-packed place
+    // [K-tile][row block][row % 32][(row % 128) / 32]; the values are the bf16-rounded GELU outputs of the plain epilogue, so the bytes equal
+    // epilogue -> utx_quant_mx8_packed.  8 bytes per lane and piece instead of 16: half the C traffic, and the quantiser's pass over the tensor is gone.
+#define W4_MXQ_PIECE(im_, t_, Y_)                                                                                      \
+        {                                                                                                              \
+            const uint32_t yw_[4] = {Y_.x, Y_.y, Y_.z, Y_.w};                                                          \
+            float f_[8], am_ = 0.f;                                                                                    \
+            _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) {                                                         \
+                f_[2 * c_] = bf2f((uint16_t)(yw_[c_] & 0xffff)); f_[2 * c_ + 1] = bf2f((uint16_t)(yw_[c_] >> 16));     \
+                am_ = fmaxf(am_, fmaxf(fabsf(f_[2 * c_]), fabsf(f_[2 * c_ + 1])));                                     \
+            }                                                                                                          \
+            am_ = fmaxf(am_, __shfl_xor(am_, 1, 64));                                                                  \
+            am_ = fmaxf(am_, __shfl_xor(am_, 2, 64));                                                                  \
+            int e_ = (int)((__float_as_uint(am_) >> 23) & 0xff) - 127 - 8;                                             \
+            if (am_ == 0.f || e_ < -127) e_ = -127;                                                                    \
+            if (e_ > 127) e_ = 127;                                                                                    \
+            const float inv_ = __uint_as_float((uint32_t)(127 - e_) << 23);                                            \
+            float a_[8];                                                                                               \
+            _Pragma("unroll") for (int c_ = 0; c_ < 8; ++c_) a_[c_] = fminf(fmaxf(f_[c_] * inv_, -448.f), 448.f);      \
+            int p0_ = 0, p1_ = 0;                                                                                      \
+            p0_ = __builtin_amdgcn_cvt_pk_fp8_f32(a_[0], a_[1], p0_, false); p0_ = __builtin_amdgcn_cvt_pk_fp8_f32(a_[2], a_[3], p0_, true);  \
+            p1_ = __builtin_amdgcn_cvt_pk_fp8_f32(a_[4], a_[5], p1_, false); p1_ = __builtin_amdgcn_cvt_pk_fp8_f32(a_[6], a_[7], p1_, true);  \
+            uint32_t w_ = (uint32_t)(e_ + 127) << (8 * ((elane >> 2) & 3));                                            \
+            w_ |= (uint32_t)__shfl_xor((int)w_, 4, 64);                                                                \
+            w_ |= (uint32_t)__shfl_xor((int)w_, 8, 64);                                                                \
+            if (full || W4_ROW(im_, t_) < p.M) {                                                                       \
+                *reinterpret_cast<uint2*>(mxq_b + (long)(32 * (im_) + 4 * (t_)) * p.ldq_out + mxq_vo) = make_uint2((uint32_t)p0_, (uint32_t)p1_); \
+                if ((elane & 15) == 0) mxq_s[(4 * (t_) + (elane >> 4)) * 4 + (im_)] = w_;                              \
+            }                                                                                                          \
+        }
+#define W4_MXQ_BLOCK(im_)                                                                                              \
+        W4_EPI_WRITE(im_, true)                                                                                        \
+        {                                                                                                              \
+            W4_EPI_READ8()                                                                                             \
+            W4_MXQ_PIECE(im_, 0, y0_) W4_MXQ_PIECE(im_, 1, y1_) W4_MXQ_PIECE(im_, 2, y2_) W4_MXQ_PIECE(im_, 3, y3_)    \
+            W4_MXQ_PIECE(im_, 4, y4_) W4_MXQ_PIECE(im_, 5, y5_) W4_MXQ_PIECE(im_, 6, y6_) W4_MXQ_PIECE(im_, 7, y7_)    \
+        }
     // ---- fused q / k post-processing (QKF; utx_gemm_desc.qk_cols): after the LDS transpose a lane holds 8 consecutive channels of one token's
     // head row and 16 lanes share the row -- exactly the decomposition of qkv_post_kernel (dit_elementwise.hip), so its arithmetic is repeated
     // verbatim: same sum order (in-lane pairs, then xor 8, 4, 2, 1 over the 16 lanes), same bf16 rounding points, IEEE div / sqrt, no contraction.
@@ -628,6 +667,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const char* const qdst = (const char*)(isk ? p.qk_Kh : p.qk_Qh);                                          \
             const unsigned qhead = (unsigned)head * (unsigned)p.qk_hs * 2u;        /* byte offset of this head: < 4 GB for any S this library sizes for */ \
             W4_QK_BLOCK(0) W4_QK_BLOCK(1) W4_QK_BLOCK(2) W4_QK_BLOCK(3)                                                \
+        } else if (MX && !GATED && do_gelu && p.q_out) {                                                              \
+            /* the wave's 128 GELU columns = K-tile (n - gelu_from) / 128 of the next GEMM's activation operand */         \
+            const int qc0 = c_n0 + wn * 128 - p.gelu_from;                                                             \
+            uint8_t* const mxq_b = (uint8_t*)p.q_out + (long)(c_m0 + wm * 128) * p.ldq_out + qc0;                      \
+            const unsigned mxq_vo = (unsigned)((elane >> 4) * (unsigned)p.ldq_out + (unsigned)(elane & 15) * 8u);      \
+            uint32_t* const mxq_s = (uint32_t*)p.qs_out + ((long)(p.q_out_kt0 + (qc0 >> 7)) * p.qs_out_rb + ((c_m0 >> 7) + wm)) * 128; \
+            W4_MXQ_BLOCK(0) W4_MXQ_BLOCK(1) W4_MXQ_BLOCK(2) W4_MXQ_BLOCK(3)                                            \
         } else {                                                                                                       \
             if (do_gelu) { W4_PLAIN_BLOCK(0, true) W4_PLAIN_BLOCK(1, true) W4_PLAIN_BLOCK(2, true) W4_PLAIN_BLOCK(3, true) } \
             else { W4_PLAIN_BLOCK(0, false) W4_PLAIN_BLOCK(1, false) W4_PLAIN_BLOCK(2, false) W4_PLAIN_BLOCK(3, false) } \
@@ -891,7 +937,7 @@ extern "C" void utx_gemm_w4_split_plan(const GemmParams* pp, int tiles, int grid
     const GemmParams& p = *pp;
     *T_out = 0; *S_out = 0;
     const int opt = g_utx_opt.gemm_streamk;
-    if (opt <= 0 || !has_work || grid <= 0 || tiles <= grid || p.qk_cols != 0) return;
+    if (opt <= 0 || !has_work || grid <= 0 || tiles <= grid || p.qk_cols != 0 || p.q_out != nullptr) return;      // (the fix-up kernel has neither the fused q / k nor the fp8-output epilogue)
     const int T = tiles % grid;
     if (T == 0) return;
     if (!(p.K2 == 0 || p.lora_n_limit <= 0 || p.lora_n_limit >= p.N)) return;       // every tail tile must have the same K extent
@@ -948,6 +994,8 @@ extern "C" int utx_launch_gemm_w4(GemmParams p, hipStream_t stream) {
         if (p.K2 > 0 || p.qk_cols > 0 || (p.K % 64) || !p.a_scale || !p.b_scale || p.lds_a < (p.M + 127) / 128 || p.lds_b < p.N / 128 ||
             ((uintptr_t)p.a_scale & 15) || ((uintptr_t)p.b_scale & 15)) return -2;
         if (p.gate && (p.gelu_from < p.N || p.n_split < p.N)) return -2;
+        if (p.q_out && (p.gate || !p.qs_out || p.gelu_from >= p.N || (p.gelu_from % 128) || (p.ldq_out & 7) || p.ldq_out < p.N - p.gelu_from ||
+                        p.qs_out_rb < (p.M + 127) / 128 || p.q_out_kt0 < 0 || ((uintptr_t)p.qs_out & 15) || ((uintptr_t)p.q_out & 7))) return -2;
         UTX_ONCE_PER_DEVICE(ax) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_w4_kernel<false, 0, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess ||
                 hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_w4_kernel<true, 0, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;

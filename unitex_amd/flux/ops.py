@@ -51,7 +51,7 @@ def attention(q, k, vt, S=None, scale=None, out=None, o_ss=None, key_bias_log2=0
 
 
 def make_gemm_desc(A, B, C_out, bias=None, A2=None, B2=None, lora_n_limit=None, lora_seg_n=None, alpha=1.0,
-                   gelu_from=None, gate=None, res=None, n_split=None, C1=None, a_scale=None, b_scale=None, qk_post=None, sk_work=None):
+                   gelu_from=None, gate=None, res=None, n_split=None, C1=None, a_scale=None, b_scale=None, qk_post=None, sk_work=None, q_out=None):
     """a_scale / b_scale given: A and B are OCP MX fp8 operands (uint8 e4m3 bytes + E8M0 scales [rows, K/32], flux/mx8.py).
     sk_work: uint8 scratch tensor of streamk_workspace() bytes for the balanced tail of the large-M kernel (utx_gemm_desc.sk_work); one per
     stream that launches GEMMs concurrently.  None = the tail round is never split."""
@@ -92,6 +92,11 @@ def make_gemm_desc(A, B, C_out, bias=None, A2=None, B2=None, lora_n_limit=None, 
         d.C1, d.ldc1 = ptr(C1), C1.stride(0)
     if sk_work is not None:
         d.sk_work, d.sk_work_bytes = ptr(sk_work), sk_work.numel() * sk_work.element_size()
+    if q_out is not None:
+        # (uint8 view [M, N - gelu_from] of the consumer's fp8 activation scratch, its packed scale buffer [K/128, row blocks, 512], first K-tile): the GELU
+        # columns leave as MX fp8 (utx_gemm_desc.q_out; mx8 = 2 only)
+        qv, qs, kt0 = q_out
+        d.q_out, d.ldq_out, d.qs_out, d.qs_out_rb, d.q_out_kt0 = ptr(qv), qv.stride(0), ptr(qs), qs.stride(0) // 512, int(kt0)
     return d
 
 

@@ -357,16 +357,22 @@ class FluxDiT:
         """append (optional LoRA-down GEMM +) the main GEMM to the plan.  mx8 = (Wq, Ws, aq, as_): the base product runs on OCP MX fp8
         operands -- the activation is quantised by utx_quant_mx8 into (aq, as_) first; the LoRA branch keeps its bf16 operands."""
         if mx8 is not None:
-            Wq, Ws, aq, as_ = mx8
+            Wq, Ws, aq, as_ = mx8[:4]
+            opt = mx8[4] if len(mx8) > 4 else {}
             M, K = A.shape
-            aqv = aq[:M, :K]
+            c0 = int(opt.get("a_col0", 0))     # first column of the activation's fp8 image inside the scratch (a producer's fused output lies behind x_n's)
+            aqv = aq[:M, c0: c0 + K]
             if hasattr(Ws, "row_blocks"):      # tile-packed scales: the scratch buffer is shared by every fp8 GEMM of the plan (>= K/128 slabs, >= M/128 row blocks)
                 from .mx8 import PackedScales
-                asv = PackedScales(as_, M, K)
+                asv = PackedScales(as_[c0 // 128:], M, K)
             else:
                 asv = as_[:M, : K // 32]
-            plan.append(("quant_mx8", (A, aqv, asv)))
+            nq = int(opt.get("quant_cols", K))
+            if nq > 0:      # columns [0, nq) of A are quantised here; the rest (0 = all of it) was written as fp8 by its producer (ln_mod / a GELU epilogue)
+                plan.append(("quant_mx8", (A[:, :nq], aqv[:, :nq], PackedScales(as_[c0 // 128:], M, nq) if hasattr(Ws, "row_blocks") else asv)))
             kw = dict(kw, a_scale=asv, b_scale=Ws)
+            if opt.get("q_out") is not None:
+                kw["q_out"] = opt["q_out"]
             A_main, B_main = aqv, Wq
             lora = None     # merged into the fp8 weight (_quantize_fp8_weights)
         else:
@@ -390,10 +396,15 @@ class FluxDiT:
             plan.extend(main_ops)
             plan.extend(side_ops)
 
-    def _lnmod(self, plan, x, y, shift, scale):
+    def _lnmod(self, plan, x, y, shift, scale, mxq=None):
+        """mxq = (aq uint8 scratch rows, packed scale buffer): the result leaves as MX fp8 into aq[:n_tok, :D] + tile-packed scales instead of bf16 into y
+        (utx_ln_mod_desc.q: the activation operand of the fp8 GEMM behind it, without the bf16 round trip and the quantiser's pass)."""
         d = LnModDesc()
         d.x, d.ldx, d.shift, d.scale = ptr(x), x.stride(0), ptr(shift), ptr(scale)
         d.y, d.ldy, d.n_tok, d.D, d.eps = ptr(y), y.stride(0), x.shape[0], x.shape[1], 1e-6
+        if mxq is not None:
+            aq, asp = mxq
+            d.q, d.ldq, d.qs, d.qs_row_blocks = ptr(aq), aq.stride(0), ptr(asp), asp.stride(0) // 512
         plan.append((self.lib.utx_ln_mod, d))
 
     def _qkvpost(self, plan, qkv, wq, wk, ws, n_tok, tok_off, skip_qk=False):
@@ -489,14 +500,21 @@ class FluxDiT:
         T = ws.get("T")
         Tc = ws.get("Tc") if self.overlap_text else T
 
-        def mx(b, nm, row0=0, M=None, **shape_kw):
+        def mx(b, nm, row0=0, M=None, opt=(), **shape_kw):
             """MX fp8 operands of linear `nm` of block b (None = bf16 path); the activation scratch rows start at row0.  Shapes that fill the
             chip with 256 x 256 tiles take the one-wave-per-SIMD kernel (tile-packed scales), the rest the 128 x 128-tile kernel (row-major)."""
             if not self.fp8_weights or (nm + ".q") not in b:
                 return None
             if (nm + ".sp") in b and ops.mx8_uses_packed(S if M is None else M, b[nm + ".q"].shape[0], **shape_kw):
-                return (b[nm + ".q"], b[nm + ".sp"], ws["aq"][row0:], ws["asp"])
-            return (b[nm + ".q"], b[nm + ".s"], ws["aq"][row0:], ws["as"][row0:])
+                return (b[nm + ".q"], b[nm + ".sp"], ws["aq"][row0:], ws["asp"], dict(opt))
+            return (b[nm + ".q"], b[nm + ".s"], ws["aq"][row0:], ws["as"][row0:], {})
+
+        def packed(m_):
+            return m_ is not None and hasattr(m_[1], "row_blocks")
+        # fp8 mode, tile-packed operands: the activation of an fp8 GEMM is written AS fp8 by its producer -- LayerNorm-modulation (utx_ln_mod_desc.q) and
+        # the GELU epilogue of the GEMM in front (utx_gemm_desc.q_out) -- instead of bf16 + a quantiser pass.  Scratch layout per token row:
+        # columns [0, D) = the LayerNorm output (or the attention output of a single block), [D, 5D) = the GELU output.  UTX_FP8_FUSE_QUANT=0: separate passes.
+        fuse_quant = self.fp8_weights and os.environ.get("UTX_FP8_FUSE_QUANT", "1") != "0"
         W, mod = self.W, ws["mod"][0]
 
         def qk_fused(M, N, tok_off, wq, wk, **shape_kw):
@@ -535,12 +553,21 @@ class FluxDiT:
             csh_a, csc_a, cg_a, csh_m, csc_m, cg_m = chunks(("d", i, "c"), 6)
             # image half / text half of the block are independent except at the joint attention: two op lists per segment
             px, pc = [], []
-            self._lnmod(px, h_x, xn_x, sh_a, sc_a)
+            m_qkv = mx(b, "qkv_x", S_txt, S_img)
+            m_ff1, m_ff2 = mx(b, "ff1_x", S_txt, S_img), mx(b, "ff2_x", S_txt, S_img)
+            f_qkv = fuse_quant and packed(m_qkv)
+            f_ff = fuse_quant and packed(m_ff1) and packed(m_ff2)
+            if f_qkv:
+                m_qkv[4]["quant_cols"] = 0
+            if f_ff:      # ln_mod -> fp8 -> ff1 -> GELU -> fp8 (columns D.. of the scratch) -> ff2
+                m_ff1[4].update(quant_cols=0, q_out=(ws["aq"][S_txt:][:S_img, D:], ws["asp"], D // 128))
+                m_ff2[4].update(quant_cols=0, a_col0=D)
+            self._lnmod(px, h_x, xn_x, sh_a, sc_a, mxq=(ws["aq"][S_txt:], ws["asp"]) if f_qkv else None)
             self._lnmod(pc, h_c, xn_c, csh_a, csc_a)
             has_l = b.get("lora.qkv_x") is not None
             qkx = qk_fused(S_img, 3 * D, S_txt, b["nq"], b["nk"], K2=(Rp if has_l else 0), lora_seg_n=D, lora_n_limit=3 * D)
             self._gemm(px, xn_x, b["qkv_x.w"], qkv[S_txt:], bias=b["qkv_x.b"], lora=b.get("lora.qkv_x"),
-                       lora_n_limit=3 * D, lora_seg_n=D, T=T, mx8=mx(b, "qkv_x", S_txt, S_img), qk_post=qkx)
+                       lora_n_limit=3 * D, lora_seg_n=D, T=T, mx8=m_qkv, qk_post=qkx)
             self._gemm(pc, xn_c, b["qkv_c.w"], qkv[:S_txt], bias=b["qkv_c.b"], lora=b.get("lora.qkv_c"),
                        lora_n_limit=3 * D, lora_seg_n=D, T=Tc)
             self._qkvpost(px, qkv[S_txt:], b["nq"], b["nk"], ws, S_img, S_txt, skip_qk=qkx is not None)
@@ -554,11 +581,11 @@ class FluxDiT:
                        gate=g_a, res=h_x)
             self._gemm(pc, attn[:S_txt], b["out_c.w"], h_c, bias=b["out_c.b"], lora=b.get("lora.out_c"), T=Tc,
                        gate=cg_a, res=h_c)
-            self._lnmod(px, h_x, xn_x, sh_m, sc_m)
+            self._lnmod(px, h_x, xn_x, sh_m, sc_m, mxq=(ws["aq"][S_txt:], ws["asp"]) if f_ff else None)
             self._gemm(px, xn_x, b["ff1_x.w"], ff[S_txt:], bias=b["ff1_x.b"], lora=b.get("lora.ff1_x"), T=T, gelu_from=0,
-                       mx8=mx(b, "ff1_x", S_txt, S_img))
+                       mx8=m_ff1)
             self._gemm(px, ff[S_txt:], b["ff2_x.w"], h_x, bias=b["ff2_x.b"], lora=b.get("lora.ff2_x"), T=T,
-                       gate=g_m, res=h_x, mx8=mx(b, "ff2_x", S_txt, S_img))
+                       gate=g_m, res=h_x, mx8=m_ff2)
             self._lnmod(pc, h_c, xn_c, csh_m, csc_m)
             self._gemm(pc, xn_c, b["ff1_c.w"], ff[:S_txt], bias=b["ff1_c.b"], lora=b.get("lora.ff1_c"), T=Tc, gelu_from=0)
             self._gemm(pc, ff[:S_txt], b["ff2_c.w"], h_c, bias=b["ff2_c.b"], lora=b.get("lora.ff2_c"), T=Tc,
@@ -567,8 +594,15 @@ class FluxDiT:
         n_out = S_img if (self.out_rows is None or self.sp is not None) else max(1, min(int(self.out_rows), S_img))
         for i, b in enumerate(self.single):
             sh_, sc_, g_ = chunks(("s", i), 3)
-            self._lnmod(plan, h, xn, sh_, sc_)
-            if i == len(self.single) - 1 and n_out < S_img:
+            pruned = i == len(self.single) - 1 and n_out < S_img
+            m_qkvm = None if (pruned or self.sp is not None) else mx(b, "qkvm", n_split=3 * D, gelu_from=3 * D)
+            m_out = None if pruned else mx(b, "out")
+            f_sgl = fuse_quant and packed(m_qkvm) and packed(m_out)
+            if f_sgl:     # ln_mod -> fp8 -> [q|k|v|mlp] projection, GELU(mlp) -> fp8 (columns D..) ; attention output quantised into columns [0, D) ; out-projection
+                m_qkvm[4].update(quant_cols=0, q_out=(ws["aq"][:S, D:], ws["asp"], D // 128))
+                m_out[4].update(quant_cols=D)
+            self._lnmod(plan, h, xn, sh_, sc_, mxq=(ws["aq"], ws["asp"]) if f_sgl else None)
+            if pruned:
                 # LAST block, only rows [r0, r1) of its output are consumed (set_output_rows): keys / values for every token, but query,
                 # MLP and output projection for those rows only.  Same weights, same K order per output element: the rows that are
                 # computed equal the unpruned block's bit for bit (up to which query blocks the attention tail split picks).
@@ -623,7 +657,7 @@ class FluxDiT:
                 qkm = qk_fused(S, (3 + sh.mlp_ratio) * D, 0, b["nq"], b["nk"], n_split=3 * D, gelu_from=3 * D, K2=(Rp if has_l else 0),
                                lora_seg_n=D, lora_n_limit=3 * D)
                 self._gemm(plan, xn, b["qkvm.w"], qkv, bias=b["qkvm.b"], lora=b.get("lora.qkvm"), lora_n_limit=3 * D,
-                           lora_seg_n=D, T=T, gelu_from=3 * D, n_split=3 * D, C1=cat[:, D:], mx8=mx(b, "qkvm", n_split=3 * D, gelu_from=3 * D), qk_post=qkm)
+                           lora_seg_n=D, T=T, gelu_from=3 * D, n_split=3 * D, C1=cat[:, D:], mx8=m_qkvm, qk_post=qkm)
                 self._qkvpost(plan, qkv, b["nq"], b["nk"], ws, S, 0, skip_qk=qkm is not None)
             else:
                 # sequence parallel: the same GEMM cut at column 3D (identical arithmetic per column) so that the Q/K/V exchange
@@ -634,7 +668,7 @@ class FluxDiT:
                 plan.append(("sp_start", None))
                 self._gemm(plan, xn, b["qkvm.w"][3 * D:], cat[:, D:], bias=b["qkvm.b"][3 * D:], gelu_from=0)
             self._attn(plan, ws, cat, S)  # attention output lands in cat[:, :D] (row stride 5D)
-            self._gemm(plan, cat, b["out.w"], h, bias=b["out.b"], gate=g_, res=h, mx8=mx(b, "out"))
+            self._gemm(plan, cat, b["out.w"], h, bias=b["out.b"], gate=g_, res=h, mx8=m_out)
         o = self.mod_off[("out",)]
         scale, shift = mod[o: o + D], mod[o + D: o + 2 * D]  # AdaLayerNormContinuous: (scale, shift) [3p]
         self._lnmod(plan, h_x[:n_out], xn_x[:n_out], shift, scale)
