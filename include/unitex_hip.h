@@ -390,6 +390,33 @@ int utx_to_u8(utx_ctx* ctx, const float* src, long n_rows, long row_elems, int f
  * (convergence test).  Returns the number of sweeps (> 0) or a negative error. */
 int utx_chart_flood(utx_ctx* ctx, const int* adj, const int* bucket, int F, int* chart, int* flag, utx_stream stream);
 
+/* ---- utx_plan: one denoise step as a replayable list of launches (SURVEY 8b `utx_dit_step`) ------------------------------------------------
+ * The host builds a step of the FLUX DiT once as a list of descriptors over fixed workspaces (unitex_amd/flux/transformer.py is the builder this
+ * repo ships; any caller that can fill the descriptors can be one); utx_plan_add_* COPY them, utx_plan_run replays them on `stream` with the
+ * same launchers as the single-call entry points above -- same kernels, same order, bit-identical -- in ONE C call per step, nothing allocated,
+ * nothing synchronised (capturable into a HIP graph).  Inputs that change between steps (latents, timestep projection, conditioning) live in
+ * the device buffers the descriptors point at.  Two-stream sections: utx_plan_fork; entries for the plan's side stream; utx_plan_main; entries for
+ * the caller's stream; utx_plan_join (events recorded / awaited inside utx_plan_run).  utx_plan_add_add3: out = bf16(bf16(a + b) + c), n bf16
+ * elements (b may be NULL) -- the conditioning-embedding sum of CombinedTimestepGuidanceTextProjEmbeddings [3p].
+ * utx_plan_run returns 0 or the failing launcher's code (entry index in *failed_entry when not NULL). */
+typedef struct utx_plan utx_plan;
+int utx_plan_create(utx_ctx* ctx, utx_plan** out);
+void utx_plan_free(utx_plan* plan);
+int utx_plan_size(const utx_plan* plan);
+int utx_plan_add_gemm(utx_plan* plan, const utx_gemm_desc* d);
+int utx_plan_add_gemv(utx_plan* plan, const utx_gemv_desc* d);
+int utx_plan_add_ln_mod(utx_plan* plan, const utx_ln_mod_desc* d);
+int utx_plan_add_qkv_post(utx_plan* plan, const utx_qkv_post_desc* d);
+int utx_plan_add_attn(utx_plan* plan, const void* q, const void* k, const void* vt, void* o, long q_hs, long q_ss, long k_hs, long k_ss, long vt_hs,
+                      long vt_ds, long o_ss, int H, int S_q, int S_kv, float softmax_scale, float key_bias_log2, int key_bias_period, void* work,
+                      size_t work_bytes);
+int utx_plan_add_quant_mx8(utx_plan* plan, const void* x, long ldx, void* q, long ldq, void* s, long lds_or_row_blocks, int M, int K, int packed);
+int utx_plan_add_add3(utx_plan* plan, const void* a, const void* b, const void* c, void* out, int n);
+int utx_plan_fork(utx_plan* plan);
+int utx_plan_main(utx_plan* plan);
+int utx_plan_join(utx_plan* plan);
+int utx_plan_run(utx_plan* plan, utx_stream stream, int* failed_entry);
+
 /* HOST-side mesh preparation (no device work, no context): quadric-error-metric edge-collapse decimation to at most target_faces triangles.
  * Replaces open3d's simplify_quadric_decimation in preprocess_blank_mesh_o3d (uv_atlas.py:155-163; open3d / VTK [3p]) with the published
  * algorithm (Garland & Heckbert 1997): area-weighted face quadrics, boundary edges held by perpendicular constraint planes

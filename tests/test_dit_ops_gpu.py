@@ -598,6 +598,49 @@ def test_hip_graph_replay_is_bit_identical_to_the_eager_plan():
     assert not m._graphs, "a new adapter set must drop the captured graph"
 
 
+@pytest.mark.parametrize("fp8", [False, True])
+def test_c_side_plan_replay_is_bit_identical_to_the_python_launch_list(fp8):
+    """utx_plan (csrc/plan.cpp; SURVEY 8b `utx_dit_step`): FluxDiT copies its per-step launch list into a utx_plan and forward() replays it with ONE
+    C call -- the same launchers, descriptors, order and two streams as the Python loop over ctypes calls, so the outputs must be bit-identical, with
+    LoRA, the text half on the second stream, last-block pruning, and (fp8) the quantiser entries; a new timestep / new latents are picked up
+    through the device buffers the descriptors point at."""
+    from unitex_amd.flux.transformer import FluxDiT, FluxShape
+    cfg = dit_ref.tiny_config(heads=2, double=2, single=2, joint_dim=64, pooled_dim=64)
+    sd = dit_ref.make_synthetic_state_dict(cfg, seed=0)
+    shape = FluxShape(num_heads=2, num_double=2, num_single=2, joint_dim=64, pooled_dim=64)
+    S_txt, S_img = 64, 8 * 24 + 8 * 24 + 16
+    g = torch.Generator().manual_seed(12)
+    lat = torch.randn(S_img, 64, generator=g).to(BF).cuda(); lat2 = torch.randn(S_img, 64, generator=g).to(BF).cuda()
+    enc = (0.5 * torch.randn(S_txt, 64, generator=g)).to(BF).cuda(); pooled = (0.5 * torch.randn(1, 64, generator=g)).to(BF).cuda()
+    txt_ids = torch.zeros(S_txt, 3)
+    img_ids = torch.cat([dit_ref.latent_image_ids(8, 24), dit_ref.latent_image_ids(8, 24, offset_y=8),
+                         dit_ref.latent_image_ids(4, 4, offset_x=24, offset_y=8)], 0)
+    m = FluxDiT(sd, shape, device="cuda:0", fp8_weights=fp8)
+    m.set_lora([(dit_ref.make_synthetic_lora(cfg, sd, rank=16, seed=2), 1.0)])
+    m.set_positions(txt_ids, img_ids)
+    m.set_output_rows(192)
+    m.set_conditioning(enc, pooled, 3.5)
+    p = next(iter(m._plans.values()))
+    assert p.get("cplan") is not None and m.overlap_text, "the plan was not compiled into a utx_plan"
+    n_c = m.lib.utx_plan_size(p["cplan"])
+    n_py = sum((len(d[0]) + len(d[1]) + 2) if (isinstance(fn, str) and fn == "par") else 1 for fn, d in p["plan"])
+    assert n_c == n_py and n_c > 40      # fork + join entries per two-stream section
+    a1 = m.forward(lat, 0.5).clone(); a2 = m.forward(lat2, 0.25).clone()
+    torch.cuda.synchronize()
+    cplan, p["cplan"] = p["cplan"], None          # the Python loop over the same list
+    b1 = m.forward(lat, 0.5).clone(); b2 = m.forward(lat2, 0.25).clone()
+    torch.cuda.synchronize()
+    p["cplan"] = cplan
+    assert torch.equal(a1.view(torch.int16), b1.view(torch.int16)) and torch.equal(a2.view(torch.int16), b2.view(torch.int16))
+    assert not torch.equal(a1, a2) and a1.float().abs().max() > 0.1
+    # and the list can still be captured into a HIP graph
+    m.capture_graph()
+    c1 = m.forward(lat, 0.5).clone()
+    torch.cuda.synchronize()
+    m.release_graph()
+    assert torch.equal(c1.view(torch.int16), a1.view(torch.int16))
+
+
 @pytest.mark.parametrize("S", [2830, 4096])
 def test_attention_tail_split_matches_oracle_and_unsplit_launch(S):
     """more workgroups than CUs: the partly filled last round is cut along the keys (partial outputs + log-sum-exp, merged by

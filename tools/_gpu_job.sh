@@ -1,21 +1,15 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 export PYTHONUNBUFFERED=1
-# round 3, job 4: fused fp8 quantisation + fp8 pruning, chart unwrap (exact overlap check), bf16 / fp8 bench pair on one box, rocprofv3 kernel stats of the bench
-timeout 900 python -m pytest tests/test_fp8_gpu.py -x -q -s -m gpu > gpurun_out/r03_fp8_tests_d.log 2>&1; echo "fp8 tests rc=$?"
-grep -v amdgpu gpurun_out/r03_fp8_tests_d.log | tail -n 14
-timeout 900 python -m pytest tests/test_geometry_gpu.py tests/test_pipeline_gpu.py tests/test_multigpu_gpu.py -x -q -m gpu > gpurun_out/r03_geom_pipe_tests_d.log 2>&1; echo "geom/pipe/multigpu rc=$?"
-tail -n 12 gpurun_out/r03_geom_pipe_tests_d.log
-timeout 400 python bench.py --steps 6 --warmup 2 --no-cpu-baseline > gpurun_out/r03_bench_strip1024x6_v2.json.log 2>&1; echo "bench rc=$?"
-tail -n 1 gpurun_out/r03_bench_strip1024x6_v2.json.log | cut -c 1-220
-timeout 400 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --fp8 > gpurun_out/r03_bench_strip1024x6_fp8_v1.json.log 2>&1; echo "bench fp8 rc=$?"
-tail -n 1 gpurun_out/r03_bench_strip1024x6_fp8_v1.json.log | cut -c 1-220
-UTX_FP8_FUSE_QUANT=0 timeout 400 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --fp8 > gpurun_out/r03_bench_strip1024x6_fp8_v1_unfused.json.log 2>&1; echo "bench fp8 unfused rc=$?"
-tail -n 1 gpurun_out/r03_bench_strip1024x6_fp8_v1_unfused.json.log | cut -c 1-220
-cd /tmp; export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r03_prof -o r03 -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/r03_rocprof_bench.log 2>&1; echo "rocprof rc=$?"
-cd $GRAFT_REPO_ROOT
-find gpurun_out/r03_prof -name "*kernel_stats.csv" | head -3
-f=$(find gpurun_out/r03_prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -n 14 $f | cut -c 1-200
-# keep only the small stats file (the trace itself is tens of MB)
-[ -n "$f" ] && cp $f gpurun_out/r03_rocprofv3_kernel_stats_strip1024x6_v1.csv; rm -rf gpurun_out/r03_prof
+# round 3, job 6: the whole GPU suite on the current tree (C-side plan replay is now the default forward path), PMC passes of the GEMMs, reference operating point bench
+timeout 1500 python -m pytest tests -q -m gpu -x > gpurun_out/r03_gpu_tests_e.log 2>&1; echo "gpu suite rc=$?"
+tail -n 15 gpurun_out/r03_gpu_tests_e.log
+PASSES="sq1 tcc1 tcc2" bash tools/pmc_kernel.sh gpurun_out/r03_pmc_gemm_mx8 gemm256_w4 python tools/gemm_one.py mx8 > gpurun_out/r03_pmc_gemm_mx8.log 2>&1; echo "pmc mx8 rc=$?"
+cat gpurun_out/r03_pmc_gemm_mx8.log; tail -n 5 gpurun_out/r03_pmc_gemm_mx8/sq1.log; ls gpurun_out/r03_pmc_gemm_mx8/sq1 | head
+PASSES="sq1 tcc1 tcc2" bash tools/pmc_kernel.sh gpurun_out/r03_pmc_gemm_bf16 gemm256_w4 python tools/gemm_one.py bf16 > gpurun_out/r03_pmc_gemm_bf16.log 2>&1; echo "pmc bf16 rc=$?"
+cat gpurun_out/r03_pmc_gemm_bf16.log
+find gpurun_out/r03_pmc_gemm_mx8 gpurun_out/r03_pmc_gemm_bf16 -name "*.csv" -size +2000k -delete
+timeout 300 python bench.py --workload ref512x6 --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/r03_bench_ref512x6_v0.json.log 2>&1; echo "bench ref512 rc=$?"
+tail -n 1 gpurun_out/r03_bench_ref512x6_v0.json.log | cut -c 1-200
+timeout 300 python bench.py --workload ref512x6 --steps 10 --warmup 3 --no-cpu-baseline --fp8 > gpurun_out/r03_bench_ref512x6_fp8_v0.json.log 2>&1; echo "bench ref512 fp8 rc=$?"
+tail -n 1 gpurun_out/r03_bench_ref512x6_fp8_v0.json.log | cut -c 1-200

@@ -18,6 +18,7 @@ ap.add_argument("--no-uv", action="store_true", help="feed a mesh without UVs (e
 ap.add_argument("--out", default=None)
 ap.add_argument("--view", type=int, default=512, help="per-view resolution: 512 = reference, 1024 = BASELINE configs[1..2]")
 ap.add_argument("--reps", type=int, default=2)
+ap.add_argument("--fp8", action="store_true", help="speedup_mode='fp8': the big linears on OCP MX fp8 operands (BASELINE configs[4] numerics)")
 a = ap.parse_args()
 out = a.out or tempfile.mkdtemp(prefix="utx_full_")
 v, f, uv = meshes.sphere_with_faces(a.faces)
@@ -26,7 +27,8 @@ meshes.save_obj(mesh_path, v, f, None if a.no_uv else uv)
 yy, xx = np.mgrid[0:768, 0:768]
 Image.fromarray(np.stack([xx % 256, yy % 256, (xx + yy) % 256], -1).astype(np.uint8)).save(os.path.join(out, "ref.png"))
 t0 = time.perf_counter()
-pipe = CustomRGBTextureFullPipeline(pretrain_models=None, super_resolutions=False, seed=63, num_inference_steps=a.steps, view_size=a.view)
+pipe = CustomRGBTextureFullPipeline(pretrain_models=None, super_resolutions=False, seed=63, num_inference_steps=a.steps, view_size=a.view,
+                                    speedup_mode="fp8" if a.fp8 else None)
 torch.cuda.synchronize()
 t1 = time.perf_counter()
 print("pipeline construction (synthetic 12B-parameter weights): %.1f s" % (t1 - t0), flush=True)

@@ -82,6 +82,20 @@ SYMBOLS = {
     "utx_free": (None, [c_void_p]),
     "utx_last_error": (C.c_char_p, [c_void_p]),
     "utx_abi_sizes": (c_int, [C.POINTER(c_int), c_int]),
+    "utx_plan_create": (c_int, [c_void_p, C.POINTER(c_void_p)]),
+    "utx_plan_free": (None, [c_void_p]),
+    "utx_plan_size": (c_int, [c_void_p]),
+    "utx_plan_add_gemm": (c_int, [c_void_p, C.POINTER(GemmDesc)]),
+    "utx_plan_add_gemv": (c_int, [c_void_p, C.POINTER(GemvDesc)]),
+    "utx_plan_add_ln_mod": (c_int, [c_void_p, C.POINTER(LnModDesc)]),
+    "utx_plan_add_qkv_post": (c_int, [c_void_p, C.POINTER(QkvPostDesc)]),
+    "utx_plan_add_attn": (c_int, [c_void_p] * 5 + [c_long] * 7 + [c_int, c_int, c_int, c_float, c_float, c_int, c_void_p, C.c_size_t]),
+    "utx_plan_add_quant_mx8": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_int]),
+    "utx_plan_add_add3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
+    "utx_plan_fork": (c_int, [c_void_p]),
+    "utx_plan_main": (c_int, [c_void_p]),
+    "utx_plan_join": (c_int, [c_void_p]),
+    "utx_plan_run": (c_int, [c_void_p, c_void_p, C.POINTER(c_int)]),
     "utx_mesh_decimate_qem": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, C.c_double, c_void_p, c_void_p, C.POINTER(c_int), C.POINTER(c_int)]),
     "utx_set_option": (c_int, [C.c_char_p, c_int]),
     "utx_get_option": (c_int, [C.c_char_p, C.POINTER(c_int)]),

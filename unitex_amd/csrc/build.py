@@ -27,6 +27,7 @@ SOURCES = [
     ("vae.hip", []),
     ("capi.cpp", []),
     ("meshproc.cpp", []),
+    ("plan.cpp", []),
 ]
 GEOM = [
     ("raster.hip", ["-ffp-contract=off"]),

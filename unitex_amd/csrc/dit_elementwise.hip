@@ -364,6 +364,23 @@ extern "C" int utx_launch_ln_mod(const LnModParams* hp, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// out = bf16(bf16(a + b) + c) (b may be null: out = bf16(a + c)): the sum of the timestep / guidance / pooled-text embeddings,
+// conditioning = (timesteps_emb + guidance_emb) + pooled_projections in bf16 (CombinedTimestepGuidanceTextProjEmbeddings [3p]); n <= a few thousand.
+__global__ __launch_bounds__(256) void add3_bf16_kernel(const bf16_t* a, const bf16_t* b, const bf16_t* c, bf16_t* out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float t = bf2f(a[i]);
+    if (b) t = rbf(t + bf2f(b[i]));
+    out[i] = f2bf(t + bf2f(c[i]));
+}
+
+extern "C" int utx_launch_add3_bf16(const void* a, const void* b, const void* c, void* out, int n, hipStream_t stream) {
+    if (!a || !c || !out || n <= 0) return -2;
+    hipLaunchKernelGGL(add3_bf16_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (const bf16_t*)a, (const bf16_t*)b, (const bf16_t*)c, (bf16_t*)out, n);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Flow-match Euler step + condition re-pin, fused:
 //   x[s] = bf16( float(x[s]) + dsigma * float(v[s]) )   for s <  n_noise   (scheduler.step, fp32 upcast)
 //   x[s] = cond[s - n_noise]                           for s >= n_noise   (re-pin of clean condition tokens)

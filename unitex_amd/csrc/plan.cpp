@@ -1,0 +1,141 @@
+// utx_plan: a replayable list of stream-ordered launches -- the C side of FluxDiT's per-step plan (`utx_dit_step`).
+//
+// The Python host builds one denoise step as a flat list of (entry point, descriptor) pairs over fixed workspaces (unitex_amd/flux/transformer.py).
+// Replaying that list is ~700 ctypes calls per step; here the descriptors are COPIED once into a utx_plan and utx_plan_run replays them with plain C
+// calls of the same launchers -- one C call per step, the same kernels in the same order on the same streams (bit-identical by construction), usable
+// from any language that can fill the descriptors, and capturable into a HIP graph (nothing synchronises, nothing allocates).
+// Two-stream sections (the text half of a double block beside its image half): FORK records an event on the caller's stream and makes the plan's side
+// stream wait for it; entries tagged `side` launch there; JOIN records on the side stream and makes the caller's stream wait.
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include <vector>
+#include "kernels.h"
+
+namespace {
+enum Kind { K_GEMM, K_GEMV, K_LN_MOD, K_QKV_POST, K_ATTN, K_QUANT, K_ADD3, K_FORK, K_JOIN };
+struct AttnArgs { const void *q, *k, *vt; void* o; long q_hs, q_ss, k_hs, k_ss, vt_hs, vt_ds, o_ss; int H, S_q, S_kv; float scale, kb; int period; void* work; size_t work_bytes; };
+struct QuantArgs { const void* x; long ldx; void* q; long ldq; void* s; long lds; int M, K, packed; };
+struct Add3Args { const void *a, *b, *c; void* out; int n; };
+struct Entry {
+    Kind kind; int side;
+    union { utx_gemm_desc gemm; utx_gemv_desc gemv; utx_ln_mod_desc ln; utx_qkv_post_desc qkv; AttnArgs attn; QuantArgs quant; Add3Args add3; };
+    Entry() { memset(this, 0, sizeof(*this)); }
+};
+}  // namespace
+
+struct utx_plan {
+    std::vector<Entry> entries;
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> events;     // one (fork, join) pair per two-stream section
+    int cur_side = 0, open_sections = 0;
+    int device = 0;
+};
+
+extern "C" int utx_launch_add3_bf16(const void* a, const void* b, const void* c, void* out, int n, hipStream_t stream);   // dit_elementwise.hip
+
+extern "C" {
+
+int utx_plan_create(utx_ctx* ctx, utx_plan** out) {
+    (void)ctx;
+    if (!out) return -2;
+    utx_plan* p = new utx_plan();
+    if (hipGetDevice(&p->device) != hipSuccess) { delete p; return -5; }
+    *out = p;
+    return 0;
+}
+
+void utx_plan_free(utx_plan* p) {
+    if (!p) return;
+    for (hipEvent_t e : p->events) (void)hipEventDestroy(e);
+    if (p->side) (void)hipStreamDestroy(p->side);
+    delete p;
+}
+
+int utx_plan_size(const utx_plan* p) { return p ? (int)p->entries.size() : -2; }
+
+static Entry& push(utx_plan* p, Kind k) { p->entries.emplace_back(); Entry& e = p->entries.back(); e.kind = k; e.side = p->cur_side; return e; }
+
+int utx_plan_add_gemm(utx_plan* p, const utx_gemm_desc* d) { if (!p || !d) return -2; push(p, K_GEMM).gemm = *d; return 0; }
+int utx_plan_add_gemv(utx_plan* p, const utx_gemv_desc* d) { if (!p || !d) return -2; push(p, K_GEMV).gemv = *d; return 0; }
+int utx_plan_add_ln_mod(utx_plan* p, const utx_ln_mod_desc* d) { if (!p || !d) return -2; push(p, K_LN_MOD).ln = *d; return 0; }
+int utx_plan_add_qkv_post(utx_plan* p, const utx_qkv_post_desc* d) { if (!p || !d) return -2; push(p, K_QKV_POST).qkv = *d; return 0; }
+int utx_plan_add_attn(utx_plan* p, const void* q, const void* k, const void* vt, void* o, long q_hs, long q_ss, long k_hs, long k_ss, long vt_hs,
+                      long vt_ds, long o_ss, int H, int S_q, int S_kv, float softmax_scale, float key_bias_log2, int key_bias_period, void* work,
+                      size_t work_bytes) {
+    if (!p || !q || !k || !vt || !o) return -2;
+    AttnArgs a = {q, k, vt, o, q_hs, q_ss, k_hs, k_ss, vt_hs, vt_ds, o_ss, H, S_q, S_kv, softmax_scale, key_bias_log2, key_bias_period, work, work_bytes};
+    push(p, K_ATTN).attn = a;
+    return 0;
+}
+int utx_plan_add_quant_mx8(utx_plan* p, const void* x, long ldx, void* q, long ldq, void* s, long lds_or_row_blocks, int M, int K, int packed) {
+    if (!p || !x || !q || !s) return -2;
+    QuantArgs a = {x, ldx, q, ldq, s, lds_or_row_blocks, M, K, packed};
+    push(p, K_QUANT).quant = a;
+    return 0;
+}
+int utx_plan_add_add3(utx_plan* p, const void* a, const void* b, const void* c, void* out, int n) {
+    if (!p || !a || !c || !out || n <= 0) return -2;      // b may be NULL: out = a + c
+    Add3Args g = {a, b, c, out, n};
+    push(p, K_ADD3).add3 = g;
+    return 0;
+}
+// two-stream section: fork; [side entries]; utx_plan_main; [main entries]; join
+int utx_plan_fork(utx_plan* p) {
+    if (!p || p->cur_side || p->open_sections) return -2;
+    if (!p->side && hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) != hipSuccess) return -5;
+    hipEvent_t a, b;
+    if (hipEventCreateWithFlags(&a, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&b, hipEventDisableTiming) != hipSuccess) return -5;
+    p->events.push_back(a); p->events.push_back(b);
+    push(p, K_FORK);
+    p->cur_side = 1; p->open_sections = 1;
+    return 0;
+}
+int utx_plan_main(utx_plan* p) { if (!p || !p->open_sections) return -2; p->cur_side = 0; return 0; }
+int utx_plan_join(utx_plan* p) {
+    if (!p || !p->open_sections) return -2;
+    p->cur_side = 0; p->open_sections = 0;
+    push(p, K_JOIN);
+    return 0;
+}
+
+// Replay.  Returns 0, or the first failing launcher's code with its entry index in *failed_entry (may be NULL).
+int utx_plan_run(utx_plan* p, utx_stream stream_, int* failed_entry) {
+    if (!p || p->open_sections) return -2;
+    hipStream_t main_s = (hipStream_t)stream_;
+    size_t section = 0;
+    for (size_t i = 0; i < p->entries.size(); ++i) {
+        const Entry& e = p->entries[i];
+        hipStream_t st = e.side ? p->side : main_s;
+        int rc = 0;
+        switch (e.kind) {
+            case K_GEMM: rc = utx_launch_gemm_bf16(&e.gemm, st); break;
+            case K_GEMV: rc = utx_launch_gemv_bf16(&e.gemv, st); break;
+            case K_LN_MOD: rc = utx_launch_ln_mod(&e.ln, st); break;
+            case K_QKV_POST: rc = utx_launch_qkv_post(&e.qkv, st); break;
+            case K_ATTN: {
+                const AttnArgs& a = e.attn;
+                rc = utx_launch_attn_fwd(a.q, a.k, a.vt, a.o, a.q_hs, a.q_ss, a.k_hs, a.k_ss, a.vt_hs, a.vt_ds, a.o_ss, a.H, a.S_kv, a.S_q, a.scale, a.kb,
+                                         a.period, a.work, a.work_bytes, st);
+                break;
+            }
+            case K_QUANT: {
+                const QuantArgs& a = e.quant;
+                rc = a.packed ? utx_launch_quant_mx8_packed(a.x, a.ldx, a.q, a.ldq, a.s, a.lds, a.M, a.K, st)
+                              : utx_launch_quant_mx8(a.x, a.ldx, a.q, a.ldq, a.s, a.lds, a.M, a.K, st);
+                break;
+            }
+            case K_ADD3: rc = utx_launch_add3_bf16(e.add3.a, e.add3.b, e.add3.c, e.add3.out, e.add3.n, st); break;
+            case K_FORK:
+                if (hipEventRecord(p->events[2 * section], main_s) != hipSuccess || hipStreamWaitEvent(p->side, p->events[2 * section], 0) != hipSuccess) rc = -4;
+                break;
+            case K_JOIN:
+                if (hipEventRecord(p->events[2 * section + 1], p->side) != hipSuccess || hipStreamWaitEvent(main_s, p->events[2 * section + 1], 0) != hipSuccess) rc = -4;
+                ++section;
+                break;
+        }
+        if (rc != 0) { if (failed_entry) *failed_entry = (int)i; return rc; }
+    }
+    return 0;
+}
+
+}  // extern "C"

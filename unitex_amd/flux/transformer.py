@@ -228,8 +228,7 @@ class FluxDiT:
         injected with weight 0: pipeline.py:110-111,245,263 -- contributing exactly 0)."""
         self._lora_active = [(d, float(s)) for d, s in adapters if float(s) != 0.0]
         self._lora_version += 1
-        self._plans.clear()
-        self._graphs = {}
+        self._drop_plans()
         self._pack_full_overrides()
         self._pack_lora()
         if self.fp8_weights:
@@ -733,6 +732,14 @@ class FluxDiT:
         from .ulysses import local_slice
         return (0, S_img) if self.sp is None else local_slice(S_img, self.sp[0], self.sp[1])
 
+    def _drop_plans(self):
+        for p in self._plans.values():
+            if p.get("cplan") is not None:
+                self.lib.utx_plan_free(p["cplan"])
+                p["cplan"] = None
+        self._plans.clear()
+        self._graphs = {}
+
     def set_output_rows(self, n):
         """Only the first n image tokens' prediction will be read from forward()'s result (None = all).  Call it BETWEEN set_positions and
         set_conditioning: set_positions starts a new job and resets it to None, so a later user of the same FluxDiT never inherits a previous
@@ -775,9 +782,10 @@ class FluxDiT:
         self.key_bias_period = (S_loc // 64) if (identical and world > 1) else 0
         key = (t1 - t0, i1 - i0, self._lora_version, self.key_bias_log2, self.key_bias_period, self.out_rows)
         if key not in self._plans:
-            self._plans.clear()  # one live plan: workspaces are large
-            self._graphs = {}
+            self._drop_plans()   # one live plan: workspaces are large
             self._plans[key] = self._build(t1 - t0, i1 - i0)
+            if os.environ.get("UTX_C_PLAN", "1") != "0":
+                self.compile_plan(self._plans[key])
         p = self._plans[key]
         ws = p["ws"]
         cos, sin = rope_tables(torch.cat([txt_ids[t0:t1], img_ids[i0:i1]], dim=0), self.shape.axes_dim, self.shape.theta)
@@ -880,6 +888,59 @@ class FluxDiT:
             else:
                 self._launch(fn, d, st)
 
+    # ------------------------------------------------------------------ C-side replay (utx_plan)
+    def compile_plan(self, p=None):
+        """Copy the per-step plan into a utx_plan (include/unitex_hip.h, csrc/plan.cpp): forward() then replays it with ONE C call per step
+        (utx_plan_run = SURVEY 8b's `utx_dit_step`) instead of ~700 ctypes calls -- the same launchers in the same order on the same two streams, so
+        the result is bit-identical.  Not under sequence parallelism (the collectives are torch.distributed calls) and not while per-kernel events
+        are requested (bench.py's roofline timing walks the Python list).  Returns the handle, or None when the plan has entries C cannot replay."""
+        p = next(iter(self._plans.values())) if p is None else p
+        if self.sp is not None:
+            return None
+        lib, ws = self.lib, p["ws"]
+        h = C.c_void_p()
+        self.ctx.check(lib.utx_plan_create(self.ctx.handle, C.byref(h)))
+
+        def add(fn, d):
+            if fn is lib.utx_gemm_bf16:
+                return lib.utx_plan_add_gemm(h, C.byref(d))
+            if fn is lib.utx_gemv_bf16:
+                return lib.utx_plan_add_gemv(h, C.byref(d))
+            if fn is lib.utx_ln_mod:
+                return lib.utx_plan_add_ln_mod(h, C.byref(d))
+            if fn is lib.utx_qkv_post:
+                return lib.utx_plan_add_qkv_post(h, C.byref(d))
+            if fn is lib.utx_attn_fwd_bf16_ws:
+                return lib.utx_plan_add_attn(h, *d)
+            if isinstance(fn, str) and fn == "quant_mx8":
+                x_, q_, s_ = d
+                if hasattr(s_, "row_blocks"):
+                    return lib.utx_plan_add_quant_mx8(h, ptr(x_), x_.stride(0), ptr(q_), q_.stride(0), ptr(s_.data), s_.row_blocks, x_.shape[0], x_.shape[1], 1)
+                return lib.utx_plan_add_quant_mx8(h, ptr(x_), x_.stride(0), ptr(q_), q_.stride(0), ptr(s_), s_.stride(0), x_.shape[0], x_.shape[1], 0)
+            if isinstance(fn, str) and fn == "temb_sum":
+                g = ws["e_g"] if self.shape.guidance_embeds else None
+                return lib.utx_plan_add_add3(h, ptr(ws["e_t"]), ptr(g), ptr(ws["e_p"]), ptr(ws["temb"]), ws["temb"].numel())
+            return -100
+        ok = True
+        for fn, d in p["plan"]:
+            if isinstance(fn, str) and fn == "par":
+                main_ops, side_ops = d[0], d[1]
+                rcs = [lib.utx_plan_fork(h)] + [add(f2, d2) for f2, d2 in side_ops] + [lib.utx_plan_main(h)] + \
+                      [add(f2, d2) for f2, d2 in main_ops] + [lib.utx_plan_join(h)]
+            else:
+                rcs = [add(fn, d)]
+            if any(rc != 0 for rc in rcs):
+                ok = False
+                break
+        if not ok:
+            lib.utx_plan_free(h)
+            return None
+        old = p.get("cplan")
+        if old is not None:
+            lib.utx_plan_free(old)
+        p["cplan"] = h
+        return h
+
     def forward(self, hidden_states, timestep: float, out: Optional[torch.Tensor] = None):
         """One transformer evaluation.  hidden_states [S_img, 64] bf16 (noise ++ condition tokens);
         `timestep` is the value the pipeline passes (t/1000, already rounded to the latent dtype).
@@ -893,6 +954,11 @@ class FluxDiT:
         g = self._graphs.get(id(p))
         if g is not None:
             g.replay()
+        elif p.get("cplan") is not None and self.attn_events is None and self.gemm_events is None:
+            bad = C.c_int(-1)
+            rc = self.lib.utx_plan_run(p["cplan"], self.ctx.stream(), C.byref(bad))
+            if rc:
+                raise RuntimeError("utx_plan_run: entry %d failed with code %d" % (bad.value, rc))
         else:
             self.run_plan(p)
         if out is not None:

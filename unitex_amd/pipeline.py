@@ -24,8 +24,9 @@ PNG_LEVEL = int(os.environ.get("UTX_PNG_LEVEL", "1"))
 
 
 def build_pipeline(pretrain_models=None, pipeline_name="texture_plus", device="cuda:0", seed=0, lora_rank=64, shape=None,
-                   sequence_parallel=False, process_group=None):
-    """FluxDiT + VAE + adapters.  With a `pretrain_models` directory holding diffusers-format safetensors the real
+                   sequence_parallel=False, process_group=None, speedup_mode=None):
+    """FluxDiT + VAE + adapters.  speedup_mode: the reference's constructor takes the argument and never reads it (pipeline.py:81,142-145); here
+    "fp8" runs the big linears on OCP MX fp8 operands (FluxDiT(fp8_weights=True): BASELINE configs[4] numerics, NOT the default), anything else = bf16.  With a `pretrain_models` directory holding diffusers-format safetensors the real
     weights are loaded; otherwise (no checkpoints exist here) FLUX.1-dev-shaped synthetic weights are generated.
     sequence_parallel: ONE job over the ranks of `process_group` (flux/ulysses.py)."""
     from .flux.pipeline import PBRFluxPipeline
@@ -45,7 +46,8 @@ def build_pipeline(pretrain_models=None, pipeline_name="texture_plus", device="c
         vae = AutoencoderKL.synthetic(seed=0, device=device)
         tex = synthetic_lora(sd, shape, rank=lora_rank, seed=1, device=device)
         dlt = synthetic_lora(sd, shape, rank=lora_rank, seed=2, device=device)
-    pipe = PBRFluxPipeline(FluxDiT(sd, shape, device=device, sequence_parallel=sequence_parallel, sp_group=process_group), vae, device=device)
+    pipe = PBRFluxPipeline(FluxDiT(sd, shape, device=device, sequence_parallel=sequence_parallel, sp_group=process_group,
+                                   fp8_weights=(speedup_mode == "fp8")), vae, device=device)
     pipe.load_lora_weights(tex, adapter_name="texture")
     pipe.load_lora_weights(dlt, adapter_name="delight")
     pipe._num_inference_steps = 28
@@ -76,7 +78,7 @@ class RGBTextureFullPipelineBase:
         shard = (self.rank, self.world)
         if pipeline is None:
             pipeline, wt, wd, names = build_pipeline(pretrain_models, pipeline_name, device=device, sequence_parallel=bool(multi_gpu),
-                                                     process_group=self.process_group)
+                                                     process_group=self.process_group, speedup_mode=speedup_mode)
         else:
             wt, wd, names = [1.0, 0.0], [0.0, 1.0], ["texture", "delight"]
         if num_inference_steps is not None:
