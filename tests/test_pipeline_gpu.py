@@ -209,3 +209,27 @@ def test_condition_render_uses_the_raw_input_mesh_not_the_processed_one(tmp_path
         r, c = divmod(v, 3)
         ref = G.rasterize(clip[v], rf_, 256, 256)[..., 3] > 0
         assert np.array_equal(alpha_img[r * 256:(r + 1) * 256, c * 256:(c + 1) * 256] > 0, ref), "condition alpha of the raw mesh, view %d" % v
+
+
+def test_speedup_mode_fp8_builds_an_mx_fp8_transformer_and_runs(tmp_path):
+    """The reference's constructor takes `speedup_mode` and never reads it (pipeline.py:81,142-145); here "fp8" selects BASELINE configs[4]'s numerics:
+    build_pipeline(speedup_mode="fp8") -> FluxDiT(fp8_weights=True) with both adapters loaded; a 2-step texture + delight pass runs end to end and
+    differs from the bf16 pipeline by fp8 rounding only (same seed, same control image)."""
+    from unitex_amd.flux.transformer import FluxShape
+    from unitex_amd.pipeline import build_pipeline
+    shape = FluxShape(num_heads=2, num_double=1, num_single=1, joint_dim=64, pooled_dim=64)
+    yy, xx = np.mgrid[0:64, 0:192]
+    ctrl = Image.fromarray(np.stack([xx % 256, (yy * 4) % 256, (xx + yy) % 256], -1).astype(np.uint8))
+    outs = {}
+    for mode in (None, "fp8"):
+        pipe, wt, wd, names = build_pipeline(None, device="cuda:0", lora_rank=16, shape=shape, speedup_mode=mode)
+        assert pipe.transformer.fp8_weights == (mode == "fp8")
+        pipe.vae = fakes.FakeVAE()
+        pipe.set_adapters(names, wt)
+        img = pipe(prompt="[MVFLUX]", control_image=ctrl, height=64, width=192, num_inference_steps=2, guidance_scale=3.5, max_sequence_length=64,
+                   generator=torch.Generator().manual_seed(63)).images[0]
+        outs[mode] = np.asarray(img).astype(np.int32)
+        del pipe
+        torch.cuda.empty_cache()
+    d = np.abs(outs["fp8"] - outs[None])
+    assert outs[None].std() > 1.0 and d.max() > 0 and d.mean() < 8.0, "fp8 pipeline vs bf16 pipeline: mean |d| %.2f LSB, max %d" % (d.mean(), d.max())
