@@ -709,8 +709,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         W4_STAGE_HALF(0); W4_STAGE_HALF(1);
         W4_XSCALE_LOAD(sa_nxt, s_pSA); W4_XSCALE_LOAD(sb_nxt, s_pSB);
         W4_STAGE_ADVANCE();
-        W4_DMA(0, 0); W4_DMA(0, 1); W4_DMA(0, 2); W4_DMA(0, 3); W4_DMA(0, 4); W4_DMA(0, 5); W4_DMA(0, 6); W4_DMA(0, 7); W4_DMA(1, 0); W4_DMA(1, 1); W4_DMA(1, 2);
-        asm volatile("s_waitcnt vmcnt(11)" : "+v"(sa_nxt), "+v"(sb_nxt) : : "memory");
+        W4_DMA(0, 0); W4_DMA(0, 1); W4_DMA(0, 2); W4_DMA(0, 3); W4_DMA(0, 4); W4_DMA(0, 5); W4_DMA(0, 6); W4_DMA(0, 7);
+        if constexpr ((ABL & 2048) != 0) { asm volatile("s_waitcnt vmcnt(8)" : "+v"(sa_nxt), "+v"(sb_nxt) : : "memory"); }
+        else if constexpr ((ABL & 1024) != 0) {
+            W4_DMA(1, 0); W4_DMA(1, 1); W4_DMA(1, 2); W4_DMA(1, 3); W4_DMA(1, 4);
+            asm volatile("s_waitcnt vmcnt(13)" : "+v"(sa_nxt), "+v"(sb_nxt) : : "memory");
+        } else {
+            W4_DMA(1, 0); W4_DMA(1, 1); W4_DMA(1, 2);
+            asm volatile("s_waitcnt vmcnt(11)" : "+v"(sa_nxt), "+v"(sb_nxt) : : "memory");
+        }
         W4_FENCE();
         W4_XSCALE_TAKE();
         W4_COMPUTE_AT(0, -1);
@@ -771,7 +778,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         //             to land: the bf16 schedule's 18 x 32], s_barrier
         //   K-step 1: MFMAs on X1 | reads -> X0 (first half of the NEXT stage) | pieces 0..10 of K-tile + 2 into THIS stage (two per three slots:
         //             one DMA per 96 matrix-pipe cycles, the spacing the bf16 schedule settled on); scales next -> current
-#define W4_XPIECE_OF(ks_, i_) ((ks_) == 1 ? ((((i_) % 3) != 2) ? ((i_) / 3) * 2 + ((i_) % 3) : -1) : (((((i_) % 3) != 2) && (i_) < 7) ? 11 + ((i_) / 3) * 2 + ((i_) % 3) : -1))
+        // (ablation build, correct results, tools/mx_dma_sweep.py: other placements of the same sixteen pieces -- ABL 1024: 3 in K-step 0 (slots 0, 2, 4) + 13 in
+        // K-step 1 (one per MFMA); ABL 2048: 8 + 8 (K-step 0 slots 0..7, K-step 1 every other slot); ABL 4096: the default placement with the two scale
+        // loads in slots 0, 1 instead of 8, 9)
+#define W4_XPIECE_OF(ks_, i_) (((ABL) & 1024) ? ((ks_) == 1 ? ((i_) < 13 ? (i_) : -1) : (((i_) % 2 == 0 && (i_) < 6) ? 13 + (i_) / 2 : -1))                  \
+                               : ((ABL) & 2048) ? ((ks_) == 1 ? (((i_) % 2 == 0) ? (i_) / 2 : -1) : ((i_) < 8 ? 8 + (i_) : -1))                                \
+                               : ((ks_) == 1 ? ((((i_) % 3) != 2) ? ((i_) / 3) * 2 + ((i_) % 3) : -1) : (((((i_) % 3) != 2) && (i_) < 7) ? 11 + ((i_) / 3) * 2 + ((i_) % 3) : -1)))
 #define W4_XKSTEP(i_, ks_, FA_, FB_, FAn_, FBn_, base_, xlo_, xhi_)                                        \
         {                                                                                                  \
             constexpr int pc_ = W4_XPIECE_OF(ks_, i_);                                                     \
@@ -780,8 +792,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             W4_FENCE();                                                                                    \
             W4_XREAD(i_, FAn_, FBn_, base_, xlo_, xhi_);                                                   \
             if constexpr (pc_ >= 0) W4_DMA_M0(isb_, d_);                                                   \
-            if constexpr ((ks_) == 0 && (i_) == 8) W4_XSCALE_LOAD(sa_nxt, s_pSA);                          \
-            if constexpr ((ks_) == 0 && (i_) == 9) W4_XSCALE_LOAD(sb_nxt, s_pSB);                          \
+            if constexpr ((ks_) == 0 && (i_) == (((ABL) & 4096) ? 0 : 8)) W4_XSCALE_LOAD(sa_nxt, s_pSA);   \
+            if constexpr ((ks_) == 0 && (i_) == (((ABL) & 4096) ? 1 : 9)) W4_XSCALE_LOAD(sb_nxt, s_pSB);   \
             W4_FENCE();                                                                                    \
         }
 #define W4_XKSTEP16(ks_, FA_, FB_, FAn_, FBn_, base_, xlo_, xhi_)                                          \
@@ -980,6 +992,12 @@ extern "C" int utx_launch_gemm_w4(GemmParams p, hipStream_t stream) {
     int sk_T = 0, sk_S = 0;
     utx_gemm_w4_split_plan(&p, tiles, grid, (p.sk_work && p.sk_work_bytes >= (size_t)2 * grid * 262144) ? 1 : 0, &sk_T, &sk_S);     // a plan holds at most 2 grid partial tiles
 #ifdef UTX_ABLATION
+    if (p.mx8 == 2 && !p.gate) {      // DMA-placement variants of the MX kernel (correct results): UTX_GEMM_DEBUG = 32 * {1024, 2048, 4096}
+        const int xabl = (g_utx_opt.gemm_debug_abl >> 5) & (1024 | 2048 | 4096);
+#define W4_XABL_CASE(a_) if (xabl == (a_)) { hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_w4_kernel<false, (a_), false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
+                                            hipLaunchKernelGGL((gemm256_w4_kernel<false, (a_), false, true>), dim3(grid), dim3(256), LDS, stream, p, tiles, trace_wg, 0, 0); return hipGetLastError() == hipSuccess ? 0 : -4; }   /* never split: compare with UTX_GEMM_STREAMK=0 */
+        W4_XABL_CASE(1024) W4_XABL_CASE(2048) W4_XABL_CASE(4096)
+    }
     {
         const int abl = (g_utx_opt.gemm_debug_abl >> 5) & 1023;   // (ABL 256 = start-time stagger, 512 = plain instead of nontemporal C stores: results stay correct)     // UTX_GEMM_DEBUG bits 5..14
         if (abl && !p.gate) {
