@@ -147,7 +147,7 @@ def test_full_depth_full_width_forward_matches_oracle():
     """ALL 19 double + 38 single blocks at the real FLUX width (D = 3072, 24 heads, 11.9 G synthetic parameters, rank-16 LoRA) on a short sequence
     (64 text + 512 + 512 + 64 image tokens = 1152), one transformer evaluation against the bf16-emulating fp32 oracle: the drift of the HIP kernels'
     bf16 evaluation order through the full depth (SURVEY 7 "hard parts": 57 layers), which the 1 + 1-block full-width tests cannot show.
-    STATED TOLERANCE: max |d| <= 0.08 max|out|, mean |d| <= 0.01 max|out| (measured value printed)."""
+    STATED TOLERANCE: max |d| <= 0.03 max|out|, mean |d| <= 0.005 max|out| (measured on MI355X, profiles/r03_full_depth_a.log: 0.012 and 0.0023)."""
     from unitex_amd.flux.synthetic import SyntheticFluxStateDict, synthetic_lora
     from unitex_amd.flux.transformer import FluxDiT, FluxShape
     cfg = dit_ref.FluxConfig()
@@ -179,4 +179,4 @@ def test_full_depth_full_width_forward_matches_oracle():
     print("\n[full depth 19 + 38 blocks, full width, S = %d] max|d| %.4g = %.4g of max|out| %.3g, mean|d| %.4g = %.4g of max" % (
         S_txt + S_img, d.max().item(), d.max().item() / mx, mx, d.mean().item(), d.mean().item() / mx))
     assert torch.isfinite(out).all()
-    assert d.max().item() <= 0.08 * mx and d.mean().item() <= 0.01 * mx
+    assert d.max().item() <= 0.03 * mx and d.mean().item() <= 0.005 * mx

@@ -12,7 +12,7 @@ _lib.set_option("UTX_GEMM_STREAMK", 0)
 def t1(fn):
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record(); fn(); b.record(); torch.cuda.synchronize(); return a.elapsed_time(b)
-names = {0: "default 5+11", 1024: "3+13", 2048: "8+8", 4096: "5+11, scales early"}
+names = {0: "default 5+11, scales in slots 0,1", 1024: "3+13", 2048: "8+8", 4096: "5+11, scales in slots 8,9"}   # profiles/r03_mx_dma_sweep_v0.log predates the adoption: its "default" had the scales in slots 8, 9
 for M, N, K in [(50688, 9216, 3072), (50688, 21504, 3072), (50688, 3072, 12288), (50688, 3072, 15360), (13824, 21504, 3072)]:
     A = (torch.randn(M, K, device="cuda") / math.sqrt(K)).to(torch.bfloat16); B = torch.randn(N, K, device="cuda").to(torch.bfloat16)
     bias = torch.randn(N, device="cuda").to(torch.bfloat16)

@@ -774,13 +774,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // ---- MX fp8: a K-tile (128 k) is TWO K-steps of 16 scaled MFMAs (64 cycles each: the same 2048 matrix-pipe cycles as the 64 bf16 MFMAs
         // of a 64-k K-tile, on twice the k).  Slot i carries one 16-byte fragment read (the next K-step's) and at most one DMA:
         //   K-step 0: MFMAs on X0 | reads -> X1 (second half of this stage) | pieces 11..15 of the cursor's K-tile (= compute K-tile + 1) in slots
-        //             0, 1, 3, 4, 6, its scale dwords in slots 8, 9, the cursor advances; lgkmcnt(0), vmcnt(0) [9 MFMAs = 576 cycles for the last piece
+        //             0, 1, 3, 4, 6, its scale dwords in slots 0, 1, the cursor advances; lgkmcnt(0), vmcnt(0) [9 MFMAs = 576 cycles for the last piece
         //             to land: the bf16 schedule's 18 x 32], s_barrier
         //   K-step 1: MFMAs on X1 | reads -> X0 (first half of the NEXT stage) | pieces 0..10 of K-tile + 2 into THIS stage (two per three slots:
         //             one DMA per 96 matrix-pipe cycles, the spacing the bf16 schedule settled on); scales next -> current
         // (ablation build, correct results, tools/mx_dma_sweep.py: other placements of the same sixteen pieces -- ABL 1024: 3 in K-step 0 (slots 0, 2, 4) + 13 in
         // K-step 1 (one per MFMA); ABL 2048: 8 + 8 (K-step 0 slots 0..7, K-step 1 every other slot); ABL 4096: the default placement with the two scale
-        // loads in slots 0, 1 instead of 8, 9)
+        // loads in slots 8, 9 instead of 0, 1.  Measured, profiles/r03_mx_dma_sweep_v0.log (taken while 8, 9 was the default): 3 + 13 equal (+-0.3 %), 8 + 8
+        // -2.3...-2.7 % on every shape (the last piece gets 8 instead of 9 MFMAs to land), scale loads in slots 0, 1 +0.4...+1.8 % -> adopted)
 #define W4_XPIECE_OF(ks_, i_) (((ABL) & 1024) ? ((ks_) == 1 ? ((i_) < 13 ? (i_) : -1) : (((i_) % 2 == 0 && (i_) < 6) ? 13 + (i_) / 2 : -1))                  \
                                : ((ABL) & 2048) ? ((ks_) == 1 ? (((i_) % 2 == 0) ? (i_) / 2 : -1) : ((i_) < 8 ? 8 + (i_) : -1))                                \
                                : ((ks_) == 1 ? ((((i_) % 3) != 2) ? ((i_) / 3) * 2 + ((i_) % 3) : -1) : (((((i_) % 3) != 2) && (i_) < 7) ? 11 + ((i_) / 3) * 2 + ((i_) % 3) : -1)))
@@ -792,8 +793,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             W4_FENCE();                                                                                    \
             W4_XREAD(i_, FAn_, FBn_, base_, xlo_, xhi_);                                                   \
             if constexpr (pc_ >= 0) W4_DMA_M0(isb_, d_);                                                   \
-            if constexpr ((ks_) == 0 && (i_) == (((ABL) & 4096) ? 0 : 8)) W4_XSCALE_LOAD(sa_nxt, s_pSA);   \
-            if constexpr ((ks_) == 0 && (i_) == (((ABL) & 4096) ? 1 : 9)) W4_XSCALE_LOAD(sb_nxt, s_pSB);   \
+            if constexpr ((ks_) == 0 && (i_) == (((ABL) & 4096) ? 8 : 0)) W4_XSCALE_LOAD(sa_nxt, s_pSA);   \
+            if constexpr ((ks_) == 0 && (i_) == (((ABL) & 4096) ? 9 : 1)) W4_XSCALE_LOAD(sb_nxt, s_pSB);   \
             W4_FENCE();                                                                                    \
         }
 #define W4_XKSTEP16(ks_, FA_, FB_, FAn_, FBn_, base_, xlo_, xhi_)                                          \
