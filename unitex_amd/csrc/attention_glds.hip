@@ -297,6 +297,11 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
                 uint2 v;                                                                                     \
                 v.x = pack2bf(oacc[db][4 * a + 0] * inv, oacc[db][4 * a + 1] * inv);                         \
                 v.y = pack2bf(oacc[db][4 * a + 2] * inv, oacc[db][4 * a + 3] * inv);                         \
+                if constexpr (VAR == 8) {   /* ablation build: NONTEMPORAL output stores -- O is read once, by the out-projection, long after; K / V should keep the L2 */ \
+                    typedef __attribute__((ext_vector_type(2))) unsigned int ag_u32x2;                       \
+                    const ag_u32x2 nv_ = {v.x, v.y};                                                         \
+                    __builtin_nontemporal_store(nv_, reinterpret_cast<ag_u32x2*>(o8_ + 32 * db + 8 * a));    \
+                } else                                                                                       \
                 *reinterpret_cast<uint2*>(o8_ + 32 * db + 8 * a) = v;                                        \
             }                                                                                                \
         }                                                                                                    \
@@ -392,7 +397,7 @@ static int launch_glds(AttnParams p, hipStream_t stream) {
     p.nqb = ((p.Sq > 0 ? p.Sq : p.S) + 255) / 256;
     p.w_base = 0; p.nsplit = 1; p.tiles_per_split = 0; p.part_o = nullptr; p.part_lse = nullptr;
     int pl[4] = {p.nqb * p.H, 0, 1, 0};
-    if (TPB == 1 && (VAR == 0 || VAR == 6 || VAR == 7) && !p.flags) utx_attn_split_plan_impl(p.H, p.Sq, p.S, utx_ncu(), pl);
+    if (TPB == 1 && (VAR == 0 || VAR == 6 || VAR == 7 || VAR == 8) && !p.flags) utx_attn_split_plan_impl(p.H, p.Sq, p.S, utx_ncu(), pl);
     const int nwg = pl[0], nfull = pl[1], ns = pl[2], tps = pl[3], r = nwg - nfull;
     // the scratch of the split is CALLER-OWNED (utx_attn_fwd_bf16_ws; the legacy entry points pass the context's own buffer, grown outside of any
     // capture): nothing is allocated here, a launch whose scratch is missing or too small runs unsplit -- same result up to one bf16 rounding of the
@@ -424,6 +429,7 @@ extern "C" int utx_launch_attn_fwd_glds(const AttnParams* p, int presc, hipStrea
       if (var == 4 && presc) return launch_glds<1, 1, 4>(*p, stream);
       if (var == 5 && presc) return launch_glds<1, 1, 5>(*p, stream);
       if (var == 6 && presc) return launch_glds<1, 1, 6>(*p, stream);      // static priority for waves 4-7 (correct results)
+      if (var == 8 && presc) return launch_glds<1, 1, 8>(*p, stream);      // nontemporal output stores (correct results)
       if (var == 7 && presc) return launch_glds<1, 1, 7>(*p, stream); }    // 16-byte epilogue stores through v_permlane32_swap (correct results)
 #endif
     return presc ? launch_glds<1, 1>(*p, stream) : launch_glds<0, 1>(*p, stream);

@@ -732,6 +732,12 @@ class FluxDiT:
         from .ulysses import local_slice
         return (0, S_img) if self.sp is None else local_slice(S_img, self.sp[0], self.sp[1])
 
+    def __del__(self):
+        try:
+            self._drop_plans()      # the C-side plans own a HIP stream and events
+        except Exception:  # noqa: BLE001 -- interpreter shutdown: the library may be gone already
+            pass
+
     def _drop_plans(self):
         for p in self._plans.values():
             if p.get("cplan") is not None:
