@@ -174,6 +174,12 @@ def load_library():
         raise RuntimeError(
             "libunitex_hip.so not found at %s -- run `python unitex_amd/csrc/build.py` "
             "(or __graft_entry__.build()). There is no CPU/PyTorch fallback by design." % LIB_PATH)
+    # ONE HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so (SONAME libamdhip64.so.7, requested by libtorch_hip.so under the
+    # unversioned name); this library asks for libamdhip64.so.7.  With torch loaded first the dynamic loader resolves our request to torch's copy (SONAME
+    # match); the other way round it maps the system copy for us and torch's bundled one afterwards -- two runtimes, and the second one to touch the
+    # device fails (seen as utx_init -> -5 when __graft_entry__.build() loaded this library before smoke() imported torch).  torch owns the device
+    # memory and the streams here anyway: import it first.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
