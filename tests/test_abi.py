@@ -63,3 +63,25 @@ def test_no_gpu_means_loud_failure():
         pytest.skip("GPU present")
     with pytest.raises(RuntimeError):
         _lib.Context(0)
+
+
+def test_bit_exact_kernels_are_built_without_fp_contraction():
+    """The float32 outputs that the GPU tests compare BIT FOR BIT with the C / numpy oracle (clip transform, barycentrics, interpolation, gathered colours,
+    LBVH boxes, pull-push, k-NN distances, LayerNorm / RoPE roundings) are bit-exact only because both sides evaluate the same expression order
+    without fused multiply-adds: the build table must carry -ffp-contract=off for exactly those sources, and the oracle's Makefile as well.  The files
+    outside the set are the ones whose tests carry a tolerance (MFMA GEMMs / attention: bf16 bounds; vae.hip: bf16 bounds) or compute integers only
+    (unwrap.hip: label propagation)."""
+    import re
+    from unitex_amd.csrc import build as b
+    flags = {name: extra for name, extra in b.SOURCES}
+    must = ["dit_elementwise.hip", "raster.hip", "bvh.hip", "backproject.hip", "texture_post.hip", "knn.hip"]
+    for name in must:
+        assert "-ffp-contract=off" in flags[name], "%s must be compiled with -ffp-contract=off (bit-exact tests depend on it)" % name
+    for name in ("gemm.hip", "gemm_w4.hip", "gemm_pers.hip", "attention.hip", "attention_glds.hip", "attention_q64.hip", "vae.hip", "unwrap.hip"):
+        assert "-ffp-contract=off" not in flags[name]
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(here, "unitex_amd", "csrc", "unwrap.hip")).read()
+    body = re.sub(r"//[^\n]*", "", src)
+    assert not re.search(r"\bfloat\b|\bdouble\b", body), "unwrap.hip is outside the no-contraction set because it has no floating-point arithmetic"
+    mk = open(os.path.join(here, "oracle", "Makefile")).read()
+    assert "-ffp-contract=off" in mk, "the C oracle must be built without contraction as well"
