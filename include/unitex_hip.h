@@ -416,6 +416,59 @@ int utx_plan_fork(utx_plan* plan);
 int utx_plan_main(utx_plan* plan);
 int utx_plan_join(utx_plan* plan);
 int utx_plan_run(utx_plan* plan, utx_stream stream, int* failed_entry);
+int utx_plan_assign_sk(utx_plan* plan, void* sk_work, size_t sk_work_bytes, int n_cus);   /* split-tail scratch for the caller-stream GEMMs when any has more 256^2 tiles than CUs */
+int utx_plan_entry(const utx_plan* plan, int i, int* kind, int* side, void* buf, size_t cap);   /* read an entry back: kind 0 gemm 1 gemv 2 ln_mod 3 qkv_post 4 attn 5 quant 6 add3 7 fork 8 join */
+
+/* ---- utx_dit_load / utx_dit_step: the FLUX.1-dev transformer step built in C -------------------------------------------------------------
+ * Replaces FluxTransformer2DModel.forward as the reference calls it (flux_piplines/texturing/pipeline.py:646-656; block arithmetic = diffusers [3p]) for the
+ * bf16 single-GPU path: utx_dit_load builds the SAME utx_plan unitex_amd/flux/transformer.py::FluxDiT builds (compared entry by entry, byte by byte, in
+ * tests/test_dit_ops_gpu.py::test_c_built_dit_plan_equals_the_python_built_one) from plain structs.  The caller owns everything: weights PACKED as FluxDiT packs
+ * them -- double block: qkv_x = [to_q; to_k; to_v] (9216 x 3072), qkv_c = [add_q; add_k; add_v]; single block: qkvm = [to_q; to_k; to_v; proj_mlp] (21504 x
+ * 3072); `mod` = every AdaLN modulation Linear concatenated (mod_x / mod_c / mod / mod_out = row offset of a block's slice); LoRA (optional per linear,
+ * un-merged, peft semantics): lora_A = s x A of the switched-on adapters concatenated along rank, one block of lora_rp (multiple of 64) rows per output
+ * segment (lora_nseg: 3 for the fused q|k|v projections, else 1), lora_B [N_lora, lora_rp], lora_alpha -- and every workspace (bf16 unless noted; S = S_txt +
+ * S_img, S_pad = S rounded up to 64, D = 128 heads): lat [S_img, in], enc [S_txt, joint], pooled [1, pooled], tproj / gproj [1, 256] (sinusoidal timestep /
+ * guidance projections, filled by the caller per step), e1 / e_t / e_g / e_p / temb [1, D], mod [n_mod], h / xn / attn [S, D], qkv [S, 3D], cat [S, 5D], out
+ * [S_img, in], cos / sin [S, 64] fp32 (RoPE tables), Qh / Kh [H, S_pad, 128], Vt [H, 128, S_pad] (zero-filled once: pad rows stay zero), T [S, 3 R] and Tc
+ * [S_txt, 3 R] (LoRA temps, R = lora_rank_padded = the largest lora_rp), sk_work (utx_gemm_streamk_workspace_bytes) and attn_work (utx_attn_workspace_bytes)
+ * optional.  n_out < S_img: last-block pruning (only the first n_out image rows of `out` are defined); key_bias_*: multiplicity of de-duplicated text keys;
+ * two_streams: the text half of the double blocks on the plan's side stream.  A step: write lat / tproj (and enc / pooled / gproj / cos / sin when they change),
+ * utx_dit_step(plan, stream) = utx_plan_run, read out.  Not in the C builder: sequence parallelism, the MX fp8 path (Python builder only). */
+typedef struct utx_dit_linear {
+    const void* w; const void* b;
+    const void* lora_A; const void* lora_B;
+    float lora_alpha; int lora_rp; int lora_nseg;
+} utx_dit_linear;
+typedef struct utx_dit_double_block {
+    utx_dit_linear qkv_x, qkv_c, out_x, out_c, ff1_x, ff2_x, ff1_c, ff2_c;
+    const void* nq; const void* nk; const void* naq; const void* nak;      /* RMSNorm weights [128] */
+    int mod_x, mod_c;
+} utx_dit_double_block;
+typedef struct utx_dit_single_block {
+    utx_dit_linear qkvm, out;
+    const void* nq; const void* nk;
+    int mod;
+} utx_dit_single_block;
+typedef struct utx_dit_weights {
+    utx_dit_linear x_embedder, context_embedder, proj_out, t_lin1, t_lin2, g_lin1, g_lin2, p_lin1, p_lin2, mod;
+    const utx_dit_double_block* dbl; const utx_dit_single_block* sgl;
+    int mod_out, n_mod;
+} utx_dit_weights;
+typedef struct utx_dit_config {
+    int num_heads, num_double, num_single, in_channels, joint_dim, pooled_dim, mlp_ratio, guidance_embeds;
+    int S_txt, S_img, n_out;
+    float key_bias_log2; int key_bias_period;
+    int two_streams, n_cus, lora_rank_padded;
+} utx_dit_config;
+typedef struct utx_dit_workspace {
+    void *lat, *enc, *pooled, *tproj, *gproj, *e1, *e_t, *e_g, *e_p, *temb, *mod, *h, *xn, *qkv, *cat, *attn, *out;
+    float *cos, *sin;
+    void *Qh, *Kh, *Vt, *T, *Tc;
+    void* sk_work; size_t sk_work_bytes;
+    void* attn_work; size_t attn_work_bytes;
+} utx_dit_workspace;
+int utx_dit_load(utx_ctx* ctx, const utx_dit_config* cfg, const utx_dit_weights* weights, const utx_dit_workspace* ws, utx_plan** out);
+int utx_dit_step(utx_plan* plan, utx_stream stream, int* failed_entry);
 
 /* HOST-side mesh preparation (no device work, no context): quadric-error-metric edge-collapse decimation to at most target_faces triangles.
  * Replaces open3d's simplify_quadric_decimation in preprocess_blank_mesh_o3d (uv_atlas.py:155-163; open3d / VTK [3p]) with the published

@@ -641,6 +641,76 @@ def test_c_side_plan_replay_is_bit_identical_to_the_python_launch_list(fp8):
     assert torch.equal(c1.view(torch.int16), a1.view(torch.int16))
 
 
+def _plan_entries(lib, h):
+    import ctypes as C
+    out = []
+    buf = C.create_string_buffer(1024)
+    for i in range(lib.utx_plan_size(h)):
+        kind, side = C.c_int(), C.c_int()
+        n = lib.utx_plan_entry(h, i, C.byref(kind), C.byref(side), buf, 1024)
+        assert n >= 0
+        raw = bytes(buf.raw[:n])
+        if kind.value == 4:          # attention: the scratch pointer / size are the caller's (one buffer per plan in either builder; sizes may differ per entry)
+            raw = raw[:-16]
+        out.append((kind.value, side.value, raw))
+    return out
+
+
+@pytest.mark.parametrize("full_width,lora,rows", [(False, True, None), (False, False, 192), (False, True, 192), (True, True, 4096)])
+def test_c_built_dit_plan_equals_the_python_built_one(full_width, lora, rows):
+    """utx_dit_load (csrc/dit_plan.cpp): the C-side builder assembles a FLUX step from plain pointer structs.  It must produce the launch list
+    FluxDiT builds -- same entries, same order, same streams, every descriptor BYTE-IDENTICAL (all pointers, strides, shapes, LoRA segments, gates,
+    split-tail scratch) -- with and without LoRA, with last-block pruning, at a tiny shape and at full width (D = 3072, S = 9728, where the large-M
+    kernels and the split tail are in play); and replaying it gives the same bits."""
+    from unitex_amd.flux.transformer import FluxDiT, FluxShape
+    if full_width:
+        cfg = dit_ref.FluxConfig(num_double=1, num_single=2)
+        shape = FluxShape(num_double=1, num_single=2)
+        S_txt = 512
+        img_ids = torch.cat([dit_ref.latent_image_ids(32, 128), dit_ref.latent_image_ids(32, 128, offset_y=32), dit_ref.latent_image_ids(32, 32, offset_x=128, offset_y=32)], 0)
+        enc = torch.zeros(S_txt, cfg.joint_dim).to(BF).cuda(); pooled = torch.zeros(1, cfg.pooled_dim).to(BF).cuda()       # zero text: the de-duplicated path (key bias)
+        rank = 64
+    else:
+        cfg = dit_ref.tiny_config(heads=2, double=2, single=2, joint_dim=64, pooled_dim=64)
+        shape = FluxShape(num_heads=2, num_double=2, num_single=2, joint_dim=64, pooled_dim=64)
+        S_txt = 64
+        img_ids = torch.cat([dit_ref.latent_image_ids(8, 24), dit_ref.latent_image_ids(8, 24, offset_y=8), dit_ref.latent_image_ids(4, 4, offset_x=24, offset_y=8)], 0)
+        g0 = torch.Generator().manual_seed(4)
+        enc = (0.5 * torch.randn(S_txt, 64, generator=g0)).to(BF).cuda(); pooled = (0.5 * torch.randn(1, 64, generator=g0)).to(BF).cuda()
+        rank = 16
+    sd = dit_ref.make_synthetic_state_dict(cfg, seed=0)
+    g = torch.Generator().manual_seed(9)
+    lat = torch.randn(img_ids.shape[0], 64, generator=g).to(BF).cuda()
+    m = FluxDiT(sd, shape, device="cuda:0")
+    if lora:
+        m.set_lora([(dit_ref.make_synthetic_lora(cfg, sd, rank=rank, seed=2), 1.0)])
+    m.set_positions(torch.zeros(S_txt, 3), img_ids)
+    m.set_output_rows(rows)
+    m.set_conditioning(enc, pooled, 3.5)
+    p = next(iter(m._plans.values()))
+    ref = m.forward(lat, 0.5).clone()           # (first run: lazily sized scratch exists afterwards)
+    torch.cuda.synchronize()
+    py = _plan_entries(m.lib, p["cplan"])
+    h = m.build_c_dit_plan(p)
+    assert h is not None
+    try:
+        cc = _plan_entries(m.lib, h)
+        assert len(cc) == len(py), "entry count: C %d vs Python %d" % (len(cc), len(py))
+        for i, (a, b) in enumerate(zip(cc, py)):
+            assert a[0] == b[0] and a[1] == b[1], "entry %d: kind / stream %s vs %s" % (i, a[:2], b[:2])
+            if a[2] != b[2]:
+                diff = [j for j in range(0, len(a[2]), 8) if a[2][j:j + 8] != b[2][j:j + 8]]
+                raise AssertionError("entry %d (kind %d): descriptor differs at byte offsets %s" % (i, a[0], diff[:8]))
+        import ctypes as C
+        bad = C.c_int(-1)
+        assert m.lib.utx_dit_step(h, m.ctx.stream(), C.byref(bad)) == 0, bad.value
+        torch.cuda.synchronize()
+        got = next(iter(m._plans.values()))["ws"]["out"].clone()
+        assert torch.equal(got.view(torch.int16), ref.view(torch.int16))
+    finally:
+        m.lib.utx_plan_free(h)
+
+
 @pytest.mark.parametrize("S", [2830, 4096])
 def test_attention_tail_split_matches_oracle_and_unsplit_launch(S):
     """more workgroups than CUs: the partly filled last round is cut along the keys (partial outputs + log-sum-exp, merged by

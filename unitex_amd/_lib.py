@@ -73,7 +73,38 @@ class KnnDesc(C.Structure):
                 ("out_attr", c_void_p), ("out_idx", c_void_p), ("out_d2", c_void_p)]
 
 
-ABI_STRUCTS = [GemmDesc, GemvDesc, QkvPostDesc, LnModDesc, SchedDesc, BackprojectDesc, KnnDesc]
+class DitLinear(C.Structure):
+    _fields_ = [("w", c_void_p), ("b", c_void_p), ("lora_A", c_void_p), ("lora_B", c_void_p), ("lora_alpha", c_float), ("lora_rp", c_int), ("lora_nseg", c_int)]
+
+
+class DitDoubleBlock(C.Structure):
+    _fields_ = [(n, DitLinear) for n in ("qkv_x", "qkv_c", "out_x", "out_c", "ff1_x", "ff2_x", "ff1_c", "ff2_c")] + \
+               [("nq", c_void_p), ("nk", c_void_p), ("naq", c_void_p), ("nak", c_void_p), ("mod_x", c_int), ("mod_c", c_int)]
+
+
+class DitSingleBlock(C.Structure):
+    _fields_ = [("qkvm", DitLinear), ("out", DitLinear), ("nq", c_void_p), ("nk", c_void_p), ("mod", c_int)]
+
+
+class DitWeights(C.Structure):
+    _fields_ = [(n, DitLinear) for n in ("x_embedder", "context_embedder", "proj_out", "t_lin1", "t_lin2", "g_lin1", "g_lin2", "p_lin1", "p_lin2", "mod")] + \
+               [("dbl", C.POINTER(DitDoubleBlock)), ("sgl", C.POINTER(DitSingleBlock)), ("mod_out", c_int), ("n_mod", c_int)]
+
+
+class DitConfig(C.Structure):
+    _fields_ = [(n, c_int) for n in ("num_heads", "num_double", "num_single", "in_channels", "joint_dim", "pooled_dim", "mlp_ratio", "guidance_embeds",
+                                     "S_txt", "S_img", "n_out")] + [("key_bias_log2", c_float), ("key_bias_period", c_int), ("two_streams", c_int), ("n_cus", c_int),
+                                                                     ("lora_rank_padded", c_int)]
+
+
+class DitWorkspace(C.Structure):
+    _fields_ = [(n, c_void_p) for n in ("lat", "enc", "pooled", "tproj", "gproj", "e1", "e_t", "e_g", "e_p", "temb", "mod", "h", "xn", "qkv", "cat", "attn", "out",
+                                        "cos", "sin", "Qh", "Kh", "Vt", "T", "Tc")] + \
+               [("sk_work", c_void_p), ("sk_work_bytes", C.c_size_t), ("attn_work", c_void_p), ("attn_work_bytes", C.c_size_t)]
+
+
+ABI_STRUCTS = [GemmDesc, GemvDesc, QkvPostDesc, LnModDesc, SchedDesc, BackprojectDesc, KnnDesc, DitLinear, DitDoubleBlock, DitSingleBlock, DitWeights, DitConfig,
+               DitWorkspace]
 
 # every symbol include/unitex_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
@@ -96,6 +127,10 @@ SYMBOLS = {
     "utx_plan_main": (c_int, [c_void_p]),
     "utx_plan_join": (c_int, [c_void_p]),
     "utx_plan_run": (c_int, [c_void_p, c_void_p, C.POINTER(c_int)]),
+    "utx_plan_assign_sk": (c_int, [c_void_p, c_void_p, C.c_size_t, c_int]),
+    "utx_plan_entry": (c_int, [c_void_p, c_int, C.POINTER(c_int), C.POINTER(c_int), c_void_p, C.c_size_t]),
+    "utx_dit_load": (c_int, [c_void_p, C.POINTER(DitConfig), C.POINTER(DitWeights), C.POINTER(DitWorkspace), C.POINTER(c_void_p)]),
+    "utx_dit_step": (c_int, [c_void_p, c_void_p, C.POINTER(c_int)]),
     "utx_mesh_decimate_qem": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, C.c_double, c_void_p, c_void_p, C.POINTER(c_int), C.POINTER(c_int)]),
     "utx_set_option": (c_int, [C.c_char_p, c_int]),
     "utx_get_option": (c_int, [C.c_char_p, C.POINTER(c_int)]),

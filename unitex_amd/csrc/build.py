@@ -28,6 +28,7 @@ SOURCES = [
     ("capi.cpp", []),
     ("meshproc.cpp", []),
     ("plan.cpp", []),
+    ("dit_plan.cpp", []),
 ]
 GEOM = [
     ("raster.hip", ["-ffp-contract=off"]),

@@ -376,7 +376,8 @@ int utx_to_u8(utx_ctx* ctx, const float* src, long n_rows, long row_elems, int f
 extern "C" int utx_abi_sizes(int* out, int n) {
     const int v[] = {(int)sizeof(utx_gemm_desc), (int)sizeof(utx_gemv_desc), (int)sizeof(utx_qkv_post_desc),
                      (int)sizeof(utx_ln_mod_desc), (int)sizeof(utx_sched_desc), (int)sizeof(utx_backproject_desc),
-                     (int)sizeof(utx_knn_desc)};
+                     (int)sizeof(utx_knn_desc), (int)sizeof(utx_dit_linear), (int)sizeof(utx_dit_double_block), (int)sizeof(utx_dit_single_block),
+                     (int)sizeof(utx_dit_weights), (int)sizeof(utx_dit_config), (int)sizeof(utx_dit_workspace)};
     const int m = (int)(sizeof(v) / sizeof(v[0]));
     for (int i = 0; i < m && i < n; ++i) out[i] = v[i];
     return m;

@@ -98,6 +98,44 @@ int utx_plan_join(utx_plan* p) {
     return 0;
 }
 
+// the split-tail scratch of the large-M GEMM (utx_gemm_desc.sk_work) for the GEMMs of the caller's stream -- they are ordered among themselves; the side
+// stream's GEMMs (the text half: far below the size where a tail is split) get none.  Only when some launch has more 256 x 256 tiles than CUs
+// (FluxDiT._assign_streamk).  Returns the number of descriptors that received the scratch.
+int utx_plan_assign_sk(utx_plan* p, void* sk_work, size_t sk_work_bytes, int n_cus) {
+    if (!p || !sk_work || n_cus <= 0) return 0;
+    bool any = false;
+    for (const Entry& e : p->entries)
+        if (e.kind == K_GEMM && !e.side && (long)((e.gemm.M + 255) / 256) * (e.gemm.N / 256) > n_cus) any = true;
+    if (!any) return 0;
+    int n = 0;
+    for (Entry& e : p->entries)
+        if (e.kind == K_GEMM && !e.side) { e.gemm.sk_work = sk_work; e.gemm.sk_work_bytes = sk_work_bytes; ++n; }
+    return n;
+}
+
+// Read an entry back (tests, debuggers): kind 0 gemm, 1 gemv, 2 ln_mod, 3 qkv_post, 4 attention, 5 quant_mx8, 6 add3, 7 fork, 8 join; `side` = launched on the
+// plan's side stream; the descriptor (kinds 0-3: the public structs) or the entry's argument block (kinds 4-6) is copied into buf.  Returns the bytes copied,
+// or a negative code.
+int utx_plan_entry(const utx_plan* p, int i, int* kind, int* side, void* buf, size_t cap) {
+    if (!p || i < 0 || i >= (int)p->entries.size() || !kind || !side) return -2;
+    const Entry& e = p->entries[i];
+    *kind = (int)e.kind; *side = e.side;
+    const void* src = nullptr; size_t n = 0;
+    switch (e.kind) {
+        case K_GEMM: src = &e.gemm; n = sizeof(e.gemm); break;
+        case K_GEMV: src = &e.gemv; n = sizeof(e.gemv); break;
+        case K_LN_MOD: src = &e.ln; n = sizeof(e.ln); break;
+        case K_QKV_POST: src = &e.qkv; n = sizeof(e.qkv); break;
+        case K_ATTN: src = &e.attn; n = sizeof(e.attn); break;
+        case K_QUANT: src = &e.quant; n = sizeof(e.quant); break;
+        case K_ADD3: src = &e.add3; n = sizeof(e.add3); break;
+        default: break;
+    }
+    if (n > cap) return -2;
+    if (n && buf) memcpy(buf, src, n);
+    return (int)n;
+}
+
 // Replay.  Returns 0, or the first failing launcher's code with its entry index in *failed_entry (may be NULL).
 int utx_plan_run(utx_plan* p, utx_stream stream_, int* failed_entry) {
     if (!p || p->open_sections) return -2;

@@ -673,7 +673,7 @@ class FluxDiT:
         self._lnmod(plan, h_x[:n_out], xn_x[:n_out], shift, scale)
         self._gemm(plan, xn_x[:n_out], W["proj_out.w"], ws["out"][:n_out], bias=W["proj_out.b"])
         self._assign_streamk(plan, ws)
-        return {"ws": ws, "plan": plan, "S_txt": S_txt, "S_img": S_img}
+        return {"ws": ws, "plan": plan, "S_txt": S_txt, "S_img": S_img, "n_out": n_out}
 
     def gemm_census(self, n_cus=None):
         """{kernel name: launches per forward} of the current plan, as the library's own dispatch (utx_gemm_plan) sees each descriptor, plus
@@ -957,6 +957,67 @@ class FluxDiT:
         if old is not None:
             lib.utx_plan_free(old)
         p["cplan"] = h
+        return h
+
+    def build_c_dit_plan(self, p=None):
+        """The same step built by the C-side builder (utx_dit_load, csrc/dit_plan.cpp): this object's packed weights and the plan's workspaces are
+        handed over as plain pointer structs and the library assembles the launch list itself -- what a non-Python host would do.  bf16 single-GPU path only
+        (returns None under sequence parallelism, with fp8 weights or with the fused q / k epilogue).  The result must equal compile_plan()'s entry for entry
+        (tests/test_dit_ops_gpu.py::test_c_built_dit_plan_equals_the_python_built_one); the caller frees it with utx_plan_free."""
+        from .._lib import DitConfig, DitDoubleBlock, DitLinear, DitSingleBlock, DitWeights, DitWorkspace
+        if self.sp is not None or self.fp8_weights or self.fuse_qk:
+            return None
+        p = next(iter(self._plans.values())) if p is None else p
+        ws, sh, W = p["ws"], self.shape, self.W
+
+        def lin(w, b_, lora=None):
+            L = DitLinear()
+            L.w, L.b = ptr(w), ptr(b_)
+            if lora is not None:
+                A_cat, B_cat, alpha, Rp = lora
+                L.lora_A, L.lora_B, L.lora_alpha, L.lora_rp, L.lora_nseg = ptr(A_cat), ptr(B_cat), float(alpha), int(Rp), A_cat.shape[0] // Rp
+            return L
+        wt = DitWeights()
+        wt.x_embedder = lin(self._w("x_embedder.w"), self._w("x_embedder.b"))
+        wt.context_embedder = lin(W["context_embedder.w"], W["context_embedder.b"])
+        wt.proj_out = lin(W["proj_out.w"], W["proj_out.b"])
+        k = "time_text_embed.%s.%s"
+        for dst, nm in (("t", "timestep_embedder"), ("g", "guidance_embedder"), ("p", "text_embedder")):
+            if nm == "guidance_embedder" and not sh.guidance_embeds:
+                continue
+            for j in (1, 2):
+                setattr(wt, "%s_lin%d" % (dst, j), lin(W[k % (nm, "linear_%d" % j) + ".w"], W[k % (nm, "linear_%d" % j) + ".b"]))
+        wt.mod = lin(W["mod.w"], W["mod.b"])
+        dbl = (DitDoubleBlock * max(1, len(self.double)))()
+        for i, b in enumerate(self.double):
+            for nm in ("qkv_x", "qkv_c", "out_x", "out_c", "ff1_x", "ff2_x", "ff1_c", "ff2_c"):
+                setattr(dbl[i], nm, lin(b[nm + ".w"], b[nm + ".b"], b.get("lora." + nm)))
+            dbl[i].nq, dbl[i].nk, dbl[i].naq, dbl[i].nak = ptr(b["nq"]), ptr(b["nk"]), ptr(b["naq"]), ptr(b["nak"])
+            dbl[i].mod_x, dbl[i].mod_c = self.mod_off[("d", i, "x")], self.mod_off[("d", i, "c")]
+        sgl = (DitSingleBlock * max(1, len(self.single)))()
+        for i, b in enumerate(self.single):
+            sgl[i].qkvm = lin(b["qkvm.w"], b["qkvm.b"], b.get("lora.qkvm"))
+            sgl[i].out = lin(b["out.w"], b["out.b"])
+            sgl[i].nq, sgl[i].nk, sgl[i].mod = ptr(b["nq"]), ptr(b["nk"]), self.mod_off[("s", i)]
+        wt.dbl, wt.sgl = dbl, sgl
+        wt.mod_out, wt.n_mod = self.mod_off[("out",)], self.n_mod
+        cfg = DitConfig()
+        cfg.num_heads, cfg.num_double, cfg.num_single = sh.num_heads, sh.num_double, sh.num_single
+        cfg.in_channels, cfg.joint_dim, cfg.pooled_dim, cfg.mlp_ratio, cfg.guidance_embeds = sh.in_channels, sh.joint_dim, sh.pooled_dim, sh.mlp_ratio, int(sh.guidance_embeds)
+        cfg.S_txt, cfg.S_img, cfg.n_out = p["S_txt"], p["S_img"], p["n_out"]
+        cfg.key_bias_log2, cfg.key_bias_period = float(self.key_bias_log2), int(self.key_bias_period)
+        cfg.two_streams = int(bool(self.overlap_text))
+        cfg.n_cus = torch.cuda.get_device_properties(self.device).multi_processor_count
+        cfg.lora_rank_padded = int(self.lora_rank) if self._lora_active else 0
+        w = DitWorkspace()
+        for nm in ("lat", "enc", "pooled", "tproj", "gproj", "e1", "e_t", "e_g", "e_p", "temb", "mod", "h", "xn", "qkv", "cat", "attn", "out", "cos", "sin", "Qh", "Kh",
+                   "Vt", "T", "Tc"):
+            setattr(w, nm, ptr(ws.get(nm)))
+        sk, aw = ws.get("sk"), ws.get("attn_ws")
+        w.sk_work, w.sk_work_bytes = ptr(sk), 0 if sk is None else sk.numel()
+        w.attn_work, w.attn_work_bytes = ptr(aw), 0 if aw is None else aw.numel()
+        h = C.c_void_p()
+        self.ctx.check(self.lib.utx_dit_load(self.ctx.handle, C.byref(cfg), C.byref(wt), C.byref(w), C.byref(h)))
         return h
 
     def forward(self, hidden_states, timestep: float, out: Optional[torch.Tensor] = None):
