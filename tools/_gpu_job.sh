@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-export PYTHONUNBUFFERED=1
-timeout 900 python -m pytest tests/test_dit_ops_gpu.py -x -q -m gpu -k "c_built or c_side" > gpurun_out/r03_c_dit_tests_a.log 2>&1; echo "c dit tests rc=$?"
-grep -v amdgpu gpurun_out/r03_c_dit_tests_a.log | tail -n 30
+PASSES="sq1 tcc1 tcc2" bash tools/pmc_kernel.sh gpurun_out/r03_pmc_attn attn_fwd_glds python $GRAFT_REPO_ROOT/tools/attn_one.py > gpurun_out/r03_pmc_attn_strip1024x6.log 2>&1; echo "pmc attn rc=$?"
+cat gpurun_out/r03_pmc_attn_strip1024x6.log
+rm -rf gpurun_out/r03_pmc_attn
