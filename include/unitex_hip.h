@@ -433,11 +433,18 @@ int utx_plan_entry(const utx_plan* plan, int i, int* kind, int* side, void* buf,
  * [S_txt, 3 R] (LoRA temps, R = lora_rank_padded = the largest lora_rp), sk_work (utx_gemm_streamk_workspace_bytes) and attn_work (utx_attn_workspace_bytes)
  * optional.  n_out < S_img: last-block pruning (only the first n_out image rows of `out` are defined); key_bias_*: multiplicity of de-duplicated text keys;
  * two_streams: the text half of the double blocks on the plan's side stream.  A step: write lat / tproj (and enc / pooled / gproj / cos / sin when they change),
- * utx_dit_step(plan, stream) = utx_plan_run, read out.  Not in the C builder: sequence parallelism, the MX fp8 path (Python builder only). */
+ * utx_dit_step(plan, stream) = utx_plan_run, read out.  fp8 = 1: the MX fp8 step (BASELINE configs[4] numerics) -- the linears that carry q / s / sp run
+ * on fp8 operands (their LoRA is ignored: merged by the caller), shapes that fill the chip on the one-wave-per-SIMD kernel with tile-packed scales and, with
+ * fp8_fuse_quant, activations written as fp8 by LayerNorm-modulation / the GELU epilogues; the rest on the 128^2-tile kernel behind a quantiser pass.  Not in
+ * the C builder: sequence parallelism (the collectives are the host's). */
 typedef struct utx_dit_linear {
     const void* w; const void* b;
     const void* lora_A; const void* lora_B;
     float lora_alpha; int lora_rp; int lora_nseg;
+    /* fp8 mode (utx_dit_config.fp8), the five big image-stream linears only: the weight once more as OCP MX fp8 -- adapters MERGED in before quantising
+     * (W + sum s B A, rounded to bf16, then utx_quant_mx8) -- q = e4m3 bytes [N, K], s = row-major E8M0 scales [N, lds_s >= K / 32], sp = the same scales
+     * tile-packed (utx_quant_mx8_packed; sp_row_blocks = row blocks per K-tile slab; NULL when N % 256) */
+    const void* q; const void* s; long lds_s; const void* sp; int sp_row_blocks;
 } utx_dit_linear;
 typedef struct utx_dit_double_block {
     utx_dit_linear qkv_x, qkv_c, out_x, out_c, ff1_x, ff2_x, ff1_c, ff2_c;
@@ -459,6 +466,7 @@ typedef struct utx_dit_config {
     int S_txt, S_img, n_out;
     float key_bias_log2; int key_bias_period;
     int two_streams, n_cus, lora_rank_padded;
+    int fp8, fp8_fuse_quant;      /* MX fp8 linears (qkv_x / ff1_x / ff2_x of the double blocks, qkvm / out of the single blocks); producers write fp8 operands directly */
 } utx_dit_config;
 typedef struct utx_dit_workspace {
     void *lat, *enc, *pooled, *tproj, *gproj, *e1, *e_t, *e_g, *e_p, *temb, *mod, *h, *xn, *qkv, *cat, *attn, *out;
@@ -466,6 +474,10 @@ typedef struct utx_dit_workspace {
     void *Qh, *Kh, *Vt, *T, *Tc;
     void* sk_work; size_t sk_work_bytes;
     void* attn_work; size_t attn_work_bytes;
+    /* fp8 mode: activation scratch aq [S, 5D] e4m3 bytes, as_rm [S, 5D / 32] row-major scales (shapes on the 128^2-tile MX kernel), asp = tile-packed scales
+     * [5D / 128][asp_row_blocks >= ceil(S / 128)][512]; aq2 [n_out, 5D] / asp2 the same for the rows a pruned last block keeps (n_out < S_img only) */
+    void *aq, *as_rm, *asp; int asp_row_blocks;
+    void *aq2, *asp2; int asp2_row_blocks;
 } utx_dit_workspace;
 int utx_dit_load(utx_ctx* ctx, const utx_dit_config* cfg, const utx_dit_weights* weights, const utx_dit_workspace* ws, utx_plan** out);
 int utx_dit_step(utx_plan* plan, utx_stream stream, int* failed_entry);

@@ -656,12 +656,14 @@ def _plan_entries(lib, h):
     return out
 
 
-@pytest.mark.parametrize("full_width,lora,rows", [(False, True, None), (False, False, 192), (False, True, 192), (True, True, 4096)])
-def test_c_built_dit_plan_equals_the_python_built_one(full_width, lora, rows):
+@pytest.mark.parametrize("full_width,lora,rows,fp8", [(False, True, None, False), (False, False, 192, False), (False, True, 192, False), (True, True, 4096, False),
+                                                      (False, True, 192, True), (True, True, None, True), (True, True, 4096, True)])
+def test_c_built_dit_plan_equals_the_python_built_one(full_width, lora, rows, fp8):
     """utx_dit_load (csrc/dit_plan.cpp): the C-side builder assembles a FLUX step from plain pointer structs.  It must produce the launch list
     FluxDiT builds -- same entries, same order, same streams, every descriptor BYTE-IDENTICAL (all pointers, strides, shapes, LoRA segments, gates,
     split-tail scratch) -- with and without LoRA, with last-block pruning, at a tiny shape and at full width (D = 3072, S = 9728, where the large-M
-    kernels and the split tail are in play); and replaying it gives the same bits."""
+    kernels and the split tail are in play), on the bf16 and on the MX fp8 path (tiny: row-major scales + quantiser passes; full width: tile-packed scales,
+    fp8 emitted by LayerNorm-modulation / GELU epilogues, pruned block on the second scratch); and replaying it gives the same bits."""
     from unitex_amd.flux.transformer import FluxDiT, FluxShape
     if full_width:
         cfg = dit_ref.FluxConfig(num_double=1, num_single=2)
@@ -681,7 +683,7 @@ def test_c_built_dit_plan_equals_the_python_built_one(full_width, lora, rows):
     sd = dit_ref.make_synthetic_state_dict(cfg, seed=0)
     g = torch.Generator().manual_seed(9)
     lat = torch.randn(img_ids.shape[0], 64, generator=g).to(BF).cuda()
-    m = FluxDiT(sd, shape, device="cuda:0")
+    m = FluxDiT(sd, shape, device="cuda:0", fp8_weights=fp8)
     if lora:
         m.set_lora([(dit_ref.make_synthetic_lora(cfg, sd, rank=rank, seed=2), 1.0)])
     m.set_positions(torch.zeros(S_txt, 3), img_ids)
@@ -689,6 +691,9 @@ def test_c_built_dit_plan_equals_the_python_built_one(full_width, lora, rows):
     m.set_conditioning(enc, pooled, 3.5)
     p = next(iter(m._plans.values()))
     ref = m.forward(lat, 0.5).clone()           # (first run: lazily sized scratch exists afterwards)
+    if fp8:
+        kinds = [e[0] for e in _plan_entries(m.lib, p["cplan"])]
+        assert 5 in kinds or full_width, "the tiny fp8 plan carries quantiser passes"
     torch.cuda.synchronize()
     py = _plan_entries(m.lib, p["cplan"])
     h = m.build_c_dit_plan(p)

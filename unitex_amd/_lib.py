@@ -74,7 +74,8 @@ class KnnDesc(C.Structure):
 
 
 class DitLinear(C.Structure):
-    _fields_ = [("w", c_void_p), ("b", c_void_p), ("lora_A", c_void_p), ("lora_B", c_void_p), ("lora_alpha", c_float), ("lora_rp", c_int), ("lora_nseg", c_int)]
+    _fields_ = [("w", c_void_p), ("b", c_void_p), ("lora_A", c_void_p), ("lora_B", c_void_p), ("lora_alpha", c_float), ("lora_rp", c_int), ("lora_nseg", c_int),
+                ("q", c_void_p), ("s", c_void_p), ("lds_s", c_long), ("sp", c_void_p), ("sp_row_blocks", c_int)]
 
 
 class DitDoubleBlock(C.Structure):
@@ -94,13 +95,14 @@ class DitWeights(C.Structure):
 class DitConfig(C.Structure):
     _fields_ = [(n, c_int) for n in ("num_heads", "num_double", "num_single", "in_channels", "joint_dim", "pooled_dim", "mlp_ratio", "guidance_embeds",
                                      "S_txt", "S_img", "n_out")] + [("key_bias_log2", c_float), ("key_bias_period", c_int), ("two_streams", c_int), ("n_cus", c_int),
-                                                                     ("lora_rank_padded", c_int)]
+                                                                     ("lora_rank_padded", c_int), ("fp8", c_int), ("fp8_fuse_quant", c_int)]
 
 
 class DitWorkspace(C.Structure):
     _fields_ = [(n, c_void_p) for n in ("lat", "enc", "pooled", "tproj", "gproj", "e1", "e_t", "e_g", "e_p", "temb", "mod", "h", "xn", "qkv", "cat", "attn", "out",
                                         "cos", "sin", "Qh", "Kh", "Vt", "T", "Tc")] + \
-               [("sk_work", c_void_p), ("sk_work_bytes", C.c_size_t), ("attn_work", c_void_p), ("attn_work_bytes", C.c_size_t)]
+               [("sk_work", c_void_p), ("sk_work_bytes", C.c_size_t), ("attn_work", c_void_p), ("attn_work_bytes", C.c_size_t),
+                ("aq", c_void_p), ("as_rm", c_void_p), ("asp", c_void_p), ("asp_row_blocks", c_int), ("aq2", c_void_p), ("asp2", c_void_p), ("asp2_row_blocks", c_int)]
 
 
 ABI_STRUCTS = [GemmDesc, GemvDesc, QkvPostDesc, LnModDesc, SchedDesc, BackprojectDesc, KnnDesc, DitLinear, DitDoubleBlock, DitSingleBlock, DitWeights, DitConfig,

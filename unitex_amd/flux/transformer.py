@@ -961,21 +961,26 @@ class FluxDiT:
 
     def build_c_dit_plan(self, p=None):
         """The same step built by the C-side builder (utx_dit_load, csrc/dit_plan.cpp): this object's packed weights and the plan's workspaces are
-        handed over as plain pointer structs and the library assembles the launch list itself -- what a non-Python host would do.  bf16 single-GPU path only
-        (returns None under sequence parallelism, with fp8 weights or with the fused q / k epilogue).  The result must equal compile_plan()'s entry for entry
+        handed over as plain pointer structs and the library assembles the launch list itself -- what a non-Python host would do.  Single-GPU paths, bf16 and
+        MX fp8 (returns None under sequence parallelism or with the fused q / k epilogue).  The result must equal compile_plan()'s entry for entry
         (tests/test_dit_ops_gpu.py::test_c_built_dit_plan_equals_the_python_built_one); the caller frees it with utx_plan_free."""
         from .._lib import DitConfig, DitDoubleBlock, DitLinear, DitSingleBlock, DitWeights, DitWorkspace
-        if self.sp is not None or self.fp8_weights or self.fuse_qk:
+        if self.sp is not None or self.fuse_qk:
             return None
         p = next(iter(self._plans.values())) if p is None else p
         ws, sh, W = p["ws"], self.shape, self.W
 
-        def lin(w, b_, lora=None):
+        def lin(w, b_, lora=None, blk=None, nm=None):
             L = DitLinear()
             L.w, L.b = ptr(w), ptr(b_)
             if lora is not None:
                 A_cat, B_cat, alpha, Rp = lora
                 L.lora_A, L.lora_B, L.lora_alpha, L.lora_rp, L.lora_nseg = ptr(A_cat), ptr(B_cat), float(alpha), int(Rp), A_cat.shape[0] // Rp
+            if self.fp8_weights and blk is not None and (nm + ".q") in blk:      # the MX fp8 image of the weight (adapters merged in, _quantize_fp8_weights)
+                L.q, L.s, L.lds_s = ptr(blk[nm + ".q"]), ptr(blk[nm + ".s"]), blk[nm + ".s"].stride(0)
+                sp = blk.get(nm + ".sp")
+                if sp is not None:
+                    L.sp, L.sp_row_blocks = ptr(sp.data), sp.row_blocks
             return L
         wt = DitWeights()
         wt.x_embedder = lin(self._w("x_embedder.w"), self._w("x_embedder.b"))
@@ -991,13 +996,13 @@ class FluxDiT:
         dbl = (DitDoubleBlock * max(1, len(self.double)))()
         for i, b in enumerate(self.double):
             for nm in ("qkv_x", "qkv_c", "out_x", "out_c", "ff1_x", "ff2_x", "ff1_c", "ff2_c"):
-                setattr(dbl[i], nm, lin(b[nm + ".w"], b[nm + ".b"], b.get("lora." + nm)))
+                setattr(dbl[i], nm, lin(b[nm + ".w"], b[nm + ".b"], b.get("lora." + nm), b, nm))
             dbl[i].nq, dbl[i].nk, dbl[i].naq, dbl[i].nak = ptr(b["nq"]), ptr(b["nk"]), ptr(b["naq"]), ptr(b["nak"])
             dbl[i].mod_x, dbl[i].mod_c = self.mod_off[("d", i, "x")], self.mod_off[("d", i, "c")]
         sgl = (DitSingleBlock * max(1, len(self.single)))()
         for i, b in enumerate(self.single):
-            sgl[i].qkvm = lin(b["qkvm.w"], b["qkvm.b"], b.get("lora.qkvm"))
-            sgl[i].out = lin(b["out.w"], b["out.b"])
+            sgl[i].qkvm = lin(b["qkvm.w"], b["qkvm.b"], b.get("lora.qkvm"), b, "qkvm")
+            sgl[i].out = lin(b["out.w"], b["out.b"], None, b, "out")
             sgl[i].nq, sgl[i].nk, sgl[i].mod = ptr(b["nq"]), ptr(b["nk"]), self.mod_off[("s", i)]
         wt.dbl, wt.sgl = dbl, sgl
         wt.mod_out, wt.n_mod = self.mod_off[("out",)], self.n_mod
@@ -1009,6 +1014,8 @@ class FluxDiT:
         cfg.two_streams = int(bool(self.overlap_text))
         cfg.n_cus = torch.cuda.get_device_properties(self.device).multi_processor_count
         cfg.lora_rank_padded = int(self.lora_rank) if self._lora_active else 0
+        cfg.fp8 = int(bool(self.fp8_weights))
+        cfg.fp8_fuse_quant = int(bool(self.fp8_weights) and os.environ.get("UTX_FP8_FUSE_QUANT", "1") != "0")
         w = DitWorkspace()
         for nm in ("lat", "enc", "pooled", "tproj", "gproj", "e1", "e_t", "e_g", "e_p", "temb", "mod", "h", "xn", "qkv", "cat", "attn", "out", "cos", "sin", "Qh", "Kh",
                    "Vt", "T", "Tc"):
@@ -1016,6 +1023,10 @@ class FluxDiT:
         sk, aw = ws.get("sk"), ws.get("attn_ws")
         w.sk_work, w.sk_work_bytes = ptr(sk), 0 if sk is None else sk.numel()
         w.attn_work, w.attn_work_bytes = ptr(aw), 0 if aw is None else aw.numel()
+        if self.fp8_weights:
+            w.aq, w.as_rm, w.asp, w.asp_row_blocks = ptr(ws["aq"]), ptr(ws["as"]), ptr(ws["asp"]), ws["asp"].stride(0) // 512
+            if "aq2" in ws:
+                w.aq2, w.asp2, w.asp2_row_blocks = ptr(ws["aq2"]), ptr(ws["asp2"]), ws["asp2"].stride(0) // 512
         h = C.c_void_p()
         self.ctx.check(self.lib.utx_dit_load(self.ctx.handle, C.byref(cfg), C.byref(wt), C.byref(w), C.byref(h)))
         return h
