@@ -233,3 +233,51 @@ def test_speedup_mode_fp8_builds_an_mx_fp8_transformer_and_runs(tmp_path):
         torch.cuda.empty_cache()
     d = np.abs(outs["fp8"] - outs[None])
     assert outs[None].std() > 1.0 and d.max() > 0 and d.mean() < 8.0, "fp8 pipeline vs bf16 pipeline: mean |d| %.2f LSB, max %d" % (d.mean(), d.max())
+
+
+def test_add_lora_adapters_join_both_passes(tmp_path):
+    """Call surface, reference pipeline.py:112-117,142-145: `add_lora_path` / `add_lora_weights` load further adapters `add_lora_<i>` and switch them on with their
+    weight in BOTH passes (weights_for_texture = [1, 0, w...], weights_for_delight = [0, 1, w...]).  Here: one extra adapter from a diffusers-spelled
+    safetensors file; the transformer then runs with two switched-on adapters (rank-concatenated LoRA segment) and gives exactly what FluxDiT.set_lora gives
+    for the same pair, and something else than without the extra adapter; a weight list of the wrong length is refused."""
+    from safetensors.torch import save_file
+    from unitex_amd.flux.synthetic import SyntheticFluxStateDict, synthetic_lora
+    from unitex_amd.flux.transformer import FluxShape
+    from unitex_amd.pipeline import build_pipeline
+    dev = "cuda:0"
+    shape = FluxShape(num_heads=2, num_double=1, num_single=1, joint_dim=64, pooled_dim=64)
+    sd = SyntheticFluxStateDict(shape, seed=0, device=dev)
+    extra = synthetic_lora(sd, shape, rank=8, seed=7, device=dev)
+    flat = {}
+    for mod, (A, B) in extra.items():
+        if not isinstance(mod, str) or not hasattr(A, "shape"):
+            continue
+        flat["transformer.%s.lora_A.weight" % mod] = A.float().cpu().contiguous()
+        flat["transformer.%s.lora_B.weight" % mod] = B.float().cpu().contiguous()
+    path = str(tmp_path / "extra.safetensors")
+    save_file(flat, path)
+    with pytest.raises(ValueError):
+        build_pipeline(None, device=dev, lora_rank=16, shape=shape, add_lora_path=[path], add_lora_weights=[])
+    pipe, wt, wd, names = build_pipeline(None, device=dev, lora_rank=16, shape=shape, add_lora_path=[path], add_lora_weights=[0.5])
+    assert names == ["texture", "delight", "add_lora_0"] and wt == [1.0, 0.0, 0.5] and wd == [0.0, 1.0, 0.5]
+    pipe.vae = fakes.FakeVAE()
+    yy, xx = np.mgrid[0:64, 0:192]
+    ctrl = Image.fromarray(np.stack([xx % 256, (yy * 4) % 256, (xx + yy) % 256], -1).astype(np.uint8))
+
+    def run(weights):
+        pipe.set_adapters(names, weights)
+        return np.asarray(pipe(prompt="[MVFLUX]", control_image=ctrl, height=64, width=192, num_inference_steps=2, guidance_scale=3.5, max_sequence_length=64,
+                               generator=torch.Generator().manual_seed(63)).images[0]).astype(np.int32)
+    with_extra = run(wt)
+    active = pipe.transformer._lora_active
+    assert len(active) == 2 and [s_ for _, s_ in active] == [1.0, 0.5], "texture + the extra adapter are switched on, the zero-weighted delight adapter is dropped"
+    without = run([1.0, 0.0, 0.0])
+    assert len(pipe.transformer._lora_active) == 1
+    assert np.abs(with_extra - without).max() > 0, "the extra adapter must change the texture pass"
+    delight = run(wd)
+    assert [s_ for _, s_ in pipe.transformer._lora_active] == [1.0, 0.5] and np.abs(delight - with_extra).max() > 0
+    # the same pair set directly on the transformer: identical image
+    pipe.transformer.set_lora([(pipe._adapters["texture"], 1.0), (pipe._adapters["add_lora_0"], 0.5)])
+    direct = np.asarray(pipe(prompt="[MVFLUX]", control_image=ctrl, height=64, width=192, num_inference_steps=2, guidance_scale=3.5, max_sequence_length=64,
+                             generator=torch.Generator().manual_seed(63)).images[0]).astype(np.int32)
+    assert np.array_equal(direct, with_extra)

@@ -1,4 +1,4 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 300 python tools/gemm_zero_vs_random.py > gpurun_out/r03_gemm_zero_vs_random.log 2>&1; echo "rc=$?"
-cat gpurun_out/r03_gemm_zero_vs_random.log
+timeout 900 python -m pytest tests/test_pipeline_gpu.py -m gpu -x -q > gpurun_out/r03_pipeline_tests_e.log 2>&1; echo "pytest rc=$?"
+tail -30 gpurun_out/r03_pipeline_tests_e.log

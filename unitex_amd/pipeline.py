@@ -24,11 +24,14 @@ PNG_LEVEL = int(os.environ.get("UTX_PNG_LEVEL", "1"))
 
 
 def build_pipeline(pretrain_models=None, pipeline_name="texture_plus", device="cuda:0", seed=0, lora_rank=64, shape=None,
-                   sequence_parallel=False, process_group=None, speedup_mode=None):
+                   sequence_parallel=False, process_group=None, speedup_mode=None, add_lora_path=None, add_lora_weights=None):
     """FluxDiT + VAE + adapters.  speedup_mode: the reference's constructor takes the argument and never reads it (pipeline.py:81,142-145); here
     "fp8" runs the big linears on OCP MX fp8 operands (FluxDiT(fp8_weights=True): BASELINE configs[4] numerics, NOT the default), anything else = bf16.  With a `pretrain_models` directory holding diffusers-format safetensors the real
     weights are loaded; otherwise (no checkpoints exist here) FLUX.1-dev-shaped synthetic weights are generated.
-    sequence_parallel: ONE job over the ranks of `process_group` (flux/ulysses.py)."""
+    sequence_parallel: ONE job over the ranks of `process_group` (flux/ulysses.py).
+    add_lora_path / add_lora_weights (reference pipeline.py:112-117): further adapters `add_lora_<i>` (safetensors paths, or already loaded dicts), switched on
+    with weight add_lora_weights[i] in BOTH passes beside the texture / delight adapter -- they join the rank-concatenated LoRA segment of the GEMMs (bf16) or
+    are merged into the fp8 weights like the others."""
     from .flux.pipeline import PBRFluxPipeline
     from .flux.synthetic import SyntheticFluxStateDict, synthetic_lora
     from .flux.transformer import FluxDiT, FluxShape
@@ -50,8 +53,17 @@ def build_pipeline(pretrain_models=None, pipeline_name="texture_plus", device="c
                                    fp8_weights=(speedup_mode == "fp8")), vae, device=device)
     pipe.load_lora_weights(tex, adapter_name="texture")
     pipe.load_lora_weights(dlt, adapter_name="delight")
+    weights_for_texture, weights_for_delight, adapter_names = [1.0, 0.0], [0.0, 1.0], ["texture", "delight"]
+    if add_lora_path is not None:
+        if add_lora_weights is None or len(add_lora_weights) != len(add_lora_path):
+            raise ValueError("add_lora_weights must give one weight per entry of add_lora_path")
+        for i, src in enumerate(add_lora_path):
+            pipe.load_lora_weights(src, adapter_name="add_lora_%d" % i)
+            adapter_names.append("add_lora_%d" % i)
+            weights_for_texture.append(float(add_lora_weights[i]))
+            weights_for_delight.append(float(add_lora_weights[i]))
     pipe._num_inference_steps = 28
-    return pipe, [1.0, 0.0], [0.0, 1.0], ["texture", "delight"]
+    return pipe, weights_for_texture, weights_for_delight, adapter_names
 
 
 class RGBTextureFullPipelineBase:
@@ -78,9 +90,16 @@ class RGBTextureFullPipelineBase:
         shard = (self.rank, self.world)
         if pipeline is None:
             pipeline, wt, wd, names = build_pipeline(pretrain_models, pipeline_name, device=device, sequence_parallel=bool(multi_gpu),
-                                                     process_group=self.process_group, speedup_mode=speedup_mode)
+                                                     process_group=self.process_group, speedup_mode=speedup_mode, add_lora_path=add_lora_path,
+                                                     add_lora_weights=add_lora_weights)
         else:
             wt, wd, names = [1.0, 0.0], [0.0, 1.0], ["texture", "delight"]
+            if add_lora_path is not None:       # a caller-built pipeline: the extra adapters are registered on it the same way
+                if add_lora_weights is None or len(add_lora_weights) != len(add_lora_path):
+                    raise ValueError("add_lora_weights must give one weight per entry of add_lora_path")
+                for i, src in enumerate(add_lora_path):
+                    pipeline.load_lora_weights(src, adapter_name="add_lora_%d" % i)
+                    names.append("add_lora_%d" % i); wt.append(float(add_lora_weights[i])); wd.append(float(add_lora_weights[i]))
         if num_inference_steps is not None:
             pipeline._num_inference_steps = num_inference_steps
         self.weights_for_texture, self.weights_for_delight, self.adapter_names = wt, wd, names
