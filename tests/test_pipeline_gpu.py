@@ -281,3 +281,41 @@ def test_add_lora_adapters_join_both_passes(tmp_path):
     direct = np.asarray(pipe(prompt="[MVFLUX]", control_image=ctrl, height=64, width=192, num_inference_steps=2, guidance_scale=3.5, max_sequence_length=64,
                              generator=torch.Generator().manual_seed(63)).images[0]).astype(np.int32)
     assert np.array_equal(direct, with_extra)
+
+
+def test_callback_on_step_end_and_refused_arguments():
+    """flux_piplines/texturing/pipeline.py:664-671: `callback_on_step_end(pipe, i, t, {"latents": ...})` runs after every scheduler step and a returned
+    "latents" replaces the running latents; arguments this loop cannot honour (custom timesteps -- the reference's own call raises for them --,
+    several images per prompt, the dead redux path) are refused instead of ignored."""
+    from unitex_amd.flux.transformer import FluxShape
+    from unitex_amd.pipeline import build_pipeline
+    shape = FluxShape(num_heads=2, num_double=1, num_single=1, joint_dim=64, pooled_dim=64)
+    pipe, wt, wd, names = build_pipeline(None, device="cuda:0", lora_rank=16, shape=shape)
+    pipe.vae = fakes.FakeVAE()
+    pipe.set_adapters(names, wt)
+    yy, xx = np.mgrid[0:64, 0:192]
+    ctrl = Image.fromarray(np.stack([xx % 256, (yy * 4) % 256, (xx + yy) % 256], -1).astype(np.uint8))
+    kw = dict(prompt="[MVFLUX]", control_image=ctrl, height=64, width=192, num_inference_steps=3, guidance_scale=3.5, max_sequence_length=64)
+    seen = []
+
+    def watch(p, i, t, tensors):
+        assert p is pipe and set(tensors) == {"latents"}
+        lat = tensors["latents"]
+        assert lat.dim() == 3 and lat.shape[0] == 1 and lat.shape[2] == 64 and lat.shape[1] == 2 * (64 // 16) * (192 // 16)   # noise + control tokens
+        seen.append((i, float(t), lat.float().abs().mean().item()))
+        return {}
+    base = np.asarray(pipe(generator=torch.Generator().manual_seed(63), callback_on_step_end=watch, **kw).images[0]).astype(np.int32)
+    assert [s_[0] for s_ in seen] == [0, 1, 2] and seen[0][1] > seen[1][1] > seen[2][1] > 0, seen
+    plain = np.asarray(pipe(generator=torch.Generator().manual_seed(63), **kw).images[0]).astype(np.int32)
+    assert np.array_equal(base, plain), "an observing callback must not change the result"
+
+    def halve(p, i, t, tensors):
+        return {"latents": tensors["latents"] * 0.5} if i == 1 else {}
+    changed = np.asarray(pipe(generator=torch.Generator().manual_seed(63), callback_on_step_end=halve, **kw).images[0]).astype(np.int32)
+    assert np.abs(changed - plain).max() > 0, "returned latents replace the running ones"
+    with pytest.raises(ValueError):
+        pipe(generator=torch.Generator().manual_seed(63), timesteps=[900, 500, 100], **kw)
+    with pytest.raises(NotImplementedError):
+        pipe(generator=torch.Generator().manual_seed(63), num_images_per_prompt=2, **kw)
+    with pytest.raises(ValueError):
+        pipe(generator=torch.Generator().manual_seed(63), callback_on_step_end=watch, callback_on_step_end_tensor_inputs=["noise_pred"], **kw)

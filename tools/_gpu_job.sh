@@ -1,4 +1,4 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_pipeline_gpu.py -m gpu -x -q > gpurun_out/r03_pipeline_tests_e.log 2>&1; echo "pytest rc=$?"
-tail -30 gpurun_out/r03_pipeline_tests_e.log
+timeout 900 python -m pytest tests/test_pipeline_gpu.py -m gpu -x -q > gpurun_out/r03_pipeline_tests_f.log 2>&1; echo "pytest rc=$?"
+tail -30 gpurun_out/r03_pipeline_tests_f.log

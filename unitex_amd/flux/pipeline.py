@@ -176,7 +176,7 @@ class PBRFluxPipeline:
             # Euler step on the noise tokens + re-pin of the clean condition tail, one fused kernel
             ops.sched_step(latents, v, self.scheduler.dsigma(i), n_noise_tokens=n_noise_loc, cond=cond)
             if step_callback is not None:
-                step_callback(i, latents)
+                step_callback(i, timesteps[i], latents)
         if sp is not None and sp[1] > 1:
             from ..texturetools.distributed import _all_gather
             full = torch.empty(S_img_full, latents.shape[1], dtype=latents.dtype, device=latents.device)
@@ -195,6 +195,11 @@ class PBRFluxPipeline:
         width = width or 1024
         if redux_image is not None:
             raise NotImplementedError("redux_image is dead code in the reference (SURVEY 0.2) and is not supported")
+        if timesteps is not None:
+            # the reference hands `timesteps` AND its own sigmas to diffusers' retrieve_timesteps (pipeline.py:603-610), which refuses the pair [3p]
+            raise ValueError("custom timesteps are not supported (the reference's call raises for them as well)")
+        if num_images_per_prompt not in (None, 1):
+            raise NotImplementedError("num_images_per_prompt > 1: the reference's texture pipeline always asks for one image (pipeline.py:246-261)")
         batch_size = 1
         sh = self.transformer.shape
         # zero embeddings stand in for CLIP / T5 (reference pipeline.py:538-543)
@@ -216,8 +221,26 @@ class PBRFluxPipeline:
             condition_latents, condition_ids = control_latents, control_ids
         else:
             condition_latents = condition_ids = None
+        step_callback = None
+        if callback_on_step_end is not None:
+            # reference pipeline.py:664-671: callback(self, i, t, {name: tensor}) after every scheduler step; a returned "latents" replaces the running latents
+            # (here: [1, tokens, 64] bf16 -- noise tokens followed by the clean condition tail; a sequence-parallel rank sees its own token slice)
+            unknown = [k for k in callback_on_step_end_tensor_inputs if k not in ("latents", "prompt_embeds")]
+            if unknown:
+                raise ValueError("callback_on_step_end_tensor_inputs %s: only 'latents' and 'prompt_embeds' exist in this loop" % unknown)
+
+            def step_callback(i, t, cur):
+                kw = {}
+                if "latents" in callback_on_step_end_tensor_inputs:
+                    kw["latents"] = cur.unsqueeze(0)
+                if "prompt_embeds" in callback_on_step_end_tensor_inputs:
+                    kw["prompt_embeds"] = prompt_embeds
+                out = callback_on_step_end(self, i, torch.as_tensor(float(t)), kw) or {}
+                new = out.get("latents")
+                if new is not None and new.data_ptr() != cur.data_ptr():
+                    cur.copy_(new.reshape(cur.shape).to(cur.dtype))
         lat = self.denoise(noise_latents, noise_ids, condition_latents, condition_ids, prompt_embeds,
-                           pooled_prompt_embeds, text_ids, num_inference_steps, guidance_scale)
+                           pooled_prompt_embeds, text_ids, num_inference_steps, guidance_scale, step_callback=step_callback)
         self.last_latents = lat
         if output_type == "latent":
             return PBRFluxPipelineOutput(images=lat)
