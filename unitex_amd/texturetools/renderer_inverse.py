@@ -228,6 +228,16 @@ class NVDiffRendererInverse:
         the gradient / facing filter to the view masks.  Colours: 3 channels (rgb) or 9 (PBR stack) for 'kdtree', 3 for 'reproject'."""
         assert method in ("kdtree", "reproject")
         assert not perspective, "the reference's texture path is orthographic (pipeline.py:208-210)"
+        # keyword arguments of the reference's signature (renderer_inverse.py:635-659) that this build fixes at the values the pipeline uses: anything else is
+        # refused, not dropped
+        fixed = dict(reproject_kernel_size_boundary=3, reproject_kernel_size_boundary_blur=3, reproject_kernel_size_blur=5, return_mv_reproject_uv=False)
+        for k_, v_ in unused.items():
+            if k_ not in fixed:
+                raise TypeError("infer() got an unexpected keyword argument %r" % k_)
+            if v_ != fixed[k_]:
+                raise NotImplementedError("infer(%s=%r): only %r (the pipeline's value) is built" % (k_, v_, fixed[k_]))
+        if grid_interpolate_mode not in ("torch", "pytorch"):
+            raise NotImplementedError("grid_interpolate_mode %r: the bilinear grid_sample form ('torch') is the one the pipeline uses and the one built" % (grid_interpolate_mode,))
         assert reproject_method == "lens"
         assert len(self.index) == image_attrs.shape[0] == torch.as_tensor(c2ws).shape[0]
         m = self.pbr_mesh

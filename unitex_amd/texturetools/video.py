@@ -59,6 +59,10 @@ class VideoExporter:
                          return_image=True, return_mesh=False, return_camera=False):
         assert n_views == n_rows * n_cols, "Value Error: (n_views, n_rows, n_cols)=%s" % ((n_views, n_rows, n_cols),)
         assert not orbit and not perspective, "the texture pipeline renders orthographic box views (pipeline.py:200-214)"
+        if return_info or return_mesh or not return_image:
+            # export_nvdiffrast_video.py:948-975: the set-up only / float arrays / the loaded mesh object -- forms the texture pipeline never asks for
+            # (pipeline.py:200-216); the fused shade kernel produces the uint8 images directly
+            raise NotImplementedError("export_condition: only return_image=True (+ return_camera) is built")
         if isinstance(mesh_path, str):
             # the reference renders the conditions from the RAW input mesh (pipeline.py:573 -> export_nvdiffrast_video.py:900-999), any format its
             # loader reads; here .obj (shared positions: normals are smoothed over position indices) and .glb
