@@ -89,6 +89,10 @@ class PBRFluxPipeline:
 
     # ---- image <-> tensor (diffusers VaeImageProcessor [3p])
     def _preprocess(self, image: Image.Image, height, width):
+        # VaeImageProcessor(vae_scale_factor=16).preprocess (reference pipeline.py:218,316,365): the target size is floored to a multiple of 16 -- one 2 x 2
+        # patch of 8x-compressed latents -- and the image Lanczos-resized when that changes it [3p]
+        f = self.vae_scale_factor * 2
+        width, height = width - width % f, height - height % f
         if image.size != (width, height):
             image = image.resize((width, height), Image.LANCZOS)
         arr = np.asarray(image.convert("RGB"), dtype=np.float32) / 255.0
