@@ -319,3 +319,57 @@ def test_callback_on_step_end_and_refused_arguments():
         pipe(generator=torch.Generator().manual_seed(63), num_images_per_prompt=2, **kw)
     with pytest.raises(ValueError):
         pipe(generator=torch.Generator().manual_seed(63), callback_on_step_end=watch, callback_on_step_end_tensor_inputs=["noise_pred"], **kw)
+
+
+def test_build_pipeline_from_a_checkpoint_directory(tmp_path):
+    """The production entry: `pretrain_models` names a directory laid out as the reference expects (pipeline.py:83-86,96-109) --
+    black-forest-labs/FLUX.1-dev/{transformer,vae}/*.safetensors in diffusers key names (sharded), UniTex/{texture_gen,delight}/pytorch_lora_weights.safetensors
+    in diffusers' LoRA spelling.  A tiny-shaped tree written here must load into the same pipeline as the one assembled from the tensors directly:
+    identical images for the texture and the delight pass, real HIP VAE included."""
+    from safetensors.torch import save_file
+    from oracle import dit_ref
+    from unitex_amd.flux.pipeline import PBRFluxPipeline
+    from unitex_amd.flux.synthetic import synthetic_vae_state_dict
+    from unitex_amd.flux.transformer import FluxDiT, FluxShape
+    from unitex_amd.flux.vae_hip import AutoencoderKL
+    from unitex_amd.pipeline import build_pipeline
+    dev = "cuda:0"
+    cfg = dit_ref.tiny_config(heads=2, double=1, single=2, joint_dim=64, pooled_dim=64)
+    shape = FluxShape(num_heads=2, num_double=1, num_single=2, joint_dim=64, pooled_dim=64)
+    sd = {k: v.to(torch.bfloat16).contiguous() for k, v in dit_ref.make_synthetic_state_dict(cfg, seed=0).items()}
+    vae_sd = {k: v.to(torch.bfloat16).contiguous() for k, v in synthetic_vae_state_dict(0).items()}
+    tex = dit_ref.make_synthetic_lora(cfg, sd, rank=16, seed=1)
+    dlt = dit_ref.make_synthetic_lora(cfg, sd, rank=16, seed=2)
+    root = tmp_path / "pretrain"
+    tdir = root / "black-forest-labs" / "FLUX.1-dev" / "transformer"
+    vdir = root / "black-forest-labs" / "FLUX.1-dev" / "vae"
+    for d in (tdir, vdir, root / "UniTex" / "texture_gen", root / "UniTex" / "delight"):
+        os.makedirs(d)
+    keys = sorted(sd)
+    save_file({k: sd[k] for k in keys[: len(keys) // 2]}, str(tdir / "diffusion_pytorch_model-00001-of-00002.safetensors"))
+    save_file({k: sd[k] for k in keys[len(keys) // 2:]}, str(tdir / "diffusion_pytorch_model-00002-of-00002.safetensors"))
+    save_file(vae_sd, str(vdir / "diffusion_pytorch_model.safetensors"))
+    for name, lo in (("texture_gen", tex), ("delight", dlt)):
+        flat = {}
+        for mod, (A, B) in lo.items():
+            flat["transformer.%s.lora_A.weight" % mod] = A.float().contiguous()
+            flat["transformer.%s.lora_B.weight" % mod] = B.float().contiguous()
+        save_file(flat, str(root / "UniTex" / name / "pytorch_lora_weights.safetensors"))
+    pipe, wt, wd, names = build_pipeline(str(root), device=dev, shape=shape)
+    assert isinstance(pipe.vae, AutoencoderKL) and names == ["texture", "delight"]
+    direct = PBRFluxPipeline(FluxDiT(sd, shape, device=dev), AutoencoderKL(vae_sd, device=dev), device=dev)
+    direct.load_lora_weights(tex, adapter_name="texture")
+    direct.load_lora_weights(dlt, adapter_name="delight")
+    yy, xx = np.mgrid[0:64, 0:192]
+    ctrl = Image.fromarray(np.stack([xx % 256, (yy * 4) % 256, (xx + yy) % 256], -1).astype(np.uint8))
+    kw = dict(prompt="[MVFLUX]", control_image=ctrl, height=64, width=192, num_inference_steps=2, guidance_scale=3.5, max_sequence_length=64)
+    for weights in (wt, wd):
+        imgs = []
+        for p in (pipe, direct):
+            p.set_adapters(names, weights)
+            imgs.append(np.asarray(p(generator=torch.Generator().manual_seed(63), **kw).images[0]))
+        assert imgs[0].shape == (64, 192, 3) and imgs[0].std() > 1.0
+        assert np.array_equal(imgs[0], imgs[1]), "pipeline loaded from the checkpoint tree differs from the one built from the same tensors"
+    with pytest.raises(FileNotFoundError):
+        os.remove(str(vdir / "diffusion_pytorch_model.safetensors"))
+        build_pipeline(str(root), device=dev, shape=shape)

@@ -1,5 +1,4 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/r03_final_gpu_tests.log 2>&1; echo "pytest rc=$?"
-tail -3 gpurun_out/r03_final_gpu_tests.log
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/r03_smoke_final.log 2>&1; echo "smoke rc=$?"; tail -2 gpurun_out/r03_smoke_final.log
+timeout 900 python -m pytest tests/test_pipeline_gpu.py -m gpu -x -q -k "checkpoint or callback or add_lora" > gpurun_out/r03_pipeline_tests_g.log 2>&1; echo "pytest rc=$?"
+tail -30 gpurun_out/r03_pipeline_tests_g.log
