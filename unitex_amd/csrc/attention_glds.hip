@@ -231,7 +231,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
             __builtin_amdgcn_sched_group_barrier(0x402, 4, 1);
         }
-        if (t == 0 || ragged || !__all(ps0 <= 8192.0f)) {
+        if ((t == 0 && VAR != 10) || ragged || !__all(ps0 <= 8192.0f)) {      /* VAR 10 (ablation build, WRONG results): no first-tile max pass -- what the prologue's slow path costs */
             AG_SLOW(sa0, sa1, true, 0, 0, t == 0)
             AG_EXPB(sa0, pb[0], pb[1], ps0)
         }
@@ -314,6 +314,15 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
         return;
     }
     const bool wide = VAR == 7 && ((p.o_ss & 7) == 0) && ((((uintptr_t)p.o) & 15) == 0);     // wave-uniform
+    if constexpr (VAR == 9) {      // ablation build, WRONG results: no output stores (one dword per lane keeps the accumulators alive) -- what the store tail costs
+        float keep_ = 0.f;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) keep_ += oacc[db][r];
+        if (keep_ * inv == 123.456f) p.o[0] = (bf16_t)1u;
+        return;
+    }
     AG_STORE_ROW(p.o + (long)(qrow < Sq ? qrow : 0) * p.o_ss + head * 128, wide);
 }
 
@@ -397,7 +406,7 @@ static int launch_glds(AttnParams p, hipStream_t stream) {
     p.nqb = ((p.Sq > 0 ? p.Sq : p.S) + 255) / 256;
     p.w_base = 0; p.nsplit = 1; p.tiles_per_split = 0; p.part_o = nullptr; p.part_lse = nullptr;
     int pl[4] = {p.nqb * p.H, 0, 1, 0};
-    if (TPB == 1 && (VAR == 0 || VAR == 6 || VAR == 7 || VAR == 8) && !p.flags) utx_attn_split_plan_impl(p.H, p.Sq, p.S, utx_ncu(), pl);
+    if (TPB == 1 && (VAR == 0 || VAR == 6 || VAR == 7 || VAR == 8 || VAR == 9 || VAR == 10) && !p.flags) utx_attn_split_plan_impl(p.H, p.Sq, p.S, utx_ncu(), pl);
     const int nwg = pl[0], nfull = pl[1], ns = pl[2], tps = pl[3], r = nwg - nfull;
     // the scratch of the split is CALLER-OWNED (utx_attn_fwd_bf16_ws; the legacy entry points pass the context's own buffer, grown outside of any
     // capture): nothing is allocated here, a launch whose scratch is missing or too small runs unsplit -- same result up to one bf16 rounding of the
@@ -430,6 +439,8 @@ extern "C" int utx_launch_attn_fwd_glds(const AttnParams* p, int presc, hipStrea
       if (var == 5 && presc) return launch_glds<1, 1, 5>(*p, stream);
       if (var == 6 && presc) return launch_glds<1, 1, 6>(*p, stream);      // static priority for waves 4-7 (correct results)
       if (var == 8 && presc) return launch_glds<1, 1, 8>(*p, stream);      // nontemporal output stores (correct results)
+      if (var == 9 && presc) return launch_glds<1, 1, 9>(*p, stream);      // no output stores (WRONG results): the store tail's share of a workgroup's fixed cost
+      if (var == 10 && presc) return launch_glds<1, 1, 10>(*p, stream);    // no first-tile max pass (WRONG results)
       if (var == 7 && presc) return launch_glds<1, 1, 7>(*p, stream); }    // 16-byte epilogue stores through v_permlane32_swap (correct results)
 #endif
     return presc ? launch_glds<1, 1>(*p, stream) : launch_glds<0, 1>(*p, stream);
