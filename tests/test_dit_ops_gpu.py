@@ -492,13 +492,14 @@ def _sp_worker(rank, world, port, q, zero_text=False, groups=1):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,zero_text,groups", [(2, False, 1), (2, True, 1), (2, False, 2), (2, True, 2)])
+@pytest.mark.parametrize("world,zero_text,groups", [(2, False, 1), (2, True, 1), (2, False, 2), (2, True, 2), (4, True, 1), (4, False, 1)])
 def test_sequence_parallel_two_ranks_match_unsharded_forward(world, zero_text, groups):
     """two processes share cuda:0 and exchange through gloo (host-staged all-to-all): the token-sharded /
     head-sharded FluxDiT plan -- real kernels, real slicing of ids / embeddings / latents -- against the plain forward.
     Differences can only come from the key order inside attention (fp32 summation order): a few bf16 ulps.
     groups = 2: the two heads of a rank as two head groups -- send buffer written through the two-level grouped addressing of
-    utx_qkv_post, one all-to-all + unpack + attention launch + return exchange per group (the pipelined form, ulysses.py)."""
+    utx_qkv_post, one all-to-all + unpack + attention launch + return exchange per group (the pipelined form, ulysses.py).
+    world = 4: one head per rank (the H / P = 3 regime of 8 ranks on the real model has the same single-group control flow)."""
     import os
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
