@@ -192,6 +192,9 @@ def main():
     ap.add_argument("--parallelism", default=os.environ.get("UTX_PARALLELISM", "ulysses"), choices=["replicas", "ulysses"],
                     help="N > 1: 'ulysses' (default) = ONE job, head-parallel sequence parallelism with two all-to-alls per layer "
                          "over RCCL (strong scaling) + view-sharded back-projection; 'replicas' = N independent jobs (weak scaling)")
+    ap.add_argument("--sp-self-test", action="store_true",
+                    help="diagnostic, N = 1 only: run the sequence-parallel plan on a 1-rank NCCL group with every collective issued (all-to-alls to itself, "
+                         "UTX_SP_FORCE_A2A=1): the step's non-fabric cost of the exchange machinery (RCCL launches, copies, unpack kernels) against the plain step")
     ap.add_argument("--fp8", action="store_true",
                     help="BASELINE configs[4] numerics: the five big linears on OCP MX fp8 operands (utx_gemm_desc.mx8); NOT the default "
                          "bench line (the metric is quoted in bf16) -- reported with dtype 'mx-fp8 linears + bf16 attention'")
@@ -233,6 +236,15 @@ def main():
     shape = FluxShape()
     sd = SyntheticFluxStateDict(shape, seed=0, device=dev)
     ulysses = args.parallelism == "ulysses" and world > 1
+    if args.sp_self_test:
+        if world != 1:
+            raise SystemExit("--sp-self-test is a single-GPU diagnostic")
+        import torch.distributed as dist
+        os.environ["UTX_SP_FORCE_A2A"] = "1"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29655")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(dev))
+        ulysses = True
     model = FluxDiT(sd, shape, device=dev, sequence_parallel=ulysses, fp8_weights=args.fp8)
     tex = synthetic_lora(sd, shape, rank=args.lora_rank, seed=1, device=dev)
     dlt = synthetic_lora(sd, shape, rank=args.lora_rank, seed=2, device=dev)
@@ -362,7 +374,8 @@ def main():
             attn_launch_flops = (attn_launch_flops * (n_attn - 1) + attn_last) / n_attn      # mean over the step's calls, as attn_avg_ms is
         achieved = attn_launch_flops / (attn_avg_ms * 1e-3) / 1e12
         value = (1 if ulysses else world) * args.steps / dt
-        par = ("ulysses sp%d: ONE job, 2 all-to-alls / layer (RCCL) + view-sharded back-projection with one all-gather" % world) if ulysses \
+        par = "DIAGNOSTIC --sp-self-test: the sequence-parallel plan on ONE rank, every all-to-all issued to itself through RCCL (not a speed)" if args.sp_self_test else \
+            ("ulysses sp%d: ONE job, 2 all-to-alls / layer (RCCL) + view-sharded back-projection with one all-gather" % world) if ulysses \
             else ("single GPU" if world == 1 else "replicas x%d (independent jobs, no data-path collective)" % world)
         out = {
             "metric": "denoising-steps/sec", "value": value, "unit": "steps/s", "n_gpus": world,
@@ -486,7 +499,7 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": ncpu, "kind": "port",
                                        "sample": "failed: %r" % (e,)}
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or args.sp_self_test:
         import torch.distributed as dist
         dist.destroy_process_group()
 

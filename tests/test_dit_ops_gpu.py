@@ -448,6 +448,51 @@ def test_sequence_parallel_plan_world1_matches_plain_forward():
             dist.destroy_process_group()
 
 
+def test_sequence_parallel_world1_through_rccl_collectives(monkeypatch):
+    """RCCL on a one-GPU box: with UTX_SP_FORCE_A2A=1 a 1-rank NCCL group still issues every collective of the sequence-parallel plan -- per layer and
+    head group an asynchronous all_to_all_single to itself on ProcessGroupNCCL's stream, work.wait() on the compute stream, then the HIP unpack / attention
+    kernels launched through ctypes on that stream, and the same for the return exchange.  What it pins: the call pattern RCCL accepts (views of the
+    group-major buffers, async_op), and the ORDERING between RCCL's stream and the kernels the C ABI launches (a missing dependency shows up as stale
+    Q / K / V or stale outputs).  One rank sees every key in the plain order, so the result must equal the plain forward bit for bit, every time."""
+    import os
+    import torch.distributed as dist
+    from unitex_amd.flux.transformer import FluxDiT, FluxShape
+    monkeypatch.setenv("UTX_SP_FORCE_A2A", "1")
+    monkeypatch.setenv("UTX_SP_GROUPS", "2")
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29800 + os.getpid() % 100))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+        created = True
+    try:
+        assert dist.get_backend() == "nccl"
+        cfg = dit_ref.tiny_config(heads=4, double=2, single=3, joint_dim=64, pooled_dim=64)
+        sd = dit_ref.make_synthetic_state_dict(cfg, seed=3)
+        shape = FluxShape(num_heads=4, num_double=2, num_single=3, joint_dim=64, pooled_dim=64)
+        S_txt, S_img = 64, 64 * 48
+        g = torch.Generator().manual_seed(5)
+        enc = (0.5 * torch.randn(S_txt, 64, generator=g)).to(BF).cuda()
+        pooled = (0.5 * torch.randn(1, 64, generator=g)).to(BF).cuda()
+        txt_ids, img_ids = torch.zeros(S_txt, 3), dit_ref.latent_image_ids(64, 48)
+        plain = FluxDiT(sd, shape, device="cuda:0")
+        spm = FluxDiT(sd, shape, device="cuda:0", sequence_parallel=True)
+        for m in (plain, spm):
+            m.set_positions(txt_ids, img_ids)
+            m.set_conditioning(enc, pooled, 3.5)
+        ex = spm.ex
+        assert ex.force and ex.can_async and ex.G == 2 and ex.recv.data_ptr() != ex.send.data_ptr() and ex.o_recv.data_ptr() != ex.o.data_ptr()
+        for it in range(6):
+            lat = torch.randn(S_img, 64, generator=g).to(BF).cuda()
+            a = plain.forward(lat, 0.5 - 0.05 * it).clone()
+            b = spm.forward(lat, 0.5 - 0.05 * it).clone()
+            torch.cuda.synchronize()
+            assert torch.equal(a.view(torch.int16), b.view(torch.int16)), "iteration %d: the plan through RCCL differs from the plain forward" % it
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 def _sp_worker(rank, world, port, q, zero_text=False, groups=1):
     import os
     import sys

@@ -18,12 +18,16 @@ Per layer and rank (S_loc = S / P local tokens, D = 3072, bf16):
         first-in / last-out:   (t_in + t_out) / G      (single blocks: the MLP half of the fused projection runs beside exchange 1 as well)
         + what the fabric cannot finish behind the other G - 1 groups' attention:  max(0, (t_in + t_out) (G - 1) / G - t_attn (G - 1) / G)
     not sharded: the AdaLN-modulation GEMV (6.5 GB of weights streamed per step) + embedders, ~1.5 ms.
+    only under sequence parallelism (measured on ONE GPU with `bench.py --sp-self-test`: the plan on a 1-rank NCCL group with every all-to-all issued to itself,
+    profiles/r03_bench_sp_self_test.json.log + r03_rocprofv3_kernel_stats_sp_self_test.csv): the relayout kernels behind the exchanges -- sp_unpack_qkv 4 x 89 us
+    + sp_unpack_o 4 x 32 us per layer at P = 1 = 27.6 ms per step, 1 / P of it per rank, on the compute stream -- and the attention launches running 1.3 % slower
+    while RCCL's kernels hold CUs beside them (6.589 x 4 vs 26.01 ms per layer).  The whole machinery at P = 1, fabric excluded: 2106 vs 2035 ms per step (+3.5 %).
 """
 import math
 
 D, HEADS, LAYERS, N_DOUBLE, N_SINGLE = 3072, 24, 57, 19, 38
 
-MEASURED_1GPU = dict(step_ms=1998.9, attn_ms_per_layer=25.47, gemm_ms_per_step=515.4, replicated_ms=1.5)
+MEASURED_1GPU = dict(step_ms=1998.9, attn_ms_per_layer=25.47, gemm_ms_per_step=515.4, replicated_ms=1.5, sp_unpack_ms_per_step=27.6, attn_corun_factor=1.013)
 # the large-M GEMMs lose efficiency as M = S / P shrinks (fewer rounds of 256 x 256 tiles per launch, a larger share of fill / epilogue): bf16 TF/s at
 # M = 13 824 vs 50 688 on the FLUX shapes, same process (profiles/r03_perf_fp8_v0.log, bf16 column): 1224 / 1360, 1326 / 1292, 1241 / 1337 -> ~0.93 at a
 # quarter of the rows; 0.97 at half and 0.85 at an eighth are interpolated / extrapolated, not measured
@@ -67,10 +71,10 @@ def predict(P, S=50240, groups=None, measured=None, xgmi=None, plan=None, n_cus=
     t_in = exchange_bytes_per_peer(S_loc, P) / link * 1e3            # ms; every peer pair on its own link, all at once
     t_out = t_in / 3.0
     grow = S_all / float(S)                                          # the extra text rows
-    t_attn = m["attn_ms_per_layer"] / P * grow * grow * attention_round_factor(P, S_all, n_cus, G, plan)
+    t_attn = m["attn_ms_per_layer"] / P * grow * grow * attention_round_factor(P, S_all, n_cus, G, plan) * m["attn_corun_factor"]
     other_ms = m["step_ms"] - LAYERS * m["attn_ms_per_layer"] - m["gemm_ms_per_step"] - m["replicated_ms"]
     t_gemm_layer = m["gemm_ms_per_step"] / LAYERS / P * grow / GEMM_EFFICIENCY.get(P, 0.85)
-    t_other_layer = other_ms / LAYERS / P * grow
+    t_other_layer = (other_ms + m["sp_unpack_ms_per_step"]) / LAYERS / P * grow      # + the relayout kernels of the two exchanges
     t_mlp_half = t_gemm_layer * (12288.0 / (9216 + 12288 + 15360))  # the MLP half of a single block's fused projection, by FLOPs
     fabric = t_in + t_out
     behind = max(0.0, fabric * (G - 1) / G - t_attn * (G - 1) / G)

@@ -84,21 +84,24 @@ class UlyssesExchange:
         self.ctx = ctx                      # unitex_amd._lib.Context: the HIP unpack kernels (GPU path)
         if self.on_gpu and ctx is None:
             raise RuntimeError("UlyssesExchange on a GPU needs the library context (HIP unpack kernels)")
-        backend = dist.get_backend(group) if (dist.is_initialized() and P > 1) else None
+        # UTX_SP_FORCE_A2A=1 (tests): a 1-rank group still goes through the collectives (separate receive buffers, asynchronous all-to-alls to itself) -- the
+        # only way to run the RCCL call pattern and its stream ordering against the HIP kernels on a box with one GPU
+        self.force = bool(P == 1 and dist.is_initialized() and os.environ.get("UTX_SP_FORCE_A2A", "0") == "1")
+        backend = dist.get_backend(group) if (dist.is_initialized() and (P > 1 or self.force)) else None
         # gloo cannot move device tensors through all_to_all: stage through the host (two ranks sharing one GPU in the tests --
         # production uses NCCL = RCCL, device to device over xGMI)
-        self.host_staged = bool(P > 1 and self.on_gpu and backend == "gloo")
-        self.can_async = bool(P > 1 and backend == "nccl")
+        self.host_staged = bool((P > 1 or self.force) and self.on_gpu and backend == "gloo")
+        self.can_async = bool((P > 1 or self.force) and backend == "nccl")
         self.E = S_loc * 128
         G, Hg = self.G, self.Hg
         z = lambda *s: torch.zeros(*s, dtype=dtype, device=device)
         self.send = z(G, P, 3, Hg, self.E)            # [head group][dest rank][q|k|v][head of the group][S_loc*128]
-        self.recv = z(G, P, 3, Hg, self.E) if P > 1 else self.send
+        self.recv = z(G, P, 3, Hg, self.E) if (P > 1 or self.force) else self.send
         self.q = z(self.Hp, self.S, 128)              # heads of group g = rows [g*Hg, (g+1)*Hg)
         self.k = z(self.Hp, self.S, 128)
         self.vt = z(self.Hp, 128, self.S)
         self.o = z(G, self.S, Hg * 128)               # attention output of group g = [P][S_loc][Hg*128]: the send buffer of its exchange 2
-        self.o_recv = z(G, P, S_loc, Hg * 128) if P > 1 else self.o.view(G, P, S_loc, Hg * 128)
+        self.o_recv = z(G, P, S_loc, Hg * 128) if (P > 1 or self.force) else self.o.view(G, P, S_loc, Hg * 128)
         # utx_qkv_post's two-level grouped head addressing into `send`: head h -> dest h // Hp, group (h % Hp) // Hg, head h % Hg
         self.dest_stride = 3 * Hg * self.E            # elements between the blocks of two destination ranks (inside a head group)
         self.group_stride = P * 3 * Hg * self.E       # elements between two head groups
@@ -123,7 +126,7 @@ class UlyssesExchange:
         self.o.view(G, S, Hg, 128).copy_(o_heads.reshape(G, Hg, S, 128).transpose(1, 2))
 
     def _a2a(self, out, inp, async_op=False):
-        if self.P == 1:
+        if self.P == 1 and not self.force:
             return None
         if self.host_staged:
             rc, sc = torch.empty_like(out, device="cpu"), inp.cpu()
