@@ -35,6 +35,7 @@ WORKLOADS = {
     # name: (strip_h, strip_w, dual_px, description)
     "strip1024x6": (1024, 6144, 512, "FLUX.1-dev + texture LoRA r64, joint strip 1024x6144 (6 views @1024^2) + control strip + 512^2 dual"),
     "ref512x6": (512, 3072, 512, "FLUX.1-dev + texture LoRA r64, joint strip 512x3072 (reference operating point) + control + 512^2 dual"),
+    "strip2048x8": (2048, 16384, 512, "FLUX.1-dev + texture LoRA r64, joint strip 2048x16384 (8 views @2048^2, the reference's joint semantics carried to BASELINE configs[4]'s resolution: 263 680 tokens) + control strip + 512^2 dual"),
     "view2048": (2048, 2048, 512, "FLUX.1-dev + texture LoRA r64, single 2048^2 view + control + 512^2 dual (BASELINE configs[4] per-view shape; NOT the reference's joint semantics)"),
     "view1024": (1024, 1024, 512, "FLUX.1-dev + texture LoRA r64, single 1024^2 view + control + 512^2 dual (per-view variant; NOT the reference's joint semantics)"),
 }

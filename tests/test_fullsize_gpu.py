@@ -403,3 +403,68 @@ def _flat_plan(m):
             else:
                 yield fn, d
     return list(walk(next(iter(m._plans.values()))["plan"]))
+
+
+def test_address_arithmetic_beyond_32_bit_offsets():
+    """Maximum sizes: the joint-sequence reading of BASELINE configs[4] (2048^2 x 8 views in ONE strip) is 263 232 executed tokens -- the single-block `cat`
+    buffer [S, 15 360] holds 4.04e9 elements (8.1 GB), `qkv` [S, 9216] 2.4e9: element AND byte offsets leave 32 bits.  Every kernel on the step path is run at
+    that token count and its rows at the far end are checked (an index that wraps reads / writes the wrong rows): the large-M GEMM (GELU columns into the
+    strided cat view), LayerNorm-modulation, q / k / v post-processing (24 heads, the V^T transpose across a 263 232-column row), attention (one head, all keys)."""
+    ops = _ops()
+    S, D = 263232, 3072
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(3)
+    far = torch.arange(S - 200, S, device=dev)
+    near = torch.arange(0, 200, device=dev)
+    rows = torch.cat([near, torch.tensor([70000, 139811, 139812, 209715, 209716], device=dev), far])     # around 2^31 / 15360 and 2^32 / (2 * 15360) rows as well
+    # ---- GEMM: cat[:, D:] = GELU(x W^T + b), M = S, N = 12 288, K = 3072, ldc = 15 360
+    x = (torch.randn(S, D, device=dev, generator=g) * 0.5).to(BF)
+    W = (torch.randn(4 * D, D, device=dev, generator=g) / math.sqrt(D)).to(BF)
+    b = torch.randn(4 * D, device=dev, generator=g).to(BF)
+    cat = torch.zeros(S, 5 * D, dtype=BF, device=dev)
+    ops.gemm(x, W, bias=b, out=cat[:, D:], gelu_from=0)
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.gelu(x[rows].float() @ W.float().t() + b.float(), approximate="tanh")
+    got = cat[rows][:, D:].float()
+    err = (got - ref).abs().max().item()
+    assert err < 3e-2 * max(1.0, ref.abs().max().item()), "GEMM rows at the far end: %g" % err
+    assert cat[rows][:, :D].abs().max().item() == 0.0, "the GEMM wrote outside its column window"
+    del W, b
+    # ---- LayerNorm-modulation over S rows
+    shift = torch.randn(D, device=dev, generator=g).to(BF); scale = (0.1 * torch.randn(D, device=dev, generator=g)).to(BF)
+    y = ops.ln_mod(x, shift, scale)
+    torch.cuda.synchronize()
+    y_rows = ops.ln_mod(x[rows].contiguous(), shift, scale)      # a per-row operation: the same rows processed on their own must give the same bits
+    torch.cuda.synchronize()
+    assert torch.equal(y[rows], y_rows), "ln_mod rows at the far end"
+    ref = torch.nn.functional.layer_norm(x[rows].float(), (D,), eps=1e-6) * (1.0 + scale.float()) + shift.float()
+    assert (y_rows.float() - ref).abs().max().item() < 0.08      # (the kernel rounds to bf16 where the reference's bf16 modules do: a few ulps of values up to ~6)
+    del y, cat
+    # ---- q / k / v post-processing: 24 heads, S tokens (rows of the far end must equal the same rows processed on their own)
+    H = H_FULL
+    qkv = (torch.randn(S, 3 * D, device=dev, generator=g) * 0.5).to(BF)
+    wq = (1.0 + 0.1 * torch.randn(128, device=dev, generator=g)).to(BF); wk = (1.0 + 0.1 * torch.randn(128, device=dev, generator=g)).to(BF)
+    ang = torch.rand(S, 64, device=dev, generator=g) * 6.28
+    cos, sin = torch.cos(ang).contiguous(), torch.sin(ang).contiguous()
+    Qh = torch.zeros(H, S, 128, dtype=BF, device=dev); Kh = torch.zeros(H, S, 128, dtype=BF, device=dev); Vt = torch.zeros(H, 128, S, dtype=BF, device=dev)
+    ops.qkv_post(qkv, 0, D, 2 * D, wq, wk, cos, sin, Qh, Kh, Vt, S, 0, H, q_scale=0.1275)
+    torch.cuda.synchronize()
+    n = 256
+    for r0 in (0, S - n):
+        q2 = torch.zeros(H, n, 128, dtype=BF, device=dev); k2 = torch.zeros(H, n, 128, dtype=BF, device=dev); v2 = torch.zeros(H, 128, n, dtype=BF, device=dev)
+        ops.qkv_post(qkv[r0:r0 + n].contiguous(), 0, D, 2 * D, wq, wk, cos[r0:r0 + n].contiguous(), sin[r0:r0 + n].contiguous(), q2, k2, v2, n, 0, H, q_scale=0.1275)
+        torch.cuda.synchronize()
+        assert torch.equal(Qh[:, r0:r0 + n], q2) and torch.equal(Kh[:, r0:r0 + n], k2) and torch.equal(Vt[:, :, r0:r0 + n], v2), "qkv_post rows at %d" % r0
+    assert torch.equal(Vt[H - 1, 127, S - 8:].float(), qkv[S - 8:, 2 * D + (H - 1) * 128 + 127].float()), "last V^T row, last columns"
+    del qkv, cos, sin, ang
+    # ---- attention: one head over all 263 232 keys, first / last query rows against the fp32 softmax
+    q1, k1, vt1 = Qh[:1].contiguous(), Kh[:1].contiguous(), Vt[:1].contiguous()
+    out = ops.attention(q1, k1, vt1, S=S, scale=0.0)       # Q carries scale * log2(e) (q_scale above): scores are base-2 exponents
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()
+    pick = torch.cat([torch.arange(0, 64, device=dev), torch.arange(S - 64, S, device=dev)])
+    sc = (q1[0, pick].float() @ k1[0].float().t()) * math.log(2.0)
+    p = torch.softmax(sc, dim=-1)
+    ref = p @ vt1[0].float().t()
+    err = (out[pick].float() - ref).abs().max().item()
+    assert err < 3e-2, "attention over 263 232 keys: %g" % err

@@ -1,7 +1,5 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 1000 python -m pytest tests -m gpu -x -q > gpurun_out/r03_final_gpu_tests.log 2>&1; echo "pytest rc=$?"
-grep -n "passed\|failed" gpurun_out/r03_final_gpu_tests.log | tail -2
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/r03_smoke_final.log 2>&1; echo "smoke rc=$?"; tail -2 gpurun_out/r03_smoke_final.log
-timeout 600 python bench.py > gpurun_out/r03_final_bench.log 2>&1; echo "bench rc=$?"
-grep '^{' gpurun_out/r03_final_bench.log | cut -c1-200
+timeout 560 python bench.py --workload strip2048x8 --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/r03_bench_strip2048x8_v0.json.log 2>&1; echo "rc=$?"
+grep '^{' gpurun_out/r03_bench_strip2048x8_v0.json.log | cut -c1-600
+tail -4 gpurun_out/r03_bench_strip2048x8_v0.json.log | cut -c1-300
