@@ -468,3 +468,45 @@ def test_address_arithmetic_beyond_32_bit_offsets():
     ref = p @ vt1[0].float().t()
     err = (out[pick].float() - ref).abs().max().item()
     assert err < 3e-2, "attention over 263 232 keys: %g" % err
+
+
+def test_address_arithmetic_beyond_32_bit_offsets_mx_fp8():
+    """The same at 263 232 tokens for the MX fp8 path: the activation scratch [S, 15 360] bytes is 4.04e9 B (beyond 2^31, just below 2^32), its tile-packed
+    scale buffer has 2057 row blocks per K-tile slab.  The quantiser (packed) over all rows into the strided scratch, then the one-wave-per-SIMD MX GEMM over
+    K = 15 360 (the single blocks' out-projection shape); the last 128-aligned row block must equal, bit for bit, the same rows quantised and multiplied on their own."""
+    ops = _ops()
+    from unitex_amd.flux import mx8
+    ctx = ops.get_ctx(0)
+    S, D = 263232, 3072
+    K = 5 * D
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = torch.empty(S, K, dtype=BF, device=dev)
+    for c0 in range(0, S, 32768):      # filled in slabs: randn of 4e9 elements at once would need 16 GB of fp32
+        c1 = min(S, c0 + 32768)
+        x[c0:c1] = (torch.randn(c1 - c0, K, device=dev, generator=g) * 0.5).to(BF)
+    W = (torch.randn(D, K, device=dev, generator=g) / math.sqrt(K)).to(BF)
+    b = torch.randn(D, device=dev, generator=g).to(BF)
+    wq, wp = mx8.quantize_weight(W, ctx, packed=True)
+    aq = torch.empty(S, K, dtype=torch.uint8, device=dev)
+    ap = mx8.PackedScales(mx8.packed_scale_buffer(S, K, dev), S, K)
+    mx8.quantize_act(x, ctx, out=(aq, ap), packed=True)
+    y = torch.empty(S, D, dtype=BF, device=dev)
+    ops.gemm(aq, wq, bias=b, out=y, a_scale=ap, b_scale=wp)
+    torch.cuda.synchronize()
+    r0 = (S // 128 - 2) * 128          # the last two whole row blocks + the ragged tail
+    n = S - r0
+    aq2, ap2 = mx8.quantize_act(x[r0:].contiguous(), ctx, packed=True)
+    torch.cuda.synchronize()
+    assert torch.equal(aq[r0:], aq2), "quantised bytes of the far-end rows"
+    assert torch.equal(ap.rowmajor()[r0:], ap2.rowmajor()), "E8M0 scales of the far-end rows"
+    y2 = torch.empty(n, D, dtype=BF, device=dev)
+    ops.gemm(aq2, wq, bias=b, out=y2, a_scale=ap2, b_scale=wp)
+    torch.cuda.synchronize()
+    # (these rows lie in the launch's last, partly filled round, which is cut along K and summed by the fix-up kernel: another fp32 summation order than the
+    # unsplit launch of the slice -- equal up to one bf16 ulp, not bit for bit)
+    dmax = (y[r0:].float() - y2.float()).abs().max().item()
+    assert dmax <= 2.0 ** -6 * max(1.0, y2.float().abs().max().item()), "MX GEMM rows at the far end: %g" % dmax
+    ref = x[r0:].float() @ W.float().t() + b.float()
+    rel = ((y2.float() - ref).norm() / ref.norm()).item()
+    assert rel < 0.06, "fp8 product vs the bf16 operands: relative Frobenius %g" % rel

@@ -1,5 +1,4 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 560 python bench.py --workload strip2048x8 --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/r03_bench_strip2048x8_v0.json.log 2>&1; echo "rc=$?"
-grep '^{' gpurun_out/r03_bench_strip2048x8_v0.json.log | cut -c1-600
-tail -4 gpurun_out/r03_bench_strip2048x8_v0.json.log | cut -c1-300
+timeout 500 python -m pytest tests/test_fullsize_gpu.py -m gpu -x -q -k "mx_fp8" > gpurun_out/r03_maxsize_test_fp8.log 2>&1; echo "pytest rc=$?"
+tail -30 gpurun_out/r03_maxsize_test_fp8.log | cut -c1-300
