@@ -333,16 +333,24 @@ def main():
         ex = model.ex
         tmp = torch.empty(ex.S_loc, shape.dim, dtype=torch.bfloat16, device=dev)
         reps = 8
+        def heads_in():      # zero copy (default): the exchange alone -- no relayout pass behind it in the step either
+            if ex.zero_copy:
+                for w_ in ex.start_heads_in():
+                    if w_ is not None:
+                        w_.wait()
+            else:
+                ex.heads_in()
         for _ in range(2):
-            ex.heads_in(); ex.tokens_out(tmp)
+            heads_in(); ex.tokens_out(tmp)
         torch.cuda.synchronize(); barrier()
         e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         t_in = t_out = 0.0
         for _ in range(reps):
-            e[0].record(); ex.heads_in(); e[1].record(); ex.tokens_out(tmp); e[2].record()
+            e[0].record(); heads_in(); e[1].record(); ex.tokens_out(tmp); e[2].record()
             torch.cuda.synchronize()
             t_in += e[0].elapsed_time(e[1]); t_out += e[1].elapsed_time(e[2])
-        exchange = {"qkv_all_to_all_plus_unpack_ms": t_in / reps, "out_all_to_all_plus_unpack_ms": t_out / reps,
+        exchange = {"qkv_exchange": "zero copy: attention reads the receive buffer (utx_attn_fwd_bf16_blk)" if ex.zero_copy else "all-to-all + relayout pass",
+                    "qkv_all_to_all_plus_unpack_ms": t_in / reps, "out_all_to_all_plus_unpack_ms": t_out / reps,
                     "bytes_per_rank_per_layer": ex.bytes_per_layer, "layers": N_DOUBLE + N_SINGLE, "head_groups": ex.G,
                     "note": "measured back to back without compute; in the step the Q/K/V exchange of the 38 single blocks runs beside the MLP half of the projection GEMM"}
     bp = None

@@ -96,6 +96,15 @@ int utx_attn_fwd_bf16_ws(utx_ctx* ctx, const void* q, const void* k, const void*
                          void* work, size_t work_bytes, utx_stream stream);
 size_t utx_attn_workspace_bytes(utx_ctx* ctx, int H, int S_q, int S_kv);
 int utx_attn_plan(int H, int S_q, int S_kv, int n_cus, int out[4]);
+/* The same on BLOCK-STRIDED operands: the S_kv tokens (queries and keys alike) come in blocks of blk_rows (a multiple of 64 that divides S_kv); block b of Q / K /
+ * V^T of a head starts q_bs / k_bs / vt_bs elements (multiples of 8) behind block b - 1, rows inside a block are q_ss / k_ss apart, V^T rows vt_ds (each holding the
+ * blk_rows columns of its block).  This is the receive buffer of the sequence-parallel Q / K / V all-to-all, [source rank][q | k | v][head][S_loc x 128]
+ * (unitex_amd/flux/ulysses.py), consumed where RCCL put it instead of behind a relayout pass; the output rows stay in token order (block-major), o_ss apart.
+ * Same tiles in the same order as the contiguous call: bit-identical results.  Replaces nothing in the reference (it is single-GPU); beyond it, SURVEY 8e. */
+int utx_attn_fwd_bf16_blk(utx_ctx* ctx, const void* q, const void* k, const void* vt, void* o,
+                          long q_hs, long q_ss, long k_hs, long k_ss, long vt_hs, long vt_ds, long o_ss,
+                          int H, int S_q, int S_kv, float softmax_scale, float key_bias_log2, int key_bias_period,
+                          void* work, size_t work_bytes, int blk_rows, long q_bs, long k_bs, long vt_bs, utx_stream stream);
 
 /* C = epi(alpha * (A B^T + A2 B2^T) + bias): bf16 GEMM, fp32 accumulate, fused epilogues.
  * Replaces every nn.Linear (+ peft LoRA branch, + GELU, + gated residual) inside the FLUX blocks

@@ -448,6 +448,49 @@ def test_sequence_parallel_plan_world1_matches_plain_forward():
             dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("P,H,S_loc,kb", [(2, 2, 192, False), (4, 3, 128, True), (4, 6, 3136, True), (8, 3, 6336, True)])
+def test_attention_on_block_strided_operands_equals_the_contiguous_call(P, H, S_loc, kb):
+    """utx_attn_fwd_bf16_blk: Q / K / V^T consumed from the sequence-parallel receive buffer [source rank][q | k | v][head][S_loc x 128] (ulysses.py) -- blocks
+    of S_loc tokens, 3 H S_loc 128 elements apart -- must give the bits of the contiguous call on the head-major tensors: same tiles, same order.  Cases with
+    the key-split tail round (6 heads x 12 544 tokens = 294 workgroups; 3 heads x 50 688 = 594: the 8-rank launch of the real model) and with the key
+    multiplicity of the per-rank text tile (period = S_loc / 64 tiles)."""
+    import ctypes as C
+    from unitex_amd.flux import ops
+    ctx = ops.get_ctx(0)
+    lib = ctx.lib
+    S, E = P * S_loc, S_loc * 128
+    g = torch.Generator(device="cuda").manual_seed(P * 1000 + H)
+    q = (torch.randn(H, S, 128, device="cuda", generator=g) * 0.1275).to(BF)
+    k = torch.randn(H, S, 128, device="cuda", generator=g).to(BF)
+    v = torch.randn(H, S, 128, device="cuda", generator=g).to(BF)
+    vt = v.transpose(1, 2).contiguous()
+    kbl, per = (2.0, S_loc // 64) if kb else (0.0, 0)
+    ref = ops.attention(q, k, vt, S=S, scale=0.0, key_bias_log2=kbl, key_bias_period=per)
+    buf = torch.empty(P, 3, H, E, dtype=BF, device="cuda")
+    buf[:, 0] = q.view(H, P, E).transpose(0, 1)
+    buf[:, 1] = k.view(H, P, E).transpose(0, 1)
+    buf[:, 2] = vt.view(H, 128, P, S_loc).permute(2, 0, 1, 3).reshape(P, H, E)
+    out = torch.empty(S, H * 128, dtype=BF, device="cuda")
+    nbytes = int(lib.utx_attn_workspace_bytes(ctx.handle, H, S, S))
+    work = torch.empty(max(nbytes, 16), dtype=torch.uint8, device="cuda")
+    bs = 3 * H * E
+    rc = lib.utx_attn_fwd_bf16_blk(ctx.handle, C.c_void_p(buf[0, 0].data_ptr()), C.c_void_p(buf[0, 1].data_ptr()), C.c_void_p(buf[0, 2].data_ptr()),
+                                   C.c_void_p(out.data_ptr()), E, 128, E, 128, E, S_loc, out.stride(0), H, S, S, 0.0, kbl, per,
+                                   C.c_void_p(work.data_ptr()), nbytes, S_loc, bs, bs, bs, ctx.stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    plan = (C.c_int * 4)()
+    assert lib.utx_attn_plan(H, S, S, torch.cuda.get_device_properties(0).multi_processor_count, plan) == 0
+    if H * ((S + 255) // 256) > 256:
+        assert plan[2] > 1 and nbytes > 0, "this case is meant to run the key-split tail round"
+    assert torch.equal(out.view(torch.int16), ref.view(torch.int16)), "block-strided attention differs from the contiguous call"
+    # refusals: a block that is not whole 64-key tiles, a sequence that is not whole blocks
+    for bad_rows in (S_loc + 32, S_loc * P + 64):
+        assert lib.utx_attn_fwd_bf16_blk(ctx.handle, C.c_void_p(buf[0, 0].data_ptr()), C.c_void_p(buf[0, 1].data_ptr()), C.c_void_p(buf[0, 2].data_ptr()),
+                                         C.c_void_p(out.data_ptr()), E, 128, E, 128, E, S_loc, out.stride(0), H, S, S, 0.0, 0.0, 0,
+                                         None, 0, bad_rows, bs, bs, bs, ctx.stream()) != 0
+
+
 def test_sequence_parallel_world1_through_rccl_collectives(monkeypatch):
     """RCCL on a one-GPU box: with UTX_SP_FORCE_A2A=1 a 1-rank NCCL group still issues every collective of the sequence-parallel plan -- per layer and
     head group an asynchronous all_to_all_single to itself on ProcessGroupNCCL's stream, work.wait() on the compute stream, then the HIP unpack / attention
@@ -500,6 +543,9 @@ def _sp_worker(rank, world, port, q, zero_text=False, groups=1):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    if groups < 0:      # negative: the relayout form of the exchange (UTX_SP_ZERO_COPY=0) instead of the default zero-copy attention operands
+        os.environ["UTX_SP_ZERO_COPY"] = "0"
+        groups = -groups
     os.environ["UTX_SP_GROUPS"] = str(groups)      # head groups per rank whose exchanges are pipelined with attention (ulysses.pick_head_groups)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import dit_ref as R
@@ -520,6 +566,7 @@ def _sp_worker(rank, world, port, q, zero_text=False, groups=1):
     m.set_conditioning(enc, pooled, 3.5)
     assert (m.text_rows == 64 and m.key_bias_period == (64 + 192) // 64 and abs(m.key_bias_log2 - 2.0) < 1e-6) if zero_text else (m.text_rows is None)
     assert m.ex.G == groups and m.ex.Hg * groups * world == 4 and m.overlap_text      # two streams in the double blocks under sequence parallelism as well
+    assert m.ex.zero_copy == (os.environ.get("UTX_SP_ZERO_COPY", "1") != "0")
     i0, i1 = m.local_image_range(S_img)
     out_loc = m.forward(lat[i0:i1].contiguous(), 0.5).float().cpu()
     torch.cuda.synchronize()
@@ -537,7 +584,7 @@ def _sp_worker(rank, world, port, q, zero_text=False, groups=1):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,zero_text,groups", [(2, False, 1), (2, True, 1), (2, False, 2), (2, True, 2), (4, True, 1), (4, False, 1)])
+@pytest.mark.parametrize("world,zero_text,groups", [(2, False, 1), (2, True, 1), (2, False, 2), (2, True, 2), (4, True, 1), (4, False, 1), (2, True, -2)])
 def test_sequence_parallel_two_ranks_match_unsharded_forward(world, zero_text, groups):
     """two processes share cuda:0 and exchange through gloo (host-staged all-to-all): the token-sharded /
     head-sharded FluxDiT plan -- real kernels, real slicing of ids / embeddings / latents -- against the plain forward.

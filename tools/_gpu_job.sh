@@ -1,4 +1,4 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 500 python tools/run_full_pipeline.py > gpurun_out/r03_full_pipeline_e2e_final.log 2>&1; echo "rc=$?"
-grep -n "sec_per_mesh\|>>> infer_mv\|peak mem" gpurun_out/r03_full_pipeline_e2e_final.log | tail -8
+timeout 900 python -m pytest tests/test_dit_ops_gpu.py tests/test_fullsize_gpu.py -m gpu -x -q -k "attention or sequence_parallel" > gpurun_out/r03_zero_copy_tests.log 2>&1; echo "pytest rc=$?"
+tail -25 gpurun_out/r03_zero_copy_tests.log | cut -c1-250

@@ -423,7 +423,16 @@ extern "C" int utx_launch_attn_fwd(const void* q, const void* k, const void* vt,
                                    long q_hs, long q_ss, long k_hs, long k_ss, long vt_hs, long vt_ds,
                                    long o_ss, int H, int S, int Sq, float scale, float key_bias_log2, int key_bias_period, void* work, size_t work_bytes,
                                    hipStream_t stream) {
-    if (S <= 0 || H <= 0 || scale < 0.f || key_bias_period < 0 || Sq < 0 || Sq > S) return -1;
+    return utx_launch_attn_fwd_blk(q, k, vt, o, q_hs, q_ss, k_hs, k_ss, vt_hs, vt_ds, o_ss, H, S, Sq, scale, key_bias_log2, key_bias_period, work, work_bytes,
+                                   0, 0, 0, 0, stream);
+}
+
+// blk_rows > 0: Q / K / V^T in blocks of blk_rows tokens q_bs / k_bs / vt_bs elements apart (attention_glds.hip BLK; the default kernel only)
+extern "C" int utx_launch_attn_fwd_blk(const void* q, const void* k, const void* vt, void* o,
+                                       long q_hs, long q_ss, long k_hs, long k_ss, long vt_hs, long vt_ds,
+                                       long o_ss, int H, int S, int Sq, float scale, float key_bias_log2, int key_bias_period, void* work, size_t work_bytes,
+                                       int blk_rows, long q_bs, long k_bs, long vt_bs, hipStream_t stream) {
+    if (S <= 0 || H <= 0 || scale < 0.f || key_bias_period < 0 || Sq < 0 || Sq > S || blk_rows < 0) return -1;
     if (Sq == S) Sq = 0;
     if ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)vt)) & 15) return -2;                       // 16-byte aligned bases (LDS-DMA / b128 loads)
     if ((vt_ds & 7) || (q_ss & 7) || (k_ss & 7) || (o_ss & 3) || (q_hs & 7) || (k_hs & 7) || (vt_hs & 7)) return -2;   // 16-byte rows
@@ -437,6 +446,8 @@ extern "C" int utx_launch_attn_fwd(const void* q, const void* k, const void* vt,
     p.flags = nullptr; p.flag_hs = 0;
     p.key_bias_log2 = key_bias_log2; p.key_bias_period = key_bias_period;
     p.work = work; p.work_bytes = work_bytes;
+    p.blk_rows = blk_rows; p.q_bs = q_bs; p.k_bs = k_bs; p.vt_bs = vt_bs;
+    if (blk_rows > 0 && (g_utx_opt.attn_glds == 0 || g_utx_opt.attn_q64 == 1 || g_utx_opt.attn_tpb != 1)) return -2;
     // key multiplicity and a query count below the key count exist in the default (LDS-DMA staged) kernel only
     if ((key_bias_log2 != 0.f || Sq != 0) && (g_utx_opt.attn_glds == 0 || g_utx_opt.attn_q64 == 1 || g_utx_opt.attn_tpb != 1)) return -2;
     // opt-in: the 4 x 64 kernel (attention_q64.hip) followed by its repair pass; it needs whole 64-key tiles

@@ -17,6 +17,7 @@
 #include "common.h"
 #include "kernels.h"
 #include <stdlib.h>
+#include <type_traits>
 
 #define AG_KVB 64
 #define AG_KTILE 16384
@@ -41,7 +42,12 @@ __device__ __forceinline__ void ag_glds16(const bf16_t* g, char* lds) {
         acc_[4] = hi_[0]; acc_[5] = hi_[1]; acc_[6] = hi_[2]; acc_[7] = hi_[3];                              \
     } else acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b_, c_, 0, 0, 0);
 
-template <int PRESC, int TPB, int VAR>
+// BLK: Q rows, K rows and V^T columns arrive in BLOCKS of p.blk_rows tokens (a multiple of the 64-key tile) that lie p.q_bs / p.k_bs / p.vt_bs elements apart --
+// the receive buffer of the sequence-parallel Q / K / V exchange, [source rank][q | k | v][head][S_loc * 128] (flux/ulysses.py), read where the all-to-all put it
+// instead of behind a relayout pass.  Token j = block j / blk_rows, row j % blk_rows; inside a block rows are q_ss / k_ss apart and V^T rows vt_ds (= blk_rows for
+// the exchange buffer).  The staging cursor below walks tiles in order, so the block term is two scalar adds per tile; same tiles, same order, same arithmetic
+// as the contiguous form: bit-identical results.
+template <int PRESC, int TPB, int VAR, bool BLK = false>
 __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const kring = smem;
@@ -70,15 +76,21 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
         for (int g = 0; g < 4; ++g) any |= (qb * 4 + g < p.flag_hs) ? f[g] : 0;
         if (!any) return;
     }
-    const bf16_t* kbase = p.k + (long)head * p.k_hs + (long)tb * AG_KVB * p.k_ss;
-    const bf16_t* vbase = p.vt + (long)head * p.vt_hs + tb * AG_KVB;
+    const int tpblk = BLK ? p.blk_rows / AG_KVB : 0;          // 64-key tiles per block
+    const int blk0 = BLK ? tb / tpblk : 0, loc0 = BLK ? tb - blk0 * tpblk : 0;
+    const bf16_t* kbase = BLK ? p.k + (long)head * p.k_hs + (long)blk0 * p.k_bs + (long)loc0 * AG_KVB * p.k_ss
+                              : p.k + (long)head * p.k_hs + (long)tb * AG_KVB * p.k_ss;
+    const bf16_t* vbase = BLK ? p.vt + (long)head * p.vt_hs + (long)blk0 * p.vt_bs + loc0 * AG_KVB
+                              : p.vt + (long)head * p.vt_hs + tb * AG_KVB;
 
     const int q0 = qb * 256 + wave * 32;
     bf16x8 qf[8];
     {
         int qrow = q0 + lq;
         if (qrow > Sq - 1) qrow = Sq - 1;
-        const bf16_t* qp = p.q + (long)head * p.q_hs + (long)qrow * p.q_ss + lh * 8;
+        const int qblk = BLK ? qrow / p.blk_rows : 0;
+        const bf16_t* qp = BLK ? p.q + (long)head * p.q_hs + (long)qblk * p.q_bs + (long)(qrow - qblk * p.blk_rows) * p.q_ss + lh * 8
+                               : p.q + (long)head * p.q_hs + (long)qrow * p.q_ss + lh * 8;
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(qp + kk * 16);
     }
@@ -94,14 +106,22 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
     const bf16_t* vsrc0 = vbase + (long)vr0 * p.vt_ds + (((ks0 & 7) ^ ((vr0 >> 1) & 7)) << 3);
     const bf16_t* vsrc1 = vbase + (long)vr1 * p.vt_ds + (((ks1 & 7) ^ ((vr1 >> 1) & 7)) << 3);
     const int dma_off = (2 * wave) * 1024;
+    // BLK: the staging cursor (tiles are requested strictly in order, once each): element offsets of the next tile from kbase / vbase, wave-uniform
+    typedef typename std::conditional<BLK, long, int>::type ag_vadv_t;      // (the contiguous form keeps its 32-bit V^T column offset)
+    long st_k = 0, st_v = 0;
+    int st_loc = loc0;
 #define AG_STAGE(t_, slot_)                                                                      \
     do {                                                                                         \
-        const long kadv_ = (long)(t_) * AG_KVB * p.k_ss;                                         \
-        const int vadv_ = (t_) * AG_KVB;                                                         \
+        const long kadv_ = BLK ? st_k : (long)(t_) * AG_KVB * p.k_ss;                            \
+        const ag_vadv_t vadv_ = BLK ? (ag_vadv_t)st_v : (ag_vadv_t)((t_) * AG_KVB);              \
         ag_glds16(ksrc0 + kadv_, kring + (slot_) * AG_KTILE + dma_off);                          \
         ag_glds16(ksrc1 + kadv_, kring + (slot_) * AG_KTILE + dma_off + 1024);                   \
         ag_glds16(vsrc0 + vadv_, vring + (slot_) * AG_VTILE + dma_off);                          \
         ag_glds16(vsrc1 + vadv_, vring + (slot_) * AG_VTILE + dma_off + 1024);                   \
+        if (BLK) {                                                                               \
+            st_k += (long)AG_KVB * p.k_ss; st_v += AG_KVB;                                       \
+            if (++st_loc == tpblk) { st_loc = 0; st_k += p.k_bs - (long)p.blk_rows * p.k_ss; st_v += p.vt_bs - p.blk_rows; } \
+        }                                                                                        \
     } while (0)
 
     // ---- fragment read offsets.  kappa: MFMA row i = 8a + 4h' + c -> key 16(a>>1) + 8h' + 4(a&1) + c (attention.hip)
@@ -396,10 +416,10 @@ extern "C" size_t utx_attn_workspace_bytes_impl(int H, int Sq, int S, int ncu) {
     return rows * 128 * sizeof(bf16_t) + rows * sizeof(float);
 }
 
-template <int PRESC, int TPB, int VAR = 0>
+template <int PRESC, int TPB, int VAR = 0, bool BLK = false>
 static int launch_glds(AttnParams p, hipStream_t stream) {
     UTX_ONCE_PER_DEVICE(attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_glds_kernel<PRESC, TPB, VAR>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_glds_kernel<PRESC, TPB, VAR, BLK>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, AG_LDS(TPB)) != hipSuccess) return -3;
         UTX_ONCE_DONE(attr_set);
     }
@@ -413,14 +433,14 @@ static int launch_glds(AttnParams p, hipStream_t stream) {
     // tail rows, a fraction of a round slower
     const size_t rows = (size_t)r * ns * 256;
     if (ns <= 1 || !p.work || p.work_bytes < rows * (128 * sizeof(bf16_t) + sizeof(float))) {
-        hipLaunchKernelGGL((attn_fwd_glds_kernel<PRESC, TPB, VAR>), dim3(nwg), dim3(512), AG_LDS(TPB), stream, p);
+        hipLaunchKernelGGL((attn_fwd_glds_kernel<PRESC, TPB, VAR, BLK>), dim3(nwg), dim3(512), AG_LDS(TPB), stream, p);
         return hipGetLastError() == hipSuccess ? 0 : -4;
     }
-    hipLaunchKernelGGL((attn_fwd_glds_kernel<PRESC, TPB, VAR>), dim3(nfull), dim3(512), AG_LDS(TPB), stream, p);
+    hipLaunchKernelGGL((attn_fwd_glds_kernel<PRESC, TPB, VAR, BLK>), dim3(nfull), dim3(512), AG_LDS(TPB), stream, p);
     AttnParams t = p;
     t.w_base = nfull; t.nsplit = ns; t.tiles_per_split = tps;
     t.part_o = (bf16_t*)p.work; t.part_lse = (float*)((char*)p.work + rows * 128 * sizeof(bf16_t));
-    hipLaunchKernelGGL((attn_fwd_glds_kernel<PRESC, TPB, VAR>), dim3(r * ns), dim3(512), AG_LDS(TPB), stream, t);
+    hipLaunchKernelGGL((attn_fwd_glds_kernel<PRESC, TPB, VAR, BLK>), dim3(r * ns), dim3(512), AG_LDS(TPB), stream, t);
     const long mt = (long)r * 256 * 16;
     hipLaunchKernelGGL(attn_merge_kernel, dim3((unsigned)((mt + 255) / 256)), dim3(256), 0, stream, t, r);
     return hipGetLastError() == hipSuccess ? 0 : -4;
@@ -429,6 +449,10 @@ static int launch_glds(AttnParams p, hipStream_t stream) {
 // UTX_ATTN_TPB: tiles per barrier (ring = 2 groups of TPB tiles): 1 -> 64 KB LDS, 2 -> 128 KB
 extern "C" int utx_launch_attn_fwd_glds(const AttnParams* p, int presc, hipStream_t stream) {
     const int tpb = g_utx_opt.attn_tpb;
+    if (p->blk_rows > 0) {      // block-strided operands (the sequence-parallel receive buffer): whole 64-key tiles per block, whole blocks per sequence
+        if (tpb != 1 || p->flags || (p->blk_rows % AG_KVB) || (p->S % p->blk_rows) || ((p->q_bs | p->k_bs | p->vt_bs) & 7)) return -2;
+        return presc ? launch_glds<1, 1, 0, true>(*p, stream) : launch_glds<0, 1, 0, true>(*p, stream);
+    }
     if (tpb == 2) return presc ? launch_glds<1, 2>(*p, stream) : launch_glds<0, 2>(*p, stream);
 #ifdef UTX_ABLATION
     { const int var = g_utx_opt.attn_var_abl;   // timing A/B only: 1 = no s_setprio, 2 = no interleave hints, 3 = half the fragment reads (WRONG results), 4 = row sums with v_pk_add_f32

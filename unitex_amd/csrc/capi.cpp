@@ -176,6 +176,16 @@ int utx_attn_fwd_bf16_ws(utx_ctx* ctx, const void* q, const void* k, const void*
                                  softmax_scale, key_bias_log2, key_bias_period, work, work_bytes, (hipStream_t)stream));
 }
 
+int utx_attn_fwd_bf16_blk(utx_ctx* ctx, const void* q, const void* k, const void* vt, void* o,
+                          long q_hs, long q_ss, long k_hs, long k_ss, long vt_hs, long vt_ds, long o_ss,
+                          int H, int S_q, int S_kv, float softmax_scale, float key_bias_log2, int key_bias_period,
+                          void* work, size_t work_bytes, int blk_rows, long q_bs, long k_bs, long vt_bs, utx_stream stream) {
+    if (!q || !k || !vt || !o || blk_rows <= 0) return fail(ctx, -2, "utx_attn_fwd_bf16_blk");
+    UTX_CALL(ctx, "utx_attn_fwd_bf16_blk",
+             utx_launch_attn_fwd_blk(q, k, vt, o, q_hs, q_ss, k_hs, k_ss, vt_hs, vt_ds, o_ss, H, S_kv, S_q,
+                                     softmax_scale, key_bias_log2, key_bias_period, work, work_bytes, blk_rows, q_bs, k_bs, vt_bs, (hipStream_t)stream));
+}
+
 size_t utx_attn_workspace_bytes(utx_ctx* ctx, int H, int S_q, int S_kv) {
     (void)ctx;
     if (H <= 0 || S_kv <= 0 || S_q <= 0 || S_q > S_kv) return 0;

@@ -33,6 +33,9 @@ struct AttnParams {
     // caller-owned scratch of the tail split (utx_attn_workspace_bytes); null / too small: the launch stays unsplit
     void* work;
     size_t work_bytes;
+    // block-strided operands (attention_glds.hip, BLK): tokens in blocks of blk_rows (0 = contiguous) lying q_bs / k_bs / vt_bs elements apart
+    int blk_rows;
+    long q_bs, k_bs, vt_bs;
 };
 // Launch options.  Every field is result-preserving (kernel selection / scheduling A/B): read ONCE from the environment by
 // the first utx_init (UTX_ATTN_*, UTX_GEMM_* variables of the same names), afterwards changed only through utx_set_option.
@@ -69,6 +72,9 @@ int utx_launch_attn_fwd(const void* q, const void* k, const void* vt, void* o,
 void utx_attn_split_plan_impl(int H, int Sq, int S, int ncu, int out[4]);     // attention_glds.hip (pure): {workgroups, in full rounds, key ranges per tail workgroup, tiles per range}
 size_t utx_attn_workspace_bytes_impl(int H, int Sq, int S, int ncu);
 int utx_launch_attn_fwd_glds(const AttnParams* p, int presc, hipStream_t stream);
+int utx_launch_attn_fwd_blk(const void* q, const void* k, const void* vt, void* o, long q_hs, long q_ss, long k_hs, long k_ss, long vt_hs, long vt_ds,
+                            long o_ss, int H, int S, int Sq, float scale, float key_bias_log2, int key_bias_period, void* work, size_t work_bytes,
+                            int blk_rows, long q_bs, long k_bs, long vt_bs, hipStream_t stream);
 int utx_launch_attn_fwd_q64(const AttnParams* p, int presc, hipStream_t stream);
 int utx_launch_gemm_bf16(const GemmParams* p, hipStream_t stream);
 size_t utx_gemm_streamk_workspace_bytes_impl(void);

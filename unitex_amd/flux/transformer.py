@@ -873,15 +873,23 @@ class FluxDiT:
                 wk = self._attn_work(ws, ex.Hg, ex.S, ex.S)
                 back = []
                 for g in range(ex.G):
-                    q, k, vt = ex.finish_heads_in_group(g, None if works is None else works[g])
+                    hd = ex.finish_heads_in_group(g, None if works is None else works[g])
                     og = ex.o[g]
                     if ev is not None:
                         a = torch.cuda.Event(enable_timing=True)
                         b = torch.cuda.Event(enable_timing=True)
                         a.record()
-                    rc = lib.utx_attn_fwd_bf16_ws(h, ptr(q), ptr(k), ptr(vt), ptr(og), q.stride(0), q.stride(1), k.stride(0), k.stride(1),
-                                                  vt.stride(0), vt.stride(1), og.stride(0), ex.Hg, ex.S, ex.S, 0.0, float(self.key_bias_log2),
-                                                  int(self.key_bias_period), ptr(wk), 0 if wk is None else wk.numel(), st)
+                    if hd is None:
+                        # zero copy: Q / K / V^T read from the receive buffer of the all-to-all, one block of S_loc tokens per source rank (utx_attn_fwd_bf16_blk)
+                        qp, kp, vp, hs, bs, rows = ex.heads_blocks(g)
+                        rc = lib.utx_attn_fwd_bf16_blk(h, C.c_void_p(qp), C.c_void_p(kp), C.c_void_p(vp), ptr(og), hs, 128, hs, 128, hs, rows, og.stride(0),
+                                                       ex.Hg, ex.S, ex.S, 0.0, float(self.key_bias_log2), int(self.key_bias_period), ptr(wk),
+                                                       0 if wk is None else wk.numel(), rows, bs, bs, bs, st)
+                    else:
+                        q, k, vt = hd
+                        rc = lib.utx_attn_fwd_bf16_ws(h, ptr(q), ptr(k), ptr(vt), ptr(og), q.stride(0), q.stride(1), k.stride(0), k.stride(1),
+                                                      vt.stride(0), vt.stride(1), og.stride(0), ex.Hg, ex.S, ex.S, 0.0, float(self.key_bias_log2),
+                                                      int(self.key_bias_period), ptr(wk), 0 if wk is None else wk.numel(), st)
                     if ev is not None:
                         b.record()
                         ev.append((a, b))

@@ -97,15 +97,33 @@ class UlyssesExchange:
         z = lambda *s: torch.zeros(*s, dtype=dtype, device=device)
         self.send = z(G, P, 3, Hg, self.E)            # [head group][dest rank][q|k|v][head of the group][S_loc*128]
         self.recv = z(G, P, 3, Hg, self.E) if (P > 1 or self.force) else self.send
-        self.q = z(self.Hp, self.S, 128)              # heads of group g = rows [g*Hg, (g+1)*Hg)
-        self.k = z(self.Hp, self.S, 128)
-        self.vt = z(self.Hp, 128, self.S)
+        # zero copy (GPU, default; UTX_SP_ZERO_COPY=0 restores the relayout pass): the attention kernel reads Q / K / V^T where the all-to-all put them --
+        # blocks of S_loc tokens per source rank, 3 Hg E elements apart (utx_attn_fwd_bf16_blk) -- so the head-major copies below are never filled
+        self.zero_copy = bool(self.on_gpu and os.environ.get("UTX_SP_ZERO_COPY", "1") != "0")
+        self._z = z
+        self._qkv = None                              # head-major copies (relayout form / CPU): allocated on first use
         self.o = z(G, self.S, Hg * 128)               # attention output of group g = [P][S_loc][Hg*128]: the send buffer of its exchange 2
         self.o_recv = z(G, P, S_loc, Hg * 128) if (P > 1 or self.force) else self.o.view(G, P, S_loc, Hg * 128)
         # utx_qkv_post's two-level grouped head addressing into `send`: head h -> dest h // Hp, group (h % Hp) // Hg, head h % Hg
         self.dest_stride = 3 * Hg * self.E            # elements between the blocks of two destination ranks (inside a head group)
         self.group_stride = P * 3 * Hg * self.E       # elements between two head groups
         self.bytes_per_layer = 4 * S_loc * H * 128 * self.send.element_size()
+
+    def _heads(self):
+        if self._qkv is None:
+            z = self._z
+            self._qkv = (z(self.Hp, self.S, 128), z(self.Hp, self.S, 128), z(self.Hp, 128, self.S))     # heads of group g = rows [g*Hg, (g+1)*Hg)
+        return self._qkv
+
+    q = property(lambda self: self._heads()[0])
+    k = property(lambda self: self._heads()[1])
+    vt = property(lambda self: self._heads()[2])
+
+    def heads_blocks(self, g):
+        """zero-copy form of group g's Q / K / V^T for utx_attn_fwd_bf16_blk: (q, k, vt device pointers of head 0 / source rank 0, head stride, block stride,
+        block rows) -- receive buffer recv[g] = [source rank][q | k | v][head][S_loc * 128]."""
+        r = self.recv[g]
+        return r[0, 0].data_ptr(), r[0, 1].data_ptr(), r[0, 2].data_ptr(), self.E, 3 * self.Hg * self.E, self.S_loc
 
     # ---- send-side views: where utx_qkv_post writes
     def send_base(self, which):
@@ -144,10 +162,13 @@ class UlyssesExchange:
         before finish_heads_in_group run beside them).  Returns the handles for finish_heads_in_group / finish_heads_in."""
         return [self._a2a(self.recv[g], self.send[g], async_op=True) for g in range(self.G)]
 
-    def finish_heads_in_group(self, g, work=None, stream=None):
-        """wait for group g's exchange, then ONE relayout pass: recv[g] [P][3][Hg][E] -> q, k [Hg, S, 128], vt [Hg, 128, S] of the group."""
+    def finish_heads_in_group(self, g, work=None, stream=None, unpack=None):
+        """wait for group g's exchange, then (unless zero copy) ONE relayout pass: recv[g] [P][3][Hg][E] -> q, k [Hg, S, 128], vt [Hg, 128, S] of the group.
+        Zero copy: returns None -- the attention call takes heads_blocks(g)."""
         if work is not None:
             work.wait()                                   # the current stream waits for the collective; the host does not block
+        if (self.zero_copy if unpack is None else not unpack):
+            return None
         P, Hg, S_loc = self.P, self.Hg, self.S_loc
         r = self.recv[g]
         q, k, vt = self.q[g * Hg:(g + 1) * Hg], self.k[g * Hg:(g + 1) * Hg], self.vt[g * Hg:(g + 1) * Hg]
@@ -165,7 +186,7 @@ class UlyssesExchange:
     def finish_heads_in(self, works=None, stream=None):
         """all groups (blocking form): self.q, self.k [Hp, S, 128], self.vt [Hp, 128, S]."""
         for g in range(self.G):
-            self.finish_heads_in_group(g, None if works is None else works[g], stream)
+            self.finish_heads_in_group(g, None if works is None else works[g], stream, unpack=True)
         return self.q, self.k, self.vt
 
     def heads_in(self, Qh=None, Kh=None, Vt=None):
