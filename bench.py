@@ -333,7 +333,7 @@ def main():
         ex = model.ex
         tmp = torch.empty(ex.S_loc, shape.dim, dtype=torch.bfloat16, device=dev)
         reps = 8
-        def heads_in():      # zero copy (default): the exchange alone -- no relayout pass behind it in the step either
+        def heads_in():      # zero copy (UTX_SP_ZERO_COPY=1): the exchange alone -- no relayout pass behind it in the step either
             if ex.zero_copy:
                 for w_ in ex.start_heads_in():
                     if w_ is not None:

@@ -491,7 +491,8 @@ def test_attention_on_block_strided_operands_equals_the_contiguous_call(P, H, S_
                                          None, 0, bad_rows, bs, bs, bs, ctx.stream()) != 0
 
 
-def test_sequence_parallel_world1_through_rccl_collectives(monkeypatch):
+@pytest.mark.parametrize("zero_copy", [False, True])
+def test_sequence_parallel_world1_through_rccl_collectives(monkeypatch, zero_copy):
     """RCCL on a one-GPU box: with UTX_SP_FORCE_A2A=1 a 1-rank NCCL group still issues every collective of the sequence-parallel plan -- per layer and
     head group an asynchronous all_to_all_single to itself on ProcessGroupNCCL's stream, work.wait() on the compute stream, then the HIP unpack / attention
     kernels launched through ctypes on that stream, and the same for the return exchange.  What it pins: the call pattern RCCL accepts (views of the
@@ -501,6 +502,7 @@ def test_sequence_parallel_world1_through_rccl_collectives(monkeypatch):
     import torch.distributed as dist
     from unitex_amd.flux.transformer import FluxDiT, FluxShape
     monkeypatch.setenv("UTX_SP_FORCE_A2A", "1")
+    monkeypatch.setenv("UTX_SP_ZERO_COPY", "1" if zero_copy else "0")      # the relayout pass behind the Q / K / V exchange (default), or attention on the receive buffer
     monkeypatch.setenv("UTX_SP_GROUPS", "2")
     created = False
     if not dist.is_initialized():
@@ -525,6 +527,7 @@ def test_sequence_parallel_world1_through_rccl_collectives(monkeypatch):
             m.set_conditioning(enc, pooled, 3.5)
         ex = spm.ex
         assert ex.force and ex.can_async and ex.G == 2 and ex.recv.data_ptr() != ex.send.data_ptr() and ex.o_recv.data_ptr() != ex.o.data_ptr()
+        assert ex.zero_copy == zero_copy
         for it in range(6):
             lat = torch.randn(S_img, 64, generator=g).to(BF).cuda()
             a = plain.forward(lat, 0.5 - 0.05 * it).clone()
@@ -543,8 +546,8 @@ def _sp_worker(rank, world, port, q, zero_text=False, groups=1):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    if groups < 0:      # negative: the relayout form of the exchange (UTX_SP_ZERO_COPY=0) instead of the default zero-copy attention operands
-        os.environ["UTX_SP_ZERO_COPY"] = "0"
+    if groups < 0:      # negative: the zero-copy form of the exchange (UTX_SP_ZERO_COPY=1: attention reads the receive buffer) instead of the default relayout
+        os.environ["UTX_SP_ZERO_COPY"] = "1"
         groups = -groups
     os.environ["UTX_SP_GROUPS"] = str(groups)      # head groups per rank whose exchanges are pipelined with attention (ulysses.pick_head_groups)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -566,7 +569,7 @@ def _sp_worker(rank, world, port, q, zero_text=False, groups=1):
     m.set_conditioning(enc, pooled, 3.5)
     assert (m.text_rows == 64 and m.key_bias_period == (64 + 192) // 64 and abs(m.key_bias_log2 - 2.0) < 1e-6) if zero_text else (m.text_rows is None)
     assert m.ex.G == groups and m.ex.Hg * groups * world == 4 and m.overlap_text      # two streams in the double blocks under sequence parallelism as well
-    assert m.ex.zero_copy == (os.environ.get("UTX_SP_ZERO_COPY", "1") != "0")
+    assert m.ex.zero_copy == (os.environ.get("UTX_SP_ZERO_COPY", "0") == "1")
     i0, i1 = m.local_image_range(S_img)
     out_loc = m.forward(lat[i0:i1].contiguous(), 0.5).float().cpu()
     torch.cuda.synchronize()
@@ -584,7 +587,7 @@ def _sp_worker(rank, world, port, q, zero_text=False, groups=1):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,zero_text,groups", [(2, False, 1), (2, True, 1), (2, False, 2), (2, True, 2), (4, True, 1), (4, False, 1), (2, True, -2)])
+@pytest.mark.parametrize("world,zero_text,groups", [(2, False, 1), (2, True, 1), (2, False, 2), (2, True, 2), (4, True, 1), (4, False, 1), (2, True, -2), (4, True, -1)])
 def test_sequence_parallel_two_ranks_match_unsharded_forward(world, zero_text, groups):
     """two processes share cuda:0 and exchange through gloo (host-staged all-to-all): the token-sharded /
     head-sharded FluxDiT plan -- real kernels, real slicing of ids / embeddings / latents -- against the plain forward.

@@ -97,9 +97,12 @@ class UlyssesExchange:
         z = lambda *s: torch.zeros(*s, dtype=dtype, device=device)
         self.send = z(G, P, 3, Hg, self.E)            # [head group][dest rank][q|k|v][head of the group][S_loc*128]
         self.recv = z(G, P, 3, Hg, self.E) if (P > 1 or self.force) else self.send
-        # zero copy (GPU, default; UTX_SP_ZERO_COPY=0 restores the relayout pass): the attention kernel reads Q / K / V^T where the all-to-all put them --
-        # blocks of S_loc tokens per source rank, 3 Hg E elements apart (utx_attn_fwd_bf16_blk) -- so the head-major copies below are never filled
-        self.zero_copy = bool(self.on_gpu and os.environ.get("UTX_SP_ZERO_COPY", "1") != "0")
+        # zero copy (GPU, opt-in: UTX_SP_ZERO_COPY=1): the attention kernel reads Q / K / V^T where the all-to-all put them -- blocks of S_loc tokens per
+        # source rank, 3 Hg E elements apart (utx_attn_fwd_bf16_blk) -- and the relayout pass disappears.  Built, bit-identical, and MEASURED A NET LOSS
+        # (profiles/r03_attn_blk_ab.log, r03_bench_sp_self_test_zero_copy / _relayout): attention on the block-strided operands runs 2.1-2.4 % slower at
+        # 2 / 4 / 8 blocks (+0.6 % with one block: the cursor arithmetic; the rest is the V^T rows lying S_loc instead of S columns apart), i.e. +0.16 ms per
+        # layer at 4 ranks against 0.09 ms of relayout saved.  The default keeps the relayout into head-major tensors.
+        self.zero_copy = bool(self.on_gpu and os.environ.get("UTX_SP_ZERO_COPY", "0") == "1")
         self._z = z
         self._qkv = None                              # head-major copies (relayout form / CPU): allocated on first use
         self.o = z(G, self.S, Hg * 128)               # attention output of group g = [P][S_loc][Hg*128]: the send buffer of its exchange 2
