@@ -541,8 +541,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define W4_QK_BLOCK(im_)                                                                                               \
         {                                                                                                              \
             /* rolling window of four pieces of cos / sin (16 registers): piece t + 4 is requested into the registers of piece t as soon as that is done. \
-               Literal waits (full tiles): t < 4: 2 (3 - t) older-window loads + 3 t (store + 2 loads per finished piece) = 6 + t;                   \
-               t = 4 + j: 3 (3 - j) + j = 9 - 2 j */                                                                    \
+               Literal waits (full tiles) count the YOUNGER LOADS ONLY: t < 4: 2 (3 - t) loads of the first window + 2 t refills = 6; t = 4 + j: the refills \
+               of pieces j + 1 .. 3 = 6 - 2 j.  The stores issued in between are left out on purpose: vmcnt retires loads in order among themselves, but a    \
+               store may retire before an older load, so a count that included the younger stores (round 2: 6 + t / 9 - 2 j) could let a piece through     \
+               with its cos / sin still in flight -- seen once as a one-ulp difference of the fused plan in the full-width test (end of round 3) */           \
             w4_f32x4v c0_, s0_, c1_, s1_, c2_, s2_, c3_, s3_;                                                           \
             W4_QK_CS_LOAD(c0_, p.qk_cos, im_, 0); W4_QK_CS_LOAD(s0_, p.qk_sin, im_, 0); W4_QK_CS_LOAD(c1_, p.qk_cos, im_, 1); W4_QK_CS_LOAD(s1_, p.qk_sin, im_, 1); \
             W4_QK_CS_LOAD(c2_, p.qk_cos, im_, 2); W4_QK_CS_LOAD(s2_, p.qk_sin, im_, 2); W4_QK_CS_LOAD(c3_, p.qk_cos, im_, 3); W4_QK_CS_LOAD(s3_, p.qk_sin, im_, 3); \
@@ -550,10 +552,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             W4_EPI_WRITE(im_, false)                                                                                   \
             W4_EPI_READ8()                                                                                             \
             W4_QK_PIECE(im_, 0, y0_, c0_, s0_, 6) W4_QK_CS_LOAD(c0_, p.qk_cos, im_, 4); W4_QK_CS_LOAD(s0_, p.qk_sin, im_, 4); W4_FENCE(); \
-            W4_QK_PIECE(im_, 1, y1_, c1_, s1_, 7) W4_QK_CS_LOAD(c1_, p.qk_cos, im_, 5); W4_QK_CS_LOAD(s1_, p.qk_sin, im_, 5); W4_FENCE(); \
-            W4_QK_PIECE(im_, 2, y2_, c2_, s2_, 8) W4_QK_CS_LOAD(c2_, p.qk_cos, im_, 6); W4_QK_CS_LOAD(s2_, p.qk_sin, im_, 6); W4_FENCE(); \
-            W4_QK_PIECE(im_, 3, y3_, c3_, s3_, 9) W4_QK_CS_LOAD(c3_, p.qk_cos, im_, 7); W4_QK_CS_LOAD(s3_, p.qk_sin, im_, 7); W4_FENCE(); \
-            W4_QK_PIECE(im_, 4, y4_, c0_, s0_, 9) W4_QK_PIECE(im_, 5, y5_, c1_, s1_, 7) W4_QK_PIECE(im_, 6, y6_, c2_, s2_, 5) W4_QK_PIECE(im_, 7, y7_, c3_, s3_, 3) \
+            W4_QK_PIECE(im_, 1, y1_, c1_, s1_, 6) W4_QK_CS_LOAD(c1_, p.qk_cos, im_, 5); W4_QK_CS_LOAD(s1_, p.qk_sin, im_, 5); W4_FENCE(); \
+            W4_QK_PIECE(im_, 2, y2_, c2_, s2_, 6) W4_QK_CS_LOAD(c2_, p.qk_cos, im_, 6); W4_QK_CS_LOAD(s2_, p.qk_sin, im_, 6); W4_FENCE(); \
+            W4_QK_PIECE(im_, 3, y3_, c3_, s3_, 6) W4_QK_CS_LOAD(c3_, p.qk_cos, im_, 7); W4_QK_CS_LOAD(s3_, p.qk_sin, im_, 7); W4_FENCE(); \
+            W4_QK_PIECE(im_, 4, y4_, c0_, s0_, 6) W4_QK_PIECE(im_, 5, y5_, c1_, s1_, 4) W4_QK_PIECE(im_, 6, y6_, c2_, s2_, 2) W4_QK_PIECE(im_, 7, y7_, c3_, s3_, 0) \
         }
     // gated: out = res + bf16(gate * y), the rounding points of gemm.hip
 #define W4_GATE_OUT(Y_, R_, O_)                                                                                        \
