@@ -24,6 +24,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: exactly the functions declared in this header are exported (tests/test_abi.py compares `nm -D` with
+ * this file); its internal launchers are not part of the ABI. */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define UTX_VERSION 100
 
@@ -173,6 +178,11 @@ typedef struct utx_gemm_desc {
 } utx_gemm_desc;
 int utx_gemm_bf16(utx_ctx* ctx, const utx_gemm_desc* d, utx_stream stream);
 size_t utx_gemm_streamk_workspace_bytes(utx_ctx* ctx);   /* size of utx_gemm_desc.sk_work for this device (2 partial tiles per CU) */
+/* What utx_gemm_bf16 would do with this descriptor on a device of n_cus compute units under the current launch options -- the library's own dispatch
+ * arithmetic, no device needed (the host uses it to decide which projections can take the fused q / k epilogue, and bench.py to report the launch census):
+ * out[0] = kernel (0 128x128 tiles, 1 one wave per SIMD, 2 persistent 8-wave, 3 per-tile 8-phase, 4 two-barrier 256^2), out[1] = output tiles of that kernel (128^2 for kernel 0, else 256^2), out[2] = tiles
+ * of the last round that are cut along K (0: unsplit; needs d->sk_work != NULL), out[3] = K ranges per such tile. */
+int utx_gemm_plan(const utx_gemm_desc* d, int n_cus, int out[4]);
 
 /* OCP MX fp8 quantisation of a bf16 matrix along its rows (the activation operand of an mx8 GEMM):
  *   per block of 32 consecutive elements: e = floor(log2(max|x|)) - 8 (clamped to [-127, 127]; -127 for an all-zero block),
@@ -425,6 +435,9 @@ int utx_plan_fork(utx_plan* plan);
 int utx_plan_main(utx_plan* plan);
 int utx_plan_join(utx_plan* plan);
 int utx_plan_run(utx_plan* plan, utx_stream stream, int* failed_entry);
+/* entries [begin, end) only (whole two-stream sections): a host that interleaves its own work with the step -- the sequence-parallel host issues its
+ * all-to-alls between ranges -- replays each range with one call.  A launcher error inside a forked section still joins the side stream before returning. */
+int utx_plan_run_range(utx_plan* plan, int begin, int end, utx_stream stream, int* failed_entry);
 int utx_plan_assign_sk(utx_plan* plan, void* sk_work, size_t sk_work_bytes, int n_cus);   /* split-tail scratch for the caller-stream GEMMs when any has more 256^2 tiles than CUs */
 int utx_plan_entry(const utx_plan* plan, int i, int* kind, int* side, void* buf, size_t cap);   /* read an entry back: kind 0 gemm 1 gemv 2 ln_mod 3 qkv_post 4 attn 5 quant 6 add3 7 fork 8 join */
 
@@ -495,12 +508,17 @@ int utx_dit_step(utx_plan* plan, utx_stream stream, int* failed_entry);
  * Replaces open3d's simplify_quadric_decimation in preprocess_blank_mesh_o3d (uv_atlas.py:155-163; open3d / VTK [3p]) with the published
  * algorithm (Garland & Heckbert 1997): area-weighted face quadrics, boundary edges held by perpendicular constraint planes
  * (boundary_weight, 1.0 in the reference's legacy call), optimal placement, flip rejection.  verts [V][3] f32, faces [F][3] i32 ->
- * verts_out (capacity V), faces_out (capacity F), counts in *V_out / *F_out.  Deterministic. */
+ * verts_out (capacity V), faces_out (capacity F), counts in *V_out / *F_out.  Deterministic.  A collapse is admissible when no surviving face flips, the
+ * edge is not a non-manifold fan and the link condition holds (the common neighbours of its ends are exactly the apexes of its faces).  Returns 0, or 1 when
+ * no admissible collapse was left above target_faces (the output is valid, *F_out > target_faces), negative on invalid arguments. */
 int utx_mesh_decimate_qem(const float* verts, int V, const int* faces, int F, int target_faces, double boundary_weight,
                           float* verts_out, int* faces_out, int* V_out, int* F_out);
 
 int utx_abi_sizes(int* out, int n);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

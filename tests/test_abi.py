@@ -25,6 +25,11 @@ def test_library_loads_and_exports_all_declared_symbols():
         assert hasattr(lib, n), "declared in unitex_hip.h but not exported: %s" % n
         assert n in _lib.SYMBOLS, "declared in unitex_hip.h but not bound in _lib.SYMBOLS: %s" % n
     assert lib.utx_version() == 100
+    # ... and nothing else: the library is built with hidden visibility, its internal launchers (utx_launch_*, *_impl) are not ABI
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted({l.split()[-1] for l in out.splitlines() if " T " in l and l.split()[-1].startswith("utx_")})
+    assert exported == names, "exported but not declared: %s; declared but not exported: %s" % (sorted(set(exported) - set(names)), sorted(set(names) - set(exported)))
 
 
 def test_product_library_has_no_wrong_result_switches():

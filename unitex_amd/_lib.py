@@ -129,6 +129,7 @@ SYMBOLS = {
     "utx_plan_main": (c_int, [c_void_p]),
     "utx_plan_join": (c_int, [c_void_p]),
     "utx_plan_run": (c_int, [c_void_p, c_void_p, C.POINTER(c_int)]),
+    "utx_plan_run_range": (c_int, [c_void_p, c_int, c_int, c_void_p, C.POINTER(c_int)]),
     "utx_plan_assign_sk": (c_int, [c_void_p, c_void_p, C.c_size_t, c_int]),
     "utx_plan_entry": (c_int, [c_void_p, c_int, C.POINTER(c_int), C.POINTER(c_int), c_void_p, C.c_size_t]),
     "utx_dit_load": (c_int, [c_void_p, C.POINTER(DitConfig), C.POINTER(DitWeights), C.POINTER(DitWorkspace), C.POINTER(c_void_p)]),

@@ -42,7 +42,9 @@ for s in GEOM:
     if os.path.exists(os.path.join(HERE, s[0])):
         SOURCES.append(s)
 
-COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + HERE,
+# -fvisibility=hidden: the .so exports exactly what include/unitex_hip.h declares (the header pushes default visibility around its declarations);
+# the utx_launch_* / *_impl launchers the objects share among themselves stay internal
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-I" + HERE,
           "-I" + os.path.normpath(os.path.join(HERE, "..", "..", "include")), "-x", "hip"]
 
 

@@ -6,6 +6,9 @@
 #include <string>
 #include <stdlib.h>
 #include <mutex>
+#include <map>
+#include <vector>
+#include <utility>
 #include "kernels.h"
 #include "common.h"
 
@@ -45,29 +48,34 @@ static void options_from_env_once() {
 struct utx_ctx {
     int device;
     std::string err;
-    // scratch of the attention tail split for the entry points that take no workspace argument: owned by THIS context (not process-static), grown
-    // only outside of a stream capture; callers that want no allocation at all on the launch path use utx_attn_fwd_bf16_ws with their own buffer
-    void* attn_ws = nullptr;
-    size_t attn_ws_cap = 0;
+    // scratch of the attention tail split for the entry points that take no workspace argument: owned by THIS context (not process-static), one buffer PER
+    // STREAM (two streams of a context may run attention side by side) and GROW-ONLY: a buffer that was handed to a launch is never freed before utx_free
+    // -- a replaced (smaller) buffer is parked in `retired`, so nothing that still holds its pointer (a launch in flight, a captured graph) can be left
+    // dangling.  A CAPTURING stream gets no context scratch at all (the launch stays unsplit): a graph must not bake in a pointer whose other users
+    // this library cannot order against the replays.  Callers that want the split under capture, or no allocation on the launch path, pass their own
+    // buffer through utx_attn_fwd_bf16_ws (what FluxDiT does).
+    std::mutex ws_mu;
+    std::map<hipStream_t, std::pair<void*, size_t>> attn_ws;
+    std::vector<void*> retired;
 };
 
-// the context's attention scratch for one launch: grown when too small (hipFree + hipMalloc: a device sync, on growth only, never under capture --
-// a capturing stream gets no scratch and the launch stays unsplit)
 static void* ctx_attn_ws(utx_ctx* ctx, int H, int Sq, int S, hipStream_t stream, size_t* bytes) {
     *bytes = 0;
     if (!ctx) return nullptr;
     const size_t need = utx_attn_workspace_bytes_impl(H, Sq == S ? 0 : Sq, S, utx_ncu());
     if (need == 0) return nullptr;
-    if (ctx->attn_ws_cap < need) {
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
-        if (ctx->attn_ws) (void)hipFree(ctx->attn_ws);
-        ctx->attn_ws = nullptr; ctx->attn_ws_cap = 0;
-        if (hipMalloc(&ctx->attn_ws, need) != hipSuccess) { ctx->attn_ws = nullptr; return nullptr; }
-        ctx->attn_ws_cap = need;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+    std::lock_guard<std::mutex> lock(ctx->ws_mu);
+    std::pair<void*, size_t>& slot = ctx->attn_ws[stream];
+    if (slot.second < need) {
+        void* nb = nullptr;
+        if (hipMalloc(&nb, need) != hipSuccess) { (void)hipGetLastError(); return nullptr; }      // no scratch: the launch stays unsplit
+        if (slot.first) ctx->retired.push_back(slot.first);
+        slot = {nb, need};
     }
-    *bytes = ctx->attn_ws_cap;
-    return ctx->attn_ws;
+    *bytes = slot.second;
+    return slot.first;
 }
 
 static int fail(utx_ctx* ctx, int code, const char* what) {
@@ -130,7 +138,10 @@ int utx_get_option(const char* name, int* value) {
 int utx_is_ablation_build(void) { return kAblationBuild ? 1 : 0; }
 
 void utx_free(utx_ctx* ctx) {
-    if (ctx && ctx->attn_ws) (void)hipFree(ctx->attn_ws);
+    if (ctx) {
+        for (auto& kv : ctx->attn_ws) if (kv.second.first) (void)hipFree(kv.second.first);
+        for (void* p : ctx->retired) (void)hipFree(p);
+    }
     delete ctx;
 }
 

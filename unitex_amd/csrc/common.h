@@ -57,12 +57,21 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 // ---- host side: one-time launch setup is PER DEVICE (hipFuncSetAttribute applies to the current device; CU counts may differ between
 // partitions): call sites keep a bit mask indexed by device instead of a process-wide flag
-static inline int utx_device() { int d = 0; return (hipGetDevice(&d) == hipSuccess && d >= 0 && d < 64) ? d : 0; }
+// Thread-safe (a multi-GPU C host runs one thread per device): the mask and the table are atomics; a lost race only repeats the idempotent set-up.
+// Device ids >= 64 do not alias slot 0: utx_device() returns -1 for them, the set-up then runs on every call and utx_ncu() asks the runtime each time.
+#include <atomic>
+static inline int utx_device() { int d = 0; return (hipGetDevice(&d) == hipSuccess && d >= 0 && d < 64) ? d : -1; }
 static inline int utx_ncu() {
-    static int tab[64] = {};
+    static std::atomic<int> tab[64] = {};
     const int d = utx_device();
-    if (!tab[d]) { hipDeviceProp_t pr; tab[d] = (hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; }
-    return tab[d];
+    int n = d >= 0 ? tab[d].load(std::memory_order_relaxed) : 0;
+    if (!n) {
+        int cur = 0; hipDeviceProp_t pr;
+        n = (hipGetDevice(&cur) == hipSuccess && hipGetDeviceProperties(&pr, cur) == hipSuccess) ? pr.multiProcessorCount : 256;
+        if (d >= 0) tab[d].store(n, std::memory_order_relaxed);
+    }
+    return n;
 }
-#define UTX_ONCE_PER_DEVICE(flag_) static unsigned long long flag_ = 0; const int flag_##_dev = utx_device(); if (!((flag_ >> flag_##_dev) & 1ull))
-#define UTX_ONCE_DONE(flag_) flag_ |= 1ull << flag_##_dev
+#define UTX_ONCE_PER_DEVICE(flag_) static std::atomic<unsigned long long> flag_{0}; const int flag_##_dev = utx_device(); \
+    if (flag_##_dev < 0 || !((flag_.load(std::memory_order_acquire) >> flag_##_dev) & 1ull))
+#define UTX_ONCE_DONE(flag_) do { if (flag_##_dev >= 0) flag_.fetch_or(1ull << flag_##_dev, std::memory_order_release); } while (0)

@@ -49,11 +49,14 @@ __device__ __forceinline__ gp_u32x4 gp_load16_asm(const void* p) {
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(p) : "memory");
     return r;
 }
-// counted wait for one residual load; naming the destination "+v" pins every consumer below the wait
-// (cdna_hip_programming.md 5.7 item 1, form (ii))
+// counted wait for one residual load.  The wait names no register (a tied "+v" operand on the s_waitcnt itself lets the compiler place a copy of the
+// register IN FRONT of the wait, i.e. read the load's destination while it is in flight -- gemm_w4.hip, W4_WAIT_VM); the destination is re-defined by an
+// empty asm behind the wait and a scheduling fence, which pins every consumer below it.  tools/vmcnt_hazard_check.py audits the listing.
 template <int N>
 __device__ __forceinline__ void gp_wait_res(gp_u32x4& a) {
-    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(N) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" : "+v"(a));
     __builtin_amdgcn_sched_barrier(0);
 }
 

@@ -384,7 +384,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     char* const stg = smem + 2 * W4_STAGE + wave * 8192;
     // residual / gate loads hipcc does not see (a visible load would be waited for with vmcnt(0): a drain of the staging pipeline)
 #define W4_LOAD16_ASM(dst_, ptr_) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst_) : "v"(ptr_) : "memory")
-#define W4_WAIT_RES(n_, r_) do { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r_) : "n"(n_) : "memory"); W4_FENCE(); } while (0)
+// Counted waits for registers an asm load fills.  THE WAIT NAMES NO REGISTER: with a tied operand ("+v"(r_) on the s_waitcnt itself) the compiler is free to
+// give the asm's input and output different registers and to put the COPY between them IN FRONT of the asm -- a v_mov that reads the load's destination
+// while the load is still in flight.  It did exactly that in the ragged-tile branch of the fused q / k epilogue (round 3's one-off one-ulp difference:
+// v_mov_b64 of the cos / sin registers ahead of `s_waitcnt vmcnt(0)`, right whenever the tables happened to have landed -- tools/vmcnt_hazard_check.py finds
+// it in the listing).  Here the wait is followed by a scheduling fence and only then by an empty asm that re-defines the registers (W4_LANDED): a copy the
+// compiler makes for that asm sits behind the wait.  tests/test_asm_hazards_cpu.py runs the checker over every kernel of the build.
+#define W4_WAIT_VM(n_) do { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(n_) : "memory"); W4_FENCE(); } while (0)
+#define W4_LANDED(r_) asm volatile("" : "+v"(r_))
+#define W4_LANDED2(r0_, r1_) asm volatile("" : "+v"(r0_), "+v"(r1_))
+#define W4_WAIT_RES(n_, r_) do { W4_WAIT_VM(n_); W4_LANDED(r_); W4_FENCE(); } while (0)
     // gate of this lane's 8 output columns (store layout); fused q / k tiles (QKF): the RMSNorm weight of this wave's head (q or k), eight
     // channels per lane in store layout.  Requested at the START OF THE EPILOGUE by a load hipcc does not see, and older than every residual /
     // cos-sin load behind it: the first counted wait of the epilogue covers it (in-order retirement).  It must not be requested earlier (say at
@@ -508,8 +517,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst_) : "v"(qvo + W4_QK_ROWOFF(im_, t_)), "s"(tab_) : "memory")
 #define W4_QK_PIECE(im_, t_, Y_, CS_, SN_, n_)                                                                         \
         {                                                                                                              \
-            if (full) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(CS_), "+v"(SN_) : "n"(n_) : "memory"); }            \
-            else { asm volatile("s_waitcnt vmcnt(0)" : "+v"(CS_), "+v"(SN_) : : "memory"); }                           \
+            if (full) { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(n_) : "memory"); }                                  \
+            else { asm volatile("s_waitcnt vmcnt(0)" : : : "memory"); }                                                \
+            W4_FENCE();                                                                                                \
+            W4_LANDED2(CS_, SN_);                                                                                      \
+            if ((im_) == 0 && (t_) == 0) W4_LANDED(gq);     /* the norm weight requested by W4_GATE_FETCH is older than every cos / sin load */ \
             W4_FENCE();                                                                                                \
             {                                                                                                          \
             _Pragma("clang fp contract(off)")                                                                          \
@@ -531,9 +543,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 const float r1_ = (a1_ * CS_[c_] + a0_ * SN_[c_]) * qs;                                                \
                 ow_[c_] = pack2bf(r0_, r1_);                                                                           \
             }                                                                                                          \
-            if (full || W4_ROW(im_, t_) < p.M) {                                                                       \
+            if (full || W4_ROW(im_, t_) < p.M) {     /* s_nop 1 inside the store's string: hipcc does not see the store, and a VALU write of its data registers within two wait states of a > 64-bit store corrupts the data */ \
                 w4_u32x4 od_ = {ow_[0], ow_[1], ow_[2], ow_[3]};                                                       \
-                asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"(qvo + qhead + (unsigned)(qsrow0 + 32 * (im_) + 4 * (t_)) * 256u), "v"(od_), "s"(qdst) : "memory"); \
+                asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(qvo + qhead + (unsigned)(qsrow0 + 32 * (im_) + 4 * (t_)) * 256u), "v"(od_), "s"(qdst) : "memory"); \
             }                                                                                                          \
             }                                                                                                          \
             W4_FENCE();                                                                                                \
@@ -541,10 +553,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define W4_QK_BLOCK(im_)                                                                                               \
         {                                                                                                              \
             /* rolling window of four pieces of cos / sin (16 registers): piece t + 4 is requested into the registers of piece t as soon as that is done. \
-               Literal waits (full tiles) count the YOUNGER LOADS ONLY: t < 4: 2 (3 - t) loads of the first window + 2 t refills = 6; t = 4 + j: the refills \
-               of pieces j + 1 .. 3 = 6 - 2 j.  The stores issued in between are left out on purpose: vmcnt retires loads in order among themselves, but a    \
-               store may retire before an older load, so a count that included the younger stores (round 2: 6 + t / 9 - 2 j) could let a piece through     \
-               with its cos / sin still in flight -- seen once as a one-ulp difference of the fused plan in the full-width test (end of round 3) */           \
+               Issue order of a block: L0 L1 L2 L3 (two loads each) | [wait L(t), store S(t), refill R(t + 4) (two loads)] t = 0..3 | [wait R(4 + j), S(4 + j)] \
+               j = 0..3.  Literal waits (full tiles) = the number of YOUNGER vector-memory operations, loads and stores alike -- one counter, in-order      \
+               retirement (tools/vmcnt_order_probe.hip; DESIGN "waits and hazards"): behind L(t) come 2 (3 - t) window loads + t stores + 2 t refills      \
+               = 6 + t; behind R(4 + j) come the refills and stores of pieces j + 1 .. 3 (3 (3 - j)) and the stores S(4) .. S(3 + j) (j) = 9 - 2 j.        \
+               (Round 3 suspected these counts after a one-off one-ulp difference and dropped the stores from them.  The cause was elsewhere: the           \
+               compiler's register copy IN FRONT of the ragged branch's tied-operand wait -- see W4_WAIT_VM.)  */ \
             w4_f32x4v c0_, s0_, c1_, s1_, c2_, s2_, c3_, s3_;                                                           \
             W4_QK_CS_LOAD(c0_, p.qk_cos, im_, 0); W4_QK_CS_LOAD(s0_, p.qk_sin, im_, 0); W4_QK_CS_LOAD(c1_, p.qk_cos, im_, 1); W4_QK_CS_LOAD(s1_, p.qk_sin, im_, 1); \
             W4_QK_CS_LOAD(c2_, p.qk_cos, im_, 2); W4_QK_CS_LOAD(s2_, p.qk_sin, im_, 2); W4_QK_CS_LOAD(c3_, p.qk_cos, im_, 3); W4_QK_CS_LOAD(s3_, p.qk_sin, im_, 3); \
@@ -552,10 +566,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             W4_EPI_WRITE(im_, false)                                                                                   \
             W4_EPI_READ8()                                                                                             \
             W4_QK_PIECE(im_, 0, y0_, c0_, s0_, 6) W4_QK_CS_LOAD(c0_, p.qk_cos, im_, 4); W4_QK_CS_LOAD(s0_, p.qk_sin, im_, 4); W4_FENCE(); \
-            W4_QK_PIECE(im_, 1, y1_, c1_, s1_, 6) W4_QK_CS_LOAD(c1_, p.qk_cos, im_, 5); W4_QK_CS_LOAD(s1_, p.qk_sin, im_, 5); W4_FENCE(); \
-            W4_QK_PIECE(im_, 2, y2_, c2_, s2_, 6) W4_QK_CS_LOAD(c2_, p.qk_cos, im_, 6); W4_QK_CS_LOAD(s2_, p.qk_sin, im_, 6); W4_FENCE(); \
-            W4_QK_PIECE(im_, 3, y3_, c3_, s3_, 6) W4_QK_CS_LOAD(c3_, p.qk_cos, im_, 7); W4_QK_CS_LOAD(s3_, p.qk_sin, im_, 7); W4_FENCE(); \
-            W4_QK_PIECE(im_, 4, y4_, c0_, s0_, 6) W4_QK_PIECE(im_, 5, y5_, c1_, s1_, 4) W4_QK_PIECE(im_, 6, y6_, c2_, s2_, 2) W4_QK_PIECE(im_, 7, y7_, c3_, s3_, 0) \
+            W4_QK_PIECE(im_, 1, y1_, c1_, s1_, 7) W4_QK_CS_LOAD(c1_, p.qk_cos, im_, 5); W4_QK_CS_LOAD(s1_, p.qk_sin, im_, 5); W4_FENCE(); \
+            W4_QK_PIECE(im_, 2, y2_, c2_, s2_, 8) W4_QK_CS_LOAD(c2_, p.qk_cos, im_, 6); W4_QK_CS_LOAD(s2_, p.qk_sin, im_, 6); W4_FENCE(); \
+            W4_QK_PIECE(im_, 3, y3_, c3_, s3_, 9) W4_QK_CS_LOAD(c3_, p.qk_cos, im_, 7); W4_QK_CS_LOAD(s3_, p.qk_sin, im_, 7); W4_FENCE(); \
+            W4_QK_PIECE(im_, 4, y4_, c0_, s0_, 9) W4_QK_PIECE(im_, 5, y5_, c1_, s1_, 7) W4_QK_PIECE(im_, 6, y6_, c2_, s2_, 5) W4_QK_PIECE(im_, 7, y7_, c3_, s3_, 3) \
         }
     // gated: out = res + bf16(gate * y), the rounding points of gemm.hip
 #define W4_GATE_OUT(Y_, R_, O_)                                                                                        \
@@ -578,6 +592,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define W4_GATE_PIECE(im_, t_, Y_, R_, n_, next_)                                                                      \
         {                                                                                                              \
             W4_WAIT_RES(n_, R_);                                                                                       \
+            if ((im_) == 0 && (t_) == 0) { W4_LANDED(gq); W4_FENCE(); }     /* the gate vector (W4_GATE_FETCH) is older than every residual load */ \
             uint4 o_;                                                                                                  \
             W4_GATE_OUT(Y_, R_, o_)                                                                                    \
             W4_STORE_U(im_, t_, o_)                                                                                    \
@@ -600,6 +615,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             w4_u32x4 r_;                                                                                               \
             W4_LOAD16_ASM(r_, pres + (long)(W4_ROW(im_, t_) > p.M - 1 ? p.M - 1 : W4_ROW(im_, t_)) * p.ldres + gcol);  \
             W4_WAIT_RES(0, r_);                                                                                        \
+            if ((im_) == 0 && (t_) == 0) { W4_LANDED(gq); W4_FENCE(); }                                                \
             uint4 o_;                                                                                                  \
             W4_GATE_OUT(Y_, r_, o_)                                                                                    \
             W4_STORE_M(im_, t_, o_)                                                                                    \
@@ -712,14 +728,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         W4_XSCALE_LOAD(sa_nxt, s_pSA); W4_XSCALE_LOAD(sb_nxt, s_pSB);
         W4_STAGE_ADVANCE();
         W4_DMA(0, 0); W4_DMA(0, 1); W4_DMA(0, 2); W4_DMA(0, 3); W4_DMA(0, 4); W4_DMA(0, 5); W4_DMA(0, 6); W4_DMA(0, 7);
-        if constexpr ((ABL & 2048) != 0) { asm volatile("s_waitcnt vmcnt(8)" : "+v"(sa_nxt), "+v"(sb_nxt) : : "memory"); }
+        if constexpr ((ABL & 2048) != 0) { W4_WAIT_VM(8); }
         else if constexpr ((ABL & 1024) != 0) {
             W4_DMA(1, 0); W4_DMA(1, 1); W4_DMA(1, 2); W4_DMA(1, 3); W4_DMA(1, 4);
-            asm volatile("s_waitcnt vmcnt(13)" : "+v"(sa_nxt), "+v"(sb_nxt) : : "memory");
+            W4_WAIT_VM(13);
         } else {
             W4_DMA(1, 0); W4_DMA(1, 1); W4_DMA(1, 2);
-            asm volatile("s_waitcnt vmcnt(11)" : "+v"(sa_nxt), "+v"(sb_nxt) : : "memory");
+            W4_WAIT_VM(11);
         }
+        W4_LANDED2(sa_nxt, sb_nxt);
         W4_FENCE();
         W4_XSCALE_TAKE();
         W4_COMPUTE_AT(0, -1);
@@ -814,7 +831,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             W4_STAGE_ADVANCE();
             xlds = lds_w + (unsigned)s_slot * W4_STAGE;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(sa_nxt), "+v"(sb_nxt) : : "memory");      // K-tile + 1 and its scales landed
+            W4_WAIT_VM(0);      // K-tile + 1 and its scales landed
+            W4_LANDED2(sa_nxt, sb_nxt);
             W4_FENCE();
             __builtin_amdgcn_s_barrier();
             W4_FENCE();

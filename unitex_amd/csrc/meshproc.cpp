@@ -124,7 +124,7 @@ extern "C" int utx_mesh_decimate_qem(const float* verts_in, int V, const int* fa
         i = j;
     }
     int nf = F;
-    std::vector<int> nb;
+    std::vector<int> nb, na, nbv;
     while (nf > target_faces && !heap.empty()) {
         const Cand c = heap.top(); heap.pop();
         const int a = c.a, b = c.b;
@@ -149,6 +149,20 @@ extern "C" int utx_mesh_decimate_qem(const float* verts_in, int V, const int* fa
             }
         }
         if (!ok || shared > 2) continue;      // shared > 2: a non-manifold fan around the edge -- leave it alone
+        // link condition: the vertices adjacent to BOTH ends must be exactly the apexes of the faces on the edge (one per shared face); a further common
+        // neighbour means the collapse would pinch the surface (two sheets glued along an edge: duplicate / non-manifold faces)
+        {
+            na.clear(); nbv.clear();
+            for (int f : vf[a]) if (falive[f]) for (int k = 0; k < 3; ++k) if (Fc[3 * f + k] != a) na.push_back(Fc[3 * f + k]);
+            for (int f : vf[b]) if (falive[f]) for (int k = 0; k < 3; ++k) if (Fc[3 * f + k] != b) nbv.push_back(Fc[3 * f + k]);
+            std::sort(na.begin(), na.end()); na.erase(std::unique(na.begin(), na.end()), na.end());
+            std::sort(nbv.begin(), nbv.end()); nbv.erase(std::unique(nbv.begin(), nbv.end()), nbv.end());
+            int common = 0;
+            for (size_t i = 0, j = 0; i < na.size() && j < nbv.size();) {
+                if (na[i] < nbv[j]) ++i; else if (na[i] > nbv[j]) ++j; else { ++common; ++i; ++j; }
+            }
+            if (common != shared) continue;
+        }
         // collapse b into a
         for (int d = 0; d < 3; ++d) P[3 * a + d] = c.p[d];
         Q[a] = Q[a] + Q[b];
@@ -183,5 +197,5 @@ extern "C" int utx_mesh_decimate_qem(const float* verts_in, int V, const int* fa
         ++of;
     }
     *V_out = nv; *F_out = of;
-    return 0;
+    return of > target_faces ? 1 : 0;      // 1: every remaining collapse was rejected (flip / fan / link condition) before the target was reached -- the mesh is valid, but larger than asked
 }

@@ -137,14 +137,20 @@ int utx_plan_entry(const utx_plan* p, int i, int* kind, int* side, void* buf, si
 }
 
 // Replay.  Returns 0, or the first failing launcher's code with its entry index in *failed_entry (may be NULL).
-int utx_plan_run(utx_plan* p, utx_stream stream_, int* failed_entry) {
-    if (!p || p->open_sections) return -2;
+// entries [begin, end) of the plan (utx_plan_run = all of them).  A range must hold whole two-stream sections; sections are numbered by the JOINs in
+// front of `begin`.  A launcher error inside a forked section still JOINS before returning: the caller's stream must not be left without its wait on the
+// side stream (work already queued there would otherwise run unordered against whatever the caller launches next).
+int utx_plan_run_range(utx_plan* p, int begin, int end, utx_stream stream_, int* failed_entry) {
+    if (!p || p->open_sections || begin < 0 || end > (int)p->entries.size() || begin > end) return -2;
     hipStream_t main_s = (hipStream_t)stream_;
     size_t section = 0;
-    for (size_t i = 0; i < p->entries.size(); ++i) {
+    for (int i = 0; i < begin; ++i) if (p->entries[i].kind == K_JOIN) ++section;
+    bool forked = false;
+    int rc = 0, bad = -1;
+    for (int i = begin; i < end; ++i) {
         const Entry& e = p->entries[i];
         hipStream_t st = e.side ? p->side : main_s;
-        int rc = 0;
+        if (e.side && !forked) { rc = -2; bad = i; break; }      // a range that starts inside a section
         switch (e.kind) {
             case K_GEMM: rc = utx_launch_gemm_bf16(&e.gemm, st); break;
             case K_GEMV: rc = utx_launch_gemv_bf16(&e.gemv, st); break;
@@ -165,15 +171,27 @@ int utx_plan_run(utx_plan* p, utx_stream stream_, int* failed_entry) {
             case K_ADD3: rc = utx_launch_add3_bf16(e.add3.a, e.add3.b, e.add3.c, e.add3.out, e.add3.n, st); break;
             case K_FORK:
                 if (hipEventRecord(p->events[2 * section], main_s) != hipSuccess || hipStreamWaitEvent(p->side, p->events[2 * section], 0) != hipSuccess) rc = -4;
+                else forked = true;
                 break;
             case K_JOIN:
                 if (hipEventRecord(p->events[2 * section + 1], p->side) != hipSuccess || hipStreamWaitEvent(main_s, p->events[2 * section + 1], 0) != hipSuccess) rc = -4;
+                forked = false;
                 ++section;
                 break;
         }
-        if (rc != 0) { if (failed_entry) *failed_entry = (int)i; return rc; }
+        if (rc != 0) { bad = i; break; }
     }
-    return 0;
+    if (rc == 0 && forked) { rc = -2; bad = end; }      // a range that ends inside a section
+    if (forked) {      // error (or a cut section): join what was forked
+        if (hipEventRecord(p->events[2 * section + 1], p->side) == hipSuccess) (void)hipStreamWaitEvent(main_s, p->events[2 * section + 1], 0);
+    }
+    if (rc != 0 && failed_entry) *failed_entry = bad;
+    return rc;
+}
+
+int utx_plan_run(utx_plan* p, utx_stream stream_, int* failed_entry) {
+    if (!p) return -2;
+    return utx_plan_run_range(p, 0, (int)p->entries.size(), stream_, failed_entry);
 }
 
 }  // extern "C"

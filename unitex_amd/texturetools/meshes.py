@@ -420,8 +420,11 @@ def decimate_qem(verts, faces, max_faces, boundary_weight=1.0):
     nv, nf = C.c_int(0), C.c_int(0)
     rc = lib.utx_mesh_decimate_qem(v.ctypes.data_as(C.c_void_p), len(v), f.ctypes.data_as(C.c_void_p), len(f), int(max_faces), float(boundary_weight),
                                    vo.ctypes.data_as(C.c_void_p), fo.ctypes.data_as(C.c_void_p), C.byref(nv), C.byref(nf))
-    if rc != 0:
+    if rc < 0:
         raise RuntimeError("utx_mesh_decimate_qem -> %d" % rc)
+    if rc == 1:      # every remaining collapse was rejected (flip / non-manifold fan / link condition): a valid mesh, but larger than asked
+        import warnings
+        warnings.warn("decimate_qem: stopped at %d faces, above the requested %d (no admissible edge collapse left)" % (nf.value, int(max_faces)), RuntimeWarning)
     return vo[: nv.value].copy(), fo[: nf.value].copy()
 
 
