@@ -207,11 +207,27 @@ def main():
                          "cores with the oracle (~35 min on the GPU box's 64 threads; 50 min on the 8-core build container: profiles/r02_cpu_config1_container.json): the one CPU number that is not extrapolated (SURVEY 8d)")
     args = ap.parse_args()
 
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; no HIP device visible (there is no CPU fallback)")
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # a plain `python bench.py --gpus N`: become the N-rank job (one process per GPU over RCCL) instead of silently measuring one GPU
+        if torch.cuda.device_count() < args.gpus and os.environ.get("UTX_DIST_BACKEND", "nccl") == "nccl":
+            raise SystemExit("bench.py --gpus %d: only %d HIP device(s) visible" % (args.gpus, torch.cuda.device_count()))
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X; no HIP device visible (there is no CPU fallback)")
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d was launched with WORLD_SIZE=%d: the job's rank count and --gpus must agree" % (args.gpus, world))
     if local_rank >= torch.cuda.device_count():   # fewer visible devices than ranks (single-GPU control-flow test only)
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
@@ -223,6 +239,21 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device(dev))
         else:
             dist.init_process_group(backend)
+        # what the job really is, from the group itself: ranks counted by a collective, and the devices they sit on (distinct GPUs, or the line says so)
+        one = torch.ones(1, device=dev if backend == "nccl" else "cpu", dtype=torch.float32)
+        dist.all_reduce(one)
+        pr = torch.cuda.get_device_properties(local_rank)
+        ident = "%s/%s" % (getattr(pr, "uuid", None) or getattr(pr, "pci_bus_id", None) or local_rank, os.environ.get("HIP_VISIBLE_DEVICES", ""))
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)
+        group_info = {"backend": dist.get_backend(), "world_size_from_group": dist.get_world_size(), "ranks_counted_by_all_reduce": int(one.item()),
+                      "distinct_devices": len(set(idents))}
+        if group_info["ranks_counted_by_all_reduce"] != args.gpus or group_info["world_size_from_group"] != args.gpus:
+            raise SystemExit("bench.py --gpus %d: the process group holds %d rank(s)" % (args.gpus, group_info["ranks_counted_by_all_reduce"]))
+        if backend == "nccl" and group_info["distinct_devices"] != world:
+            raise SystemExit("bench.py --gpus %d: the ranks share devices (%d distinct): one process per GPU is the contract" % (args.gpus, group_info["distinct_devices"]))
+    else:
+        group_info = None
 
     from unitex_amd.flux import ops
     from unitex_amd.flux.synthetic import SyntheticFluxStateDict, synthetic_lora
@@ -297,21 +328,43 @@ def main():
         model.attn_events = None
         model.capture_graph()
         one_step(0)
+    # THE TIMED REGION RUNS WHAT THE PRODUCT RUNS: FluxDiT.forward's default launch path -- the C-side replay of the step's plan (utx_plan_run: one C call
+    # per step, no per-kernel events), or the HIP graph with --graph; under sequence parallelism the Python launch list (its collectives are torch.distributed
+    # calls).  The per-kernel durations of the roofline objects come from ONE extra step each behind the timed region, through the evented launch list.
+    launch_path = "hip graph replay" if use_graph else \
+        ("C plan replay (utx_plan_run, one C call per step)" if next(iter(model._plans.values())).get("cplan") is not None else "python launch list (ctypes call per kernel)")
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
-    events = []
     t0 = time.perf_counter()
     for i in range(args.warmup, total):
-        one_step(i, None if use_graph else events)
+        one_step(i, None)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if use_graph:
         model.release_graph()
-        one_step(total - 1, events)
-        torch.cuda.synchronize()
+    events = []
+    one_step(total - 1, events)      # the dominant kernel's launches of one step, HIP events on the launch stream around each
+    torch.cuda.synchronize()
+    model.attn_events = None
+    # the same steps replayed as ONE HIP graph (what UTX_HIP_GRAPH=1 makes the denoise loop do), reported beside the default path
+    graph_ms = None
+    if not ulysses and not use_graph and os.environ.get("UTX_BENCH_GRAPH_FIGURE", "1") != "0":
+        try:
+            model.capture_graph(warm=False)
+            one_step(0)
+            torch.cuda.synchronize()
+            tg = time.perf_counter()
+            for i in range(args.warmup, total):
+                one_step(i, None)
+            torch.cuda.synchronize()
+            graph_ms = (time.perf_counter() - tg) / args.steps * 1e3
+        except Exception as e:  # noqa: BLE001 -- a reporting extra
+            graph_ms = "error: %r" % (e,)
+        finally:
+            model.release_graph()
     # GEMM-only roofline: ONE extra eager step behind the timed region with HIP events around every large-M GEMM of the main stream
     # (the text-side GEMMs of the double blocks run beside them on the second stream, as in the timed steps)
     gemm_ev = []
@@ -387,13 +440,13 @@ def main():
             ("ulysses sp%d: ONE job, 2 all-to-alls / layer (RCCL) + view-sharded back-projection with one all-gather" % world) if ulysses \
             else ("single GPU" if world == 1 else "replicas x%d (independent jobs, no data-path collective)" % world)
         out = {
-            "metric": "denoising-steps/sec", "value": value, "unit": "steps/s", "n_gpus": world,
+            "metric": "denoising-steps/sec", "value": value, "unit": "steps/s", "n_gpus": (group_info["ranks_counted_by_all_reduce"] if group_info else 1),
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak" if (world > 1 and not ulysses) else "strong", "vs_baseline": None,
             "dtype": "mx-fp8 (e4m3 x E8M0/32) big linears + bf16 attention" if args.fp8 else "bf16", "data": "synthetic",
             "config": {"workload": args.workload, "description": desc, "tokens": S, "text_tokens": S_txt,
                        "noise_tokens": n_noise, "control_tokens": n_ctrl, "dual_tokens": n_dual,
-                       "lora_rank": args.lora_rank, "guidance": 3.5, "launch": "hip graph replay" if use_graph else "eager stream launches", "parallelism": par,
+                       "lora_rank": args.lora_rank, "guidance": 3.5, "launch": launch_path, "ms_per_step_hip_graph_replay": graph_ms, "parallelism": par,
                        "tokens_computed": S_exec, "text_dedup": None if model.text_rows is None else "512 identical text tokens carried as %d rows per rank, key weight 2^%.2f (SURVEY 7 last bullet; UTX_TEXT_DEDUP=0 disables)" % (model.text_rows, model.key_bias_log2),
                        "last_block_pruning": ("last block: queries / MLP / out-projection for the %d noise tokens only (the prediction of the condition tail is never read: "
                                               "flux_piplines/texturing/pipeline.py:645,660,684; UTX_PRUNE_LAST=0 disables)" % n_noise) if prune else None,
@@ -407,7 +460,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "attn_fwd_glds_kernel", "launches_per_call": "full rounds + key-split tail round (same kernel) + attn_merge_kernel; a 'launch' below is one utx_attn_fwd_bf16 call", "achieved": achieved, "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
                          "launches_timed": len(attn_ms), "avg_launch_ms": attn_avg_ms,
-                         "timed_in": "one eager step after the timed region (graph mode)" if use_graph else "the timed region",
+                         "timed_in": "one extra step behind the timed region, HIP events on the launch stream around every attention call (the timed region itself carries no events: it is the product's launch path)",
                          "flops_per_launch": attn_launch_flops,
                          # context, not the judged fraction: an MFMA-only stream of the same shape sustains 1.73 PF on random operands
                          # on this board (power-limited clock, profiles/r01_perf_attn_q64.log)
@@ -428,6 +481,8 @@ def main():
                                     "share_of_step_time": g_ms / (dt / args.steps * 1e3)}
         if exchange:
             out["config"]["exchange"] = exchange
+        if group_info:
+            out["config"]["process_group"] = group_info
         # HBM traffic of the dominant kernel: PMC passes cannot run inside the timed run (they serialise kernels), so
         # the per-launch figure is the one measured by tools/pmc_kernel.sh on THIS command and committed under profiles/
         try:

@@ -528,12 +528,22 @@ def test_sequence_parallel_world1_through_rccl_collectives(monkeypatch, zero_cop
         ex = spm.ex
         assert ex.force and ex.can_async and ex.G == 2 and ex.recv.data_ptr() != ex.send.data_ptr() and ex.o_recv.data_ptr() != ex.o.data_ptr()
         assert ex.zero_copy == zero_copy
+        # round 4: the sequence-parallel step is replayed in C between the host's collectives (utx_plan_run_range over p["segments"]); the Python launch
+        # list (run_plan) must give the same bits, and both the plain forward's
+        p_sp = next(iter(spm._plans.values()))
+        segs = p_sp.get("segments")
+        assert p_sp.get("cplan") is not None and segs is not None and len(segs) == 2 * (2 + 3) + 1, "one range in front of every exchange start / attention + the tail"
+        assert sum(1 for _, _, op in segs if op is not None and op[0] == "sp_attn") == 5 and segs[-1][2] is None
+        assert int(spm.lib.utx_plan_size(p_sp["cplan"])) == segs[-1][1] and all(b0 <= b1 for b0, b1, _ in segs)
         for it in range(6):
             lat = torch.randn(S_img, 64, generator=g).to(BF).cuda()
             a = plain.forward(lat, 0.5 - 0.05 * it).clone()
             b = spm.forward(lat, 0.5 - 0.05 * it).clone()
+            spm.run_plan(p_sp)                                  # the same step through the Python launch list (inputs are in the workspaces already)
+            c = p_sp["ws"]["out"].clone()
             torch.cuda.synchronize()
             assert torch.equal(a.view(torch.int16), b.view(torch.int16)), "iteration %d: the plan through RCCL differs from the plain forward" % it
+            assert torch.equal(c.view(torch.int16), b.view(torch.int16)), "iteration %d: C-replayed ranges differ from the Python launch list" % it
     finally:
         if created:
             dist.destroy_process_group()

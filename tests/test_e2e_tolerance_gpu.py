@@ -22,7 +22,7 @@ import numpy as np
 import pytest
 import torch
 
-from oracle import dit_ref, vae_ref
+from oracle import dit_ref, pipeline_ref, vae_ref
 
 pytestmark = pytest.mark.gpu
 BF = torch.bfloat16
@@ -34,7 +34,8 @@ def _postprocess_u8(img):
     return (x * 255).round().astype(np.uint8)
 
 
-def _run_both(cfg, shape, S_txt, zero_text, lat_hw, dual_hw, K, lora_rank, n_threads=None):
+def _run_both(cfg, shape, S_txt, zero_text, lat_hw, dual_hw, K, lora_rank, n_threads=None, fp8_too=False, fp32_too=False):
+    """-> {"bf16": (latents, uint8), ["fp8": ...]} of the product, {"emulated": (latents, uint8), ["fp32": ...]} of the oracle"""
     from unitex_amd.flux.pipeline import PBRFluxPipeline
     from unitex_amd.flux.synthetic import synthetic_vae_state_dict
     from unitex_amd.flux.transformer import FluxDiT
@@ -59,30 +60,35 @@ def _run_both(cfg, shape, S_txt, zero_text, lat_hw, dual_hw, K, lora_rank, n_thr
         enc = (0.5 * torch.randn(S_txt, cfg.joint_dim, generator=g)).to(BF); pooled = (0.5 * torch.randn(1, cfg.pooled_dim, generator=g)).to(BF)
     txt_ids = torch.zeros(S_txt, 3)
     vsd = synthetic_vae_state_dict(1)
-    # ---- product
-    tr = FluxDiT(sd, shape, device=DEV)
-    vae = AutoencoderKL(vsd, device=DEV)
-    pipe = PBRFluxPipeline(tr, vae, device=DEV)
-    pipe.load_lora_weights(la, "texture")
-    pipe.set_adapters(["texture"], [1.0])
-    lat = pipe.denoise(noise[None], noise_ids, cond[None], cond_ids, enc.to(DEV)[None], pooled.to(DEV), txt_ids, K, 3.5)
     H, W = 16 * hl, 16 * wl
-    z = pipe._unpack_latents(lat, H, W, 8)
-    z = (z / vae.scaling_factor) + vae.shift_factor
-    img = vae.decode(z.to(BF))
-    torch.cuda.synchronize()
-    got_lat = lat[0].float().cpu()
-    got_u8 = _postprocess_u8(img)
+    # ---- product
+    vae = AutoencoderKL(vsd, device=DEV)
+    got = {}
+    for mode in (("bf16", "fp8") if fp8_too else ("bf16",)):
+        tr = FluxDiT(sd, shape, device=DEV, fp8_weights=(mode == "fp8"))
+        pipe = PBRFluxPipeline(tr, vae, device=DEV)
+        pipe.load_lora_weights(la, "texture")
+        pipe.set_adapters(["texture"], [1.0])
+        lat = pipe.denoise(noise[None], noise_ids, cond[None], cond_ids, enc.to(DEV)[None], pooled.to(DEV), txt_ids, K, 3.5)
+        z = pipe._unpack_latents(lat, H, W, 8)
+        z = (z / vae.scaling_factor) + vae.shift_factor
+        img = vae.decode(z.to(BF))
+        torch.cuda.synchronize()
+        got[mode] = (lat[0].float().cpu(), _postprocess_u8(img))
+        del tr, pipe
+        torch.cuda.empty_cache()
     # ---- oracle
     if n_threads:
         torch.set_num_threads(n_threads)
-    ref_lat = dit_ref.denoise_loop(sd, cfg, noise.float(), cond.float(), enc.float(), pooled.float(), txt_ids,
-                                   torch.cat([noise_ids, cond_ids], 0), K, guidance=3.5, loras=loras, emulate_bf16=True)
-    rz = dit_ref.unpack_latents(ref_lat[None], H, W, 8)
-    rz = dit_ref._rb(dit_ref._rb(rz / vae_ref.AutoencoderKL.scaling_factor, True) + vae_ref.AutoencoderKL.shift_factor, True)
-    ref_img = vae_ref.AutoencoderKL.from_state_dict(vsd).decode(rz)
-    ref_u8 = _postprocess_u8(ref_img)
-    return got_lat, ref_lat, got_u8, ref_u8
+    vref = vae_ref.AutoencoderKL.from_state_dict(vsd)
+    ref = {}
+    for name, em in ((("emulated", True), ("fp32", False)) if fp32_too else (("emulated", True),)):
+        ref_lat = dit_ref.denoise_loop(sd, cfg, noise.float(), cond.float(), enc.float(), pooled.float(), txt_ids,
+                                       torch.cat([noise_ids, cond_ids], 0), K, guidance=3.5, loras=loras, emulate_bf16=em)
+        rz = dit_ref.unpack_latents(ref_lat[None], H, W, 8)
+        rz = dit_ref._rb(dit_ref._rb(rz / vae_ref.AutoencoderKL.scaling_factor, em) + vae_ref.AutoencoderKL.shift_factor, em)
+        ref[name] = (ref_lat, _postprocess_u8(vref.decode(rz)))
+    return got, ref
 
 
 def _report(tag, got_lat, ref_lat, got_u8, ref_u8):
@@ -105,7 +111,8 @@ def test_k_step_denoise_and_vae_decode_tiny_full_depth_pattern(zero_text):
     from unitex_amd.flux.transformer import FluxShape
     cfg = dit_ref.tiny_config(heads=2, double=2, single=4, joint_dim=64, pooled_dim=64)
     shape = FluxShape(num_heads=2, num_double=2, num_single=4, joint_dim=64, pooled_dim=64)
-    got_lat, ref_lat, got_u8, ref_u8 = _run_both(cfg, shape, 128 if zero_text else 64, zero_text, (8, 24), (4, 4), 4, 16)
+    got, ref = _run_both(cfg, shape, 128 if zero_text else 64, zero_text, (8, 24), (4, 4), 4, 16)
+    (got_lat, got_u8), (ref_lat, ref_u8) = got["bf16"], ref["emulated"]
     mx, d, du, hist, spread = _report("tiny 2+4 blocks, %s text" % ("zero" if zero_text else "random"), got_lat, ref_lat, got_u8, ref_u8)
     assert torch.isfinite(got_lat).all() and spread > 4.0
     assert d.max().item() <= 0.02 * mx and d.mean().item() <= 0.0015 * mx
@@ -114,16 +121,116 @@ def test_k_step_denoise_and_vae_decode_tiny_full_depth_pattern(zero_text):
 
 def test_k_step_denoise_and_vae_decode_full_width_at_config1_shape():
     """BASELINE configs[0] shape at the real FLUX width: D = 3072, 24 heads, rank-64 LoRA, 512 zero text tokens, 512 x 2048 strip (4096 noise
-    tokens) + control + 512^2 dual = 9728 joint tokens; depth cut to 1 + 1 blocks so the fp32 oracle does the 4 steps in about two minutes."""
+    tokens) + control + 512^2 dual = 9728 joint tokens; depth cut to 1 + 1 blocks so the fp32 oracle does its steps in minutes.  Round 4: K = 8 steps
+    (round 3: 4), the MX fp8 product (speedup_mode="fp8") against the SAME bf16-emulating oracle run, and the distance of everything to the plain fp32
+    evaluation (emulate_bf16=False) printed beside it.
+    STATED TOLERANCE, bf16: as the tiny cases.  fp8 (a different numerics contract, never the default): latents max |d| <= 0.03 max|latent|, mean <= 0.003;
+    decoded image >= 97 % of the pixels within 2 LSB, >= 99.9 % within 4, none beyond 12.  Measured (profiles/r04_e2e_tol_a.log): bf16 max 0.0097 / mean
+    0.00037 of max|latent|, 54 % equal, 94.6 % within 1 LSB, 99.8 % within 2, max 5; MX fp8 0.0097 / 0.00096, 49.7 % / 91.2 % / 99.4 %, max 6."""
     from unitex_amd.flux.transformer import FluxShape
     cfg = dit_ref.FluxConfig(num_double=1, num_single=1)
     shape = FluxShape(num_double=1, num_single=1)
     nt = max(1, min(len(os.sched_getaffinity(0)), 64))
-    got_lat, ref_lat, got_u8, ref_u8 = _run_both(cfg, shape, 512, True, (32, 128), (32, 32), 4, 64, n_threads=nt)
-    mx, d, du, hist, spread = _report("full width 1+1 blocks, S = 9728", got_lat, ref_lat, got_u8, ref_u8)
-    assert torch.isfinite(got_lat).all() and spread > 4.0
+    # the plain-fp32 leg doubles the oracle's CPU time (8 full-width steps are ~3 minutes on 64 host threads): opt-in, run once per round and quoted in DESIGN
+    fp32_too = os.environ.get("UTX_TEST_FP32_ORACLE", "0") == "1"
+    got, ref = _run_both(cfg, shape, 512, True, (32, 128), (32, 32), 8, 64, n_threads=nt, fp8_too=True, fp32_too=fp32_too)
+    ref_lat, ref_u8 = ref["emulated"]
+    mx, d, du, hist, spread = _report("full width 1+1 blocks, S = 9728, K = 8, bf16 vs emulating oracle", got["bf16"][0], ref_lat, got["bf16"][1], ref_u8)
+    assert torch.isfinite(got["bf16"][0]).all() and spread > 4.0
     assert d.max().item() <= 0.02 * mx and d.mean().item() <= 0.0015 * mx
     assert hist[2] >= 0.99 and hist[4] >= 0.999 and du.max() <= 8
+    mx8, d8, du8, hist8, _ = _report("full width 1+1 blocks, S = 9728, K = 8, MX fp8 vs emulating oracle", got["fp8"][0], ref_lat, got["fp8"][1], ref_u8)
+    assert torch.isfinite(got["fp8"][0]).all()
+    assert d8.max().item() <= 0.03 * mx8 and d8.mean().item() <= 0.003 * mx8
+    assert hist8[2] >= 0.97 and hist8[4] >= 0.999 and du8.max() <= 12
+    # the distance to the plain fp32 evaluation (no bf16 rounding anywhere in the oracle): reported, and bounded loosely -- it is the reference's own bf16 error too
+    if fp32_too:
+        _report("    the emulating oracle itself vs plain fp32", ref_lat, ref["fp32"][0], ref_u8, ref["fp32"][1])
+        _report("    bf16 product vs plain fp32", got["bf16"][0], ref["fp32"][0], got["bf16"][1], ref["fp32"][1])
+        _report("    MX fp8 product vs plain fp32", got["fp8"][0], ref["fp32"][0], got["fp8"][1], ref["fp32"][1])
+
+
+def _smooth_image(h, w, seed):
+    """a synthetic RGB uint8 picture with structure at several scales (a flat or white-noise image would make the VAE round trip trivial)"""
+    g = torch.Generator().manual_seed(seed)
+    img = torch.zeros(1, 3, h, w)
+    for s_ in (4, 16, 64):
+        img = img + torch.nn.functional.interpolate(torch.randn(1, 3, max(1, h // s_), max(1, w // s_), generator=g), size=(h, w), mode="bicubic", align_corners=False)
+    img = (img - img.min()) / (img.max() - img.min())
+    return (img[0].permute(1, 2, 0).numpy() * 255).round().astype(np.uint8)
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp8"])
+def test_full_schedule_28_steps_two_passes_with_uint8_handoff(mode):
+    """THE REAL SCHEDULE: /root/reference/pipeline.py:246-289 -- texture pass, 28 steps (control image + reference image, texture adapter
+    on) -> uint8 image -> delight pass, 28 more steps with THAT image as the control image (delight adapter on) -> uint8 image; each pass is one
+    PBRFluxPipeline.__call__ (flux_piplines/texturing/pipeline.py:404-700: VAE encode + posterior sample from the shared generator, pack, denoise with
+    re-pin, unpack, VAE decode, postprocess).  Product: unitex_amd PBRFluxPipeline on the HIP FluxDiT / VAE, bf16 and MX fp8 (speedup_mode="fp8").
+    Oracle: oracle/pipeline_ref.texturing_call twice (bf16-emulating) on the same seed; the plain fp32 evaluation of the same schedule beside it.
+    Tiny 2 + 4-block network (2 heads) so that 2 x 56 CPU evaluations + 12 VAE passes stay in the minute range: 128 x 384 strip, 64 x 64 reference image.
+    STATED TOLERANCE on the final (delighted) image and on the intermediate one -- asserted below, measured values printed and quoted in DESIGN section 3."""
+    from PIL import Image
+    from unitex_amd.flux.pipeline import PBRFluxPipeline
+    from unitex_amd.flux.synthetic import synthetic_vae_state_dict
+    from unitex_amd.flux.transformer import FluxDiT, FluxShape
+    from unitex_amd.flux.vae_hip import AutoencoderKL
+    cfg = dit_ref.tiny_config(heads=2, double=2, single=4, joint_dim=64, pooled_dim=64)
+    shape = FluxShape(num_heads=2, num_double=2, num_single=4, joint_dim=64, pooled_dim=64)
+    H, W, steps, S_txt = 128, 384, 28, 128
+    sd = dit_ref.make_synthetic_state_dict(cfg, seed=0)
+    la = dit_ref.make_synthetic_lora(cfg, sd, rank=16, seed=2)
+    lb = dit_ref.make_synthetic_lora(cfg, sd, rank=16, seed=3)
+    vsd = synthetic_vae_state_dict(1)
+    control = _smooth_image(H, W, 5)
+    reference = _smooth_image(64, 64, 6)
+    # ---- product: the reference's call sequence
+    tr = FluxDiT(sd, shape, device=DEV, fp8_weights=(mode == "fp8"))
+    pipe = PBRFluxPipeline(tr, AutoencoderKL(vsd, device=DEV), device=DEV)
+    pipe.load_lora_weights(la, "texture")
+    pipe.load_lora_weights(lb, "delight")
+    g = torch.Generator().manual_seed(2024)
+    pipe.set_adapters(["texture", "delight"], [1.0, 0.0])
+    tex = pipe(prompt="[MVFLUX]", control_image=Image.fromarray(control), dual_image=Image.fromarray(reference), height=H, width=W, n_rows=1, n_cols=6,
+               num_inference_steps=steps, guidance_scale=3.5, max_sequence_length=S_txt, generator=g).images[0]
+    pipe.set_adapters(["texture", "delight"], [0.0, 1.0])
+    out = pipe(prompt="[MVFLUX]", control_image=tex, height=H, width=W, n_rows=1, n_cols=6, num_inference_steps=steps, guidance_scale=3.5,
+               max_sequence_length=S_txt, generator=g).images[0]
+    torch.cuda.synchronize()
+    got_tex, got_out = np.asarray(tex), np.asarray(out)
+    # ---- oracle: bf16-emulating and plain fp32
+    vref = vae_ref.AutoencoderKL.from_state_dict(vsd)
+    ref = {}
+    for name, em in (("emulated", True), ("fp32", False)):
+        g2 = torch.Generator().manual_seed(2024)
+
+        def call(ctrl, dual, loras):
+            return pipeline_ref.texturing_call(sd, cfg, vref, ctrl, dual, H, W, g2, steps, loras, max_sequence_length=S_txt, emulate_bf16=em)
+        t_ = call(control, reference, [(la, 1.0), (lb, 0.0)])
+        ref[name] = (t_, call(t_, None, [(la, 0.0), (lb, 1.0)]))
+
+    def hist_of(a, b):
+        du = np.abs(a.astype(np.int32) - b.astype(np.int32))
+        return {k: float((du <= k).mean()) for k in (0, 1, 2, 4, 8, 16)}, int(du.max()), float(du.mean())
+    rows = []
+    for what, a, b in (("texture pass (28 steps)", got_tex, ref["emulated"][0]), ("delight pass (28 + 28 steps, uint8 hand-off)", got_out, ref["emulated"][1]),
+                       ("  same, product vs plain fp32", got_out, ref["fp32"][1]), ("  emulating oracle vs plain fp32", ref["emulated"][1], ref["fp32"][1])):
+        h, mxd, mean = hist_of(a, b)
+        rows.append((what, h, mxd, mean))
+        print("\n[full schedule, %s] %s: uint8 ==0 %.4f, <=1 %.4f, <=2 %.4f, <=4 %.4f, <=8 %.4f, <=16 %.4f, max %d LSB, mean %.3f LSB (image std %.1f)" % (
+            mode, what, h[0], h[1], h[2], h[4], h[8], h[16], mxd, mean, float(b.std())))
+    assert float(ref["emulated"][1].std()) > 4.0 and float(ref["emulated"][0].std()) > 4.0, "a constant image would make the comparison vacuous"
+    (_, h_tex, mx_tex, _), (_, h_out, mx_out, _) = rows[0], rows[1]
+    # measured on MI355X (profiles/r04_e2e_tol_a.log): bf16 -- texture pass 52 % equal / 92.5 % within 1 LSB / 99.5 % within 2 / max 4, delight pass (56 steps,
+    # uint8 hand-off) 52 % / 92.8 % / 99.6 % / max 4; MX fp8 -- 46 % / 86 % / 98 % / max 6 and 5.  The bf16-emulating oracle itself is 17 % / 26 % / 34 % / max 45
+    # from the plain fp32 evaluation of the same schedule (mean 5.9 LSB): that is the bf16 network's own distance to fp32, and the product's is the same.
+    if mode == "bf16":
+        assert h_tex[2] >= 0.99 and h_tex[4] >= 0.999 and mx_tex <= 8
+        assert h_out[2] >= 0.99 and h_out[4] >= 0.999 and mx_out <= 8
+    else:
+        assert h_tex[2] >= 0.95 and h_tex[4] >= 0.995 and mx_tex <= 12
+        assert h_out[2] >= 0.95 and h_out[4] >= 0.995 and mx_out <= 12
+    # the product is no further from plain fp32 than the reference's own bf16 arithmetic is (the emulating oracle): mean LSB distance within 10 % of each other
+    assert rows[2][3] <= 1.10 * rows[3][3] + 0.1
 
 
 class _HostView:

@@ -331,3 +331,60 @@ def _flat(m):
             else:
                 yield fn, d
     return list(walk(next(iter(m._plans.values()))["plan"]))
+
+
+def test_sequence_parallel_single_blocks_run_their_projection_in_fp8():
+    """VERDICT r3 missing #1 / DESIGN 9 (v): under sequence parallelism the single blocks' [q|k|v|mlp] projection is cut at column 3D (q|k|v first, the MLP
+    half beside the all-to-all) -- round 3 ran both halves in bf16 even in fp8 mode, i.e. configs[4] ("8 x MI355X, fp8 weights") would have run 38 of 57
+    blocks' biggest GEMM in bf16.  Now both halves take the MX kernel on row slices of the same quantised weight.  One rank (a 1-rank RCCL group with every
+    collective issued to itself) sees every key in the plain order and every output element keeps its K order, so the sequence-parallel fp8 forward must
+    equal the plain fp8 forward BIT FOR BIT (split tail rounds off: the two forms launch different shapes)."""
+    import os
+    import torch.distributed as dist
+    from unitex_amd import _lib
+    from unitex_amd.flux.transformer import FluxDiT, FluxShape
+    os.environ["UTX_SP_FORCE_A2A"] = "1"
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29850 + os.getpid() % 100))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+        created = True
+    try:
+        cfg = dit_ref.FluxConfig(num_double=1, num_single=2)
+        sd = dit_ref.make_synthetic_state_dict(cfg, seed=0)
+        shape = FluxShape(num_double=1, num_single=2)
+        S_txt, img_ids = 512, dit_ref.latent_image_ids(64, 64)
+        S_img = img_ids.shape[0]                      # 4096 image tokens + 64 de-duplicated text rows = 4160 = 65 x 64
+        g = torch.Generator().manual_seed(9)
+        lat = torch.randn(S_img, 64, generator=g).to(BF).cuda()
+        enc = torch.zeros(S_txt, cfg.joint_dim).to(BF).cuda()
+        pooled = torch.zeros(1, cfg.pooled_dim).to(BF).cuda()
+        _lib.set_option("UTX_GEMM_STREAMK", 0)
+        outs = {}
+        for name, sp in (("plain", False), ("sp", True)):
+            m = FluxDiT(sd, shape, device="cuda:0", sequence_parallel=sp, fp8_weights=True)
+            m.set_positions(torch.zeros(S_txt, 3), img_ids)
+            m.set_conditioning(enc, pooled, 3.5)
+            descs = [d for fn, d in _flat(m) if fn is m.lib.utx_gemm_bf16 and d.M >= 4096]
+            big = [d for d in descs if d.N in (9216, 12288, 21504)]
+            if sp:
+                # per single block: the q|k|v half (N = 9216) and the MLP half (N = 12288), both on MX operands with tile-packed scales; the MLP half hands
+                # its GELU output over as fp8 (q_out) to the fp8 out-projection
+                sgl = [d for d in big if d.N in (9216, 12288) and d.K == 3072]
+                assert sum(1 for d in sgl if d.N == 12288 and d.mx8 == 2 and d.q_out) == 2, [(d.N, d.mx8) for d in sgl]
+                assert sum(1 for d in sgl if d.N == 9216 and d.mx8 == 2) >= 2 + 1            # 2 single blocks + the double block's image-side q|k|v
+                assert m.ex.force and m.ex.can_async
+            else:
+                assert sum(1 for d in big if d.N == 21504 and d.mx8 == 2) == 2
+            outs[name] = [m.forward(lat, 0.5 - 0.1 * i).clone() for i in range(3)]
+            torch.cuda.synchronize()
+            del m
+        for a, b in zip(outs["plain"], outs["sp"]):
+            assert torch.isfinite(a.float()).all()
+            assert torch.equal(a.view(torch.int16), b.view(torch.int16)), "sequence-parallel fp8 forward differs from the plain fp8 forward: max |d| %g" % (a.float() - b.float()).abs().max().item()
+    finally:
+        _lib.set_option("UTX_GEMM_STREAMK", 1)
+        os.environ.pop("UTX_SP_FORCE_A2A", None)
+        if created:
+            dist.destroy_process_group()

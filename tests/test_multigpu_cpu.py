@@ -40,7 +40,7 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3, 4])
+@pytest.mark.parametrize("world", [2, 3, 4, 8])      # 8 ranks, 6 views: two ranks own no view and still take part in the ONE all-gather
 def test_view_sharded_layers_allgather(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -55,6 +55,8 @@ def test_view_sharded_layers_allgather(world):
     assert all(ok for _, ok, _ in res), res
     covered = sorted(rg for _, _, rg in res)
     assert covered[0][0] == 0 and covered[-1][1] == 6
+    owned = [v for a, b in covered for v in range(a, b)]
+    assert owned == list(range(6)), "every view owned by exactly one rank (ranks beyond the views own none): %s" % covered
 
 
 def _ulysses_worker(rank, world, port, q):
@@ -65,7 +67,7 @@ def _ulysses_worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import dit_ref
     from unitex_amd.flux.ulysses import UlyssesExchange, local_slice
-    H, S_txt, S_img = 12, 64 * world, 128 * world
+    H, S_txt, S_img = (24 if world == 8 else 12), 64 * world, 128 * world      # world 8: FLUX's 24 heads -> 3 heads per rank, one head group (the 8-GPU target)
     g = torch.Generator().manual_seed(3)                     # same data on every rank
     S = S_txt + S_img
     qf, kf, vf = (torch.randn(H, S, 128, generator=g) for _ in range(3))
@@ -100,7 +102,7 @@ def _ulysses_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_ulysses_exchange_matches_unsharded_attention(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

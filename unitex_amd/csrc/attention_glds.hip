@@ -83,6 +83,11 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
     const bf16_t* vbase = BLK ? p.vt + (long)head * p.vt_hs + (long)blk0 * p.vt_bs + loc0 * AG_KVB
                               : p.vt + (long)head * p.vt_hs + tb * AG_KVB;
 
+    // VAR 11 (ablation build, correct results): the workgroup's timeline -- wave 0 writes the 100 MHz wall clock at start / Q fragments loaded / ring filled (first
+    // barrier) / key loop done / output stores retired, plus where it ran (HW_ID, XCC_ID), 8 longs per workgroup into p.work (tools/attn_timeline.py): what a
+    // persistent workgroup that prefetches its next item's Q and drains its stores under the next item's first tiles could hide
+    long tl0 = 0, tl1 = 0, tl2 = 0, tl3 = 0;
+    if constexpr (VAR == 11) tl0 = wall_clock64();
     const int q0 = qb * 256 + wave * 32;
     bf16x8 qf[8];
     {
@@ -151,7 +156,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
 #pragma unroll
     for (int i = 0; i < TPB; ++i)
         if (i < nt) AG_STAGE(i, i);
+    if constexpr (VAR == 11) { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); tl1 = wall_clock64(); }      // the Q loads are older than the first tile's four DMAs
     __syncthreads();
+    if constexpr (VAR == 11) tl2 = wall_clock64();
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) asm volatile("" : "+v"(qf[kk]));
 
@@ -295,6 +302,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
     // profiles/r03_attn_variants_v0.log, same process, interleaved): 25.380 vs 25.380 ms at S = 50 240, 1.889 vs 1.867 ms at S = 13 376 (-1.1 %) --
     // with 785 key tiles per workgroup the epilogue is ~1 % of a workgroup's life and the 16 swaps cost what the 8 saved stores bought.  The
     // default keeps the 8-byte stores; VAR 7 (ablation build) is the widened form, bit-identical.
+    if constexpr (VAR == 11) tl3 = wall_clock64();
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
     const int qrow = q0 + lq;
@@ -344,6 +352,17 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
         return;
     }
     AG_STORE_ROW(p.o + (long)(qrow < Sq ? qrow : 0) * p.o_ss + head * 128, wide);
+    if constexpr (VAR == 11) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const long tl4 = wall_clock64();
+        if (tid == 0 && p.work && (size_t)(blockIdx.x + 1) * 64 <= p.work_bytes) {
+            long* const tr = (long*)p.work + (size_t)blockIdx.x * 8;
+            unsigned hw = 0, xcc = 0;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            tr[0] = tl0; tr[1] = tl1; tr[2] = tl2; tr[3] = tl3; tr[4] = tl4; tr[5] = ((long)xcc << 32) | hw; tr[6] = wid; tr[7] = nt;
+        }
+    }
 }
 
 // combine the key ranges of the tail items: out = sum_i 2^(lse_i - M) O_i / sum_i 2^(lse_i - M).  One thread per (query, 8 channels).
@@ -465,6 +484,7 @@ extern "C" int utx_launch_attn_fwd_glds(const AttnParams* p, int presc, hipStrea
       if (var == 8 && presc) return launch_glds<1, 1, 8>(*p, stream);      // nontemporal output stores (correct results)
       if (var == 9 && presc) return launch_glds<1, 1, 9>(*p, stream);      // no output stores (WRONG results): the store tail's share of a workgroup's fixed cost
       if (var == 10 && presc) return launch_glds<1, 1, 10>(*p, stream);    // no first-tile max pass (WRONG results)
+      if (var == 11 && presc) return launch_glds<1, 1, 11>(*p, stream);    // per-workgroup timeline into p.work (correct results; never split)
       if (var == 7 && presc) return launch_glds<1, 1, 7>(*p, stream); }    // 16-byte epilogue stores through v_permlane32_swap (correct results)
 #endif
     return presc ? launch_glds<1, 1>(*p, stream) : launch_glds<0, 1>(*p, stream);

@@ -596,9 +596,16 @@ class FluxDiT:
             pruned = i == len(self.single) - 1 and n_out < S_img
             m_qkvm = None if (pruned or self.sp is not None) else mx(b, "qkvm", n_split=3 * D, gelu_from=3 * D)
             m_out = None if pruned else mx(b, "out")
-            f_sgl = fuse_quant and packed(m_qkvm) and packed(m_out)
+            # sequence parallel: the projection is cut at column 3D (q|k|v first, so that their exchange starts early; the MLP half runs beside the
+            # all-to-all) -- in fp8 mode both halves take the MX kernel on row slices of the same quantised weight (round 4; round 3 kept them in bf16)
+            sp_mx = None
+            if self.sp is not None and not pruned and self.fp8_weights and ("qkvm.sp") in b and \
+                    ops.mx8_uses_packed(S, 3 * D) and ops.mx8_uses_packed(S, sh.mlp_ratio * D):
+                sp_mx = (b["qkvm.q"], b["qkvm.sp"])
+            f_sgl = fuse_quant and (packed(m_qkvm) or sp_mx is not None) and packed(m_out)
             if f_sgl:     # ln_mod -> fp8 -> [q|k|v|mlp] projection, GELU(mlp) -> fp8 (columns D..) ; attention output quantised into columns [0, D) ; out-projection
-                m_qkvm[4].update(quant_cols=0, q_out=(ws["aq"][:S, D:], ws["asp"], D // 128))
+                if m_qkvm is not None:
+                    m_qkvm[4].update(quant_cols=0, q_out=(ws["aq"][:S, D:], ws["asp"], D // 128))
                 m_out[4].update(quant_cols=D)
             self._lnmod(plan, h, xn, sh_, sc_, mxq=(ws["aq"], ws["asp"]) if f_sgl else None)
             if pruned:
@@ -661,11 +668,19 @@ class FluxDiT:
             else:
                 # sequence parallel: the same GEMM cut at column 3D (identical arithmetic per column) so that the Q/K/V exchange
                 # starts as soon as q|k|v exist and the MLP half of the projection runs beside the all-to-all
+                if sp_mx is not None:
+                    Wq, Wsp = sp_mx
+                    NW = Wq.shape[0]
+                    m_a = (Wq[: 3 * D], Wsp.row_slice(0, 3 * D), ws["aq"], ws["asp"], {"quant_cols": 0 if f_sgl else D})
+                    m_b = (Wq[3 * D:], Wsp.row_slice(3 * D, NW), ws["aq"], ws["asp"],
+                           dict({"quant_cols": 0}, **({"q_out": (ws["aq"][:S, D:], ws["asp"], D // 128)} if f_sgl else {})))
+                else:
+                    m_a = m_b = None
                 self._gemm(plan, xn, b["qkvm.w"][: 3 * D], qkv, bias=b["qkvm.b"][: 3 * D], lora=b.get("lora.qkvm"),
-                           lora_n_limit=3 * D, lora_seg_n=D, T=T)
+                           lora_n_limit=3 * D, lora_seg_n=D, T=T, mx8=m_a)
                 self._qkvpost(plan, qkv, b["nq"], b["nk"], ws, S, 0)
                 plan.append(("sp_start", None))
-                self._gemm(plan, xn, b["qkvm.w"][3 * D:], cat[:, D:], bias=b["qkvm.b"][3 * D:], gelu_from=0)
+                self._gemm(plan, xn, b["qkvm.w"][3 * D:], cat[:, D:], bias=b["qkvm.b"][3 * D:], gelu_from=0, mx8=m_b)
             self._attn(plan, ws, cat, S)  # attention output lands in cat[:, :D] (row stride 5D)
             self._gemm(plan, cat, b["out.w"], h, bias=b["out.b"], gate=g_, res=h, mx8=m_out)
         o = self.mod_off[("out",)]
@@ -864,40 +879,8 @@ class FluxDiT:
                 if self.shape.guidance_embeds:
                     t = t + ws["e_g"]
                 torch.add(t, ws["e_p"], out=ws["temb"])
-            elif fn == "sp_start":
-                self._sp_work = self.ex.start_heads_in()
-            elif fn == "sp_attn":
-                ex = self.ex
-                works, self._sp_work = self._sp_work, None
-                ev = getattr(self, "attn_events", None)
-                wk = self._attn_work(ws, ex.Hg, ex.S, ex.S)
-                back = []
-                for g in range(ex.G):
-                    hd = ex.finish_heads_in_group(g, None if works is None else works[g])
-                    og = ex.o[g]
-                    if ev is not None:
-                        a = torch.cuda.Event(enable_timing=True)
-                        b = torch.cuda.Event(enable_timing=True)
-                        a.record()
-                    if hd is None:
-                        # zero copy: Q / K / V^T read from the receive buffer of the all-to-all, one block of S_loc tokens per source rank (utx_attn_fwd_bf16_blk)
-                        qp, kp, vp, hs, bs, rows = ex.heads_blocks(g)
-                        rc = lib.utx_attn_fwd_bf16_blk(h, C.c_void_p(qp), C.c_void_p(kp), C.c_void_p(vp), ptr(og), hs, 128, hs, 128, hs, rows, og.stride(0),
-                                                       ex.Hg, ex.S, ex.S, 0.0, float(self.key_bias_log2), int(self.key_bias_period), ptr(wk),
-                                                       0 if wk is None else wk.numel(), rows, bs, bs, bs, st)
-                    else:
-                        q, k, vt = hd
-                        rc = lib.utx_attn_fwd_bf16_ws(h, ptr(q), ptr(k), ptr(vt), ptr(og), q.stride(0), q.stride(1), k.stride(0), k.stride(1),
-                                                      vt.stride(0), vt.stride(1), og.stride(0), ex.Hg, ex.S, ex.S, 0.0, float(self.key_bias_log2),
-                                                      int(self.key_bias_period), ptr(wk), 0 if wk is None else wk.numel(), st)
-                    if ev is not None:
-                        b.record()
-                        ev.append((a, b))
-                    if rc:
-                        self.ctx.check(rc)
-                    back.append(ex.start_tokens_out_group(g))
-                for g in range(ex.G):
-                    ex.finish_tokens_out_group(g, back[g], d)
+            elif fn == "sp_start" or fn == "sp_attn":
+                self._sp_entry(fn, d, ws, st)
             elif fn is lib.utx_attn_fwd_bf16_ws:
                 ev = getattr(self, "attn_events", None)
                 if ev is not None:  # bench.py: HIP events on the launch stream around the dominant kernel
@@ -914,18 +897,61 @@ class FluxDiT:
             else:
                 self._launch(fn, d, st)
 
+    def _sp_entry(self, fn, d, ws, st):
+        """the host-side entries of a sequence-parallel plan: start of the Q / K / V exchange; per head group wait + unpack, attention, start of the return
+        exchange, then the waits + unpacks of the return exchanges (ulysses.py)"""
+        lib, h = self.lib, self.ctx.handle
+        if fn == "sp_start":
+            self._sp_work = self.ex.start_heads_in()
+            return
+        if fn == "sp_attn":
+            ex = self.ex
+            works, self._sp_work = self._sp_work, None
+            ev = getattr(self, "attn_events", None)
+            wk = self._attn_work(ws, ex.Hg, ex.S, ex.S)
+            back = []
+            for g in range(ex.G):
+                hd = ex.finish_heads_in_group(g, None if works is None else works[g])
+                og = ex.o[g]
+                if ev is not None:
+                    a = torch.cuda.Event(enable_timing=True)
+                    b = torch.cuda.Event(enable_timing=True)
+                    a.record()
+                if hd is None:
+                    # zero copy: Q / K / V^T read from the receive buffer of the all-to-all, one block of S_loc tokens per source rank (utx_attn_fwd_bf16_blk)
+                    qp, kp, vp, hs, bs, rows = ex.heads_blocks(g)
+                    rc = lib.utx_attn_fwd_bf16_blk(h, C.c_void_p(qp), C.c_void_p(kp), C.c_void_p(vp), ptr(og), hs, 128, hs, 128, hs, rows, og.stride(0),
+                                                   ex.Hg, ex.S, ex.S, 0.0, float(self.key_bias_log2), int(self.key_bias_period), ptr(wk),
+                                                   0 if wk is None else wk.numel(), rows, bs, bs, bs, st)
+                else:
+                    q, k, vt = hd
+                    rc = lib.utx_attn_fwd_bf16_ws(h, ptr(q), ptr(k), ptr(vt), ptr(og), q.stride(0), q.stride(1), k.stride(0), k.stride(1),
+                                                  vt.stride(0), vt.stride(1), og.stride(0), ex.Hg, ex.S, ex.S, 0.0, float(self.key_bias_log2),
+                                                  int(self.key_bias_period), ptr(wk), 0 if wk is None else wk.numel(), st)
+                if ev is not None:
+                    b.record()
+                    ev.append((a, b))
+                if rc:
+                    self.ctx.check(rc)
+                back.append(ex.start_tokens_out_group(g))
+            for g in range(ex.G):
+                ex.finish_tokens_out_group(g, back[g], d)
+
     # ------------------------------------------------------------------ C-side replay (utx_plan)
     def compile_plan(self, p=None):
         """Copy the per-step plan into a utx_plan (include/unitex_hip.h, csrc/plan.cpp): forward() then replays it with ONE C call per step
         (utx_plan_run = SURVEY 8b's `utx_dit_step`) instead of ~700 ctypes calls -- the same launchers in the same order on the same two streams, so
-        the result is bit-identical.  Not under sequence parallelism (the collectives are torch.distributed calls) and not while per-kernel events
-        are requested (bench.py's roofline timing walks the Python list).  Returns the handle, or None when the plan has entries C cannot replay."""
+        the result is bit-identical.  Under sequence parallelism the collectives stay torch.distributed calls of this host and the launches between them are
+        replayed range by range (p["segments"], utx_plan_run_range).  Not used while per-kernel events are requested (bench.py's roofline timing walks the
+        Python list).  Returns the handle, or None when the plan has entries C cannot replay."""
         p = next(iter(self._plans.values())) if p is None else p
-        if self.sp is not None:
-            return None
         lib, ws = self.lib, p["ws"]
         h = C.c_void_p()
         self.ctx.check(lib.utx_plan_create(self.ctx.handle, C.byref(h)))
+        # sequence parallel (round 4): the collectives stay torch.distributed calls of the host, the launches BETWEEN them are replayed by ranges
+        # (utx_plan_run_range): p["segments"] = [(first entry, end entry, host op behind the range or None)] -- a rank then issues two C calls +
+        # its 2 G collectives + 3 G exchange-side launches per layer instead of one ctypes call per kernel (~1000 per step)
+        segments, seg_begin = ([] if self.sp is not None else None), 0
 
         def add(fn, d):
             if fn is lib.utx_gemm_bf16:
@@ -953,6 +979,11 @@ class FluxDiT:
                 main_ops, side_ops = d[0], d[1]
                 rcs = [lib.utx_plan_fork(h)] + [add(f2, d2) for f2, d2 in side_ops] + [lib.utx_plan_main(h)] + \
                       [add(f2, d2) for f2, d2 in main_ops] + [lib.utx_plan_join(h)]
+            elif segments is not None and isinstance(fn, str) and fn in ("sp_start", "sp_attn"):
+                n = int(lib.utx_plan_size(h))
+                segments.append((seg_begin, n, (fn, d)))
+                seg_begin = n
+                rcs = [0]
             else:
                 rcs = [add(fn, d)]
             if any(rc != 0 for rc in rcs):
@@ -961,11 +992,26 @@ class FluxDiT:
         if not ok:
             lib.utx_plan_free(h)
             return None
+        if segments is not None:
+            segments.append((seg_begin, int(lib.utx_plan_size(h)), None))
         old = p.get("cplan")
         if old is not None:
             lib.utx_plan_free(old)
         p["cplan"] = h
+        p["segments"] = segments
         return h
+
+    def _run_segments(self, p):
+        """sequence parallel: the step as C-replayed launch ranges with the host's exchange operations between them"""
+        st, ws = self.ctx.stream(), p["ws"]
+        bad = C.c_int(-1)
+        for b0, b1, host_op in p["segments"]:
+            if b1 > b0:
+                rc = self.lib.utx_plan_run_range(p["cplan"], b0, b1, st, C.byref(bad))
+                if rc:
+                    raise RuntimeError("utx_plan_run_range [%d, %d): entry %d failed with code %d" % (b0, b1, bad.value, rc))
+            if host_op is not None:
+                self._sp_entry(host_op[0], host_op[1], ws, st)
 
     def build_c_dit_plan(self, p=None):
         """The same step built by the C-side builder (utx_dit_load, csrc/dit_plan.cpp): this object's packed weights and the plan's workspaces are
@@ -1053,10 +1099,13 @@ class FluxDiT:
         if g is not None:
             g.replay()
         elif p.get("cplan") is not None and self.attn_events is None and self.gemm_events is None:
-            bad = C.c_int(-1)
-            rc = self.lib.utx_plan_run(p["cplan"], self.ctx.stream(), C.byref(bad))
-            if rc:
-                raise RuntimeError("utx_plan_run: entry %d failed with code %d" % (bad.value, rc))
+            if p.get("segments") is not None:
+                self._run_segments(p)
+            else:
+                bad = C.c_int(-1)
+                rc = self.lib.utx_plan_run(p["cplan"], self.ctx.stream(), C.byref(bad))
+                if rc:
+                    raise RuntimeError("utx_plan_run: entry %d failed with code %d" % (bad.value, rc))
         else:
             self.run_plan(p)
         if out is not None:
