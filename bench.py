@@ -332,7 +332,9 @@ def main():
     # per step, no per-kernel events), or the HIP graph with --graph; under sequence parallelism the Python launch list (its collectives are torch.distributed
     # calls).  The per-kernel durations of the roofline objects come from ONE extra step each behind the timed region, through the evented launch list.
     launch_path = "hip graph replay" if use_graph else \
-        ("C plan replay (utx_plan_run, one C call per step)" if next(iter(model._plans.values())).get("cplan") is not None else "python launch list (ctypes call per kernel)")
+        ("python launch list (ctypes call per kernel)" if next(iter(model._plans.values())).get("cplan") is None else
+         "C plan ranges between the host's collectives (utx_plan_run_range; the all-to-alls are torch.distributed calls)" if ulysses else
+         "C plan replay (utx_plan_run, one C call per step)")
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -356,11 +358,12 @@ def main():
             model.capture_graph(warm=False)
             one_step(0)
             torch.cuda.synchronize()
+            n_graph = min(args.steps, 4)          # a figure beside the line, not a second timed region
             tg = time.perf_counter()
-            for i in range(args.warmup, total):
+            for i in range(args.warmup, args.warmup + n_graph):
                 one_step(i, None)
             torch.cuda.synchronize()
-            graph_ms = (time.perf_counter() - tg) / args.steps * 1e3
+            graph_ms = (time.perf_counter() - tg) / n_graph * 1e3
         except Exception as e:  # noqa: BLE001 -- a reporting extra
             graph_ms = "error: %r" % (e,)
         finally:

@@ -31,9 +31,12 @@ def preprocess(image_u8):
     return 2.0 * t - 1.0
 
 
-def postprocess_u8(image):
-    """VaeImageProcessor.postprocess(output_type='pil') up to the PIL wrapper: (x / 2 + 0.5).clamp(0, 1) -> round(255 x) [3p]."""
-    x = (image.float() / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).numpy()
+def postprocess_u8(image, em=True):
+    """VaeImageProcessor.postprocess(output_type='pil') up to the PIL wrapper [3p]: denormalize = (x / 2 + 0.5).clamp(0, 1) ON THE VAE'S OUTPUT TENSOR -- a bf16
+    tensor in the reference's pipeline, so the halving and the add are bf16 operations (em) -- then .float(), x 255, round, uint8.  Pinned through fixture G1
+    (the reference's own pipeline ran this on a stand-in VAE's bf16 output: tests/test_golden_cpu.py)."""
+    x = dit_ref._rb(image.float(), em)
+    x = dit_ref._rb(dit_ref._rb(x / 2, em) + 0.5, em).clamp(0, 1).permute(0, 2, 3, 1).numpy()
     return (x * 255).round().astype(np.uint8)[0]
 
 
@@ -51,20 +54,27 @@ def encode_image(vae, image_u8, generator, em):
 
 @torch.no_grad()
 def texturing_call(sd, cfg, vae, control_u8, dual_u8, height, width, generator, num_steps, loras, guidance=3.5, max_sequence_length=512,
-                   emulate_bf16=True, return_latents=False):
-    """one PBRFluxPipeline.__call__ (batch 1, zero prompt embeddings) -> uint8 image [H, W, 3] (and the final noise-token latents)."""
+                   emulate_bf16=True, return_latents=False, encode_fn=None, decode_fn=None, forward_fn=None):
+    """one PBRFluxPipeline.__call__ (batch 1, zero prompt embeddings) -> uint8 image [H, W, 3] (and the final noise-token latents).
+    encode_fn(image_u8, generator) -> scaled latents [1, 16, h, w], decode_fn(z) -> image, forward_fn(latents, t, img_ids) -> velocity: stand-ins for the
+    third-party seams (VAE, transformer), so that THIS function's own logic -- draw order, ids, condition order, re-pin, unpack, postprocess -- can be pinned
+    against fixture G1, which the reference's own pipeline produced with the same stand-ins (tests/test_golden_cpu.py)."""
     em = emulate_bf16
+    if encode_fn is None:
+        encode_fn = lambda img, gen: encode_image(vae, img, gen, em)       # noqa: E731
+    if decode_fn is None:
+        decode_fn = vae.decode
     HL, WL = 2 * (height // 16), 2 * (width // 16)
     noise = torch.randn((1, 16, HL, WL), generator=generator, dtype=BF).to(F32)                # draw 1
     noise_tok = dit_ref.pack_latents(noise)[0]
     ids = [dit_ref.latent_image_ids(HL // 2, WL // 2)]
     dual_tok = control_tok = None
     if dual_u8 is not None:                                                                     # draw 2
-        dl = encode_image(vae, dual_u8, generator, em)
+        dl = encode_fn(dual_u8, generator)
         dual_tok = dit_ref.pack_latents(dl)[0]
         dual_ids = dit_ref.latent_image_ids(dl.shape[2] // 2, dl.shape[3] // 2, offset_x=WL // 2, offset_y=HL // 2)
     if control_u8 is not None:                                                                  # draw 3
-        cl = encode_image(vae, control_u8, generator, em)
+        cl = encode_fn(control_u8, generator)
         control_tok = dit_ref.pack_latents(cl)[0]
         control_ids = dit_ref.latent_image_ids(cl.shape[2] // 2, cl.shape[3] // 2, offset_x=0, offset_y=HL // 2)
     cond, cond_ids = [], []
@@ -74,13 +84,14 @@ def texturing_call(sd, cfg, vae, control_u8, dual_u8, height, width, generator, 
         cond.append(dual_tok); cond_ids.append(dual_ids)
     cond_t = torch.cat(cond, 0) if cond else None
     img_ids = torch.cat(ids + cond_ids, 0)
-    enc = torch.zeros(max_sequence_length, cfg.joint_dim)
-    pooled = torch.zeros(1, cfg.pooled_dim)
+    enc = torch.zeros(max_sequence_length, cfg.joint_dim) if cfg is not None else None        # (a stand-in transformer takes neither)
+    pooled = torch.zeros(1, cfg.pooled_dim) if cfg is not None else None
     txt_ids = torch.zeros(max_sequence_length, 3)
-    lat = dit_ref.denoise_loop(sd, cfg, noise_tok, cond_t, enc, pooled, txt_ids, img_ids, num_steps, guidance=guidance, loras=loras, emulate_bf16=em)
+    lat = dit_ref.denoise_loop(sd, cfg, noise_tok, cond_t, enc, pooled, txt_ids, img_ids, num_steps, guidance=guidance, loras=loras, emulate_bf16=em,
+                               forward_fn=forward_fn)
     z = dit_ref.unpack_latents(lat[None], height, width, 8)
     z = dit_ref._rb(dit_ref._rb(z / vae.scaling_factor, em) + vae.shift_factor, em)
-    img = postprocess_u8(vae.decode(z))
+    img = postprocess_u8(decode_fn(z), em)
     return (img, lat) if return_latents else img
 
 

@@ -29,9 +29,13 @@ BF = torch.bfloat16
 DEV = "cuda:0"
 
 
-def _postprocess_u8(img):
-    x = (img.float() / 2 + 0.5).clamp(0, 1).cpu().permute(0, 2, 3, 1).numpy()
-    return (x * 255).round().astype(np.uint8)
+def _postprocess_u8(img, em=None):
+    """product (em None): the pipeline's own postprocess on the HIP VAE's bf16 output; oracle: oracle/pipeline_ref.postprocess_u8 -- the reference denormalises
+    the VAE's bf16 output tensor in bf16 (VaeImageProcessor [3p], pinned through fixture G1), the plain-fp32 leg in fp32"""
+    if em is None:
+        from unitex_amd.flux.pipeline import PBRFluxPipeline
+        return np.asarray(PBRFluxPipeline._postprocess(img)[0])[None]
+    return pipeline_ref.postprocess_u8(img, em)[None]
 
 
 def _run_both(cfg, shape, S_txt, zero_text, lat_hw, dual_hw, K, lora_rank, n_threads=None, fp8_too=False, fp32_too=False):
@@ -87,7 +91,7 @@ def _run_both(cfg, shape, S_txt, zero_text, lat_hw, dual_hw, K, lora_rank, n_thr
                                        torch.cat([noise_ids, cond_ids], 0), K, guidance=3.5, loras=loras, emulate_bf16=em)
         rz = dit_ref.unpack_latents(ref_lat[None], H, W, 8)
         rz = dit_ref._rb(dit_ref._rb(rz / vae_ref.AutoencoderKL.scaling_factor, em) + vae_ref.AutoencoderKL.shift_factor, em)
-        ref[name] = (ref_lat, _postprocess_u8(vref.decode(rz)))
+        ref[name] = (ref_lat, _postprocess_u8(vref.decode(rz), em))
     return got, ref
 
 

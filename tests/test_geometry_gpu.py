@@ -133,8 +133,24 @@ def _full_case(n_faces, T, HW, seed):
     return dict(verts=verts, faces=faces, uvs=uvs, vndc=vndc, rast2d=rast2d, fn=fn, dirs=dirs, imgs=imgs)
 
 
+def test_backprojection_ray_packets_on_an_atlas_that_is_no_multiple_of_the_ray_tiles():
+    """the packet walk maps a wave to an 8 x 8 texel tile and a workgroup to 16 x 16: a 250 x 250 atlas has ragged tiles on two sides"""
+    from unitex_amd import _lib
+    ops = _ops()
+    c = _full_case(3000, 250, 96, seed=11)
+    bvh_ref = G.BVH(c["verts"], c["faces"])
+    col_ref, rv_ref, ao_ref = G.backproject(c["rast2d"], c["verts"], c["faces"], c["fn"], c["vndc"], c["dirs"], c["imgs"], bvh_ref)
+    vd, fd = _cu(c["verts"]), _cu(c["faces"])
+    bvh = ops.BVH(vd, fd)
+    assert _lib.get_options()["UTX_BVH_PACKET"] == 1
+    col, rv, ao = ops.backproject(_cu(c["rast2d"]), vd, fd, _cu(c["fn"]), _cu(c["vndc"]), _cu(c["dirs"]), _cu(c["imgs"]), bvh)
+    assert np.array_equal(rv.cpu().numpy(), rv_ref) and np.array_equal(ao.cpu().numpy(), ao_ref) and np.array_equal(col.cpu().numpy(), col_ref)
+    assert 0.05 < rv_ref.mean() < 0.9
+
+
 @pytest.mark.parametrize("n_faces,T,HW", [(3000, 256, 128), (20000, 512, 256)])
 def test_backprojection_chain_bit_exact(n_faces, T, HW):
+    from unitex_amd import _lib
     ops = _ops()
     c = _full_case(n_faces, T, HW, seed=n_faces)
     bvh_ref = G.BVH(c["verts"], c["faces"])
@@ -142,10 +158,18 @@ def test_backprojection_chain_bit_exact(n_faces, T, HW):
     vd, fd = _cu(c["verts"]), _cu(c["faces"])
     bvh = ops.BVH(vd, fd)
     rast_d = _cu(c["rast2d"])
-    col, rv, ao = ops.backproject(rast_d, vd, fd, _cu(c["fn"]), _cu(c["vndc"]), _cu(c["dirs"]), _cu(c["imgs"]), bvh)
-    assert np.array_equal(rv.cpu().numpy(), rv_ref), "ray visibility mask"
-    assert np.array_equal(ao.cpu().numpy(), ao_ref), "alpha mask"
-    assert np.array_equal(col.cpu().numpy(), col_ref), "gathered colours"
+    # the three walks of the same tree -- wave-wide packets over 8 x 8 texel tiles (round 4, the default), one thread per ray (stackless), the reference's
+    # stack walk -- must give the oracle's bits
+    assert _lib.get_options()["UTX_BVH_PACKET"] == 1
+    try:
+        for packet, stack in ((0, 1), (0, 0), (1, 0)):
+            _lib.set_option("UTX_BVH_PACKET", packet); _lib.set_option("UTX_BVH_STACK_WALK", stack)
+            col, rv, ao = ops.backproject(rast_d, vd, fd, _cu(c["fn"]), _cu(c["vndc"]), _cu(c["dirs"]), _cu(c["imgs"]), bvh)
+            assert np.array_equal(rv.cpu().numpy(), rv_ref), "ray visibility mask (packet %d, stack walk %d)" % (packet, stack)
+            assert np.array_equal(ao.cpu().numpy(), ao_ref), "alpha mask"
+            assert np.array_equal(col.cpu().numpy(), col_ref), "gathered colours"
+    finally:
+        _lib.set_option("UTX_BVH_PACKET", 1); _lib.set_option("UTX_BVH_STACK_WALK", 0)
     assert 0.05 < rv_ref.mean() < 0.9
     # view sharding: views [2,4) only
     col2, rv2, ao2 = ops.backproject(rast_d, vd, fd, _cu(c["fn"]), _cu(c["vndc"]), _cu(c["dirs"]), _cu(c["imgs"]), bvh,

@@ -89,6 +89,27 @@ def test_g1_denoise_orchestration_matches_reference(tag, with_dual):
     assert np.array_equal(nxt, f["orch_%s_next_randn" % tag]), "RNG stream position after the call (A19)"
 
 
+@pytest.mark.parametrize("tag,with_dual", [("tex", True), ("delight", False)])
+def test_g1_pins_the_oracle_of_a_whole_pipeline_call(tag, with_dual):
+    """oracle/pipeline_ref.texturing_call (the oracle of tests/test_e2e_tolerance_gpu.py's full-schedule test) run with the stand-ins the reference ran with
+    when fixture G1 was captured: its final uint8 image and the position of the shared RNG stream behind the call must equal the reference's -- draw order
+    noise -> dual -> control, ids and their offsets, condition order control ++ dual, re-pin, cut, unpack, decode, postprocess are the function's own."""
+    from oracle import pipeline_ref
+    f = _load("g1_pipeline.npz")
+    vae = fakes.FakeVAE()
+    gen = torch.Generator().manual_seed(63)
+
+    def enc(img_u8, g):
+        x = 2.0 * torch.from_numpy(np.asarray(img_u8).astype(np.float32) / 255.0).permute(2, 0, 1)[None] - 1.0
+        z = vae.encode(x.to(BF)).sample(g)
+        return ((z - vae.shift_factor) * vae.scaling_factor).to(BF).float()
+    fwd = lambda lat, t_in, ii: fakes.fake_velocity(lat[None].to(BF), torch.tensor([t_in]).to(BF), ii)[0].float()      # noqa: E731
+    img = pipeline_ref.texturing_call(None, None, vae, f["orch_control"], f["orch_dual"] if with_dual else None, 64, 192, gen, 4, None, max_sequence_length=16,
+                                      encode_fn=enc, decode_fn=lambda z: vae.decode(z.to(BF)), forward_fn=fwd)
+    assert np.array_equal(img, f["orch_%s_image" % tag])
+    assert np.array_equal(torch.randn(4, generator=gen).numpy(), f["orch_%s_next_randn" % tag]), "RNG stream position after the call"
+
+
 # ------------------------------------------------------------------------------------------------ G2
 def test_g2_attention_core_matches_reference():
     f = _load("g2_attn_core.npz")

@@ -1,9 +1,7 @@
 cd $GRAFT_REPO_ROOT
+exec < /dev/null
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_dit_ops_gpu.py tests/test_fp8_gpu.py tests/test_multigpu_gpu.py -m gpu -x -q -k "sequence_parallel or view_sharded or c_side_plan or c_built" --durations=6 > gpurun_out/r04_sp_tests_a.log 2>&1; echo "sp pytest rc=$?"
-tail -12 gpurun_out/r04_sp_tests_a.log | cut -c1-300
-timeout 300 python tools/attn_timeline.py 13376 50240 > gpurun_out/r04_attn_timeline.log 2>&1; echo "timeline rc=$?"; cat gpurun_out/r04_attn_timeline.log | cut -c1-250
-timeout 500 python bench.py --steps 6 --warmup 2 > gpurun_out/r04_bench_b.log 2>&1; echo "bench rc=$?"; tail -1 gpurun_out/r04_bench_b.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['config']['launch'], d['config']['ms_per_step_hip_graph_replay'], d['roofline']['frac'], d['roofline']['avg_launch_ms'], d.get('roofline_gemm',{}).get('frac'))"
-timeout 300 python bench.py --steps 10 --warmup 2 --workload ref512x6 --no-cpu-baseline > gpurun_out/r04_bench_ref512_b.log 2>&1; echo "bench ref rc=$?"; tail -1 gpurun_out/r04_bench_ref512_b.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['config']['launch'], d['config']['ms_per_step_hip_graph_replay'], d['roofline']['frac'], d['roofline']['avg_launch_ms'])"
-python bench.py --gpus 8 --steps 1 --warmup 0 > gpurun_out/r04_bench_gpus8_on_one_gpu.log 2>&1; echo "bench --gpus 8 on a 1-GPU box rc=$? (must be non-zero)"; tail -2 gpurun_out/r04_bench_gpus8_on_one_gpu.log
-UTX_DIST_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 2 --warmup 1 --workload ref512x6 --no-cpu-baseline > gpurun_out/r04_bench_gpus2_gloo_reexec.log 2>&1; echo "bench --gpus 2 (gloo rehearsal through the re-exec) rc=$?"; tail -1 gpurun_out/r04_bench_gpus2_gloo_reexec.log | cut -c1-400
+timeout -s KILL 400 python -m pytest tests/test_geometry_gpu.py tests/test_pipeline_gpu.py -m gpu -x -q -k "backprojection or bvh or pipeline_end_to_end" --durations=5 > gpurun_out/r04_bp_tests_b.log 2>&1; echo "geometry pytest rc=$?"
+tail -6 gpurun_out/r04_bp_tests_b.log | cut -c1-300
+timeout -s KILL 200 python tools/bp_ab.py > gpurun_out/r04_bp_ab_b.log 2>&1; echo "bp_ab rc=$?"; grep "packet\|packed" gpurun_out/r04_bp_ab_b.log | cut -c1-220
+timeout -s KILL 300 python -m pytest tests/test_fp8_gpu.py -m gpu -x -q -k "sequence_parallel" > gpurun_out/r04_sp_fp8_test.log 2>&1; echo "sp fp8 pytest rc=$?"; tail -4 gpurun_out/r04_sp_fp8_test.log | cut -c1-300

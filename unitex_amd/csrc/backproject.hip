@@ -18,20 +18,43 @@ __device__ __forceinline__ float4 tap4(const float4* img, int H, int W, int x, i
     return img[(long)y * W + x];
 }
 
-// PACKED: stackless walk over the packed tree (bvh_device.h) -- the product path; !PACKED: the reference's 64-entry stack walk, kept for
-// trees deeper than UTX_BVH_PACKED_MAX_DEPTH (where the reference's stack overflow quirk could matter) and for A/B tests
-template <bool PACKED>
+// MODE 1: stackless thread-per-ray walk over the packed tree (bvh_device.h); MODE 0: the reference's 64-entry stack walk, kept for trees deeper than
+// UTX_BVH_PACKED_MAX_DEPTH (where the reference's stack overflow quirk could matter) and for A/B tests; MODE 2 (round 4, the default): a wave owns an
+// 8 x 8 TEXEL TILE of one view and its 64 parallel rays walk the packed tree as ONE PACKET (bvh_trace_packet: nodes through the scalar cache, per-lane
+// box / triangle tests, bit-identical results); 256 threads = a 16 x 16 block of texels, tiles without a covered texel skip the walk.
+template <int MODE>
 __global__ __launch_bounds__(256) void backproject_kernel(utx_backproject_desc p, const int* info, const float* aabb, const float4* nodes, const float4* tris) {
+    __shared__ int pstack[MODE == 2 ? 4 * 192 : 1];      // MODE 2: the packets' DFS stacks, 64 x {node, mask lo, mask hi} per wave
     const long T = (long)p.T_h * p.T_w;
-    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long t;
+    bool inside = true;
+    if constexpr (MODE == 2) {
+        const int tiles_x = (p.T_w + 15) / 16;
+        const int by = blockIdx.x / tiles_x, bx = blockIdx.x - by * tiles_x;
+        const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+        const int x = bx * 16 + (wv & 1) * 8 + (ln & 7), y = by * 16 + (wv >> 1) * 8 + (ln >> 3);
+        inside = x < p.T_w && y < p.T_h;
+        t = inside ? (long)y * p.T_w + x : 0;
+    } else {
+        t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+        if (t >= T) return;
+    }
     const int vw = p.view_begin + blockIdx.y;
-    if (t >= T) return;
-    const float4 r = ((const float4*)p.rast2d)[t];
+    const float4 r = inside ? ((const float4*)p.rast2d)[t] : make_float4(0.f, 0.f, 0.f, 0.f);
     const int id = (int)r.w - 1;
     float* oc = (float*)p.color + ((long)vw * T + t) * 3;
     unsigned char* rv = (unsigned char*)p.rayvis + (long)vw * T + t;
     unsigned char* ao = (unsigned char*)p.alphaok + (long)vw * T + t;
-    if (id < 0) { oc[0] = 0.f; oc[1] = 0.f; oc[2] = 0.f; *rv = 0; *ao = 0; return; }
+    if constexpr (MODE == 2) {
+        if (__ballot(id >= 0) == 0) {      // nothing of this tile is covered
+            if (inside) { oc[0] = 0.f; oc[1] = 0.f; oc[2] = 0.f; *rv = 0; *ao = 0; }
+            return;
+        }
+        if (id < 0) {      // an uncovered texel of a covered tile stays in the wave (the packet walk is wave-wide) with its ray switched off
+            if (inside) { oc[0] = 0.f; oc[1] = 0.f; oc[2] = 0.f; *rv = 0; *ao = 0; }
+            return;      // (the packet walk below ballots over the lanes that are still here)
+        }
+    } else if (id < 0) { oc[0] = 0.f; oc[1] = 0.f; oc[2] = 0.f; *rv = 0; *ao = 0; return; }
     const float* vert = (const float*)p.verts;
     const int* faces = (const int*)p.faces;
     const float u = r.x, v = r.y, w = (1.0f - u) - v;
@@ -67,7 +90,8 @@ __global__ __launch_bounds__(256) void backproject_kernel(utx_backproject_desc p
     oc[2] = ((a.z * w00 + b.z * w01) + c.z * w10) + e.z * w11;
     const float sa = ((a.w * w00 + b.w * w01) + c.w * w10) + e.w * w11;
     *ao = sa > 0.999f ? 1 : 0;
-    const int hit = PACKED ? bvh_trace_packed(nodes, tris, ro, d, nullptr) : bvh_trace_one(info, aabb, vert, faces, ro, d);
+    const int hit = MODE == 2 ? bvh_trace_packet(nodes, tris, ro, d, true, pstack + (threadIdx.x >> 6) * 192, nullptr)
+                  : MODE == 1 ? bvh_trace_packed(nodes, tris, ro, d, nullptr) : bvh_trace_one(info, aabb, vert, faces, ro, d);
     *rv = (hit == id && hit != -1 && cs < p.cos_thresh) ? 1 : 0;
 }
 
@@ -76,10 +100,13 @@ extern "C" int utx_launch_backproject(const utx_backproject_desc* hp, const utx_
     if (!bvh || p.T_h <= 0 || p.T_w <= 0 || p.view_count <= 0) return -2;
     const long T = (long)p.T_h * p.T_w;
     dim3 grid((unsigned)((T + 255) / 256), p.view_count);
-    if (bvh->depth <= UTX_BVH_PACKED_MAX_DEPTH && !g_utx_opt.bvh_stack_walk)
-        hipLaunchKernelGGL(backproject_kernel<true>, grid, dim3(256), 0, stream, p, bvh->info, bvh->aabb, bvh->nodes, bvh->tris);
+    if (bvh->depth <= UTX_BVH_PACKED_MAX_DEPTH && !g_utx_opt.bvh_stack_walk && g_utx_opt.bvh_packet) {
+        dim3 gridp((unsigned)(((p.T_w + 15) / 16) * ((p.T_h + 15) / 16)), p.view_count);
+        hipLaunchKernelGGL(backproject_kernel<2>, gridp, dim3(256), 0, stream, p, bvh->info, bvh->aabb, bvh->nodes, bvh->tris);
+    } else if (bvh->depth <= UTX_BVH_PACKED_MAX_DEPTH && !g_utx_opt.bvh_stack_walk)
+        hipLaunchKernelGGL(backproject_kernel<1>, grid, dim3(256), 0, stream, p, bvh->info, bvh->aabb, bvh->nodes, bvh->tris);
     else
-        hipLaunchKernelGGL(backproject_kernel<false>, grid, dim3(256), 0, stream, p, bvh->info, bvh->aabb, bvh->nodes, bvh->tris);
+        hipLaunchKernelGGL(backproject_kernel<0>, grid, dim3(256), 0, stream, p, bvh->info, bvh->aabb, bvh->nodes, bvh->tris);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 

@@ -111,6 +111,83 @@ __device__ __forceinline__ int bvh_trace_packed(const float4* __restrict__ nodes
     return hit_tid;
 }
 
+// ---- the same traversal for a COHERENT PACKET: the 64 rays of a wave walk the packed tree together (backproject.hip: an 8 x 8 texel tile of one view --
+// parallel rays from neighbouring surface points).  One node per step for the whole wave, fetched through the SCALAR cache (a uniform 32-byte
+// s_load instead of 64 divergent 2 x 16-byte vector loads per step: the thread-per-ray walk is bound by exactly those -- 50 dependent divergent
+// fetches per ray); each lane tests the box with its OWN ray and its OWN `closest`; the packet descends where any lane hits, and a lane takes part
+// in a node iff it hit every ancestor -- the 64-bit masks travel with the packet's DFS stack (<= depth entries of {node, mask}, kept lane-distributed
+// in LDS, 12 bytes per entry and wave, written and read wave-uniformly).  (A first version kept the stack lane-distributed in VGPRs -- entry i in lane i,
+// v_writelane / v_readlane -- and hung the GPU: entries parked in lanes that are INACTIVE in the calling branch are lost whenever the compiler copies the
+// register, because its copies are EXEC-masked.)
+// Per lane the sequence of nodes it takes part in, and of triangles it tests, is EXACTLY the sequence of its own stackless walk above (the packet
+// visits second child before first child, as the reference pops them; a lane that misses a node skips the subtree as `esc` would): the same
+// `closest` at every test, the same last-hit-wins result -- bit-identical to bvh_trace_packed, ray by ray.  `first child` is not stored in a node:
+// it is the escape link of the second child, so the push of (first child, mask) happens when the second child's words arrive.
+typedef float bvh_f32x8 __attribute__((ext_vector_type(8)));
+typedef float bvh_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bvh_f32x8 bvh_sload8(const void* p) {
+    bvh_f32x8 r;
+    asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(p) : "memory");
+    return r;
+}
+__device__ __forceinline__ bvh_f32x4 bvh_sload4(const void* p) {
+    bvh_f32x4 r;
+    asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(p) : "memory");
+    return r;
+}
+__device__ __forceinline__ int bvh_trace_packet(const float4* __restrict__ nodes, const float4* __restrict__ tris, const float* ro, const float* rd_in,
+                                                bool valid, int* stk /* this wave's 64 x 3 ints of LDS */, unsigned* visited) {
+    const float nrm = sqrtf(dot3(rd_in, rd_in));
+    const float rd[3] = {rd_in[0] / nrm, rd_in[1] / nrm, rd_in[2] / nrm};
+    float closest = 1e9f;
+    int hit_tid = -1;
+    unsigned nv = 0;
+    const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const unsigned long long lbit = 1ull << lane;
+    int sp = 0;                                        // the packet's stack: stk[3 sp + {0, 1, 2}] = {node, mask lo, mask hi}
+    int cur = 0;
+    unsigned long long cm = __ballot(valid);
+    bool pend = false;                                 // the first child of the node just descended from is still to be pushed (with mask pm)
+    unsigned long long pm = 0;
+    while (cm != 0) {
+        const bvh_f32x8 n8 = bvh_sload8((const char*)nodes + (long)cur * 32);
+        const float bb[6] = {n8[0], n8[1], n8[2], n8[3], n8[4], n8[5]};
+        const int link = __float_as_int(n8[6]), esc = __float_as_int(n8[7]);
+        if (pend) {
+            stk[3 * sp] = esc; stk[3 * sp + 1] = (int)(unsigned)pm; stk[3 * sp + 2] = (int)(unsigned)(pm >> 32);      // every active lane writes the same words
+            ++sp;
+            pend = false;
+        }
+        const bool act = (cm & lbit) != 0;
+        if (act) ++nv;
+        const bool h = act && aabb_hit(ro, rd, 0.f, closest, bb);
+        const unsigned long long hm = __ballot(h);
+        if (link > 0) {
+            if (hm != 0) { cur = link; cm = hm; pm = hm; pend = true; continue; }
+        } else if (hm != 0) {
+            const int prim = ~link;
+            const char* tp = (const char*)tris + (long)prim * 48;
+            const bvh_f32x8 ta = bvh_sload8(tp);
+            const bvh_f32x4 tb = bvh_sload4(tp + 32);
+            if (h) {
+                const float v0[3] = {ta[0], ta[1], ta[2]}, v1[3] = {ta[4], ta[5], ta[6]}, v2[3] = {tb[0], tb[1], tb[2]};
+                float t;
+                if (tri_hit(ro, rd, v0, v1, v2, t)) {
+                    closest = t < closest ? t : closest;
+                    hit_tid = prim;
+                }
+            }
+        }
+        if (sp == 0) break;
+        --sp;
+        cur = __builtin_amdgcn_readfirstlane(stk[3 * sp]);
+        cm = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(stk[3 * sp + 1]) |
+             ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(stk[3 * sp + 2]) << 32);
+    }
+    if (visited) *visited = nv;
+    return hit_tid;
+}
+
 struct utx_bvh {
     int F;
     int* info;       // [2F-1][3]

@@ -55,6 +55,7 @@ struct UtxOptions {
     int gemm_streamk;     // 1 (default): one-wave-per-SIMD GEMM balances the K loops of its last, partly filled round over all CUs (needs utx_gemm_desc.sk_work)
     int bvh_stack_walk;   // 1: the reference's stack walk over the unpacked tree instead of the stackless packed walk (A/B; same results)
     int attn_var_abl, attn_debug_abl, gemm_debug_abl;
+    int bvh_packet;       // 1 (default): back-projection rays walk the tree as wave-wide packets over 8 x 8 texel tiles (bvh_trace_packet); 0: one thread per ray (A/B; same results)
 };
 extern UtxOptions g_utx_opt;
 

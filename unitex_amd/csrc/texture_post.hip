@@ -58,7 +58,12 @@ extern "C" int utx_launch_seam_mask(const void* winner, const float* rast2d, int
 // d2 = (dx*dx + dy*dy) + dz*dz in float32; ties -> lowest texel index (= lowest index in the reference's
 // row-major compaction).
 // ---------------------------------------------------------------------------------------------
-#define NN_G 128
+// Round 4: the time of this stage was the QUERY kernel (5.4 of 5.5 ms at 50 k faces / 2048^2 -- rocprofv3, profiles/r04_rocprofv3_kernel_stats_backprojection.csv),
+// not the sort: with 128^3 cells a surface cell holds ~100 seen texels and every query scans 27 cells of them through an index indirection (a
+// dependent, scattered 12-byte load per candidate).  Now (a) 256^3 cells (a quarter of the candidates per ring volume on a surface), (b) the seen texels'
+// positions are GATHERED into cell order once ({x, y, z, texel index} as one 16-byte record), so a query streams each cell's candidates from
+// consecutive addresses.  Same exact search, same stopping rule, same tie rule: the result does not depend on the grid.
+#define NN_G 256
 __device__ __forceinline__ int nn_cell1(float v) {
     int c = (int)floorf((v + 1.0f) * (NN_G * 0.5f));
     return c < 0 ? 0 : (c > NN_G - 1 ? NN_G - 1 : c);
@@ -73,16 +78,19 @@ __global__ __launch_bounds__(256) void nn_keys_kernel(const float* pos, const si
     }
     keys[t] = k; vals[t] = (int)t;
 }
-__global__ __launch_bounds__(256) void nn_bounds_kernel(const unsigned* keys, long T, int* cell_start, int* cell_end) {
+// cell bounds + the candidates' records in cell order: spos[i] = {pos[vals[i]], vals[i]}
+__global__ __launch_bounds__(256) void nn_bounds_kernel(const unsigned* keys, const int* vals, const float* pos, long T, int* cell_start, int* cell_end, float4* spos) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= T) return;
     const unsigned k = keys[i];
     if (k == 0xffffffffu) return;
     if (i == 0 || keys[i - 1] != k) cell_start[k] = (int)i;
     if (i == T - 1 || keys[i + 1] != k) cell_end[k] = (int)i + 1;
+    const int j = vals[i];
+    spos[i] = make_float4(pos[3 * (long)j], pos[3 * (long)j + 1], pos[3 * (long)j + 2], __int_as_float(j));
 }
 __global__ __launch_bounds__(256) void nn_query_kernel(const float* pos, const signed char* winner, const float4* rast2d, long T,
-                                                       const int* vals, const int* cell_start, const int* cell_end,
+                                                       const float4* __restrict__ spos, const int* __restrict__ cell_start, const int* __restrict__ cell_end,
                                                        float* atlas, int* nn_index) {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
@@ -98,18 +106,41 @@ __global__ __launch_bounds__(256) void nn_query_kernel(const float* pos, const s
             for (int dy = -r; dy <= r; ++dy) {
                 const int y = cy + dy; if (y < 0 || y >= NN_G) continue;
                 const bool shell_zy = (dz == -r || dz == r || dy == -r || dy == r);
-                const int step = (shell_zy || r == 0) ? 1 : 2 * r;
-                for (int dx = -r; dx <= r; dx += step) {
-                    const int x = cx + dx; if (x < 0 || x >= NN_G) continue;
-                    const int cell = (z * NN_G + y) * NN_G + x;
-                    const int s = cell_start[cell];
-                    if (s < 0) continue;
-                    const int e = cell_end[cell];
+                if (shell_zy || r == 0) {
+                    // a whole x-row of the shell: its cells are consecutive cell ids, and consecutive NON-EMPTY cells are consecutive ranges of spos --
+                    // one pass over [start of the first non-empty cell, end of the last one)
+                    int x0 = cx - r, x1 = cx + r;
+                    if (x0 < 0) x0 = 0;
+                    if (x1 > NN_G - 1) x1 = NN_G - 1;
+                    const int base = (z * NN_G + y) * NN_G;
+                    int s = -1, e = -1;
+                    for (int x = x0; x <= x1; ++x) {
+                        const int cs_ = cell_start[base + x];
+                        if (cs_ < 0) continue;
+                        if (s < 0) s = cs_;
+                        e = cell_end[base + x];
+                    }
                     for (int i = s; i < e; ++i) {
-                        const int j = vals[i];
-                        const float ddx = pos[3 * (long)j] - qx, ddy = pos[3 * (long)j + 1] - qy, ddz = pos[3 * (long)j + 2] - qz;
+                        const float4 c = spos[i];
+                        const int j = __float_as_int(c.w);
+                        const float ddx = c.x - qx, ddy = c.y - qy, ddz = c.z - qz;
                         const float d2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
                         if (d2 < best || (d2 == best && j < bi)) { best = d2; bi = j; }
+                    }
+                } else {
+                    for (int dx = -r; dx <= r; dx += 2 * r) {
+                        const int x = cx + dx; if (x < 0 || x >= NN_G) continue;
+                        const int cell = (z * NN_G + y) * NN_G + x;
+                        const int s = cell_start[cell];
+                        if (s < 0) continue;
+                        const int e = cell_end[cell];
+                        for (int i = s; i < e; ++i) {
+                            const float4 c = spos[i];
+                            const int j = __float_as_int(c.w);
+                            const float ddx = c.x - qx, ddy = c.y - qy, ddz = c.z - qz;
+                            const float d2 = (ddx * ddx + ddy * ddy) + ddz * ddz;
+                            if (d2 < best || (d2 == best && j < bi)) { best = d2; bi = j; }
+                        }
                     }
                 }
             }
@@ -124,7 +155,7 @@ __global__ __launch_bounds__(256) void nn_query_kernel(const float* pos, const s
 extern "C" size_t utx_nn_fill_workspace_bytes_impl(long T) {
     size_t tmp = 0;
     (void)rocprim::radix_sort_pairs(nullptr, tmp, (unsigned*)nullptr, (unsigned*)nullptr, (int*)nullptr, (int*)nullptr, (size_t)T, 0, 32, (hipStream_t)0);
-    return (size_t)T * 16 + (size_t)NN_G * NN_G * NN_G * 8 + tmp + 256;
+    return (size_t)T * 16 + (size_t)T * 16 + (size_t)NN_G * NN_G * NN_G * 8 + tmp + 512;
 }
 
 extern "C" int utx_launch_nn_fill(const float* pos, const void* winner, const float* rast2d, long T, float* atlas, int* nn_index,
@@ -133,16 +164,17 @@ extern "C" int utx_launch_nn_fill(const float* pos, const void* winner, const fl
     if (work_bytes < utx_nn_fill_workspace_bytes_impl(T)) return -2;
     unsigned* keys = (unsigned*)work; unsigned* keys_s = keys + T;
     int* vals = (int*)(keys_s + T); int* vals_s = vals + T;
-    int* cell_start = vals_s + T; int* cell_end = cell_start + NN_G * NN_G * NN_G;
-    void* tmp = (void*)(((uintptr_t)(cell_end + NN_G * NN_G * NN_G) + 255) & ~(uintptr_t)255);
+    float4* spos = (float4*)(((uintptr_t)(vals_s + T) + 15) & ~(uintptr_t)15);
+    int* cell_start = (int*)(spos + T); int* cell_end = cell_start + (size_t)NN_G * NN_G * NN_G;
+    void* tmp = (void*)(((uintptr_t)(cell_end + (size_t)NN_G * NN_G * NN_G) + 255) & ~(uintptr_t)255);
     size_t tmp_bytes = 0;
     if (rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys_s, vals, vals_s, (size_t)T, 0, 32, stream) != hipSuccess) return -7;
     const unsigned nb = (unsigned)((T + 255) / 256);
     if (hipMemsetAsync(cell_start, 0xff, (size_t)NN_G * NN_G * NN_G * 4, stream) != hipSuccess) return -7;
     hipLaunchKernelGGL(nn_keys_kernel, dim3(nb), dim3(256), 0, stream, pos, (const signed char*)winner, T, keys, vals);
     if (rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys_s, vals, vals_s, (size_t)T, 0, 32, stream) != hipSuccess) return -7;
-    hipLaunchKernelGGL(nn_bounds_kernel, dim3(nb), dim3(256), 0, stream, keys_s, T, cell_start, cell_end);
-    hipLaunchKernelGGL(nn_query_kernel, dim3(nb), dim3(256), 0, stream, pos, (const signed char*)winner, (const float4*)rast2d, T, vals_s,
+    hipLaunchKernelGGL(nn_bounds_kernel, dim3(nb), dim3(256), 0, stream, keys_s, vals_s, pos, T, cell_start, cell_end, spos);
+    hipLaunchKernelGGL(nn_query_kernel, dim3(nb), dim3(256), 0, stream, pos, (const signed char*)winner, (const float4*)rast2d, T, spos,
                        cell_start, cell_end, atlas, nn_index);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
