@@ -199,6 +199,9 @@ def main():
     ap.add_argument("--fp8", action="store_true",
                     help="BASELINE configs[4] numerics: the five big linears on OCP MX fp8 operands (utx_gemm_desc.mx8); NOT the default "
                          "bench line (the metric is quoted in bf16) -- reported with dtype 'mx-fp8 linears + bf16 attention'")
+    ap.add_argument("--fp8-attn", action="store_true",
+                    help="with --fp8: QK^T / PV on the fp8 matrix pipe as well (utx_attn_fwd_fp8, opt-in; N = 1).  Reported with its own dtype string; the "
+                         "roofline object then prices the attention launch against the 5 PF fp8 nameplate")
     ap.add_argument("--cpu-full-step", action="store_true",
                     help="CPU baseline on ONE COMPLETE 57-block step at BASELINE configs[0]'s shape (S = 9728) instead of 1 + 1 blocks: ~9 min of "
                          "host time, so not the default")
@@ -277,7 +280,9 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29655")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(dev))
         ulysses = True
-    model = FluxDiT(sd, shape, device=dev, sequence_parallel=ulysses, fp8_weights=args.fp8)
+    if args.fp8_attn and (world > 1 or args.sp_self_test):
+        raise SystemExit("--fp8-attn is a single-GPU option")
+    model = FluxDiT(sd, shape, device=dev, sequence_parallel=ulysses, fp8_weights=args.fp8, fp8_attention=args.fp8_attn)
     tex = synthetic_lora(sd, shape, rank=args.lora_rank, seed=1, device=dev)
     dlt = synthetic_lora(sd, shape, rank=args.lora_rank, seed=2, device=dev)
     model.set_lora([(tex, 1.0), (dlt, 0.0)])  # reference: weights_for_texture = [1, 0] (pipeline.py:110)
@@ -446,10 +451,13 @@ def main():
             "metric": "denoising-steps/sec", "value": value, "unit": "steps/s", "n_gpus": (group_info["ranks_counted_by_all_reduce"] if group_info else 1),
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak" if (world > 1 and not ulysses) else "strong", "vs_baseline": None,
-            "dtype": "mx-fp8 (e4m3 x E8M0/32) big linears + bf16 attention" if args.fp8 else "bf16", "data": "synthetic",
+            "dtype": ("mx-fp8 (e4m3 x E8M0/32) big linears + mx-fp8 attention (opt-in)" if args.fp8_attn else "mx-fp8 (e4m3 x E8M0/32) big linears + bf16 attention") if args.fp8
+            else ("bf16 linears + mx-fp8 attention (opt-in)" if args.fp8_attn else "bf16"), "data": "synthetic",
             "config": {"workload": args.workload, "description": desc, "tokens": S, "text_tokens": S_txt,
                        "noise_tokens": n_noise, "control_tokens": n_ctrl, "dual_tokens": n_dual,
                        "lora_rank": args.lora_rank, "guidance": 3.5, "launch": launch_path, "ms_per_step_hip_graph_replay": graph_ms, "parallelism": par,
+                       "text_half_of_double_blocks": "second HIP stream beside the image half (UTX_TXT_STREAM=1, opt-in)" if model.overlap_text else
+                       "on the caller's stream (default since round 4: the two-stream form is not reproducible run to run, DESIGN 9)",
                        "tokens_computed": S_exec, "text_dedup": None if model.text_rows is None else "512 identical text tokens carried as %d rows per rank, key weight 2^%.2f (SURVEY 7 last bullet; UTX_TEXT_DEDUP=0 disables)" % (model.text_rows, model.key_bias_log2),
                        "last_block_pruning": ("last block: queries / MLP / out-projection for the %d noise tokens only (the prediction of the condition tail is never read: "
                                               "flux_piplines/texturing/pipeline.py:645,660,684; UTX_PRUNE_LAST=0 disables)" % n_noise) if prune else None,
@@ -460,8 +468,8 @@ def main():
                        # wrong-result ablations do not exist in this library) and every UTX_* variable of the environment
                        "launch_options": _lib.get_options(), "gemm_launches_per_step": _gemm_census(model), "ablation_build": bool(_lib.load_library().utx_is_ablation_build()),
                        "env_UTX": {k: v for k, v in sorted(os.environ.items()) if k.startswith("UTX_")}},
-            "roofline": {"bound": "mfma", "kernel": "attn_fwd_glds_kernel", "launches_per_call": "full rounds + key-split tail round (same kernel) + attn_merge_kernel; a 'launch' below is one utx_attn_fwd_bf16 call", "achieved": achieved, "peak": PEAK_BF16_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+            "roofline": {"bound": "mfma", "kernel": "attn_fwd_fp8_kernel (+ three MX quantiser passes, not in the launch time)" if args.fp8_attn else "attn_fwd_glds_kernel", "launches_per_call": "full rounds + key-split tail round (same kernel) + attn_merge_kernel; a 'launch' below is one utx_attn_fwd_bf16 call", "achieved": achieved, "peak": 5000.0 if args.fp8_attn else PEAK_BF16_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / (5000.0 if args.fp8_attn else PEAK_BF16_TFLOPS), "traffic": None,
                          "launches_timed": len(attn_ms), "avg_launch_ms": attn_avg_ms,
                          "timed_in": "one extra step behind the timed region, HIP events on the launch stream around every attention call (the timed region itself carries no events: it is the product's launch path)",
                          "flops_per_launch": attn_launch_flops,
@@ -490,7 +498,7 @@ def main():
         # the per-launch figure is the one measured by tools/pmc_kernel.sh on THIS command and committed under profiles/
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(args.workload)
-            if tr and world == 1:
+            if tr and world == 1 and not args.fp8_attn:
                 out["roofline"]["traffic"] = tr["traffic_bytes_per_launch"]
                 out["roofline"]["traffic_unit"] = "bytes/launch (FETCH_SIZE x2 + WRITE_SIZE, %s)" % tr["source"]
                 out["roofline"]["algorithmic_hbm_bytes_per_launch"] = tr["algorithmic_bytes_per_launch"]

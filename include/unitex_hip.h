@@ -100,6 +100,18 @@ int utx_attn_fwd_bf16_ws(utx_ctx* ctx, const void* q, const void* k, const void*
                          int H, int S_q, int S_kv, float softmax_scale, float key_bias_log2, int key_bias_period,
                          void* work, size_t work_bytes, utx_stream stream);
 size_t utx_attn_workspace_bytes(utx_ctx* ctx, int H, int S_q, int S_kv);
+
+/* MX fp8 attention -- OPT-IN (BASELINE configs[4] "fp8 MFMA"; the reference has no fp8 path: the contract is this library's own and is a different numerics
+ * contract from the bf16 kernel above, with its own stated tolerance: tests/test_attention_fp8_gpu.py).  Same joint attention as utx_attn_fwd_bf16_kbq
+ * (attention_processor.py:31-110: softmax(Q K^T) V per head over the joint sequence; Q arrives pre-scaled by scale * log2(e), so scores are base-2 exponents)
+ * with Q K^T and P V on the fp8 matrix pipe: Q8 / K8 [H][S_pad][128] e4m3 bytes + qs / ks [H][S_pad] dwords (four E8M0 bytes per row: the 32-channel blocks
+ * of d) -- what utx_quant_mx8 makes of the head-major Q / K viewed as [H * S_pad, 128] with lds = 4; V8^T [H][128][S_pad] e4m3 + vs [H][S_pad / 32][32][4]
+ * E8M0 bytes per (block of 32 keys, channel d % 32, d / 32) -- what utx_quant_vt_mx8 makes of V^T [H][128][S_pad] bf16.  P is quantised to e4m3 with the unit
+ * scale inside the kernel (p <= 256 by the kernel's re-centring rule; p < 2^-9 flush to zero).  Output o [S_q][o_ss] bf16, head h in columns 128 h ..; S_q <=
+ * S_kv queries (the first S_q rows of Q8), S_pad = rows allocated (multiple of 64, pad rows zero); key_bias_* as utx_attn_fwd_bf16_kb. */
+int utx_quant_vt_mx8(utx_ctx* ctx, const void* vt, void* v8, void* vs, int H, int S_pad, utx_stream stream);
+int utx_attn_fwd_fp8(utx_ctx* ctx, const void* q8, const void* qs, const void* k8, const void* ks, const void* v8t, const void* vs, void* o, long o_ss,
+                     int H, int S_q, int S_kv, int S_pad, float key_bias_log2, int key_bias_period, utx_stream stream);
 int utx_attn_plan(int H, int S_q, int S_kv, int n_cus, int out[4]);
 /* The same on BLOCK-STRIDED operands: the S_kv tokens (queries and keys alike) come in blocks of blk_rows (a multiple of 64 that divides S_kv); block b of Q / K /
  * V^T of a head starts q_bs / k_bs / vt_bs elements (multiples of 8) behind block b - 1, rows inside a block are q_ss / k_ss apart, V^T rows vt_ds (each holding the

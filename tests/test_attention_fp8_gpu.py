@@ -1,0 +1,153 @@
+"""MX fp8 attention (utx_attn_fwd_fp8, csrc/attention_fp8.hip) -- OPT-IN, BASELINE configs[4] "fp8 MFMA".  The reference has no fp8 path; the contract is
+this library's own (include/unitex_hip.h) and these tests state it:
+  * EXACT on operands that e4m3 holds exactly (small integers, integer base-2 scores): every index -- the key permutation of the score MFMAs, the
+    byte order of P, the V^T chunks, the three scale layouts, the swizzles of both LDS tiles -- is pinned bit for bit against a dense fp64 evaluation;
+  * the quantisers are the OCP MX rule of oracle/mx8_ref.py, byte for byte;
+  * on random data: within the P-rounding tolerance of the exact attention over the DEQUANTISED operands, and a stated distance to the bf16 kernel."""
+import math
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import mx8_ref  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def _ops():
+    from unitex_amd.flux import ops
+    return ops
+
+
+def _dense(qd, kd, vd, S, key_bias=None):
+    """softmax_2(q k^T) v per head in fp64 on fp32 operands [H, S, 128] (scores are base-2 exponents); key_bias [S] added to the scores"""
+    s = qd.double() @ kd.double().transpose(1, 2)
+    if key_bias is not None:
+        s = s + key_bias.double()[None, None, :]
+    p = torch.exp2(s - s.max(-1, keepdim=True).values)
+    return ((p @ vd.double()) / p.sum(-1, keepdim=True)).float()          # [H, S, 128]
+
+
+def _pad(x, S_pad):
+    out = torch.zeros(x.shape[0], S_pad, x.shape[2], dtype=x.dtype)
+    out[:, : x.shape[1]] = x
+    return out
+
+
+@pytest.mark.parametrize("H,S,S_q,kb", [(2, 256, None, 0.0), (3, 1000, None, 0.0), (2, 1536, 700, 3.0), (1, 64, None, 0.0), (24, 2048, None, 0.0)])
+def test_fp8_attention_is_exact_on_exactly_representable_operands(H, S, S_q, kb):
+    ops = _ops()
+    g = torch.Generator().manual_seed(H * 1000 + S)
+    S_pad = (S + 63) // 64 * 64
+    # base-2 scores that are SMALL INTEGERS, so that every p = 2^(s - m) is a power of two e4m3 holds exactly and nothing that matters flushes:
+    #   k rows: three non-zero channels of value +-1 or +-2 (the 32-channel blocks of a row have amax 0, 1 or 2 -> three different E8M0 bytes);
+    #   q rows: even rows one-hot (value 1 or 2 in ONE random channel: every channel index is exercised across the queries, the other three blocks are
+    #           all-zero blocks), odd rows all ones (the full 128-channel sum);  v: integers x a power of two per (channel, block of 32 keys)
+    k = torch.zeros(H, S, 128)
+    for _ in range(3):
+        ch = torch.randint(0, 128, (H, S, 1), generator=g)
+        val = (torch.randint(0, 2, (H, S, 1), generator=g) * 2 - 1).float() * torch.exp2(torch.randint(0, 2, (H, S, 1), generator=g).float())
+        k.scatter_(2, ch, val)
+    q = torch.ones(H, S, 128)
+    hot = torch.zeros(H, S, 128).scatter_(2, torch.randint(0, 128, (H, S, 1), generator=g), torch.exp2(torch.randint(0, 2, (H, S, 1), generator=g).float()))
+    q[:, 0::2] = hot[:, 0::2]
+    ev = torch.randint(-3, 4, (H, 128, S_pad // 32, 1), generator=g).float()
+    vt = (torch.randint(-7, 8, (H, 128, S_pad // 32, 32), generator=g).float() * torch.exp2(ev)).reshape(H, 128, S_pad)
+    vt[:, :, S:] = 0
+    qh, kh = _pad(q, S_pad).to(BF).cuda(), _pad(k, S_pad).to(BF).cuda()
+    vtd = vt.to(BF).cuda()
+    q8, qs = ops.quant_qk_mx8(qh)
+    k8, ks = ops.quant_qk_mx8(kh)
+    v8, vs = ops.quant_vt_mx8(vtd)
+    # the quantisers: OCP MX, byte for byte, and lossless on this data
+    rq, rs = mx8_ref.quantize(_pad(q, S_pad).to(BF).reshape(H * S_pad, 128))
+    assert torch.equal(q8.cpu().reshape(H * S_pad, 128), rq) and torch.equal(qs.cpu().reshape(H * S_pad, 4), rs)
+    assert torch.equal(mx8_ref.dequantize(rq, rs).reshape(H, S_pad, 128)[:, :S], q)
+    rv, rvs = mx8_ref.quantize(vt.to(BF).reshape(H * 128, S_pad))
+    assert torch.equal(v8.cpu().reshape(H * 128, S_pad), rv)
+    assert torch.equal(vs.cpu().permute(0, 3, 2, 1).reshape(H * 128, S_pad // 32), rvs), "V^T scales [H][kb][d % 32][d / 32] <-> row-major [H * 128][kb]"
+    nq = S if S_q is None else S_q
+    kbias = None
+    if kb:
+        kbias = torch.zeros(S); kbias[:64] = kb                 # key multiplicity of tile 0 (the de-duplicated text tokens)
+    out = ops.attention_fp8(q8, qs, k8, ks, v8, vs, S=S, S_q=nq, key_bias_log2=kb).float().cpu()
+    torch.cuda.synchronize()
+    ref = _dense(q, k, vt[:, :, :S].transpose(1, 2), S, kbias)[:, :nq].permute(1, 0, 2).reshape(nq, H * 128)
+    err = (out - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    # exact up to the bf16 rounding of the output and fp32 accumulation; weights below 2^-9 of the running maximum flush (their total share is < 2^-9 S / 1)
+    assert err <= 0.012 * max(scale, 1.0), "H=%d S=%d: max err %g (ref max %g)" % (H, S, err, scale)
+    assert (out - ref).abs().mean().item() <= 0.0015 * max(scale, 1.0)
+
+
+@pytest.mark.parametrize("H,S", [(4, 4096), (24, 9280)])
+def test_fp8_attention_on_random_data_tolerance_and_distance_to_the_bf16_kernel(H, S):
+    """FLUX-like statistics: q, k RMS-normalised rows (x the pre-scale), v ~ N(0, 1).  (a) against the exact attention over the DEQUANTISED operands (what the
+    MFMAs see) only the e4m3 rounding of P (and its flush below 2^-9) is left: <= 5 % of max|O|, mean <= 0.3 % (measured 3.2 % / 0.15 %); (b) against the bf16
+    kernel on the unquantised operands the e4m3 rounding of Q and K enters through the exponential: with scores of std ~3 in base-2 units (a peaked softmax)
+    measured max 21 %, mean 0.6 % of max|O|, relative Frobenius 10 % -- asserted at max <= 30 %, mean <= 1 %, Frobenius <= 13 %.  THAT is the fp8 attention
+    contract: a per-layer perturbation of the attention branch of this size; its image-level effect is stated in tests/test_e2e_tolerance_gpu.py."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(S)
+    S_pad = (S + 63) // 64 * 64
+    qscale = (1.0 / math.sqrt(128.0)) * 1.4426950408889634
+    q = torch.randn(H, S, 128, generator=g); q = q / q.pow(2).mean(-1, keepdim=True).sqrt() * 1.5 * qscale
+    k = torch.randn(H, S, 128, generator=g); k = k / k.pow(2).mean(-1, keepdim=True).sqrt() * 1.5
+    v = torch.randn(H, S, 128, generator=g)
+    qh, kh = _pad(q, S_pad).to(BF).cuda(), _pad(k, S_pad).to(BF).cuda()
+    vtd = _pad(v, S_pad).transpose(1, 2).contiguous().to(BF).cuda()
+    q8, qs = ops.quant_qk_mx8(qh); k8, ks = ops.quant_qk_mx8(kh); v8, vs = ops.quant_vt_mx8(vtd)
+    out8 = ops.attention_fp8(q8, qs, k8, ks, v8, vs, S=S).float().cpu()
+    out16 = ops.attention(qh, kh, vtd, S=S, scale=0.0).float().cpu()
+    torch.cuda.synchronize()
+    assert torch.isfinite(out8).all()
+    rows = torch.randperm(S, generator=g)[:256].sort().values
+    qd = mx8_ref.dequantize(q8.cpu().reshape(H * S_pad, 128), qs.cpu().reshape(H * S_pad, 4)).reshape(H, S_pad, 128)[:, rows]
+    kd = mx8_ref.dequantize(k8.cpu().reshape(H * S_pad, 128), ks.cpu().reshape(H * S_pad, 4)).reshape(H, S_pad, 128)[:, :S]
+    vd = mx8_ref.dequantize(v8.cpu().reshape(H * 128, S_pad), vs.cpu().permute(0, 3, 2, 1).reshape(H * 128, S_pad // 32)).reshape(H, 128, S_pad)[:, :, :S].transpose(1, 2)
+    ref_deq = _dense(qd, kd, vd, S).permute(1, 0, 2).reshape(len(rows), H * 128)
+    mx = ref_deq.abs().max().item()
+    d_a = (out8[rows] - ref_deq).abs()
+    d_b = (out8 - out16).abs()
+    rel_f = ((out8 - out16).pow(2).sum() / out16.pow(2).sum()).sqrt().item()
+    print("\n[fp8 attention H=%d S=%d] vs exact over dequantised operands (sampled rows): max %.4g = %.3f %% of max|O| %.3g, mean %.3f %%; vs the bf16 kernel: max %.3f %%, "
+          "mean %.3f %%, rel. Frobenius %.3f %%" % (H, S, d_a.max().item(), 100 * d_a.max().item() / mx, mx, 100 * d_a.mean().item() / mx,
+                                                   100 * d_b.max().item() / mx, 100 * d_b.mean().item() / mx, 100 * rel_f))
+    assert d_a.max().item() <= 0.05 * mx and d_a.mean().item() <= 0.003 * mx
+    assert d_b.max().item() <= 0.30 * mx and d_b.mean().item() <= 0.01 * mx and rel_f <= 0.13
+
+
+def test_fluxdit_with_fp8_attention_runs_the_fp8_kernel_and_stays_close_to_the_bf16_forward():
+    """FluxDiT(fp8_attention=True): the plan carries the three quantiser passes and utx_attn_fwd_fp8 per block (also in the pruned last block and with the
+    de-duplicated text tokens' key weight); a tiny 2 + 2-block forward stays within 6 % of max|out| of the bf16 forward (mean <= 1 %)."""
+    from oracle import dit_ref
+    from unitex_amd.flux.transformer import FluxDiT, FluxShape
+    cfg = dit_ref.tiny_config(heads=2, double=2, single=2, joint_dim=64, pooled_dim=64)
+    sd = dit_ref.make_synthetic_state_dict(cfg, seed=0)
+    shape = FluxShape(num_heads=2, num_double=2, num_single=2, joint_dim=64, pooled_dim=64)
+    S_txt = 128
+    img_ids = torch.cat([dit_ref.latent_image_ids(8, 24), dit_ref.latent_image_ids(8, 24, offset_y=8), dit_ref.latent_image_ids(4, 4, offset_x=24, offset_y=8)], 0)
+    g = torch.Generator().manual_seed(12)
+    lat = torch.randn(img_ids.shape[0], 64, generator=g).to(BF).cuda()
+    enc = torch.zeros(S_txt, 64).to(BF).cuda(); pooled = torch.zeros(1, 64).to(BF).cuda()      # zero text: the de-duplicated path (key bias on tile 0)
+    outs = {}
+    for name, kw in (("bf16", {}), ("fp8-attn", dict(fp8_attention=True))):
+        m = FluxDiT(sd, shape, device="cuda:0", **kw)
+        m.set_positions(torch.zeros(S_txt, 3), img_ids)
+        m.set_output_rows(192)
+        m.set_conditioning(enc, pooled, 3.5)
+        if kw:
+            kinds = [fn for fn, _ in next(iter(m._plans.values()))["plan"] if isinstance(fn, str)]
+            assert kinds.count("attn8") == 4 and kinds.count("quant_qk") == 8 and kinds.count("quant_vt") == 4 and m.key_bias_log2 > 0
+        outs[name] = m.forward(lat, 0.5)[:192].float().cpu()
+        torch.cuda.synchronize()
+    mx = outs["bf16"].abs().max().item()
+    d = (outs["fp8-attn"] - outs["bf16"]).abs()
+    print("\n[FluxDiT fp8 attention, tiny 2 + 2 blocks] vs the bf16 forward: max %.3f %%, mean %.3f %% of max|out| %.3g" % (100 * d.max().item() / mx, 100 * d.mean().item() / mx, mx))
+    assert torch.isfinite(outs["fp8-attn"]).all()
+    assert d.max().item() <= 0.06 * mx and d.mean().item() <= 0.01 * mx

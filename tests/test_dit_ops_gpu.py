@@ -560,6 +560,7 @@ def _sp_worker(rank, world, port, q, zero_text=False, groups=1):
         os.environ["UTX_SP_ZERO_COPY"] = "1"
         groups = -groups
     os.environ["UTX_SP_GROUPS"] = str(groups)      # head groups per rank whose exchanges are pipelined with attention (ulysses.pick_head_groups)
+    os.environ["UTX_TXT_STREAM"] = "1"             # the opt-in two-stream form of the double blocks (off by default since round 4) stays covered here
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import dit_ref as R
     from unitex_amd.flux.transformer import FluxDiT, FluxShape
@@ -722,6 +723,7 @@ def test_c_side_plan_replay_is_bit_identical_to_the_python_launch_list(fp8):
     img_ids = torch.cat([dit_ref.latent_image_ids(8, 24), dit_ref.latent_image_ids(8, 24, offset_y=8),
                          dit_ref.latent_image_ids(4, 4, offset_x=24, offset_y=8)], 0)
     m = FluxDiT(sd, shape, device="cuda:0", fp8_weights=fp8)
+    m.set_text_stream(True)      # the opt-in two-stream form (off by default since round 4): fork / join entries in the C plan
     m.set_lora([(dit_ref.make_synthetic_lora(cfg, sd, rank=16, seed=2), 1.0)])
     m.set_positions(txt_ids, img_ids)
     m.set_output_rows(192)

@@ -164,7 +164,7 @@ def _smooth_image(h, w, seed):
     return (img[0].permute(1, 2, 0).numpy() * 255).round().astype(np.uint8)
 
 
-@pytest.mark.parametrize("mode", ["bf16", "fp8"])
+@pytest.mark.parametrize("mode", ["bf16", "fp8", "fp8-attn"])
 def test_full_schedule_28_steps_two_passes_with_uint8_handoff(mode):
     """THE REAL SCHEDULE: /root/reference/pipeline.py:246-289 -- texture pass, 28 steps (control image + reference image, texture adapter
     on) -> uint8 image -> delight pass, 28 more steps with THAT image as the control image (delight adapter on) -> uint8 image; each pass is one
@@ -188,7 +188,9 @@ def test_full_schedule_28_steps_two_passes_with_uint8_handoff(mode):
     control = _smooth_image(H, W, 5)
     reference = _smooth_image(64, 64, 6)
     # ---- product: the reference's call sequence
-    tr = FluxDiT(sd, shape, device=DEV, fp8_weights=(mode == "fp8"))
+    tr = FluxDiT(sd, shape, device=DEV, fp8_weights=(mode != "bf16"), fp8_attention=(mode == "fp8-attn"))
+    if mode == "fp8-attn":
+        assert tr.fp8_attention
     pipe = PBRFluxPipeline(tr, AutoencoderKL(vsd, device=DEV), device=DEV)
     pipe.load_lora_weights(la, "texture")
     pipe.load_lora_weights(lb, "delight")
@@ -230,11 +232,19 @@ def test_full_schedule_28_steps_two_passes_with_uint8_handoff(mode):
     if mode == "bf16":
         assert h_tex[2] >= 0.99 and h_tex[4] >= 0.999 and mx_tex <= 8
         assert h_out[2] >= 0.99 and h_out[4] >= 0.999 and mx_out <= 8
+    elif mode == "fp8":
+        assert h_tex[2] >= 0.95 and h_tex[4] >= 0.995 and mx_tex <= 12
+        assert h_out[2] >= 0.95 and h_out[4] >= 0.995 and mx_out <= 12
     else:
+        # MX fp8 linears AND MX fp8 attention (opt-in): e4m3 Q / K enter through the exponential -- a per-layer perturbation of the attention branch of a few
+        # per cent (tests/test_attention_fp8_gpu.py); what it does to the image after the full schedule is STATED here, asserted loosely
+        # measured (profiles/r04_attn_fp8_e2e.log): 48 % equal / 86.5 % within 1 LSB / 98.3 % within 2 / max 5 -- on this tiny 2-head network indistinguishable from
+        # fp8 linears alone; a peaked full-size softmax is perturbed more per layer (10 % relative Frobenius on the attention output in test_attention_fp8_gpu.py)
         assert h_tex[2] >= 0.95 and h_tex[4] >= 0.995 and mx_tex <= 12
         assert h_out[2] >= 0.95 and h_out[4] >= 0.995 and mx_out <= 12
     # the product is no further from plain fp32 than the reference's own bf16 arithmetic is (the emulating oracle): mean LSB distance within 10 % of each other
-    assert rows[2][3] <= 1.10 * rows[3][3] + 0.1
+    # (fp8 attention: within 35 %)
+    assert rows[2][3] <= (1.35 if mode == "fp8-attn" else 1.10) * rows[3][3] + 0.1
 
 
 class _HostView:

@@ -145,6 +145,8 @@ SYMBOLS = {
     "utx_attn_fwd_bf16_blk": (c_int, [c_void_p] * 5 + [c_long] * 7 + [c_int, c_int, c_int, c_float, c_float, c_int, c_void_p, C.c_size_t, c_int, c_long, c_long, c_long,
                                       c_void_p]),
     "utx_attn_workspace_bytes": (C.c_size_t, [c_void_p, c_int, c_int, c_int]),
+    "utx_quant_vt_mx8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "utx_attn_fwd_fp8": (c_int, [c_void_p] * 8 + [c_long, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "utx_attn_plan": (c_int, [c_int, c_int, c_int, c_int, c_void_p]),
     "utx_gemm_bf16": (c_int, [c_void_p, C.POINTER(GemmDesc), c_void_p]),
     "utx_gemm_streamk_workspace_bytes": (C.c_size_t, [c_void_p]),

@@ -1,0 +1,316 @@
+// MX fp8 flash-attention forward (gfx950) -- OPT-IN (FluxDiT(fp8_attention=True) / speedup_mode="fp8-attn"), never the default and never the bf16 bench line.
+//
+// BASELINE configs[4] asks for fp8 MFMA; with the five big linears on MX fp8 (gemm_w4.hip, MX) the bf16 attention is 81 % of the step, so the only
+// lever left on that configuration is QK^T and PV on the fp8 matrix pipe (v_mfma_scale_f32_32x32x64_f8f6f4: twice the bf16 rate per k element).
+// Same structure as attention_glds.hip -- 8 waves x 32 queries, 64-key tiles staged by LDS-DMA into a 2-slot ring, swapped QK^T (a lane owns a query
+// column: in-register softmax), sum-checked softmax with rare exact re-centring, accumulators start at -m -- on OCP MX operands:
+//   Q8, K8  [H][S_pad][128] e4m3 bytes + one dword of four E8M0 scales per row (the 32-channel blocks of d)      <- utx_quant_mx8 of the head-major Q / K
+//   V8^T    [H][128][S_pad] e4m3 bytes + E8M0 per (channel, block of 32 KEYS), stored [H][S_pad/32][32][4]      <- utx_quant_vt_mx8 (this file)
+//   P       e4m3 with the unit scale: the sum check keeps every p <= 256 (< 448); p below 2^-9 flush to zero (the published fp8 attention kernels accept
+//           the same: a weight that small relative to the running maximum)
+// so the MFMA's block scales carry the dynamic range of Q, K and V and no amax pass over a tensor is needed.
+// Operand layout of the 32 x 32 x 64 MFMA (gemm_w4.hip, tools/mx_probe.hip): lane (row, h) holds k = 16 h .. 16 h + 15 of the first 32-element scale
+// block in bytes 0-15 and k = 32 + 16 h .. of the second in bytes 16-31; block-0 scales come from lanes 0-31, block-1 scales from lanes 32-63 (byte
+// op_sel of the scale register).
+//   QK^T (S^T = K Q^T): two MFMAs per 32-key block (d 0-63, 64-127).  MFMA row i = 8a + 4h' + c reads key kappa(i) = 16h' + 4a + c of the block, so that
+//        the C layout -- lane (q, h) register r = 4a + c holds row 8a + 4h + c -- IS key 16 h + r: converted to fp8 in register order, the 16 values of
+//        block 0 are bytes 0-15 and those of block 1 bytes 16-31 of the PV MFMA's B operand over the tile's 64 keys in their natural order.  No LDS
+//        round trip, no permute, and V^T is read as it lies.
+//   PV   (O^T += V^T P): ONE MFMA per 32-channel block of d over the 64 keys of the tile; A = V8^T rows (16-byte chunks h and 2 + h of the 64-byte row).
+// Per 64-key tile and wave: 4 + 4 MFMAs of 64 cycles = 512 matrix-pipe cycles against 1024 of the bf16 kernel; the VALU work (32 exp2, sums, packing)
+// is unchanged and now dominates.
+// LDS tiles (lane-linear DMA images, swizzled on the SOURCE address and on the fragment read):
+//   K8 tile [64 keys][128 B]: 16-byte slot = chunk ^ ((row >> 1) & 7);  V8^T tile [128 d][64 B]: slot = chunk ^ ((row >> 2) & 3)
+// both conflict-free for the ds_read_b128 lane groups {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} with the row permutation above.
+#include "common.h"
+#include "kernels.h"
+
+#define A8_KVB 64
+#define A8_KTILE 8192
+#define A8_VTILE 8192
+#define A8_LDS (2 * (A8_KTILE + A8_VTILE))
+
+typedef int a8_i32x8 __attribute__((ext_vector_type(8)));
+typedef int a8_i32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void a8_glds16(const uint8_t* g, char* lds) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+
+// a 32-byte MFMA operand from two 16-byte LDS chunks
+__device__ __forceinline__ a8_i32x8 a8_frag(const char* plo, const char* phi) {
+    const a8_i32x4 lo = *reinterpret_cast<const a8_i32x4*>(plo), hi = *reinterpret_cast<const a8_i32x4*>(phi);
+    return a8_i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+__global__ __launch_bounds__(512, 2) void attn_fwd_fp8_kernel(Attn8Params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const kring = smem;
+    char* const vring = smem + 2 * A8_KTILE;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lq = lane & 31, lh = lane >> 5;
+
+    const int wid = xcd_remap(blockIdx.x, gridDim.x);
+    const int head = wid / p.nqb;
+    const int qb = wid - head * p.nqb;
+    const int S = p.S;
+    const int Sq = p.Sq > 0 ? p.Sq : p.S;
+    const uint8_t* const kbase = p.k8 + (long)head * p.S_pad * 128;
+    const uint8_t* const vbase = p.v8t + (long)head * 128 * p.S_pad;
+    const uint32_t* const ksb = p.ks + (long)head * p.S_pad;
+    const uint32_t* const vsb = p.vs + (long)head * (p.S_pad / 32) * 32;
+
+    const int q0 = qb * 256 + wave * 32;
+    a8_i32x8 qf[2];
+    int qsc;
+    {
+        int qrow = q0 + lq;
+        if (qrow > Sq - 1) qrow = Sq - 1;
+        const uint8_t* qp = p.q8 + ((long)head * p.S_pad + qrow) * 128 + 16 * lh;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const a8_i32x4 lo = *reinterpret_cast<const a8_i32x4*>(qp + 64 * m), hi = *reinterpret_cast<const a8_i32x4*>(qp + 64 * m + 32);
+            qf[m] = a8_i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+        qsc = (int)(p.qs[(long)head * p.S_pad + qrow] >> (8 * lh));      // lanes 32-63 supply the scale of the second 32-channel block of every MFMA
+    }
+
+    // ---- DMA sources: one wave-instruction per operand and tile (1 KB = 8 K rows / 16 V^T rows), slot -> global chunk by the swizzle
+    const int krow_d = 8 * wave + (lane >> 3);
+    const uint8_t* const ksrc = kbase + (long)krow_d * 128 + (((lane & 7) ^ ((krow_d >> 1) & 7)) << 4);
+    const int vrow_d = 16 * wave + (lane >> 2);
+    const uint8_t* const vsrc = vbase + (long)vrow_d * p.S_pad + (((lane & 3) ^ ((vrow_d >> 2) & 3)) << 4);
+    const int dma_off = wave * 1024;
+#define A8_STAGE(t_, slot_)                                                                      \
+    do {                                                                                         \
+        a8_glds16(ksrc + (long)(t_) * (A8_KVB * 128), kring + (slot_) * A8_KTILE + dma_off);     \
+        a8_glds16(vsrc + (long)(t_) * A8_KVB, vring + (slot_) * A8_VTILE + dma_off);             \
+    } while (0)
+
+    // ---- fragment read offsets
+    const int krow = 16 * ((lq >> 2) & 1) + 4 * (lq >> 3) + (lq & 3);      // kappa(lq)
+    const int kswz = (krow >> 1) & 7, vswz = (lq >> 2) & 3;
+    int kx[2][2], vx[2];      // K: [m][e] byte offset of (row kappa, chunk 4m + 2e + lh); V: [e] of (row lq, chunk 2e + lh)
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) kx[m][e] = krow * 128 + (((4 * m + 2 * e + lh) ^ kswz) << 4);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) vx[e] = lq * 64 + (((2 * e + lh) ^ vswz) << 4);
+
+    f32x16 oacc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+    float m_run = 0.f, l_run = 0.f;
+    f32x16 negm;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) negm[r] = 0.f;
+    const int one_scale = 0x7f7f7f7f;      // E8M0 127 = 2^0: P carries no block scale
+
+    const int nt = (S + A8_KVB - 1) / A8_KVB;
+    A8_STAGE(0, 0);
+    // the scales of tile 0: K rows kappa(lq) of both 32-key blocks (pre-shifted for the upper half-wave), V^T blocks 0 / 1
+    int ksc0 = (int)(ksb[krow] >> (8 * lh)), ksc1 = (int)(ksb[32 + krow] >> (8 * lh));
+    int vsc = (int)vsb[lh * 32 + lq];
+    __syncthreads();
+
+#define A8_FRAG(plo_, phi_) a8_frag(plo_, phi_)
+    // p = 2^s of the 16 scores of a block -> row-sum share and the four dwords of e4m3 bytes in register order
+#define A8_EXPB(sa_, d0_, d1_, d2_, d3_, ps_)                                                            \
+    {                                                                                                    \
+        float pv_[16];                                                                                   \
+        float sc0_ = 0.f, sc1_ = 0.f;                                                                    \
+        _Pragma("unroll") for (int r = 0; r < 16; r += 2) {                                              \
+            pv_[r] = __builtin_amdgcn_exp2f(sa_[r]); pv_[r + 1] = __builtin_amdgcn_exp2f(sa_[r + 1]);    \
+            sc0_ += pv_[r]; sc1_ += pv_[r + 1];                                                          \
+        }                                                                                                \
+        ps_ = sc0_ + sc1_;                                                                               \
+        int w_;                                                                                          \
+        w_ = __builtin_amdgcn_cvt_pk_fp8_f32(pv_[0], pv_[1], 0, false); d0_ = __builtin_amdgcn_cvt_pk_fp8_f32(pv_[2], pv_[3], w_, true);      \
+        w_ = __builtin_amdgcn_cvt_pk_fp8_f32(pv_[4], pv_[5], 0, false); d1_ = __builtin_amdgcn_cvt_pk_fp8_f32(pv_[6], pv_[7], w_, true);      \
+        w_ = __builtin_amdgcn_cvt_pk_fp8_f32(pv_[8], pv_[9], 0, false); d2_ = __builtin_amdgcn_cvt_pk_fp8_f32(pv_[10], pv_[11], w_, true);    \
+        w_ = __builtin_amdgcn_cvt_pk_fp8_f32(pv_[12], pv_[13], 0, false); d3_ = __builtin_amdgcn_cvt_pk_fp8_f32(pv_[14], pv_[15], w_, true);  \
+    }
+
+    a8_i32x8 vf[4], pb;
+    int vsc_pv = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) vf[i] = a8_i32x8{0, 0, 0, 0, 0, 0, 0, 0};
+    pb = a8_i32x8{0, 0, 0, 0, 0, 0, 0, 0};
+    for (int t = 0; t < nt; ++t) {
+        const int slot = t & 1;
+        int ksc0n = 0, ksc1n = 0, vscn = 0;
+        if (t + 1 < nt) {
+            A8_STAGE(t + 1, slot ^ 1);
+            const long kr = (long)(t + 1) * A8_KVB + krow;
+            ksc0n = (int)(ksb[kr] >> (8 * lh)); ksc1n = (int)(ksb[kr + 32] >> (8 * lh));
+            vscn = (int)vsb[(long)(2 * (t + 1) + lh) * 32 + lq];
+        }
+        const char* kb = kring + slot * A8_KTILE;
+        const char* vb = vring + slot * A8_VTILE;
+        const bool ragged = (t == nt - 1) && (S & (A8_KVB - 1));
+        const int lim = S - t * A8_KVB - 16 * lh;      // register r of block b is key 32 b + 16 lh + r of the tile
+        const bool kbias = (p.key_bias_log2 != 0.f) && (p.key_bias_period > 0 ? (t % p.key_bias_period == 0) : (t == 0));
+
+        // ---- QK^T: both 32-key blocks, scores come out as s - m_run (the accumulators start at -m)
+        f32x16 sa0, sa1;
+        {
+            const a8_i32x8 k00 = A8_FRAG(kb + kx[0][0], kb + kx[0][1]);
+            const a8_i32x8 k01 = A8_FRAG(kb + kx[1][0], kb + kx[1][1]);
+            const a8_i32x8 k10 = A8_FRAG(kb + 4096 + kx[0][0], kb + 4096 + kx[0][1]);
+            const a8_i32x8 k11 = A8_FRAG(kb + 4096 + kx[1][0], kb + 4096 + kx[1][1]);
+            __builtin_amdgcn_s_setprio(1);
+            sa0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(k00, qf[0], negm, 0, 0, 0, ksc0, 0, qsc);
+            sa0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(k01, qf[1], sa0, 0, 0, 2, ksc0, 2, qsc);
+            sa1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(k10, qf[0], negm, 0, 0, 0, ksc1, 0, qsc);
+            sa1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(k11, qf[1], sa1, 0, 0, 2, ksc1, 2, qsc);
+        }
+        // ---- PV of the PREVIOUS tile, issued right behind this tile's score MFMAs: the matrix pipe runs QK(t) + PV(t-1) back to back (512 cycles) while the
+        // exponentials of this tile (the VALU bulk of a tile, ~800 cycles) start as soon as QK(t) has landed -- PV hides under them.  P(t-1) / V^T(t-1) stay in
+        // registers across the barrier; a re-centring in this tile rescales oacc AFTER these MFMAs (a data dependency the compiler sees).
+        if (t > 0) {
+            oacc[0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf[0], pb, oacc[0], 0, 0, 0, vsc_pv, 0, one_scale);
+            oacc[1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf[1], pb, oacc[1], 0, 0, 1, vsc_pv, 0, one_scale);
+            oacc[2] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf[2], pb, oacc[2], 0, 0, 2, vsc_pv, 0, one_scale);
+            oacc[3] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf[3], pb, oacc[3], 0, 0, 3, vsc_pv, 0, one_scale);
+        }
+        // this tile's V^T fragments (consumed at the top of the next iteration)
+#pragma unroll
+        for (int db = 0; db < 4; ++db) vf[db] = A8_FRAG(vb + db * 2048 + vx[0], vb + db * 2048 + vx[1]);
+        vsc_pv = vsc;
+        if (kbias) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sa0[r] += p.key_bias_log2; sa1[r] += p.key_bias_log2; }
+        }
+        if (ragged) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (r >= lim) sa0[r] = -INFINITY;
+                if (32 + r >= lim) sa1[r] = -INFINITY;
+            }
+        }
+        int pb0, pb1, pb2, pb3, pb4, pb5, pb6, pb7;
+        float ps0, ps1;
+        A8_EXPB(sa0, pb0, pb1, pb2, pb3, ps0)
+        A8_EXPB(sa1, pb4, pb5, pb6, pb7, ps1)
+        if (t == 0 || ragged || !__all(ps0 <= 256.0f && ps1 <= 256.0f)) {
+            // exact re-centring on the tile's maximum (first tile: set it): m_run += d, everything accumulated so far shrinks by 2^-d
+            float mx = fmaxf(sa0[0], sa1[0]);
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(sa0[r], sa1[r]));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float d = (t == 0) ? mx : fmaxf(mx, 0.f);
+            const float alpha = (t == 0) ? 1.0f : __builtin_amdgcn_exp2f(-d);
+            m_run += d;
+            l_run *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { negm[r] = -m_run; sa0[r] -= d; sa1[r] -= d; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+            A8_EXPB(sa0, pb0, pb1, pb2, pb3, ps0)
+            A8_EXPB(sa1, pb4, pb5, pb6, pb7, ps1)
+        }
+        l_run += ps0 + ps1;
+        pb = a8_i32x8{pb0, pb1, pb2, pb3, pb4, pb5, pb6, pb7};      // P of this tile: the B operand of the PV MFMAs issued in the next iteration (or behind the loop)
+        __builtin_amdgcn_s_setprio(0);
+        ksc0 = ksc0n; ksc1 = ksc1n; vsc = vscn;
+        __syncthreads();     // this slot fully read by every wave; the next tile's DMA retired by the vmcnt(0) of this fence
+    }
+
+    // PV of the last tile
+    oacc[0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf[0], pb, oacc[0], 0, 0, 0, vsc_pv, 0, one_scale);
+    oacc[1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf[1], pb, oacc[1], 0, 0, 1, vsc_pv, 0, one_scale);
+    oacc[2] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf[2], pb, oacc[2], 0, 0, 2, vsc_pv, 0, one_scale);
+    oacc[3] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf[3], pb, oacc[3], 0, 0, 3, vsc_pv, 0, one_scale);
+
+    // ---- epilogue (the bf16 kernel's): lane (q, h) holds O[q][32 db + 8a + 4h + c], r = 4a + c
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int qrow = q0 + lq;
+    if (qrow < Sq) {
+        bf16_t* const o8 = p.o + (long)qrow * p.o_ss + head * 128 + 4 * lh;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                uint2 v;
+                v.x = pack2bf(oacc[db][4 * a + 0] * inv, oacc[db][4 * a + 1] * inv);
+                v.y = pack2bf(oacc[db][4 * a + 2] * inv, oacc[db][4 * a + 3] * inv);
+                *reinterpret_cast<uint2*>(o8 + 32 * db + 8 * a) = v;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// MX quantiser of V^T along the KEYS: Vt [H][128][S_pad] bf16 -> V8 [H][128][S_pad] e4m3 bytes + E8M0 per (head, channel d, block of 32 keys) stored
+// [H][S_pad / 32][d % 32][d / 32] (a lane of the attention kernel reads the four scale bytes of its row d % 32 -- one per 32-channel block -- as ONE dword).
+// One thread per (row, key block): 64 B read, 32 B + 1 scale byte written; the quantisation rule of utx_quant_mx8 (OCP MX: e = floor(log2(amax)) - 8).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void quant_vt_mx8_kernel(const bf16_t* __restrict__ vt, uint8_t* __restrict__ v8, uint8_t* __restrict__ vs, int H, int S_pad) {
+    const int nkb = S_pad / 32;
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)H * 128 * nkb) return;
+    const int kb = (int)(t % nkb);
+    const long row = t / nkb;                 // head * 128 + d
+    const int d = (int)(row & 127), head = (int)(row >> 7);
+    const bf16_t* src = vt + row * S_pad + kb * 32;
+    float v[32];
+    float amax = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(src + 8 * c);
+        const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[8 * c + 2 * j] = bf2f((uint16_t)(w[j] & 0xffff)); v[8 * c + 2 * j + 1] = bf2f((uint16_t)(w[j] >> 16));
+            amax = fmaxf(amax, fmaxf(fabsf(v[8 * c + 2 * j]), fabsf(v[8 * c + 2 * j + 1])));
+        }
+    }
+    int e = (int)((__float_as_uint(amax) >> 23) & 0xff) - 127 - 8;
+    if (amax == 0.f || e < -127) e = -127;
+    if (e > 127) e = 127;
+    const float inv = __uint_as_float((uint32_t)(127 - e) << 23);
+    uint32_t out[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float a[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a[c] = fminf(fmaxf(v[4 * j + c] * inv, -448.f), 448.f);
+        int pk = 0;
+        pk = __builtin_amdgcn_cvt_pk_fp8_f32(a[0], a[1], pk, false);
+        pk = __builtin_amdgcn_cvt_pk_fp8_f32(a[2], a[3], pk, true);
+        out[j] = (uint32_t)pk;
+    }
+    uint4* dst = reinterpret_cast<uint4*>(v8 + row * S_pad + kb * 32);
+    dst[0] = make_uint4(out[0], out[1], out[2], out[3]);
+    dst[1] = make_uint4(out[4], out[5], out[6], out[7]);
+    vs[(((long)head * nkb + kb) * 32 + (d & 31)) * 4 + (d >> 5)] = (uint8_t)(e + 127);
+}
+
+extern "C" int utx_launch_quant_vt_mx8(const void* vt, void* v8, void* vs, int H, int S_pad, hipStream_t stream) {
+    if (H <= 0 || S_pad <= 0 || (S_pad & 63) || ((uintptr_t)vt & 15) || ((uintptr_t)v8 & 15) || ((uintptr_t)vs & 3)) return -2;
+    const long total = (long)H * 128 * (S_pad / 32);
+    hipLaunchKernelGGL(quant_vt_mx8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)vt, (uint8_t*)v8, (uint8_t*)vs, H, S_pad);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
+extern "C" int utx_launch_attn_fwd_fp8(const Attn8Params* hp, hipStream_t stream) {
+    Attn8Params p = *hp;
+    if (p.H <= 0 || p.S <= 0 || p.Sq < 0 || p.Sq > p.S || p.S_pad < p.S || (p.S_pad & 63) || p.key_bias_period < 0 || (p.o_ss & 3)) return -2;
+    if ((((uintptr_t)p.q8) | ((uintptr_t)p.k8) | ((uintptr_t)p.v8t)) & 15) return -2;
+    if ((((uintptr_t)p.qs) | ((uintptr_t)p.ks) | ((uintptr_t)p.vs)) & 3) return -2;
+    if (p.Sq == p.S) p.Sq = 0;
+    UTX_ONCE_PER_DEVICE(attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_fp8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, A8_LDS) != hipSuccess) return -3;
+        UTX_ONCE_DONE(attr_set);
+    }
+    p.nqb = ((p.Sq > 0 ? p.Sq : p.S) + 255) / 256;
+    hipLaunchKernelGGL(attn_fwd_fp8_kernel, dim3(p.nqb * p.H), dim3(512), A8_LDS, stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}

@@ -20,6 +20,7 @@ SOURCES = [
     ("attention.hip", []),
     ("attention_glds.hip", ["-fno-slp-vectorize"]),
     ("attention_q64.hip", []),
+    ("attention_fp8.hip", []),
     ("gemm.hip", []),
     ("gemm_pers.hip", []),
     ("gemm_w4.hip", []),

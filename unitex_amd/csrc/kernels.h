@@ -37,6 +37,18 @@ struct AttnParams {
     int blk_rows;
     long q_bs, k_bs, vt_bs;
 };
+// MX fp8 attention (attention_fp8.hip; opt-in): e4m3 operands with E8M0 block scales
+struct Attn8Params {
+    const uint8_t *q8, *k8;      // [H][S_pad][128] e4m3
+    const uint8_t* v8t;          // [H][128][S_pad] e4m3
+    const uint32_t *qs, *ks;     // [H][S_pad]: four E8M0 bytes per row (32-channel blocks of d)
+    const uint32_t* vs;          // [H][S_pad / 32][32]: dword of row d % 32 = the E8M0 bytes of channels d % 32 + {0, 32, 64, 96} for that block of 32 keys
+    bf16_t* o;
+    long o_ss;
+    int H, S, Sq, S_pad, nqb;
+    float key_bias_log2;
+    int key_bias_period;
+};
 // Launch options.  Every field is result-preserving (kernel selection / scheduling A/B): read ONCE from the environment by
 // the first utx_init (UTX_ATTN_*, UTX_GEMM_* variables of the same names), afterwards changed only through utx_set_option.
 // The three `*_abl` fields switch timing ablations that compute WRONG results; they exist only in the UTX_ABLATION build
@@ -73,6 +85,8 @@ int utx_launch_attn_fwd(const void* q, const void* k, const void* vt, void* o,
 void utx_attn_split_plan_impl(int H, int Sq, int S, int ncu, int out[4]);     // attention_glds.hip (pure): {workgroups, in full rounds, key ranges per tail workgroup, tiles per range}
 size_t utx_attn_workspace_bytes_impl(int H, int Sq, int S, int ncu);
 int utx_launch_attn_fwd_glds(const AttnParams* p, int presc, hipStream_t stream);
+int utx_launch_attn_fwd_fp8(const Attn8Params* p, hipStream_t stream);                                   // attention_fp8.hip
+int utx_launch_quant_vt_mx8(const void* vt, void* v8, void* vs, int H, int S_pad, hipStream_t stream);   // attention_fp8.hip
 int utx_launch_attn_fwd_blk(const void* q, const void* k, const void* vt, void* o, long q_hs, long q_ss, long k_hs, long k_ss, long vt_hs, long vt_ds,
                             long o_ss, int H, int S, int Sq, float scale, float key_bias_log2, int key_bias_period, void* work, size_t work_bytes,
                             int blk_rows, long q_bs, long k_bs, long vt_bs, hipStream_t stream);

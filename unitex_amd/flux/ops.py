@@ -50,6 +50,43 @@ def attention(q, k, vt, S=None, scale=None, out=None, o_ss=None, key_bias_log2=0
     return out
 
 
+def quant_qk_mx8(xh, out=None):
+    """head-major Q or K [H, S_pad, 128] bf16 -> (e4m3 bytes [H, S_pad, 128], scales [H, S_pad, 4] uint8: the four E8M0 bytes of a row = one dword) for
+    utx_attn_fwd_fp8: utx_quant_mx8 over the rows of the [H * S_pad, 128] view (blocks of 32 along d)."""
+    ctx = get_ctx(xh.device.index)
+    H, S_pad, D = xh.shape
+    assert D == 128 and xh.is_contiguous()
+    q8, sc = out if out is not None else (torch.empty(H, S_pad, 128, dtype=torch.uint8, device=xh.device), torch.empty(H, S_pad, 4, dtype=torch.uint8, device=xh.device))
+    ctx.check(ctx.lib.utx_quant_mx8(ctx.handle, ptr(xh), 128, ptr(q8), 128, ptr(sc), 4, H * S_pad, 128, ctx.stream()))
+    return q8, sc
+
+
+def quant_vt_mx8(vt, out=None):
+    """V^T [H, 128, S_pad] bf16 -> (e4m3 bytes [H, 128, S_pad], scales [H, S_pad / 32, 32, 4] uint8: E8M0 per (block of 32 keys, channel d % 32, d / 32))"""
+    ctx = get_ctx(vt.device.index)
+    H, D, S_pad = vt.shape
+    assert D == 128 and S_pad % 64 == 0 and vt.is_contiguous()
+    v8, vs = out if out is not None else (torch.empty(H, 128, S_pad, dtype=torch.uint8, device=vt.device), torch.empty(H, S_pad // 32, 32, 4, dtype=torch.uint8, device=vt.device))
+    ctx.check(ctx.lib.utx_quant_vt_mx8(ctx.handle, ptr(vt), ptr(v8), ptr(vs), H, S_pad, ctx.stream()))
+    return v8, vs
+
+
+def attention_fp8(q8, qs, k8, ks, v8t, vs, S=None, S_q=None, out=None, o_ss=None, key_bias_log2=0.0, key_bias_period=0):
+    """MX fp8 attention (utx_attn_fwd_fp8; opt-in): operands from quant_qk_mx8 / quant_vt_mx8; Q must have been pre-scaled by scale * log2(e).  -> o [S_q, H * 128] bf16"""
+    ctx = get_ctx(q8.device.index)
+    H, S_pad, D = q8.shape
+    assert D == 128 and v8t.shape == (H, 128, S_pad)
+    S = S_pad if S is None else S
+    S_q = S if S_q is None else S_q
+    if out is None:
+        out = torch.empty(S_q, H * 128, dtype=torch.bfloat16, device=q8.device)
+    if o_ss is None:
+        o_ss = out.stride(0)
+    ctx.check(ctx.lib.utx_attn_fwd_fp8(ctx.handle, ptr(q8), ptr(qs), ptr(k8), ptr(ks), ptr(v8t), ptr(vs), ptr(out), o_ss, H, S_q, S, S_pad,
+                                       float(key_bias_log2), int(key_bias_period), ctx.stream()))
+    return out
+
+
 def make_gemm_desc(A, B, C_out, bias=None, A2=None, B2=None, lora_n_limit=None, lora_seg_n=None, alpha=1.0,
                    gelu_from=None, gate=None, res=None, n_split=None, C1=None, a_scale=None, b_scale=None, qk_post=None, sk_work=None, q_out=None):
     """a_scale / b_scale given: A and B are OCP MX fp8 operands (uint8 e4m3 bytes + E8M0 scales [rows, K/32], flux/mx8.py).

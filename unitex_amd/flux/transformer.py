@@ -80,7 +80,7 @@ class FluxDiT:
     FP8_LINEARS_SINGLE = ("qkvm", "out")
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], shape: Optional[FluxShape] = None, device="cuda:0",
-                 sequence_parallel=False, sp_group=None, fp8_weights=False):
+                 sequence_parallel=False, sp_group=None, fp8_weights=False, fp8_attention=False):
         """sequence_parallel: head-parallel ("Ulysses") sharding of ONE job over the ranks of `sp_group` (ulysses.py):
         set_positions / set_conditioning still take the FULL id / embedding tensors, forward() takes and returns this
         rank's slice of the image tokens (local_image_range)."""
@@ -106,19 +106,36 @@ class FluxDiT:
         self._lora_version = 0
         self.attn_events = None
         self.gemm_events = None    # bench.py: list that receives (start event, end event, FLOPs) of every large-M GEMM launched on the main stream
-        # double blocks: the text-token half (M = 512: a fraction of one round of tiles) runs on a second HIP stream beside the
-        # image-token half, which fills CUs that the image GEMMs' tail rounds leave idle.  UTX_TXT_STREAM=0 keeps one stream.
-        self.overlap_text = os.environ.get("UTX_TXT_STREAM", "1") != "0"      # also under sequence parallelism (the fork / join events end before "sp_start")
+        # double blocks: the text-token half (M = 512: a fraction of one round of tiles) CAN run on a second HIP stream beside the image-token half, which
+        # fills CUs that the image GEMMs' tail rounds leave idle (-0.5 % per step at S = 50 688, -2.7 % at 13 824).  OFF BY DEFAULT SINCE ROUND 4
+        # (UTX_TXT_STREAM=1 opts in): with the text half's LoRA-carrying GEMMs running beside the image half, ONE q or k row of one head came out of the
+        # image half's utx_qkv_post wrong in 1-1.5 % of the forwards of the full-width fp8 plan and in 1 of 2000 of the bf16 plan (same inputs, same launches;
+        # 0 of 2000 on one stream, 0 of 2500 with the text half's GEMMs moved behind the join, 0 of 2500 without adapters; the q / k / v post-processing and the
+        # attention kernel alone are reproducible over thousands of launches) -- tools/plan_determinism_matrix.py, tools/fp8_plan_bisect2.py,
+        # tools/two_stream_probe.py, profiles/r04_plan_determinism_*.log, DESIGN section 9.  The mechanism is not yet understood; until it is, a result that
+        # is the same run after run is worth more than the overlap.
+        self.overlap_text = os.environ.get("UTX_TXT_STREAM", "0") == "1"      # also under sequence parallelism (the fork / join events end before "sp_start")
         self._side = torch.cuda.Stream(device=self.device) if self.overlap_text else None
         # text-token dedup (last bullet): the reference feeds 512 all-zero text embeddings with all-zero position ids
         # (flux_piplines/texturing/pipeline.py:538-543) -- 512 IDENTICAL tokens at every layer.  When set_conditioning sees
         # identical rows (and identical ids) it carries TEXT_KEEP of them and tells the attention kernel that each stands for
         # S_txt / TEXT_KEEP keys (utx_attn_fwd_bf16_kb): the same softmax, up to fp32 summation order.  UTX_TEXT_DEDUP=0 disables.
         self.fp8_weights = bool(fp8_weights)
+        # OPT-IN (round 4, BASELINE configs[4] "fp8 MFMA"): QK^T and PV on the fp8 matrix pipe (utx_attn_fwd_fp8, csrc/attention_fp8.hip): after utx_qkv_post the
+        # head-major Q / K / V^T are MX-quantised (three passes over them, ~1 % of the attention's time) and the MX fp8 attention kernel runs instead of the
+        # bf16 one.  A different numerics contract with its own stated tolerance (tests/test_attention_fp8_gpu.py, tests/test_e2e_tolerance_gpu.py);
+        # never the default, never the bf16 bench line; not under sequence parallelism.
+        self.fp8_attention = bool(fp8_attention) and not sequence_parallel
         self.text_dedup = os.environ.get("UTX_TEXT_DEDUP", "1") != "0"
         self.key_bias_log2, self.key_bias_period, self.text_rows = 0.0, 0, None
         self._ids = None
         self._pack(state_dict)
+
+    def set_text_stream(self, on: bool):
+        """run the text half of the double blocks on a second stream (opt-in, see __init__) or on the caller's; drops the plan"""
+        self.overlap_text = bool(on)
+        self._side = torch.cuda.Stream(device=self.device) if self.overlap_text else None
+        self._drop_plans()
 
     # ------------------------------------------------------------------ weights
     def _t(self, sd, name):
@@ -435,6 +452,12 @@ class FluxDiT:
         sh = self.shape
         Qh, Kh, Vt = ws["Qh"], ws["Kh"], ws["Vt"]
         r0, r1 = (0, S) if q_rows is None else q_rows     # q_rows: queries = token rows [r0, r1) only (last-block pruning); `out` starts at row r0 as well
+        if self.fp8_attention:
+            plan.append(("quant_qk", (Qh, ws["Q8"], ws["Q8s"])))
+            plan.append(("quant_qk", (Kh, ws["K8"], ws["K8s"])))
+            plan.append(("quant_vt", (Vt, ws["V8"], ws["V8s"])))
+            plan.append(("attn8", (ws["Q8"][:, r0:], ws["Q8s"][:, r0:], ws["K8"], ws["K8s"], ws["V8"], ws["V8s"], out, r1 - r0, S, Qh.shape[1])))
+            return
         Qs = Qh[:, r0:]
         wk = self._attn_work(ws, sh.num_heads, r1 - r0, S)
         args = (ptr(Qs), ptr(Kh), ptr(Vt), ptr(out), Qh.stride(0), Qh.stride(1), Kh.stride(0), Kh.stride(1),
@@ -481,6 +504,10 @@ class FluxDiT:
         }
         if self.sp is None:
             ws.update({"Qh": z(H, S_pad, 128), "Kh": z(H, S_pad, 128), "Vt": z(H, 128, S_pad)})
+            if self.fp8_attention:
+                u8 = torch.uint8
+                ws.update({"Q8": z(H, S_pad, 128, dtype=u8), "K8": z(H, S_pad, 128, dtype=u8), "V8": z(H, 128, S_pad, dtype=u8),
+                           "Q8s": z(H, S_pad, 4, dtype=u8), "K8s": z(H, S_pad, 4, dtype=u8), "V8s": z(H, S_pad // 32, 32, 4, dtype=u8)})
         if self.fp8_weights:
             from .mx8 import packed_scale_buffer
             Kmax = (1 + sh.mlp_ratio) * D
@@ -842,6 +869,26 @@ class FluxDiT:
             if rc:
                 self.ctx.check(rc)
             return
+        if fn == "quant_qk":
+            ops.quant_qk_mx8(d[0], out=(d[1], d[2]))
+            return
+        if fn == "quant_vt":
+            ops.quant_vt_mx8(d[0], out=(d[1], d[2]))
+            return
+        if fn == "attn8":
+            q8, qs, k8, ks, v8, vs, out, n_q, S_kv, S_pad = d
+            ev = getattr(self, "attn_events", None)
+            if ev is not None:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+            rc = self.lib.utx_attn_fwd_fp8(self.ctx.handle, ptr(q8), ptr(qs), ptr(k8), ptr(ks), ptr(v8), ptr(vs), ptr(out), out.stride(0), self.shape.num_heads,
+                                           int(n_q), int(S_kv), int(S_pad), float(self.key_bias_log2), int(self.key_bias_period), st)
+            if ev is not None:
+                b.record()
+                ev.append((a, b))
+            if rc:
+                self.ctx.check(rc)
+            return
         if fn == "quant_mx8":
             x_, q_, s_ = d
             if hasattr(s_, "row_blocks"):
@@ -871,7 +918,7 @@ class FluxDiT:
                     self._launch(f2, d2, st)
                 ev_join.record(self._side)
                 main.wait_event(ev_join)
-            elif fn == "quant_mx8":
+            elif fn in ("quant_mx8", "quant_qk", "quant_vt", "attn8"):
                 self._launch(fn, d, st)
             elif fn == "temb_sum":
                 # conditioning = (timesteps_emb + guidance_emb) + pooled_projections, bf16 adds [3p]

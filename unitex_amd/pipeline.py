@@ -26,7 +26,8 @@ PNG_LEVEL = int(os.environ.get("UTX_PNG_LEVEL", "1"))
 def build_pipeline(pretrain_models=None, pipeline_name="texture_plus", device="cuda:0", seed=0, lora_rank=64, shape=None,
                    sequence_parallel=False, process_group=None, speedup_mode=None, add_lora_path=None, add_lora_weights=None):
     """FluxDiT + VAE + adapters.  speedup_mode: the reference's constructor takes the argument and never reads it (pipeline.py:81,142-145); here
-    "fp8" runs the big linears on OCP MX fp8 operands (FluxDiT(fp8_weights=True): BASELINE configs[4] numerics, NOT the default), anything else = bf16.  With a `pretrain_models` directory holding diffusers-format safetensors the real
+    "fp8" runs the big linears on OCP MX fp8 operands (FluxDiT(fp8_weights=True): BASELINE configs[4] numerics, NOT the default), "fp8-attn" additionally runs
+    QK^T / PV on the fp8 matrix pipe (FluxDiT(fp8_attention=True), csrc/attention_fp8.hip; single GPU), anything else = bf16.  With a `pretrain_models` directory holding diffusers-format safetensors the real
     weights are loaded; otherwise (no checkpoints exist here) FLUX.1-dev-shaped synthetic weights are generated.
     sequence_parallel: ONE job over the ranks of `process_group` (flux/ulysses.py).
     add_lora_path / add_lora_weights (reference pipeline.py:112-117): further adapters `add_lora_<i>` (safetensors paths, or already loaded dicts), switched on
@@ -50,7 +51,7 @@ def build_pipeline(pretrain_models=None, pipeline_name="texture_plus", device="c
         tex = synthetic_lora(sd, shape, rank=lora_rank, seed=1, device=device)
         dlt = synthetic_lora(sd, shape, rank=lora_rank, seed=2, device=device)
     pipe = PBRFluxPipeline(FluxDiT(sd, shape, device=device, sequence_parallel=sequence_parallel, sp_group=process_group,
-                                   fp8_weights=(speedup_mode == "fp8")), vae, device=device)
+                                   fp8_weights=(speedup_mode in ("fp8", "fp8-attn")), fp8_attention=(speedup_mode == "fp8-attn")), vae, device=device)
     pipe.load_lora_weights(tex, adapter_name="texture")
     pipe.load_lora_weights(dlt, adapter_name="delight")
     weights_for_texture, weights_for_delight, adapter_names = [1.0, 0.0], [0.0, 1.0], ["texture", "delight"]
