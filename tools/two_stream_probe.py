@@ -7,6 +7,9 @@ pruned plan, Python launch list, arms = surgery on the first two-stream section 
 usage: two_stream_probe.py [reps]"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from unitex_amd import _lib
+if os.environ.get("UTX_LIB"):
+    _lib.LIB_PATH = os.path.abspath(os.environ["UTX_LIB"])      # A/B of a differently built library (e.g. dit_elementwise.hip without packed fp32 instructions)
 from oracle import dit_ref
 from unitex_amd.flux.transformer import FluxDiT, FluxShape
 BF = torch.bfloat16
