@@ -456,8 +456,8 @@ def main():
             "config": {"workload": args.workload, "description": desc, "tokens": S, "text_tokens": S_txt,
                        "noise_tokens": n_noise, "control_tokens": n_ctrl, "dual_tokens": n_dual,
                        "lora_rank": args.lora_rank, "guidance": 3.5, "launch": launch_path, "ms_per_step_hip_graph_replay": graph_ms, "parallelism": par,
-                       "text_half_of_double_blocks": "second HIP stream beside the image half (UTX_TXT_STREAM=1, opt-in)" if model.overlap_text else
-                       "on the caller's stream (default since round 4: the two-stream form is not reproducible run to run, DESIGN 9)",
+                       "text_half_of_double_blocks": "second HIP stream beside the image half (default; elementwise kernels built without packed fp32 instructions, DESIGN 9)" if model.overlap_text else
+                       "on the caller's stream (UTX_TXT_STREAM=0)",
                        "tokens_computed": S_exec, "text_dedup": None if model.text_rows is None else "512 identical text tokens carried as %d rows per rank, key weight 2^%.2f (SURVEY 7 last bullet; UTX_TEXT_DEDUP=0 disables)" % (model.text_rows, model.key_bias_log2),
                        "last_block_pruning": ("last block: queries / MLP / out-projection for the %d noise tokens only (the prediction of the condition tail is never read: "
                                               "flux_piplines/texturing/pipeline.py:645,660,684; UTX_PRUNE_LAST=0 disables)" % n_noise) if prune else None,

@@ -20,10 +20,11 @@ g = torch.Generator().manual_seed(9)
 lat = torch.randn(img_ids.shape[0], 64, generator=g).to(BF).cuda()
 junk = torch.empty(1 << 29, dtype=torch.uint8, device="cuda")
 CASES = {"all": ((True, 4096, True, True), (True, None, True, True), (False, 4096, True, True), (False, None, True, True), (True, 4096, False, True), (True, 4096, True, False)),
-         "streams": ((True, 4096, False, True), (True, 4096, True, True), (False, 4096, True, True), (False, None, True, True))}
+         "streams": ((True, 4096, False, True), (True, 4096, True, True), (False, 4096, True, True), (False, None, True, True)),
+         "soak": ((True, 4096, True, True), (False, 4096, True, True), (True, None, True, True))}
 for fp8, rows, two_streams, cplan in CASES[sys.argv[2] if len(sys.argv) > 2 else "all"]:
     m = FluxDiT(sd, shape, device="cuda:0", fp8_weights=fp8)
-    m.overlap_text = two_streams
+    m.set_text_stream(two_streams)
     m.set_lora([(lora, 1.0)])
     m.set_positions(torch.zeros(S_txt, 3), img_ids)
     m.set_output_rows(rows)

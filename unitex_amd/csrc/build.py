@@ -24,7 +24,11 @@ SOURCES = [
     ("gemm.hip", []),
     ("gemm_pers.hip", []),
     ("gemm_w4.hip", []),
-    ("dit_elementwise.hip", ["-ffp-contract=off"]),
+    # -packed-fp32-ops (device pass; the host pass prints "not a recognized feature" and ignores it): NO v_pk_mul / v_pk_add / v_pk_fma_f32 in the elementwise
+    # kernels.  With them, utx_qkv_post running beside another stream's MFMA GEMM produced a wrong low element in lanes 48-63 of a wave about once per 100
+    # forwards of the full-width fp8 plan; built without them: 0 of 3000 (tools/two_stream_probe.py, profiles/r04_two_stream_probe_nopk.log).
+    # These kernels are HBM-bound: the packed forms bought nothing measurable.
+    ("dit_elementwise.hip", ["-ffp-contract=off", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]),
     ("vae.hip", []),
     ("capi.cpp", []),
     ("meshproc.cpp", []),
