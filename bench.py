@@ -280,8 +280,6 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29655")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(dev))
         ulysses = True
-    if args.fp8_attn and (world > 1 or args.sp_self_test):
-        raise SystemExit("--fp8-attn is a single-GPU option")
     model = FluxDiT(sd, shape, device=dev, sequence_parallel=ulysses, fp8_weights=args.fp8, fp8_attention=args.fp8_attn)
     tex = synthetic_lora(sd, shape, rank=args.lora_rank, seed=1, device=dev)
     dlt = synthetic_lora(sd, shape, rank=args.lora_rank, seed=2, device=dev)

@@ -443,6 +443,11 @@ int utx_plan_add_attn(utx_plan* plan, const void* q, const void* k, const void* 
                       size_t work_bytes);
 int utx_plan_add_quant_mx8(utx_plan* plan, const void* x, long ldx, void* q, long ldq, void* s, long lds_or_row_blocks, int M, int K, int packed);
 int utx_plan_add_add3(utx_plan* plan, const void* a, const void* b, const void* c, void* out, int n);
+/* the opt-in MX fp8 attention as plan entries: arguments of utx_quant_vt_mx8 / utx_attn_fwd_fp8 (Q8 / K8 come from utx_plan_add_quant_mx8 over the
+ * [H * S_pad, 128] row view: ldx = ldq = 128, lds = 4, packed = 0) */
+int utx_plan_add_quant_vt_mx8(utx_plan* plan, const void* vt, void* v8, void* vs, int H, int S_pad);
+int utx_plan_add_attn_fp8(utx_plan* plan, const void* q8, const void* qs, const void* k8, const void* ks, const void* v8t, const void* vs, void* o, long o_ss,
+                          int H, int S_q, int S_kv, int S_pad, float key_bias_log2, int key_bias_period);
 int utx_plan_fork(utx_plan* plan);
 int utx_plan_main(utx_plan* plan);
 int utx_plan_join(utx_plan* plan);

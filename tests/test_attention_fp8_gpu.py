@@ -4,6 +4,7 @@ this library's own (include/unitex_hip.h) and these tests state it:
     byte order of P, the V^T chunks, the three scale layouts, the swizzles of both LDS tiles -- is pinned bit for bit against a dense fp64 evaluation;
   * the quantisers are the OCP MX rule of oracle/mx8_ref.py, byte for byte;
   * on random data: within the P-rounding tolerance of the exact attention over the DEQUANTISED operands, and a stated distance to the bf16 kernel."""
+import ctypes as C
 import math
 import os
 import sys
@@ -146,6 +147,18 @@ def test_fluxdit_with_fp8_attention_runs_the_fp8_kernel_and_stays_close_to_the_b
             assert kinds.count("attn8") == 4 and kinds.count("quant_qk") == 8 and kinds.count("quant_vt") == 4 and m.key_bias_log2 > 0
         outs[name] = m.forward(lat, 0.5)[:192].float().cpu()
         torch.cuda.synchronize()
+        if kw:      # the default launch path is the C replay (utx_plan_add_quant_vt_mx8 / utx_plan_add_attn_fp8); the Python launch list gives the same bits
+            pl = next(iter(m._plans.values()))
+            assert pl.get("cplan") is not None, "the fp8 attention entries must be replayable from C"
+            kinds = []
+            for i in range(m.lib.utx_plan_size(pl["cplan"])):
+                k_, s_ = C.c_int(), C.c_int()
+                assert m.lib.utx_plan_entry(pl["cplan"], i, C.byref(k_), C.byref(s_), None, 4096) >= 0
+                kinds.append(k_.value)
+            assert kinds.count(10) == 4 and kinds.count(9) == 4 and kinds.count(4) == 0
+            m.run_plan(pl)
+            torch.cuda.synchronize()
+            assert torch.equal(pl["ws"]["out"][:192].float().cpu(), outs[name])
     mx = outs["bf16"].abs().max().item()
     d = (outs["fp8-attn"] - outs["bf16"]).abs()
     print("\n[FluxDiT fp8 attention, tiny 2 + 2 blocks] vs the bf16 forward: max %.3f %%, mean %.3f %% of max|out| %.3g" % (100 * d.max().item() / mx, 100 * d.mean().item() / mx, mx))

@@ -125,6 +125,8 @@ SYMBOLS = {
     "utx_plan_add_attn": (c_int, [c_void_p] * 5 + [c_long] * 7 + [c_int, c_int, c_int, c_float, c_float, c_int, c_void_p, C.c_size_t]),
     "utx_plan_add_quant_mx8": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_int]),
     "utx_plan_add_add3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
+    "utx_plan_add_quant_vt_mx8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int]),
+    "utx_plan_add_attn_fp8": (c_int, [c_void_p] * 8 + [c_long, c_int, c_int, c_int, c_int, c_float, c_int]),
     "utx_plan_fork": (c_int, [c_void_p]),
     "utx_plan_main": (c_int, [c_void_p]),
     "utx_plan_join": (c_int, [c_void_p]),

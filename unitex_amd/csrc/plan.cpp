@@ -12,13 +12,14 @@
 #include "kernels.h"
 
 namespace {
-enum Kind { K_GEMM, K_GEMV, K_LN_MOD, K_QKV_POST, K_ATTN, K_QUANT, K_ADD3, K_FORK, K_JOIN };
+enum Kind { K_GEMM, K_GEMV, K_LN_MOD, K_QKV_POST, K_ATTN, K_QUANT, K_ADD3, K_FORK, K_JOIN, K_QUANT_VT, K_ATTN8 };
 struct AttnArgs { const void *q, *k, *vt; void* o; long q_hs, q_ss, k_hs, k_ss, vt_hs, vt_ds, o_ss; int H, S_q, S_kv; float scale, kb; int period; void* work; size_t work_bytes; };
 struct QuantArgs { const void* x; long ldx; void* q; long ldq; void* s; long lds; int M, K, packed; };
 struct Add3Args { const void *a, *b, *c; void* out; int n; };
+struct QuantVtArgs { const void* vt; void *v8, *vs; int H, S_pad; };
 struct Entry {
     Kind kind; int side;
-    union { utx_gemm_desc gemm; utx_gemv_desc gemv; utx_ln_mod_desc ln; utx_qkv_post_desc qkv; AttnArgs attn; QuantArgs quant; Add3Args add3; };
+    union { utx_gemm_desc gemm; utx_gemv_desc gemv; utx_ln_mod_desc ln; utx_qkv_post_desc qkv; AttnArgs attn; QuantArgs quant; Add3Args add3; QuantVtArgs qvt; Attn8Params attn8; };
     Entry() { memset(this, 0, sizeof(*this)); }
 };
 }  // namespace
@@ -79,6 +80,25 @@ int utx_plan_add_add3(utx_plan* p, const void* a, const void* b, const void* c, 
     push(p, K_ADD3).add3 = g;
     return 0;
 }
+// the opt-in MX fp8 attention (attention_fp8.hip): V^T quantised along the keys, and the attention over utx_quant_mx8's Q8 / K8 and that V8^T
+int utx_plan_add_quant_vt_mx8(utx_plan* p, const void* vt, void* v8, void* vs, int H, int S_pad) {
+    if (!p || !vt || !v8 || !vs) return -2;
+    QuantVtArgs a = {vt, v8, vs, H, S_pad};
+    push(p, K_QUANT_VT).qvt = a;
+    return 0;
+}
+int utx_plan_add_attn_fp8(utx_plan* p, const void* q8, const void* qs, const void* k8, const void* ks, const void* v8t, const void* vs, void* o, long o_ss,
+                          int H, int S_q, int S_kv, int S_pad, float key_bias_log2, int key_bias_period) {
+    if (!p || !q8 || !qs || !k8 || !ks || !v8t || !vs || !o) return -2;
+    Attn8Params a;
+    memset(&a, 0, sizeof(a));
+    a.q8 = (const uint8_t*)q8; a.k8 = (const uint8_t*)k8; a.v8t = (const uint8_t*)v8t;
+    a.qs = (const uint32_t*)qs; a.ks = (const uint32_t*)ks; a.vs = (const uint32_t*)vs;
+    a.o = (bf16_t*)o; a.o_ss = o_ss; a.H = H; a.S = S_kv; a.Sq = S_q; a.S_pad = S_pad;
+    a.key_bias_log2 = key_bias_log2; a.key_bias_period = key_bias_period;
+    push(p, K_ATTN8).attn8 = a;
+    return 0;
+}
 // two-stream section: fork; [side entries]; utx_plan_main; [main entries]; join
 int utx_plan_fork(utx_plan* p) {
     if (!p || p->cur_side || p->open_sections) return -2;
@@ -113,7 +133,8 @@ int utx_plan_assign_sk(utx_plan* p, void* sk_work, size_t sk_work_bytes, int n_c
     return n;
 }
 
-// Read an entry back (tests, debuggers): kind 0 gemm, 1 gemv, 2 ln_mod, 3 qkv_post, 4 attention, 5 quant_mx8, 6 add3, 7 fork, 8 join; `side` = launched on the
+// Read an entry back (tests, debuggers): kind 0 gemm, 1 gemv, 2 ln_mod, 3 qkv_post, 4 attention, 5 quant_mx8, 6 add3, 7 fork, 8 join, 9 quant_vt_mx8, 10 fp8
+// attention (its argument block = {q8, k8, v8t, qs, ks, vs, o, ...} as kernels.h's Attn8Params lays them out); `side` = launched on the
 // plan's side stream; the descriptor (kinds 0-3: the public structs) or the entry's argument block (kinds 4-6) is copied into buf.  Returns the bytes copied,
 // or a negative code.
 int utx_plan_entry(const utx_plan* p, int i, int* kind, int* side, void* buf, size_t cap) {
@@ -129,6 +150,8 @@ int utx_plan_entry(const utx_plan* p, int i, int* kind, int* side, void* buf, si
         case K_ATTN: src = &e.attn; n = sizeof(e.attn); break;
         case K_QUANT: src = &e.quant; n = sizeof(e.quant); break;
         case K_ADD3: src = &e.add3; n = sizeof(e.add3); break;
+        case K_QUANT_VT: src = &e.qvt; n = sizeof(e.qvt); break;
+        case K_ATTN8: src = &e.attn8; n = sizeof(e.attn8); break;
         default: break;
     }
     if (n > cap) return -2;
@@ -169,6 +192,8 @@ int utx_plan_run_range(utx_plan* p, int begin, int end, utx_stream stream_, int*
                 break;
             }
             case K_ADD3: rc = utx_launch_add3_bf16(e.add3.a, e.add3.b, e.add3.c, e.add3.out, e.add3.n, st); break;
+            case K_QUANT_VT: rc = utx_launch_quant_vt_mx8(e.qvt.vt, e.qvt.v8, e.qvt.vs, e.qvt.H, e.qvt.S_pad, st); break;
+            case K_ATTN8: rc = utx_launch_attn_fwd_fp8(&e.attn8, st); break;
             case K_FORK:
                 if (hipEventRecord(p->events[2 * section], main_s) != hipSuccess || hipStreamWaitEvent(p->side, p->events[2 * section], 0) != hipSuccess) rc = -4;
                 else forked = true;

@@ -124,8 +124,9 @@ class FluxDiT:
         # OPT-IN (round 4, BASELINE configs[4] "fp8 MFMA"): QK^T and PV on the fp8 matrix pipe (utx_attn_fwd_fp8, csrc/attention_fp8.hip): after utx_qkv_post the
         # head-major Q / K / V^T are MX-quantised (three passes over them, ~1 % of the attention's time) and the MX fp8 attention kernel runs instead of the
         # bf16 one.  A different numerics contract with its own stated tolerance (tests/test_attention_fp8_gpu.py, tests/test_e2e_tolerance_gpu.py);
-        # never the default, never the bf16 bench line; not under sequence parallelism.
-        self.fp8_attention = bool(fp8_attention) and not sequence_parallel
+        # never the default, never the bf16 bench line.  Under sequence parallelism the exchange stays bf16 and a rank quantises each head group's Q / K / V^T
+        # (its heads x the full sequence) behind the group's unpack.
+        self.fp8_attention = bool(fp8_attention)
         self.text_dedup = os.environ.get("UTX_TEXT_DEDUP", "1") != "0"
         self.key_bias_log2, self.key_bias_period, self.text_rows = 0.0, 0, None
         self._ids = None
@@ -523,6 +524,12 @@ class FluxDiT:
                 raise ValueError("sequence parallel: the local token count %d must be a multiple of 64" % S)
             self.ex = UlyssesExchange(H, S, group=self.sp[2], device=dev, dtype=BF16, ctx=self.ctx,
                                       n_cus=torch.cuda.get_device_properties(dev).multi_processor_count)
+            if self.fp8_attention:      # MX operands of ONE head group (the groups' attentions are ordered on the stream): Hg heads x the full sequence
+                ex, u8 = self.ex, torch.uint8
+                if ex.zero_copy:
+                    raise ValueError("fp8 attention quantises the unpacked head-major operands: not with the zero-copy exchange (UTX_SP_ZERO_COPY)")
+                ws.update({"Q8": z(ex.Hg, ex.S, 128, dtype=u8), "K8": z(ex.Hg, ex.S, 128, dtype=u8), "V8": z(ex.Hg, 128, ex.S, dtype=u8),
+                           "Q8s": z(ex.Hg, ex.S, 4, dtype=u8), "K8s": z(ex.Hg, ex.S, 4, dtype=u8), "V8s": z(ex.Hg, ex.S // 32, 32, 4, dtype=u8)})
         T = ws.get("T")
         Tc = ws.get("Tc") if self.overlap_text else T
 
@@ -960,6 +967,11 @@ class FluxDiT:
             for g in range(ex.G):
                 hd = ex.finish_heads_in_group(g, None if works is None else works[g])
                 og = ex.o[g]
+                if self.fp8_attention:      # the group's MX operands (in front of the timed bracket, as on one GPU: `attn_events` bracket the attention kernel)
+                    q, k, vt = hd
+                    for src, d8, s8 in ((q, ws["Q8"], ws["Q8s"]), (k, ws["K8"], ws["K8s"])):
+                        self.ctx.check(lib.utx_quant_mx8(h, ptr(src), 128, ptr(d8), 128, ptr(s8), 4, ex.Hg * ex.S, 128, st))
+                    self.ctx.check(lib.utx_quant_vt_mx8(h, ptr(vt), ptr(ws["V8"]), ptr(ws["V8s"]), ex.Hg, ex.S, st))
                 if ev is not None:
                     a = torch.cuda.Event(enable_timing=True)
                     b = torch.cuda.Event(enable_timing=True)
@@ -970,6 +982,9 @@ class FluxDiT:
                     rc = lib.utx_attn_fwd_bf16_blk(h, C.c_void_p(qp), C.c_void_p(kp), C.c_void_p(vp), ptr(og), hs, 128, hs, 128, hs, rows, og.stride(0),
                                                    ex.Hg, ex.S, ex.S, 0.0, float(self.key_bias_log2), int(self.key_bias_period), ptr(wk),
                                                    0 if wk is None else wk.numel(), rows, bs, bs, bs, st)
+                elif self.fp8_attention:
+                    rc = lib.utx_attn_fwd_fp8(h, ptr(ws["Q8"]), ptr(ws["Q8s"]), ptr(ws["K8"]), ptr(ws["K8s"]), ptr(ws["V8"]), ptr(ws["V8s"]), ptr(og), og.stride(0),
+                                              ex.Hg, ex.S, ex.S, ex.S, float(self.key_bias_log2), int(self.key_bias_period), st)
                 else:
                     q, k, vt = hd
                     rc = lib.utx_attn_fwd_bf16_ws(h, ptr(q), ptr(k), ptr(vt), ptr(og), q.stride(0), q.stride(1), k.stride(0), k.stride(1),
@@ -1016,6 +1031,16 @@ class FluxDiT:
                 if hasattr(s_, "row_blocks"):
                     return lib.utx_plan_add_quant_mx8(h, ptr(x_), x_.stride(0), ptr(q_), q_.stride(0), ptr(s_.data), s_.row_blocks, x_.shape[0], x_.shape[1], 1)
                 return lib.utx_plan_add_quant_mx8(h, ptr(x_), x_.stride(0), ptr(q_), q_.stride(0), ptr(s_), s_.stride(0), x_.shape[0], x_.shape[1], 0)
+            if isinstance(fn, str) and fn == "quant_qk":      # head-major Q / K rows: utx_quant_mx8 over the [H * S_pad, 128] view (ops.quant_qk_mx8)
+                x_, q_, s_ = d
+                return lib.utx_plan_add_quant_mx8(h, ptr(x_), 128, ptr(q_), 128, ptr(s_), 4, x_.shape[0] * x_.shape[1], 128, 0)
+            if isinstance(fn, str) and fn == "quant_vt":
+                x_, q_, s_ = d
+                return lib.utx_plan_add_quant_vt_mx8(h, ptr(x_), ptr(q_), ptr(s_), x_.shape[0], x_.shape[2])
+            if isinstance(fn, str) and fn == "attn8":
+                q8, qs, k8, ks, v8, vs, out, n_q, S_kv, S_pad = d
+                return lib.utx_plan_add_attn_fp8(h, ptr(q8), ptr(qs), ptr(k8), ptr(ks), ptr(v8), ptr(vs), ptr(out), out.stride(0), self.shape.num_heads,
+                                                 int(n_q), int(S_kv), int(S_pad), float(self.key_bias_log2), int(self.key_bias_period))
             if isinstance(fn, str) and fn == "temb_sum":
                 g = ws["e_g"] if self.shape.guidance_embeds else None
                 return lib.utx_plan_add_add3(h, ptr(ws["e_t"]), ptr(g), ptr(ws["e_p"]), ptr(ws["temb"]), ws["temb"].numel())
@@ -1066,7 +1091,7 @@ class FluxDiT:
         MX fp8 (returns None under sequence parallelism or with the fused q / k epilogue).  The result must equal compile_plan()'s entry for entry
         (tests/test_dit_ops_gpu.py::test_c_built_dit_plan_equals_the_python_built_one); the caller frees it with utx_plan_free."""
         from .._lib import DitConfig, DitDoubleBlock, DitLinear, DitSingleBlock, DitWeights, DitWorkspace
-        if self.sp is not None or self.fuse_qk:
+        if self.sp is not None or self.fuse_qk or self.fp8_attention:      # (the C-side builder assembles the bf16 attention only)
             return None
         p = next(iter(self._plans.values())) if p is None else p
         ws, sh, W = p["ws"], self.shape, self.W
