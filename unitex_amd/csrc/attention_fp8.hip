@@ -143,12 +143,15 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_fp8_kernel(Attn8Params p) {
     pb = a8_i32x8{0, 0, 0, 0, 0, 0, 0, 0};
     for (int t = 0; t < nt; ++t) {
         const int slot = t & 1;
-        int ksc0n = 0, ksc1n = 0, vscn = 0;
+        // the next tile's scale dwords are requested IN FRONT of its DMAs and stay untouched until the end of this iteration: the in-order counter then lets
+        // the one wait for them leave the two younger DMAs in flight (vmcnt(2)), behind this tile's compute.  (Round 4's first form shifted them at once:
+        // hipcc put `s_waitcnt vmcnt(0)` right behind the DMA requests -- every wave sat out the next tile's full fetch latency at the top of every tile.)
+        uint32_t ksc0n = 0, ksc1n = 0, vscn = 0;
         if (t + 1 < nt) {
-            A8_STAGE(t + 1, slot ^ 1);
             const long kr = (long)(t + 1) * A8_KVB + krow;
-            ksc0n = (int)(ksb[kr] >> (8 * lh)); ksc1n = (int)(ksb[kr + 32] >> (8 * lh));
-            vscn = (int)vsb[(long)(2 * (t + 1) + lh) * 32 + lq];
+            ksc0n = ksb[kr]; ksc1n = ksb[kr + 32];
+            vscn = vsb[(long)(2 * (t + 1) + lh) * 32 + lq];
+            A8_STAGE(t + 1, slot ^ 1);
         }
         const char* kb = kring + slot * A8_KTILE;
         const char* vb = vring + slot * A8_VTILE;
@@ -219,7 +222,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_fp8_kernel(Attn8Params p) {
         l_run += ps0 + ps1;
         pb = a8_i32x8{pb0, pb1, pb2, pb3, pb4, pb5, pb6, pb7};      // P of this tile: the B operand of the PV MFMAs issued in the next iteration (or behind the loop)
         __builtin_amdgcn_s_setprio(0);
-        ksc0 = ksc0n; ksc1 = ksc1n; vsc = vscn;
+        asm volatile("" : "+v"(ksc0n), "+v"(ksc1n), "+v"(vscn));      // first use of the three dwords: the wait for them lands HERE
+        ksc0 = (int)(ksc0n >> (8 * lh)); ksc1 = (int)(ksc1n >> (8 * lh)); vsc = (int)vscn;
         __syncthreads();     // this slot fully read by every wave; the next tile's DMA retired by the vmcnt(0) of this fence
     }
 
