@@ -104,7 +104,8 @@ int utx_plan_fork(utx_plan* p) {
     if (!p || p->cur_side || p->open_sections) return -2;
     if (!p->side && hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) != hipSuccess) return -5;
     hipEvent_t a, b;
-    if (hipEventCreateWithFlags(&a, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&b, hipEventDisableTiming) != hipSuccess) return -5;
+    if (hipEventCreateWithFlags(&a, hipEventDisableTiming) != hipSuccess) return -5;
+    if (hipEventCreateWithFlags(&b, hipEventDisableTiming) != hipSuccess) { (void)hipEventDestroy(a); return -5; }
     p->events.push_back(a); p->events.push_back(b);
     push(p, K_FORK);
     p->cur_side = 1; p->open_sections = 1;
