@@ -172,6 +172,38 @@ def cpu_baseline_backprojection():
             "sample": "oracle/geom_ref.c + numpy, 20k faces, 6 x 256^2 views, 512^2 atlas (x16 texels -> 2048^2)"}
 
 
+VISIBLE_ENV = ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")
+
+
+def device_identity(index):
+    """what one rank knows about the GPU it sits on: (the *_VISIBLE_DEVICES strings that number the devices of this process, its device index,
+    the hardware identity torch reports: uuid string + PCI domain / bus / device)."""
+    vis = tuple(os.environ.get(k, "") for k in VISIBLE_ENV)
+    hw = None
+    try:
+        pr = torch.cuda.get_device_properties(index)
+        hw = (str(getattr(pr, "uuid", "")), int(getattr(pr, "pci_domain_id", -1)), int(getattr(pr, "pci_bus_id", -1)), int(getattr(pr, "pci_device_id", -1)))
+    except Exception:  # noqa: BLE001 -- an identity that cannot be read is reported as unknown, never guessed
+        pass
+    return {"visible": vis, "index": int(index), "hw": hw}
+
+
+def count_distinct_devices(idents):
+    """(number of distinct GPUs under the ranks of a job, how it was counted) from the gathered device_identity() records.  Ranks that number the
+    same device list (identical *_VISIBLE_DEVICES -- what torch.distributed.run gives its workers) are on distinct GPUs exactly when their device
+    indices differ: that count needs nothing from the driver.  Ranks with different device lists are told apart by the hardware identity (PCI
+    address + uuid); if that is missing or the same placeholder everywhere while the lists differ, the answer is (None, ...) -- unknown is reported,
+    not turned into a refusal: an all-zero uuid must not abort a valid 8-GPU run."""
+    if all(i["visible"] == idents[0]["visible"] for i in idents):
+        return len({i["index"] for i in idents}), "device index under identical *_VISIBLE_DEVICES"
+    hws = [i["hw"] for i in idents]
+    if any(h is None for h in hws):
+        return None, "unknown (hardware identity unreadable on some rank)"
+    if len(set(hws)) == 1 and len({(i["visible"], i["index"]) for i in idents}) > 1:
+        return None, "unknown (every rank reports the same uuid / PCI address under different device lists)"
+    return len(set(hws)), "uuid + PCI address"
+
+
 def _gemm_census(model):
     try:
         return model.gemm_census()
@@ -245,16 +277,15 @@ def main():
         # what the job really is, from the group itself: ranks counted by a collective, and the devices they sit on (distinct GPUs, or the line says so)
         one = torch.ones(1, device=dev if backend == "nccl" else "cpu", dtype=torch.float32)
         dist.all_reduce(one)
-        pr = torch.cuda.get_device_properties(local_rank)
-        ident = "%s/%s" % (getattr(pr, "uuid", None) or getattr(pr, "pci_bus_id", None) or local_rank, os.environ.get("HIP_VISIBLE_DEVICES", ""))
         idents = [None] * world
-        dist.all_gather_object(idents, ident)
+        dist.all_gather_object(idents, device_identity(local_rank))
+        distinct, how = count_distinct_devices(idents)
         group_info = {"backend": dist.get_backend(), "world_size_from_group": dist.get_world_size(), "ranks_counted_by_all_reduce": int(one.item()),
-                      "distinct_devices": len(set(idents))}
+                      "distinct_devices": distinct, "distinct_devices_from": how}
         if group_info["ranks_counted_by_all_reduce"] != args.gpus or group_info["world_size_from_group"] != args.gpus:
             raise SystemExit("bench.py --gpus %d: the process group holds %d rank(s)" % (args.gpus, group_info["ranks_counted_by_all_reduce"]))
-        if backend == "nccl" and group_info["distinct_devices"] != world:
-            raise SystemExit("bench.py --gpus %d: the ranks share devices (%d distinct): one process per GPU is the contract" % (args.gpus, group_info["distinct_devices"]))
+        if backend == "nccl" and distinct is not None and distinct != world:
+            raise SystemExit("bench.py --gpus %d: the ranks share devices (%d distinct, by %s): one process per GPU is the contract" % (args.gpus, distinct, how))
     else:
         group_info = None
 

@@ -172,6 +172,36 @@ def test_bench_workload_arithmetic_matches_baseline_md():
             assert abs(fa / 1e12 - attn_ref) / attn_ref < 5e-3
 
 
+def test_bench_counts_the_gpus_under_a_job_without_trusting_a_placeholder_uuid():
+    """bench.py --gpus N refuses ranks that share a GPU; the count must not turn a driver that reports the same (all-zero) uuid for every device
+    into a refusal of a valid 8-GPU job, and must still see two ranks on one device."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(HERE), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    zero = ("00000000-0000-0000-0000-000000000000", 0, 0, 0)
+    same_env = ("", "", "")
+    # torch.distributed.run: one device list, rank r on index r -- distinct whatever the driver says about uuids
+    ids = [{"visible": same_env, "index": r, "hw": zero} for r in range(8)]
+    assert bench.count_distinct_devices(ids)[0] == 8
+    # fewer devices than ranks (indices wrapped): shared
+    ids = [{"visible": same_env, "index": r % 4, "hw": zero} for r in range(8)]
+    assert bench.count_distinct_devices(ids)[0] == 4
+    # one device per process through HIP_VISIBLE_DEVICES: told apart by the hardware identity ...
+    ids = [{"visible": (str(r), "", ""), "index": 0, "hw": ("GPU-%02x" % r, 0, 0x10 + r, 0)} for r in range(4)]
+    assert bench.count_distinct_devices(ids) == (4, "uuid + PCI address")
+    # ... two of them on the same physical GPU are seen ...
+    ids[3]["hw"] = ids[2]["hw"]
+    assert bench.count_distinct_devices(ids)[0] == 3
+    # ... and a placeholder identity under different device lists is "unknown", not a refusal
+    ids = [{"visible": (str(r), "", ""), "index": 0, "hw": zero} for r in range(4)]
+    assert bench.count_distinct_devices(ids)[0] is None
+    ids[1]["hw"] = None
+    assert bench.count_distinct_devices(ids)[0] is None
+    rec = bench.device_identity(0)      # no GPU here: the record still forms, hardware identity unknown
+    assert rec["index"] == 0 and len(rec["visible"]) == 3
+
+
 def test_reproject_and_query_field_forwards_variant_switches(tmp_path):
     """host logic of RGBTextureFullPipelineBase.reproject_and_query_field (reference pipeline.py:313-347): the 2 x 3 grid is
     cut into six view images in (row, col) order, and `method` / `inpainting` reach the inverse renderer as method,
