@@ -1,0 +1,62 @@
+#!/usr/bin/env python
+"""A/B of the opt-in peeled attention loop (UTX_ATTN_PEEL = 1 / 2: attention_glds.hip VAR 12 / 13) against the default kernel, same process, interleaved launches,
+at the two operating points (S = 13 376 and 50 240 executed tokens, 24 heads, pre-scaled Q, key multiplicity 8 on tile 0 as in the step).  Prints bit-identity
+and TF/s per arm.  RUN tests/test_attention_peel_gpu.py FIRST (UTX_RUN_UNVALIDATED=1): these variants had not run on hardware when they were committed.
+
+    UTX_RUN_UNVALIDATED=1 python -m pytest tests/test_attention_peel_gpu.py -m gpu -q && python tools/attn_peel_ab.py"""
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from unitex_amd import _lib            # noqa: E402
+from unitex_amd.flux import ops        # noqa: E402
+
+BF, H = torch.bfloat16, 24
+
+
+def main():
+    rounds = int(os.environ.get("UTX_AB_ROUNDS", "5"))
+    for S in (13376, 50240):
+        g = torch.Generator(device="cuda").manual_seed(S)
+        S_pad = (S + 63) // 64 * 64
+        Qh = (torch.randn(H, S_pad, 128, generator=g, device="cuda") * (1.4426950408889634 / math.sqrt(128.0))).to(BF)
+        Kh = torch.randn(H, S_pad, 128, generator=g, device="cuda").to(BF)
+        Vt = torch.randn(H, 128, S_pad, generator=g, device="cuda").to(BF)
+        out = torch.empty(S, H * 128, dtype=BF, device="cuda")
+        fl = 4.0 * S * S * 128 * H
+
+        def run(peel):
+            _lib.set_option("UTX_ATTN_PEEL", peel)
+            ops.attention(Qh, Kh, Vt, S=S, scale=0.0, key_bias_log2=3.0, out=out)
+
+        ref = None
+        for peel in (0, 1, 2):
+            run(peel)
+            torch.cuda.synchronize()
+            if ref is None:
+                ref = out.clone()
+            else:
+                print("S = %6d  UTX_ATTN_PEEL=%d  bit-identical to the default: %s" % (S, peel, torch.equal(out.view(torch.int16), ref.view(torch.int16))), flush=True)
+        times = {0: [], 1: [], 2: []}
+        for _ in range(rounds):
+            for peel in (0, 1, 2):
+                run(peel)      # warm
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _r in range(3):
+                    run(peel)
+                b.record()
+                torch.cuda.synchronize()
+                times[peel].append(a.elapsed_time(b) / 3.0)
+        for peel in (0, 1, 2):
+            t = sorted(times[peel])
+            med = t[len(t) // 2]
+            print("S = %6d  UTX_ATTN_PEEL=%d  med %8.3f ms  best %8.3f ms  -> %7.1f TF/s" % (S, peel, med, t[0], fl / (med * 1e-3) / 1e12), flush=True)
+    _lib.set_option("UTX_ATTN_PEEL", 0)
+
+
+if __name__ == "__main__":
+    main()

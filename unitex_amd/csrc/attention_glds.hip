@@ -168,21 +168,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
     // halves alternate compute and load segments behind barriers; here all eight waves run the same interleaved stream and the per-tile flips
     // (prio 1 while computing, 0 at the barrier) already are the better arbitration
     if (VAR == 6 && wave >= 4) __builtin_amdgcn_s_setprio(1);
-    for (int u = 0; u < ngrp; ++u) {
-      const int gs = (u & 1) * TPB;                      // first ring slot of this group
-#pragma unroll
-      for (int i = 0; i < TPB; ++i)
-          if ((u + 1) * TPB + i < nt) AG_STAGE((u + 1) * TPB + i, (gs ^ TPB) + i);
-      for (int sub = 0; sub < TPB; ++sub) {
-        const int t = u * TPB + sub;
-        if (t >= nt) break;
-        const char* kb = kring + (gs + sub) * AG_KTILE;
-        const char* vb = vring + (gs + sub) * AG_VTILE;
-        const bool ragged = (t == nt - 1) && (Sk & (AG_KVB - 1));
-        const int lim = Sk - t * AG_KVB - 8 * lh;
-
-        f32x16 sa0, sa1;
-        bf16x8 kfa[8], kfb[8], vfa[8], vfb[8];
+    // The tile body as a macro over SP_: 1 = the general tile (first tile, ragged last tile, key-multiplicity tiles), 0 = a tile none of these can apply to (their
+    // branches fold away).  The default kernel expands AG_TILE_BODY(1) only: the instruction stream it always had (listing compared before / after the refactor).
 #define AG_EXPB(sa_, p0_, p1_, ps_)                                                                  \
         {                                                                                            \
             f32x2 acc2_ = {0.f, 0.f};                                                                \
@@ -220,77 +207,122 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
             _Pragma("unroll") for (int i = 0; i < 4; ++i)                                            \
                 _Pragma("unroll") for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha_;                 \
         }
-        float ps0 = 0.f, ps1 = 0.f;
-        // key multiplicity: every key of this tile stands for 2^key_bias_log2 identical keys (text-token dedup) -> bias on its scores
-        const int tg = tb + t;                               // tile index in the whole sequence
-        const bool kbias = (p.key_bias_log2 != 0.f) && (p.key_bias_period > 0 ? (tg % p.key_bias_period == 0) : (tg == 0));
-        const float kbv = PRESC ? p.key_bias_log2 : p.key_bias_log2 / c2;
-        // S0: QK(0); block-1 K fragments stream in behind the MFMAs
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) kfa[kk] = *reinterpret_cast<const bf16x8*>(kb + kx[kk]);
-        if (VAR != 1 && VAR != 6) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            if (VAR == 3) kfb[kk] = kfa[kk];   /* ablation: half of the K fragment reads removed (wrong results) */
-            else kfb[kk] = *reinterpret_cast<const bf16x8*>(kb + 8192 + kx[kk]);
-            if (kk == 0) { AG_MM(sa0, kfa[kk], qf[kk], negm) } else { AG_MM(sa0, kfa[kk], qf[kk], sa0) }
+#define AG_TILE_BODY(SP_)                                                                            \
+        {                                                                                            \
+        const char* kb = kring + (gs + sub) * AG_KTILE;                                              \
+        const char* vb = vring + (gs + sub) * AG_VTILE;                                              \
+        const bool ragged = (SP_) && (t == nt - 1) && (Sk & (AG_KVB - 1));                           \
+        const int lim = Sk - t * AG_KVB - 8 * lh;                                                    \
+        f32x16 sa0, sa1;                                                                             \
+        bf16x8 kfa[8], kfb[8], vfa[8], vfb[8];                                                       \
+        float ps0 = 0.f, ps1 = 0.f;                                                                  \
+        /* key multiplicity: every key of this tile stands for 2^key_bias_log2 identical keys (text-token dedup) -> bias on its scores */ \
+        const int tg = tb + t;   /* tile index in the whole sequence */                              \
+        const bool kbias = (SP_) && (p.key_bias_log2 != 0.f) && (p.key_bias_period > 0 ? (tg % p.key_bias_period == 0) : (tg == 0)); \
+        const float kbv = PRESC ? p.key_bias_log2 : p.key_bias_log2 / c2;                            \
+        /* S0: QK(0); block-1 K fragments stream in behind the MFMAs */                              \
+        _Pragma("unroll")                                                                            \
+        for (int kk = 0; kk < 8; ++kk) kfa[kk] = *reinterpret_cast<const bf16x8*>(kb + kx[kk]);      \
+        if (VAR != 1 && VAR != 6) __builtin_amdgcn_s_setprio(1);                                     \
+        _Pragma("unroll")                                                                            \
+        for (int kk = 0; kk < 8; ++kk) {                                                             \
+            if (VAR == 3) kfb[kk] = kfa[kk];   /* ablation: half of the K fragment reads removed (wrong results) */ \
+            else kfb[kk] = *reinterpret_cast<const bf16x8*>(kb + 8192 + kx[kk]);                     \
+            if (kk == 0) { AG_MM(sa0, kfa[kk], qf[kk], negm) } else { AG_MM(sa0, kfa[kk], qf[kk], sa0) } \
+        }                                                                                            \
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                                           \
+        _Pragma("unroll")                                                                            \
+        for (int i_ = 0; i_ < 8; ++i_) {                                                             \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                       \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                       \
+        }                                                                                            \
+        /* S1: QK(1) || exp(0); V fragments of block 0 (key chunks s = 0, 1) stream in */            \
+        _Pragma("unroll")                                                                            \
+        for (int kk = 0; kk < 8; ++kk) {                                                             \
+            vfa[kk] = *reinterpret_cast<const bf16x8*>(vb + (kk & 3) * 4096 + vx[kk >> 2]);          \
+            if (kk == 0) { AG_MM(sa1, kfb[kk], qf[kk], negm) } else { AG_MM(sa1, kfb[kk], qf[kk], sa1) } \
+        }                                                                                            \
+        if (kbias) {                                                                                 \
+        _Pragma("unroll")                                                                            \
+            for (int r = 0; r < 16; ++r) sa0[r] += kbv;                                              \
+        }                                                                                            \
+        AG_EXPB(sa0, pb[0], pb[1], ps0)                                                              \
+        _Pragma("unroll")                                                                            \
+        for (int i_ = 0; i_ < ((VAR == 2 || VAR == 13) ? 0 : 8); ++i_) {                                            \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);                                       \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);                                       \
+            __builtin_amdgcn_sched_group_barrier(0x402, 4, 1);                                       \
+        }                                                                                            \
+        if (((SP_) && t == 0 && VAR != 10) || ragged || !__all(ps0 <= 8192.0f)) {      /* VAR 10 (ablation build, WRONG results): no first-tile max pass -- what the prologue's slow path costs */ \
+            AG_SLOW(sa0, sa1, true, 0, 0, (SP_) && t == 0)                                           \
+            AG_EXPB(sa0, pb[0], pb[1], ps0)                                                          \
+        }                                                                                            \
+        l_run += ps0;                                                                                \
+        /* S2: PV(0) || exp(1); V fragments of block 1 (s = 2, 3) stream in */                       \
+        _Pragma("unroll")                                                                            \
+        for (int i = 0; i < 8; ++i) {                                                                \
+            if (VAR == 3) vfb[i] = vfa[i];   /* ablation: half of the V fragment reads removed (wrong results) */ \
+            else vfb[i] = *reinterpret_cast<const bf16x8*>(vb + (i & 3) * 4096 + vx[2 + (i >> 2)]);  \
+            AG_MM(oacc[i & 3], vfa[i], pb[i >> 2], oacc[i & 3])                                      \
+        }                                                                                            \
+        if (kbias) {                                                                                 \
+        _Pragma("unroll")                                                                            \
+            for (int r = 0; r < 16; ++r) sa1[r] += kbv;                                              \
+        }                                                                                            \
+        AG_EXPB(sa1, pb[2], pb[3], ps1)                                                              \
+        _Pragma("unroll")                                                                            \
+        for (int i_ = 0; i_ < ((VAR == 2 || VAR == 13) ? 0 : 8); ++i_) {                                            \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 2);                                       \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 2);                                       \
+            __builtin_amdgcn_sched_group_barrier(0x402, 4, 2);                                       \
+        }                                                                                            \
+        if (ragged || !__all(ps1 <= 8192.0f)) {                                                      \
+            AG_SLOW(sa1, sa0, false, 8192, 32, false)                                                \
+            AG_EXPB(sa1, pb[2], pb[3], ps1)                                                          \
+        }                                                                                            \
+        l_run += ps1;                                                                                \
+        /* S3: PV(1) */                                                                              \
+        _Pragma("unroll")                                                                            \
+        for (int i = 0; i < 8; ++i)                                                                  \
+            AG_MM(oacc[i & 3], vfb[i], pb[2 + (i >> 2)], oacc[i & 3])                                \
+        if (VAR != 1 && VAR != 6) __builtin_amdgcn_s_setprio(0);                                     \
         }
-        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+    // VAR 12 / 13 (opt-in: UTX_ATTN_PEEL=1 / 2, 13 = without the S1 / S2 interleave hints; same arithmetic in the same order per element = bit-identical by construction; NOT yet run on hardware): the first tile and a
+    // ragged last tile run the general body in FRONT of / BEHIND the loop, the loop itself a copy without their branches.  In the general body `if (kbias)` and the
+    // first-tile test cut S1 / S2 into several basic blocks: hipcc then puts the QK^T / PV MFMAs into one block and the exponentials into the next (visible in the
+    // listing of the default kernel), so within a wave matrix and VALU work never overlap and the sched_group_barrier interleave -- which works inside ONE block --
+    // cannot bind.  (Peeling with an if / else INSIDE the loop made hipcc spill: 256 VGPRs + 216 B of scratch.)  Launches whose key-multiplicity tiles recur
+    // (key_bias_period > 0: sequence parallelism) keep the general loop.
+    if ((VAR == 12 || VAR == 13) && TPB == 1 && !(p.key_bias_period > 0 && p.key_bias_log2 != 0.f)) {
+        const bool rag_ = (Sk & (AG_KVB - 1)) != 0;
+        const int fast_end_ = rag_ ? nt - 1 : nt;                 // tiles [1, fast_end_) take the fast body
+        {
+            const int gs = 0, sub = 0, t = 0;
+            if (1 < nt) AG_STAGE(1, 1);
+            AG_TILE_BODY(1)
+            __syncthreads();
+        }
+        for (int u = 1; u < fast_end_; ++u) {
+            const int gs = u & 1, sub = 0, t = u;
+            if (u + 1 < nt) AG_STAGE(u + 1, gs ^ 1);
+            AG_TILE_BODY(0)
+            __syncthreads();
+        }
+        if (rag_ && nt > 1) {
+            const int gs = (nt - 1) & 1, sub = 0, t = nt - 1;
+            AG_TILE_BODY(1)
+            __syncthreads();
+        }
+    } else
+    for (int u = 0; u < ngrp; ++u) {
+      const int gs = (u & 1) * TPB;                      // first ring slot of this group
 #pragma unroll
-        for (int i_ = 0; i_ < 8; ++i_) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        // S1: QK(1) || exp(0); V fragments of block 0 (key chunks s = 0, 1) stream in
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            vfa[kk] = *reinterpret_cast<const bf16x8*>(vb + (kk & 3) * 4096 + vx[kk >> 2]);
-            if (kk == 0) { AG_MM(sa1, kfb[kk], qf[kk], negm) } else { AG_MM(sa1, kfb[kk], qf[kk], sa1) }
-        }
-        if (kbias) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sa0[r] += kbv;
-        }
-        AG_EXPB(sa0, pb[0], pb[1], ps0)
-#pragma unroll
-        for (int i_ = 0; i_ < (VAR == 2 ? 0 : 8); ++i_) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
-            __builtin_amdgcn_sched_group_barrier(0x402, 4, 1);
-        }
-        if ((t == 0 && VAR != 10) || ragged || !__all(ps0 <= 8192.0f)) {      /* VAR 10 (ablation build, WRONG results): no first-tile max pass -- what the prologue's slow path costs */
-            AG_SLOW(sa0, sa1, true, 0, 0, t == 0)
-            AG_EXPB(sa0, pb[0], pb[1], ps0)
-        }
-        l_run += ps0;
-        // S2: PV(0) || exp(1); V fragments of block 1 (s = 2, 3) stream in
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if (VAR == 3) vfb[i] = vfa[i];   /* ablation: half of the V fragment reads removed (wrong results) */
-            else vfb[i] = *reinterpret_cast<const bf16x8*>(vb + (i & 3) * 4096 + vx[2 + (i >> 2)]);
-            AG_MM(oacc[i & 3], vfa[i], pb[i >> 2], oacc[i & 3])
-        }
-        if (kbias) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sa1[r] += kbv;
-        }
-        AG_EXPB(sa1, pb[2], pb[3], ps1)
-#pragma unroll
-        for (int i_ = 0; i_ < (VAR == 2 ? 0 : 8); ++i_) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 2);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 2);
-            __builtin_amdgcn_sched_group_barrier(0x402, 4, 2);
-        }
-        if (ragged || !__all(ps1 <= 8192.0f)) {
-            AG_SLOW(sa1, sa0, false, 8192, 32, false)
-            AG_EXPB(sa1, pb[2], pb[3], ps1)
-        }
-        l_run += ps1;
-        // S3: PV(1)
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            AG_MM(oacc[i & 3], vfb[i], pb[2 + (i >> 2)], oacc[i & 3])
-        if (VAR != 1 && VAR != 6) __builtin_amdgcn_s_setprio(0);
+      for (int i = 0; i < TPB; ++i)
+          if ((u + 1) * TPB + i < nt) AG_STAGE((u + 1) * TPB + i, (gs ^ TPB) + i);
+      for (int sub = 0; sub < TPB; ++sub) {
+        const int t = u * TPB + sub;
+        if (t >= nt) break;
+        AG_TILE_BODY(1)
       }
       __syncthreads();     // this group fully read by every wave; the next group (DMA) retired by the vmcnt(0) of this fence
     }
@@ -445,7 +477,7 @@ static int launch_glds(AttnParams p, hipStream_t stream) {
     p.nqb = ((p.Sq > 0 ? p.Sq : p.S) + 255) / 256;
     p.w_base = 0; p.nsplit = 1; p.tiles_per_split = 0; p.part_o = nullptr; p.part_lse = nullptr;
     int pl[4] = {p.nqb * p.H, 0, 1, 0};
-    if (TPB == 1 && (VAR == 0 || VAR == 6 || VAR == 7 || VAR == 8 || VAR == 9 || VAR == 10) && !p.flags) utx_attn_split_plan_impl(p.H, p.Sq, p.S, utx_ncu(), pl);
+    if (TPB == 1 && (VAR == 0 || VAR == 6 || VAR == 7 || VAR == 8 || VAR == 9 || VAR == 10 || VAR == 12 || VAR == 13) && !p.flags) utx_attn_split_plan_impl(p.H, p.Sq, p.S, utx_ncu(), pl);
     const int nwg = pl[0], nfull = pl[1], ns = pl[2], tps = pl[3], r = nwg - nfull;
     // the scratch of the split is CALLER-OWNED (utx_attn_fwd_bf16_ws; the legacy entry points pass the context's own buffer, grown outside of any
     // capture): nothing is allocated here, a launch whose scratch is missing or too small runs unsplit -- same result up to one bf16 rounding of the
@@ -473,6 +505,9 @@ extern "C" int utx_launch_attn_fwd_glds(const AttnParams* p, int presc, hipStrea
         return presc ? launch_glds<1, 1, 0, true>(*p, stream) : launch_glds<0, 1, 0, true>(*p, stream);
     }
     if (tpb == 2) return presc ? launch_glds<1, 2>(*p, stream) : launch_glds<0, 2>(*p, stream);
+    // UTX_ATTN_PEEL=1 (opt-in; the pre-scaled form the DiT uses): the hot loop without the first-tile / ragged / key-multiplicity branches (VAR 12 above)
+    if (g_utx_opt.attn_peel == 1 && presc) return launch_glds<1, 1, 12>(*p, stream);
+    if (g_utx_opt.attn_peel == 2 && presc) return launch_glds<1, 1, 13>(*p, stream);      // the same without the S1 / S2 interleave hints
 #ifdef UTX_ABLATION
     { const int var = g_utx_opt.attn_var_abl;   // timing A/B only: 1 = no s_setprio, 2 = no interleave hints, 3 = half the fragment reads (WRONG results), 4 = row sums with v_pk_add_f32
       if (var == 1 && presc) return launch_glds<1, 1, 1>(*p, stream);
