@@ -204,6 +204,27 @@ def count_distinct_devices(idents):
     return len(set(hws)), "uuid + PCI address"
 
 
+def attention_variant_experiment(timeout_s=150):
+    """Beside the line, never part of `value`: the opt-in peeled attention loop (UTX_ATTN_PEEL = 1 / 2 / 3, csrc/attention_glds.hip VAR 12 / 13 / 14) against the default
+    kernel -- bit-identity and an interleaved A/B at the two operating points (tools/attn_peel_ab.py --json).  Those variants were written without GPU access; they
+    run in a CHILD process with a timeout, after every measurement of this process is finished, so that whatever they do cannot cost the bench line.
+    UTX_BENCH_EXPERIMENTS=0 skips it."""
+    import subprocess
+    tool = os.path.join(ROOT, "tools", "attn_peel_ab.py")
+    note = "opt-in variants, measured in a child process behind the timed region; the line's value / roofline are the DEFAULT kernel's"
+    try:
+        env = dict(os.environ, UTX_AB_ROUNDS="3")
+        env.pop("UTX_ATTN_PEEL", None)
+        r = subprocess.run([sys.executable, tool, "--json"], capture_output=True, text=True, timeout=timeout_s, env=env)
+        last = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not last:
+            return {"attn_peel": {"error": "rc %d: %s" % (r.returncode, (r.stderr or r.stdout)[-400:])}, "note": note}
+        return {"attn_peel": json.loads(last[-1]), "note": note,
+                "layout": "{tokens: {UTX_ATTN_PEEL value: {bit_identical_to_default, med_ms, best_ms, tflops}}}, 24 heads, key multiplicity 8 on tile 0; '0' = the default kernel in the same process"}
+    except Exception as e:  # noqa: BLE001 -- an experiment must never cost the line
+        return {"attn_peel": {"error": repr(e)[:400]}, "note": note}
+
+
 def _gemm_census(model):
     try:
         return model.gemm_census()
@@ -602,7 +623,14 @@ def main():
             except Exception as e:  # noqa: BLE001 -- the GPU number must still be reported
                 out["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": ncpu, "kind": "port",
                                        "sample": "failed: %r" % (e,)}
+        if world == 1 and not args.sp_self_test and not args.fp8 and not args.fp8_attn and os.environ.get("UTX_BENCH_EXPERIMENTS", "1") != "0":
+            torch.cuda.synchronize()      # nothing of this process is in flight any more
+            out["config"]["experiments"] = attention_variant_experiment()
         print(json.dumps(out))
+        sys.stdout.flush()
+        if "error" in out["config"].get("experiments", {}).get("attn_peel", {}):
+            # the child failed (an unvalidated kernel may have faulted the device): the line is out, skip this process's device teardown
+            os._exit(0)
     if world > 1 or args.sp_self_test:
         import torch.distributed as dist
         dist.destroy_process_group()

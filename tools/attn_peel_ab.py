@@ -14,12 +14,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from unitex_amd import _lib            # noqa: E402
 from unitex_amd.flux import ops        # noqa: E402
 
-BF, H = torch.bfloat16, 24
+BF, H = torch.bfloat16, int(os.environ.get("UTX_AB_HEADS", "24"))
+SIZES = tuple(int(x) for x in os.environ.get("UTX_AB_SIZES", "13376,50240").split(","))      # executed tokens of the two operating points
 
 
 def main():
     rounds = int(os.environ.get("UTX_AB_ROUNDS", "5"))
-    for S in (13376, 50240):
+    as_json = "--json" in sys.argv      # bench.py: one JSON object on the last line instead of the table
+    result = {}
+    say = (lambda *a, **k: None) if as_json else print
+    for S in SIZES:
         g = torch.Generator(device="cuda").manual_seed(S)
         S_pad = (S + 63) // 64 * 64
         Qh = (torch.randn(H, S_pad, 128, generator=g, device="cuda") * (1.4426950408889634 / math.sqrt(128.0))).to(BF)
@@ -39,7 +43,9 @@ def main():
             if ref is None:
                 ref = out.clone()
             else:
-                print("S = %6d  UTX_ATTN_PEEL=%d  bit-identical to the default: %s" % (S, peel, torch.equal(out.view(torch.int16), ref.view(torch.int16))), flush=True)
+                same = bool(torch.equal(out.view(torch.int16), ref.view(torch.int16)))
+                result.setdefault(str(S), {}).setdefault(str(peel), {})["bit_identical_to_default"] = same
+                say("S = %6d  UTX_ATTN_PEEL=%d  bit-identical to the default: %s" % (S, peel, same), flush=True)
         times = {0: [], 1: [], 2: [], 3: []}
         for _ in range(rounds):
             for peel in (0, 1, 2, 3):
@@ -54,8 +60,12 @@ def main():
         for peel in (0, 1, 2, 3):
             t = sorted(times[peel])
             med = t[len(t) // 2]
-            print("S = %6d  UTX_ATTN_PEEL=%d  med %8.3f ms  best %8.3f ms  -> %7.1f TF/s" % (S, peel, med, t[0], fl / (med * 1e-3) / 1e12), flush=True)
+            result.setdefault(str(S), {}).setdefault(str(peel), {}).update(med_ms=med, best_ms=t[0], tflops=fl / (med * 1e-3) / 1e12)
+            say("S = %6d  UTX_ATTN_PEEL=%d  med %8.3f ms  best %8.3f ms  -> %7.1f TF/s" % (S, peel, med, t[0], fl / (med * 1e-3) / 1e12), flush=True)
     _lib.set_option("UTX_ATTN_PEEL", 0)
+    if as_json:
+        import json
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":
