@@ -1,7 +1,7 @@
-"""The control flow of the opt-in peeled attention loop (attention_glds.hip, VAR 12 / 13 / 14: UTX_ATTN_PEEL) against the general loop, on the CPU.
+"""The control flow of the opt-in peeled attention loop (attention_glds.hip, VAR 12 ... 15: UTX_ATTN_PEEL) against the general loop, on the CPU.
 
 The peeled variants run the SAME tile body (a macro) -- what was written by hand is only WHICH tile goes through which copy, into which ring slot the next
-tile is staged, and where the barriers sit.  This test lifts exactly those source lines out of the kernel (from the `if ((VAR == 12 ...` that selects the
+tile is staged, and where the barriers sit.  This test lifts exactly those source lines out of the kernel (from the `if ((VAR >= 12 ...` that selects the
 peeled loop to the end of the general loop), compiles them with g++ around stubs that record the events (stage(tile, slot) / body(tile, slot, special) /
 barrier), and checks for every tile count and raggedness that the peeled loop issues the general loop's event sequence -- with the general body exactly on
 the first tile and a ragged last tile, and with the general loop itself whenever key-multiplicity tiles recur."""
@@ -42,7 +42,7 @@ int main() {
         const int nt = (Sk + 63) / 64;
         const bool rag = Sk %% 64;
         Ev g = run<0, 1>(Sk, p);
-        Ev vs[3] = {run<12, 1>(Sk, p), run<13, 1>(Sk, p), run<14, 1>(Sk, p)};
+        Ev vs[4] = {run<12, 1>(Sk, p), run<13, 1>(Sk, p), run<14, 1>(Sk, p), run<15, 1>(Sk, p)};
         for (auto& v : vs) {
             ++checked;
             if (v.size() != g.size()) { ++bad; printf("Sk %%d per %%d: %%zu vs %%zu events\n", Sk, per, v.size(), g.size()); continue; }
@@ -74,7 +74,7 @@ int main() {
 
 def _loop_source():
     lines = open(SRC).read().split("\n")
-    start = next(i for i, l in enumerate(lines) if l.lstrip().startswith("if ((VAR == 12 || VAR == 13 || VAR == 14) && TPB == 1"))
+    start = next(i for i, l in enumerate(lines) if l.lstrip().startswith("if ((VAR >= 12 && VAR <= 15) && TPB == 1"))
     end = next(i for i, l in enumerate(lines) if "this group fully read by every wave" in l)
     assert 0 < start < end and lines[end + 1].strip() == "}", "the loop block of attention_glds.hip moved: update this test's markers"
     block = [l for l in lines[start:end + 2] if not l.lstrip().startswith("#pragma")]

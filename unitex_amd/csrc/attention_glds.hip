@@ -229,6 +229,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
             if (VAR == 3) kfb[kk] = kfa[kk];   /* ablation: half of the K fragment reads removed (wrong results) */ \
             else kfb[kk] = *reinterpret_cast<const bf16x8*>(kb + 8192 + kx[kk]);                     \
             if (kk == 0) { AG_MM(sa0, kfa[kk], qf[kk], negm) } else { AG_MM(sa0, kfa[kk], qf[kk], sa0) } \
+            if (VAR == 15 && !(SP_)) __builtin_amdgcn_sched_barrier(0);                              \
         }                                                                                            \
         __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                                           \
         _Pragma("unroll")                                                                            \
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                       \
         }                                                                                            \
         /* S1: QK(1) || exp(0); V fragments of block 0 (key chunks s = 0, 1) stream in */            \
-        if (VAR == 14 && !(SP_)) __builtin_amdgcn_sched_barrier(0);                                  \
+        if ((VAR == 14 || VAR == 15) && !(SP_)) __builtin_amdgcn_sched_barrier(0);                                  \
         _Pragma("unroll")                                                                            \
         for (int kk = 0; kk < 8; ++kk) {                                                             \
             vfa[kk] = *reinterpret_cast<const bf16x8*>(vb + (kk & 3) * 4096 + vx[kk >> 2]);          \
@@ -288,14 +289,15 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
             AG_MM(oacc[i & 3], vfb[i], pb[2 + (i >> 2)], oacc[i & 3])                                \
         if (VAR != 1 && VAR != 6) __builtin_amdgcn_s_setprio(0);                                     \
         }
-    // VAR 12 / 13 / 14 (opt-in: UTX_ATTN_PEEL=1 / 2 / 3; 13 = without the S1 / S2 interleave hints, 14 = 12 + a hard scheduling boundary between S0 and S1, so that S1's
-    // hint pipeline sees the QK^T(1) MFMAs only and hipcc does not hoist them into S0; same arithmetic in the same order per element = bit-identical by construction; NOT yet run on hardware): the first tile and a
+    // VAR 12 / 13 / 14 / 15 (opt-in: UTX_ATTN_PEEL=1 / 2 / 3 / 4; 13 = without the S1 / S2 interleave hints, 14 = 12 + a hard scheduling boundary between S0 and S1, so that S1's
+    // hint pipeline sees the QK^T(1) MFMAs only and hipcc does not hoist them into S0, 15 = 14 + a boundary behind every {K fragment read, QK^T(0) MFMA} pair of S0, so that the
+    // second block's fragment reads stream in behind the MFMAs instead of all sixteen reads standing in front of the first one; same arithmetic in the same order per element = bit-identical by construction; NOT yet run on hardware): the first tile and a
     // ragged last tile run the general body in FRONT of / BEHIND the loop, the loop itself a copy without their branches.  In the general body `if (kbias)` and the
     // first-tile test cut S1 / S2 into several basic blocks: hipcc then puts the QK^T / PV MFMAs into one block and the exponentials into the next (visible in the
     // listing of the default kernel), so within a wave matrix and VALU work never overlap and the sched_group_barrier interleave -- which works inside ONE block --
     // cannot bind.  (Peeling with an if / else INSIDE the loop made hipcc spill: 256 VGPRs + 216 B of scratch.)  Launches whose key-multiplicity tiles recur
     // (key_bias_period > 0: sequence parallelism) keep the general loop.
-    if ((VAR == 12 || VAR == 13 || VAR == 14) && TPB == 1 && !(p.key_bias_period > 0 && p.key_bias_log2 != 0.f)) {
+    if ((VAR >= 12 && VAR <= 15) && TPB == 1 && !(p.key_bias_period > 0 && p.key_bias_log2 != 0.f)) {
         const bool rag_ = (Sk & (AG_KVB - 1)) != 0;
         const int fast_end_ = rag_ ? nt - 1 : nt;                 // tiles [1, fast_end_) take the fast body
         {
@@ -479,7 +481,7 @@ static int launch_glds(AttnParams p, hipStream_t stream) {
     p.nqb = ((p.Sq > 0 ? p.Sq : p.S) + 255) / 256;
     p.w_base = 0; p.nsplit = 1; p.tiles_per_split = 0; p.part_o = nullptr; p.part_lse = nullptr;
     int pl[4] = {p.nqb * p.H, 0, 1, 0};
-    if (TPB == 1 && (VAR == 0 || VAR == 6 || VAR == 7 || VAR == 8 || VAR == 9 || VAR == 10 || VAR == 12 || VAR == 13 || VAR == 14) && !p.flags) utx_attn_split_plan_impl(p.H, p.Sq, p.S, utx_ncu(), pl);
+    if (TPB == 1 && (VAR == 0 || VAR == 6 || VAR == 7 || VAR == 8 || VAR == 9 || VAR == 10 || (VAR >= 12 && VAR <= 15)) && !p.flags) utx_attn_split_plan_impl(p.H, p.Sq, p.S, utx_ncu(), pl);
     const int nwg = pl[0], nfull = pl[1], ns = pl[2], tps = pl[3], r = nwg - nfull;
     // the scratch of the split is CALLER-OWNED (utx_attn_fwd_bf16_ws; the legacy entry points pass the context's own buffer, grown outside of any
     // capture): nothing is allocated here, a launch whose scratch is missing or too small runs unsplit -- same result up to one bf16 rounding of the
@@ -510,7 +512,8 @@ extern "C" int utx_launch_attn_fwd_glds(const AttnParams* p, int presc, hipStrea
     // UTX_ATTN_PEEL=1 (opt-in; the pre-scaled form the DiT uses): the hot loop without the first-tile / ragged / key-multiplicity branches (VAR 12 above)
     if (g_utx_opt.attn_peel == 1 && presc) return launch_glds<1, 1, 12>(*p, stream);
     if (g_utx_opt.attn_peel == 2 && presc) return launch_glds<1, 1, 13>(*p, stream);
-    if (g_utx_opt.attn_peel == 3 && presc) return launch_glds<1, 1, 14>(*p, stream);      // + scheduling boundary between S0 and S1      // the same without the S1 / S2 interleave hints
+    if (g_utx_opt.attn_peel == 3 && presc) return launch_glds<1, 1, 14>(*p, stream);
+    if (g_utx_opt.attn_peel == 4 && presc) return launch_glds<1, 1, 15>(*p, stream);      // + K fragment reads pinned 1 : 1 behind the QK^T(0) MFMAs      // + scheduling boundary between S0 and S1      // the same without the S1 / S2 interleave hints
 #ifdef UTX_ABLATION
     { const int var = g_utx_opt.attn_var_abl;   // timing A/B only: 1 = no s_setprio, 2 = no interleave hints, 3 = half the fragment reads (WRONG results), 4 = row sums with v_pk_add_f32
       if (var == 1 && presc) return launch_glds<1, 1, 1>(*p, stream);
