@@ -1,9 +1,10 @@
-"""UTX_ATTN_PEEL = 1 / 2 / 3 / 4 (attention_glds.hip, VAR 12 / 13 / 14 / 15; opt-in): the LDS-DMA attention kernel with the first tile and a ragged last tile run in front of / behind
-the loop, so that the loop body carries none of their branches and its QK^T || exp and PV || exp stages are single basic blocks.  Same arithmetic in the same order
+"""UTX_ATTN_PEEL = 1 ... 5 (attention_glds.hip, VAR 12 ... 16; opt-in): the LDS-DMA attention kernel with the first tile and a ragged last tile run in front of / behind
+the loop, so that the loop body carries none of their branches and its QK^T || exp and PV || exp stages are single basic blocks; 5 (VAR 16) also moves the tile's barrier between S2
+and S3 and reads the next tile's first K fragments under S3's MFMAs.  Same arithmetic in the same order
 per element: every output must equal the default kernel's BIT FOR BIT, on every feature of the launch (ragged S, pruned queries, key multiplicity with and without a
 period, the key-split tail round, a spike that forces the exact re-centring path late in the sequence).
 
-These variants were written in a session that had no GPU minutes left: they have been compiled for gfx950 and their listings read (230 / 248 / 234 / 234 VGPRs, no scratch; the
+These variants were written in a session that had no GPU minutes left: they have been compiled for gfx950 and their listings read (230 / 248 / 234 / 234 / 230 VGPRs, no scratch; the
 default instances' listings are byte-identical to what they were before the tile body became a macro), but they have NOT run on hardware yet.  Until they have, this
 file only runs on request -- UTX_RUN_UNVALIDATED=1 python -m pytest tests/test_attention_peel_gpu.py -m gpu -- so that code nobody has executed cannot turn the suite
 red, and it is the first thing tools/attn_peel_ab.py's user should run.  The default kernel is what every other test and bench.py exercise."""
@@ -49,7 +50,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("peel", [1, 2, 3, 4])
+@pytest.mark.parametrize("peel", [1, 2, 3, 4, 5])
 @pytest.mark.parametrize("H,S,S_q,kb,period,spike", CASES)
 def test_peeled_attention_loop_equals_the_default_kernel_bit_for_bit(peel, H, S, S_q, kb, period, spike):
     from unitex_amd import _lib

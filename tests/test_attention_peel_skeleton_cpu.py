@@ -1,14 +1,17 @@
-"""The control flow of the opt-in peeled attention loop (attention_glds.hip, VAR 12 ... 15: UTX_ATTN_PEEL) against the general loop, on the CPU.
+"""The control flow of the opt-in attention loops (attention_glds.hip, VAR 12 ... 16: UTX_ATTN_PEEL = 1 ... 5) against the general loop, on the CPU.
 
-The peeled variants run the SAME tile body (a macro) -- what was written by hand is only WHICH tile goes through which copy, into which ring slot the next
-tile is staged, and where the barriers sit.  This test lifts exactly those source lines out of the kernel (from the `if ((VAR >= 12 ...` that selects the
-peeled loop to the end of the general loop), compiles them with g++ around stubs that record the events (stage(tile, slot) / body(tile, slot, special) /
-barrier), and checks for every tile count and raggedness that the peeled loop issues the general loop's event sequence -- with the general body exactly on
-the first tile and a ragged last tile, and with the general loop itself whenever key-multiplicity tiles recur."""
+These variants run the SAME tile arithmetic (macros) -- what was written by hand is WHICH tile goes through which copy, into which ring slot the next tile is
+requested and when, where the barrier sits, and (VAR 16) which ring slot the next tile's first K fragments are read from.  This test lifts exactly those source lines
+out of the kernel (from the `if` that selects the peeled loops to the end of the general loop), compiles them with g++ around stubs that record the events, and
+checks for every tile count and raggedness
+  * that every loop processes tiles 0 .. nt - 1 once each, in order, with the general body exactly on the first tile and on a ragged last tile (and the general loop
+    itself whenever key-multiplicity tiles recur), VAR 12 ... 15 event for event like the general loop;
+  * the ring discipline of a workgroup whose waves are only ordered by its barriers: a slot is read only when the tile expected there was requested into it and a
+    barrier (which carries the vmcnt(0) that retires the DMA) lies between request and read; a slot is requested into only when a barrier lies between the last read
+    of its old content and the request, and that content has been consumed;
+  * (VAR 16) that the K fragments a fast tile computes on were read from that tile's slot."""
 import os
 import subprocess
-
-import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(os.path.dirname(HERE), "unitex_amd", "csrc", "attention_glds.hip")
@@ -18,11 +21,17 @@ HARNESS = r"""
 #include <vector>
 #include <tuple>
 struct P { float key_bias_log2; int key_bias_period; };
-typedef std::vector<std::tuple<int, int, int, int>> Ev;      // (kind 0 stage / 1 body / 2 barrier, tile, slot, special)
+typedef int bf16x8;
+typedef std::vector<std::tuple<int, int, int, int>> Ev;
+// kinds: 0 request(tile, slot) | 1 old-style body(tile, slot, general?) reads K and V of its slot | 2 barrier | 3 fast A(tile, slot) computes on the prefetched fragments,
+//        reads the rest of K and V of its slot | 4 fast B: prefetch K fragments of (tile, slot) | 5 prefetch K fragments from (slot) in front of the loop
 #define AG_KVB 64
 #define AG_STAGE(t_, slot_) ev.push_back({0, (int)(t_), (int)(slot_), 0})
 #define AG_TILE_BODY(SP_) { ev.push_back({1, t, gs + sub, (SP_)}); }
 #define __syncthreads() ev.push_back({2, 0, 0, 0})
+#define AG_FAST_A ev.push_back({3, u, gs, 0});
+#define AG_FAST_B(PF_) ev.push_back({4, u + 1, gs ^ 1, (PF_)});
+#define AG_LOAD_KFA(slot_) ev.push_back({5, -1, (int)(slot_), 0});
 template <int VAR, int TPB>
 static Ev run(int Sk, P p) {
     Ev ev;
@@ -34,36 +43,60 @@ static Ev run(int Sk, P p) {
 %s
     return ev;
 }
+static int bad = 0;
+#define FAIL(...) do { ++bad; printf(__VA_ARGS__); printf("\n"); } while (0)
+static void discipline(const Ev& ev, int Sk, int var, bool general_everywhere) {
+    const int nt = (Sk + 63) / 64;
+    const bool rag = Sk %% 64;
+    int content[2] = {-1, -1};
+    bool requested[2] = {false, false}, read[2] = {false, false};
+    std::vector<int> done(nt, 0);
+    int next = 0, kfa_tile = -1;
+    for (auto [k, t, s, sp] : ev) {
+        if (k == 0) {
+            if (t < 0 || t >= nt || s < 0 || s > 1) { FAIL("var %%d Sk %%d: request of tile %%d into slot %%d", var, Sk, t, s); continue; }
+            if (read[s]) FAIL("var %%d Sk %%d: tile %%d requested into slot %%d while waves may still read it (no barrier since the last read)", var, Sk, t, s);
+            if (content[s] >= 0 && !done[content[s]]) FAIL("var %%d Sk %%d: tile %%d overwrites tile %%d, which has not been processed", var, Sk, t, content[s]);
+            content[s] = t; requested[s] = true;
+        } else if (k == 2) {
+            requested[0] = requested[1] = read[0] = read[1] = false;
+        } else if (k == 1 || k == 3) {
+            if (t != next) FAIL("var %%d Sk %%d: tile %%d processed, expected %%d", var, Sk, t, next);
+            if (content[s] != t || requested[s]) FAIL("var %%d Sk %%d: tile %%d reads slot %%d (holds %%d, requested since the last barrier: %%d)", var, Sk, t, s, content[s], (int)requested[s]);
+            if (k == 3 && kfa_tile != t) FAIL("var %%d Sk %%d: fast tile %%d computes on the K fragments of tile %%d", var, Sk, t, kfa_tile);
+            if (k == 1) {
+                const bool want = general_everywhere || t == 0 || (rag && t == nt - 1);
+                if ((sp == 1) != want) FAIL("var %%d Sk %%d: tile %%d takes the %%s body", var, Sk, t, sp ? "general" : "fast");
+            } else if (general_everywhere || t == 0 || (rag && t == nt - 1)) FAIL("var %%d Sk %%d: tile %%d takes the fast form", var, Sk, t);
+            read[s] = true; if (t >= 0 && t < nt) done[t] = 1; ++next;
+        } else {      // 4 / 5: K fragment prefetch from slot s
+            if (requested[s]) FAIL("var %%d Sk %%d: K fragments read from slot %%d behind a request without a barrier", var, Sk, s);
+            read[s] = true;
+            kfa_tile = content[s];
+        }
+    }
+    if (next != nt) FAIL("var %%d Sk %%d: %%d of %%d tiles processed", var, Sk, next, nt);
+}
 int main() {
-    int bad = 0, checked = 0;
+    int checked = 0;
     for (int per = 0; per < 2; ++per)
     for (int Sk = 1; Sk <= 64 * 9; Sk += (Sk %% 64 == 0 ? 1 : 21)) {
         P p = {per ? 3.0f : (Sk %% 2 ? 0.0f : 3.0f), per ? 4 : 0};
-        const int nt = (Sk + 63) / 64;
-        const bool rag = Sk %% 64;
+        const bool general_everywhere = per && p.key_bias_log2 != 0.f;
         Ev g = run<0, 1>(Sk, p);
-        Ev vs[4] = {run<12, 1>(Sk, p), run<13, 1>(Sk, p), run<14, 1>(Sk, p), run<15, 1>(Sk, p)};
-        for (auto& v : vs) {
+        discipline(g, Sk, 0, true);
+        Ev vs[5] = {run<12, 1>(Sk, p), run<13, 1>(Sk, p), run<14, 1>(Sk, p), run<15, 1>(Sk, p), run<16, 1>(Sk, p)};
+        for (int vi = 0; vi < 5; ++vi) {
             ++checked;
-            if (v.size() != g.size()) { ++bad; printf("Sk %%d per %%d: %%zu vs %%zu events\n", Sk, per, v.size(), g.size()); continue; }
+            discipline(vs[vi], Sk, 12 + vi, general_everywhere);
+            if (vi == 4 && !general_everywhere) continue;      // VAR 16 has its own event order; the discipline above is its check
+            const Ev& v = vs[vi];
+            if (v.size() != g.size()) { FAIL("var %%d Sk %%d per %%d: %%zu vs %%zu events", 12 + vi, Sk, per, v.size(), g.size()); continue; }
             for (size_t i = 0; i < g.size(); ++i) {
                 auto [k0, t0, s0, sp0] = g[i];
                 auto [k1, t1, s1, sp1] = v[i];
-                bool ok = k0 == k1 && t0 == t1 && s0 == s1;
-                if (k0 == 1) {      // which copy of the body: general on the first tile and on a ragged last tile -- everywhere when the key-multiplicity tiles recur
-                    const bool want_special = (per && p.key_bias_log2 != 0.f) ? true : (t0 == 0 || (rag && t0 == nt - 1));
-                    ok = ok && sp0 == 1 && (sp1 == 1) == want_special;
-                }
-                if (!ok) { ++bad; printf("Sk %%d per %%d event %%zu: (%%d %%d %%d %%d) vs (%%d %%d %%d %%d)\n", Sk, per, i, k0, t0, s0, sp0, k1, t1, s1, sp1); break; }
+                if (!(k0 == k1 && t0 == t1 && s0 == s1)) { FAIL("var %%d Sk %%d per %%d event %%zu: (%%d %%d %%d) vs (%%d %%d %%d)", 12 + vi, Sk, per, i, k0, t0, s0, k1, t1, s1); break; }
             }
-        }
-        // the staging discipline itself: a tile is staged exactly once, into the slot its body later reads, before that body, and never into the slot of the tile being read
-        std::vector<int> slot(nt, -1);
-        int reading = -1;
-        for (auto [k, t, s, sp] : vs[0]) {
-            if (k == 0) { if (slot[t] != -1 || (reading >= 0 && slot[reading] == s)) { ++bad; printf("Sk %%d: bad staging of tile %%d\n", Sk, t); } slot[t] = s; }
-            if (k == 1) { if (slot[t] != s) { ++bad; printf("Sk %%d: body of tile %%d reads slot %%d, staged into %%d\n", Sk, t, s, slot[t]); } reading = t; }
-            if (k == 2) reading = -1;
         }
     }
     printf("checked %%d bad %%d\n", checked, bad);
@@ -78,15 +111,35 @@ def _loop_source():
     end = next(i for i, l in enumerate(lines) if "this group fully read by every wave" in l)
     assert 0 < start < end and lines[end + 1].strip() == "}", "the loop block of attention_glds.hip moved: update this test's markers"
     block = [l for l in lines[start:end + 2] if not l.lstrip().startswith("#pragma")]
+    assert any("VAR == 16" in l for l in block)
     return "\n".join(block)
 
 
-def test_peeled_attention_loop_issues_the_general_loops_events(tmp_path):
-    src = tmp_path / "skeleton.cpp"
-    src.write_text(HARNESS % _loop_source())
-    exe = tmp_path / "skeleton"
+def _run(tmp_path, code, name="skeleton"):
+    src = tmp_path / (name + ".cpp")
+    src.write_text(HARNESS % code)
+    exe = tmp_path / name
     r = subprocess.run(["g++", "-std=c++17", "-O1", "-w", "-o", str(exe), str(src)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
-    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
-    assert r.returncode == 0, r.stdout[-3000:]
-    assert "bad 0" in r.stdout and "checked 0" not in r.stdout, r.stdout[-500:]
+    return subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+
+
+def test_opt_in_attention_loops_keep_the_tile_order_and_the_ring_discipline(tmp_path):
+    r = _run(tmp_path, _loop_source())
+    assert r.returncode == 0 and "bad 0" in r.stdout and "checked 0" not in r.stdout, r.stdout[-3000:]
+
+
+def test_the_skeleton_check_sees_a_broken_loop(tmp_path):
+    """mutations of the lifted source that each describe a real bug (wrong slot, request in front of the barrier, prefetch from the slot being overwritten, a ragged
+    last tile on the fast path, a dropped barrier) must all be reported"""
+    src = _loop_source()
+    mutations = [("AG_STAGE(u + 1, gs ^ 1)", "AG_STAGE(u + 1, gs)"),
+                 ("const int fast_end_ = rag_ ? nt - 1 : nt;                 // tiles [1, fast_end_) take the fast body", "const int fast_end_ = nt;"),
+                 ("            if (u + 2 < nt) AG_STAGE(u + 2, gs);\n", "            if (u + 2 < nt) AG_STAGE(u + 2, gs ^ 1);\n"),
+                 ("            AG_FAST_A\n            __syncthreads();", "            AG_FAST_A"),
+                 ("        if (2 < nt) AG_STAGE(2, 0);", "        if (2 < nt) AG_STAGE(2, 1);"),
+                 ("        if (1 < fast_end_) AG_LOAD_KFA(1)", "        if (1 < fast_end_) AG_LOAD_KFA(0)")]
+    for i, (a, b) in enumerate(mutations):
+        assert src.count(a) >= 1, a
+        r = _run(tmp_path, src.replace(a, b), "mut%d" % i)
+        assert r.returncode == 1 and "bad 0" not in r.stdout, "mutation %d (%s -> %s) went unnoticed" % (i, a, b)

@@ -534,8 +534,8 @@ def test_attention_variant_ab_tool_runs_its_whole_script_against_stubs(monkeypat
     tool.main()
     last = [l for l in capsys.readouterr().out.splitlines() if l.startswith("{")][-1]
     res = json.loads(last)
-    assert set(res) == {"128", "200"} and set(res["128"]) == {"0", "1", "2", "3", "4"}
+    assert set(res) == {"128", "200"} and set(res["128"]) == {"0", "1", "2", "3", "4", "5"}
     assert res["200"]["1"]["bit_identical_to_default"] is True and res["200"]["2"]["bit_identical_to_default"] is False and res["200"]["3"]["bit_identical_to_default"] is True
     assert abs(res["128"]["0"]["med_ms"] - 1.0) < 1e-9 and res["128"]["3"]["tflops"] > 0
     assert calls["opt"][-1] == ("UTX_ATTN_PEEL", 0), "the tool leaves the option as it found it"
-    assert calls["attn"] == 2 * (5 + 2 * 5 * 4)
+    assert calls["attn"] == 2 * (6 + 2 * 6 * 4)

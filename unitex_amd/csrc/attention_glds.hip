@@ -289,6 +289,79 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
             AG_MM(oacc[i & 3], vfb[i], pb[2 + (i >> 2)], oacc[i & 3])                                \
         if (VAR != 1 && VAR != 6) __builtin_amdgcn_s_setprio(0);                                     \
         }
+    // VAR 16 (opt-in: UTX_ATTN_PEEL=5; same arithmetic in the same order per element; NOT yet run on hardware): the fast tile cut in two around the tile's ONE barrier, which moves
+    // from the end of the tile to between S2 and S3.  S3 (PV of block 1) reads nothing from LDS -- its V fragments came in during S2 -- so behind that barrier (a) the ring slot of
+    // tile t is free and takes the DMA of tile t + 2, and (b) tile t + 1, requested a whole tile earlier, has landed and is visible: its first eight K fragments are read UNDER the
+    // S3 MFMAs into registers that live across the back edge.  The next tile then starts on its MFMAs at once, where the default kernel has all eight waves issue sixteen
+    // ds_read_b128 right behind the barrier and wait for them with the matrix pipe idle.
+#define AG_LOAD_KFA(slot_)                                                                           \
+        { _Pragma("unroll") for (int kk = 0; kk < 8; ++kk) kfa_n[kk] = *reinterpret_cast<const bf16x8*>(kring + (slot_) * AG_KTILE + kx[kk]); }
+#define AG_FAST_A                                                                                    \
+        {                                                                                            \
+        const char* kb = kring + gs * AG_KTILE;                                                      \
+        const char* vb = vring + gs * AG_VTILE;                                                      \
+        const bool ragged = false, kbias = false;   /* no such tile in this loop: AG_SLOW's branches fold */ \
+        const int lim = 0;                                                                           \
+        const float kbv = 0.f;                                                                       \
+        f32x16 sa0, sa1;                                                                             \
+        bf16x8 kfb[8], vfa[8];                                                                       \
+        float ps0 = 0.f, ps1 = 0.f;                                                                  \
+        __builtin_amdgcn_s_setprio(1);                                                               \
+        /* S0: QK(0) on the prefetched fragments; block-1 K fragments stream in behind the MFMAs */  \
+        _Pragma("unroll")                                                                            \
+        for (int kk = 0; kk < 8; ++kk) {                                                             \
+            kfb[kk] = *reinterpret_cast<const bf16x8*>(kb + 8192 + kx[kk]);                          \
+            if (kk == 0) { AG_MM(sa0, kfa_n[kk], qf[kk], negm) } else { AG_MM(sa0, kfa_n[kk], qf[kk], sa0) } \
+            __builtin_amdgcn_sched_barrier(0);                                                       \
+        }                                                                                            \
+        /* S1: QK(1) || exp(0); V fragments of block 0 stream in */                                  \
+        _Pragma("unroll")                                                                            \
+        for (int kk = 0; kk < 8; ++kk) {                                                             \
+            vfa[kk] = *reinterpret_cast<const bf16x8*>(vb + (kk & 3) * 4096 + vx[kk >> 2]);          \
+            if (kk == 0) { AG_MM(sa1, kfb[kk], qf[kk], negm) } else { AG_MM(sa1, kfb[kk], qf[kk], sa1) } \
+        }                                                                                            \
+        AG_EXPB(sa0, pb[0], pb[1], ps0)                                                              \
+        _Pragma("unroll")                                                                            \
+        for (int i_ = 0; i_ < 8; ++i_) {                                                             \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);                                       \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);                                       \
+            __builtin_amdgcn_sched_group_barrier(0x402, 4, 1);                                       \
+        }                                                                                            \
+        if (!__all(ps0 <= 8192.0f)) {                                                                \
+            AG_SLOW(sa0, sa1, true, 0, 0, false)                                                     \
+            AG_EXPB(sa0, pb[0], pb[1], ps0)                                                          \
+        }                                                                                            \
+        l_run += ps0;                                                                                \
+        /* S2: PV(0) || exp(1); V fragments of block 1 stream in (they outlive this macro: S3 sits behind the barrier) */ \
+        _Pragma("unroll")                                                                            \
+        for (int i = 0; i < 8; ++i) {                                                                \
+            vfb_n[i] = *reinterpret_cast<const bf16x8*>(vb + (i & 3) * 4096 + vx[2 + (i >> 2)]);     \
+            AG_MM(oacc[i & 3], vfa[i], pb[i >> 2], oacc[i & 3])                                      \
+        }                                                                                            \
+        AG_EXPB(sa1, pb[2], pb[3], ps1)                                                              \
+        _Pragma("unroll")                                                                            \
+        for (int i_ = 0; i_ < 8; ++i_) {                                                             \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 2);                                       \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 2);                                       \
+            __builtin_amdgcn_sched_group_barrier(0x402, 4, 2);                                       \
+        }                                                                                            \
+        if (!__all(ps1 <= 8192.0f)) {                                                                \
+            AG_SLOW(sa1, sa0, false, 8192, 32, false)                                                \
+            AG_EXPB(sa1, pb[2], pb[3], ps1)                                                          \
+        }                                                                                            \
+        l_run += ps1;                                                                                \
+        }
+    /* S3: PV(1); PF_ (literal): the next tile's first K fragments come in from ring slot gs ^ 1 behind the MFMAs */
+#define AG_FAST_B(PF_)                                                                               \
+        {                                                                                            \
+        _Pragma("unroll")                                                                            \
+        for (int i = 0; i < 8; ++i) {                                                                \
+            if (PF_) kfa_n[i] = *reinterpret_cast<const bf16x8*>(kring + (gs ^ 1) * AG_KTILE + kx[i]); \
+            AG_MM(oacc[i & 3], vfb_n[i], pb[2 + (i >> 2)], oacc[i & 3])                              \
+            __builtin_amdgcn_sched_barrier(0);                                                       \
+        }                                                                                            \
+        __builtin_amdgcn_s_setprio(0);                                                               \
+        }
     // VAR 12 / 13 / 14 / 15 (opt-in: UTX_ATTN_PEEL=1 / 2 / 3 / 4; 13 = without the S1 / S2 interleave hints, 14 = 12 + a hard scheduling boundary between S0 and S1, so that S1's
     // hint pipeline sees the QK^T(1) MFMAs only and hipcc does not hoist them into S0, 15 = 14 + a boundary behind every {K fragment read, QK^T(0) MFMA} pair of S0, so that the
     // second block's fragment reads stream in behind the MFMAs instead of all sixteen reads standing in front of the first one; same arithmetic in the same order per element = bit-identical by construction; NOT yet run on hardware): the first tile and a
@@ -314,6 +387,30 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
         }
         if (rag_ && nt > 1) {
             const int gs = (nt - 1) & 1, sub = 0, t = nt - 1;
+            AG_TILE_BODY(1)
+            __syncthreads();
+        }
+    } else if (VAR == 16 && TPB == 1 && !(p.key_bias_period > 0 && p.key_bias_log2 != 0.f)) {
+        const bool rag_ = (Sk & (AG_KVB - 1)) != 0;
+        const int fast_end_ = rag_ ? nt - 1 : nt;                 // tiles [1, fast_end_) take the fast form
+        bf16x8 kfa_n[8], vfb_n[8];
+        {
+            const int gs = 0, sub = 0, t = 0;                     // tile 0: the general body, barrier at its end
+            if (1 < nt) AG_STAGE(1, 1);
+            AG_TILE_BODY(1)
+            __syncthreads();
+        }
+        if (2 < nt) AG_STAGE(2, 0);                               // slot 0 is free behind that barrier; from here on tile u + 2 is requested behind the barrier of tile u
+        if (1 < fast_end_) AG_LOAD_KFA(1)
+        for (int u = 1; u < fast_end_; ++u) {
+            const int gs = u & 1;
+            AG_FAST_A
+            __syncthreads();                                      // tile u + 1 has landed (the vmcnt(0) this fence carries) and is visible; every wave is done with slot gs
+            if (u + 2 < nt) AG_STAGE(u + 2, gs);
+            AG_FAST_B(1)      // always prefetches: behind the last fast tile the fragments are not used (slot gs ^ 1 then holds the ragged last tile or old data; nothing writes it)
+        }
+        if (rag_ && nt > 1) {
+            const int gs = (nt - 1) & 1, sub = 0, t = nt - 1;     // its tile was requested two tiles ago and retired by the last barrier above (or by tile 0's)
             AG_TILE_BODY(1)
             __syncthreads();
         }
@@ -481,7 +578,7 @@ static int launch_glds(AttnParams p, hipStream_t stream) {
     p.nqb = ((p.Sq > 0 ? p.Sq : p.S) + 255) / 256;
     p.w_base = 0; p.nsplit = 1; p.tiles_per_split = 0; p.part_o = nullptr; p.part_lse = nullptr;
     int pl[4] = {p.nqb * p.H, 0, 1, 0};
-    if (TPB == 1 && (VAR == 0 || VAR == 6 || VAR == 7 || VAR == 8 || VAR == 9 || VAR == 10 || (VAR >= 12 && VAR <= 15)) && !p.flags) utx_attn_split_plan_impl(p.H, p.Sq, p.S, utx_ncu(), pl);
+    if (TPB == 1 && (VAR == 0 || VAR == 6 || VAR == 7 || VAR == 8 || VAR == 9 || VAR == 10 || (VAR >= 12 && VAR <= 16)) && !p.flags) utx_attn_split_plan_impl(p.H, p.Sq, p.S, utx_ncu(), pl);
     const int nwg = pl[0], nfull = pl[1], ns = pl[2], tps = pl[3], r = nwg - nfull;
     // the scratch of the split is CALLER-OWNED (utx_attn_fwd_bf16_ws; the legacy entry points pass the context's own buffer, grown outside of any
     // capture): nothing is allocated here, a launch whose scratch is missing or too small runs unsplit -- same result up to one bf16 rounding of the
@@ -513,7 +610,8 @@ extern "C" int utx_launch_attn_fwd_glds(const AttnParams* p, int presc, hipStrea
     if (g_utx_opt.attn_peel == 1 && presc) return launch_glds<1, 1, 12>(*p, stream);
     if (g_utx_opt.attn_peel == 2 && presc) return launch_glds<1, 1, 13>(*p, stream);
     if (g_utx_opt.attn_peel == 3 && presc) return launch_glds<1, 1, 14>(*p, stream);
-    if (g_utx_opt.attn_peel == 4 && presc) return launch_glds<1, 1, 15>(*p, stream);      // + K fragment reads pinned 1 : 1 behind the QK^T(0) MFMAs      // + scheduling boundary between S0 and S1      // the same without the S1 / S2 interleave hints
+    if (g_utx_opt.attn_peel == 4 && presc) return launch_glds<1, 1, 15>(*p, stream);
+    if (g_utx_opt.attn_peel == 5 && presc) return launch_glds<1, 1, 16>(*p, stream);      // the tile's barrier between S2 and S3, next tile's first K fragments prefetched under S3      // + K fragment reads pinned 1 : 1 behind the QK^T(0) MFMAs      // + scheduling boundary between S0 and S1      // the same without the S1 / S2 interleave hints
 #ifdef UTX_ABLATION
     { const int var = g_utx_opt.attn_var_abl;   // timing A/B only: 1 = no s_setprio, 2 = no interleave hints, 3 = half the fragment reads (WRONG results), 4 = row sums with v_pk_add_f32
       if (var == 1 && presc) return launch_glds<1, 1, 1>(*p, stream);
