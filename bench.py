@@ -220,7 +220,7 @@ def attention_variant_experiment(timeout_s=150):
         if r.returncode != 0 or not last:
             return {"attn_peel": {"error": "rc %d: %s" % (r.returncode, (r.stderr or r.stdout)[-400:])}, "note": note}
         return {"attn_peel": json.loads(last[-1]), "note": note,
-                "layout": "{tokens: {UTX_ATTN_PEEL value: {bit_identical_to_default, med_ms, best_ms, tflops}}}, 24 heads, key multiplicity 8 on tile 0; '0' = the default kernel in the same process"}
+                "layout": "{tokens: {UTX_ATTN_PEEL value: {bit_identical_to_default, repeats, mismatches_in_repeats, med_ms, best_ms, tflops}}}, 24 heads, key multiplicity 8 on tile 0; '0' = the default kernel in the same process"}
     except Exception as e:  # noqa: BLE001 -- an experiment must never cost the line
         return {"attn_peel": {"error": repr(e)[:400]}, "note": note}
 

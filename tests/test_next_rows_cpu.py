@@ -511,6 +511,7 @@ def test_attention_variant_ab_tool_runs_its_whole_script_against_stubs(monkeypat
     monkeypatch.setenv("UTX_AB_SIZES", "128,200")
     monkeypatch.setenv("UTX_AB_HEADS", "2")
     monkeypatch.setenv("UTX_AB_ROUNDS", "2")
+    monkeypatch.setenv("UTX_AB_REPEATS", "3")
     real_gen, real_randn, real_empty = torch.Generator, torch.randn, torch.empty
     monkeypatch.setattr(torch, "Generator", lambda device=None: real_gen())
     monkeypatch.setattr(torch, "randn", lambda *a, device=None, **k: real_randn(*a, **k))
@@ -538,4 +539,5 @@ def test_attention_variant_ab_tool_runs_its_whole_script_against_stubs(monkeypat
     assert res["200"]["1"]["bit_identical_to_default"] is True and res["200"]["2"]["bit_identical_to_default"] is False and res["200"]["3"]["bit_identical_to_default"] is True
     assert abs(res["128"]["0"]["med_ms"] - 1.0) < 1e-9 and res["128"]["3"]["tflops"] > 0
     assert calls["opt"][-1] == ("UTX_ATTN_PEEL", 0), "the tool leaves the option as it found it"
-    assert calls["attn"] == 2 * (6 + 2 * 6 * 4)
+    assert calls["attn"] == 2 * (6 + 5 * 3 + 2 * 6 * 4)
+    assert res["200"]["2"]["mismatches_in_repeats"] == 3 and res["200"]["5"]["mismatches_in_repeats"] == 0 and res["200"]["5"]["repeats"] == 3

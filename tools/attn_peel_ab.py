@@ -20,6 +20,7 @@ SIZES = tuple(int(x) for x in os.environ.get("UTX_AB_SIZES", "13376,50240").spli
 
 def main():
     rounds = int(os.environ.get("UTX_AB_ROUNDS", "5"))
+    repeats = int(os.environ.get("UTX_AB_REPEATS", "10"))
     as_json = "--json" in sys.argv      # bench.py: one JSON object on the last line instead of the table
     result = {}
     say = (lambda *a, **k: None) if as_json else print
@@ -44,8 +45,15 @@ def main():
                 ref = out.clone()
             else:
                 same = bool(torch.equal(out.view(torch.int16), ref.view(torch.int16)))
-                result.setdefault(str(S), {}).setdefault(str(peel), {})["bit_identical_to_default"] = same
-                say("S = %6d  UTX_ATTN_PEEL=%d  bit-identical to the default: %s" % (S, peel, same), flush=True)
+                # a first race screen (the variants that move a barrier): the same launch again and again, every result against the default kernel's bits
+                miss = 0
+                for _rep in range(repeats):
+                    out.zero_()
+                    run(peel)
+                    torch.cuda.synchronize()
+                    miss += int(not torch.equal(out.view(torch.int16), ref.view(torch.int16)))
+                result.setdefault(str(S), {}).setdefault(str(peel), {}).update(bit_identical_to_default=same, repeats=repeats, mismatches_in_repeats=miss)
+                say("S = %6d  UTX_ATTN_PEEL=%d  bit-identical to the default: %s   (%d of %d repeated launches differ)" % (S, peel, same, miss, repeats), flush=True)
         times = {0: [], 1: [], 2: [], 3: [], 4: [], 5: []}
         for _ in range(rounds):
             for peel in (0, 1, 2, 3, 4, 5):
