@@ -205,7 +205,7 @@ def count_distinct_devices(idents):
 
 
 def attention_variant_experiment(timeout_s=150):
-    """Beside the line, never part of `value`: the opt-in peeled attention loop (UTX_ATTN_PEEL = 1 ... 5, csrc/attention_glds.hip VAR 12 ... 16) against the default
+    """Beside the line, never part of `value`: the opt-in peeled attention loop (UTX_ATTN_PEEL = 1 ... 5, csrc/attention_glds.hip VAR 12 ... 16; UTX_ATTN8_PEEL = 1, csrc/attention_fp8.hip) against the default
     kernel -- bit-identity and an interleaved A/B at the two operating points (tools/attn_peel_ab.py --json).  Those variants were written without GPU access; they
     run in a CHILD process with a timeout, after every measurement of this process is finished, so that whatever they do cannot cost the bench line.
     UTX_BENCH_EXPERIMENTS=0 skips it."""
@@ -220,7 +220,7 @@ def attention_variant_experiment(timeout_s=150):
         if r.returncode != 0 or not last:
             return {"attn_peel": {"error": "rc %d: %s" % (r.returncode, (r.stderr or r.stdout)[-400:])}, "note": note}
         return {"attn_peel": json.loads(last[-1]), "note": note,
-                "layout": "{tokens: {UTX_ATTN_PEEL value: {bit_identical_to_default, repeats, mismatches_in_repeats, med_ms, best_ms, tflops}}}, 24 heads, key multiplicity 8 on tile 0; '0' = the default kernel in the same process"}
+                "layout": "{tokens: {UTX_ATTN_PEEL value: {bit_identical_to_default, repeats, mismatches_in_repeats, med_ms, best_ms, tflops}}}, 24 heads, key multiplicity 8 on tile 0; '0' = the default kernel in the same process; keys 'fp8_<tokens>': the MX fp8 attention kernel (opt-in path) and its peeled form UTX_ATTN8_PEEL = 1, bits against the default fp8 kernel"}
     except Exception as e:  # noqa: BLE001 -- an experiment must never cost the line
         return {"attn_peel": {"error": repr(e)[:400]}, "note": note}
 

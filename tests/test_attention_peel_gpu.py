@@ -1,4 +1,4 @@
-"""UTX_ATTN_PEEL = 1 ... 5 (attention_glds.hip, VAR 12 ... 16; opt-in): the LDS-DMA attention kernel with the first tile and a ragged last tile run in front of / behind
+"""UTX_ATTN_PEEL = 1 ... 5 (attention_glds.hip, VAR 12 ... 16; opt-in) and UTX_ATTN8_PEEL = 1 (attention_fp8.hip, its last test below): the LDS-DMA attention kernel with the first tile and a ragged last tile run in front of / behind
 the loop, so that the loop body carries none of their branches and its QK^T || exp and PV || exp stages are single basic blocks; 5 (VAR 16) also moves the tile's barrier between S2
 and S3 and reads the next tile's first K fragments under S3's MFMAs.  Same arithmetic in the same order
 per element: every output must equal the default kernel's BIT FOR BIT, on every feature of the launch (ragged S, pruned queries, key multiplicity with and without a
@@ -68,3 +68,40 @@ def test_peeled_attention_loop_equals_the_default_kernel_bit_for_bit(peel, H, S,
     assert torch.isfinite(out.float()).all()
     assert torch.equal(out.view(torch.int16), ref.view(torch.int16)), \
         "UTX_ATTN_PEEL=%d differs from the default kernel: max |d| = %g" % (peel, (out.float() - ref.float()).abs().max().item())
+
+
+FP8_CASES = [
+    # H, S, S_q, key_bias_log2, key_bias_period, spike
+    (2, 64, None, 0.0, 0, False),
+    (2, 100, None, 0.0, 0, False),
+    (3, 1000, None, 0.0, 0, True),
+    (2, 2304, None, 0.0, 0, True),
+    (4, 960, None, 3.0, 0, False),
+    (4, 1024, None, 2.0, 8, False),          # periodic key multiplicity: the variant must fall back to the general loop
+    (4, 1500, 700, 3.0, 0, True),
+    (24, 3000, None, 0.0, 0, True),
+]
+
+
+@pytest.mark.parametrize("H,S,S_q,kb,period,spike", FP8_CASES)
+def test_peeled_fp8_attention_loop_equals_the_default_fp8_kernel_bit_for_bit(H, S, S_q, kb, period, spike):
+    """UTX_ATTN8_PEEL=1 (attention_fp8.hip, attn_fwd_fp8_kernel<1>): tile 0 / a ragged last tile outside the loop, the loop's exponentials in quarters under the PV MFMAs
+    (running sums carried across the quarters: the same summation order).  Same MX operands in, the default fp8 kernel's bits out."""
+    from unitex_amd import _lib
+    from unitex_amd.flux import ops
+    Qh, Kh, Vt = _inputs(H, S, seed=S + 11 * H, spike=spike)
+    q8, qs = ops.quant_qk_mx8(Qh)
+    k8, ks = ops.quant_qk_mx8(Kh)
+    v8, vs = ops.quant_vt_mx8(Vt)
+    assert _lib.get_options()["UTX_ATTN8_PEEL"] == 0
+    ref = ops.attention_fp8(q8, qs, k8, ks, v8, vs, S=S, S_q=S_q, key_bias_log2=kb, key_bias_period=period)
+    torch.cuda.synchronize()
+    try:
+        _lib.set_option("UTX_ATTN8_PEEL", 1)
+        out = ops.attention_fp8(q8, qs, k8, ks, v8, vs, S=S, S_q=S_q, key_bias_log2=kb, key_bias_period=period)
+        torch.cuda.synchronize()
+    finally:
+        _lib.set_option("UTX_ATTN8_PEEL", 0)
+    assert torch.isfinite(out.float()).all()
+    assert torch.equal(out.view(torch.int16), ref.view(torch.int16)), \
+        "UTX_ATTN8_PEEL=1 differs from the default fp8 kernel: max |d| = %g" % (out.float() - ref.float()).abs().max().item()

@@ -143,3 +143,121 @@ def test_the_skeleton_check_sees_a_broken_loop(tmp_path):
         assert src.count(a) >= 1, a
         r = _run(tmp_path, src.replace(a, b), "mut%d" % i)
         assert r.returncode == 1 and "bad 0" not in r.stdout, "mutation %d (%s -> %s) went unnoticed" % (i, a, b)
+
+
+FP8_SRC = os.path.join(os.path.dirname(HERE), "unitex_amd", "csrc", "attention_fp8.hip")
+FP8_HARNESS = r"""
+#include <cstdio>
+#include <vector>
+#include <utility>
+struct P { float key_bias_log2; int key_bias_period; };
+#define A8_KVB 64
+#define A8_TILE_BODY(SP_) { ev.push_back({t, 1}); }
+#define A8_FAST_BODY { ev.push_back({t, 0}); }
+template <int VAR>
+static std::vector<std::pair<int, int>> run(int S, P p) {
+    std::vector<std::pair<int, int>> ev;
+    const int nt = (S + A8_KVB - 1) / A8_KVB;
+%s
+    return ev;
+}
+int main() {
+    int bad = 0, checked = 0;
+    for (int per = 0; per < 2; ++per)
+    for (int S = 1; S <= 64 * 7; S += (S %% 64 == 0 ? 1 : 21)) {
+        P p = {per ? 3.0f : (S %% 2 ? 0.0f : 3.0f), per ? 4 : 0};
+        const int nt = (S + 63) / 64;
+        const bool rag = S %% 64, general_everywhere = per && p.key_bias_log2 != 0.f;
+        auto g = run<0>(S, p), v = run<1>(S, p);
+        ++checked;
+        if ((int)g.size() != nt || (int)v.size() != nt) { ++bad; printf("S %%d: %%zu / %%zu tiles of %%d\n", S, g.size(), v.size(), nt); continue; }
+        for (int t = 0; t < nt; ++t) {
+            const bool want_general = general_everywhere || t == 0 || (rag && t == nt - 1);
+            if (g[t].first != t || g[t].second != 1 || v[t].first != t || (v[t].second == 1) != want_general) { ++bad; printf("S %%d per %%d tile %%d: general loop (%%d, %%d), variant (%%d, %%d)\n", S, per, t, g[t].first, g[t].second, v[t].first, v[t].second); break; }
+        }
+    }
+    printf("checked %%d bad %%d\n", checked, bad);
+    return bad ? 1 : 0;
+}
+"""
+
+
+def test_peeled_fp8_attention_loop_takes_every_tile_once_through_the_right_body(tmp_path):
+    """attention_fp8.hip, VAR 1 (UTX_ATTN8_PEEL): the loop selection lifted from the source -- tiles 0 .. nt - 1 in order, the general body exactly on tile 0 and on a ragged
+    last tile, the general loop whenever key-multiplicity tiles recur.  (Requests, ring slots and the barrier sit INSIDE both bodies, copied line for line.)"""
+    lines = open(FP8_SRC).read().split("\n")
+    start = next(i for i, l in enumerate(lines) if l.lstrip().startswith("if (VAR == 1 && !(p.key_bias_period > 0"))
+    end = next(i for i, l in enumerate(lines) if l.strip() == "for (int t = 0; t < nt; ++t) A8_TILE_BODY(1)")
+    assert 0 < start < end < start + 12
+    src = tmp_path / "fp8_skeleton.cpp"
+    src.write_text(FP8_HARNESS % "\n".join(lines[start:end + 1]))
+    exe = tmp_path / "fp8_skeleton"
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-w", "-o", str(exe), str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "bad 0" in r.stdout and "checked 0" not in r.stdout, r.stdout[-2000:]
+    # the fast body's request / fence lines are the general body's, character for character
+    text = open(FP8_SRC).read()
+    gen = text[text.index("#define A8_TILE_BODY(SP_)"):text.index("#define A8_EXPQ")]
+    fast = text[text.index("#define A8_FAST_BODY"):text.index("// VAR 1 (opt-in: UTX_ATTN8_PEEL=1")]
+    norm = lambda s: " ".join(s.replace("\\", " ").split())
+    for must in ("A8_STAGE(t + 1, slot ^ 1);", "ksc0n = ksb[kr]; ksc1n = ksb[kr + 32];", "vscn = vsb[(long)(2 * (t + 1) + lh) * 32 + lq];", "const int slot = t & 1;",
+                 'asm volatile("" : "+v"(ksc0n), "+v"(ksc1n), "+v"(vscn));', "ksc0 = (int)(ksc0n >> (8 * lh)); ksc1 = (int)(ksc1n >> (8 * lh)); vsc = (int)vscn;", "__syncthreads();",
+                 "vsc_pv = vsc;", "l_run += ps0 + ps1;", "pb = a8_i32x8{pb0, pb1, pb2, pb3, pb4, pb5, pb6, pb7};"):
+        assert norm(must) in norm(gen) and norm(must) in norm(fast), must
+
+
+EXP_HARNESS = r"""
+#include <cstdio>
+#include <cstdint>
+#include <cstring>
+#include <cmath>
+#include <random>
+static float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
+// stand-in for the packing instruction: any injective-looking function of (a, b, old, which half) pins WHICH values go WHERE in which order
+static int __builtin_amdgcn_cvt_pk_fp8_f32(float a, float b, int old, bool hi) {
+    uint32_t ua, ub; memcpy(&ua, &a, 4); memcpy(&ub, &b, 4);
+    const uint32_t h = ((ua * 2654435761u) ^ (ub * 40503u + 0x9e3779b9u)) & 0xffffu;
+    return hi ? (int)(((uint32_t)old & 0xffffu) | (h << 16)) : (int)(((uint32_t)old & 0xffff0000u) | h);
+}
+#define _Pragma(x)
+%s
+int main() {
+    std::mt19937 g(1);
+    std::uniform_real_distribution<float> d(-12.f, 4.f);
+    int bad = 0;
+    for (int it = 0; it < 2000; ++it) {
+        float sa[16];
+        for (int r = 0; r < 16; ++r) sa[r] = d(g);
+        int a0, a1, a2, a3, b0, b1, b2, b3; float psa, psb;
+        A8_EXPB(sa, a0, a1, a2, a3, psa)
+        { float sc0_ = 0.f, sc1_ = 0.f; A8_EXPQ(sa, 0, b0, b1) A8_EXPQ(sa, 8, b2, b3) psb = sc0_ + sc1_; }
+        uint32_t x, y; memcpy(&x, &psa, 4); memcpy(&y, &psb, 4);
+        if (x != y || a0 != b0 || a1 != b1 || a2 != b2 || a3 != b3) ++bad;
+    }
+    printf("bad %%d\n", bad);
+    return bad ? 1 : 0;
+}
+"""
+
+
+def test_exponential_quarters_of_the_fp8_fast_body_equal_the_whole_block(tmp_path):
+    """A8_EXPQ twice (running sums carried across) against A8_EXPB, both macro texts lifted from attention_fp8.hip and compiled on the host: the same row-sum bits
+    (same summation order) and the same values in the same packing slots."""
+    text = open(FP8_SRC).read()
+
+    def macro(name):
+        i = text.index("#define " + name + "(")
+        out = []
+        for l in text[i:].split("\n"):
+            out.append(l)
+            if not l.rstrip().endswith("\\"):
+                break
+        return "\n".join(out).replace('_Pragma("unroll")', "")
+    src = tmp_path / "expq.cpp"
+    src.write_text(EXP_HARNESS % (macro("A8_EXPB") + "\n" + macro("A8_EXPQ")))
+    exe = tmp_path / "expq"
+    r = subprocess.run(["g++", "-std=c++17", "-O0", "-ffp-contract=off", "-w", "-o", str(exe), str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "bad 0" in r.stdout, r.stdout[-500:]

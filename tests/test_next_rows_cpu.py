@@ -499,7 +499,13 @@ def test_attention_variant_ab_tool_runs_its_whole_script_against_stubs(monkeypat
         assert scale == 0.0 and key_bias_log2 == 3.0 and out.shape == (S, q.shape[0] * 128)
         out.fill_(1.0 if state["peel"] != 2 else 2.0)       # variant 2 "differs" from the default
         return out
-    fake_ops = types.SimpleNamespace(attention=attention)
+    def attention_fp8(q8, qs, k8, ks, v8, vs, S=None, out=None, key_bias_log2=0.0, **kw):
+        calls["attn8"] = calls.get("attn8", 0) + 1
+        assert key_bias_log2 == 3.0 and out.shape == (S, q8.shape[0] * 128)
+        out.fill_(3.0)
+        return out
+    fake_ops = types.SimpleNamespace(attention=attention, attention_fp8=attention_fp8,
+                                     quant_qk_mx8=lambda x: (x, x[..., :4]), quant_vt_mx8=lambda x: (x, x[:, :, :4]))
     pkg = types.ModuleType("unitex_amd")
     pkg._lib = fake_lib
     flux = types.ModuleType("unitex_amd.flux")
@@ -535,9 +541,10 @@ def test_attention_variant_ab_tool_runs_its_whole_script_against_stubs(monkeypat
     tool.main()
     last = [l for l in capsys.readouterr().out.splitlines() if l.startswith("{")][-1]
     res = json.loads(last)
-    assert set(res) == {"128", "200"} and set(res["128"]) == {"0", "1", "2", "3", "4", "5"}
+    assert set(res) == {"128", "200", "fp8_128", "fp8_200"} and res["fp8_200"]["1"]["bit_identical_to_default"] is True and res["fp8_128"]["0"]["tflops"] > 0 and set(res["128"]) == {"0", "1", "2", "3", "4", "5"}
     assert res["200"]["1"]["bit_identical_to_default"] is True and res["200"]["2"]["bit_identical_to_default"] is False and res["200"]["3"]["bit_identical_to_default"] is True
     assert abs(res["128"]["0"]["med_ms"] - 1.0) < 1e-9 and res["128"]["3"]["tflops"] > 0
-    assert calls["opt"][-1] == ("UTX_ATTN_PEEL", 0), "the tool leaves the option as it found it"
+    assert calls["opt"][-1] == ("UTX_ATTN8_PEEL", 0) and ("UTX_ATTN_PEEL", 0) in calls["opt"], "the tool leaves the options as it found them"
+    assert calls["attn8"] == 2 * (1 + 4 + 2 * 2 * 4)
     assert calls["attn"] == 2 * (6 + 5 * 3 + 2 * 6 * 4)
     assert res["200"]["2"]["mismatches_in_repeats"] == 3 and res["200"]["5"]["mismatches_in_repeats"] == 0 and res["200"]["5"]["repeats"] == 3

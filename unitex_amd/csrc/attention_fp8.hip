@@ -43,6 +43,7 @@ __device__ __forceinline__ a8_i32x8 a8_frag(const char* plo, const char* phi) {
     return a8_i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
+template <int VAR>
 __global__ __launch_bounds__(512, 2) void attn_fwd_fp8_kernel(Attn8Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const kring = smem;
@@ -141,91 +142,191 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_fp8_kernel(Attn8Params p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) vf[i] = a8_i32x8{0, 0, 0, 0, 0, 0, 0, 0};
     pb = a8_i32x8{0, 0, 0, 0, 0, 0, 0, 0};
-    for (int t = 0; t < nt; ++t) {
-        const int slot = t & 1;
-        // the next tile's scale dwords are requested IN FRONT of its DMAs and stay untouched until the end of this iteration: the in-order counter then lets
-        // the one wait for them leave the two younger DMAs in flight (vmcnt(2)), behind this tile's compute.  (Round 4's first form shifted them at once:
-        // hipcc put `s_waitcnt vmcnt(0)` right behind the DMA requests -- every wave sat out the next tile's full fetch latency at the top of every tile.)
-        uint32_t ksc0n = 0, ksc1n = 0, vscn = 0;
-        if (t + 1 < nt) {
-            const long kr = (long)(t + 1) * A8_KVB + krow;
-            ksc0n = ksb[kr]; ksc1n = ksb[kr + 32];
-            vscn = vsb[(long)(2 * (t + 1) + lh) * 32 + lq];
-            A8_STAGE(t + 1, slot ^ 1);
+    // The tile body as a macro (SP_ = 1: the general tile -- first tile, ragged last tile, key-multiplicity tiles; the literal only marks which tests a specialised copy could
+    // drop).  VAR 0 (the default) expands this body only -- the instruction stream it always had; VAR 1 uses it for tile 0 and a ragged last tile.
+#define A8_TILE_BODY(SP_)                                                                                              \
+        {                                                                                                              \
+        const int slot = t & 1;                                                                                        \
+        /* the next tile's scale dwords are requested IN FRONT of its DMAs and stay untouched until the end of this iteration: the in-order counter then lets */ \
+        /* the one wait for them leave the two younger DMAs in flight (vmcnt(2)), behind this tile's compute.  (Round 4's first form shifted them at once: */ \
+        /* hipcc put `s_waitcnt vmcnt(0)` right behind the DMA requests -- every wave sat out the next tile's full fetch latency at the top of every tile.) */ \
+        uint32_t ksc0n = 0, ksc1n = 0, vscn = 0;                                                                       \
+        if (t + 1 < nt) {                                                                                              \
+            const long kr = (long)(t + 1) * A8_KVB + krow;                                                             \
+            ksc0n = ksb[kr]; ksc1n = ksb[kr + 32];                                                                     \
+            vscn = vsb[(long)(2 * (t + 1) + lh) * 32 + lq];                                                            \
+            A8_STAGE(t + 1, slot ^ 1);                                                                                 \
+        }                                                                                                              \
+        const char* kb = kring + slot * A8_KTILE;                                                                      \
+        const char* vb = vring + slot * A8_VTILE;                                                                      \
+        const bool ragged = (SP_) && (t == nt - 1) && (S & (A8_KVB - 1));                                              \
+        const int lim = S - t * A8_KVB - 16 * lh;   /* register r of block b is key 32 b + 16 lh + r of the tile */    \
+        const bool kbias = (SP_) && (p.key_bias_log2 != 0.f) && (p.key_bias_period > 0 ? (t % p.key_bias_period == 0) : (t == 0)); \
+        /* ---- QK^T: both 32-key blocks, scores come out as s - m_run (the accumulators start at -m) */               \
+        f32x16 sa0, sa1;                                                                                               \
+        {                                                                                                              \
+            const a8_i32x8 k00 = A8_FRAG(kb + kx[0][0], kb + kx[0][1]);                                                \
+            const a8_i32x8 k01 = A8_FRAG(kb + kx[1][0], kb + kx[1][1]);                                                \
+            const a8_i32x8 k10 = A8_FRAG(kb + 4096 + kx[0][0], kb + 4096 + kx[0][1]);                                  \
+            const a8_i32x8 k11 = A8_FRAG(kb + 4096 + kx[1][0], kb + 4096 + kx[1][1]);                                  \
+            __builtin_amdgcn_s_setprio(1);                                                                             \
+            sa0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(k00, qf[0], negm, 0, 0, 0, ksc0, 0, qsc);            \
+            sa0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(k01, qf[1], sa0, 0, 0, 2, ksc0, 2, qsc);             \
+            sa1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(k10, qf[0], negm, 0, 0, 0, ksc1, 0, qsc);            \
+            sa1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(k11, qf[1], sa1, 0, 0, 2, ksc1, 2, qsc);             \
+        }                                                                                                              \
+        /* ---- PV of the PREVIOUS tile, issued right behind this tile's score MFMAs: the matrix pipe runs QK(t) + PV(t-1) back to back (512 cycles) while the */ \
+        /* exponentials of this tile (the VALU bulk of a tile, ~800 cycles) start as soon as QK(t) has landed -- PV hides under them.  P(t-1) / V^T(t-1) stay in */ \
+        /* registers across the barrier; a re-centring in this tile rescales oacc AFTER these MFMAs (a data dependency the compiler sees). */ \
+        if (!(SP_) || t > 0) {                                                                                         \
+            oacc[0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf[0], pb, oacc[0], 0, 0, 0, vsc_pv, 0, one_scale); \
+            oacc[1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf[1], pb, oacc[1], 0, 0, 1, vsc_pv, 0, one_scale); \
+            oacc[2] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf[2], pb, oacc[2], 0, 0, 2, vsc_pv, 0, one_scale); \
+            oacc[3] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf[3], pb, oacc[3], 0, 0, 3, vsc_pv, 0, one_scale); \
+        }                                                                                                              \
+        /* this tile's V^T fragments (consumed at the top of the next iteration) */                                    \
+        _Pragma("unroll")                                                                                              \
+        for (int db = 0; db < 4; ++db) vf[db] = A8_FRAG(vb + db * 2048 + vx[0], vb + db * 2048 + vx[1]);               \
+        vsc_pv = vsc;                                                                                                  \
+        if (kbias) {                                                                                                   \
+        _Pragma("unroll")                                                                                              \
+            for (int r = 0; r < 16; ++r) { sa0[r] += p.key_bias_log2; sa1[r] += p.key_bias_log2; }                     \
+        }                                                                                                              \
+        if (ragged) {                                                                                                  \
+        _Pragma("unroll")                                                                                              \
+            for (int r = 0; r < 16; ++r) {                                                                             \
+                if (r >= lim) sa0[r] = -INFINITY;                                                                      \
+                if (32 + r >= lim) sa1[r] = -INFINITY;                                                                 \
+            }                                                                                                          \
+        }                                                                                                              \
+        int pb0, pb1, pb2, pb3, pb4, pb5, pb6, pb7;                                                                    \
+        float ps0, ps1;                                                                                                \
+        A8_EXPB(sa0, pb0, pb1, pb2, pb3, ps0)                                                                          \
+        A8_EXPB(sa1, pb4, pb5, pb6, pb7, ps1)                                                                          \
+        if (((SP_) && t == 0) || ragged || !__all(ps0 <= 256.0f && ps1 <= 256.0f)) {                                   \
+            /* exact re-centring on the tile's maximum (first tile: set it): m_run += d, everything accumulated so far shrinks by 2^-d */ \
+            float mx = fmaxf(sa0[0], sa1[0]);                                                                          \
+        _Pragma("unroll")                                                                                              \
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(sa0[r], sa1[r]));                                        \
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));                                                                    \
+            const float d = ((SP_) && t == 0) ? mx : fmaxf(mx, 0.f);                                                   \
+            const float alpha = ((SP_) && t == 0) ? 1.0f : __builtin_amdgcn_exp2f(-d);                                 \
+            m_run += d;                                                                                                \
+            l_run *= alpha;                                                                                            \
+        _Pragma("unroll")                                                                                              \
+            for (int r = 0; r < 16; ++r) { negm[r] = -m_run; sa0[r] -= d; sa1[r] -= d; }                               \
+        _Pragma("unroll")                                                                                              \
+            for (int i = 0; i < 4; ++i)                                                                                \
+        _Pragma("unroll")                                                                                              \
+                for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;                                                      \
+            A8_EXPB(sa0, pb0, pb1, pb2, pb3, ps0)                                                                      \
+            A8_EXPB(sa1, pb4, pb5, pb6, pb7, ps1)                                                                      \
+        }                                                                                                              \
+        l_run += ps0 + ps1;                                                                                            \
+        pb = a8_i32x8{pb0, pb1, pb2, pb3, pb4, pb5, pb6, pb7};   /* P of this tile: the B operand of the PV MFMAs issued in the next iteration (or behind the loop) */ \
+        __builtin_amdgcn_s_setprio(0);                                                                                 \
+        asm volatile("" : "+v"(ksc0n), "+v"(ksc1n), "+v"(vscn));   /* first use of the three dwords: the wait for them lands HERE */ \
+        ksc0 = (int)(ksc0n >> (8 * lh)); ksc1 = (int)(ksc1n >> (8 * lh)); vsc = (int)vscn;                             \
+        __syncthreads();   /* this slot fully read by every wave; the next tile's DMA retired by the vmcnt(0) of this fence */ \
         }
-        const char* kb = kring + slot * A8_KTILE;
-        const char* vb = vring + slot * A8_VTILE;
-        const bool ragged = (t == nt - 1) && (S & (A8_KVB - 1));
-        const int lim = S - t * A8_KVB - 16 * lh;      // register r of block b is key 32 b + 16 lh + r of the tile
-        const bool kbias = (p.key_bias_log2 != 0.f) && (p.key_bias_period > 0 ? (t % p.key_bias_period == 0) : (t == 0));
-
-        // ---- QK^T: both 32-key blocks, scores come out as s - m_run (the accumulators start at -m)
-        f32x16 sa0, sa1;
-        {
-            const a8_i32x8 k00 = A8_FRAG(kb + kx[0][0], kb + kx[0][1]);
-            const a8_i32x8 k01 = A8_FRAG(kb + kx[1][0], kb + kx[1][1]);
-            const a8_i32x8 k10 = A8_FRAG(kb + 4096 + kx[0][0], kb + 4096 + kx[0][1]);
-            const a8_i32x8 k11 = A8_FRAG(kb + 4096 + kx[1][0], kb + 4096 + kx[1][1]);
-            __builtin_amdgcn_s_setprio(1);
-            sa0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(k00, qf[0], negm, 0, 0, 0, ksc0, 0, qsc);
-            sa0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(k01, qf[1], sa0, 0, 0, 2, ksc0, 2, qsc);
-            sa1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(k10, qf[0], negm, 0, 0, 0, ksc1, 0, qsc);
-            sa1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(k11, qf[1], sa1, 0, 0, 2, ksc1, 2, qsc);
-        }
-        // ---- PV of the PREVIOUS tile, issued right behind this tile's score MFMAs: the matrix pipe runs QK(t) + PV(t-1) back to back (512 cycles) while the
-        // exponentials of this tile (the VALU bulk of a tile, ~800 cycles) start as soon as QK(t) has landed -- PV hides under them.  P(t-1) / V^T(t-1) stay in
-        // registers across the barrier; a re-centring in this tile rescales oacc AFTER these MFMAs (a data dependency the compiler sees).
-        if (t > 0) {
-            oacc[0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf[0], pb, oacc[0], 0, 0, 0, vsc_pv, 0, one_scale);
-            oacc[1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf[1], pb, oacc[1], 0, 0, 1, vsc_pv, 0, one_scale);
-            oacc[2] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf[2], pb, oacc[2], 0, 0, 2, vsc_pv, 0, one_scale);
-            oacc[3] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf[3], pb, oacc[3], 0, 0, 3, vsc_pv, 0, one_scale);
-        }
-        // this tile's V^T fragments (consumed at the top of the next iteration)
-#pragma unroll
-        for (int db = 0; db < 4; ++db) vf[db] = A8_FRAG(vb + db * 2048 + vx[0], vb + db * 2048 + vx[1]);
-        vsc_pv = vsc;
-        if (kbias) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { sa0[r] += p.key_bias_log2; sa1[r] += p.key_bias_log2; }
-        }
-        if (ragged) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if (r >= lim) sa0[r] = -INFINITY;
-                if (32 + r >= lim) sa1[r] = -INFINITY;
-            }
-        }
-        int pb0, pb1, pb2, pb3, pb4, pb5, pb6, pb7;
-        float ps0, ps1;
-        A8_EXPB(sa0, pb0, pb1, pb2, pb3, ps0)
-        A8_EXPB(sa1, pb4, pb5, pb6, pb7, ps1)
-        if (t == 0 || ragged || !__all(ps0 <= 256.0f && ps1 <= 256.0f)) {
-            // exact re-centring on the tile's maximum (first tile: set it): m_run += d, everything accumulated so far shrinks by 2^-d
-            float mx = fmaxf(sa0[0], sa1[0]);
-#pragma unroll
-            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(sa0[r], sa1[r]));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float d = (t == 0) ? mx : fmaxf(mx, 0.f);
-            const float alpha = (t == 0) ? 1.0f : __builtin_amdgcn_exp2f(-d);
-            m_run += d;
-            l_run *= alpha;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { negm[r] = -m_run; sa0[r] -= d; sa1[r] -= d; }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
-            A8_EXPB(sa0, pb0, pb1, pb2, pb3, ps0)
-            A8_EXPB(sa1, pb4, pb5, pb6, pb7, ps1)
-        }
-        l_run += ps0 + ps1;
-        pb = a8_i32x8{pb0, pb1, pb2, pb3, pb4, pb5, pb6, pb7};      // P of this tile: the B operand of the PV MFMAs issued in the next iteration (or behind the loop)
-        __builtin_amdgcn_s_setprio(0);
-        asm volatile("" : "+v"(ksc0n), "+v"(ksc1n), "+v"(vscn));      // first use of the three dwords: the wait for them lands HERE
-        ksc0 = (int)(ksc0n >> (8 * lh)); ksc1 = (int)(ksc1n >> (8 * lh)); vsc = (int)vscn;
-        __syncthreads();     // this slot fully read by every wave; the next tile's DMA retired by the vmcnt(0) of this fence
+    // eight exponentials (scores r0_ .. r0_ + 7 of a block) with the running sums carried along (same summation order as A8_EXPB), packed into two dwords of e4m3 bytes
+#define A8_EXPQ(sa_, r0_, da_, db_)                                                                      \
+    {                                                                                                    \
+        float pq_[8];                                                                                    \
+        _Pragma("unroll") for (int r = 0; r < 8; r += 2) {                                               \
+            pq_[r] = __builtin_amdgcn_exp2f(sa_[(r0_) + r]); pq_[r + 1] = __builtin_amdgcn_exp2f(sa_[(r0_) + r + 1]); \
+            sc0_ += pq_[r]; sc1_ += pq_[r + 1];                                                          \
+        }                                                                                                \
+        int w_;                                                                                          \
+        w_ = __builtin_amdgcn_cvt_pk_fp8_f32(pq_[0], pq_[1], 0, false); da_ = __builtin_amdgcn_cvt_pk_fp8_f32(pq_[2], pq_[3], w_, true); \
+        w_ = __builtin_amdgcn_cvt_pk_fp8_f32(pq_[4], pq_[5], 0, false); db_ = __builtin_amdgcn_cvt_pk_fp8_f32(pq_[6], pq_[7], w_, true); \
     }
+#define A8_FAST_BODY                                                                                     \
+        {                                                                                                \
+        const int slot = t & 1;                                                                          \
+        uint32_t ksc0n = 0, ksc1n = 0, vscn = 0;                                                         \
+        if (t + 1 < nt) {                                                                                \
+            const long kr = (long)(t + 1) * A8_KVB + krow;                                               \
+            ksc0n = ksb[kr]; ksc1n = ksb[kr + 32];                                                       \
+            vscn = vsb[(long)(2 * (t + 1) + lh) * 32 + lq];                                              \
+            A8_STAGE(t + 1, slot ^ 1);                                                                   \
+        }                                                                                                \
+        const char* kb = kring + slot * A8_KTILE;                                                        \
+        const char* vb = vring + slot * A8_VTILE;                                                        \
+        f32x16 sa0, sa1;                                                                                 \
+        const a8_i32x8 k00 = A8_FRAG(kb + kx[0][0], kb + kx[0][1]);                                      \
+        const a8_i32x8 k01 = A8_FRAG(kb + kx[1][0], kb + kx[1][1]);                                      \
+        const a8_i32x8 k10 = A8_FRAG(kb + 4096 + kx[0][0], kb + 4096 + kx[0][1]);                        \
+        const a8_i32x8 k11 = A8_FRAG(kb + 4096 + kx[1][0], kb + 4096 + kx[1][1]);                        \
+        __builtin_amdgcn_s_setprio(1);                                                                   \
+        sa0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(k00, qf[0], negm, 0, 0, 0, ksc0, 0, qsc);  \
+        sa0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(k01, qf[1], sa0, 0, 0, 2, ksc0, 2, qsc);   \
+        sa1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(k10, qf[0], negm, 0, 0, 0, ksc1, 0, qsc);  \
+        sa1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(k11, qf[1], sa1, 0, 0, 2, ksc1, 2, qsc);   \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        int pb0, pb1, pb2, pb3, pb4, pb5, pb6, pb7;                                                      \
+        float ps0, ps1;                                                                                  \
+        {   /* the exponentials in quarters, each in the shadow of one MFMA: QK^T(1b) above, then the four PV MFMAs of the previous tile */ \
+            float sc0_ = 0.f, sc1_ = 0.f;                                                                \
+            A8_EXPQ(sa0, 0, pb0, pb1)                                                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                           \
+            oacc[0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf[0], pb, oacc[0], 0, 0, 0, vsc_pv, 0, one_scale); \
+            A8_EXPQ(sa0, 8, pb2, pb3)                                                                    \
+            ps0 = sc0_ + sc1_;                                                                           \
+            __builtin_amdgcn_sched_barrier(0);                                                           \
+            oacc[1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf[1], pb, oacc[1], 0, 0, 1, vsc_pv, 0, one_scale); \
+            sc0_ = 0.f; sc1_ = 0.f;                                                                      \
+            A8_EXPQ(sa1, 0, pb4, pb5)                                                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                           \
+            oacc[2] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf[2], pb, oacc[2], 0, 0, 2, vsc_pv, 0, one_scale); \
+            A8_EXPQ(sa1, 8, pb6, pb7)                                                                    \
+            ps1 = sc0_ + sc1_;                                                                           \
+            __builtin_amdgcn_sched_barrier(0);                                                           \
+            oacc[3] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf[3], pb, oacc[3], 0, 0, 3, vsc_pv, 0, one_scale); \
+        }                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        _Pragma("unroll")                                                                                \
+        for (int db = 0; db < 4; ++db) vf[db] = A8_FRAG(vb + db * 2048 + vx[0], vb + db * 2048 + vx[1]); \
+        vsc_pv = vsc;                                                                                    \
+        if (!__all(ps0 <= 256.0f && ps1 <= 256.0f)) {                                                    \
+            float mx = fmaxf(sa0[0], sa1[0]);                                                            \
+            _Pragma("unroll")                                                                            \
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(sa0[r], sa1[r]));                          \
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));                                                      \
+            const float d = fmaxf(mx, 0.f);                                                              \
+            const float alpha = __builtin_amdgcn_exp2f(-d);                                              \
+            m_run += d;                                                                                  \
+            l_run *= alpha;                                                                              \
+            _Pragma("unroll")                                                                            \
+            for (int r = 0; r < 16; ++r) { negm[r] = -m_run; sa0[r] -= d; sa1[r] -= d; }                 \
+            _Pragma("unroll")                                                                            \
+            for (int i = 0; i < 4; ++i)                                                                  \
+            _Pragma("unroll")                                                                            \
+                for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;                                        \
+            A8_EXPB(sa0, pb0, pb1, pb2, pb3, ps0)                                                        \
+            A8_EXPB(sa1, pb4, pb5, pb6, pb7, ps1)                                                        \
+        }                                                                                                \
+        l_run += ps0 + ps1;                                                                              \
+        pb = a8_i32x8{pb0, pb1, pb2, pb3, pb4, pb5, pb6, pb7};                                           \
+        __builtin_amdgcn_s_setprio(0);                                                                   \
+        asm volatile("" : "+v"(ksc0n), "+v"(ksc1n), "+v"(vscn));                                         \
+        ksc0 = (int)(ksc0n >> (8 * lh)); ksc1 = (int)(ksc1n >> (8 * lh)); vsc = (int)vscn;               \
+        __syncthreads();                                                                                 \
+        }
+    // VAR 1 (opt-in: UTX_ATTN8_PEEL=1; same arithmetic in the same order per element = bit-identical by construction; NOT yet run on hardware): tile 0 and a ragged last tile
+    // run the general body in front of / behind the loop; the loop runs A8_FAST_BODY, the general tile without its `if (t > 0)`, key-multiplicity, ragged and first-tile branches
+    // and in a hand order: QK^T(t) x 4, then the exponentials in QUARTERS (A8_EXPQ: eight v_exp + their share of the sums and packs, the running sums carried across), one
+    // quarter in front of each of the four PV(t - 1) MFMAs, pinned by sched_barrier.  In the default listing the eight MFMAs of a tile and its thirty-two v_exp sit in basic
+    // blocks of their own -- within a wave they never overlap, and a tile costs its 512 matrix cycles PLUS its ~600 VALU cycles; here the listing shows eight v_exp behind
+    // each MFMA (the sums and packs still trail behind the last MFMA: pure nodes float).  Periodic key multiplicity (sequence parallelism) keeps the general loop.
+    if (VAR == 1 && !(p.key_bias_period > 0 && p.key_bias_log2 != 0.f)) {
+        const bool rag_ = (S & (A8_KVB - 1)) != 0;
+        const int fast_end_ = rag_ ? nt - 1 : nt;                 // tiles [1, fast_end_) take the fast body
+        { const int t = 0; A8_TILE_BODY(1) }
+        for (int t = 1; t < fast_end_; ++t) A8_FAST_BODY
+        if (rag_ && nt > 1) { const int t = nt - 1; A8_TILE_BODY(1) }
+    } else
+    for (int t = 0; t < nt; ++t) A8_TILE_BODY(1)
 
     // PV of the last tile
     oacc[0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf[0], pb, oacc[0], 0, 0, 0, vsc_pv, 0, one_scale);
@@ -304,17 +405,22 @@ extern "C" int utx_launch_quant_vt_mx8(const void* vt, void* v8, void* vs, int H
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
+template <int VAR>
+static int a8_launch(const Attn8Params& p, hipStream_t stream) {
+    UTX_ONCE_PER_DEVICE(attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_fp8_kernel<VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, A8_LDS) != hipSuccess) return -3;
+        UTX_ONCE_DONE(attr_set);
+    }
+    hipLaunchKernelGGL((attn_fwd_fp8_kernel<VAR>), dim3(p.nqb * p.H), dim3(512), A8_LDS, stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+
 extern "C" int utx_launch_attn_fwd_fp8(const Attn8Params* hp, hipStream_t stream) {
     Attn8Params p = *hp;
     if (p.H <= 0 || p.S <= 0 || p.Sq < 0 || p.Sq > p.S || p.S_pad < p.S || (p.S_pad & 63) || p.key_bias_period < 0 || (p.o_ss & 3)) return -2;
     if ((((uintptr_t)p.q8) | ((uintptr_t)p.k8) | ((uintptr_t)p.v8t)) & 15) return -2;
     if ((((uintptr_t)p.qs) | ((uintptr_t)p.ks) | ((uintptr_t)p.vs)) & 3) return -2;
     if (p.Sq == p.S) p.Sq = 0;
-    UTX_ONCE_PER_DEVICE(attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_fp8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, A8_LDS) != hipSuccess) return -3;
-        UTX_ONCE_DONE(attr_set);
-    }
     p.nqb = ((p.Sq > 0 ? p.Sq : p.S) + 255) / 256;
-    hipLaunchKernelGGL(attn_fwd_fp8_kernel, dim3(p.nqb * p.H), dim3(512), A8_LDS, stream, p);
-    return hipGetLastError() == hipSuccess ? 0 : -4;
+    return g_utx_opt.attn8_peel == 1 ? a8_launch<1>(p, stream) : a8_launch<0>(p, stream);      // UTX_ATTN8_PEEL=1: the peeled loop (VAR 1, opt-in)
 }
