@@ -217,9 +217,13 @@ def attention_variant_experiment(timeout_s=150):
         env.pop("UTX_ATTN_PEEL", None)
         r = subprocess.run([sys.executable, tool, "--json"], capture_output=True, text=True, timeout=timeout_s, env=env)
         last = [l for l in r.stdout.splitlines() if l.startswith("{")]
-        if r.returncode != 0 or not last:
+        if not last:
             return {"attn_peel": {"error": "rc %d: %s" % (r.returncode, (r.stderr or r.stdout)[-400:])}, "note": note}
-        return {"attn_peel": json.loads(last[-1]), "note": note,
+        res = json.loads(last[-1])      # the tool prints a complete line behind its bf16 arms and again at its end: a child that dies in between still reports the first
+        if r.returncode != 0:
+            res["child_rc"] = r.returncode
+            res["error"] = (r.stderr or "")[-300:]
+        return {"attn_peel": res, "note": note,
                 "layout": "{tokens: {UTX_ATTN_PEEL value: {bit_identical_to_default, repeats, mismatches_in_repeats, med_ms, best_ms, tflops}}}, 24 heads, key multiplicity 8 on tile 0; '0' = the default kernel in the same process; keys 'fp8_<tokens>': the MX fp8 attention kernel (opt-in path) and its peeled form UTX_ATTN8_PEEL = 1, bits against the default fp8 kernel"}
     except Exception as e:  # noqa: BLE001 -- an experiment must never cost the line
         return {"attn_peel": {"error": repr(e)[:400]}, "note": note}

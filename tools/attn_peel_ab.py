@@ -71,52 +71,59 @@ def main():
             result.setdefault(str(S), {}).setdefault(str(peel), {}).update(med_ms=med, best_ms=t[0], tflops=fl / (med * 1e-3) / 1e12)
             say("S = %6d  UTX_ATTN_PEEL=%d  med %8.3f ms  best %8.3f ms  -> %7.1f TF/s" % (S, peel, med, t[0], fl / (med * 1e-3) / 1e12), flush=True)
     _lib.set_option("UTX_ATTN_PEEL", 0)
+    if as_json:      # a first complete line: whatever the fp8 arm below does to this process, the bf16 result is out (the reader takes the LAST line that parses)
+        import json
+        print(json.dumps(result), flush=True)
     # the MX fp8 attention kernel (opt-in path) and its own peeled form, UTX_ATTN8_PEEL = 1 (attention_fp8.hip): same operands, bits against the default fp8 kernel
-    for S in SIZES:
-        g = torch.Generator(device="cuda").manual_seed(S + 1)
-        S_pad = (S + 63) // 64 * 64
-        Qh = (torch.randn(H, S_pad, 128, generator=g, device="cuda") * (1.4426950408889634 / math.sqrt(128.0))).to(BF)
-        Kh = torch.randn(H, S_pad, 128, generator=g, device="cuda").to(BF)
-        Vt = torch.randn(H, 128, S_pad, generator=g, device="cuda").to(BF)
-        q8, qs = ops.quant_qk_mx8(Qh)
-        k8, ks = ops.quant_qk_mx8(Kh)
-        v8, vs = ops.quant_vt_mx8(Vt)
-        del Qh, Kh, Vt
-        out = torch.empty(S, H * 128, dtype=BF, device="cuda")
-        fl = 4.0 * S * S * 128 * H
+    try:      # its own try: a failure here must not take the bf16 results above with it
+        for S in SIZES:
+            g = torch.Generator(device="cuda").manual_seed(S + 1)
+            S_pad = (S + 63) // 64 * 64
+            Qh = (torch.randn(H, S_pad, 128, generator=g, device="cuda") * (1.4426950408889634 / math.sqrt(128.0))).to(BF)
+            Kh = torch.randn(H, S_pad, 128, generator=g, device="cuda").to(BF)
+            Vt = torch.randn(H, 128, S_pad, generator=g, device="cuda").to(BF)
+            q8, qs = ops.quant_qk_mx8(Qh)
+            k8, ks = ops.quant_qk_mx8(Kh)
+            v8, vs = ops.quant_vt_mx8(Vt)
+            del Qh, Kh, Vt
+            out = torch.empty(S, H * 128, dtype=BF, device="cuda")
+            fl = 4.0 * S * S * 128 * H
 
-        def run8(peel):
-            _lib.set_option("UTX_ATTN8_PEEL", peel)
-            ops.attention_fp8(q8, qs, k8, ks, v8, vs, S=S, out=out, key_bias_log2=3.0)
+            def run8(peel):
+                _lib.set_option("UTX_ATTN8_PEEL", peel)
+                ops.attention_fp8(q8, qs, k8, ks, v8, vs, S=S, out=out, key_bias_log2=3.0)
 
-        run8(0)
-        torch.cuda.synchronize()
-        ref = out.clone()
-        miss = 0
-        for _rep in range(repeats + 1):
-            out.zero_()
-            run8(1)
+            run8(0)
             torch.cuda.synchronize()
-            miss += int(not torch.equal(out.view(torch.int16), ref.view(torch.int16)))
-        key = "fp8_%d" % S
-        result.setdefault(key, {}).setdefault("1", {}).update(bit_identical_to_default=(miss == 0), repeats=repeats + 1, mismatches_in_repeats=miss)
-        say("fp8  S = %6d  UTX_ATTN8_PEEL=1  %d of %d launches differ from the default fp8 kernel" % (S, miss, repeats + 1), flush=True)
-        times8 = {0: [], 1: []}
-        for _ in range(rounds):
-            for peel in (0, 1):
-                run8(peel)
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record()
-                for _r in range(3):
-                    run8(peel)
-                b.record()
+            ref = out.clone()
+            miss = 0
+            for _rep in range(repeats + 1):
+                out.zero_()
+                run8(1)
                 torch.cuda.synchronize()
-                times8[peel].append(a.elapsed_time(b) / 3.0)
-        for peel in (0, 1):
-            tt = sorted(times8[peel])
-            med = tt[len(tt) // 2]
-            result.setdefault(key, {}).setdefault(str(peel), {}).update(med_ms=med, best_ms=tt[0], tflops=fl / (med * 1e-3) / 1e12)
-            say("fp8  S = %6d  UTX_ATTN8_PEEL=%d  med %8.3f ms  best %8.3f ms  -> %7.1f TF/s" % (S, peel, med, tt[0], fl / (med * 1e-3) / 1e12), flush=True)
+                miss += int(not torch.equal(out.view(torch.int16), ref.view(torch.int16)))
+            key = "fp8_%d" % S
+            result.setdefault(key, {}).setdefault("1", {}).update(bit_identical_to_default=(miss == 0), repeats=repeats + 1, mismatches_in_repeats=miss)
+            say("fp8  S = %6d  UTX_ATTN8_PEEL=1  %d of %d launches differ from the default fp8 kernel" % (S, miss, repeats + 1), flush=True)
+            times8 = {0: [], 1: []}
+            for _ in range(rounds):
+                for peel in (0, 1):
+                    run8(peel)
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    for _r in range(3):
+                        run8(peel)
+                    b.record()
+                    torch.cuda.synchronize()
+                    times8[peel].append(a.elapsed_time(b) / 3.0)
+            for peel in (0, 1):
+                tt = sorted(times8[peel])
+                med = tt[len(tt) // 2]
+                result.setdefault(key, {}).setdefault(str(peel), {}).update(med_ms=med, best_ms=tt[0], tflops=fl / (med * 1e-3) / 1e12)
+                say("fp8  S = %6d  UTX_ATTN8_PEEL=%d  med %8.3f ms  best %8.3f ms  -> %7.1f TF/s" % (S, peel, med, tt[0], fl / (med * 1e-3) / 1e12), flush=True)
+    except Exception as e:  # noqa: BLE001
+        result["fp8_error"] = repr(e)[:300]
+        say("fp8 arm failed: %r" % (e,), flush=True)
     _lib.set_option("UTX_ATTN8_PEEL", 0)
     if as_json:
         import json
