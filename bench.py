@@ -205,7 +205,7 @@ def count_distinct_devices(idents):
 
 
 def attention_variant_experiment(timeout_s=150):
-    """Beside the line, never part of `value`: the opt-in peeled attention loop (UTX_ATTN_PEEL = 1 ... 5, csrc/attention_glds.hip VAR 12 ... 16; UTX_ATTN8_PEEL = 1, csrc/attention_fp8.hip) against the default
+    """Beside the line, never part of `value`: the opt-in peeled attention loop (UTX_ATTN_PEEL = 1 ... 6, csrc/attention_glds.hip VAR 12 ... 17; UTX_ATTN8_PEEL = 1, csrc/attention_fp8.hip) against the default
     kernel -- bit-identity and an interleaved A/B at the two operating points (tools/attn_peel_ab.py --json).  Those variants were written without GPU access; they
     run in a CHILD process with a timeout, after every measurement of this process is finished, so that whatever they do cannot cost the bench line.
     UTX_BENCH_EXPERIMENTS=0 skips it."""

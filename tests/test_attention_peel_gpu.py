@@ -1,4 +1,4 @@
-"""UTX_ATTN_PEEL = 1 ... 5 (attention_glds.hip, VAR 12 ... 16; opt-in) and UTX_ATTN8_PEEL = 1 (attention_fp8.hip, its last test below): the LDS-DMA attention kernel with the first tile and a ragged last tile run in front of / behind
+"""UTX_ATTN_PEEL = 1 ... 6 (attention_glds.hip, VAR 12 ... 17; opt-in) and UTX_ATTN8_PEEL = 1 (attention_fp8.hip, its last test below): the LDS-DMA attention kernel with the first tile and a ragged last tile run in front of / behind
 the loop, so that the loop body carries none of their branches and its QK^T || exp and PV || exp stages are single basic blocks; 5 (VAR 16) also moves the tile's barrier between S2
 and S3 and reads the next tile's first K fragments under S3's MFMAs.  Same arithmetic in the same order
 per element: every output must equal the default kernel's BIT FOR BIT, on every feature of the launch (ragged S, pruned queries, key multiplicity with and without a
@@ -50,7 +50,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("peel", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("peel", [1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("H,S,S_q,kb,period,spike", CASES)
 def test_peeled_attention_loop_equals_the_default_kernel_bit_for_bit(peel, H, S, S_q, kb, period, spike):
     from unitex_amd import _lib

@@ -1,4 +1,4 @@
-"""The control flow of the opt-in attention loops (attention_glds.hip, VAR 12 ... 16: UTX_ATTN_PEEL = 1 ... 5) against the general loop, on the CPU.
+"""The control flow of the opt-in attention loops (attention_glds.hip, VAR 12 ... 17: UTX_ATTN_PEEL = 1 ... 6) against the general loop, on the CPU.
 
 These variants run the SAME tile arithmetic (macros) -- what was written by hand is WHICH tile goes through which copy, into which ring slot the next tile is
 requested and when, where the barrier sits, and (VAR 16) which ring slot the next tile's first K fragments are read from.  This test lifts exactly those source lines
@@ -85,11 +85,11 @@ int main() {
         const bool general_everywhere = per && p.key_bias_log2 != 0.f;
         Ev g = run<0, 1>(Sk, p);
         discipline(g, Sk, 0, true);
-        Ev vs[5] = {run<12, 1>(Sk, p), run<13, 1>(Sk, p), run<14, 1>(Sk, p), run<15, 1>(Sk, p), run<16, 1>(Sk, p)};
-        for (int vi = 0; vi < 5; ++vi) {
+        Ev vs[6] = {run<12, 1>(Sk, p), run<13, 1>(Sk, p), run<14, 1>(Sk, p), run<15, 1>(Sk, p), run<16, 1>(Sk, p), run<17, 1>(Sk, p)};
+        for (int vi = 0; vi < 6; ++vi) {
             ++checked;
             discipline(vs[vi], Sk, 12 + vi, general_everywhere);
-            if (vi == 4 && !general_everywhere) continue;      // VAR 16 has its own event order; the discipline above is its check
+            if (vi >= 4 && !general_everywhere) continue;      // VAR 16 / 17 have their own event order; the discipline above is its check
             const Ev& v = vs[vi];
             if (v.size() != g.size()) { FAIL("var %%d Sk %%d per %%d: %%zu vs %%zu events", 12 + vi, Sk, per, v.size(), g.size()); continue; }
             for (size_t i = 0; i < g.size(); ++i) {
@@ -111,7 +111,7 @@ def _loop_source():
     end = next(i for i, l in enumerate(lines) if "this group fully read by every wave" in l)
     assert 0 < start < end and lines[end + 1].strip() == "}", "the loop block of attention_glds.hip moved: update this test's markers"
     block = [l for l in lines[start:end + 2] if not l.lstrip().startswith("#pragma")]
-    assert any("VAR == 16" in l for l in block)
+    assert any("VAR == 16 || VAR == 17" in l for l in block)
     return "\n".join(block)
 
 

@@ -541,10 +541,10 @@ def test_attention_variant_ab_tool_runs_its_whole_script_against_stubs(monkeypat
     tool.main()
     last = [l for l in capsys.readouterr().out.splitlines() if l.startswith("{")][-1]
     res = json.loads(last)
-    assert set(res) == {"128", "200", "fp8_128", "fp8_200"} and res["fp8_200"]["1"]["bit_identical_to_default"] is True and res["fp8_128"]["0"]["tflops"] > 0 and set(res["128"]) == {"0", "1", "2", "3", "4", "5"}
+    assert set(res) == {"128", "200", "fp8_128", "fp8_200"} and res["fp8_200"]["1"]["bit_identical_to_default"] is True and res["fp8_128"]["0"]["tflops"] > 0 and set(res["128"]) == {"0", "1", "2", "3", "4", "5", "6"}
     assert res["200"]["1"]["bit_identical_to_default"] is True and res["200"]["2"]["bit_identical_to_default"] is False and res["200"]["3"]["bit_identical_to_default"] is True
     assert abs(res["128"]["0"]["med_ms"] - 1.0) < 1e-9 and res["128"]["3"]["tflops"] > 0
     assert calls["opt"][-1] == ("UTX_ATTN8_PEEL", 0) and ("UTX_ATTN_PEEL", 0) in calls["opt"], "the tool leaves the options as it found them"
     assert calls["attn8"] == 2 * (1 + 4 + 2 * 2 * 4)
-    assert calls["attn"] == 2 * (6 + 5 * 3 + 2 * 6 * 4)
+    assert calls["attn"] == 2 * (7 + 6 * 3 + 2 * 7 * 4)
     assert res["200"]["2"]["mismatches_in_repeats"] == 3 and res["200"]["5"]["mismatches_in_repeats"] == 0 and res["200"]["5"]["repeats"] == 3

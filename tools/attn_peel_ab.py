@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""A/B of the opt-in peeled attention loop (UTX_ATTN_PEEL = 1 ... 5: attention_glds.hip VAR 12 ... 16) against the default kernel, same process, interleaved launches,
+"""A/B of the opt-in peeled attention loop (UTX_ATTN_PEEL = 1 ... 6: attention_glds.hip VAR 12 ... 17) against the default kernel, same process, interleaved launches,
 at the two operating points (S = 13 376 and 50 240 executed tokens, 24 heads, pre-scaled Q, key multiplicity 8 on tile 0 as in the step).  Prints bit-identity
 and TF/s per arm.  RUN tests/test_attention_peel_gpu.py FIRST (UTX_RUN_UNVALIDATED=1): these variants had not run on hardware when they were committed.
 
@@ -38,7 +38,7 @@ def main():
             ops.attention(Qh, Kh, Vt, S=S, scale=0.0, key_bias_log2=3.0, out=out)
 
         ref = None
-        for peel in (0, 1, 2, 3, 4, 5):
+        for peel in (0, 1, 2, 3, 4, 5, 6):
             run(peel)
             torch.cuda.synchronize()
             if ref is None:
@@ -54,9 +54,9 @@ def main():
                     miss += int(not torch.equal(out.view(torch.int16), ref.view(torch.int16)))
                 result.setdefault(str(S), {}).setdefault(str(peel), {}).update(bit_identical_to_default=same, repeats=repeats, mismatches_in_repeats=miss)
                 say("S = %6d  UTX_ATTN_PEEL=%d  bit-identical to the default: %s   (%d of %d repeated launches differ)" % (S, peel, same, miss, repeats), flush=True)
-        times = {0: [], 1: [], 2: [], 3: [], 4: [], 5: []}
+        times = {0: [], 1: [], 2: [], 3: [], 4: [], 5: [], 6: []}
         for _ in range(rounds):
-            for peel in (0, 1, 2, 3, 4, 5):
+            for peel in (0, 1, 2, 3, 4, 5, 6):
                 run(peel)      # warm
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
@@ -65,7 +65,7 @@ def main():
                 b.record()
                 torch.cuda.synchronize()
                 times[peel].append(a.elapsed_time(b) / 3.0)
-        for peel in (0, 1, 2, 3, 4, 5):
+        for peel in (0, 1, 2, 3, 4, 5, 6):
             t = sorted(times[peel])
             med = t[len(t) // 2]
             result.setdefault(str(S), {}).setdefault(str(peel), {}).update(med_ms=med, best_ms=t[0], tflops=fl / (med * 1e-3) / 1e12)

@@ -289,7 +289,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
             AG_MM(oacc[i & 3], vfb[i], pb[2 + (i >> 2)], oacc[i & 3])                                \
         if (VAR != 1 && VAR != 6) __builtin_amdgcn_s_setprio(0);                                     \
         }
-    // VAR 16 (opt-in: UTX_ATTN_PEEL=5; same arithmetic in the same order per element; NOT yet run on hardware): the fast tile cut in two around the tile's ONE barrier, which moves
+    // VAR 16 / 17 (opt-in: UTX_ATTN_PEEL=5 / 6, 17 = 16 without the S1 / S2 interleave hints; same arithmetic in the same order per element; NOT yet run on hardware): the fast tile cut in two around the tile's ONE barrier, which moves
     // from the end of the tile to between S2 and S3.  S3 (PV of block 1) reads nothing from LDS -- its V fragments came in during S2 -- so behind that barrier (a) the ring slot of
     // tile t is free and takes the DMA of tile t + 2, and (b) tile t + 1, requested a whole tile earlier, has landed and is visible: its first eight K fragments are read UNDER the
     // S3 MFMAs into registers that live across the back edge.  The next tile then starts on its MFMAs at once, where the default kernel has all eight waves issue sixteen
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
         }                                                                                            \
         AG_EXPB(sa0, pb[0], pb[1], ps0)                                                              \
         _Pragma("unroll")                                                                            \
-        for (int i_ = 0; i_ < 8; ++i_) {                                                             \
+        for (int i_ = 0; i_ < (VAR == 17 ? 0 : 8); ++i_) {                                                             \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);                                       \
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);                                       \
             __builtin_amdgcn_sched_group_barrier(0x402, 4, 1);                                       \
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
         }                                                                                            \
         AG_EXPB(sa1, pb[2], pb[3], ps1)                                                              \
         _Pragma("unroll")                                                                            \
-        for (int i_ = 0; i_ < 8; ++i_) {                                                             \
+        for (int i_ = 0; i_ < (VAR == 17 ? 0 : 8); ++i_) {                                                             \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 2);                                       \
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 2);                                       \
             __builtin_amdgcn_sched_group_barrier(0x402, 4, 2);                                       \
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
             AG_TILE_BODY(1)
             __syncthreads();
         }
-    } else if (VAR == 16 && TPB == 1 && !(p.key_bias_period > 0 && p.key_bias_log2 != 0.f)) {
+    } else if ((VAR == 16 || VAR == 17) && TPB == 1 && !(p.key_bias_period > 0 && p.key_bias_log2 != 0.f)) {
         const bool rag_ = (Sk & (AG_KVB - 1)) != 0;
         const int fast_end_ = rag_ ? nt - 1 : nt;                 // tiles [1, fast_end_) take the fast form
         bf16x8 kfa_n[8], vfb_n[8];
@@ -578,7 +578,7 @@ static int launch_glds(AttnParams p, hipStream_t stream) {
     p.nqb = ((p.Sq > 0 ? p.Sq : p.S) + 255) / 256;
     p.w_base = 0; p.nsplit = 1; p.tiles_per_split = 0; p.part_o = nullptr; p.part_lse = nullptr;
     int pl[4] = {p.nqb * p.H, 0, 1, 0};
-    if (TPB == 1 && (VAR == 0 || VAR == 6 || VAR == 7 || VAR == 8 || VAR == 9 || VAR == 10 || (VAR >= 12 && VAR <= 16)) && !p.flags) utx_attn_split_plan_impl(p.H, p.Sq, p.S, utx_ncu(), pl);
+    if (TPB == 1 && (VAR == 0 || VAR == 6 || VAR == 7 || VAR == 8 || VAR == 9 || VAR == 10 || (VAR >= 12 && VAR <= 17)) && !p.flags) utx_attn_split_plan_impl(p.H, p.Sq, p.S, utx_ncu(), pl);
     const int nwg = pl[0], nfull = pl[1], ns = pl[2], tps = pl[3], r = nwg - nfull;
     // the scratch of the split is CALLER-OWNED (utx_attn_fwd_bf16_ws; the legacy entry points pass the context's own buffer, grown outside of any
     // capture): nothing is allocated here, a launch whose scratch is missing or too small runs unsplit -- same result up to one bf16 rounding of the
@@ -612,6 +612,7 @@ extern "C" int utx_launch_attn_fwd_glds(const AttnParams* p, int presc, hipStrea
     if (g_utx_opt.attn_peel == 3 && presc) return launch_glds<1, 1, 14>(*p, stream);
     if (g_utx_opt.attn_peel == 4 && presc) return launch_glds<1, 1, 15>(*p, stream);
     if (g_utx_opt.attn_peel == 5 && presc) return launch_glds<1, 1, 16>(*p, stream);      // the tile's barrier between S2 and S3, next tile's first K fragments prefetched under S3      // + K fragment reads pinned 1 : 1 behind the QK^T(0) MFMAs      // + scheduling boundary between S0 and S1      // the same without the S1 / S2 interleave hints
+    if (g_utx_opt.attn_peel == 6 && presc) return launch_glds<1, 1, 17>(*p, stream);      // 5 without the S1 / S2 interleave hints: the barrier move / prefetch alone
 #ifdef UTX_ABLATION
     { const int var = g_utx_opt.attn_var_abl;   // timing A/B only: 1 = no s_setprio, 2 = no interleave hints, 3 = half the fragment reads (WRONG results), 4 = row sums with v_pk_add_f32
       if (var == 1 && presc) return launch_glds<1, 1, 1>(*p, stream);
