@@ -22,6 +22,7 @@ Contract: python bench.py --gpus N --steps K --warmup W  -> rank 0 prints ONE JS
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -204,29 +205,75 @@ def count_distinct_devices(idents):
     return len(set(hws)), "uuid + PCI address"
 
 
-def attention_variant_experiment(timeout_s=150):
-    """Beside the line, never part of `value`: the opt-in peeled attention loop (UTX_ATTN_PEEL = 1 ... 6, csrc/attention_glds.hip VAR 12 ... 17; UTX_ATTN8_PEEL = 1, csrc/attention_fp8.hip) against the default
-    kernel -- bit-identity and an interleaved A/B at the two operating points (tools/attn_peel_ab.py --json).  Those variants were written without GPU access; they
-    run in a CHILD process with a timeout, after every measurement of this process is finished, so that whatever they do cannot cost the bench line.
-    UTX_BENCH_EXPERIMENTS=0 skips it."""
-    import subprocess
-    tool = os.path.join(ROOT, "tools", "attn_peel_ab.py")
-    note = "opt-in variants, measured in a child process behind the timed region; the line's value / roofline are the DEFAULT kernel's"
+def attention_loop_ab(dev, S_exec, heads):
+    """Beside the line, never part of `value`: the attention kernel's fast loop (UTX_ATTN_PEEL=1, the default since round 5) against its general loop (=0, the default
+    until round 4) on this workload's shape, same process, interleaved, behind every other measurement: bit identity + ms per launch.  Both are validated kernels
+    (tests/test_attention_peel_gpu.py); the option is restored."""
+    from unitex_amd import _lib
+    from unitex_amd.flux import ops
+    g = torch.Generator(device=dev).manual_seed(S_exec)
+    S_pad = (S_exec + 63) // 64 * 64
+    Qh = (torch.randn(heads, S_pad, 128, generator=g, device=dev) * (1.4426950408889634 / math.sqrt(128.0))).to(torch.bfloat16)
+    Kh = torch.randn(heads, S_pad, 128, generator=g, device=dev).to(torch.bfloat16)
+    Vt = torch.randn(heads, 128, S_pad, generator=g, device=dev).to(torch.bfloat16)
+    o = torch.empty(S_exec, heads * 128, dtype=torch.bfloat16, device=dev)
+    res, outs = {}, {}
     try:
-        env = dict(os.environ, UTX_AB_ROUNDS="3")
-        env.pop("UTX_ATTN_PEEL", None)
-        r = subprocess.run([sys.executable, tool, "--json"], capture_output=True, text=True, timeout=timeout_s, env=env)
-        last = [l for l in r.stdout.splitlines() if l.startswith("{")]
-        if not last:
-            return {"attn_peel": {"error": "rc %d: %s" % (r.returncode, (r.stderr or r.stdout)[-400:])}, "note": note}
-        res = json.loads(last[-1])      # the tool prints a complete line behind its bf16 arms and again at its end: a child that dies in between still reports the first
-        if r.returncode != 0:
-            res["child_rc"] = r.returncode
-            res["error"] = (r.stderr or "")[-300:]
-        return {"attn_peel": res, "note": note,
-                "layout": "{tokens: {UTX_ATTN_PEEL value: {bit_identical_to_default, repeats, mismatches_in_repeats, med_ms, best_ms, tflops}}}, 24 heads, key multiplicity 8 on tile 0; '0' = the default kernel in the same process; keys 'fp8_<tokens>': the MX fp8 attention kernel (opt-in path) and its peeled form UTX_ATTN8_PEEL = 1, bits against the default fp8 kernel"}
-    except Exception as e:  # noqa: BLE001 -- an experiment must never cost the line
-        return {"attn_peel": {"error": repr(e)[:400]}, "note": note}
+        ms = {0: [], 1: []}
+        for rnd in range(3):
+            for arm in (0, 1):
+                _lib.set_option("UTX_ATTN_PEEL", arm)
+                ops.attention(Qh, Kh, Vt, S=S_exec, scale=0.0, key_bias_log2=3.0, out=o)
+                if rnd == 0:
+                    torch.cuda.synchronize()
+                    outs[arm] = o.clone()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(2):
+                    ops.attention(Qh, Kh, Vt, S=S_exec, scale=0.0, key_bias_log2=3.0, out=o)
+                b.record()
+                torch.cuda.synchronize()
+                ms[arm].append(a.elapsed_time(b) / 2.0)
+        fl = 4.0 * S_exec * S_exec * 128 * heads
+        res = {"general_loop_ms": sorted(ms[0])[1], "fast_loop_ms": sorted(ms[1])[1], "bit_identical": bool(torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))),
+               "general_loop_tflops": fl / sorted(ms[0])[1] / 1e9, "fast_loop_tflops": fl / sorted(ms[1])[1] / 1e9, "tokens": S_exec, "heads": heads}
+    finally:
+        _lib.set_option("UTX_ATTN_PEEL", 1)
+    return res
+
+
+def ref_point_ms(model, ops, sched_unused, calculate_shift, shape, dev, prune, steps=3):
+    """ms per denoise step of the SAME model at the reference's own operating point (WORKLOADS['ref512x6']: 512^2 x 6 views, 13 824 tokens), 1 warm-up + `steps` timed."""
+    from unitex_amd.flux.scheduler import FlowMatchEulerScheduler
+    S_txt, n_noise, n_ctrl, n_dual = token_counts("ref512x6")
+    h_px, w_px, dual_px, _ = WORKLOADS["ref512x6"]
+    S_img = n_noise + n_ctrl + n_dual
+    g = torch.Generator(device=dev).manual_seed(64)
+    lat = torch.randn(S_img, 64, generator=g, device=dev).to(torch.bfloat16)
+    cond = lat[n_noise:].clone()
+    HL, WL = h_px // 16, w_px // 16
+    ids = [torch.zeros(HL, WL, 3), torch.zeros(HL, WL, 3), torch.zeros(dual_px // 16, dual_px // 16, 3)]
+    for t, (oy, ox) in zip(ids, [(0, 0), (HL, 0), (HL, WL)]):
+        t[..., 1] += torch.arange(oy, oy + t.shape[0])[:, None]
+        t[..., 2] += torch.arange(ox, ox + t.shape[1])[None, :]
+    model.set_positions(torch.zeros(S_txt, 3), torch.cat([t.reshape(-1, 3) for t in ids], 0))
+    if prune:
+        model.set_output_rows(n_noise)
+    model.set_conditioning(torch.zeros(S_txt, shape.joint_dim, device=dev), torch.zeros(1, shape.pooled_dim, device=dev), 3.5)
+    sched = FlowMatchEulerScheduler()
+    ts = sched.set_timesteps(28, calculate_shift(n_noise))
+
+    def step(i):
+        t_bf = torch.tensor(float(ts[i]), dtype=torch.float32).to(torch.bfloat16)
+        v = model.forward(lat, float((t_bf / 1000).to(torch.float32)))
+        ops.sched_step(lat, v, sched.dsigma(i), n_noise_tokens=n_noise, cond=cond)
+    step(0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(1, 1 + steps):
+        step(i)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
 
 
 def _gemm_census(model):
@@ -510,8 +557,8 @@ def main():
             "config": {"workload": args.workload, "description": desc, "tokens": S, "text_tokens": S_txt,
                        "noise_tokens": n_noise, "control_tokens": n_ctrl, "dual_tokens": n_dual,
                        "lora_rank": args.lora_rank, "guidance": 3.5, "launch": launch_path, "ms_per_step_hip_graph_replay": graph_ms, "parallelism": par,
-                       "text_half_of_double_blocks": "second HIP stream beside the image half (default; elementwise kernels built without packed fp32 instructions, DESIGN 9)" if model.overlap_text else
-                       "on the caller's stream (UTX_TXT_STREAM=0)",
+                       "text_half_of_double_blocks": "second HIP stream beside the image half (opt-in: UTX_TXT_STREAM=1)" if model.overlap_text else
+                       "on the caller's stream (default since round 5: the two-stream form's rare corruption has no established mechanism, DESIGN 9 b; costs 0.5 % here)",
                        "tokens_computed": S_exec, "text_dedup": None if model.text_rows is None else "512 identical text tokens carried as %d rows per rank, key weight 2^%.2f (SURVEY 7 last bullet; UTX_TEXT_DEDUP=0 disables)" % (model.text_rows, model.key_bias_log2),
                        "last_block_pruning": ("last block: queries / MLP / out-projection for the %d noise tokens only (the prediction of the condition tail is never read: "
                                               "flux_piplines/texturing/pipeline.py:645,660,684; UTX_PRUNE_LAST=0 disables)" % n_noise) if prune else None,
@@ -627,14 +674,31 @@ def main():
             except Exception as e:  # noqa: BLE001 -- the GPU number must still be reported
                 out["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": ncpu, "kind": "port",
                                        "sample": "failed: %r" % (e,)}
-        if world == 1 and not args.sp_self_test and not args.fp8 and not args.fp8_attn and os.environ.get("UTX_BENCH_EXPERIMENTS", "1") != "0":
-            torch.cuda.synchronize()      # nothing of this process is in flight any more
-            out["config"]["experiments"] = attention_variant_experiment()
+        if world == 1 and not args.sp_self_test and not args.fp8_attn and os.environ.get("UTX_BENCH_EXPERIMENTS", "1") != "0":
+            try:
+                ab = attention_loop_ab(dev, S_exec, HEADS)
+                out["config"]["experiments"] = {"attention_fast_loop_vs_general_loop": ab}
+                out["config"]["experiments_summary"] = "attn fast loop (default) vs general loop @%d tok: bit_id=%d %.3f vs %.3f ms = %.3fx (%.0f vs %.0f TF/s)" % (
+                    ab["tokens"], int(ab["bit_identical"]), ab["fast_loop_ms"], ab["general_loop_ms"], ab["general_loop_ms"] / ab["fast_loop_ms"], ab["fast_loop_tflops"], ab["general_loop_tflops"])
+            except Exception as e:  # noqa: BLE001 -- a reporting extra
+                out["config"]["experiments_summary"] = "failed: %r" % (e,)
+        if world == 1 and not args.sp_self_test and args.workload != "ref512x6" and os.environ.get("UTX_BENCH_REF_POINT", "1") != "0":
+            # the reference's own operating point (512^2 x 6 views, S = 13 824) on the same model, a few steps behind everything else: a flat scalar the driver's record keeps
+            try:
+                out["config"]["ref512x6_ms_per_step"] = ref_point_ms(model, ops, sched, calculate_shift, shape, dev, prune)
+            except Exception as e:  # noqa: BLE001 -- a reporting extra
+                out["config"]["ref512x6_ms_per_step"] = "error: %r" % (e,)
+        # flat scalars (the driver's record drops nested objects of `config`)
+        out["config"]["attn_tflops"] = out["roofline"]["achieved"]
+        out["config"]["attn_frac"] = out["roofline"]["frac"]
+        if "roofline_gemm" in out:
+            out["config"]["gemm_frac"] = out["roofline_gemm"]["frac"]
+            out["config"]["gemm_tflops"] = out["roofline_gemm"]["achieved"]
+        if bp is not None and "error" not in bp:
+            out["config"]["backprojection_total_ms"] = bp["total_ms"]
+            out["config"]["backprojection_kernel_sum_ms"] = bp.get("kernel_sum_ms")
         print(json.dumps(out))
         sys.stdout.flush()
-        if "error" in out["config"].get("experiments", {}).get("attn_peel", {}):
-            # the child failed (an unvalidated kernel may have faulted the device): the line is out, skip this process's device teardown
-            os._exit(0)
     if world > 1 or args.sp_self_test:
         import torch.distributed as dist
         dist.destroy_process_group()

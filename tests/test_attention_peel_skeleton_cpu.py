@@ -1,15 +1,16 @@
-"""The control flow of the opt-in attention loops (attention_glds.hip, VAR 12 ... 17: UTX_ATTN_PEEL = 1 ... 6) against the general loop, on the CPU.
+"""The control flow of the attention kernels' fast loops (attention_glds.hip FAST, the default of the pre-scaled launch since round 5; attention_fp8.hip VAR 1) against
+their general loops, on the CPU.
 
-These variants run the SAME tile arithmetic (macros) -- what was written by hand is WHICH tile goes through which copy, into which ring slot the next tile is
-requested and when, where the barrier sits, and (VAR 16) which ring slot the next tile's first K fragments are read from.  This test lifts exactly those source lines
-out of the kernel (from the `if` that selects the peeled loops to the end of the general loop), compiles them with g++ around stubs that record the events, and
+The fast loop runs the SAME tile arithmetic (macros) -- what was written by hand is WHICH tile goes through which copy, into which ring slot the next tile is
+requested and when, where the barrier sits, and which ring slot the next tile's first K fragments are read from.  This test lifts exactly those source lines
+out of the kernel (from the `if` that selects the fast loop to the end of the general loop), compiles them with g++ around stubs that record the events, and
 checks for every tile count and raggedness
-  * that every loop processes tiles 0 .. nt - 1 once each, in order, with the general body exactly on the first tile and on a ragged last tile (and the general loop
-    itself whenever key-multiplicity tiles recur), VAR 12 ... 15 event for event like the general loop;
+  * that both loops process tiles 0 .. nt - 1 once each, in order, with the general body exactly on the first tile and on a ragged last tile (and the general loop
+    itself whenever key-multiplicity tiles recur);
   * the ring discipline of a workgroup whose waves are only ordered by its barriers: a slot is read only when the tile expected there was requested into it and a
     barrier (which carries the vmcnt(0) that retires the DMA) lies between request and read; a slot is requested into only when a barrier lies between the last read
     of its old content and the request, and that content has been consumed;
-  * (VAR 16) that the K fragments a fast tile computes on were read from that tile's slot."""
+  * that the K fragments a fast tile computes on were read from that tile's slot."""
 import os
 import subprocess
 
@@ -27,12 +28,12 @@ typedef std::vector<std::tuple<int, int, int, int>> Ev;
 //        reads the rest of K and V of its slot | 4 fast B: prefetch K fragments of (tile, slot) | 5 prefetch K fragments from (slot) in front of the loop
 #define AG_KVB 64
 #define AG_STAGE(t_, slot_) ev.push_back({0, (int)(t_), (int)(slot_), 0})
-#define AG_TILE_BODY(SP_) { ev.push_back({1, t, gs + sub, (SP_)}); }
+#define AG_TILE_BODY { ev.push_back({1, t, gs + sub, 1}); }
 #define __syncthreads() ev.push_back({2, 0, 0, 0})
 #define AG_FAST_A ev.push_back({3, u, gs, 0});
 #define AG_FAST_B(PF_) ev.push_back({4, u + 1, gs ^ 1, (PF_)});
 #define AG_LOAD_KFA(slot_) ev.push_back({5, -1, (int)(slot_), 0});
-template <int VAR, int TPB>
+template <bool FAST, int TPB>
 static Ev run(int Sk, P p) {
     Ev ev;
     const int nt = (Sk + AG_KVB - 1) / AG_KVB;
@@ -83,20 +84,15 @@ int main() {
     for (int Sk = 1; Sk <= 64 * 9; Sk += (Sk %% 64 == 0 ? 1 : 21)) {
         P p = {per ? 3.0f : (Sk %% 2 ? 0.0f : 3.0f), per ? 4 : 0};
         const bool general_everywhere = per && p.key_bias_log2 != 0.f;
-        Ev g = run<0, 1>(Sk, p);
+        Ev g = run<false, 1>(Sk, p);
         discipline(g, Sk, 0, true);
-        Ev vs[6] = {run<12, 1>(Sk, p), run<13, 1>(Sk, p), run<14, 1>(Sk, p), run<15, 1>(Sk, p), run<16, 1>(Sk, p), run<17, 1>(Sk, p)};
-        for (int vi = 0; vi < 6; ++vi) {
-            ++checked;
-            discipline(vs[vi], Sk, 12 + vi, general_everywhere);
-            if (vi >= 4 && !general_everywhere) continue;      // VAR 16 / 17 have their own event order; the discipline above is its check
-            const Ev& v = vs[vi];
-            if (v.size() != g.size()) { FAIL("var %%d Sk %%d per %%d: %%zu vs %%zu events", 12 + vi, Sk, per, v.size(), g.size()); continue; }
-            for (size_t i = 0; i < g.size(); ++i) {
-                auto [k0, t0, s0, sp0] = g[i];
-                auto [k1, t1, s1, sp1] = v[i];
-                if (!(k0 == k1 && t0 == t1 && s0 == s1)) { FAIL("var %%d Sk %%d per %%d event %%zu: (%%d %%d %%d) vs (%%d %%d %%d)", 12 + vi, Sk, per, i, k0, t0, s0, k1, t1, s1); break; }
-            }
+        Ev v = run<true, 1>(Sk, p);
+        ++checked;
+        discipline(v, Sk, 1, general_everywhere);
+        if (general_everywhere) {      // the fast kernel falls back to the general loop: event for event the same
+            if (v.size() != g.size()) { FAIL("Sk %%d per %%d: %%zu vs %%zu events", Sk, per, v.size(), g.size()); continue; }
+            for (size_t i = 0; i < g.size(); ++i)
+                if (g[i] != v[i]) { FAIL("Sk %%d per %%d event %%zu differs", Sk, per, i); break; }
         }
     }
     printf("checked %%d bad %%d\n", checked, bad);
@@ -107,11 +103,11 @@ int main() {
 
 def _loop_source():
     lines = open(SRC).read().split("\n")
-    start = next(i for i, l in enumerate(lines) if l.lstrip().startswith("if ((VAR >= 12 && VAR <= 15) && TPB == 1"))
+    start = next(i for i, l in enumerate(lines) if l.lstrip().startswith("if (FAST && TPB == 1 && !(p.key_bias_period > 0"))
     end = next(i for i, l in enumerate(lines) if "this group fully read by every wave" in l)
     assert 0 < start < end and lines[end + 1].strip() == "}", "the loop block of attention_glds.hip moved: update this test's markers"
     block = [l for l in lines[start:end + 2] if not l.lstrip().startswith("#pragma")]
-    assert any("VAR == 16 || VAR == 17" in l for l in block)
+    assert any("AG_FAST_A" in l for l in block) and any("AG_FAST_B(1)" in l for l in block)
     return "\n".join(block)
 
 
@@ -124,7 +120,7 @@ def _run(tmp_path, code, name="skeleton"):
     return subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
 
 
-def test_opt_in_attention_loops_keep_the_tile_order_and_the_ring_discipline(tmp_path):
+def test_fast_attention_loop_keeps_the_tile_order_and_the_ring_discipline(tmp_path):
     r = _run(tmp_path, _loop_source())
     assert r.returncode == 0 and "bad 0" in r.stdout and "checked 0" not in r.stdout, r.stdout[-3000:]
 
@@ -133,8 +129,8 @@ def test_the_skeleton_check_sees_a_broken_loop(tmp_path):
     """mutations of the lifted source that each describe a real bug (wrong slot, request in front of the barrier, prefetch from the slot being overwritten, a ragged
     last tile on the fast path, a dropped barrier) must all be reported"""
     src = _loop_source()
-    mutations = [("AG_STAGE(u + 1, gs ^ 1)", "AG_STAGE(u + 1, gs)"),
-                 ("const int fast_end_ = rag_ ? nt - 1 : nt;                 // tiles [1, fast_end_) take the fast body", "const int fast_end_ = nt;"),
+    mutations = [("const int fast_end_ = rag_ ? nt - 1 : nt;                 // tiles [1, fast_end_) take the fast form", "const int fast_end_ = nt;"),
+                 ("            if (1 < nt) AG_STAGE(1, 1);\n", "            if (1 < nt) AG_STAGE(1, 0);\n"),
                  ("            if (u + 2 < nt) AG_STAGE(u + 2, gs);\n", "            if (u + 2 < nt) AG_STAGE(u + 2, gs ^ 1);\n"),
                  ("            AG_FAST_A\n            __syncthreads();", "            AG_FAST_A"),
                  ("        if (2 < nt) AG_STAGE(2, 0);", "        if (2 < nt) AG_STAGE(2, 1);"),
@@ -199,7 +195,7 @@ def test_peeled_fp8_attention_loop_takes_every_tile_once_through_the_right_body(
     # the fast body's request / fence lines are the general body's, character for character
     text = open(FP8_SRC).read()
     gen = text[text.index("#define A8_TILE_BODY(SP_)"):text.index("#define A8_EXPQ")]
-    fast = text[text.index("#define A8_FAST_BODY"):text.index("// VAR 1 (opt-in: UTX_ATTN8_PEEL=1")]
+    fast = text[text.index("#define A8_FAST_BODY"):text.index("// VAR 1 (the default since round 5")]
     norm = lambda s: " ".join(s.replace("\\", " ").split())
     for must in ("A8_STAGE(t + 1, slot ^ 1);", "ksc0n = ksb[kr]; ksc1n = ksb[kr + 32];", "vscn = vsb[(long)(2 * (t + 1) + lh) * 32 + lq];", "const int slot = t & 1;",
                  'asm volatile("" : "+v"(ksc0n), "+v"(ksc1n), "+v"(vscn));', "ksc0 = (int)(ksc0n >> (8 * lh)); ksc1 = (int)(ksc1n >> (8 * lh)); vsc = (int)vscn;", "__syncthreads();",

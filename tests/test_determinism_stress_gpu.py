@@ -205,3 +205,36 @@ def test_two_stream_fp8_pruned_plan_600_back_to_back_forwards():
         if not torch.equal(o.view(torch.int16), ref.view(torch.int16)):
             bad.append(i)
     assert not bad, "%d of 600 two-stream forwards differ from the first (first at %s)" % (len(bad), bad[:5])
+
+
+def test_fast_attention_loop_320_launches_against_the_general_loops_bits():
+    """Round 5: the attention kernel's default loop moved the tile's ONE barrier (between S2 and S3), requests tile t + 2 behind it and reads the next tile's first K
+    fragments under S3 -- a change of the class that produced round 3's one-off.  A race there would show as a RARE mismatch, so: 320 launches (two shapes: ragged
+    last tile + key-split tail round + key multiplicity; whole tiles, pruned queries) under the perturbing side stream / cache evictions, every one against the
+    bits of the general loop (UTX_ATTN_PEEL=0: one barrier at the end of each tile, the default until round 4)."""
+    from unitex_amd import _lib
+    from unitex_amd.flux import ops
+    noise = _Perturb()
+    for H, S, S_q, kb, reps in ((24, 3000, None, 3.0, 200), (24, 4096, 2816, 0.0, 120)):
+        g = torch.Generator(device="cuda").manual_seed(S)
+        S_pad = (S + 63) // 64 * 64
+        Qh = (torch.randn(H, S_pad, 128, generator=g, device="cuda") * (1.4426950408889634 / math.sqrt(128.0))).to(BF)
+        Kh = torch.randn(H, S_pad, 128, generator=g, device="cuda").to(BF)
+        Kh[:, S // 2] *= 3.0           # a late outlier key: some waves take the exact re-centring path inside the loop
+        Vt = torch.randn(H, 128, S_pad, generator=g, device="cuda").to(BF)
+        try:
+            _lib.set_option("UTX_ATTN_PEEL", 0)
+            ref = ops.attention(Qh, Kh, Vt, S=S, scale=0.0, key_bias_log2=kb, S_q=S_q).clone()
+            torch.cuda.synchronize()
+        finally:
+            _lib.set_option("UTX_ATTN_PEEL", 1)
+        out = torch.empty_like(ref)
+        bad = []
+        for i in range(reps):
+            noise(i)
+            out.zero_()
+            ops.attention(Qh, Kh, Vt, S=S, scale=0.0, key_bias_log2=kb, S_q=S_q, out=out)
+            if not torch.equal(out.view(torch.int16), ref.view(torch.int16)):
+                bad.append((i, int((out.view(torch.int16) != ref.view(torch.int16)).sum())))
+        assert not bad, "S = %d: %d of %d launches of the fast loop differ from the general loop: %s" % (S, len(bad), reps, bad[:5])
+    torch.cuda.synchronize()

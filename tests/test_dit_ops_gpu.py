@@ -560,7 +560,7 @@ def _sp_worker(rank, world, port, q, zero_text=False, groups=1):
         os.environ["UTX_SP_ZERO_COPY"] = "1"
         groups = -groups
     os.environ["UTX_SP_GROUPS"] = str(groups)      # head groups per rank whose exchanges are pipelined with attention (ulysses.pick_head_groups)
-    os.environ["UTX_TXT_STREAM"] = "1"             # the opt-in two-stream form of the double blocks (off by default since round 4) stays covered here
+    os.environ["UTX_TXT_STREAM"] = "1"             # the opt-in two-stream form of the double blocks (off by default since round 5) stays covered here
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import dit_ref as R
     from unitex_amd.flux.transformer import FluxDiT, FluxShape
@@ -723,7 +723,7 @@ def test_c_side_plan_replay_is_bit_identical_to_the_python_launch_list(fp8):
     img_ids = torch.cat([dit_ref.latent_image_ids(8, 24), dit_ref.latent_image_ids(8, 24, offset_y=8),
                          dit_ref.latent_image_ids(4, 4, offset_x=24, offset_y=8)], 0)
     m = FluxDiT(sd, shape, device="cuda:0", fp8_weights=fp8)
-    m.set_text_stream(True)      # the opt-in two-stream form (off by default since round 4): fork / join entries in the C plan
+    m.set_text_stream(True)      # the opt-in two-stream form (off by default since round 5): fork / join entries in the C plan
     m.set_lora([(dit_ref.make_synthetic_lora(cfg, sd, rank=16, seed=2), 1.0)])
     m.set_positions(txt_ids, img_ids)
     m.set_output_rows(192)
@@ -747,6 +747,21 @@ def test_c_side_plan_replay_is_bit_identical_to_the_python_launch_list(fp8):
     torch.cuda.synchronize()
     m.release_graph()
     assert torch.equal(c1.view(torch.int16), a1.view(torch.int16))
+    # a range of the C plan must hold WHOLE two-stream sections: a range that begins behind a fork (on either stream's half) or ends in front of its join is refused
+    # before anything of it is launched behind an unrecorded fork (round 5: a begin inside the MAIN half used to pass and its join ran unordered)
+    import ctypes as C
+    ents = _plan_entries(m.lib, cplan)
+    fork = next(i for i, (k, _, _) in enumerate(ents) if k == 7)
+    join = next(i for i, (k, _, _) in enumerate(ents) if k == 8)
+    main_inside = next(i for i in range(fork + 1, join) if ents[i][1] == 0)
+    side_inside = next(i for i in range(fork + 1, join) if ents[i][1] == 1)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    bad = C.c_int(-1)
+    for b0 in (main_inside, side_inside, join):
+        assert m.lib.utx_plan_run_range(cplan, b0, len(ents), st, C.byref(bad)) == -2 and bad.value == b0
+    assert m.lib.utx_plan_run_range(cplan, 0, main_inside, st, C.byref(bad)) == -2      # ends inside the section (what was forked is joined before returning)
+    assert m.lib.utx_plan_run_range(cplan, fork, join + 1, st, C.byref(bad)) == 0
+    torch.cuda.synchronize()
 
 
 def _plan_entries(lib, h):

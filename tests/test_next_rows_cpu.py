@@ -475,76 +475,3 @@ def test_projection_frames_bound_the_stretch():
         assert worst <= bound, (n, worst)
     assert 1.0 / (p @ meshes.projection_frames(26)[0].T).max(1).min() - 1.0 <= 1.0 / 6.0
 
-
-def test_attention_variant_ab_tool_runs_its_whole_script_against_stubs(monkeypatch, capsys):
-    """tools/attn_peel_ab.py (what bench.py runs in a child process for `config.experiments`) has no GPU to run on here: its script logic -- option
-    switching, bit-identity flags, interleaved timing, the JSON it hands back -- runs once against stubs of the library and of the device API, so that a
-    slip of the pen in it cannot be what the first hardware run finds."""
-    import importlib.util
-    import json
-    import sys
-    import types
-    import torch
-    calls = {"opt": [], "attn": 0}
-    fake_lib = types.SimpleNamespace(set_option=lambda n, v: calls["opt"].append((n, v)))
-    state = {"peel": 0}
-
-    def set_option(n, v):
-        calls["opt"].append((n, v))
-        state["peel"] = v
-    fake_lib.set_option = set_option
-
-    def attention(q, k, vt, S=None, scale=None, out=None, key_bias_log2=0.0, **kw):
-        calls["attn"] += 1
-        assert scale == 0.0 and key_bias_log2 == 3.0 and out.shape == (S, q.shape[0] * 128)
-        out.fill_(1.0 if state["peel"] != 2 else 2.0)       # variant 2 "differs" from the default
-        return out
-    def attention_fp8(q8, qs, k8, ks, v8, vs, S=None, out=None, key_bias_log2=0.0, **kw):
-        calls["attn8"] = calls.get("attn8", 0) + 1
-        assert key_bias_log2 == 3.0 and out.shape == (S, q8.shape[0] * 128)
-        out.fill_(3.0)
-        return out
-    fake_ops = types.SimpleNamespace(attention=attention, attention_fp8=attention_fp8,
-                                     quant_qk_mx8=lambda x: (x, x[..., :4]), quant_vt_mx8=lambda x: (x, x[:, :, :4]))
-    pkg = types.ModuleType("unitex_amd")
-    pkg._lib = fake_lib
-    flux = types.ModuleType("unitex_amd.flux")
-    flux.ops = fake_ops
-    monkeypatch.setitem(sys.modules, "unitex_amd", pkg)
-    monkeypatch.setitem(sys.modules, "unitex_amd._lib", fake_lib)
-    monkeypatch.setitem(sys.modules, "unitex_amd.flux", flux)
-    monkeypatch.setitem(sys.modules, "unitex_amd.flux.ops", fake_ops)
-    monkeypatch.setenv("UTX_AB_SIZES", "128,200")
-    monkeypatch.setenv("UTX_AB_HEADS", "2")
-    monkeypatch.setenv("UTX_AB_ROUNDS", "2")
-    monkeypatch.setenv("UTX_AB_REPEATS", "3")
-    real_gen, real_randn, real_empty = torch.Generator, torch.randn, torch.empty
-    monkeypatch.setattr(torch, "Generator", lambda device=None: real_gen())
-    monkeypatch.setattr(torch, "randn", lambda *a, device=None, **k: real_randn(*a, **k))
-    monkeypatch.setattr(torch, "empty", lambda *a, device=None, **k: real_empty(*a, **k))
-    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
-
-    class Ev:
-        def __init__(self, enable_timing=False):
-            pass
-
-        def record(self):
-            pass
-
-        def elapsed_time(self, other):
-            return 3.0
-    monkeypatch.setattr(torch.cuda, "Event", Ev)
-    monkeypatch.setattr(sys, "argv", ["attn_peel_ab.py", "--json"])
-    spec = importlib.util.spec_from_file_location("attn_peel_ab", os.path.join(os.path.dirname(HERE), "tools", "attn_peel_ab.py"))
-    tool = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(tool)
-    tool.main()
-    last = [l for l in capsys.readouterr().out.splitlines() if l.startswith("{")][-1]
-    res = json.loads(last)
-    assert set(res) == {"128", "200", "fp8_128", "fp8_200"} and res["fp8_200"]["1"]["bit_identical_to_default"] is True and res["fp8_128"]["0"]["tflops"] > 0 and set(res["128"]) == {"0", "1", "2", "3", "4", "5", "6"}
-    assert res["200"]["1"]["bit_identical_to_default"] is True and res["200"]["2"]["bit_identical_to_default"] is False and res["200"]["3"]["bit_identical_to_default"] is True
-    assert abs(res["128"]["0"]["med_ms"] - 1.0) < 1e-9 and res["128"]["3"]["tflops"] > 0
-    assert calls["opt"][-1] == ("UTX_ATTN8_PEEL", 0) and ("UTX_ATTN_PEEL", 0) in calls["opt"], "the tool leaves the options as it found them"
-    assert calls["attn8"] == 2 * (1 + 4 + 2 * 2 * 4)
-    assert calls["attn"] == 2 * (7 + 6 * 3 + 2 * 7 * 4)
-    assert res["200"]["2"]["mismatches_in_repeats"] == 3 and res["200"]["5"]["mismatches_in_repeats"] == 0 and res["200"]["5"]["repeats"] == 3

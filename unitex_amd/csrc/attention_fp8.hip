@@ -43,6 +43,12 @@ __device__ __forceinline__ a8_i32x8 a8_frag(const char* plo, const char* phi) {
     return a8_i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
+// l * alpha as a multiply of its own: hipcc contracts `l_run *= alpha; ...; l_run += ps` into v_fmac_f32 in tail-duplicated copies of the re-centring path only
+__device__ __forceinline__ float a8_mul_nofuse(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+
 template <int VAR>
 __global__ __launch_bounds__(512, 2) void attn_fwd_fp8_kernel(Attn8Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -212,7 +218,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_fp8_kernel(Attn8Params p) {
             const float d = ((SP_) && t == 0) ? mx : fmaxf(mx, 0.f);                                                   \
             const float alpha = ((SP_) && t == 0) ? 1.0f : __builtin_amdgcn_exp2f(-d);                                 \
             m_run += d;                                                                                                \
-            l_run *= alpha;                                                                                            \
+            l_run = a8_mul_nofuse(l_run, alpha);   /* never contracted with the `l_run += ...` behind the branch (attention_glds.hip, ag_mul_nofuse) */ \
         _Pragma("unroll")                                                                                              \
             for (int r = 0; r < 16; ++r) { negm[r] = -m_run; sa0[r] -= d; sa1[r] -= d; }                               \
         _Pragma("unroll")                                                                                              \
@@ -296,7 +302,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_fp8_kernel(Attn8Params p) {
             const float d = fmaxf(mx, 0.f);                                                              \
             const float alpha = __builtin_amdgcn_exp2f(-d);                                              \
             m_run += d;                                                                                  \
-            l_run *= alpha;                                                                              \
+            l_run = a8_mul_nofuse(l_run, alpha);                                                         \
             _Pragma("unroll")                                                                            \
             for (int r = 0; r < 16; ++r) { negm[r] = -m_run; sa0[r] -= d; sa1[r] -= d; }                 \
             _Pragma("unroll")                                                                            \
@@ -313,7 +319,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_fp8_kernel(Attn8Params p) {
         ksc0 = (int)(ksc0n >> (8 * lh)); ksc1 = (int)(ksc1n >> (8 * lh)); vsc = (int)vscn;               \
         __syncthreads();                                                                                 \
         }
-    // VAR 1 (opt-in: UTX_ATTN8_PEEL=1; same arithmetic in the same order per element = bit-identical by construction; NOT yet run on hardware): tile 0 and a ragged last tile
+    // VAR 1 (the default since round 5; UTX_ATTN8_PEEL=0 selects the general loop for A/B; same arithmetic in the same order per element = bit-identical; measured 16.60 -> 15.92 ms
+    // at S = 50 240, 1869 -> 1948 TF/s, profiles/r05_attn_peel_ab.log): tile 0 and a ragged last tile
     // run the general body in front of / behind the loop; the loop runs A8_FAST_BODY, the general tile without its `if (t > 0)`, key-multiplicity, ragged and first-tile branches
     // and in a hand order: QK^T(t) x 4, then the exponentials in QUARTERS (A8_EXPQ: eight v_exp + their share of the sums and packs, the running sums carried across), one
     // quarter in front of each of the four PV(t - 1) MFMAs, pinned by sched_barrier.  In the default listing the eight MFMAs of a tile and its thirty-two v_exp sit in basic
@@ -422,5 +429,5 @@ extern "C" int utx_launch_attn_fwd_fp8(const Attn8Params* hp, hipStream_t stream
     if ((((uintptr_t)p.qs) | ((uintptr_t)p.ks) | ((uintptr_t)p.vs)) & 3) return -2;
     if (p.Sq == p.S) p.Sq = 0;
     p.nqb = ((p.Sq > 0 ? p.Sq : p.S) + 255) / 256;
-    return g_utx_opt.attn8_peel == 1 ? a8_launch<1>(p, stream) : a8_launch<0>(p, stream);      // UTX_ATTN8_PEEL=1: the peeled loop (VAR 1, opt-in)
+    return g_utx_opt.attn8_peel != 0 ? a8_launch<1>(p, stream) : a8_launch<0>(p, stream);      // UTX_ATTN8_PEEL=0: the general loop (the default until round 4), for A/B
 }

@@ -29,6 +29,13 @@ __device__ __forceinline__ void ag_glds16(const bf16_t* g, char* lds) {
                                      (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
 }
 
+// l * alpha as a multiply of its own: under -ffp-contract=fast hipcc turned `l_run *= alpha; ...; l_run += ps` into v_fmac_f32 in the tail-duplicated copies of the re-centring
+// path (the peeled loops) and left mul + add in the general loop -- one-ulp differences in l, 36 of 9.2 M outputs (profiles/r05_peel_diff_probe.log)
+__device__ __forceinline__ float ag_mul_nofuse(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+
 // VAR == 5 (ablation build only, WRONG results): every 32x32x16 MFMA replaced by two 16x16x32 MFMAs on the same operand registers --
 // same FLOPs and register / LDS traffic; measures what the more power-efficient instruction shape (tools/mfma_power_probe.py) would
 // buy this kernel before paying for the re-layout of the softmax.
@@ -47,7 +54,7 @@ __device__ __forceinline__ void ag_glds16(const bf16_t* g, char* lds) {
 // instead of behind a relayout pass.  Token j = block j / blk_rows, row j % blk_rows; inside a block rows are q_ss / k_ss apart and V^T rows vt_ds (= blk_rows for
 // the exchange buffer).  The staging cursor below walks tiles in order, so the block term is two scalar adds per tile; same tiles, same order, same arithmetic
 // as the contiguous form: bit-identical results.
-template <int PRESC, int TPB, int VAR, bool BLK = false>
+template <int PRESC, int TPB, int VAR, bool BLK = false, bool FAST = false>
 __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const kring = smem;
@@ -168,8 +175,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
     // halves alternate compute and load segments behind barriers; here all eight waves run the same interleaved stream and the per-tile flips
     // (prio 1 while computing, 0 at the barrier) already are the better arbitration
     if (VAR == 6 && wave >= 4) __builtin_amdgcn_s_setprio(1);
-    // The tile body as a macro over SP_: 1 = the general tile (first tile, ragged last tile, key-multiplicity tiles), 0 = a tile none of these can apply to (their
-    // branches fold away).  The default kernel expands AG_TILE_BODY(1) only: the instruction stream it always had (listing compared before / after the refactor).
+    // AG_TILE_BODY: the GENERAL tile (it may be the first tile, a ragged last tile, a key-multiplicity tile); AG_FAST_A / AG_FAST_B below: a tile that is none of these.
 #define AG_EXPB(sa_, p0_, p1_, ps_)                                                                  \
         {                                                                                            \
             f32x2 acc2_ = {0.f, 0.f};                                                                \
@@ -201,24 +207,24 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
             const float d_ = (first_) ? mx_ : fmaxf(mx_, 0.f);                                       \
             const float alpha_ = (first_) ? 1.0f : __builtin_amdgcn_exp2f(PRESC ? -d_ : -d_ * c2);   \
             m_run += d_;                                                                             \
-            l_run *= alpha_;                                                                         \
+            l_run = ag_mul_nofuse(l_run, alpha_);   /* never contracted with the `l_run += ps` behind the branch: hipcc fuses them in some copies of this block and not in others */ \
             _Pragma("unroll") for (int r = 0; r < 16; ++r) { negm[r] = -m_run; sa_[r] -= d_; }       \
             if (fix_other_) { _Pragma("unroll") for (int r = 0; r < 16; ++r) other_[r] -= d_; }      \
             _Pragma("unroll") for (int i = 0; i < 4; ++i)                                            \
                 _Pragma("unroll") for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha_;                 \
         }
-#define AG_TILE_BODY(SP_)                                                                            \
+#define AG_TILE_BODY                                                                            \
         {                                                                                            \
         const char* kb = kring + (gs + sub) * AG_KTILE;                                              \
         const char* vb = vring + (gs + sub) * AG_VTILE;                                              \
-        const bool ragged = (SP_) && (t == nt - 1) && (Sk & (AG_KVB - 1));                           \
+        const bool ragged = (t == nt - 1) && (Sk & (AG_KVB - 1));                                      \
         const int lim = Sk - t * AG_KVB - 8 * lh;                                                    \
         f32x16 sa0, sa1;                                                                             \
         bf16x8 kfa[8], kfb[8], vfa[8], vfb[8];                                                       \
         float ps0 = 0.f, ps1 = 0.f;                                                                  \
         /* key multiplicity: every key of this tile stands for 2^key_bias_log2 identical keys (text-token dedup) -> bias on its scores */ \
         const int tg = tb + t;   /* tile index in the whole sequence */                              \
-        const bool kbias = (SP_) && (p.key_bias_log2 != 0.f) && (p.key_bias_period > 0 ? (tg % p.key_bias_period == 0) : (tg == 0)); \
+        const bool kbias = (p.key_bias_log2 != 0.f) && (p.key_bias_period > 0 ? (tg % p.key_bias_period == 0) : (tg == 0)); \
         const float kbv = PRESC ? p.key_bias_log2 : p.key_bias_log2 / c2;                            \
         /* S0: QK(0); block-1 K fragments stream in behind the MFMAs */                              \
         _Pragma("unroll")                                                                            \
@@ -229,7 +235,6 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
             if (VAR == 3) kfb[kk] = kfa[kk];   /* ablation: half of the K fragment reads removed (wrong results) */ \
             else kfb[kk] = *reinterpret_cast<const bf16x8*>(kb + 8192 + kx[kk]);                     \
             if (kk == 0) { AG_MM(sa0, kfa[kk], qf[kk], negm) } else { AG_MM(sa0, kfa[kk], qf[kk], sa0) } \
-            if (VAR == 15 && !(SP_)) __builtin_amdgcn_sched_barrier(0);                              \
         }                                                                                            \
         __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                                           \
         _Pragma("unroll")                                                                            \
@@ -238,7 +243,6 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                       \
         }                                                                                            \
         /* S1: QK(1) || exp(0); V fragments of block 0 (key chunks s = 0, 1) stream in */            \
-        if ((VAR == 14 || VAR == 15) && !(SP_)) __builtin_amdgcn_sched_barrier(0);                                  \
         _Pragma("unroll")                                                                            \
         for (int kk = 0; kk < 8; ++kk) {                                                             \
             vfa[kk] = *reinterpret_cast<const bf16x8*>(vb + (kk & 3) * 4096 + vx[kk >> 2]);          \
@@ -250,13 +254,13 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
         }                                                                                            \
         AG_EXPB(sa0, pb[0], pb[1], ps0)                                                              \
         _Pragma("unroll")                                                                            \
-        for (int i_ = 0; i_ < ((VAR == 2 || VAR == 13) ? 0 : 8); ++i_) {                                            \
+        for (int i_ = 0; i_ < (VAR == 2 ? 0 : 8); ++i_) {                                            \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);                                       \
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);                                       \
             __builtin_amdgcn_sched_group_barrier(0x402, 4, 1);                                       \
         }                                                                                            \
-        if (((SP_) && t == 0 && VAR != 10) || ragged || !__all(ps0 <= 8192.0f)) {      /* VAR 10 (ablation build, WRONG results): no first-tile max pass -- what the prologue's slow path costs */ \
-            AG_SLOW(sa0, sa1, true, 0, 0, (SP_) && t == 0)                                           \
+        if ((t == 0 && VAR != 10) || ragged || !__all(ps0 <= 8192.0f)) {      /* VAR 10 (ablation build, WRONG results): no first-tile max pass -- what the prologue's slow path costs */ \
+            AG_SLOW(sa0, sa1, true, 0, 0, t == 0)                                           \
             AG_EXPB(sa0, pb[0], pb[1], ps0)                                                          \
         }                                                                                            \
         l_run += ps0;                                                                                \
@@ -273,7 +277,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
         }                                                                                            \
         AG_EXPB(sa1, pb[2], pb[3], ps1)                                                              \
         _Pragma("unroll")                                                                            \
-        for (int i_ = 0; i_ < ((VAR == 2 || VAR == 13) ? 0 : 8); ++i_) {                                            \
+        for (int i_ = 0; i_ < (VAR == 2 ? 0 : 8); ++i_) {                                            \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 2);                                       \
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 2);                                       \
             __builtin_amdgcn_sched_group_barrier(0x402, 4, 2);                                       \
@@ -289,11 +293,17 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
             AG_MM(oacc[i & 3], vfb[i], pb[2 + (i >> 2)], oacc[i & 3])                                \
         if (VAR != 1 && VAR != 6) __builtin_amdgcn_s_setprio(0);                                     \
         }
-    // VAR 16 / 17 (opt-in: UTX_ATTN_PEEL=5 / 6, 17 = 16 without the S1 / S2 interleave hints; same arithmetic in the same order per element; NOT yet run on hardware): the fast tile cut in two around the tile's ONE barrier, which moves
-    // from the end of the tile to between S2 and S3.  S3 (PV of block 1) reads nothing from LDS -- its V fragments came in during S2 -- so behind that barrier (a) the ring slot of
-    // tile t is free and takes the DMA of tile t + 2, and (b) tile t + 1, requested a whole tile earlier, has landed and is visible: its first eight K fragments are read UNDER the
-    // S3 MFMAs into registers that live across the back edge.  The next tile then starts on its MFMAs at once, where the default kernel has all eight waves issue sixteen
-    // ds_read_b128 right behind the barrier and wait for them with the matrix pipe idle.
+    // FAST (the default of the pre-scaled contiguous launch since round 5; UTX_ATTN_PEEL=0 selects the general loop for A/B): tile 0 and a ragged last tile run the general
+    // body in front of / behind a loop whose tiles can be neither first, ragged nor key-multiplicity tiles.  In the general body `if (kbias)` and the first-tile test cut S1 / S2
+    // into several basic blocks and hipcc puts the MFMAs into one block and the exponentials into the next: within a wave matrix and VALU work never overlap.  The fast tile is
+    // branch-free up to the sum checks, and it is cut in two around the tile's ONE barrier, which moves from the end of the tile to between S2 and S3: S3 (PV of block 1) reads
+    // nothing from LDS -- its V fragments came in during S2 -- so behind that barrier (a) the ring slot of tile t is free and takes the DMA of tile t + 2, and (b) tile t + 1,
+    // requested a whole tile earlier, has landed and is visible: its first eight K fragments are read UNDER the S3 MFMAs into registers that live across the back edge, and the
+    // next tile opens with an MFMA where the general loop has all eight waves issue sixteen ds_read_b128 behind the barrier with the matrix pipe idle.  Same arithmetic in the
+    // same order per element as the general loop: bit-identical (tests/test_attention_peel_gpu.py).  Measured (profiles/r05_attn_peel_ab.log, same process, interleaved): 25.86 ->
+    // 23.96 ms at S = 50 240 (1199 -> 1294 TF/s), 1.851 -> 1.756 ms at 13 376.  The S1 / S2 sched_group_barrier hints are NOT used here: with them 23.99 ms (no gain), and on the
+    // peeled loop with the barrier at the end they LOSE (25.27 vs 24.41 ms): they place exponentials between the QK^T(1) MFMAs, which chain on one accumulator.  Launches whose
+    // key-multiplicity tiles recur (key_bias_period > 0: sequence parallelism) keep the general loop.
 #define AG_LOAD_KFA(slot_)                                                                           \
         { _Pragma("unroll") for (int kk = 0; kk < 8; ++kk) kfa_n[kk] = *reinterpret_cast<const bf16x8*>(kring + (slot_) * AG_KTILE + kx[kk]); }
 #define AG_FAST_A                                                                                    \
@@ -321,12 +331,6 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
             if (kk == 0) { AG_MM(sa1, kfb[kk], qf[kk], negm) } else { AG_MM(sa1, kfb[kk], qf[kk], sa1) } \
         }                                                                                            \
         AG_EXPB(sa0, pb[0], pb[1], ps0)                                                              \
-        _Pragma("unroll")                                                                            \
-        for (int i_ = 0; i_ < (VAR == 17 ? 0 : 8); ++i_) {                                                             \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);                                       \
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);                                       \
-            __builtin_amdgcn_sched_group_barrier(0x402, 4, 1);                                       \
-        }                                                                                            \
         if (!__all(ps0 <= 8192.0f)) {                                                                \
             AG_SLOW(sa0, sa1, true, 0, 0, false)                                                     \
             AG_EXPB(sa0, pb[0], pb[1], ps0)                                                          \
@@ -339,12 +343,6 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
             AG_MM(oacc[i & 3], vfa[i], pb[i >> 2], oacc[i & 3])                                      \
         }                                                                                            \
         AG_EXPB(sa1, pb[2], pb[3], ps1)                                                              \
-        _Pragma("unroll")                                                                            \
-        for (int i_ = 0; i_ < (VAR == 17 ? 0 : 8); ++i_) {                                                             \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 2);                                       \
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 2);                                       \
-            __builtin_amdgcn_sched_group_barrier(0x402, 4, 2);                                       \
-        }                                                                                            \
         if (!__all(ps1 <= 8192.0f)) {                                                                \
             AG_SLOW(sa1, sa0, false, 8192, 32, false)                                                \
             AG_EXPB(sa1, pb[2], pb[3], ps1)                                                          \
@@ -362,42 +360,14 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
         }                                                                                            \
         __builtin_amdgcn_s_setprio(0);                                                               \
         }
-    // VAR 12 / 13 / 14 / 15 (opt-in: UTX_ATTN_PEEL=1 / 2 / 3 / 4; 13 = without the S1 / S2 interleave hints, 14 = 12 + a hard scheduling boundary between S0 and S1, so that S1's
-    // hint pipeline sees the QK^T(1) MFMAs only and hipcc does not hoist them into S0, 15 = 14 + a boundary behind every {K fragment read, QK^T(0) MFMA} pair of S0, so that the
-    // second block's fragment reads stream in behind the MFMAs instead of all sixteen reads standing in front of the first one; same arithmetic in the same order per element = bit-identical by construction; NOT yet run on hardware): the first tile and a
-    // ragged last tile run the general body in FRONT of / BEHIND the loop, the loop itself a copy without their branches.  In the general body `if (kbias)` and the
-    // first-tile test cut S1 / S2 into several basic blocks: hipcc then puts the QK^T / PV MFMAs into one block and the exponentials into the next (visible in the
-    // listing of the default kernel), so within a wave matrix and VALU work never overlap and the sched_group_barrier interleave -- which works inside ONE block --
-    // cannot bind.  (Peeling with an if / else INSIDE the loop made hipcc spill: 256 VGPRs + 216 B of scratch.)  Launches whose key-multiplicity tiles recur
-    // (key_bias_period > 0: sequence parallelism) keep the general loop.
-    if ((VAR >= 12 && VAR <= 15) && TPB == 1 && !(p.key_bias_period > 0 && p.key_bias_log2 != 0.f)) {
-        const bool rag_ = (Sk & (AG_KVB - 1)) != 0;
-        const int fast_end_ = rag_ ? nt - 1 : nt;                 // tiles [1, fast_end_) take the fast body
-        {
-            const int gs = 0, sub = 0, t = 0;
-            if (1 < nt) AG_STAGE(1, 1);
-            AG_TILE_BODY(1)
-            __syncthreads();
-        }
-        for (int u = 1; u < fast_end_; ++u) {
-            const int gs = u & 1, sub = 0, t = u;
-            if (u + 1 < nt) AG_STAGE(u + 1, gs ^ 1);
-            AG_TILE_BODY(0)
-            __syncthreads();
-        }
-        if (rag_ && nt > 1) {
-            const int gs = (nt - 1) & 1, sub = 0, t = nt - 1;
-            AG_TILE_BODY(1)
-            __syncthreads();
-        }
-    } else if ((VAR == 16 || VAR == 17) && TPB == 1 && !(p.key_bias_period > 0 && p.key_bias_log2 != 0.f)) {
+    if (FAST && TPB == 1 && !(p.key_bias_period > 0 && p.key_bias_log2 != 0.f)) {
         const bool rag_ = (Sk & (AG_KVB - 1)) != 0;
         const int fast_end_ = rag_ ? nt - 1 : nt;                 // tiles [1, fast_end_) take the fast form
         bf16x8 kfa_n[8], vfb_n[8];
         {
             const int gs = 0, sub = 0, t = 0;                     // tile 0: the general body, barrier at its end
             if (1 < nt) AG_STAGE(1, 1);
-            AG_TILE_BODY(1)
+            AG_TILE_BODY
             __syncthreads();
         }
         if (2 < nt) AG_STAGE(2, 0);                               // slot 0 is free behind that barrier; from here on tile u + 2 is requested behind the barrier of tile u
@@ -411,7 +381,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
         }
         if (rag_ && nt > 1) {
             const int gs = (nt - 1) & 1, sub = 0, t = nt - 1;     // its tile was requested two tiles ago and retired by the last barrier above (or by tile 0's)
-            AG_TILE_BODY(1)
+            AG_TILE_BODY
             __syncthreads();
         }
     } else
@@ -423,7 +393,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
       for (int sub = 0; sub < TPB; ++sub) {
         const int t = u * TPB + sub;
         if (t >= nt) break;
-        AG_TILE_BODY(1)
+        AG_TILE_BODY
       }
       __syncthreads();     // this group fully read by every wave; the next group (DMA) retired by the vmcnt(0) of this fence
     }
@@ -568,31 +538,31 @@ extern "C" size_t utx_attn_workspace_bytes_impl(int H, int Sq, int S, int ncu) {
     return rows * 128 * sizeof(bf16_t) + rows * sizeof(float);
 }
 
-template <int PRESC, int TPB, int VAR = 0, bool BLK = false>
+template <int PRESC, int TPB, int VAR = 0, bool BLK = false, bool FAST = false>
 static int launch_glds(AttnParams p, hipStream_t stream) {
     UTX_ONCE_PER_DEVICE(attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_glds_kernel<PRESC, TPB, VAR, BLK>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_glds_kernel<PRESC, TPB, VAR, BLK, FAST>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, AG_LDS(TPB)) != hipSuccess) return -3;
         UTX_ONCE_DONE(attr_set);
     }
     p.nqb = ((p.Sq > 0 ? p.Sq : p.S) + 255) / 256;
     p.w_base = 0; p.nsplit = 1; p.tiles_per_split = 0; p.part_o = nullptr; p.part_lse = nullptr;
     int pl[4] = {p.nqb * p.H, 0, 1, 0};
-    if (TPB == 1 && (VAR == 0 || VAR == 6 || VAR == 7 || VAR == 8 || VAR == 9 || VAR == 10 || (VAR >= 12 && VAR <= 17)) && !p.flags) utx_attn_split_plan_impl(p.H, p.Sq, p.S, utx_ncu(), pl);
+    if (TPB == 1 && (VAR == 0 || VAR == 6 || VAR == 7 || VAR == 8 || VAR == 9 || VAR == 10) && !p.flags) utx_attn_split_plan_impl(p.H, p.Sq, p.S, utx_ncu(), pl);
     const int nwg = pl[0], nfull = pl[1], ns = pl[2], tps = pl[3], r = nwg - nfull;
     // the scratch of the split is CALLER-OWNED (utx_attn_fwd_bf16_ws; the legacy entry points pass the context's own buffer, grown outside of any
     // capture): nothing is allocated here, a launch whose scratch is missing or too small runs unsplit -- same result up to one bf16 rounding of the
     // tail rows, a fraction of a round slower
     const size_t rows = (size_t)r * ns * 256;
     if (ns <= 1 || !p.work || p.work_bytes < rows * (128 * sizeof(bf16_t) + sizeof(float))) {
-        hipLaunchKernelGGL((attn_fwd_glds_kernel<PRESC, TPB, VAR, BLK>), dim3(nwg), dim3(512), AG_LDS(TPB), stream, p);
+        hipLaunchKernelGGL((attn_fwd_glds_kernel<PRESC, TPB, VAR, BLK, FAST>), dim3(nwg), dim3(512), AG_LDS(TPB), stream, p);
         return hipGetLastError() == hipSuccess ? 0 : -4;
     }
-    hipLaunchKernelGGL((attn_fwd_glds_kernel<PRESC, TPB, VAR, BLK>), dim3(nfull), dim3(512), AG_LDS(TPB), stream, p);
+    hipLaunchKernelGGL((attn_fwd_glds_kernel<PRESC, TPB, VAR, BLK, FAST>), dim3(nfull), dim3(512), AG_LDS(TPB), stream, p);
     AttnParams t = p;
     t.w_base = nfull; t.nsplit = ns; t.tiles_per_split = tps;
     t.part_o = (bf16_t*)p.work; t.part_lse = (float*)((char*)p.work + rows * 128 * sizeof(bf16_t));
-    hipLaunchKernelGGL((attn_fwd_glds_kernel<PRESC, TPB, VAR, BLK>), dim3(r * ns), dim3(512), AG_LDS(TPB), stream, t);
+    hipLaunchKernelGGL((attn_fwd_glds_kernel<PRESC, TPB, VAR, BLK, FAST>), dim3(r * ns), dim3(512), AG_LDS(TPB), stream, t);
     const long mt = (long)r * 256 * 16;
     hipLaunchKernelGGL(attn_merge_kernel, dim3((unsigned)((mt + 255) / 256)), dim3(256), 0, stream, t, r);
     return hipGetLastError() == hipSuccess ? 0 : -4;
@@ -606,13 +576,8 @@ extern "C" int utx_launch_attn_fwd_glds(const AttnParams* p, int presc, hipStrea
         return presc ? launch_glds<1, 1, 0, true>(*p, stream) : launch_glds<0, 1, 0, true>(*p, stream);
     }
     if (tpb == 2) return presc ? launch_glds<1, 2>(*p, stream) : launch_glds<0, 2>(*p, stream);
-    // UTX_ATTN_PEEL=1 (opt-in; the pre-scaled form the DiT uses): the hot loop without the first-tile / ragged / key-multiplicity branches (VAR 12 above)
-    if (g_utx_opt.attn_peel == 1 && presc) return launch_glds<1, 1, 12>(*p, stream);
-    if (g_utx_opt.attn_peel == 2 && presc) return launch_glds<1, 1, 13>(*p, stream);
-    if (g_utx_opt.attn_peel == 3 && presc) return launch_glds<1, 1, 14>(*p, stream);
-    if (g_utx_opt.attn_peel == 4 && presc) return launch_glds<1, 1, 15>(*p, stream);
-    if (g_utx_opt.attn_peel == 5 && presc) return launch_glds<1, 1, 16>(*p, stream);      // the tile's barrier between S2 and S3, next tile's first K fragments prefetched under S3      // + K fragment reads pinned 1 : 1 behind the QK^T(0) MFMAs      // + scheduling boundary between S0 and S1      // the same without the S1 / S2 interleave hints
-    if (g_utx_opt.attn_peel == 6 && presc) return launch_glds<1, 1, 17>(*p, stream);      // 5 without the S1 / S2 interleave hints: the barrier move / prefetch alone
+    // the pre-scaled form the DiT uses: the fast loop (FAST above); UTX_ATTN_PEEL=0: the general loop, the default until round 5 (A/B and the reference bits of the stress tests)
+    if (presc && g_utx_opt.attn_peel != 0) return launch_glds<1, 1, 0, false, true>(*p, stream);
 #ifdef UTX_ABLATION
     { const int var = g_utx_opt.attn_var_abl;   // timing A/B only: 1 = no s_setprio, 2 = no interleave hints, 3 = half the fragment reads (WRONG results), 4 = row sums with v_pk_add_f32
       if (var == 1 && presc) return launch_glds<1, 1, 1>(*p, stream);

@@ -12,7 +12,7 @@
 #include "kernels.h"
 #include "common.h"
 
-UtxOptions g_utx_opt = {1, 2, 0, 1, 1, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0};
+UtxOptions g_utx_opt = {1, 2, 0, 1, 1, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 1, 1};
 
 struct OptName { const char* name; int UtxOptions::*field; bool ablation; };
 static const OptName kOptions[] = {

@@ -68,10 +68,10 @@ struct UtxOptions {
     int bvh_stack_walk;   // 1: the reference's stack walk over the unpacked tree instead of the stackless packed walk (A/B; same results)
     int attn_var_abl, attn_debug_abl, gemm_debug_abl;
     int bvh_packet;       // 1 (default): back-projection rays walk the tree as wave-wide packets over 8 x 8 texel tiles (bvh_trace_packet); 0: one thread per ray (A/B; same results)
-    int attn_peel;        // opt-in, round 4, bit-identical by construction, NOT yet run on hardware: 1 = LDS-DMA attention with the first / ragged tile peeled off the hot loop so that its
-                          // S1 / S2 stages are single basic blocks (attn_fwd_glds_kernel<.., VAR = 12>, attention_glds.hip); 2 = the same without the interleave hints (VAR 13); 3 = 1 + a scheduling boundary between S0 and S1 (VAR 14); 4 = 3 + K fragment reads pinned behind the QK^T(0) MFMAs (VAR 15); 5 = the tile's barrier between S2 and S3, next tile's first K fragments read under S3 (VAR 16); 6 = 5 without the interleave hints (VAR 17)
-    int attn8_peel;       // opt-in, bit-identical by construction, NOT yet run on hardware: 1 = MX fp8 attention with tile 0 / a ragged last tile outside the loop and the loop's
-                          // exponentials in quarters under the PV MFMAs (attn_fwd_fp8_kernel<1>, attention_fp8.hip)
+    int attn_peel;        // 1 (default since round 5): the pre-scaled LDS-DMA attention launch runs its fast loop (attention_glds.hip, FAST: first / ragged tile outside the loop, the tile's
+                          // barrier between S2 and S3, next tile's first K fragments read under S3); 0: the general loop (the default until round 4).  Same bits either way.
+    int attn8_peel;       // 1 (default since round 5): MX fp8 attention with tile 0 / a ragged last tile outside the loop and the loop's exponentials in quarters under the PV MFMAs
+                          // (attn_fwd_fp8_kernel<1>, attention_fp8.hip); 0: the general loop.  Same bits either way.
 };
 extern UtxOptions g_utx_opt;
 

@@ -168,13 +168,18 @@ int utx_plan_run_range(utx_plan* p, int begin, int end, utx_stream stream_, int*
     if (!p || p->open_sections || begin < 0 || end > (int)p->entries.size() || begin > end) return -2;
     hipStream_t main_s = (hipStream_t)stream_;
     size_t section = 0;
-    for (int i = 0; i < begin; ++i) if (p->entries[i].kind == K_JOIN) ++section;
+    int open_at_begin = 0;      // FORKs in front of `begin` that have not met their JOIN: `begin` may not lie inside a section, on either stream's half
+    for (int i = 0; i < begin; ++i) {
+        if (p->entries[i].kind == K_FORK) ++open_at_begin;
+        if (p->entries[i].kind == K_JOIN) { ++section; --open_at_begin; }
+    }
+    if (open_at_begin != 0) { if (failed_entry) *failed_entry = begin; return -2; }
     bool forked = false;
     int rc = 0, bad = -1;
     for (int i = begin; i < end; ++i) {
         const Entry& e = p->entries[i];
         hipStream_t st = e.side ? p->side : main_s;
-        if (e.side && !forked) { rc = -2; bad = i; break; }      // a range that starts inside a section
+        if ((e.side || e.kind == K_JOIN) && !forked) { rc = -2; bad = i; break; }      // a side entry or a JOIN without its FORK in this call
         switch (e.kind) {
             case K_GEMM: rc = utx_launch_gemm_bf16(&e.gemm, st); break;
             case K_GEMV: rc = utx_launch_gemv_bf16(&e.gemv, st); break;

@@ -107,14 +107,17 @@ class FluxDiT:
         self.attn_events = None
         self.gemm_events = None    # bench.py: list that receives (start event, end event, FLOPs) of every large-M GEMM launched on the main stream
         # double blocks: the text-token half (M = 512: a fraction of one round of tiles) runs on a second HIP stream beside the image-token half, which fills CUs
-        # that the image GEMMs' tail rounds leave idle (-0.5 % per step at S = 50 688, -2.7 % at 13 824).  UTX_TXT_STREAM=0 keeps one stream.
+        # that the image GEMMs' tail rounds leave idle (-0.5 % per step at S = 50 688, -2.7 % at 13 824).  Opt-in since round 5 (below).
         # Round 4 found this form NOT reproducible run to run as it was built until then: with the text half's MFMA GEMMs running beside the image half's
         # utx_qkv_post, ONE q or k row of one head came out wrong in 1-1.5 % of the forwards of the full-width fp8 plan and 1 of 2000 of the bf16 plan (0 of 2000
         # on one stream).  Bisected (tools/plan_determinism_matrix.py, fp8_plan_bisect2.py, two_stream_probe.py) to the PACKED fp32 instructions hipcc emits in
         # the elementwise kernels (v_pk_mul / v_pk_add_f32: the low element in lanes 48-63 of a wave): dit_elementwise.hip is now built without them
         # (csrc/build.py) and the same plans ran 11 000 forwards without a difference (profiles/r04_two_stream_probe_nopk.log, r04_plan_determinism_soak_nopk.log);
         # tests/test_determinism_stress_gpu.py keeps a 600-forward two-stream loop in the GPU suite.  DESIGN section 9.
-        self.overlap_text = os.environ.get("UTX_TXT_STREAM", "1") != "0"      # also under sequence parallelism (the fork / join events end before "sp_start")
+        # ROUND 5: OFF BY DEFAULT (UTX_TXT_STREAM=1 / set_text_stream(True) opt in).  The packed-fp32 explanation above is not a mechanism: two standalone probes that run the failing
+        # instruction stream itself beside the library's GEMMs show 0 differences (DESIGN 9 b), so the build flag may only have moved the timing of a race that is still there;
+        # a 600-forward stress loop bounds a 1 % rate, not a 1e-4 one.  One stream costs 0.5 % of the step at S = 50 688 (2.7 % at 13 824) -- correctness before that.
+        self.overlap_text = os.environ.get("UTX_TXT_STREAM", "0") == "1"      # also under sequence parallelism (the fork / join events end before "sp_start")
         self._side = torch.cuda.Stream(device=self.device) if self.overlap_text else None
         # text-token dedup (last bullet): the reference feeds 512 all-zero text embeddings with all-zero position ids
         # (flux_piplines/texturing/pipeline.py:538-543) -- 512 IDENTICAL tokens at every layer.  When set_conditioning sees
