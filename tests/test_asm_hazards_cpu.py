@@ -111,4 +111,16 @@ def test_no_kernel_of_the_build_touches_a_register_of_a_load_in_flight(tmp_path)
             for ln, s_, l0, t0, regs in hz.check(body, kn):
                 report.append("%s %s line %d: %s  <- line %d: %s (v%s)" % (name, kn, ln, s_, l0, t0, regs))
     assert kernels >= 20
+    # scratch: the attention kernel's fast loop (two tiles per trip, 256 VGPRs) parks a few loop-invariant dwords in scratch AROUND its loop; no hot loop of the
+    # attention kernels may touch scratch itself
+    for name, path in outs:
+        if not name.startswith("attention"):
+            continue
+        in_loop = False
+        for l in open(path):
+            if "Loop Header" in l or "in Loop:" in l:
+                in_loop = True
+            elif l.startswith(".LBB") or l.startswith("_Z"):
+                in_loop = False
+            assert not (in_loop and "scratch_" in l), "%s: scratch access inside a loop: %s" % (name, l.strip())
     assert not report, "registers of in-flight asm loads are touched before their wait:\n" + "\n".join(report[:20])

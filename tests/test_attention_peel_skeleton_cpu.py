@@ -27,6 +27,7 @@ typedef std::vector<std::tuple<int, int, int, int>> Ev;
 // kinds: 0 request(tile, slot) | 1 old-style body(tile, slot, general?) reads K and V of its slot | 2 barrier | 3 fast A(tile, slot) computes on the prefetched fragments,
 //        reads the rest of K and V of its slot | 4 fast B: prefetch K fragments of (tile, slot) | 5 prefetch K fragments from (slot) in front of the loop
 #define AG_KVB 64
+constexpr int ABL = 0;      // the kernel's timing-ablation bits (ablation build only)
 #define AG_STAGE(t_, slot_) ev.push_back({0, (int)(t_), (int)(slot_), 0})
 #define AG_TILE_BODY { ev.push_back({1, t, gs + sub, 1}); }
 #define __syncthreads() ev.push_back({2, 0, 0, 0})
@@ -131,8 +132,10 @@ def test_the_skeleton_check_sees_a_broken_loop(tmp_path):
     src = _loop_source()
     mutations = [("const int fast_end_ = rag_ ? nt - 1 : nt;                 // tiles [1, fast_end_) take the fast form", "const int fast_end_ = nt;"),
                  ("            if (1 < nt) AG_STAGE(1, 1);\n", "            if (1 < nt) AG_STAGE(1, 0);\n"),
-                 ("            if (u + 2 < nt) AG_STAGE(u + 2, gs);\n", "            if (u + 2 < nt) AG_STAGE(u + 2, gs ^ 1);\n"),
-                 ("            AG_FAST_A\n            __syncthreads();", "            AG_FAST_A"),
+                 ("if (!(ABL & 4) && u + 2 < nt) AG_STAGE(u + 2, gs); ", "if (!(ABL & 4) && u + 2 < nt) AG_STAGE(u + 2, gs ^ 1);"),
+                 ("if constexpr (!(ABL & 8)) __syncthreads();", ""),
+                 ("                AG_FAST_TILE(uu + 1, 0)\n", "                AG_FAST_TILE(uu + 1, 1)\n"),
+                 ("            if (uu < fast_end_) AG_FAST_TILE(uu, 1)\n", ""),
                  ("        if (2 < nt) AG_STAGE(2, 0);", "        if (2 < nt) AG_STAGE(2, 1);"),
                  ("        if (1 < fast_end_) AG_LOAD_KFA(1)", "        if (1 < fast_end_) AG_LOAD_KFA(0)")]
     for i, (a, b) in enumerate(mutations):

@@ -94,6 +94,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
     // barrier) / key loop done / output stores retired, plus where it ran (HW_ID, XCC_ID), 8 longs per workgroup into p.work (tools/attn_timeline.py): what a
     // persistent workgroup that prefetches its next item's Q and drains its stores under the next item's first tiles could hide
     long tl0 = 0, tl1 = 0, tl2 = 0, tl3 = 0;
+    // VAR 32 + bits (ablation build only, WRONG results; the FAST loop's cost account, tools/attn_fast_ablate.py): 1 v_exp -> move, 2 no K / V fragment reads in the loop (stale
+    // registers), 4 no DMA in the loop, 8 no barrier in the loop, 32 reads issued by asm into registers nothing waits for (MFMAs on stale registers).  READ THE ARMS' WALL TIMES AS ENERGY: the chip is power-limited,
+    // an arm whose MFMA operands stop changing clocks higher (tools/attn_pmc_arms.sh gives cycles and clock per arm)
+    constexpr int ABL = VAR >= 32 ? VAR - 32 : 0;
     if constexpr (VAR == 11) tl0 = wall_clock64();
     const int q0 = qb * 256 + wave * 32;
     bf16x8 qf[8];
@@ -304,6 +308,22 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
     // 23.96 ms at S = 50 240 (1199 -> 1294 TF/s), 1.851 -> 1.756 ms at 13 376.  The S1 / S2 sched_group_barrier hints are NOT used here: with them 23.99 ms (no gain), and on the
     // peeled loop with the barrier at the end they LOSE (25.27 vs 24.41 ms): they place exponentials between the QK^T(1) MFMAs, which chain on one accumulator.  Launches whose
     // key-multiplicity tiles recur (key_bias_period > 0: sequence parallelism) keep the general loop.
+#define AG_EXPF(sa_, p0_, p1_, ps_, qi_)                                                             \
+        if constexpr (ABL & 1) {                                                                \
+            float sc0_ = 0.f, sc1_ = 0.f;                                                            \
+            _Pragma("unroll") for (int r = 0; r < 16; r += 2) {                                      \
+                float e0_ = sa_[r], e1_ = sa_[r + 1];                                                \
+                asm volatile("v_mov_b32 %0, %0" : "+v"(e0_)); asm volatile("v_mov_b32 %0, %0" : "+v"(e1_)); \
+                sc0_ += e0_; sc1_ += e1_;                                                            \
+                if (r < 8) { p0_[r] = (__bf16)e0_; p0_[r + 1] = (__bf16)e1_; }                       \
+                else { p1_[r - 8] = (__bf16)e0_; p1_[r - 7] = (__bf16)e1_; }                         \
+            }                                                                                        \
+            ps_ = (sc0_ + sc1_) * 0.f;                                                               \
+        } else AG_EXPB(sa_, p0_, p1_, ps_)
+// ABL 32: the fragment reads are ISSUED (inline asm: hipcc neither counts nor waits for them) into registers that an empty asm "consumes" where the MFMA would -- the MFMAs
+// themselves run on stale registers: the reads' issue slots and LDS traffic without their s_waitcnt lgkmcnt stalls
+#define AG_RD_DUMMY(dst_, ptr_) asm volatile("ds_read_b128 %0, %1" : "=v"(dst_) : "v"((uint32_t)(uintptr_t)(ptr_)))
+#define AG_USE_DUMMY(x_) asm volatile("" :: "v"(x_))
 #define AG_LOAD_KFA(slot_)                                                                           \
         { _Pragma("unroll") for (int kk = 0; kk < 8; ++kk) kfa_n[kk] = *reinterpret_cast<const bf16x8*>(kring + (slot_) * AG_KTILE + kx[kk]); }
 #define AG_FAST_A                                                                                    \
@@ -314,47 +334,51 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
         const int lim = 0;                                                                           \
         const float kbv = 0.f;                                                                       \
         f32x16 sa0, sa1;                                                                             \
-        bf16x8 kfb[8], vfa[8];                                                                       \
+        bf16x8 kfb[8], vfa[8], dk[8], dv[8];                                                         \
         float ps0 = 0.f, ps1 = 0.f;                                                                  \
         __builtin_amdgcn_s_setprio(1);                                                               \
         /* S0: QK(0) on the prefetched fragments; block-1 K fragments stream in behind the MFMAs */  \
         _Pragma("unroll")                                                                            \
         for (int kk = 0; kk < 8; ++kk) {                                                             \
-            kfb[kk] = *reinterpret_cast<const bf16x8*>(kb + 8192 + kx[kk]);                          \
+            if constexpr ((ABL & 32) != 0) { AG_RD_DUMMY(dk[kk], kb + 8192 + kx[kk]); kfb[kk] = kfa_n[kk]; } else \
+            if constexpr (ABL & 2) kfb[kk] = kfa_n[kk];                                              \
+            else kfb[kk] = *reinterpret_cast<const bf16x8*>(kb + 8192 + kx[kk]);                    \
             if (kk == 0) { AG_MM(sa0, kfa_n[kk], qf[kk], negm) } else { AG_MM(sa0, kfa_n[kk], qf[kk], sa0) } \
             __builtin_amdgcn_sched_barrier(0);                                                       \
         }                                                                                            \
         /* S1: QK(1) || exp(0); V fragments of block 0 stream in */                                  \
         _Pragma("unroll")                                                                            \
         for (int kk = 0; kk < 8; ++kk) {                                                             \
-            vfa[kk] = *reinterpret_cast<const bf16x8*>(vb + (kk & 3) * 4096 + vx[kk >> 2]);          \
+            if constexpr ((ABL & 32) != 0) { AG_USE_DUMMY(dk[kk]); AG_RD_DUMMY(dv[kk], vb + (kk & 3) * 4096 + vx[kk >> 2]); vfa[kk] = kfa_n[kk]; } else if constexpr (ABL & 2) vfa[kk] = kfa_n[kk]; else vfa[kk] = *reinterpret_cast<const bf16x8*>(vb + (kk & 3) * 4096 + vx[kk >> 2]); \
             if (kk == 0) { AG_MM(sa1, kfb[kk], qf[kk], negm) } else { AG_MM(sa1, kfb[kk], qf[kk], sa1) } \
         }                                                                                            \
-        AG_EXPB(sa0, pb[0], pb[1], ps0)                                                              \
+        AG_EXPF(sa0, pb[0], pb[1], ps0, 0)                                                              \
         if (!__all(ps0 <= 8192.0f)) {                                                                \
             AG_SLOW(sa0, sa1, true, 0, 0, false)                                                     \
-            AG_EXPB(sa0, pb[0], pb[1], ps0)                                                          \
+            AG_EXPF(sa0, pb[0], pb[1], ps0, 0)                                                          \
         }                                                                                            \
         l_run += ps0;                                                                                \
         /* S2: PV(0) || exp(1); V fragments of block 1 stream in (they outlive this macro: S3 sits behind the barrier) */ \
         _Pragma("unroll")                                                                            \
         for (int i = 0; i < 8; ++i) {                                                                \
-            vfb_n[i] = *reinterpret_cast<const bf16x8*>(vb + (i & 3) * 4096 + vx[2 + (i >> 2)]);     \
+            if constexpr ((ABL & 32) != 0) { AG_USE_DUMMY(dv[i]); AG_RD_DUMMY(dk[i], vb + (i & 3) * 4096 + vx[2 + (i >> 2)]); vfb_n[i] = kfa_n[i]; } else if constexpr (ABL & 2) vfb_n[i] = kfa_n[i]; else vfb_n[i] = *reinterpret_cast<const bf16x8*>(vb + (i & 3) * 4096 + vx[2 + (i >> 2)]); \
             AG_MM(oacc[i & 3], vfa[i], pb[i >> 2], oacc[i & 3])                                      \
         }                                                                                            \
-        AG_EXPB(sa1, pb[2], pb[3], ps1)                                                              \
+        AG_EXPF(sa1, pb[2], pb[3], ps1, 2)                                                              \
         if (!__all(ps1 <= 8192.0f)) {                                                                \
             AG_SLOW(sa1, sa0, false, 8192, 32, false)                                                \
-            AG_EXPB(sa1, pb[2], pb[3], ps1)                                                          \
+            AG_EXPF(sa1, pb[2], pb[3], ps1, 2)                                                          \
         }                                                                                            \
         l_run += ps1;                                                                                \
+        if constexpr ((ABL & 32) != 0) { _Pragma("unroll") for (int i = 0; i < 8; ++i) AG_USE_DUMMY(dk[i]); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } \
         }
     /* S3: PV(1); PF_ (literal): the next tile's first K fragments come in from ring slot gs ^ 1 behind the MFMAs */
 #define AG_FAST_B(PF_)                                                                               \
         {                                                                                            \
         _Pragma("unroll")                                                                            \
         for (int i = 0; i < 8; ++i) {                                                                \
-            if (PF_) kfa_n[i] = *reinterpret_cast<const bf16x8*>(kring + (gs ^ 1) * AG_KTILE + kx[i]); \
+            if constexpr ((ABL & 32) != 0) { bf16x8 d_; AG_RD_DUMMY(d_, kring + (gs ^ 1) * AG_KTILE + kx[i]); AG_USE_DUMMY(d_); } \
+            else if ((PF_) && !(ABL & 2)) kfa_n[i] = *reinterpret_cast<const bf16x8*>(kring + (gs ^ 1) * AG_KTILE + kx[i]); \
             AG_MM(oacc[i & 3], vfb_n[i], pb[2 + (i >> 2)], oacc[i & 3])                              \
             __builtin_amdgcn_sched_barrier(0);                                                       \
         }                                                                                            \
@@ -372,12 +396,24 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
         }
         if (2 < nt) AG_STAGE(2, 0);                               // slot 0 is free behind that barrier; from here on tile u + 2 is requested behind the barrier of tile u
         if (1 < fast_end_) AG_LOAD_KFA(1)
-        for (int u = 1; u < fast_end_; ++u) {
-            const int gs = u & 1;
-            AG_FAST_A
-            __syncthreads();                                      // tile u + 1 has landed (the vmcnt(0) this fence carries) and is visible; every wave is done with slot gs
-            if (u + 2 < nt) AG_STAGE(u + 2, gs);
-            AG_FAST_B(1)      // always prefetches: behind the last fast tile the fragments are not used (slot gs ^ 1 then holds the ragged last tile or old data; nothing writes it)
+#define AG_FAST_TILE(u_, gs_)                                                                        \
+        {                                                                                            \
+            const int u = (u_), gs = (gs_);                                                          \
+            AG_FAST_A                                                                                \
+            if constexpr (!(ABL & 8)) __syncthreads();            /* tile u + 1 has landed (the vmcnt(0) this fence carries) and is visible; every wave is done with slot gs */ \
+            if (!(ABL & 4) && u + 2 < nt) AG_STAGE(u + 2, gs);                                       \
+            AG_FAST_B(1)      /* always prefetches: behind the last fast tile the fragments are not used (slot gs ^ 1 then holds the ragged last tile or old data; nothing writes it) */ \
+        }
+        // two tiles per trip: the ring slots are literals, so every LDS address of the loop is a loop-invariant register + an immediate offset (the one-tile loop spent 20 v_add_u32 per
+        // tile on them): -7 % SQ cycles, +2.7 ... 3.6 % TF/s at both operating points (profiles/r05_attn_fv_ab*.log, r05_attn_pmc_arms.log).  256 VGPRs; hipcc parks nine
+        // loop-invariant dwords that only the epilogue needs in scratch AROUND the loop (40 B; nothing inside the loop touches scratch -- tests/test_asm_hazards_cpu.py checks the listing).
+        {
+            int uu = 1;
+            for (; uu + 1 < fast_end_; uu += 2) {
+                AG_FAST_TILE(uu, 1)
+                AG_FAST_TILE(uu + 1, 0)
+            }
+            if (uu < fast_end_) AG_FAST_TILE(uu, 1)
         }
         if (rag_ && nt > 1) {
             const int gs = (nt - 1) & 1, sub = 0, t = nt - 1;     // its tile was requested two tiles ago and retired by the last barrier above (or by tile 0's)
@@ -576,8 +612,6 @@ extern "C" int utx_launch_attn_fwd_glds(const AttnParams* p, int presc, hipStrea
         return presc ? launch_glds<1, 1, 0, true>(*p, stream) : launch_glds<0, 1, 0, true>(*p, stream);
     }
     if (tpb == 2) return presc ? launch_glds<1, 2>(*p, stream) : launch_glds<0, 2>(*p, stream);
-    // the pre-scaled form the DiT uses: the fast loop (FAST above); UTX_ATTN_PEEL=0: the general loop, the default until round 5 (A/B and the reference bits of the stress tests)
-    if (presc && g_utx_opt.attn_peel != 0) return launch_glds<1, 1, 0, false, true>(*p, stream);
 #ifdef UTX_ABLATION
     { const int var = g_utx_opt.attn_var_abl;   // timing A/B only: 1 = no s_setprio, 2 = no interleave hints, 3 = half the fragment reads (WRONG results), 4 = row sums with v_pk_add_f32
       if (var == 1 && presc) return launch_glds<1, 1, 1>(*p, stream);
@@ -589,8 +623,22 @@ extern "C" int utx_launch_attn_fwd_glds(const AttnParams* p, int presc, hipStrea
       if (var == 8 && presc) return launch_glds<1, 1, 8>(*p, stream);      // nontemporal output stores (correct results)
       if (var == 9 && presc) return launch_glds<1, 1, 9>(*p, stream);      // no output stores (WRONG results): the store tail's share of a workgroup's fixed cost
       if (var == 10 && presc) return launch_glds<1, 1, 10>(*p, stream);    // no first-tile max pass (WRONG results)
+      if (var >= 32 && presc) switch (var - 32) {      // the FAST loop's cost account (ABL bits above), WRONG results except 0
+          case 0: return launch_glds<1, 1, 32, false, true>(*p, stream);
+          case 1: return launch_glds<1, 1, 33, false, true>(*p, stream);
+          case 2: return launch_glds<1, 1, 34, false, true>(*p, stream);
+          case 4: return launch_glds<1, 1, 36, false, true>(*p, stream);
+          case 8: return launch_glds<1, 1, 40, false, true>(*p, stream);
+          case 14: return launch_glds<1, 1, 46, false, true>(*p, stream);
+          case 12: return launch_glds<1, 1, 44, false, true>(*p, stream);
+          case 32: return launch_glds<1, 1, 64, false, true>(*p, stream);
+
+          default: break;
+      }
       if (var == 11 && presc) return launch_glds<1, 1, 11>(*p, stream);    // per-workgroup timeline into p.work (correct results; never split)
       if (var == 7 && presc) return launch_glds<1, 1, 7>(*p, stream); }    // 16-byte epilogue stores through v_permlane32_swap (correct results)
 #endif
+    // the pre-scaled form the DiT uses: the fast loop (FAST above); UTX_ATTN_PEEL=0: the general loop, the default until round 5 (A/B and the reference bits of the stress tests)
+    if (presc && g_utx_opt.attn_peel != 0) return launch_glds<1, 1, 0, false, true>(*p, stream);
     return presc ? launch_glds<1, 1>(*p, stream) : launch_glds<0, 1>(*p, stream);
 }
