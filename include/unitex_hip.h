@@ -331,11 +331,19 @@ int utx_face_normals(utx_ctx* ctx, const float* verts, const int* faces, int F, 
 int utx_texture_shade(utx_ctx* ctx, const float* rast, const float* uv, const int* tri, const float* tex, int Ht, int Wt,
                       const float* bg3_host, long npix, void* out, utx_stream stream);
 
-/* LBVH ray-mesh intersector (raytracing/__init__.py:12-83 RayTracing / rt_aprmis APRMISRayTracing).
- * The handle owns its node arrays (hipMalloc inside build); verts/faces are borrowed and must stay
- * alive while the handle is used. */
+/* LBVH ray-mesh intersector (raytracing/__init__.py:12-83 RayTracing / rt_aprmis APRMISRayTracing; the build the
+ * reference runs per mesh: raytracing/rt_aprmis/bvhhelpers.py:20-84).  verts/faces are borrowed and must stay alive while
+ * the handle is used.
+ * utx_bvh_build: the handle owns its node arrays (ONE hipMalloc inside build, released by utx_bvh_free); the tree depth is
+ *   known on return (one stream synchronisation).
+ * utx_bvh_build_ws (what NVDiffRendererInverse.infer uses): every array lives in the caller's `work` (256-byte aligned,
+ *   >= utx_bvh_workspace_bytes(F); it must outlive the handle) -- nothing is allocated, freed or waited for on the path:
+ *   the build is enqueued and returns; the first launch that needs the tree depth (utx_bvh_trace*, utx_backproject,
+ *   utx_bvh_depth) waits for it, later ones do not.  utx_bvh_free releases the handle only. */
 typedef struct utx_bvh utx_bvh;
 int utx_bvh_build(utx_ctx* ctx, const float* verts, int V, const int* faces, int F, utx_bvh** out, utx_stream stream);
+size_t utx_bvh_workspace_bytes(int F);
+int utx_bvh_build_ws(utx_ctx* ctx, const float* verts, int V, const int* faces, int F, void* work, size_t work_bytes, utx_bvh** out, utx_stream stream);
 void utx_bvh_free(utx_bvh* bvh);
 /* device pointers to the node arrays (tests / diagnostics): info [2F-1][3], aabb [2F-1][6], sorted Morton
  * codes [F], sorted element ids [F]; returns F. */

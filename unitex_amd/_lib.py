@@ -175,6 +175,8 @@ SYMBOLS = {
     "utx_face_normals": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "utx_texture_shade": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, C.POINTER(c_float), c_long, c_void_p, c_void_p]),
     "utx_bvh_build": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, C.POINTER(c_void_p), c_void_p]),
+    "utx_bvh_workspace_bytes": (C.c_size_t, [c_int]),
+    "utx_bvh_build_ws": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, C.c_size_t, C.POINTER(c_void_p), c_void_p]),
     "utx_bvh_free": (None, [c_void_p]),
     "utx_bvh_arrays": (c_int, [c_void_p, C.POINTER(c_void_p), C.POINTER(c_void_p), C.POINTER(c_void_p), C.POINTER(c_void_p)]),
     "utx_bvh_trace": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_void_p]),

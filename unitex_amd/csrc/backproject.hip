@@ -100,10 +100,12 @@ extern "C" int utx_launch_backproject(const utx_backproject_desc* hp, const utx_
     if (!bvh || p.T_h <= 0 || p.T_w <= 0 || p.view_count <= 0) return -2;
     const long T = (long)p.T_h * p.T_w;
     dim3 grid((unsigned)((T + 255) / 256), p.view_count);
-    if (bvh->depth <= UTX_BVH_PACKED_MAX_DEPTH && !g_utx_opt.bvh_stack_walk && g_utx_opt.bvh_packet) {
+    const int depth = utx_bvh_depth_impl(const_cast<utx_bvh*>(bvh));      // first use after a build: waits for the build's depth word
+    if (depth < 0) return -7;
+    if (depth <= UTX_BVH_PACKED_MAX_DEPTH && !g_utx_opt.bvh_stack_walk && g_utx_opt.bvh_packet) {
         dim3 gridp((unsigned)(((p.T_w + 15) / 16) * ((p.T_h + 15) / 16)), p.view_count);
         hipLaunchKernelGGL(backproject_kernel<2>, gridp, dim3(256), 0, stream, p, bvh->info, bvh->aabb, bvh->nodes, bvh->tris);
-    } else if (bvh->depth <= UTX_BVH_PACKED_MAX_DEPTH && !g_utx_opt.bvh_stack_walk)
+    } else if (depth <= UTX_BVH_PACKED_MAX_DEPTH && !g_utx_opt.bvh_stack_walk)
         hipLaunchKernelGGL(backproject_kernel<1>, grid, dim3(256), 0, stream, p, bvh->info, bvh->aabb, bvh->nodes, bvh->tris);
     else
         hipLaunchKernelGGL(backproject_kernel<0>, grid, dim3(256), 0, stream, p, bvh->info, bvh->aabb, bvh->nodes, bvh->tris);

@@ -17,6 +17,8 @@
 // Compiled with -ffp-contract=off.
 #include "common.h"
 #include "kernels.h"
+#include <mutex>
+#include <vector>
 #include "bvh_device.h"
 #include <cstring>
 #include <string.h>
@@ -214,50 +216,112 @@ __global__ __launch_bounds__(256) void bvh_trace_kernel(const int* info, const f
 // ---------------------------------------------------------------------------------------------
 #define HCHK(e) do { if ((e) != hipSuccess) return -7; } while (0)
 
-extern "C" int utx_bvh_build_impl(const float* verts, int V, const int* faces, int F, utx_bvh** out, hipStream_t stream) {
+// Every device array of the tree lives in ONE block of memory: the caller's (utx_bvh_build_ws: a torch allocation, nothing allocated or freed on the path, no host
+// synchronisation) or, for the plain utx_bvh_build, one hipMalloc owned by the handle.  The tree depth -- which decides the traversal the launches use -- comes back
+// through a pinned host word behind an event and is read LAZILY, at the first launch that needs it (bvh_depth below).
+static size_t bvh_align(size_t x) { return (x + 255) & ~(size_t)255; }
+// pinned depth words: ONE hipHostMalloc per process (a pinned allocation costs far more than a build), slots handed out under a mutex
+namespace {
+struct DepthPool {
+    std::mutex mu;
+    int* base = nullptr;
+    std::vector<int> free_slots;
+    int* take() {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!base) {
+            if (hipHostMalloc((void**)&base, 1024 * sizeof(int), hipHostMallocDefault) != hipSuccess) { base = nullptr; return nullptr; }
+            for (int i = 1023; i >= 0; --i) free_slots.push_back(i);
+        }
+        if (free_slots.empty()) return nullptr;
+        const int i = free_slots.back(); free_slots.pop_back();
+        return base + i;
+    }
+    void give(int* p) {
+        std::lock_guard<std::mutex> lock(mu);
+        if (base && p >= base && p < base + 1024) free_slots.push_back((int)(p - base));
+    }
+};
+DepthPool g_depth_pool;
+}
+static size_t bvh_sort_bytes(int F) {
+    size_t n = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, n, (unsigned*)nullptr, (unsigned*)nullptr, (int*)nullptr, (int*)nullptr, (size_t)F, 0, 32, (hipStream_t)0);
+    return n ? n : 16;
+}
+extern "C" size_t utx_bvh_workspace_bytes_impl(int F) {
+    if (F < 1) return 0;
+    const size_t nn = 2 * (size_t)F - 1;
+    return bvh_align(nn * 3 * sizeof(int)) + bvh_align(nn * 6 * sizeof(float)) + bvh_align((size_t)F * 6 * sizeof(float)) + 4 * bvh_align((size_t)F * 4) +
+           bvh_align(nn * sizeof(int)) + bvh_align((size_t)(F > 1 ? F - 1 : 1) * sizeof(int)) + bvh_align(8 * sizeof(unsigned)) + bvh_align(nn * 2 * sizeof(float4)) +
+           bvh_align((size_t)F * 3 * sizeof(float4)) + bvh_align(sizeof(int)) + bvh_align(bvh_sort_bytes(F));
+}
+
+extern "C" int utx_bvh_build_ws_impl(const float* verts, int V, const int* faces, int F, void* work, size_t work_bytes, utx_bvh** out, hipStream_t stream) {
     (void)V;
-    if (F < 1 || !out) return -2;
+    if (F < 1 || !out || !work || ((uintptr_t)work & 255) || work_bytes < utx_bvh_workspace_bytes_impl(F)) return -2;
     utx_bvh* b = new utx_bvh();
     memset(b, 0, sizeof(*b));
-    b->F = F; b->verts = verts; b->faces = faces;
-    const long nn = 2L * F - 1;
-    HCHK(hipMalloc(&b->info, nn * 3 * sizeof(int)));
-    HCHK(hipMalloc(&b->aabb, nn * 6 * sizeof(float)));
-    HCHK(hipMalloc(&b->ebox, (long)F * 6 * sizeof(float)));
-    HCHK(hipMalloc(&b->codes, (long)F * 4)); HCHK(hipMalloc(&b->codes_sorted, (long)F * 4));
-    HCHK(hipMalloc(&b->idx, (long)F * 4)); HCHK(hipMalloc(&b->idx_sorted, (long)F * 4));
-    HCHK(hipMalloc(&b->parent, nn * sizeof(int)));
-    HCHK(hipMalloc(&b->counter, (long)(F > 1 ? F - 1 : 1) * sizeof(int)));
-    HCHK(hipMalloc(&b->extent, 8 * sizeof(unsigned)));
-    HCHK(hipMalloc(&b->nodes, nn * 2 * sizeof(float4)));
-    HCHK(hipMalloc(&b->tris, (long)F * 3 * sizeof(float4)));
-    HCHK(hipMalloc(&b->depth_dev, sizeof(int)));
-    HCHK(hipMemsetAsync(b->depth_dev, 0, sizeof(int), stream));
-    b->sort_tmp_bytes = 0;
-    HCHK(rocprim::radix_sort_pairs(nullptr, b->sort_tmp_bytes, b->codes, b->codes_sorted, b->idx, b->idx_sorted, (size_t)F, 0, 32, stream));
-    HCHK(hipMalloc(&b->sort_tmp, b->sort_tmp_bytes ? b->sort_tmp_bytes : 16));
+    b->F = F; b->verts = verts; b->faces = faces; b->depth = -1;
+    const size_t nn = 2 * (size_t)F - 1;
+    char* w = (char*)work;
+    auto take = [&](size_t bytes) { void* p_ = w; w += bvh_align(bytes); return p_; };
+    b->info = (int*)take(nn * 3 * sizeof(int));
+    b->aabb = (float*)take(nn * 6 * sizeof(float));
+    b->ebox = (float*)take((size_t)F * 6 * sizeof(float));
+    b->codes = (unsigned*)take((size_t)F * 4); b->codes_sorted = (unsigned*)take((size_t)F * 4);
+    b->idx = (int*)take((size_t)F * 4); b->idx_sorted = (int*)take((size_t)F * 4);
+    b->parent = (int*)take(nn * sizeof(int));
+    b->counter = (int*)take((size_t)(F > 1 ? F - 1 : 1) * sizeof(int));
+    b->extent = (unsigned*)take(8 * sizeof(unsigned));
+    b->nodes = (float4*)take(nn * 2 * sizeof(float4));
+    b->tris = (float4*)take((size_t)F * 3 * sizeof(float4));
+    b->depth_dev = (int*)take(sizeof(int));
+    b->sort_tmp_bytes = bvh_sort_bytes(F);
+    b->sort_tmp = take(b->sort_tmp_bytes);
+#define BCHK(e) do { if ((e) != hipSuccess) { utx_bvh_free_impl(b); return -7; } } while (0)
+    b->depth_host = g_depth_pool.take();      // more than 1024 live trees: none left
+    if (!b->depth_host) { utx_bvh_free_impl(b); return -7; }
+    BCHK(hipEventCreateWithFlags(&b->depth_ready, hipEventDisableTiming));
+    BCHK(hipMemsetAsync(b->depth_dev, 0, sizeof(int), stream));
     const int nb = (F + 255) / 256;
     hipLaunchKernelGGL(bvh_init_kernel, dim3(nb), dim3(256), 0, stream, b->extent, b->counter, F - 1);
     hipLaunchKernelGGL(bvh_elements_kernel, dim3(nb), dim3(256), 0, stream, verts, faces, F, b->ebox, b->extent);
     hipLaunchKernelGGL(bvh_morton_kernel, dim3(nb), dim3(256), 0, stream, b->ebox, F, b->extent, b->codes, b->idx);
-    HCHK(rocprim::radix_sort_pairs(b->sort_tmp, b->sort_tmp_bytes, b->codes, b->codes_sorted, b->idx, b->idx_sorted, (size_t)F, 0, 32, stream));
+    BCHK(rocprim::radix_sort_pairs(b->sort_tmp, b->sort_tmp_bytes, b->codes, b->codes_sorted, b->idx, b->idx_sorted, (size_t)F, 0, 32, stream));
     hipLaunchKernelGGL(bvh_hierarchy_kernel, dim3(nb), dim3(256), 0, stream, F, b->codes_sorted, b->idx_sorted, b->ebox, b->info, b->aabb, b->parent);
     hipLaunchKernelGGL(bvh_refit_kernel, dim3(nb), dim3(256), 0, stream, F, b->info, b->aabb, b->parent, b->counter);
     hipLaunchKernelGGL(bvh_pack_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, stream, F, b->info, b->aabb, b->parent, verts, faces,
                        b->nodes, b->tris, b->depth_dev);
-    if (hipGetLastError() != hipSuccess) return -4;
-    // the tree depth decides, once per mesh, which traversal the launches use (the build is not part of any captured graph)
-    HCHK(hipMemcpyAsync(&b->depth, b->depth_dev, sizeof(int), hipMemcpyDeviceToHost, stream));
-    HCHK(hipStreamSynchronize(stream));
+    if (hipGetLastError() != hipSuccess) { utx_bvh_free_impl(b); return -4; }
+    // the tree depth decides, once per mesh, which traversal the launches use: copied to the pinned word, read by bvh_depth() when a launch first asks (no wait here)
+    BCHK(hipMemcpyAsync(b->depth_host, b->depth_dev, sizeof(int), hipMemcpyDeviceToHost, stream));
+    BCHK(hipEventRecord(b->depth_ready, stream));
+#undef BCHK
+    *out = b;
+    return 0;
+}
+
+// the allocating form: ONE hipMalloc owned by the handle (utx_bvh_free releases it); depth known on return, as this entry point always promised
+extern "C" int utx_bvh_build_impl(const float* verts, int V, const int* faces, int F, utx_bvh** out, hipStream_t stream) {
+    if (F < 1 || !out) return -2;
+    void* blk = nullptr;
+    const size_t bytes = utx_bvh_workspace_bytes_impl(F);
+    HCHK(hipMalloc(&blk, bytes));
+    utx_bvh* b = nullptr;
+    const int rc = utx_bvh_build_ws_impl(verts, V, faces, F, blk, bytes, &b, stream);
+    if (rc != 0) { (void)hipFree(blk); return rc; }
+    b->owned = blk;
+    if (utx_bvh_depth_impl(b) < 0) { utx_bvh_free_impl(b); return -7; }
     *out = b;
     return 0;
 }
 
 extern "C" void utx_bvh_free_impl(utx_bvh* b) {
     if (!b) return;
-    void* ps[] = {b->info, b->aabb, b->ebox, b->codes, b->codes_sorted, b->idx, b->idx_sorted, b->parent, b->counter, b->extent, b->sort_tmp,
-                  b->nodes, b->tris, b->depth_dev};
-    for (void* p : ps) if (p) (void)hipFree(p);
+    if (b->depth_ready && b->depth < 0 && b->depth_host) (void)hipEventSynchronize(b->depth_ready);      // the copy into the pinned word must have landed before the word is handed on
+    if (b->depth_ready) (void)hipEventDestroy(b->depth_ready);
+    if (b->depth_host) g_depth_pool.give(b->depth_host);
+    if (b->owned) (void)hipFree(b->owned);      // the caller's workspace (utx_bvh_build_ws) is the caller's to release
     delete b;
 }
 
@@ -270,12 +334,19 @@ extern "C" int utx_bvh_arrays_impl(utx_bvh* b, int** info, float** aabb, unsigne
     return b->F;
 }
 
-extern "C" int utx_bvh_depth_impl(utx_bvh* b) { return b->depth; }
+// longest root-to-leaf path; the first call waits for the build's copy of it (an event behind the build's last kernel), later calls are a load.  -1: the wait failed
+extern "C" int utx_bvh_depth_impl(utx_bvh* b) {
+    if (b->depth < 0) {
+        if (hipEventSynchronize(b->depth_ready) != hipSuccess) return -1;
+        b->depth = *b->depth_host;
+    }
+    return b->depth;
+}
 
 extern "C" int utx_bvh_trace_impl(utx_bvh* b, const float* ro, const float* rd, long R, int* tid, unsigned long long* visited, int force_stack,
                                   hipStream_t stream) {
     if (!b || R <= 0) return -2;
-    if (b->depth <= UTX_BVH_PACKED_MAX_DEPTH && !force_stack) {
+    if (utx_bvh_depth_impl(b) <= UTX_BVH_PACKED_MAX_DEPTH && !force_stack) {
         hipLaunchKernelGGL(bvh_trace_packed_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, stream, b->nodes, b->tris, ro, rd, R, tid, visited);
         return hipGetLastError() == hipSuccess ? 0 : -4;
     }

@@ -204,6 +204,9 @@ struct utx_bvh {
     float4* nodes;   // [2F-1][2] packed tree (bvh_trace_packed)
     float4* tris;    // [F][3]
     int* depth_dev;  // max number of ancestors of a leaf
-    int depth;       // host copy; the packed traversal is used when depth <= UTX_BVH_PACKED_MAX_DEPTH
+    int depth;       // host copy (-1: not read back yet -- utx_bvh_depth_impl waits for depth_ready once); the packed traversal is used when depth <= UTX_BVH_PACKED_MAX_DEPTH
+    int* depth_host;           // pinned word the build copies depth_dev into
+    hipEvent_t depth_ready;    // recorded behind that copy
+    void* owned;               // the one hipMalloc of utx_bvh_build (null: the arrays live in the caller's workspace, utx_bvh_build_ws)
 };
 #define UTX_BVH_PACKED_MAX_DEPTH 60   // the reference's stack holds 64 entries and the walk keeps at most depth + 1 of them

@@ -339,6 +339,11 @@ int utx_bvh_build(utx_ctx* ctx, const float* verts, int V, const int* faces, int
     if (!verts || !faces || !out) return fail(ctx, -2, "utx_bvh_build");
     UTX_CALL(ctx, "utx_bvh_build", utx_bvh_build_impl(verts, V, faces, F, out, (hipStream_t)stream));
 }
+size_t utx_bvh_workspace_bytes(int F) { return utx_bvh_workspace_bytes_impl(F); }
+int utx_bvh_build_ws(utx_ctx* ctx, const float* verts, int V, const int* faces, int F, void* work, size_t work_bytes, utx_bvh** out, utx_stream stream) {
+    if (!verts || !faces || !out || !work) return fail(ctx, -2, "utx_bvh_build_ws");
+    UTX_CALL(ctx, "utx_bvh_build_ws", utx_bvh_build_ws_impl(verts, V, faces, F, work, work_bytes, out, (hipStream_t)stream));
+}
 void utx_bvh_free(utx_bvh* bvh) { utx_bvh_free_impl(bvh); }
 int utx_bvh_arrays(utx_bvh* bvh, int** info, float** aabb, unsigned** codes_sorted, int** idx_sorted) {
     return utx_bvh_arrays_impl(bvh, info, aabb, codes_sorted, idx_sorted);

@@ -124,6 +124,8 @@ size_t utx_knn_workspace_bytes_impl(long N);
 int utx_launch_knn(const KnnParams* p, void* work, size_t work_bytes, hipStream_t stream);
 int utx_launch_texture_shade(const float* rast, const float* uv, const int* tri, const float* tex, int Ht, int Wt, const float* bg3_host, long npix, void* out, hipStream_t stream);
 int utx_bvh_build_impl(const float* verts, int V, const int* faces, int F, utx_bvh** out, hipStream_t stream);
+size_t utx_bvh_workspace_bytes_impl(int F);
+int utx_bvh_build_ws_impl(const float* verts, int V, const int* faces, int F, void* work, size_t work_bytes, utx_bvh** out, hipStream_t stream);
 void utx_bvh_free_impl(utx_bvh* b);
 int utx_bvh_arrays_impl(utx_bvh* b, int** info, float** aabb, unsigned** codes_sorted, int** idx_sorted);
 int utx_bvh_trace_impl(utx_bvh* b, const float* ro, const float* rd, long R, int* tid, unsigned long long* visited, int force_stack, hipStream_t stream);

@@ -55,7 +55,7 @@ def time_backprojection(n_faces=50000, view_px=1024, atlas_px=2048, iters=3, war
         inv.index = order
     intr = camera.generate_intrinsics(1.0, 1.0, fov=False)
     images = torch.from_numpy(smooth_views(n_views, view_px, view_px)).to(device)
-    acc, totals = {}, []
+    acc, totals, host_enq = {}, [], []
     covered = 0.0
     for it in range(warmup + iters):
         inv.pbr_mesh._bvh = None          # the LBVH is rebuilt per mesh; count it
@@ -69,6 +69,7 @@ def time_backprojection(n_faces=50000, view_px=1024, atlas_px=2048, iters=3, war
         if it < warmup:
             continue
         totals.append(t0.elapsed_time(t1))
+        host_enq.append(inv.host_enqueue_ms)
         for name, a, b in inv.stage_events:
             acc.setdefault(name, []).append(a.elapsed_time(b))
         covered = float(out[2].float().mean())
@@ -92,5 +93,8 @@ def time_backprojection(n_faces=50000, view_px=1024, atlas_px=2048, iters=3, war
     T = float(atlas_px * atlas_px)
     bpt = stage_bytes_per_texel(n_views)
     gbps = {k: bpt[k] * T / (stages[k] * 1e-3) / 1e9 for k in stages if k in bpt and stages[k] > 0}
-    return {"total_ms": float(np.mean(totals)), "stages_ms": stages, "stages_gbps": gbps, "faces": int(len(faces)),
+    # total_ms brackets infer() with events on the launch stream: the stage chain + whatever the GPU idled waiting for the host.  kernel_sum_ms = the sum of the stage
+    # brackets (each bracket holds its kernels and the gaps between them; the gaps BETWEEN stages -- torch allocations, the next stage's first launch -- are not in it);
+    # host_enqueue_ms = the host's wall time to enqueue the chain: when it approaches total_ms the chain is host-bound on that box.
+    return {"total_ms": float(np.mean(totals)), "kernel_sum_ms": float(sum(stages.values())), "host_enqueue_ms": float(np.mean(host_enq)), "stages_ms": stages, "stages_gbps": gbps, "faces": int(len(faces)),
             "texels": int(T), "covered_frac": covered, "view_px": view_px, "atlas_px": atlas_px, "nodes_per_ray": nodes_per_ray, "bvh_depth": depth}

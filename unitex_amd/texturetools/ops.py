@@ -102,15 +102,18 @@ class BVH:
         self.ctx = get_ctx(verts.device.index)
         self.verts, self.faces = _f(verts), _i(faces)   # kept alive: the handle borrows them
         h = C.c_void_p()
-        self.ctx.check(self.ctx.lib.utx_bvh_build(self.ctx.handle, ptr(self.verts), verts.shape[0], ptr(self.faces),
-                                                  faces.shape[0], C.byref(h), self.ctx.stream()))
+        # every array of the tree in ONE torch allocation (caching allocator: no hipMalloc / hipFree on the path), the build enqueued without a host wait
+        nbytes = int(self.ctx.lib.utx_bvh_workspace_bytes(faces.shape[0]))
+        self.work = torch.empty(nbytes + 256, dtype=torch.uint8, device=verts.device)
+        base = (self.work.data_ptr() + 255) & ~255
+        self.ctx.check(self.ctx.lib.utx_bvh_build_ws(self.ctx.handle, ptr(self.verts), verts.shape[0], ptr(self.faces), faces.shape[0],
+                                                     C.c_void_p(base), C.c_size_t(nbytes), C.byref(h), self.ctx.stream()))
         self.handle = h
 
     def __del__(self):
         try:
             if getattr(self, "handle", None):
-                torch.cuda.synchronize()
-                self.ctx.lib.utx_bvh_free(self.handle)
+                self.ctx.lib.utx_bvh_free(self.handle)      # the handle only: the arrays are self.work, which torch releases stream-ordered like any other tensor
                 self.handle = None
         except Exception:
             pass

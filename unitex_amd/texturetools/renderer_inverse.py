@@ -18,6 +18,7 @@ views' colour/visibility layers, ONE all_gather (RCCL over xGMI, or gloo in the 
 layers, and the composite + post-processing run replicated on every rank.
 """
 import contextlib
+import time
 import os
 from typing import Callable, Optional, Tuple
 
@@ -228,6 +229,7 @@ class NVDiffRendererInverse:
         the gradient / facing filter to the view masks.  Colours: 3 channels (rgb) or 9 (PBR stack) for 'kdtree', 3 for 'reproject'."""
         assert method in ("kdtree", "reproject")
         assert not perspective, "the reference's texture path is orthographic (pipeline.py:208-210)"
+        t_host0 = time.perf_counter()
         # keyword arguments of the reference's signature (renderer_inverse.py:635-659) that this build fixes at the values the pipeline uses: anything else is
         # refused, not dropped
         fixed = dict(reproject_kernel_size_boundary=3, reproject_kernel_size_boundary_blur=3, reproject_kernel_size_blur=5, return_mv_reproject_uv=False)
@@ -259,9 +261,11 @@ class NVDiffRendererInverse:
         from .distributed import view_range
         rank, world = self.view_shard
         v0, v1, per = view_range(rank, world, n)
-        color = torch.zeros(n, H2D, W2D, 3, dtype=torch.float32, device=dev)
-        rayvis = torch.zeros(n, H2D, W2D, dtype=torch.uint8, device=dev)
-        alphaok = torch.zeros(n, H2D, W2D, dtype=torch.uint8, device=dev)
+        # the back-projection kernel writes EVERY texel of the views it is given; only a view shard (world > 1) leaves layers to others, and those start as zeros
+        alloc = torch.zeros if (world > 1 or v1 - v0 < n) else torch.empty
+        color = alloc(n, H2D, W2D, 3, dtype=torch.float32, device=dev)
+        rayvis = alloc(n, H2D, W2D, dtype=torch.uint8, device=dev)
+        alphaok = alloc(n, H2D, W2D, dtype=torch.uint8, device=dev)
         with self._stage("bvh_build"):
             bvh = m.optix
         if v1 > v0:
@@ -302,6 +306,7 @@ class NVDiffRendererInverse:
                 color_2d = torch.cat([ops.pull_push(baked[..., c:c + 3].contiguous(), mask_u8) for c in range(0, baked.shape[-1], 3)], dim=-1)
         with self._stage("to_u8"):
             tex = ops.to_u8(color_2d[..., :3].contiguous(), flip=True)  # tensor_to_image + FLIP_TOP_BOTTOM (link_pbr_to_mesh.py:17)
+        self.host_enqueue_ms = (time.perf_counter() - t_host0) * 1e3      # the host's time to ENQUEUE the whole chain (no device wait up to here); the copies below wait for the GPU
         textured = TexturedMesh(m.vertices.cpu().numpy(), m.faces.cpu().numpy(), m.uvs01, tex.cpu().numpy())
         self.last = {"rast2d": rast2d, "winner": winner, "seam": seam, "atlas_prefill": baked, "view_mask": mv["mask_visiable"]}
         out = (textured, vis.bool()[..., None], (rast2d[..., 3] > 0)[None, ..., None], color_2d[None])
