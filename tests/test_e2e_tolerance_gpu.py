@@ -301,3 +301,71 @@ def test_full_depth_full_width_forward_matches_oracle():
         S_txt + S_img, d.max().item(), d.max().item() / mx, mx, d.mean().item(), d.mean().item() / mx))
     assert torch.isfinite(out).all()
     assert d.max().item() <= 0.03 * mx and d.mean().item() <= 0.005 * mx
+
+
+def test_full_depth_full_width_fp8_numerics_stated():
+    """BASELINE configs[4] ("fp8 MFMA weights") at FULL DEPTH (round 5): the same 19 + 38 blocks at D = 3072, 24 heads, rank-16 LoRA, 1152 tokens as the bf16 test above,
+    in the product's three numerics modes -- bf16, MX fp8 linears (fp8_weights), MX fp8 linears + MX fp8 attention (fp8_attention) --
+      (a) ONE transformer evaluation of each against the bf16-emulating fp32 oracle AND against the bf16 product: max / mean |d| in units of max|out|;
+      (b) K = 4 real denoise steps (re-pin, fused Euler step) of each product -> HIP VAE decode -> uint8: histogram of LSB differences against the bf16 product.
+    STATED (measured on MI355X, profiles/r05_full_depth_fp8.log; asserted with a factor ~2 of margin):
+      one evaluation, |d| / max|out| vs the emulating oracle:  bf16 max 0.0122 mean 0.00226 | fp8 linears max 0.0509 mean 0.00896 | + fp8 attention max 0.0517 mean 0.00895
+      (the fp8 modes are 4.0 x the bf16 product's distance to the oracle; fp8 attention adds nothing measurable to fp8 linears at this sequence length)
+      K = 4 steps + VAE decode, uint8 vs the bf16 product:  fp8 30.6 % equal / 58.4 % <= 1 / 79.4 % <= 2 / 96.6 % <= 4 / 99.98 % <= 8 LSB, max 11;  + fp8 attention: the same, max 12."""
+    from unitex_amd.flux.pipeline import PBRFluxPipeline
+    from unitex_amd.flux.synthetic import SyntheticFluxStateDict, synthetic_lora, synthetic_vae_state_dict
+    from unitex_amd.flux.transformer import FluxDiT, FluxShape
+    from unitex_amd.flux.vae_hip import AutoencoderKL
+    cfg = dit_ref.FluxConfig()
+    shape = FluxShape()
+    sd = SyntheticFluxStateDict(shape, seed=0, device=DEV)
+    la_dev = synthetic_lora(sd, shape, rank=16, seed=2, device=DEV)
+    la = {k: (a.cpu(), b.cpu()) for k, (a, b) in la_dev.items()}
+    g = torch.Generator().manual_seed(63)
+    S_txt, hl, wl = 64, 16, 32
+    noise_ids = dit_ref.latent_image_ids(hl, wl)
+    cond_ids = torch.cat([dit_ref.latent_image_ids(hl, wl, offset_y=hl), dit_ref.latent_image_ids(8, 8, offset_x=wl, offset_y=hl)], 0)
+    img_ids = torch.cat([noise_ids, cond_ids], 0)
+    n_noise = hl * wl
+    lat0 = torch.randn(img_ids.shape[0], 64, generator=g).to(BF)
+    enc = (0.5 * torch.randn(S_txt, cfg.joint_dim, generator=g)).to(BF); pooled = (0.5 * torch.randn(1, cfg.pooled_dim, generator=g)).to(BF)
+    txt_ids = torch.zeros(S_txt, 3)
+    vae = AutoencoderKL(synthetic_vae_state_dict(1), device=DEV)
+    H, W, K = 16 * hl, 16 * wl, 4
+    fwd, img = {}, {}
+    for mode, kw in (("bf16", {}), ("fp8", dict(fp8_weights=True)), ("fp8-attn", dict(fp8_weights=True, fp8_attention=True))):
+        m = FluxDiT(sd, shape, device=DEV, **kw)
+        m.set_lora([(la_dev, 1.0)])
+        m.set_positions(txt_ids, img_ids)
+        m.set_conditioning(enc.to(DEV), pooled.to(DEV), 3.5)
+        fwd[mode] = m.forward(lat0.to(DEV), 0.4375).float().cpu()
+        pipe = PBRFluxPipeline(m, vae, device=DEV)
+        pipe.load_lora_weights(la_dev, "texture")
+        pipe.set_adapters(["texture"], [1.0])
+        lat = pipe.denoise(lat0[None, :n_noise], noise_ids, lat0[None, n_noise:], cond_ids, enc.to(DEV)[None], pooled.to(DEV), txt_ids, K, 3.5)
+        z = pipe._unpack_latents(lat, H, W, 8)
+        z = (z / vae.scaling_factor) + vae.shift_factor
+        img[mode] = _postprocess_u8(vae.decode(z.to(BF)))
+        torch.cuda.synchronize()
+        del m, pipe
+        torch.cuda.empty_cache()
+    torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 64)))
+    ref = dit_ref.flux_forward(_HostView(sd), cfg, lat0.float(), enc.float(), pooled.float(), 0.4375, 3.5, txt_ids, img_ids, loras=[(la, 1.0)], emulate_bf16=True)
+    mx = ref.abs().max().item()
+    stats = {}
+    for mode in ("bf16", "fp8", "fp8-attn"):
+        d_or, d_pr = (fwd[mode] - ref).abs(), (fwd[mode] - fwd["bf16"]).abs()
+        du = np.abs(img[mode].astype(np.int32) - img["bf16"].astype(np.int32))
+        hist = {k: float((du <= k).mean()) for k in (0, 1, 2, 4, 8)}
+        stats[mode] = (d_or.max().item() / mx, d_or.mean().item() / mx, d_pr.max().item() / mx, d_pr.mean().item() / mx, hist, int(du.max()))
+        print("\n[full depth 19 + 38, full width, S = %d] %-8s one evaluation vs emulating oracle: max %.4g mean %.4g of max|out| (%.3g); vs bf16 product: max %.4g mean %.4g; "
+              "K = %d steps + VAE decode, uint8 vs bf16 product: ==0 %.4f <=1 %.4f <=2 %.4f <=4 %.4f <=8 %.4f max %d LSB (image std %.1f)" % (
+                  S_txt + img_ids.shape[0], mode, stats[mode][0], stats[mode][1], mx, stats[mode][2], stats[mode][3], K, hist[0], hist[1], hist[2], hist[4], hist[8],
+                  stats[mode][5], float(img["bf16"].std())))
+        assert torch.isfinite(fwd[mode]).all()
+    assert float(img["bf16"].std()) > 4.0, "a constant decoded image would make the uint8 comparison vacuous"
+    # the bf16 leg is the test above's; the fp8 legs: bounded (measured values in the printed table; a broken quantiser or scale layout is off by O(1))
+    assert stats["bf16"][0] <= 0.03 and stats["bf16"][1] <= 0.005
+    for mode in ("fp8", "fp8-attn"):
+        assert stats[mode][0] <= 0.10 and stats[mode][1] <= 0.02, (mode, stats[mode])
+        assert stats[mode][4][4] >= 0.93 and stats[mode][4][8] >= 0.995 and stats[mode][5] <= 24, (mode, stats[mode])
