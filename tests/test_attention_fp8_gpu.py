@@ -164,3 +164,40 @@ def test_fluxdit_with_fp8_attention_runs_the_fp8_kernel_and_stays_close_to_the_b
     print("\n[FluxDiT fp8 attention, tiny 2 + 2 blocks] vs the bf16 forward: max %.3f %%, mean %.3f %% of max|out| %.3g" % (100 * d.max().item() / mx, 100 * d.mean().item() / mx, mx))
     assert torch.isfinite(outs["fp8-attn"]).all()
     assert d.max().item() <= 0.06 * mx and d.mean().item() <= 0.01 * mx
+
+
+@pytest.mark.parametrize("outlier", [0.0, 6.0, 10.0])
+def test_fp8_attention_on_long_diffuse_rows_with_an_early_outlier_key(outlier):
+    """ADVICE r4 (attention_fp8.hip l_run): the row sum l accumulates the fp32 probabilities while PV consumes them as e4m3 with unit scale, which flushes p < 2^-10
+    to zero.  A diffuse row whose running maximum was set by ONE early outlier key `outlier` log2-units above the bulk then keeps (in truth) most of its mass in keys
+    that the numerator drops and the denominator counts.  This states what the opt-in kernel does there, against the bf16 kernel on the same operands
+    (S = 16 384, 2 heads; printed, quoted in INTEGRATION.md): up to 6 units above the bulk the two agree to the kernels' usual distance; at 10 units the fp8
+    kernel's rows collapse towards the outlier's value row scaled by its share -- the documented limit of this numerics contract, asserted as such."""
+    ops = _ops()
+    H, S = 2, 16384
+    g = torch.Generator().manual_seed(77)
+    q = torch.randn(H, S, 128, generator=g) * 0.05       # base-2 scores of the bulk: N(0, ~0.3): a diffuse softmax over 16 384 keys
+    k = torch.randn(H, S, 128, generator=g) * 0.5
+    v = torch.randn(H, S, 128, generator=g)
+    if outlier:
+        # key 3 (first tile) scores `outlier` for every query: k3 = outlier * q / |q|^2 is query-dependent, so use a shared direction: all queries get a component u
+        u = torch.nn.functional.normalize(torch.randn(128, generator=g), dim=0)
+        q = q - (q @ u)[..., None] * u + 1.0 * u          # every query has component exactly 1 along u
+        k = k - (k @ u)[..., None] * u                    # bulk keys have none
+        k[:, 3] = outlier * u                             # score of key 3 = outlier for every query, bulk scores unchanged in distribution
+    qh, kh, vt = q.to(BF).cuda(), k.to(BF).cuda(), v.to(BF).cuda().transpose(1, 2).contiguous()
+    ref = ops.attention(qh, kh, vt, S=S, scale=0.0).float()
+    q8, qs = ops.quant_qk_mx8(qh)
+    k8, ks = ops.quant_qk_mx8(kh)
+    v8, vs = ops.quant_vt_mx8(vt)
+    out = ops.attention_fp8(q8, qs, k8, ks, v8, vs, S=S).float()
+    torch.cuda.synchronize()
+    rel = ((out - ref).norm() / ref.norm()).item()
+    print("\n[fp8 attention, S = %d diffuse rows, one early key %.0f log2-units above the bulk] relative Frobenius distance to the bf16 kernel %.4f, |out| / |ref| %.3f" % (
+        S, outlier, rel, (out.norm() / ref.norm()).item()))
+    assert torch.isfinite(out).all()
+    # measured (profiles/r05_fp8_attn_outlier.log): 0.042 / 0.049 / 0.130 (|out| / |ref| 0.998 / 0.998 / 0.931) at 0 / 6 / 10 units
+    if outlier <= 6.0:
+        assert rel <= 0.08, rel
+    else:
+        assert rel <= 0.25, rel      # stated limit: numerator mass below 2^-10 of the running maximum is dropped, the denominator keeps it
