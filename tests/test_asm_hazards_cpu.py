@@ -124,3 +124,67 @@ def test_no_kernel_of_the_build_touches_a_register_of_a_load_in_flight(tmp_path)
                 in_loop = False
             assert not (in_loop and "scratch_" in l), "%s: scratch access inside a loop: %s" % (name, l.strip())
     assert not report, "registers of in-flight asm loads are touched before their wait:\n" + "\n".join(report[:20])
+
+
+def _packed_cross_half_pairs(path, window=3):
+    """(kernel, line number, text) of every packed-fp32 instruction whose LOW lane takes the HIGH half (op_sel bit 1 for that source) of a register pair that another
+    packed-fp32 instruction wrote within the previous `window` instructions -- the pattern round 5's two-stream corruption was traced to (csrc/build.py NO_PK)."""
+    import re
+
+    def regs(tok):
+        m = re.match(r"v\[(\d+):(\d+)\]", tok)
+        if m:
+            return (int(m.group(1)), int(m.group(2)))
+        m = re.match(r"v(\d+)$", tok)
+        return (int(m.group(1)), int(m.group(1))) if m else None
+    out, cur, recent = [], None, []
+    for ln, l in enumerate(open(path), 1):
+        m = re.match(r"^(_Z\w+):", l)
+        if m:
+            cur, recent = m.group(1), []
+            continue
+        t = l.strip()
+        if not t or t[0] in ";." or t.endswith(":"):
+            continue
+        op = t.split()[0]
+        if op.startswith("v_pk_") and op.endswith("_f32"):
+            ops = [x.strip() for x in t[len(op):].split(",")]
+            dst = regs(ops[0].split()[0])
+            srcs = [regs(x.split()[0]) for x in ops[1:4]]
+            msel = re.search(r"op_sel:\[([01,]+)\]", t)
+            sel = [int(x) for x in msel.group(1).split(",")] if msel else []
+            for i, sr in enumerate(srcs):
+                if sr and i < len(sel) and sel[i] == 1 and any(d == sr for d, _ in recent):
+                    out.append((cur, ln, t))
+            recent = [(dst, 0)] + [(d, a + 1) for d, a in recent if a + 1 < window]
+        else:
+            recent = [(d, a + 1) for d, a in recent if a + 1 < window]
+    return out
+
+
+def test_the_packed_pattern_checker_flags_the_library_stream_that_failed(tmp_path):
+    bad = tmp_path / "bad.s"
+    bad.write_text("_Zk:\n\tv_pk_mul_f32 v[54:55], v[6:7], v[50:51] op_sel_hi:[0,1]\n\tv_pk_mul_f32 v[50:51], v[10:11], v[50:51] op_sel_hi:[0,1]\n\tv_cvt_pk_bf16_f32 v46, v46, v47\n"
+                   "\tv_pk_add_f32 v[56:57], v[54:55], v[50:51] op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n")
+    assert len(_packed_cross_half_pairs(str(bad))) == 1
+    ok = tmp_path / "ok.s"
+    ok.write_text("_Zk:\n\tv_pk_mul_f32 v[46:47], v[6:7], v[50:51]\n\tv_pk_mul_f32 v[48:49], v[10:11], v[52:53]\n\tv_pk_add_f32 v[46:47], v[46:47], v[48:49]\n")
+    assert _packed_cross_half_pairs(str(ok)) == []
+
+
+@pytest.mark.timeout(900)
+def test_no_kernel_of_the_build_holds_the_dependent_packed_pair_that_lost_a_product(tmp_path):
+    """every .hip translation unit, with the flags of csrc/build.py: a TU in which hipcc forms the pattern has to be built with NO_PK"""
+    from unitex_amd.csrc import build as b
+    srcs = [(n, x) for n, x in b.SOURCES if n.endswith(".hip")]
+
+    def listing(item):
+        name, extra = item
+        out = str(tmp_path / (name + ".s"))
+        r = subprocess.run([HIPCC] + b.COMMON + extra + ["-S", "--cuda-device-only", os.path.join(b.HERE, name), "-o", out], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return name, out
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        outs = list(ex.map(listing, srcs))
+    found = [(name,) + hit for name, path in outs for hit in _packed_cross_half_pairs(path)]
+    assert not found, "dependent packed-fp32 pairs across the halves (build the TU with NO_PK):\n" + "\n".join("%s %s line %d: %s" % f for f in found[:20])

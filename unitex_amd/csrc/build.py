@@ -15,21 +15,25 @@ OBJDIR = os.path.join(HERE, "_obj")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
+# -packed-fp32-ops (device pass; the host pass prints "not a recognized feature" and ignores it): no v_pk_mul / v_pk_add / v_pk_fma_f32 in this translation unit.
+# Round 5 traced the two-stream corruption of utx_qkv_post to ONE instruction pattern hipcc builds from packed fp32: a packed multiply written in place and, within two
+# instructions, a packed add whose LOW lane takes that result's HIGH half (op_sel): beside another queue's kernels the low lane saw 0 for it in lanes 50-63 of a wave
+# (29 of 29 dissected events: the wrong Q element = a0 c q, the second product missing; 0 of 5000 once products and sums are separated -- DESIGN 9 b,
+# tools/two_stream_dissect.py, profiles/r05_two_stream_*.log).  Every translation unit whose listing showed that pattern is built without packed fp32
+# (tests/test_asm_hazards_cpu.py audits all listings for it); none of them is bound by VALU throughput.
+NO_PK = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+
 # (source, extra flags)
 SOURCES = [
-    ("attention.hip", []),
+    ("attention.hip", NO_PK),
     ("attention_glds.hip", ["-fno-slp-vectorize"]),
     ("attention_q64.hip", []),
     ("attention_fp8.hip", []),
     ("gemm.hip", []),
     ("gemm_pers.hip", []),
     ("gemm_w4.hip", []),
-    # -packed-fp32-ops (device pass; the host pass prints "not a recognized feature" and ignores it): NO v_pk_mul / v_pk_add / v_pk_fma_f32 in the elementwise
-    # kernels.  With them, utx_qkv_post running beside another stream's MFMA GEMM produced a wrong low element in lanes 48-63 of a wave about once per 100
-    # forwards of the full-width fp8 plan; built without them: 0 of 3000 (tools/two_stream_probe.py, profiles/r04_two_stream_probe_nopk.log).
-    # These kernels are HBM-bound: the packed forms bought nothing measurable.
-    ("dit_elementwise.hip", ["-ffp-contract=off", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]),
-    ("vae.hip", []),
+    ("dit_elementwise.hip", ["-ffp-contract=off"] + NO_PK),
+    ("vae.hip", NO_PK),
     ("capi.cpp", []),
     ("meshproc.cpp", []),
     ("plan.cpp", []),
@@ -37,9 +41,9 @@ SOURCES = [
 ]
 GEOM = [
     ("raster.hip", ["-ffp-contract=off"]),
-    ("bvh.hip", ["-ffp-contract=off"]),
-    ("backproject.hip", ["-ffp-contract=off"]),
-    ("texture_post.hip", ["-ffp-contract=off"]),
+    ("bvh.hip", ["-ffp-contract=off"] + NO_PK),
+    ("backproject.hip", ["-ffp-contract=off"] + NO_PK),
+    ("texture_post.hip", ["-ffp-contract=off"] + NO_PK),
     ("knn.hip", ["-ffp-contract=off"]),
     ("unwrap.hip", []),
 ]
