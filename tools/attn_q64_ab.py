@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""A/B: default LDS-DMA attention kernel (8 x 32) vs its peeled forms vs the 4 x 64 kernel (+ repair pass), same process, interleaved; no key multiplicity (the 4 x 64 kernel has none)."""
+"""A/B: the LDS-DMA attention kernel's general loop ("default" = UTX_ATTN_PEEL=0), its fast loop ("peel1", the product's default since round 5) and the 4 x 64 kernel (+ repair pass, "q64"),
+same process, interleaved; no key multiplicity (the 4 x 64 kernel has none).  UTX_AB_ARMS=default,peel1,q64."""
 import math, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

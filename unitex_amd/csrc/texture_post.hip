@@ -63,17 +63,19 @@ extern "C" int utx_launch_seam_mask(const void* winner, const float* rast2d, int
 // dependent, scattered 12-byte load per candidate).  Now (a) 256^3 cells (a quarter of the candidates per ring volume on a surface), (b) the seen texels'
 // positions are GATHERED into cell order once ({x, y, z, texel index} as one 16-byte record), so a query streams each cell's candidates from
 // consecutive addresses.  Same exact search, same stopping rule, same tie rule: the result does not depend on the grid.
-#define NN_G 256
-__device__ __forceinline__ int nn_cell1(float v) {
-    int c = (int)floorf((v + 1.0f) * (NN_G * 0.5f));
-    return c < 0 ? 0 : (c > NN_G - 1 ? NN_G - 1 : c);
+// Round 5: the resolution follows the atlas -- 256 for T >= 1024^2 texels, 128 for T >= 256^2, 64 below: the cell table is 8 G^3 bytes (134 MB / 17 MB / 2 MB) and is
+// cleared on every call, which a small atlas should not pay for.  The result does not depend on the grid.
+static inline int nn_grid(long T) { return T >= (1L << 20) ? 256 : (T >= (1L << 16) ? 128 : 64); }
+__device__ __forceinline__ int nn_cell1(float v, int G) {
+    int c = (int)floorf((v + 1.0f) * ((float)G * 0.5f));
+    return c < 0 ? 0 : (c > G - 1 ? G - 1 : c);
 }
-__global__ __launch_bounds__(256) void nn_keys_kernel(const float* pos, const signed char* winner, long T, unsigned* keys, int* vals) {
+__global__ __launch_bounds__(256) void nn_keys_kernel(const float* pos, const signed char* winner, long T, unsigned* keys, int* vals, int NN_G) {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
     unsigned k = 0xffffffffu;
     if (winner[t] >= 0) {
-        const int cx = nn_cell1(pos[3 * t]), cy = nn_cell1(pos[3 * t + 1]), cz = nn_cell1(pos[3 * t + 2]);
+        const int cx = nn_cell1(pos[3 * t], NN_G), cy = nn_cell1(pos[3 * t + 1], NN_G), cz = nn_cell1(pos[3 * t + 2], NN_G);
         k = (unsigned)((cz * NN_G + cy) * NN_G + cx);
     }
     keys[t] = k; vals[t] = (int)t;
@@ -91,14 +93,14 @@ __global__ __launch_bounds__(256) void nn_bounds_kernel(const unsigned* keys, co
 }
 __global__ __launch_bounds__(256) void nn_query_kernel(const float* pos, const signed char* winner, const float4* rast2d, long T,
                                                        const float4* __restrict__ spos, const int* __restrict__ cell_start, const int* __restrict__ cell_end,
-                                                       float* atlas, int* nn_index) {
+                                                       float* atlas, int* nn_index, int NN_G) {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
     if (nn_index) nn_index[t] = -1;
     if (winner[t] >= 0 || !(rast2d[t].w > 0.f)) return;
     const float qx = pos[3 * t], qy = pos[3 * t + 1], qz = pos[3 * t + 2];
-    const int cx = nn_cell1(qx), cy = nn_cell1(qy), cz = nn_cell1(qz);
-    const float cs = 2.0f / NN_G;
+    const int cx = nn_cell1(qx, NN_G), cy = nn_cell1(qy, NN_G), cz = nn_cell1(qz, NN_G);
+    const float cs = 2.0f / (float)NN_G;
     float best = 3.0e38f; int bi = -1;
     for (int r = 0; r < NN_G; ++r) {
         for (int dz = -r; dz <= r; ++dz) {
@@ -155,13 +157,15 @@ __global__ __launch_bounds__(256) void nn_query_kernel(const float* pos, const s
 extern "C" size_t utx_nn_fill_workspace_bytes_impl(long T) {
     size_t tmp = 0;
     (void)rocprim::radix_sort_pairs(nullptr, tmp, (unsigned*)nullptr, (unsigned*)nullptr, (int*)nullptr, (int*)nullptr, (size_t)T, 0, 32, (hipStream_t)0);
-    return (size_t)T * 16 + (size_t)T * 16 + (size_t)NN_G * NN_G * NN_G * 8 + tmp + 512;
+    const size_t NN_G = (size_t)nn_grid(T);
+    return (size_t)T * 16 + (size_t)T * 16 + NN_G * NN_G * NN_G * 8 + tmp + 512;
 }
 
 extern "C" int utx_launch_nn_fill(const float* pos, const void* winner, const float* rast2d, long T, float* atlas, int* nn_index,
                                   void* work, size_t work_bytes, hipStream_t stream) {
     if (T <= 0) return -2;
     if (work_bytes < utx_nn_fill_workspace_bytes_impl(T)) return -2;
+    const int NN_G = nn_grid(T);
     unsigned* keys = (unsigned*)work; unsigned* keys_s = keys + T;
     int* vals = (int*)(keys_s + T); int* vals_s = vals + T;
     float4* spos = (float4*)(((uintptr_t)(vals_s + T) + 15) & ~(uintptr_t)15);
@@ -171,11 +175,11 @@ extern "C" int utx_launch_nn_fill(const float* pos, const void* winner, const fl
     if (rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys_s, vals, vals_s, (size_t)T, 0, 32, stream) != hipSuccess) return -7;
     const unsigned nb = (unsigned)((T + 255) / 256);
     if (hipMemsetAsync(cell_start, 0xff, (size_t)NN_G * NN_G * NN_G * 4, stream) != hipSuccess) return -7;
-    hipLaunchKernelGGL(nn_keys_kernel, dim3(nb), dim3(256), 0, stream, pos, (const signed char*)winner, T, keys, vals);
+    hipLaunchKernelGGL(nn_keys_kernel, dim3(nb), dim3(256), 0, stream, pos, (const signed char*)winner, T, keys, vals, NN_G);
     if (rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys_s, vals, vals_s, (size_t)T, 0, 32, stream) != hipSuccess) return -7;
     hipLaunchKernelGGL(nn_bounds_kernel, dim3(nb), dim3(256), 0, stream, keys_s, vals_s, pos, T, cell_start, cell_end, spos);
     hipLaunchKernelGGL(nn_query_kernel, dim3(nb), dim3(256), 0, stream, pos, (const signed char*)winner, (const float4*)rast2d, T, spos,
-                       cell_start, cell_end, atlas, nn_index);
+                       cell_start, cell_end, atlas, nn_index, NN_G);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
