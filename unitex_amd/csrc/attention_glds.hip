@@ -307,7 +307,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
     // same order per element as the general loop: bit-identical (tests/test_attention_peel_gpu.py).  Measured (profiles/r05_attn_peel_ab.log, same process, interleaved): 25.86 ->
     // 23.96 ms at S = 50 240 (1199 -> 1294 TF/s), 1.851 -> 1.756 ms at 13 376.  The S1 / S2 sched_group_barrier hints are NOT used here: with them 23.99 ms (no gain), and on the
     // peeled loop with the barrier at the end they LOSE (25.27 vs 24.41 ms): they place exponentials between the QK^T(1) MFMAs, which chain on one accumulator.  Launches whose
-    // key-multiplicity tiles recur (key_bias_period > 0: sequence parallelism) keep the general loop.
+    // key-multiplicity tiles recur (key_bias_period > 0: sequence parallelism) keep the general loop (the launcher's choice).
 #define AG_EXPF(sa_, p0_, p1_, ps_, qi_)                                                             \
         if constexpr (ABL & 1) {                                                                \
             float sc0_ = 0.f, sc1_ = 0.f;                                                            \
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
         }                                                                                            \
         __builtin_amdgcn_s_setprio(0);                                                               \
         }
-    if (FAST && TPB == 1 && !(p.key_bias_period > 0 && p.key_bias_log2 != 0.f)) {
+    if (FAST && TPB == 1) {      // (the launcher sends launches with periodic key multiplicity to the general instance)
         const bool rag_ = (Sk & (AG_KVB - 1)) != 0;
         const int fast_end_ = rag_ ? nt - 1 : nt;                 // tiles [1, fast_end_) take the fast form
         bf16x8 kfa_n[8], vfb_n[8];
@@ -639,6 +639,8 @@ extern "C" int utx_launch_attn_fwd_glds(const AttnParams* p, int presc, hipStrea
       if (var == 7 && presc) return launch_glds<1, 1, 7>(*p, stream); }    // 16-byte epilogue stores through v_permlane32_swap (correct results)
 #endif
     // the pre-scaled form the DiT uses: the fast loop (FAST above); UTX_ATTN_PEEL=0: the general loop, the default until round 5 (A/B and the reference bits of the stress tests)
-    if (presc && g_utx_opt.attn_peel != 0) return launch_glds<1, 1, 0, false, true>(*p, stream);
+    // launches whose key-multiplicity tiles recur (key_bias_period > 0: sequence parallelism) keep the general loop: a second copy of the fast tile for those tiles inside the loop made
+    // hipcc spill in it (round 5: 45 scratch accesses per trip with one tile per trip, 293 with two)
+    if (presc && g_utx_opt.attn_peel != 0 && !(p->key_bias_period > 0 && p->key_bias_log2 != 0.f)) return launch_glds<1, 1, 0, false, true>(*p, stream);
     return presc ? launch_glds<1, 1>(*p, stream) : launch_glds<0, 1>(*p, stream);
 }
