@@ -135,6 +135,23 @@ __global__ __launch_bounds__(256) void aggressor_mfma(float* sink, int iters) {
     if (t == 12345.678f) sink[0] = t;
 }
 
+// aggressor, MX form: the scaled fp8 MFMA of the fp8 plan's text-half GEMMs (v_mfma_scale_f32_32x32x64_f8f6f4: 16 passes, eight operand registers a side + scales) -- the
+// library's failure rate is 1-2 % of the forwards with these neighbours and 1 in 2000 with the bf16 MFMA
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void aggressor_mx(float* sink, int iters) {
+    i32x8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = 0x38383838 + (int)((threadIdx.x + i) & 3) * 0x01010101; b[i] = 0x3c3c3c3c - (int)((threadIdx.x * 3 + i) & 3) * 0x01010101; }
+    f16v acc0, acc1;
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    for (int it = 0; it < iters; ++it) {
+        acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc0, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b, a, acc1, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+    }
+    float t = 0.f;
+    for (int i = 0; i < 16; ++i) t += acc0[i] + acc1[i];
+    if (t == 12345.678f) sink[0] = t;
+}
+
 __global__ __launch_bounds__(256) void aggressor_valu(float* sink, int iters) {
     float x = (float)threadIdx.x, y = 1.0001f;
     for (int it = 0; it < iters * 16; ++it) { x = x * y + 0.5f; y = y * 0.99999f + 1e-6f; }
@@ -152,23 +169,25 @@ int main(int argc, char** argv) {
     const int nv = 1024, na = 1024;      // 4 workgroups of each kernel per CU: both co-resident on every SIMD
     float* big; CK(hipMalloc(&big, 1048576 * 4 + 65536)); CK(hipMemset(big, 0, 1048576 * 4 + 65536));
     for (int use_loads = 0; use_loads < 2; ++use_loads)
-    for (int arm = 0; arm < 7; ++arm) {
+    for (int arm = 0; arm < 9; ++arm) {
         CK(hipMemset(counts, 0, 32));
         CK(hipDeviceSynchronize());
         hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
         if (arm == 1) hipLaunchKernelGGL(aggressor_mfma, dim3(na), dim3(256), 0, s2, sink, iters * 3);
         if (arm == 2) hipLaunchKernelGGL(aggressor_valu, dim3(na), dim3(256), 0, s2, sink, iters);
         if (arm == 3) hipLaunchKernelGGL(aggressor_gemm_like, dim3(na), dim3(256), 0, s2, big, sink, iters / 4);
+        if (arm == 7) hipLaunchKernelGGL(aggressor_mx, dim3(na), dim3(256), 0, s2, sink, iters * 2);
         CK(hipEventRecord(a, s1));
         if (use_loads) hipLaunchKernelGGL(victim_loads, dim3(nv), dim3(256), 0, s1, in, counts, iters / 8);
         else hipLaunchKernelGGL(victim, dim3(nv), dim3(256), 0, s1, in, counts, iters);
         CK(hipEventRecord(b, s1));
         // arms 4-6: a STORM of short-lived workgroups beside the victim (waves of another kernel being launched onto / retired from the victim's SIMDs all the time, as the text
         // half's small GEMMs are at the tail of the image half's projection): 3000 launches of ~20 us each
-        if (arm >= 4) for (int k = 0; k < 3000; ++k) {
+        if (arm >= 4 && arm != 7) for (int k = 0; k < 3000; ++k) {
             if (arm == 4) hipLaunchKernelGGL(aggressor_mfma, dim3(256), dim3(256), 0, s2, sink, 1500);
             if (arm == 5) hipLaunchKernelGGL(aggressor_gemm_like, dim3(256), dim3(256), 0, s2, big, sink, 40);
             if (arm == 6) hipLaunchKernelGGL(aggressor_valu, dim3(512), dim3(256), 0, s2, sink, 300);
+            if (arm == 8) hipLaunchKernelGGL(aggressor_mx, dim3(256), dim3(256), 0, s2, sink, 800);
         }
         CK(hipDeviceSynchronize());
         float ms = 0; CK(hipEventElapsedTime(&ms, a, b));
@@ -176,7 +195,7 @@ int main(int argc, char** argv) {
         printf("{\"victim\": \"%s\", \"arm\": \"%s\", \"lane_iterations\": %.0f, \"low_lane_wrong\": %llu, \"of_which_second_product_missing\": %llu, \"high_lane_wrong\": %llu, \"wrong_in_lanes_48_63\": %llu, \"victim_ms\": %.1f}\n",
                use_loads ? "operands by in-statement loads + counted waits" : "operands in registers", arm == 0 ? "victim alone" : arm == 1 ? "victim beside an MFMA kernel on a second stream" : arm == 2 ? "victim beside a VALU-only kernel on a second stream"
                : arm == 3 ? "victim beside a GEMM-shaped kernel (LDS-DMA, barriers, MFMA)" : arm == 4 ? "victim beside 3000 short MFMA launches" : arm == 5 ? "victim beside 3000 short GEMM-shaped launches"
-               : "victim beside 3000 short VALU launches", (double)nv * 256 * (use_loads ? iters / 8 : iters), c[0], c[3], c[1], c[2], ms);
+               : arm == 6 ? "victim beside 3000 short VALU launches" : arm == 7 ? "victim beside an MX scaled-MFMA kernel (v_mfma_scale_f32_32x32x64_f8f6f4)" : "victim beside 3000 short MX scaled-MFMA launches", (double)nv * 256 * (use_loads ? iters / 8 : iters), c[0], c[3], c[1], c[2], ms);
         fflush(stdout);
     }
     return 0;

@@ -42,6 +42,12 @@ for arm in ARMS:
             new.append(("par", (main_ops, side_ops[:keep], e0, e1)))
             new.extend(side_ops[keep:])
             done = True
+        elif fn == "par" and not done and arm == "qkv_main":
+            # side = ln_mod + LoRA-down GEMM; the text half's QKV GEMM (the MX fp8 small-M kernel in this plan) + qkv_post run behind the join on the main stream
+            main_ops, side_ops, e0, e1 = d
+            new.append(("par", (main_ops, side_ops[:2], e0, e1)))
+            new.extend(side_ops[2:])
+            done = True
         elif fn == "par" and not done and arm == "lora_down_main":
             # side = ln_mod, QKV GEMM, qkv_post; the LoRA-down GEMM (side_ops[1]) runs on the main stream IN FRONT of the section
             main_ops, side_ops, e0, e1 = d
