@@ -188,3 +188,71 @@ def test_no_kernel_of_the_build_holds_the_dependent_packed_pair_that_lost_a_prod
         outs = list(ex.map(listing, srcs))
     found = [(name,) + hit for name, path in outs for hit in _packed_cross_half_pairs(path)]
     assert not found, "dependent packed-fp32 pairs across the halves (build the TU with NO_PK):\n" + "\n".join("%s %s line %d: %s" % f for f in found[:20])
+
+
+def _barriers_without_vmcnt0(path, window=48):
+    """(kernel, line, context) of every s_barrier of a kernel that uses LDS-DMA (global_load_lds / buffer_load ... lds) which has no `s_waitcnt ... vmcnt(0)` among the
+    `window` instructions in front of it.  An LDS-DMA'd tile is published by: this wave's vmcnt(0), THEN the barrier, then the reads (cdna_hip_programming.md 5.7); hipcc does
+    not owe the DMA that wait at __syncthreads() -- round 5 found the attention kernels relying on it (csrc/attention_glds.hip, AG_BARRIER)."""
+    import re
+    out, cur, body = [], None, []
+
+    def flush():
+        if cur is None or not any("global_load_lds" in t or (t.startswith("buffer_load") and " lds" in t) for _, t in body):
+            return
+        for i, (ln, t) in enumerate(body):
+            if t.split()[0] != "s_barrier":
+                continue
+            # walk back from the barrier: a vmcnt(0) must come before any instruction that issues vector memory traffic (VALU / SALU / LDS in between are harmless)
+            ok, prev = False, []
+            for _, x in reversed(body[max(0, i - window):i]):
+                prev.append(x)
+                if x.startswith("s_waitcnt") and "vmcnt(0)" in x:
+                    ok = True
+                    break
+                if x.split()[0].startswith(("global_", "buffer_", "flat_", "scratch_")):
+                    break
+            if not ok:
+                out.append((cur, ln, " | ".join(reversed(prev[:3]))))
+    for ln, l in enumerate(open(path), 1):
+        m = re.match(r"^(_Z\w+):", l)
+        if m:
+            flush()
+            cur, body = m.group(1), []
+            continue
+        t = l.strip()
+        if not t or t[0] in ";." or t.endswith(":"):
+            continue
+        body.append((ln, re.sub(r"\s+", " ", t)))
+    flush()
+    return out
+
+
+def test_the_barrier_checker_flags_a_fence_without_its_vmcnt(tmp_path):
+    bad = tmp_path / "bad.s"
+    bad.write_text("_Zk:\n\tglobal_load_lds_dwordx4 v[0:1], off\n\tv_mfma_f32_32x32x16_bf16 v[0:15], v[16:19], v[20:23], v[0:15]\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier\n\ts_endpgm\n")
+    assert len(_barriers_without_vmcnt0(str(bad))) == 1
+    ok = tmp_path / "ok.s"
+    ok.write_text("_Zk:\n\tglobal_load_lds_dwordx4 v[0:1], off\n\ts_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier\n\ts_endpgm\n_Zplain:\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier\n")
+    assert _barriers_without_vmcnt0(str(ok)) == []
+
+
+@pytest.mark.timeout(900)
+def test_every_barrier_of_the_attention_kernels_is_behind_a_vmcnt0(tmp_path):
+    """the three LDS-DMA attention translation units (their barriers all publish DMA'd tiles), with the flags of csrc/build.py AND with the scheduling strategy that exposed the
+    missing wait in round 5 (-mllvm -amdgpu-sched-strategy=max-memory-clause)"""
+    from unitex_amd.csrc import build as b
+    srcs = [(n, x) for n, x in b.SOURCES if n in ("attention_glds.hip", "attention_fp8.hip", "attention_q64.hip")]
+    assert len(srcs) == 3
+    jobs = [(n, x, tag, extra) for n, x in srcs for tag, extra in (("default", []), ("maxmem", ["-mllvm", "-amdgpu-sched-strategy=max-memory-clause"]))]
+
+    def listing(job):
+        name, flags, tag, extra = job
+        out = str(tmp_path / (name + "." + tag + ".s"))
+        r = subprocess.run([HIPCC] + b.COMMON + flags + extra + ["-S", "--cuda-device-only", os.path.join(b.HERE, name), "-o", out], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return name + " (" + tag + ")", out
+    with ThreadPoolExecutor(max_workers=6) as ex:
+        outs = list(ex.map(listing, jobs))
+    found = [(name,) + hit for name, path in outs for hit in _barriers_without_vmcnt0(path)]
+    assert not found, "barriers of LDS-DMA kernels without a vmcnt(0) in front of them:\n" + "\n".join("%s %s line %d: ... %s" % f for f in found[:20])

@@ -31,6 +31,7 @@ constexpr int ABL = 0;      // the kernel's timing-ablation bits (ablation build
 #define AG_STAGE(t_, slot_) ev.push_back({0, (int)(t_), (int)(slot_), 0})
 #define AG_TILE_BODY { ev.push_back({1, t, gs + sub, 1}); }
 #define __syncthreads() ev.push_back({2, 0, 0, 0})
+#define AG_BARRIER() __syncthreads()
 #define AG_FAST_A ev.push_back({3, u, gs, 0});
 #define AG_FAST_B(PF_) ev.push_back({4, u + 1, gs ^ 1, (PF_)});
 #define AG_LOAD_KFA(slot_) ev.push_back({5, -1, (int)(slot_), 0});
@@ -133,7 +134,7 @@ def test_the_skeleton_check_sees_a_broken_loop(tmp_path):
     mutations = [("const int fast_end_ = rag_ ? nt - 1 : nt;                 // tiles [1, fast_end_) take the fast form", "const int fast_end_ = nt;"),
                  ("            if (1 < nt) AG_STAGE(1, 1);\n", "            if (1 < nt) AG_STAGE(1, 0);\n"),
                  ("if (!(ABL & 4) && u + 2 < nt) AG_STAGE(u + 2, gs); ", "if (!(ABL & 4) && u + 2 < nt) AG_STAGE(u + 2, gs ^ 1);"),
-                 ("if constexpr (!(ABL & 8)) __syncthreads();", ""),
+                 ("if constexpr (!(ABL & 8)) AG_BARRIER();", ""),
                  ("                AG_FAST_TILE(uu + 1, 0)\n", "                AG_FAST_TILE(uu + 1, 1)\n"),
                  ("            if (uu < fast_end_) AG_FAST_TILE(uu, 1)\n", ""),
                  ("        if (2 < nt) AG_STAGE(2, 0);", "        if (2 < nt) AG_STAGE(2, 1);"),
@@ -201,7 +202,7 @@ def test_peeled_fp8_attention_loop_takes_every_tile_once_through_the_right_body(
     fast = text[text.index("#define A8_FAST_BODY"):text.index("// VAR 1 (the default since round 5")]
     norm = lambda s: " ".join(s.replace("\\", " ").split())
     for must in ("A8_STAGE(t + 1, slot ^ 1);", "ksc0n = ksb[kr]; ksc1n = ksb[kr + 32];", "vscn = vsb[(long)(2 * (t + 1) + lh) * 32 + lq];", "const int slot = t & 1;",
-                 'asm volatile("" : "+v"(ksc0n), "+v"(ksc1n), "+v"(vscn));', "ksc0 = (int)(ksc0n >> (8 * lh)); ksc1 = (int)(ksc1n >> (8 * lh)); vsc = (int)vscn;", "__syncthreads();",
+                 'asm volatile("" : "+v"(ksc0n), "+v"(ksc1n), "+v"(vscn));', "ksc0 = (int)(ksc0n >> (8 * lh)); ksc1 = (int)(ksc1n >> (8 * lh)); vsc = (int)vscn;", "A8_BARRIER();",
                  "vsc_pv = vsc;", "l_run += ps0 + ps1;", "pb = a8_i32x8{pb0, pb1, pb2, pb3, pb4, pb5, pb6, pb7};"):
         assert norm(must) in norm(gen) and norm(must) in norm(fast), must
 

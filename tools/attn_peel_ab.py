@@ -10,6 +10,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from unitex_amd import _lib            # noqa: E402
+if os.environ.get("UTX_LIB"):
+    _lib.LIB_PATH = os.path.abspath(os.environ["UTX_LIB"])      # a differently built library (tools/build_variant.py)
 from unitex_amd.flux import ops        # noqa: E402
 
 BF, H = torch.bfloat16, int(os.environ.get("UTX_AB_HEADS", "24"))

@@ -44,6 +44,9 @@ __device__ __forceinline__ a8_i32x8 a8_frag(const char* plo, const char* phi) {
 }
 
 // l * alpha as a multiply of its own: hipcc contracts `l_run *= alpha; ...; l_run += ps` into v_fmac_f32 in tail-duplicated copies of the re-centring path only
+// the barrier that publishes a DMA'd tile carries its own vmcnt(0): hipcc does not owe an LDS-DMA one at __syncthreads() (attention_glds.hip, AG_BARRIER)
+#define A8_BARRIER() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); } while (0)
+
 __device__ __forceinline__ float a8_mul_nofuse(float a, float b) {
 #pragma clang fp contract(off)
     return a * b;
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_fp8_kernel(Attn8Params p) {
     // the scales of tile 0: K rows kappa(lq) of both 32-key blocks (pre-shifted for the upper half-wave), V^T blocks 0 / 1
     int ksc0 = (int)(ksb[krow] >> (8 * lh)), ksc1 = (int)(ksb[32 + krow] >> (8 * lh));
     int vsc = (int)vsb[lh * 32 + lq];
-    __syncthreads();
+    A8_BARRIER();
 
 #define A8_FRAG(plo_, phi_) a8_frag(plo_, phi_)
     // p = 2^s of the 16 scores of a block -> row-sum share and the four dwords of e4m3 bytes in register order
@@ -233,7 +236,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_fp8_kernel(Attn8Params p) {
         __builtin_amdgcn_s_setprio(0);                                                                                 \
         asm volatile("" : "+v"(ksc0n), "+v"(ksc1n), "+v"(vscn));   /* first use of the three dwords: the wait for them lands HERE */ \
         ksc0 = (int)(ksc0n >> (8 * lh)); ksc1 = (int)(ksc1n >> (8 * lh)); vsc = (int)vscn;                             \
-        __syncthreads();   /* this slot fully read by every wave; the next tile's DMA retired by the vmcnt(0) of this fence */ \
+        A8_BARRIER();   /* this slot fully read by every wave; the next tile's DMA retired by the vmcnt(0) of this fence */ \
         }
     // eight exponentials (scores r0_ .. r0_ + 7 of a block) with the running sums carried along (same summation order as A8_EXPB), packed into two dwords of e4m3 bytes
 #define A8_EXPQ(sa_, r0_, da_, db_)                                                                      \
@@ -317,7 +320,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_fp8_kernel(Attn8Params p) {
         __builtin_amdgcn_s_setprio(0);                                                                   \
         asm volatile("" : "+v"(ksc0n), "+v"(ksc1n), "+v"(vscn));                                         \
         ksc0 = (int)(ksc0n >> (8 * lh)); ksc1 = (int)(ksc1n >> (8 * lh)); vsc = (int)vscn;               \
-        __syncthreads();                                                                                 \
+        A8_BARRIER();                                                                                 \
         }
     // VAR 1 (the default since round 5; UTX_ATTN8_PEEL=0 selects the general loop for A/B; same arithmetic in the same order per element = bit-identical; measured 16.60 -> 15.92 ms
     // at S = 50 240, 1869 -> 1948 TF/s, profiles/r05_attn_peel_ab.log): tile 0 and a ragged last tile

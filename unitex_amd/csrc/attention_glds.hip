@@ -13,7 +13,7 @@
 // register staging (a ds_write_b128 costs ~13 LDS cycles per wave-instruction, 4 per lane and tile) -- the kernel is
 // power/clock limited, so fewer instructions and less register traffic per tile is the lever that is left.
 // Ring: K and Vt 2-deep (64 KB); tile t+1 is requested at the top of tile t into the slot last read in tile t-1 (free
-// since the barrier that ended it) and retired by the vmcnt(0) that __syncthreads() carries while a DMA is in flight.
+// since the barrier that ended it) and retired by the explicit vmcnt(0) in front of that barrier (AG_BARRIER below).
 #include "common.h"
 #include "kernels.h"
 #include <stdlib.h>
@@ -23,6 +23,13 @@
 #define AG_KTILE 16384
 #define AG_VTILE 16384
 #define AG_LDS(tpb) ((tpb) * 2 * (AG_KTILE + AG_VTILE))
+
+// The barrier that publishes a DMA'd tile: this wave's LDS-DMAs retire through vmcnt, and the wait for them must be WRITTEN -- hipcc does not owe a global_load_lds a
+// `vmcnt(0)` at __syncthreads() (cdna_hip_programming.md 5.7: "LDS-DMA data needs your own vmcnt(N), then a barrier, then the ds_read").  Until round 5 this file relied on
+// the `s_waitcnt vmcnt(0) lgkmcnt(0)` hipcc happened to emit at the fence; built with -mllvm -amdgpu-sched-strategy=max-memory-clause the first barrier of the two-tile loop
+// came out with `lgkmcnt(0)` only and the fast loop returned run-to-run different results at full occupancy (profiles/r05_attn_lib_compare.log).  With the default
+// strategy the explicit wait is redundant (the listing shows both); tests/test_asm_hazards_cpu.py now requires a vmcnt(0) in front of every such barrier.
+#define AG_BARRIER() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); } while (0)
 
 __device__ __forceinline__ void ag_glds16(const bf16_t* g, char* lds) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -168,7 +175,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
     for (int i = 0; i < TPB; ++i)
         if (i < nt) AG_STAGE(i, i);
     if constexpr (VAR == 11) { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); tl1 = wall_clock64(); }      // the Q loads are older than the first tile's four DMAs
-    __syncthreads();
+    AG_BARRIER();
     if constexpr (VAR == 11) tl2 = wall_clock64();
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) asm volatile("" : "+v"(qf[kk]));
@@ -392,7 +399,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
             const int gs = 0, sub = 0, t = 0;                     // tile 0: the general body, barrier at its end
             if (1 < nt) AG_STAGE(1, 1);
             AG_TILE_BODY
-            __syncthreads();
+            AG_BARRIER();
         }
         if (2 < nt) AG_STAGE(2, 0);                               // slot 0 is free behind that barrier; from here on tile u + 2 is requested behind the barrier of tile u
         if (1 < fast_end_) AG_LOAD_KFA(1)
@@ -400,7 +407,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
         {                                                                                            \
             const int u = (u_), gs = (gs_);                                                          \
             AG_FAST_A                                                                                \
-            if constexpr (!(ABL & 8)) __syncthreads();            /* tile u + 1 has landed (the vmcnt(0) this fence carries) and is visible; every wave is done with slot gs */ \
+            if constexpr (!(ABL & 8)) AG_BARRIER();            /* tile u + 1 has landed (the vmcnt(0) this fence carries) and is visible; every wave is done with slot gs */ \
             if (!(ABL & 4) && u + 2 < nt) AG_STAGE(u + 2, gs);                                       \
             AG_FAST_B(1)      /* always prefetches: behind the last fast tile the fragments are not used (slot gs ^ 1 then holds the ragged last tile or old data; nothing writes it) */ \
         }
@@ -418,7 +425,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
         if (rag_ && nt > 1) {
             const int gs = (nt - 1) & 1, sub = 0, t = nt - 1;     // its tile was requested two tiles ago and retired by the last barrier above (or by tile 0's)
             AG_TILE_BODY
-            __syncthreads();
+            AG_BARRIER();
         }
     } else
     for (int u = 0; u < ngrp; ++u) {
@@ -431,7 +438,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
         if (t >= nt) break;
         AG_TILE_BODY
       }
-      __syncthreads();     // this group fully read by every wave; the next group (DMA) retired by the vmcnt(0) of this fence
+      AG_BARRIER();     // this group fully read by every wave; the next group (DMA) retired by the vmcnt(0) of this fence
     }
 
     // ---- epilogue: lane (q, h) holds O[q][32db + 8a + 4h + c], r = 4a + c -- 8 bytes of a row per (db, a), the other half-wave the neighbouring 8.

@@ -252,6 +252,7 @@ __global__ __launch_bounds__(256) void attn_fwd_q64_kernel(AttnParams p) {
     AQ_DMA_K4(1, 1)
     AQ_DMA_V4(1, 1)
     AQ_DMA_K4(2, 2)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the LDS-DMAs of the first tiles: hipcc does not owe them a vmcnt(0) at the fence (attention_glds.hip, AG_BARRIER)
     __syncthreads();
     kf[0] = AQ_LDSV(kx[0]); kf[1] = AQ_LDSV(kx[1]);
     // stage -1 (parity 1: writes sa0 from K block 0; its Vt reads are harmless prefetches that stage 0 overwrites)
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(256) void attn_fwd_q64_kernel(AttnParams p) {
         const int stepv = (c3 == 0) ? -(AQ_NSLOT - 1) * AQ_TILE : AQ_TILE;       // slot(t)   -> slot(t+1)
         kx[0] += stepk; kx[1] += stepk; vx[0] += stepv; vx[1] += stepv;
         // ---- tile boundary: everything issued one tile ago has landed; K(t+3) -> slot of K(t), V(t+2) -> slot of V(t-1)
-        if (!(ABL & 8)) __syncthreads();
+        if (!(ABL & 8)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
         const bf16_t* const kt_ = kbase + (long)AQ_MIN(t + 3, nt - 1) * AQ_KVB * p.k_ss;
         const bf16_t* const vt_ = vbase + AQ_MIN(t + 2, nt - 1) * AQ_KVB;
         const int ksl = (c3 == 0) ? AQ_NSLOT - 1 : c3 - 1;                       // t % 3 = (t + 3) % 3
