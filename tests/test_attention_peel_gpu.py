@@ -41,7 +41,12 @@ CASES = [
     (3, 1000, None, 0.0, 0, True),           # ragged last tile + re-centring in the loop
     (2, 2304, None, 0.0, 0, True),           # whole tiles only
     (4, 960, None, 3.0, 0, False),           # key multiplicity on tile 0
-    (4, 1024, None, 2.0, 8, False),          # periodic key multiplicity: the variant must fall back to the general loop
+    (4, 1024, None, 2.0, 8, False),          # periodic key multiplicity (sequence parallelism): the KBP instance -- key-multiplicity tiles through their own copy of the fast tile
+    (24, 3000, None, 3.0, 5, True),          # the same on the full machine: ragged last tile, re-centring, the key-split tail round (a split's first tile index is not 0)
+    (4, 1500, 700, 3.0, 3, True),            # periodic + pruned queries + ragged
+    (2, 640, None, 1.0, 1, False),           # EVERY tile a key-multiplicity tile (the inner loop of ordinary tiles stays empty)
+    (4, 960, None, 3.0, 100, False),         # a period longer than the sequence: tile 0 only
+    (24, 6336 * 2, None, 3.0, 99, False),    # two ranks' blocks of 64 text + 6272 image rows (the 8-rank bench shape's per-rank block), period 99
     (4, 1500, 700, 3.0, 0, True),            # pruned queries (S_q < S), ragged, key multiplicity
     (24, 3000, None, 0.0, 0, True),          # 288 workgroups > 256 CUs: full round + key-split tail round (both through the same instance)
     (24, 2900, 2816, 3.0, 0, False),         # the same with pruned queries and key multiplicity

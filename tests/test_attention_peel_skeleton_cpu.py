@@ -32,11 +32,12 @@ constexpr int ABL = 0;      // the kernel's timing-ablation bits (ablation build
 #define AG_TILE_BODY { ev.push_back({1, t, gs + sub, 1}); }
 #define __syncthreads() ev.push_back({2, 0, 0, 0})
 #define AG_BARRIER() __syncthreads()
-#define AG_FAST_A ev.push_back({3, u, gs, 0});
+#define AG_FAST_A(KB_) ev.push_back({3, u, gs, (int)(KB_)});
 #define AG_FAST_B(PF_) ev.push_back({4, u + 1, gs ^ 1, (PF_)});
 #define AG_LOAD_KFA(slot_) ev.push_back({5, -1, (int)(slot_), 0});
-template <bool FAST, int TPB>
+template <bool FAST, int TPB, bool KBP = false>
 static Ev run(int Sk, P p) {
+    const int tb = 0;      // first tile of this workgroup's key range (a key-split tail workgroup starts further in)
     Ev ev;
     const int nt = (Sk + AG_KVB - 1) / AG_KVB;
     const int ngrp = (nt + TPB - 1) / TPB;
@@ -48,7 +49,7 @@ static Ev run(int Sk, P p) {
 }
 static int bad = 0;
 #define FAIL(...) do { ++bad; printf(__VA_ARGS__); printf("\n"); } while (0)
-static void discipline(const Ev& ev, int Sk, int var, bool general_everywhere) {
+static void discipline(const Ev& ev, int Sk, int var, bool general_everywhere, int kb_period = 0) {
     const int nt = (Sk + 63) / 64;
     const bool rag = Sk %% 64;
     int content[2] = {-1, -1};
@@ -66,6 +67,7 @@ static void discipline(const Ev& ev, int Sk, int var, bool general_everywhere) {
         } else if (k == 1 || k == 3) {
             if (t != next) FAIL("var %%d Sk %%d: tile %%d processed, expected %%d", var, Sk, t, next);
             if (content[s] != t || requested[s]) FAIL("var %%d Sk %%d: tile %%d reads slot %%d (holds %%d, requested since the last barrier: %%d)", var, Sk, t, s, content[s], (int)requested[s]);
+            if (k == 3 && (sp != 0) != (kb_period > 0 && t %% kb_period == 0)) FAIL("var %%d Sk %%d: tile %%d takes the %%s copy of the fast tile", var, Sk, t, sp ? "key-multiplicity" : "plain");
             if (k == 3 && kfa_tile != t) FAIL("var %%d Sk %%d: fast tile %%d computes on the K fragments of tile %%d", var, Sk, t, kfa_tile);
             if (k == 1) {
                 const bool want = general_everywhere || t == 0 || (rag && t == nt - 1);
@@ -82,20 +84,16 @@ static void discipline(const Ev& ev, int Sk, int var, bool general_everywhere) {
 }
 int main() {
     int checked = 0;
-    for (int per = 0; per < 2; ++per)
+    for (int per : {0, 4, 3, 1, 7})      // key-multiplicity period in tiles (0: none): even and odd periods enter a run of ordinary tiles on odd and on even tiles
     for (int Sk = 1; Sk <= 64 * 9; Sk += (Sk %% 64 == 0 ? 1 : 21)) {
-        P p = {per ? 3.0f : (Sk %% 2 ? 0.0f : 3.0f), per ? 4 : 0};
+        P p = {per ? 3.0f : (Sk %% 2 ? 0.0f : 3.0f), per};
         const bool general_everywhere = per && p.key_bias_log2 != 0.f;
         Ev g = run<false, 1>(Sk, p);
         discipline(g, Sk, 0, true);
-        Ev v = general_everywhere ? run<false, 1>(Sk, p) : run<true, 1>(Sk, p);      // the LAUNCHER sends periodic key multiplicity to the general instance (utx_launch_attn_fwd_glds)
+        // the launcher: periodic key multiplicity -> the KBP instance of the fast kernel (key-multiplicity tiles through their own copy of the fast tile), else the plain one
+        Ev v = general_everywhere ? run<true, 1, true>(Sk, p) : run<true, 1, false>(Sk, p);
         ++checked;
-        discipline(v, Sk, 1, general_everywhere);
-        if (general_everywhere) {      // the fast kernel falls back to the general loop: event for event the same
-            if (v.size() != g.size()) { FAIL("Sk %%d per %%d: %%zu vs %%zu events", Sk, per, v.size(), g.size()); continue; }
-            for (size_t i = 0; i < g.size(); ++i)
-                if (g[i] != v[i]) { FAIL("Sk %%d per %%d event %%zu differs", Sk, per, i); break; }
-        }
+        discipline(v, Sk, 1, false, general_everywhere ? p.key_bias_period : 0);
     }
     printf("checked %%d bad %%d\n", checked, bad);
     return bad ? 1 : 0;
@@ -135,8 +133,11 @@ def test_the_skeleton_check_sees_a_broken_loop(tmp_path):
                  ("            if (1 < nt) AG_STAGE(1, 1);\n", "            if (1 < nt) AG_STAGE(1, 0);\n"),
                  ("if (!(ABL & 4) && u + 2 < nt) AG_STAGE(u + 2, gs); ", "if (!(ABL & 4) && u + 2 < nt) AG_STAGE(u + 2, gs ^ 1);"),
                  ("if constexpr (!(ABL & 8)) AG_BARRIER();", ""),
-                 ("                AG_FAST_TILE(uu + 1, 0)\n", "                AG_FAST_TILE(uu + 1, 1)\n"),
-                 ("            if (uu < fast_end_) AG_FAST_TILE(uu, 1)\n", ""),
+                 ("                AG_FAST_TILE_(uu + 1, 0, false)\n", "                AG_FAST_TILE_(uu + 1, 1, false)\n"),
+                 ("            if (uu < fast_end_) AG_FAST_TILE_(uu, 1, false)\n", ""),
+                 ("                if (uu < fast_end_) { AG_FAST_TILE_(uu, uu & 1, true) ++uu; }\n", "                if (uu < fast_end_) { AG_FAST_TILE_(uu, uu & 1, false) ++uu; }\n"),
+                 ("                if (uu < nb && !(uu & 1)) { AG_FAST_TILE_(uu, 0, false) ++uu; }", "                if (uu < nb && !(uu & 1)) { AG_FAST_TILE_(uu, 1, false) ++uu; }"),
+                 ("                if (uu < nb) { AG_FAST_TILE_(uu, 1, false) ++uu; }\n", "                if (uu < nb) { AG_FAST_TILE_(uu, 0, false) ++uu; }\n"),
                  ("        if (2 < nt) AG_STAGE(2, 0);", "        if (2 < nt) AG_STAGE(2, 1);"),
                  ("        if (1 < fast_end_) AG_LOAD_KFA(1)", "        if (1 < fast_end_) AG_LOAD_KFA(0)")]
     for i, (a, b) in enumerate(mutations):

@@ -61,7 +61,7 @@ __device__ __forceinline__ float ag_mul_nofuse(float a, float b) {
 // instead of behind a relayout pass.  Token j = block j / blk_rows, row j % blk_rows; inside a block rows are q_ss / k_ss apart and V^T rows vt_ds (= blk_rows for
 // the exchange buffer).  The staging cursor below walks tiles in order, so the block term is two scalar adds per tile; same tiles, same order, same arithmetic
 // as the contiguous form: bit-identical results.
-template <int PRESC, int TPB, int VAR, bool BLK = false, bool FAST = false>
+template <int PRESC, int TPB, int VAR, bool BLK = false, bool FAST = false, bool KBP = false>
 __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const kring = smem;
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
     // same order per element as the general loop: bit-identical (tests/test_attention_peel_gpu.py).  Measured (profiles/r05_attn_peel_ab.log, same process, interleaved): 25.86 ->
     // 23.96 ms at S = 50 240 (1199 -> 1294 TF/s), 1.851 -> 1.756 ms at 13 376.  The S1 / S2 sched_group_barrier hints are NOT used here: with them 23.99 ms (no gain), and on the
     // peeled loop with the barrier at the end they LOSE (25.27 vs 24.41 ms): they place exponentials between the QK^T(1) MFMAs, which chain on one accumulator.  Launches whose
-    // key-multiplicity tiles recur (key_bias_period > 0: sequence parallelism) keep the general loop (the launcher's choice).
+    // key-multiplicity tiles recur (key_bias_period > 0: sequence parallelism) run the KBP instance: runs of ordinary tiles in an inner loop, the key-multiplicity tile between two runs through a copy of its own.
 #define AG_EXPF(sa_, p0_, p1_, ps_, qi_)                                                             \
         if constexpr (ABL & 1) {                                                                \
             float sc0_ = 0.f, sc1_ = 0.f;                                                            \
@@ -333,13 +333,13 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
 #define AG_USE_DUMMY(x_) asm volatile("" :: "v"(x_))
 #define AG_LOAD_KFA(slot_)                                                                           \
         { _Pragma("unroll") for (int kk = 0; kk < 8; ++kk) kfa_n[kk] = *reinterpret_cast<const bf16x8*>(kring + (slot_) * AG_KTILE + kx[kk]); }
-#define AG_FAST_A                                                                                    \
+#define AG_FAST_A(KB_)                                                                               \
         {                                                                                            \
         const char* kb = kring + gs * AG_KTILE;                                                      \
         const char* vb = vring + gs * AG_VTILE;                                                      \
-        const bool ragged = false, kbias = false;   /* no such tile in this loop: AG_SLOW's branches fold */ \
+        const bool ragged = false, kbias = (KB_);   /* KB_ literal: a key-multiplicity tile of a periodic launch (sequence parallelism, KBP instance) has a straight-line copy of its own; AG_SLOW's branches fold */ \
         const int lim = 0;                                                                           \
-        const float kbv = 0.f;                                                                       \
+        const float kbv = PRESC ? p.key_bias_log2 : p.key_bias_log2 / c2;                            \
         f32x16 sa0, sa1;                                                                             \
         bf16x8 kfb[8], vfa[8], dk[8], dv[8];                                                         \
         float ps0 = 0.f, ps1 = 0.f;                                                                  \
@@ -359,6 +359,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
             if constexpr ((ABL & 32) != 0) { AG_USE_DUMMY(dk[kk]); AG_RD_DUMMY(dv[kk], vb + (kk & 3) * 4096 + vx[kk >> 2]); vfa[kk] = kfa_n[kk]; } else if constexpr (ABL & 2) vfa[kk] = kfa_n[kk]; else vfa[kk] = *reinterpret_cast<const bf16x8*>(vb + (kk & 3) * 4096 + vx[kk >> 2]); \
             if (kk == 0) { AG_MM(sa1, kfb[kk], qf[kk], negm) } else { AG_MM(sa1, kfb[kk], qf[kk], sa1) } \
         }                                                                                            \
+        if (KB_) { _Pragma("unroll") for (int r = 0; r < 16; ++r) sa0[r] += kbv; }                    \
         AG_EXPF(sa0, pb[0], pb[1], ps0, 0)                                                              \
         if (!__all(ps0 <= 8192.0f)) {                                                                \
             AG_SLOW(sa0, sa1, true, 0, 0, false)                                                     \
@@ -371,6 +372,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
             if constexpr ((ABL & 32) != 0) { AG_USE_DUMMY(dv[i]); AG_RD_DUMMY(dk[i], vb + (i & 3) * 4096 + vx[2 + (i >> 2)]); vfb_n[i] = kfa_n[i]; } else if constexpr (ABL & 2) vfb_n[i] = kfa_n[i]; else vfb_n[i] = *reinterpret_cast<const bf16x8*>(vb + (i & 3) * 4096 + vx[2 + (i >> 2)]); \
             AG_MM(oacc[i & 3], vfa[i], pb[i >> 2], oacc[i & 3])                                      \
         }                                                                                            \
+        if (KB_) { _Pragma("unroll") for (int r = 0; r < 16; ++r) sa1[r] += kbv; }                    \
         AG_EXPF(sa1, pb[2], pb[3], ps1, 2)                                                              \
         if (!__all(ps1 <= 8192.0f)) {                                                                \
             AG_SLOW(sa1, sa0, false, 8192, 32, false)                                                \
@@ -391,7 +393,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
         }                                                                                            \
         __builtin_amdgcn_s_setprio(0);                                                               \
         }
-    if (FAST && TPB == 1) {      // (the launcher sends launches with periodic key multiplicity to the general instance)
+    if (FAST && TPB == 1) {      // (the launcher sends launches with periodic key multiplicity to the KBP instance)
         const bool rag_ = (Sk & (AG_KVB - 1)) != 0;
         const int fast_end_ = rag_ ? nt - 1 : nt;                 // tiles [1, fast_end_) take the fast form
         bf16x8 kfa_n[8], vfb_n[8];
@@ -403,10 +405,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
         }
         if (2 < nt) AG_STAGE(2, 0);                               // slot 0 is free behind that barrier; from here on tile u + 2 is requested behind the barrier of tile u
         if (1 < fast_end_) AG_LOAD_KFA(1)
-#define AG_FAST_TILE(u_, gs_)                                                                        \
+#define AG_FAST_TILE_(u_, gs_, KB_)                                                                  \
         {                                                                                            \
             const int u = (u_), gs = (gs_);                                                          \
-            AG_FAST_A                                                                                \
+            AG_FAST_A(KB_)                                                                           \
             if constexpr (!(ABL & 8)) AG_BARRIER();            /* tile u + 1 has landed (the vmcnt(0) this fence carries) and is visible; every wave is done with slot gs */ \
             if (!(ABL & 4) && u + 2 < nt) AG_STAGE(u + 2, gs);                                       \
             AG_FAST_B(1)      /* always prefetches: behind the last fast tile the fragments are not used (slot gs ^ 1 then holds the ragged last tile or old data; nothing writes it) */ \
@@ -414,13 +416,31 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
         // two tiles per trip: the ring slots are literals, so every LDS address of the loop is a loop-invariant register + an immediate offset (the one-tile loop spent 20 v_add_u32 per
         // tile on them): -7 % SQ cycles, +2.7 ... 3.6 % TF/s at both operating points (profiles/r05_attn_fv_ab*.log, r05_attn_pmc_arms.log).  256 VGPRs; hipcc parks nine
         // loop-invariant dwords that only the epilogue needs in scratch AROUND the loop (40 B; nothing inside the loop touches scratch -- tests/test_asm_hazards_cpu.py checks the listing).
+        if constexpr (KBP) {
+            // periodic key multiplicity (sequence parallelism: the text tile of every rank's block, tile index % key_bias_period == 0): runs of ordinary tiles go through an inner loop of
+            // the fast tile (one per trip, run-time slot), the key-multiplicity tile between two runs through a second copy with the general body's two `scores += bias` lines in it --
+            // OUTSIDE the inner loop (both copies inside one loop made hipcc spill in it).  Same bits as the general loop.
+            const int per_ = p.key_bias_period;
+            int uu = 1;
+            while (uu < fast_end_) {
+                int nb = uu + (per_ - (tb + uu) % per_) % per_;      // the next key-multiplicity tile at or behind uu
+                if (nb > fast_end_) nb = fast_end_;
+                if (uu < nb && !(uu & 1)) { AG_FAST_TILE_(uu, 0, false) ++uu; }      // a run is entered on an odd tile: two tiles per trip with literal ring slots, as the plain instance
+                for (; uu + 1 < nb; uu += 2) {
+                    AG_FAST_TILE_(uu, 1, false)
+                    AG_FAST_TILE_(uu + 1, 0, false)
+                }
+                if (uu < nb) { AG_FAST_TILE_(uu, 1, false) ++uu; }
+                if (uu < fast_end_) { AG_FAST_TILE_(uu, uu & 1, true) ++uu; }
+            }
+        } else
         {
             int uu = 1;
             for (; uu + 1 < fast_end_; uu += 2) {
-                AG_FAST_TILE(uu, 1)
-                AG_FAST_TILE(uu + 1, 0)
+                AG_FAST_TILE_(uu, 1, false)
+                AG_FAST_TILE_(uu + 1, 0, false)
             }
-            if (uu < fast_end_) AG_FAST_TILE(uu, 1)
+            if (uu < fast_end_) AG_FAST_TILE_(uu, 1, false)
         }
         if (rag_ && nt > 1) {
             const int gs = (nt - 1) & 1, sub = 0, t = nt - 1;     // its tile was requested two tiles ago and retired by the last barrier above (or by tile 0's)
@@ -581,10 +601,10 @@ extern "C" size_t utx_attn_workspace_bytes_impl(int H, int Sq, int S, int ncu) {
     return rows * 128 * sizeof(bf16_t) + rows * sizeof(float);
 }
 
-template <int PRESC, int TPB, int VAR = 0, bool BLK = false, bool FAST = false>
+template <int PRESC, int TPB, int VAR = 0, bool BLK = false, bool FAST = false, bool KBP = false>
 static int launch_glds(AttnParams p, hipStream_t stream) {
     UTX_ONCE_PER_DEVICE(attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_glds_kernel<PRESC, TPB, VAR, BLK, FAST>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_glds_kernel<PRESC, TPB, VAR, BLK, FAST, KBP>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, AG_LDS(TPB)) != hipSuccess) return -3;
         UTX_ONCE_DONE(attr_set);
     }
@@ -598,14 +618,14 @@ static int launch_glds(AttnParams p, hipStream_t stream) {
     // tail rows, a fraction of a round slower
     const size_t rows = (size_t)r * ns * 256;
     if (ns <= 1 || !p.work || p.work_bytes < rows * (128 * sizeof(bf16_t) + sizeof(float))) {
-        hipLaunchKernelGGL((attn_fwd_glds_kernel<PRESC, TPB, VAR, BLK, FAST>), dim3(nwg), dim3(512), AG_LDS(TPB), stream, p);
+        hipLaunchKernelGGL((attn_fwd_glds_kernel<PRESC, TPB, VAR, BLK, FAST, KBP>), dim3(nwg), dim3(512), AG_LDS(TPB), stream, p);
         return hipGetLastError() == hipSuccess ? 0 : -4;
     }
-    hipLaunchKernelGGL((attn_fwd_glds_kernel<PRESC, TPB, VAR, BLK, FAST>), dim3(nfull), dim3(512), AG_LDS(TPB), stream, p);
+    hipLaunchKernelGGL((attn_fwd_glds_kernel<PRESC, TPB, VAR, BLK, FAST, KBP>), dim3(nfull), dim3(512), AG_LDS(TPB), stream, p);
     AttnParams t = p;
     t.w_base = nfull; t.nsplit = ns; t.tiles_per_split = tps;
     t.part_o = (bf16_t*)p.work; t.part_lse = (float*)((char*)p.work + rows * 128 * sizeof(bf16_t));
-    hipLaunchKernelGGL((attn_fwd_glds_kernel<PRESC, TPB, VAR, BLK, FAST>), dim3(r * ns), dim3(512), AG_LDS(TPB), stream, t);
+    hipLaunchKernelGGL((attn_fwd_glds_kernel<PRESC, TPB, VAR, BLK, FAST, KBP>), dim3(r * ns), dim3(512), AG_LDS(TPB), stream, t);
     const long mt = (long)r * 256 * 16;
     hipLaunchKernelGGL(attn_merge_kernel, dim3((unsigned)((mt + 255) / 256)), dim3(256), 0, stream, t, r);
     return hipGetLastError() == hipSuccess ? 0 : -4;
@@ -646,8 +666,9 @@ extern "C" int utx_launch_attn_fwd_glds(const AttnParams* p, int presc, hipStrea
       if (var == 7 && presc) return launch_glds<1, 1, 7>(*p, stream); }    // 16-byte epilogue stores through v_permlane32_swap (correct results)
 #endif
     // the pre-scaled form the DiT uses: the fast loop (FAST above); UTX_ATTN_PEEL=0: the general loop, the default until round 5 (A/B and the reference bits of the stress tests)
-    // launches whose key-multiplicity tiles recur (key_bias_period > 0: sequence parallelism) keep the general loop: a second copy of the fast tile for those tiles inside the loop made
-    // hipcc spill in it (round 5: 45 scratch accesses per trip with one tile per trip, 293 with two)
-    if (presc && g_utx_opt.attn_peel != 0 && !(p->key_bias_period > 0 && p->key_bias_log2 != 0.f)) return launch_glds<1, 1, 0, false, true>(*p, stream);
+    // launches whose key-multiplicity tiles recur (key_bias_period > 0: sequence parallelism): the KBP instance (a loop nest: a second copy of the fast tile for those tiles INSIDE the
+    // loop made hipcc spill in it -- 45 scratch accesses per trip with one tile per trip, 293 with two)
+    if (presc && g_utx_opt.attn_peel != 0 && (p->key_bias_period > 0 && p->key_bias_log2 != 0.f)) return launch_glds<1, 1, 0, false, true, true>(*p, stream);
+    if (presc && g_utx_opt.attn_peel != 0) return launch_glds<1, 1, 0, false, true>(*p, stream);
     return presc ? launch_glds<1, 1>(*p, stream) : launch_glds<0, 1>(*p, stream);
 }

@@ -1,7 +1,8 @@
 """Arithmetic model of ONE denoise step under head-parallel sequence parallelism (flux/ulysses.py) on an xGMI node -- what the first
 multi-GPU SCALE run is to be compared with.  Pure host arithmetic, no device.
 
-Inputs that are MEASURED on one MI355X (bench.py, profiles/r03_bench_strip1024x6_v1.json.log, S = 50 688 tokens, 57 layers):
+Inputs that are MEASURED on one MI355X (bench.py; round 3: profiles/r03_bench_strip1024x6_v1.json.log, S = 50 688 tokens, 57 layers; the DEFAULTS are round 5's, MEASURED_1GPU below:
+step 1909.0 ms = 57 x 23.58 + 497 + the rest -> predicted 1.83 x / 3.53 x / 6.99 x, steps 1043 / 541 / 273 ms):
     step 1998.9 ms = attention 57 x 25.47 ms (utx_attn_fwd_bf16) + large-M GEMMs 515.4 ms (roofline_gemm.sum_ms_per_step)
                      + 31.7 ms of everything else (LayerNorm-modulation, q/k post-processing, text-side GEMMs, GEMVs, launch gaps)
 Inputs that are ASSUMED (the fabric has never been measured by this repo -- no multi-GPU box in reach):
@@ -27,7 +28,11 @@ import math
 
 D, HEADS, LAYERS, N_DOUBLE, N_SINGLE = 3072, 24, 57, 19, 38
 
-MEASURED_1GPU = dict(step_ms=1998.9, attn_ms_per_layer=25.47, gemm_ms_per_step=515.4, replicated_ms=1.5, sp_unpack_ms_per_step=27.6, attn_corun_factor=1.013)
+MEASURED_1GPU_R03 = dict(step_ms=1998.9, attn_ms_per_layer=25.47, gemm_ms_per_step=515.4, replicated_ms=1.5, sp_unpack_ms_per_step=27.6, attn_corun_factor=1.013)      # the round-3 inputs the docstring quotes
+# ROUND 5 (profiles/r05_bench_strip1024x6_v2.json.log, r05_attn_kbp_ab_v2.log): step 1909.0 ms = attention 57 x 23.58 ms (the fast loop, two tiles per trip) + GEMMs 497 ms + the rest.
+# Under sequence parallelism the launches carry periodic key multiplicity and run the fast loop's KBP instance (the same two-tile loop over the runs of ordinary tiles, key-multiplicity
+# tiles through a copy of their own): 1335 / 1337 TF/s at the 4- / 8-rank per-rank shapes against 1330 for the plain instance on the same box -> no extra factor.
+MEASURED_1GPU = MEASURED_1GPU_R05 = dict(step_ms=1909.0, attn_ms_per_layer=23.58, gemm_ms_per_step=497.0, replicated_ms=1.5, sp_unpack_ms_per_step=27.6, attn_corun_factor=1.013)
 # the large-M GEMMs lose efficiency as M = S / P shrinks (fewer rounds of 256 x 256 tiles per launch, a larger share of fill / epilogue): bf16 TF/s at
 # M = 13 824 vs 50 688 on the FLUX shapes, same process (profiles/r03_perf_fp8_v0.log, bf16 column): 1224 / 1360, 1326 / 1292, 1241 / 1337 -> ~0.93 at a
 # quarter of the rows; 0.97 at half and 0.85 at an eighth are interpolated / extrapolated, not measured
