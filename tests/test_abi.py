@@ -90,3 +90,21 @@ def test_bit_exact_kernels_are_built_without_fp_contraction():
     assert not re.search(r"\bfloat\b|\bdouble\b", body), "unwrap.hip is outside the no-contraction set because it has no floating-point arithmetic"
     mk = open(os.path.join(here, "oracle", "Makefile")).read()
     assert "-ffp-contract=off" in mk, "the C oracle must be built without contraction as well"
+
+
+def test_bvh_workspace_build_refuses_a_bad_workspace_before_touching_the_device():
+    """utx_bvh_build_ws (round 5): the caller provides every byte of the tree.  Size query monotone in the face count; a misaligned or short workspace is refused with -2
+    before any device call (so this runs without a GPU)."""
+    import ctypes as C
+    from unitex_amd import _lib
+    lib = _lib.load_library()
+    sizes = [int(lib.utx_bvh_workspace_bytes(F)) for F in (0, 1, 2, 1000, 50000, 200000)]
+    assert sizes[0] == 0 and all(a <= b for a, b in zip(sizes[1:], sizes[2:])) and sizes[4] >= 50000 * (2 * 3 * 4 + 2 * 6 * 4 + 6 * 4 + 16 + 2 * 4 + 4 + 2 * 32 + 48)
+    buf = (C.c_char * 8192)()
+    base = (C.addressof(buf) + 255) & ~255
+    v, f, h = (C.c_float * 9)(), (C.c_int * 3)(0, 1, 2), C.c_void_p()
+    assert lib.utx_bvh_build_ws(None, v, 3, f, 1, C.c_void_p(base | 16), C.c_size_t(4096), C.byref(h), None) == -2      # not 256-byte aligned
+    assert lib.utx_bvh_build_ws(None, v, 3, f, 1, C.c_void_p(base), C.c_size_t(sizes[1] - 1), C.byref(h), None) == -2   # one byte short
+    assert lib.utx_bvh_build_ws(None, v, 3, f, 0, C.c_void_p(base), C.c_size_t(4096), C.byref(h), None) == -2           # no faces
+    assert lib.utx_bvh_build_ws(None, v, 3, f, 1, None, C.c_size_t(4096), C.byref(h), None) == -2                        # no workspace
+    assert not h.value
