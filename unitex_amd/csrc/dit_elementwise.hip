@@ -72,36 +72,16 @@ __global__ __launch_bounds__(256) void qkv_post_kernel(QkvPostParams p) {
             }
 #pragma unroll
             for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);     // the 16 lanes of this token row
-            float rstd = 1.0f / sqrtf(ss / 128.0f + p.eps);
-#ifdef UTX_QKV_RSTD_FENCE      // tools/build_variant.py (round 5, two-stream investigation): wait states between the division's last instruction and the first (packed) consumer of rstd
-            asm volatile("s_nop 3" : "+v"(rstd));
-#endif
-#ifdef UTX_QKV_QS_VGPR      // tools/build_variant.py (round 5, two-stream investigation): the q scale through a VGPR instead of as the SGPR source operand of a packed multiply
-            float qsv_;
-            asm volatile("v_mov_b32 %0, %1" : "=v"(qsv_) : "s"(p.q_scale));
-            const float qs = which ? 1.0f : qsv_;
-#else
+            const float rstd = 1.0f / sqrtf(ss / 128.0f + p.eps);
             const float qs = which ? 1.0f : p.q_scale;
-#endif
             uint32_t ow[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const float w0 = which ? wk[2 * c] : wq[2 * c], w1 = which ? wk[2 * c + 1] : wq[2 * c + 1];
                 const float a0 = rbf(rbf(x[2 * c] * rstd) * w0);
                 const float a1 = rbf(rbf(x[2 * c + 1] * rstd) * w1);
-#ifdef UTX_QKV_PROD_FENCE      // tools/build_variant.py (round 5, two-stream investigation): wait states between the four products and the two sums that combine them across the packed halves
-                float p0_ = a0 * csv[c], p1_ = (-a1) * snv[c], p2_ = a1 * csv[c], p3_ = a0 * snv[c];
-#if UTX_QKV_PROD_FENCE == 2      // the same re-association point without wait states: an empty statement
-                asm volatile("" : "+v"(p0_), "+v"(p1_), "+v"(p2_), "+v"(p3_));
-#else
-                asm volatile("s_nop 3" : "+v"(p0_), "+v"(p1_), "+v"(p2_), "+v"(p3_));
-#endif
-                const float r0 = (p0_ + p1_) * qs;
-                const float r1 = (p2_ + p3_) * qs;
-#else
                 const float r0 = (a0 * csv[c] + (-a1) * snv[c]) * qs;
                 const float r1 = (a1 * csv[c] + a0 * snv[c]) * qs;
-#endif
                 ow[c] = pack2bf(r0, r1);
             }
             bf16_t* dst = (bf16_t*)(which ? p.Kh : p.Qh) + hoff_qk + srow * 128 + 8 * sub;
