@@ -390,273 +390,13 @@ def test_full_width_dit_blocks_at_config1_shape_match_oracle():
         torch.cuda.synchronize()
         return o_
     try:
-        # STRICT (round 4): the one-off one-ulp difference of round 3 is explained and fixed -- the compiler had placed copies of the cos / sin registers in
-        # front of the ragged-tile branch's `s_waitcnt vmcnt(0)` in the fused epilogue (the single block's M = 9280 has a ragged last row of tiles); the wait
-        # macros no longer allow that and tests/test_asm_hazards_cpu.py audits every build's listing.  A first mismatch fails.
+        # STRICT (round 4; restored for real in round 6 -- a botched splice had left the lenient round-3 body as the definition pytest ran): the one-off one-ulp difference
+        # of round 3 is explained and fixed -- the compiler had placed copies of the cos / sin registers in front of the ragged-tile branch's `s_waitcnt vmcnt(0)` in the
+        # fused epilogue (the single block's M = 9280 has a ragged last row of tiles); the wait macros no longer allow that and tests/test_asm_hazards_cpu.py audits
+        # every build's listing.  A first mismatch fails: no re-run, no warning.
         out2 = rerun(False)
         assert torch.equal(out2, out), "fused q / k epilogue changed the forward: max |d| %g in %d elements" % ((out2 - out).abs().max().item(), int((out2 != out).sum()))
-    finally:
-        _lib.set_option("UTX_GEMM_STREAMK", 1)
-    torch.cuda.synchronize()
-    assert _same_bits(s1, s2), "split tail round is not deterministic"
-    ntn, tiles = N // 256, ((M + 255) // 256) * (N // 256)
-    ncu = torch.cuda.get_device_properties(0).multi_processor_count
-    T = tiles % ncu
-    assert tiles > ncu and T > 0, "shape does not exercise the split (tiles %d, CUs %d)" % (tiles, ncu)
-    diff = (s1 != base)
-    assert bool(diff.any()), "the split launch has the bits of the unsplit one everywhere: the tail round was not split"
-    # tiles are numbered in groups of 4 row-tiles x all column tiles, column-major inside a group (gemm_w4.hip W4_TILE_ORIGIN); the tail tiles are the
-    # last T of that order.  Everything else must be untouched.
-    ntm, gm = (M + 255) // 256, (2 if ntn >= 64 else 8 if ntn >= 32 else 4)      # the launcher's default UTX_GEMM_GROUP_M by output width
-    tail = torch.zeros(ntm, ntn, dtype=torch.bool)
-    for w in range(tiles - T, tiles):
-        grp, rem = divmod(w, gm * ntn)
-        gs = min(gm, ntm - grp * gm)
-        tn, tm = divmod(rem, gs)
-        tail[grp * gm + tm, tn] = True
-    dt = diff.cpu()
-    dt = torch.nn.functional.pad(dt, (0, 0, 0, ntm * 256 - M)).view(ntm, 256, ntn, 256).any(3).any(1)
-    assert not bool((dt & ~tail).any()), "a tile outside the last round changed"
-    # rounding only: the GEMM value moves by at most one bf16 ulp (2^-7 relative; x |gate|, GELU' <= 1.13 on top -> 2^-6 of the pre-residual
-    # value), and the gated residual sum is rounded once more (2^-7 of the output)
-    y0 = (base.float() - res.float()) if kind == "gate" else base.float()
-    y1 = (s1.float() - res.float()) if kind == "gate" else s1.float()
-    bound = 2.0 ** -6 * torch.maximum(y0.abs(), y1.abs()).clamp_min(1.0)
-    if kind == "gate":
-        bound = bound + 2.0 ** -7 * torch.maximum(base.float().abs(), s1.float().abs())
-    assert bool(((s1.float() - base.float()).abs() <= bound).all()), "split tail differs from the unsplit launch by more than rounding"
-    rows = torch.tensor([0, 255, M // 2 + 17, M - 300, M - 2, M - 1])
-    y = A[rows].float().cpu() @ W.float().cpu().t()
-    if K2:
-        y += kw["A2"][rows].float().cpu() @ kw["B2"].float().cpu().t()
-    y = (y + bias.float().cpu()).to(BF).float()
-    if kind == "gelu":
-        y = dit_ref.gelu_tanh(y).to(BF).float()
-    if kind == "gate":
-        y = (res[rows].float().cpu() + (gate.float().cpu() * y).to(BF).float()).to(BF).float()
-    rel = ((s1[rows].float().cpu() - y).abs() / y.abs().clamp_min(1.0)).max().item()
-    assert rel < 1.6e-2, "split tail vs oracle rows: %g" % rel
-
-
-@pytest.mark.parametrize("M,N,K,K2,S,kind", [(13376, 3072, 512, 512, 2, "gate"), (13376, 3072, 512, 512, 3, "gate"), (13001, 3072, 192, 64, 4, "plain"),
-                                             (13376, 3072, 320, 128, 4, "gate"), (13824, 3072, 576, 0, 3, "plain")])
-def test_gemm_split_tail_forced_range_shapes(M, N, K, K2, S, kind):
-    """UTX_GEMM_STREAMK = 1000 + S forces S ranges per tail tile on shapes the launcher's cost model never splits -- the range geometries of
-    gemm_w4.hip's staging cursor: a range that IS the LoRA segment (K = K2 = 512, S = 2), ranges that straddle the base -> LoRA switch and start
-    inside the LoRA segment at an odd K-tile (S = 3), ranges of ONE K-tile (K = 192 + 64, S = 4), four ranges of unequal length over 7 K-tiles in two passes of the grid, and
-    136 tail tiles x 3 ranges in two passes of the grid (M = 13 824).  Same contract as the test below."""
-    from unitex_amd import _lib
-    ops = _ops()
-    g = torch.Generator(device="cuda").manual_seed(M + N + K + S)
-    A = (torch.randn(M, K, device="cuda", generator=g) / 2).to(BF)
-    W = (torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K)).to(BF)
-    bias = torch.randn(N, device="cuda", generator=g).to(BF)
-    kw = {}
-    if K2:
-        kw.update(A2=(torch.randn(M, K2, device="cuda", generator=g) / 8).to(BF), B2=(torch.randn(N, K2, device="cuda", generator=g) / 4).to(BF))
-    res = torch.randn(M, N, device="cuda", generator=g).to(BF)
-    gate = torch.randn(N, device="cuda", generator=g).to(BF)
-
-    def run():
-        if kind == "gate":
-            r = res.clone()
-            ops.gemm(A, W, bias=bias, out=r, gate=gate, res=r, **kw)
-            return r
-        return ops.gemm(A, W, bias=bias, **kw)
-    try:
-        _lib.set_option("UTX_GEMM_STREAMK", 0)
-        base = run()
-        _lib.set_option("UTX_GEMM_STREAMK", 1000 + S)
-        s1 = run()
-        s2 = run()
-    finally:
-        _lib.set_option("UTX_GEMM_STREAMK", 1)
-    torch.cuda.synchronize()
-    assert _same_bits(s1, s2), "forced split is not deterministic"
-    assert bool((s1 != base).any()), "the forced split has the bits of the unsplit launch everywhere: nothing was split"
-    y0 = (base.float() - res.float()) if kind == "gate" else base.float()
-    y1 = (s1.float() - res.float()) if kind == "gate" else s1.float()
-    bound = 2.0 ** -6 * torch.maximum(y0.abs(), y1.abs()).clamp_min(1.0)
-    if kind == "gate":
-        bound = bound + 2.0 ** -7 * torch.maximum(base.float().abs(), s1.float().abs())
-    assert bool(((s1.float() - base.float()).abs() <= bound).all()), "forced split differs from the unsplit launch by more than rounding"
-    frac = float((s1 != base).float().mean())
-    assert frac < 0.02, "a forced split changes rounding in a few elements of the tail tiles only, not %.3f of the output" % frac
-
-
-@pytest.mark.parametrize("M", [S_FULL, 13824, 6336])   # 6336 = 50688 / 8: ragged last 256-row tile (sequence-parallel shard)
-def test_gemm_full_size_kernels_agree_bitwise_and_match_oracle_rows(M):
-    ops = _ops()
-    D, R = 3072, 64
-    g = torch.Generator(device="cuda").manual_seed(M)
-    x = (torch.randn(M, D, device="cuda", generator=g) / 2).to(BF)
-    # (1) fused single-stream projection: [q|k|v|mlp] with LoRA K-segment on q,k,v, GELU on mlp, column split
-    N = 3 * D + 4 * D
-    W = (torch.randn(N, D, device="cuda", generator=g) / math.sqrt(D)).to(BF)
-    bias = torch.randn(N, device="cuda", generator=g).to(BF)
-    T = (torch.randn(M, 3 * R, device="cuda", generator=g) / 8).to(BF)
-    Bl = torch.zeros(N, R, dtype=BF, device="cuda")
-    Bl[:3 * D] = (torch.randn(3 * D, R, device="cuda", generator=g) / 4).to(BF)
-
-    def fused():
-        c0 = torch.empty(M, 3 * D, dtype=BF, device="cuda")
-        c1 = torch.empty(M, 4 * D, dtype=BF, device="cuda")
-        ops.gemm(x, W, bias=bias, out=c0, A2=T, B2=Bl, lora_n_limit=3 * D, lora_seg_n=D, gelu_from=3 * D, n_split=3 * D, C1=c1)
-        return torch.cat([c0, c1], 1)
-    o = _gemm_variants(fused)
-    assert all(_same_bits(o[k], o["128"]) for k in ("2562", "256", "2560", "2564")), "fused qkv|mlp: kernels disagree"
-    rows = torch.tensor([0, 255, 256, 1000, M // 2 + 17, M - 1])
-    # oracle arithmetic (fp32 on the CPU, bf16 rounding at the same tensor boundaries) on the sampled rows
-    y = x[rows].float().cpu() @ W.float().cpu().t()
-    for si in range(3):
-        y[:, si * D:(si + 1) * D] += T[rows].float().cpu()[:, si * R:(si + 1) * R] @ Bl.float().cpu()[si * D:(si + 1) * D].t()
-    y = (y + bias.float().cpu()).to(BF).float()
-    y[:, 3 * D:] = dit_ref.gelu_tanh(y[:, 3 * D:]).to(BF).float()
-    rel = ((o["256"][rows].float().cpu() - y).abs() / y.abs().clamp_min(1.0)).max().item()
-    assert rel < 1.6e-2, "fused qkv|mlp vs oracle rows: %g" % rel
-    del o
-    # (2) out-projection with the K = 15360 concat input and the gated residual epilogue
-    cat = (torch.randn(M, 5 * D, device="cuda", generator=g) / 4).to(BF)
-    Wo = (torch.randn(D, 5 * D, device="cuda", generator=g) / math.sqrt(5 * D)).to(BF)
-    bo = torch.randn(D, device="cuda", generator=g).to(BF)
-    gate = torch.randn(D, device="cuda", generator=g).to(BF)
-    res = torch.randn(M, D, device="cuda", generator=g).to(BF)
-
-    def gated():
-        r = res.clone()
-        ops.gemm(cat, Wo, bias=bo, out=r, gate=gate, res=r)
-        return r
-    o = _gemm_variants(gated)
-    assert all(_same_bits(o[k], o["128"]) for k in ("2562", "256", "2560", "2564")), "gated residual: kernels disagree"
-    yy = ((cat[rows].float().cpu() @ Wo.float().cpu().t()) + bo.float().cpu()).to(BF).float()
-    yy = (res[rows].float().cpu() + (gate.float().cpu() * yy).to(BF).float()).to(BF).float()
-    rel = ((o["256"][rows].float().cpu() - yy).abs() / yy.abs().clamp_min(1.0)).max().item()
-    assert rel < 1.6e-2, "gated residual vs oracle rows: %g" % rel
-
-
-@pytest.mark.parametrize("M,N,K,K2", [(3500, 3584, 192, 64), (3584, 3584, 64, 0), (7000, 2048, 320, 128), (4096, 12544, 128, 64)])
-def test_gemm_persistent_kernel_edge_shapes_bit_identical_to_tiled_kernels(M, N, K, K2):
-    """the persistent continuous-stream kernels (gemm_w4.hip: default for >= 192 tiles of 256 x 256; gemm_pers.hip) at the shapes that stress their tile
-    boundary logic: ragged M (rows >= M in the last tile row, including waves with no valid row), an ODD number of K-tiles per
-    tile (K = 192, and 48 + 1 style LoRA segments: the stream re-enters at odd LDS parity), a single K-tile per tile (K = 64:
-    every K-tile is first and last), tiles with and without the LoRA segment in one launch, GELU / column split on a tile
-    boundary, and the gated residual updated IN PLACE (res aliases C).  All five kernels (incl. the one-wave-per-SIMD kernel of
-    gemm_w4.hip, whose stream unit is a 64-k K-tile: K = 64 is ONE K-tile per tile -- every K-tile first and last --, and its ragged-M gated slow
-    path) must agree bit for bit."""
-    ops = _ops()
-    g = torch.Generator(device="cuda").manual_seed(M + N + K)
-    A = (torch.randn(M, K, device="cuda", generator=g) / 2).to(BF)
-    W = (torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K)).to(BF)
-    bias = torch.randn(N, device="cuda", generator=g).to(BF)
-    n_lim = (N // 512) * 256           # LoRA on the first half of the column tiles only
-    kw = {}
-    if K2:
-        T = (torch.randn(M, K2, device="cuda", generator=g) / 8).to(BF)
-        Bl = torch.zeros(N, K2, dtype=BF, device="cuda")
-        Bl[:n_lim] = (torch.randn(n_lim, K2, device="cuda", generator=g) / 4).to(BF)
-        kw = dict(A2=T, B2=Bl, lora_n_limit=n_lim, lora_seg_n=n_lim)
-    split = (N // 768) * 256
-
-    def plain():
-        c0 = torch.full((M, split), 7.0, dtype=BF, device="cuda")
-        c1 = torch.full((M, N - split), 7.0, dtype=BF, device="cuda")
-        ops.gemm(A, W, bias=bias, out=c0, gelu_from=split, n_split=split, C1=c1, alpha=0.75, **kw)
-        return torch.cat([c0, c1], 1)
-    o = _gemm_variants(plain)
-    assert all(_same_bits(o[k], o["128"]) for k in ("2562", "256", "2560", "2564")), "plain / GELU / split epilogue: kernels disagree"
-    ref = (0.75 * (A.float() @ W.float().t() + ((kw["A2"].float() @ kw["B2"].float().t()) if K2 else 0.0)) + bias.float()).to(BF).float()
-    ref[:, split:] = dit_ref.gelu_tanh(ref[:, split:].cpu()).to(BF).float().cuda()
-    rel = ((o["2560"].float() - ref).abs() / ref.abs().clamp_min(1.0)).max().item()
-    assert rel < 1.6e-2, "persistent kernel vs fp32 reference: %g" % rel
-    gate = torch.randn(N, device="cuda", generator=g).to(BF)
-    res = torch.randn(M, N, device="cuda", generator=g).to(BF)
-
-    def gated():
-        r = res.clone()
-        ops.gemm(A, W, bias=bias, out=r, gate=gate, res=r, **kw)
-        return r
-    o = _gemm_variants(gated)
-    assert all(_same_bits(o[k], o["128"]) for k in ("2562", "256", "2560", "2564")), "gated residual (in place): kernels disagree"
-    # repeated launches: the stream has no state that survives a launch
-    again = gated()
-    assert _same_bits(again, o["2560"])
-    # the alternative DMA placement of the persistent kernel (UTX_GEMM_PERS_SCHED) computes the same bits
-    from unitex_amd import _lib
-    try:
-        _set_tile("2560")
-        for forced in (1, 2):       # both DMA placements of the persistent kernel, whatever the shape heuristic picked above
-            _lib.set_option("UTX_GEMM_PERS_SCHED", forced)
-            assert _same_bits(gated(), o["2560"])
-    finally:
-        _lib.set_option("UTX_GEMM_PERS_SCHED", 0)
-        _set_tile(None)
-
-
-def test_full_width_dit_blocks_at_config1_shape_match_oracle():
-    """BASELINE.json configs[0] shape (512^2 x 4 views: 4096 noise + 4096 control + 1024 dual + 512 text = 9728 tokens) at
-    the real FLUX width (D = 3072, 24 heads, joint_dim 4096, rank-64 LoRA), depth cut to 1 double + 1 single block so
-    the fp32 CPU oracle finishes in seconds.  This is the shape at which every large-M kernel choice (8-phase GEMM,
-    fused LoRA K-segment, split / GELU / gated epilogues, 24-head attention) is the production one."""
-    from unitex_amd.flux.transformer import FluxDiT, FluxShape
-    cfg = dit_ref.FluxConfig(num_double=1, num_single=1)
-    sd = dit_ref.make_synthetic_state_dict(cfg, seed=0)
-    shape = FluxShape(num_double=1, num_single=1)
-    S_txt = 512
-    ids = [dit_ref.latent_image_ids(32, 128), dit_ref.latent_image_ids(32, 128, offset_y=32),
-           dit_ref.latent_image_ids(32, 32, offset_x=128, offset_y=32)]
-    img_ids = torch.cat(ids, 0)
-    S_img = img_ids.shape[0]
-    assert S_txt + S_img == 9728
-    g = torch.Generator().manual_seed(63)
-    lat = torch.randn(S_img, 64, generator=g).to(BF)
-    enc = torch.zeros(S_txt, cfg.joint_dim).to(BF)              # the reference feeds zero prompt embeddings
-    pooled = torch.zeros(1, cfg.pooled_dim).to(BF)
-    txt_ids = torch.zeros(S_txt, 3)
-    la = dit_ref.make_synthetic_lora(cfg, sd, rank=64, seed=2)
-    lb = dit_ref.make_synthetic_lora(cfg, sd, rank=64, seed=3)
-    loras = [(la, 1.0), (lb, 0.0)]
-    m = FluxDiT(sd, shape, device="cuda:0")
-    m.fuse_qk = True            # opt-in (UTX_FUSE_QK=1): q / k post-processing inside the QKV projections' epilogue
-    from unitex_amd import _lib
-    _lib.set_option("UTX_GEMM_STREAMK", 0)      # the bit-comparison below spans a fused (never split) and an unfused (tail round split) QKV projection
-    m.set_lora(loras)
-    m.set_positions(txt_ids, img_ids)
-    m.set_conditioning(enc.cuda(), pooled.cuda(), 3.5)
-    out = m.forward(lat.cuda(), 0.4375).float().cpu()
-    torch.cuda.synchronize()
-    torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 64)))
-    ref = dit_ref.flux_forward(sd, cfg, lat.float(), enc.float(), pooled.float(), 0.4375, 3.5, txt_ids, img_ids,
-                               loras=loras, emulate_bf16=True)
-    err = (out - ref).abs().max().item()
-    mx = ref.abs().max().item()
-    assert torch.isfinite(out).all()
-    assert err < 0.03 * max(mx, 1.0), "full-width DiT blocks: err %g (ref max %g)" % (err, mx)
-    assert (out - ref).abs().mean().item() < 0.004 * max(mx, 1.0)
-    # the forward above ran with q / k post-processing fused into the QKV projections (these shapes take the one-wave-per-SIMD GEMM);
-    # GEMM -> utx_qkv_post must give the same bits
-    fused_gemms = sum(1 for fn, d in _flat_plan(m) if fn is m.lib.utx_gemm_bf16 and d.qk_cols > 0)
-    assert fused_gemms == 2, "expected the image-stream QKV projection of the double block and the single block's projection to be fused, got %d" % fused_gemms
-    def rerun(fused):
-        m.fuse_qk = fused
-        m._drop_plans()
-        m.set_conditioning(enc.cuda(), pooled.cuda(), 3.5)
-        assert (sum(1 for fn, d in _flat_plan(m) if fn is m.lib.utx_gemm_bf16 and d.qk_cols > 0) == 2) == fused
-        o_ = m.forward(lat.cuda(), 0.4375).float().cpu()
-        torch.cuda.synchronize()
-        return o_
-    try:
-        out2 = rerun(False)
-        if not torch.equal(out2, out):
-            # Seen ONCE in ~15 runs of this test (end of round 3, inside a full-suite run; never alone): a one-ulp difference between the fused and the
-            # unfused plan.  Classify before failing: the DEFAULT (unfused) path must reproduce itself bit for bit -- that is the property the product
-            # relies on -- and the fused (opt-in, UTX_FUSE_QK=1) plan must then agree with it on a second run; a difference that repeats is a real one.
-            d1 = (out2 - out).abs().max().item()
-            out2b, outb = rerun(False), rerun(True)
-            assert torch.equal(out2b, out2), "the default (unfused) plan does not reproduce itself: max |d| %g" % (out2b - out2).abs().max().item()
-            assert torch.equal(outb, out2), "fused q / k epilogue changed the forward: max |d| %g (first run %g)" % ((outb - out2).abs().max().item(), d1)
-            import warnings
-            warnings.warn("fused q / k epilogue (opt-in): the FIRST fused forward differed from the unfused plan by max |d| %g in %d elements and a second "
-                          "fused forward did not -- a one-off, not reproduced" % (d1, int((out2 != out).sum())))
+        print("STRICT fused-vs-unfused comparison executed: %d elements bit-identical" % out.numel())
     finally:
         _lib.set_option("UTX_GEMM_STREAMK", 1)
     # and with the split tail round of the large GEMMs (the default): same forward up to fp32 summation order in the tail tiles

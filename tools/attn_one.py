@@ -13,5 +13,5 @@ S, H = int(sys.argv[1]) if len(sys.argv) > 1 else 50240, 24
 q = (torch.randn(H, S, 128, device="cuda") * 0.1275).to(torch.bfloat16); k = torch.randn(H, S, 128, device="cuda").to(torch.bfloat16)
 vt = torch.randn(H, 128, S, device="cuda").to(torch.bfloat16); out = torch.empty(S, H * 128, dtype=torch.bfloat16, device="cuda")
 for _ in range(3):
-    ops.attention(q, k, vt, S=S, out=out, scale=0.0, key_bias_log2=0.0 if abl else 3.0)
+    ops.attention(q, k, vt, S=S, out=out, scale=0.0, key_bias_log2=0.0 if (abl or os.environ.get("UTX_ONE_KB", "1") == "0") else 3.0)
 torch.cuda.synchronize()

@@ -6,13 +6,13 @@ OUT=$1; shift
 R=$PWD; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 for arm in "$@"; do
   name=${arm%%:*}; envs=${arm#*:}; envs=${envs//,/ }
-  env $envs timeout 200 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $R/$OUT/$name -o run -- python $R/tools/attn_one.py > $R/$OUT/$name.log 2>&1
+  env $envs timeout 200 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $R/$OUT/$name -o run -- python $R/tools/attn_one.py ${UTX_ONE_S:-50240} > $R/$OUT/$name.log 2>&1
 done
 cd $R
 python - "$OUT" "$@" <<'PY'
 import csv, glob, collections, sys
 out = sys.argv[1]
-print("%-22s %8s %7s %10s %10s %10s %10s %10s %10s %10s" % ("arm", "ms", "GHz", "busy_cyc/CU", "wave_cyc", "wait_any", "wait_inst", "active", "mfma_busy%", "valu_act"))
+print("%-22s %8s %7s %10s %10s %10s %10s %10s %10s %10s %10s" % ("arm", "ms", "GHz", "cyc/CU", "wave_cyc", "wait_any", "wait_inst", "active", "mfma_busy%", "valu_act", "lds_idx"))
 for arm in sys.argv[2:]:
     name = arm.split(":")[0]
     dur = {}
@@ -32,6 +32,6 @@ for arm in sys.argv[2:]:
     ms = sum(d[1][1] for d in big) / len(big) / 1e6
     ghz = agg["GRBM_GUI_ACTIVE"] / 8.0 / (ms * 1e6)
     cyc = ms * 1e6 * ghz
-    print("%-22s %8.3f %7.3f %10.4g %10.4g %10.4g %10.4g %10.4g %9.1f%% %10.4g" % (name, ms, ghz, cyc, agg["SQ_WAVE_CYCLES"], agg["SQ_WAIT_ANY"], agg["SQ_WAIT_INST_ANY"], agg["SQ_ACTIVE_INST_ANY"],
-          100.0 * agg["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024.0), agg["SQ_ACTIVE_INST_VALU"]))
+    print("%-22s %8.3f %7.3f %10.4g %10.4g %10.4g %10.4g %10.4g %9.1f%% %10.4g %10.4g" % (name, ms, ghz, cyc, agg["SQ_WAVE_CYCLES"], agg["SQ_WAIT_ANY"], agg["SQ_WAIT_INST_ANY"], agg["SQ_ACTIVE_INST_ANY"],
+          100.0 * agg["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024.0), agg["SQ_ACTIVE_INST_VALU"], agg["SQ_LDS_IDX_ACTIVE"]))
 PY
