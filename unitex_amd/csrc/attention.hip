@@ -447,24 +447,12 @@ extern "C" int utx_launch_attn_fwd_blk(const void* q, const void* k, const void*
     p.key_bias_log2 = key_bias_log2; p.key_bias_period = key_bias_period;
     p.work = work; p.work_bytes = work_bytes;
     p.blk_rows = blk_rows; p.q_bs = q_bs; p.k_bs = k_bs; p.vt_bs = vt_bs;
-    if (blk_rows > 0 && (g_utx_opt.attn_glds == 0 || g_utx_opt.attn_q64 == 1 || g_utx_opt.attn_tpb != 1)) return -2;
-    // key multiplicity and a query count below the key count exist in the default (LDS-DMA staged) kernel only
-    if ((key_bias_log2 != 0.f || Sq != 0) && (g_utx_opt.attn_glds == 0 || g_utx_opt.attn_q64 == 1 || g_utx_opt.attn_tpb != 1)) return -2;
-    // opt-in: the 4 x 64 kernel (attention_q64.hip) followed by its repair pass; it needs whole 64-key tiles
-    { if (g_utx_opt.attn_q64 == 1 && (S & 63) == 0) {
-          static unsigned char* flag_buf[16] = {nullptr}; static size_t flag_cap[16] = {0};
-          int dev = 0; if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return -5;
-          const size_t need = (size_t)H * (size_t)(S / 64);
-          if (flag_cap[dev] < need) {
-              if (flag_buf[dev]) (void)hipFree(flag_buf[dev]);
-              if (hipMalloc((void**)&flag_buf[dev], need) != hipSuccess) { flag_buf[dev] = nullptr; flag_cap[dev] = 0; return -5; }
-              flag_cap[dev] = need;
-          }
-          p.flags = flag_buf[dev]; p.flag_hs = S / 64;
-          const int rc = utx_launch_attn_fwd_q64(&p, presc ? 1 : 0, stream);
-          if (rc) return rc;
-          return utx_launch_attn_fwd_glds(&p, presc ? 1 : 0, stream);
-      } }
+    if (blk_rows > 0 && (g_utx_opt.attn_glds == 0 || g_utx_opt.attn_tpb != 1)) return -2;
+    // key multiplicity and a query count below the key count exist in the LDS-DMA staged kernels only
+    if ((key_bias_log2 != 0.f || Sq != 0) && (g_utx_opt.attn_glds == 0 || g_utx_opt.attn_tpb != 1)) return -2;
+    // UTX_ATTN_Q64=1: the 4 x 64 kernel (attention_q64.hip: one wave per SIMD, hand-placed stream) + its repair pass, for the launches it takes (pre-scaled Q, whole 64-key
+    // tiles, contiguous operands, no periodic key multiplicity, caller scratch with room for its flags); everything else runs the 8 x 32 kernel below
+    if (g_utx_opt.attn_q64 == 1 && g_utx_opt.attn_glds != 0 && g_utx_opt.attn_tpb == 1 && utx_attn_q64_takes(&p, presc ? 1 : 0)) return utx_launch_attn_fwd_q64(&p, 1, stream);
     // default: the LDS-DMA staged kernel (attention_glds.hip), +5 % over register staging (profiles/r01_perf_attn_ablation.log);
     // UTX_ATTN_GLDS=0 selects the register-staged variants below for A/B
     if (g_utx_opt.attn_glds != 0) return utx_launch_attn_fwd_glds(&p, presc ? 1 : 0, stream);

@@ -592,13 +592,24 @@ extern "C" void utx_attn_split_plan_impl(int H, int Sq, int S, int ncu, int out[
         out[3] = tps;
     }
 }
-// bytes of caller-owned scratch the tail split of this shape needs (0: the launch is never split): normalised partial rows (bf16) + log2-sum-exp (f32)
-extern "C" size_t utx_attn_workspace_bytes_impl(int H, int Sq, int S, int ncu) {
+// bytes of scratch the tail split of this shape needs (0: the launch is never split): normalised partial rows (bf16) + log2-sum-exp (f32); a multiple of 1024
+extern "C" size_t utx_attn_split_bytes_impl(int H, int Sq, int S, int ncu) {
     int pl[4];
     utx_attn_split_plan_impl(H, Sq, S, ncu, pl);
     if (pl[2] <= 1) return 0;
     const size_t rows = (size_t)(pl[0] - pl[1]) * pl[2] * 256;
     return rows * 128 * sizeof(bf16_t) + rows * sizeof(float);
+}
+// bytes of caller-owned scratch of one attention call (C ABI: utx_attn_workspace_bytes): [tail-split scratch | headroom flags of the 4 x 64 kernel (attention_q64.hip), one byte per
+// 64-query group].  The 8 x 32 kernel uses the first part only; a call without scratch runs it unsplit.
+extern "C" size_t utx_attn_workspace_bytes_impl(int H, int Sq, int S, int ncu) {
+    return utx_attn_split_bytes_impl(H, Sq, S, ncu) + utx_attn_q64_flag_bytes(H, Sq, S);
+}
+// the merge of a split tail round, for the 4 x 64 kernel's launcher (same work items, same partial-row layout)
+extern "C" int utx_launch_attn_merge(const AttnParams* t, int n_items, hipStream_t stream) {
+    const long mt = (long)n_items * 256 * 16;
+    hipLaunchKernelGGL(attn_merge_kernel, dim3((unsigned)((mt + 255) / 256)), dim3(256), 0, stream, *t, n_items);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
 template <int PRESC, int TPB, int VAR = 0, bool BLK = false, bool FAST = false, bool KBP = false>

@@ -87,7 +87,11 @@ int utx_launch_attn_fwd(const void* q, const void* k, const void* vt, void* o,
                         long q_hs, long q_ss, long k_hs, long k_ss, long vt_hs, long vt_ds,
                         long o_ss, int H, int S, int Sq, float scale, float key_bias_log2, int key_bias_period, void* work, size_t work_bytes, hipStream_t stream);
 void utx_attn_split_plan_impl(int H, int Sq, int S, int ncu, int out[4]);     // attention_glds.hip (pure): {workgroups, in full rounds, key ranges per tail workgroup, tiles per range}
-size_t utx_attn_workspace_bytes_impl(int H, int Sq, int S, int ncu);
+size_t utx_attn_workspace_bytes_impl(int H, int Sq, int S, int ncu);      // [tail-split scratch | 4 x 64 kernel's headroom flags]
+size_t utx_attn_split_bytes_impl(int H, int Sq, int S, int ncu);
+size_t utx_attn_q64_flag_bytes(int H, int Sq, int S);                    // attention_q64.hip
+int utx_attn_q64_takes(const AttnParams* p, int presc);                  // attention_q64.hip: shape, layout and scratch fit the 4 x 64 kernel
+int utx_launch_attn_merge(const AttnParams* t, int n_items, hipStream_t stream);
 int utx_launch_attn_fwd_glds(const AttnParams* p, int presc, hipStream_t stream);
 int utx_launch_attn_fwd_fp8(const Attn8Params* p, hipStream_t stream);                                   // attention_fp8.hip
 int utx_launch_quant_vt_mx8(const void* vt, void* v8, void* vs, int H, int S_pad, hipStream_t stream);   // attention_fp8.hip
