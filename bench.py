@@ -206,9 +206,9 @@ def count_distinct_devices(idents):
 
 
 def attention_loop_ab(dev, S_exec, heads):
-    """Beside the line, never part of `value`: the attention kernel's fast loop (UTX_ATTN_PEEL=1, the default since round 5) against its general loop (=0, the default
-    until round 4) on this workload's shape, same process, interleaved, behind every other measurement: bit identity + ms per launch.  Both are validated kernels
-    (tests/test_attention_peel_gpu.py); the option is restored."""
+    """Beside the line, never part of `value`: the 4 x 64 attention kernel (UTX_ATTN_Q64=1, the default since round 6: one wave per SIMD, generated hand-placed stream) against
+    the 8 x 32 fast loop (=0, round 5's default) on this workload's shape, same process, interleaved, behind every other measurement: bit identity + ms per call.  Both are
+    validated kernels (tests/test_attention_q64_gpu.py); the option's previous value is restored."""
     from unitex_amd import _lib
     from unitex_amd.flux import ops
     g = torch.Generator(device=dev).manual_seed(S_exec)
@@ -218,11 +218,12 @@ def attention_loop_ab(dev, S_exec, heads):
     Vt = torch.randn(heads, 128, S_pad, generator=g, device=dev).to(torch.bfloat16)
     o = torch.empty(S_exec, heads * 128, dtype=torch.bfloat16, device=dev)
     res, outs = {}, {}
+    prev = _lib.get_options()["UTX_ATTN_Q64"]
     try:
         ms = {0: [], 1: []}
         for rnd in range(3):
             for arm in (0, 1):
-                _lib.set_option("UTX_ATTN_PEEL", arm)
+                _lib.set_option("UTX_ATTN_Q64", arm)
                 ops.attention(Qh, Kh, Vt, S=S_exec, scale=0.0, key_bias_log2=3.0, out=o)
                 if rnd == 0:
                     torch.cuda.synchronize()
@@ -235,10 +236,10 @@ def attention_loop_ab(dev, S_exec, heads):
                 torch.cuda.synchronize()
                 ms[arm].append(a.elapsed_time(b) / 2.0)
         fl = 4.0 * S_exec * S_exec * 128 * heads
-        res = {"general_loop_ms": sorted(ms[0])[1], "fast_loop_ms": sorted(ms[1])[1], "bit_identical": bool(torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))),
-               "general_loop_tflops": fl / sorted(ms[0])[1] / 1e9, "fast_loop_tflops": fl / sorted(ms[1])[1] / 1e9, "tokens": S_exec, "heads": heads}
+        res = {"fast8x32_ms": sorted(ms[0])[1], "q64_ms": sorted(ms[1])[1], "bit_identical": bool(torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))),
+               "fast8x32_tflops": fl / sorted(ms[0])[1] / 1e9, "q64_tflops": fl / sorted(ms[1])[1] / 1e9, "tokens": S_exec, "heads": heads}
     finally:
-        _lib.set_option("UTX_ATTN_PEEL", 1)
+        _lib.set_option("UTX_ATTN_Q64", prev)
     return res
 
 
@@ -569,7 +570,7 @@ def main():
                        # wrong-result ablations do not exist in this library) and every UTX_* variable of the environment
                        "launch_options": _lib.get_options(), "gemm_launches_per_step": _gemm_census(model), "ablation_build": bool(_lib.load_library().utx_is_ablation_build()),
                        "env_UTX": {k: v for k, v in sorted(os.environ.items()) if k.startswith("UTX_")}},
-            "roofline": {"bound": "mfma", "kernel": "attn_fwd_fp8_kernel (+ three MX quantiser passes, not in the launch time)" if args.fp8_attn else "attn_fwd_glds_kernel", "launches_per_call": "full rounds + key-split tail round (same kernel) + attn_merge_kernel; a 'launch' below is one utx_attn_fwd_bf16 call", "achieved": achieved, "peak": 5000.0 if args.fp8_attn else PEAK_BF16_TFLOPS,
+            "roofline": {"bound": "mfma", "kernel": "attn_fwd_fp8_kernel (+ three MX quantiser passes, not in the launch time)" if args.fp8_attn else ("attn_fwd_q64_kernel (4 x 64, generated stream; + flag memset + repair-pass launch of attn_fwd_glds_kernel)" if _lib.get_options().get("UTX_ATTN_Q64") == 1 and not ulysses else "attn_fwd_glds_kernel"), "launches_per_call": "full rounds + key-split tail round (same kernel) + attn_merge_kernel; a 'launch' below is one utx_attn_fwd_bf16 call", "achieved": achieved, "peak": 5000.0 if args.fp8_attn else PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / (5000.0 if args.fp8_attn else PEAK_BF16_TFLOPS), "traffic": None,
                          "launches_timed": len(attn_ms), "avg_launch_ms": attn_avg_ms,
                          "timed_in": "one extra step behind the timed region, HIP events on the launch stream around every attention call (the timed region itself carries no events: it is the product's launch path)",
@@ -603,6 +604,12 @@ def main():
                 out["roofline"]["traffic"] = tr["traffic_bytes_per_launch"]
                 out["roofline"]["traffic_unit"] = "bytes/launch (FETCH_SIZE x2 + WRITE_SIZE, %s)" % tr["source"]
                 out["roofline"]["algorithmic_hbm_bytes_per_launch"] = tr["algorithmic_bytes_per_launch"]
+                # frac = matrix-pipe busy x effective clock / 2.4 GHz: both from the counter passes of tools/attn_pmc_arms.sh on this kernel (committed; a PMC pass serialises kernels and
+                # cannot run inside the timed region)
+                if "attn_clock_ghz" in tr:
+                    out["config"]["attn_clock_ghz"] = tr["attn_clock_ghz"]
+                    out["config"]["attn_mfma_busy"] = tr["attn_mfma_busy"]
+                    out["config"]["attn_busy_x_clock_over_2p4"] = tr["attn_mfma_busy"] * tr["attn_clock_ghz"] / 2.4
         except OSError:
             pass
         if world == 1:
@@ -674,12 +681,16 @@ def main():
             except Exception as e:  # noqa: BLE001 -- the GPU number must still be reported
                 out["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": ncpu, "kind": "port",
                                        "sample": "failed: %r" % (e,)}
+        # The extras below run in-process behind every measurement of the line.  They are product kernels on product shapes, but a device fault in one of them would take the ONE
+        # stdout line with it: the line as it stands goes to STDERR first -- a safety copy in the logs, stdout keeps its single JSON line.
+        sys.stderr.write("bench.py core line (safety copy before the reporting extras): " + json.dumps(out) + "\n")
+        sys.stderr.flush()
         if world == 1 and not args.sp_self_test and not args.fp8_attn and os.environ.get("UTX_BENCH_EXPERIMENTS", "1") != "0":
             try:
                 ab = attention_loop_ab(dev, S_exec, HEADS)
-                out["config"]["experiments"] = {"attention_fast_loop_vs_general_loop": ab}
-                out["config"]["experiments_summary"] = "attn fast loop (default) vs general loop @%d tok: bit_id=%d %.3f vs %.3f ms = %.3fx (%.0f vs %.0f TF/s)" % (
-                    ab["tokens"], int(ab["bit_identical"]), ab["fast_loop_ms"], ab["general_loop_ms"], ab["general_loop_ms"] / ab["fast_loop_ms"], ab["fast_loop_tflops"], ab["general_loop_tflops"])
+                out["config"]["experiments"] = {"attention_q64_vs_fast8x32": ab}
+                out["config"]["experiments_summary"] = "attn 4x64 generated stream (default) vs 8x32 fast loop @%d tok: bit_id=%d %.3f vs %.3f ms = %.3fx (%.0f vs %.0f TF/s)" % (
+                    ab["tokens"], int(ab["bit_identical"]), ab["q64_ms"], ab["fast8x32_ms"], ab["fast8x32_ms"] / ab["q64_ms"], ab["q64_tflops"], ab["fast8x32_tflops"])
             except Exception as e:  # noqa: BLE001 -- a reporting extra
                 out["config"]["experiments_summary"] = "failed: %r" % (e,)
         if world == 1 and not args.sp_self_test and args.workload != "ref512x6" and os.environ.get("UTX_BENCH_REF_POINT", "1") != "0":

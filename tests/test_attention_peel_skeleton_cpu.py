@@ -131,8 +131,8 @@ def test_the_skeleton_check_sees_a_broken_loop(tmp_path):
     src = _loop_source()
     mutations = [("const int fast_end_ = rag_ ? nt - 1 : nt;                 // tiles [1, fast_end_) take the fast form", "const int fast_end_ = nt;"),
                  ("            if (1 < nt) AG_STAGE(1, 1);\n", "            if (1 < nt) AG_STAGE(1, 0);\n"),
-                 ("if (!(ABL & 4) && u + 2 < nt) AG_STAGE(u + 2, gs); ", "if (!(ABL & 4) && u + 2 < nt) AG_STAGE(u + 2, gs ^ 1);"),
-                 ("if constexpr (!(ABL & 8)) AG_BARRIER();", ""),
+                 ("if (u + 2 < nt) AG_STAGE(u + 2, gs); ", "if (u + 2 < nt) AG_STAGE(u + 2, gs ^ 1);"),
+                 ("            AG_BARRIER();                                      /* tile u + 1 has landed", "            /* tile u + 1 has landed"),
                  ("                AG_FAST_TILE_(uu + 1, 0, false)\n", "                AG_FAST_TILE_(uu + 1, 1, false)\n"),
                  ("            if (uu < fast_end_) AG_FAST_TILE_(uu, 1, false)\n", ""),
                  ("                if (uu < fast_end_) { AG_FAST_TILE_(uu, uu & 1, true) ++uu; }\n", "                if (uu < fast_end_) { AG_FAST_TILE_(uu, uu & 1, false) ++uu; }\n"),

@@ -641,11 +641,11 @@ def test_attention_running_max_keeps_growing():
         assert err < 4e-2, "ramp attention err %g (prescaled=%s)" % (err, prescaled)
 
 
-@pytest.mark.parametrize("S,ramp_max", [(64, 0.0), (512, 0.0), (1536, 6.0), (1536, 45.0), (1024, 150.0)])
+@pytest.mark.parametrize("S,ramp_max", [(64, 0.0), (512, 0.0), (1536, 6.0), (1536, 45.0), (1536, 110.0), (1024, 150.0)])
 def test_attention_q64_kernel_and_repair_pass(S, ramp_max):
-    """the opt-in 4 x 64 kernel (UTX_ATTN_Q64=1, whole 64-key tiles only) against the oracle: plain inputs, the growing
-    running maximum, and ramps steep enough to leave its 2^40 softmax headroom (45: finite overflow of the head-room check,
-    150: fp32 overflow inside the kernel) so that the repair pass with the 8 x 32 kernel has to rewrite the query blocks."""
+    """the 4 x 64 kernel (UTX_ATTN_Q64=1, the default since round 6; whole 64-key tiles, pre-scaled Q) against the oracle: plain inputs, the growing
+    running maximum (45 log2-units above the first block: inside its 2^96 headroom, no re-centring at all), and ramps steep enough to leave the headroom
+    (110: finite row sums beyond 2^96, 150: fp32 overflow inside the kernel) so that the repair pass with the 8 x 32 kernel has to rewrite the query blocks."""
     H = 2
     g = torch.Generator().manual_seed(S + int(ramp_max))
     q = torch.randn(H, S, 128, generator=g)

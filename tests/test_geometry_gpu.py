@@ -221,6 +221,38 @@ def test_backprojection_chain_bit_exact(n_faces, T, HW):
     assert np.array_equal(u8, G.tensor_to_u8(pp_ref)[::-1])
 
 
+def test_nn_fill_result_does_not_depend_on_the_cell_grid():
+    """the NN fill picks its uniform grid from the atlas size; the search is exact for ANY grid (ring r+1 only holds points at least r cells away), so the
+    nearest-seen-texel index must be the same for every forced grid (UTX_NN_GRID = 64 / 128 / 256), equal to the grid chosen by size, and equal to the brute-force oracle
+    -- also with positions OUTSIDE [-1, 1] (clamped into edge cells: scaled copy of the same case)."""
+    from unitex_amd import _lib
+    ops = _ops()
+    c = _full_case(3000, 250, 96, seed=5)
+    T = 250
+    bvh_ref = G.BVH(c["verts"], c["faces"])
+    col_ref, rv_ref, ao_ref = G.backproject(c["rast2d"], c["verts"], c["faces"], c["fn"], c["vndc"], c["dirs"], c["imgs"], bvh_ref)
+    mask2d = c["rast2d"][..., 3] > 0
+    vis_ref = G.dilate_visibility(rv_ref, mask2d, ao_ref)
+    atlas_ref, seen_ref, win_ref, bnd_ref = G.composite(col_ref, vis_ref)
+    rast_d = _cu(c["rast2d"])
+    for scale in (1.0, 1.7):                     # 1.7: a third of the sphere's texels lie outside the grid's cube
+        pos_ref = (G.interpolate(c["verts"], c["rast2d"], c["faces"]) * np.float32(scale)).astype(np.float32)
+        filled_ref, idx_ref = G.nn_fill_brute(atlas_ref, win_ref, c["rast2d"], pos_ref)
+        assert ((idx_ref >= 0) & (win_ref < 0)).sum() > 100, "the case must have texels to fill"
+        got = {}
+        try:
+            for grid in (0, 64, 128, 256):
+                _lib.set_option("UTX_NN_GRID", grid)
+                atlas = _cu(atlas_ref.copy())
+                idx = ops.nn_fill(atlas, _cu(win_ref), rast_d, _cu(pos_ref), want_index=True)
+                got[grid] = (idx.cpu().numpy().reshape(T, T), atlas.cpu().numpy())
+        finally:
+            _lib.set_option("UTX_NN_GRID", 0)
+        for grid, (idx, atlas) in got.items():
+            assert np.array_equal(idx, idx_ref), "grid %d, scale %g: nearest-seen-texel index" % (grid, scale)
+            assert np.array_equal(atlas, filled_ref)
+
+
 def test_orbit_video_frames_bit_exact_and_mux(tmp_path):
     """export_orbit_video (turntable of the textured mesh): perspective raster + fused UV interpolation / bilinear
     texture fetch / background composite on the GPU vs the oracle, bit for bit; container round trip."""

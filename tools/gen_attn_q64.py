@@ -9,12 +9,15 @@ simulating the in-order LGKM queue.  The C++ around it (attention_q64.hip) keeps
 
 Pipeline (b = 32-key block, two per 64-key tile; h = 32-query half of the wave's 64 queries):
     stage b :  QK^T(b+1)  ||  softmax(b)  ||  PV(b-1)          32 MFMAs in eight groups  [QK h0, QK h1, PV h0, PV h1]
-    fillers per group:  gap0  exp exp (+ LDS-DMA piece / scalar bookkeeping)     gap1  exp exp, K fragment read (two groups ahead)
-                        gap2  add add cvt_pk, V^T fragment read (two groups ahead)    gap3  add add cvt_pk, the next group's counted lgkmcnt
-One loop trip = one tile = stage 2t+1, the tile's barrier (+ vmcnt(0): the DMA issued a stage earlier), stage 2t+2 with the DMA of K(t+3) / V(t+2).
-Three-slot LDS rings (K and V^T tiles of 16 KB); fragment addresses live in registers and are stepped once per tile right behind their last use.
-The softmax is the sum-checked one of attention_glds.hip: scores leave the MFMA as s - m (the C operand is the -m block), m is the exact maximum of the
-first block, a row sum beyond 2^40 marks the 64-query group for the repair pass.  Arithmetic order per element = the 8 x 32 kernel's.
+    fillers per group:  gap0  exp exp (+ LDS-DMA piece / scalar bookkeeping)     gap1  exp exp, K fragment read (AHEAD groups ahead)
+                        gap2  add add cvt_pk, V^T fragment read                   gap3  add add cvt_pk, the next group's counted lgkmcnt
+One loop trip = one tile = stage 2t+1, the tile's barrier (+ the counted vmcnt that retires the DMA batch due now), stage 2t+2 with the DMA of
+K(t+N) / V(t+N-1) into the N-slot LDS rings (K and V^T tiles of 16 KB).  Fragment addresses live in registers and are stepped once per tile right
+behind their last use.  The softmax is the sum-checked one of attention_glds.hip: scores leave the MFMA as s - m (the C operand is the -m block), m is the
+exact maximum of the first block, a row sum beyond 2^40 marks the 64-query group for the repair pass.  Arithmetic order per element = the 8 x 32 kernel's.
+
+Variants (Config): the product stream is `default`; `python tools/gen_attn_q64.py --variants` also writes attention_q64_asm_var.inc with the A/B arms that
+attention_q64.hip compiles in the UTX_ABLATION build only (tools/attn_q64_check.py times them; arms named abl_* give WRONG results by design).
 """
 import os
 import sys
@@ -33,10 +36,21 @@ Q0, Q1 = 128, 160                                              # AGPR bases of t
 A_LO, A_HI = 128, 191
 # scalars
 S_KPTR, S_VPTR = 40, 42                                        # 64-bit: next K / V^T tile to request
-S_T3, S_KD, S_VD, S_KSTEP, S_VSTEP, S_TMP, S_CNT = 44, 45, 46, 47, 48, 49, 50
-S_POS, S_NEG, S_KD1, S_KD2, S_KDEND, S_VDEND = 51, 52, 53, 54, 55, 56
+S_TK, S_KD, S_VD, S_KSTEP, S_VSTEP, S_TMP, S_CNT = 44, 45, 46, 47, 48, 49, 50
+S_POS, S_NEG, S_KWK, S_KWV, S_KDEND, S_VDEND = 51, 52, 53, 54, 55, 56
 S_LO, S_HI = 40, 56
 TILE = 16384
+
+
+class Config:
+    def __init__(self, name, nslot=3, ahead=2, novm=False, nobar=False, noexp=False, nodma=False):
+        self.name, self.nslot, self.ahead = name, nslot, ahead
+        self.novm, self.nobar, self.noexp, self.nodma = novm, nobar, noexp, nodma      # timing ablations (wrong results)
+        assert nslot in (3, 4) and ahead in (2, 3)
+        self.dk, self.dv = nslot, nslot - 1          # tile look-ahead of the DMA: K(t + dk), V(t + dv) are requested in trip t
+        # DMA batches that may still be in flight at the tile's barrier: the 3-slot ring needs the batch requested one stage ago NOW (vmcnt(0)); with 4 slots the batch
+        # due now was requested a whole tile earlier and the latest one (8 pieces per wave) stays in flight
+        self.vm_at_barrier = 0 if nslot == 3 else 8
 
 
 def v(n, w=1):
@@ -55,7 +69,6 @@ class Stream:
     def __init__(self):
         self.lines = []
         self.lgkm = []          # in-order queue of outstanding LDS reads (tags)
-        self.n_mfma = 0
         self.gap = None         # instructions issued since the last MFMA (statistics)
         self.gaps = []
 
@@ -74,7 +87,6 @@ class Stream:
         if self.gap is not None:
             self.gaps.append(self.gap)
         self.gap = 0
-        self.n_mfma += 1
         self.lines.append("v_mfma_f32_32x32x16_bf16 %s, %s, %s, %s" % (dst, a_, b_, c_))
 
     def ds_read(self, tag, dst, addr, off=0):
@@ -96,9 +108,6 @@ class Stream:
         self.ins("s_waitcnt lgkmcnt(0)")
         self.lgkm = []
 
-    def text(self):
-        return self.lines
-
 
 def dma(st, voff_op, sbase, m0_base, m0_imm):
     """one 1 KB piece: M0 = LDS destination of the wave-instruction, then global_load_lds (saddr + per-lane 32-bit offset)"""
@@ -115,41 +124,60 @@ def advance_ptr(st, ptr, step, cond_lhs, cond_rhs):
     st.ins("s_addc_u32 %s, %s, 0" % (s(ptr + 1), s(ptr + 1)))
 
 
-def gen_prologue(st):
+def k_read(st, cfg, tag, buf, odd_target, gt):
+    """K fragment gt of the block the TARGET stage's QK^T multiplies: odd stage 2t+1 -> (tile t+1, block 0); even stage 2t+2 -> (tile t+1, block 1), after which the
+    address steps to tile t+2"""
+    if odd_target:
+        st.ds_read(tag, v(KF[buf], 4), "%%[kx%d]" % gt, 0)
+    else:
+        st.ds_read(tag, v(KF[buf], 4), "%%[kx%d]" % gt, 8192)
+        st.ins("v_add_u32 %%[kx%d], %s, %%[kx%d]" % (gt, s(S_KSTEP), gt))
+
+
+def v_read(st, cfg, tag, buf, odd_target, gt):
+    """V^T fragment (key slab, d-block gt & 3) of the block the TARGET stage's PV consumes: odd stage -> tile t slabs 0, 1; even stage -> tile t slabs 2, 3; an address steps
+    to tile t+1 behind its fourth d-block"""
+    slab = (gt >> 2) + (0 if odd_target else 2)
+    st.ds_read(tag, v(VF[buf], 4), "%%[vx%d]" % slab, 4096 * (gt & 3))
+    if (gt & 3) == 3:
+        st.ins("v_add_u32 %%[vx%d], %s, %%[vx%d]" % (slab, s(S_VSTEP), slab))
+
+
+def gen_prologue(st, cfg):
+    N = cfg.nslot
     st.comment("---- scalars")
     st.ins("s_mov_b32 %s, %%[kptr_lo]" % s(S_KPTR))
     st.ins("s_mov_b32 %s, %%[kptr_hi]" % s(S_KPTR + 1))
     st.ins("s_mov_b32 %s, %%[vptr_lo]" % s(S_VPTR))
     st.ins("s_mov_b32 %s, %%[vptr_hi]" % s(S_VPTR + 1))
-    st.ins("s_mov_b32 %s, 0x4000" % s(S_POS))
-    st.ins("s_mov_b32 %s, 0xffff8000" % s(S_NEG))
-    st.ins("s_add_u32 %s, %%[ldsk], 0x4000" % s(S_KD1))
-    st.ins("s_add_u32 %s, %%[ldsk], 0x8000" % s(S_KD2))
-    st.ins("s_add_u32 %s, %%[ldsk], 0xc000" % s(S_KDEND))
-    st.ins("s_add_u32 %s, %%[ldsv], 0xc000" % s(S_VDEND))
+    st.ins("s_mov_b32 %s, 0x%x" % (s(S_POS), TILE))
+    st.ins("s_mov_b32 %s, 0x%x" % (s(S_NEG), (-(N - 1) * TILE) & 0xffffffff))
+    # the K dest slot of trip t is t % N: the read address of K wraps in trip t + 1 iff t % N == (N - 3) % N, that of V^T iff t % N == (N - 2) % N
+    st.ins("s_add_u32 %s, %%[ldsk], 0x%x" % (s(S_KWK), ((N - 3) % N) * TILE))
+    st.ins("s_add_u32 %s, %%[ldsk], 0x%x" % (s(S_KWV), ((N - 2) % N) * TILE))
+    st.ins("s_add_u32 %s, %%[ldsk], 0x%x" % (s(S_KDEND), N * TILE))
+    st.ins("s_add_u32 %s, %%[ldsv], 0x%x" % (s(S_VDEND), N * TILE))
+    st.ins("s_mov_b32 %s, %s" % (s(S_KSTEP), s(S_POS)))
+    st.ins("s_mov_b32 %s, %s" % (s(S_VSTEP), s(S_POS)))
     st.comment("---- Q fragments of both 32-query halves, straight into AGPRs (MFMA B operands only)")
     for h, (qp, base) in enumerate((("%[qp0]", Q0), ("%[qp1]", Q1))):
         for kk in range(8):
             st.ins("global_load_dwordx4 %s, %s, off offset:%d" % (a(base + 4 * kk, 4), qp, 32 * kk))
-    st.comment("---- ring fill: K(0) V(0) K(1) V(1) K(2); tile indices clamp at nt - 1")
-    for j in range(4):
-        dma(st, "%%[ko%d]" % j, S_KPTR, "%[ldsk]", 1024 * j)
-    for j in range(4):
-        dma(st, "%%[vo%d]" % j, S_VPTR, "%[ldsv]", 1024 * j)
-    st.ins("s_mov_b32 %s, 1" % s(S_T3))
-    advance_ptr(st, S_KPTR, "%[kstride]", s(S_T3), "%[nt]")
-    advance_ptr(st, S_VPTR, "0x80", s(S_T3), "%[nt]")
-    for j in range(4):
-        dma(st, "%%[ko%d]" % j, S_KPTR, "%[ldsk]", TILE + 1024 * j)
-    for j in range(4):
-        dma(st, "%%[vo%d]" % j, S_VPTR, "%[ldsv]", TILE + 1024 * j)
-    st.ins("s_mov_b32 %s, 2" % s(S_T3))
-    advance_ptr(st, S_KPTR, "%[kstride]", s(S_T3), "%[nt]")
-    for j in range(4):
-        dma(st, "%%[ko%d]" % j, S_KPTR, "%[ldsk]", 2 * TILE + 1024 * j)
-    st.comment("state of 'trip -1': K dest slot 2, V dest slot 1, K pointer at tile min(2, nt-1), V pointer at tile min(1, nt-1), T3 = 2")
-    st.ins("s_mov_b32 %s, %s" % (s(S_KD), s(S_KD2)))
-    st.ins("s_add_u32 %s, %%[ldsv], 0x4000" % s(S_VD))
+    st.comment("---- ring fill: K(0 .. %d), V(0 .. %d); tile indices clamp at nt - 1" % (cfg.dk - 1, cfg.dv - 1))
+    for u in range(cfg.dk):
+        if u > 0:
+            st.ins("s_mov_b32 %s, %d" % (s(S_TK), u))
+            advance_ptr(st, S_KPTR, "%[kstride]", s(S_TK), "%[nt]")
+            if u < cfg.dv:
+                advance_ptr(st, S_VPTR, "0x80", s(S_TK), "%[nt]")
+        for j in range(4):
+            dma(st, "%%[ko%d]" % j, S_KPTR, "%[ldsk]", u * TILE + 1024 * j)
+        if u < cfg.dv:
+            for j in range(4):
+                dma(st, "%%[vo%d]" % j, S_VPTR, "%[ldsv]", u * TILE + 1024 * j)
+    st.comment("state of 'trip -1': K dest slot N-1, V dest slot N-2, K pointer at tile min(N-1, nt-1), V pointer at tile min(N-2, nt-1), TK = N - 1")
+    st.ins("s_add_u32 %s, %%[ldsk], 0x%x" % (s(S_KD), (N - 1) * TILE))
+    st.ins("s_add_u32 %s, %%[ldsv], 0x%x" % (s(S_VD), (N - 2) * TILE))
     st.ins("s_waitcnt vmcnt(0)")
     st.ins("s_barrier")
     st.comment("---- raw scores of blocks 0 and 1 (C = 0), K fragments four at a time")
@@ -212,64 +240,59 @@ def gen_prologue(st):
     st.ins("v_mov_b32 %[l0], 0")
     st.ins("v_mov_b32 %[l1], 0")
     st.ins("v_mov_b32 %[psmax], 0")
-    st.comment("---- fragments of the first two groups of stage 1: K(tile 1, block 0)[0, 1], V(tile 0, slab 0)[db 0, 1]")
-    st.ds_read(("K", 0), v(KF[0], 4), "%[kx0]", 0)
-    st.ds_read(("V", 0), v(VF[0], 4), "%[vx0]", 0)
-    st.ds_read(("K", 1), v(KF[1], 4), "%[kx1]", 0)
-    st.ds_read(("V", 1), v(VF[1], 4), "%[vx0]", 4096)
+    st.comment("---- fragments of the first AHEAD groups of stage 1: K(tile 1, block 0), V(tile 0, slab 0)")
+    for G in range(cfg.ahead):
+        k_read(st, cfg, ("K", G), G % 4, True, G)
+        v_read(st, cfg, ("V", G), G % 4, True, G)
     st.ins("s_mov_b32 %s, %%[nt]" % s(S_CNT))
     st.ins("s_nop 3")
 
 
-def gen_stage(st, G0, odd, stats):
+def gen_stage(st, cfg, G0, odd):
     """one stage of the loop; G0 = running index of its first group (read tags); odd: stage 2t+1 (softmax of a tile's block 1), else stage 2t+2"""
     p = 1 if odd else 0            # parity of the block whose softmax runs
     q = 1 - p                      # parity of the block QK^T writes / PV reads
     sums_p, sums_q = SUM[p], SUM[q]
+    A = cfg.ahead
+    EXP = "v_mov_b32" if cfg.noexp else "v_exp_f32"
     for g in range(8):
         G = G0 + g
         st.wait_lgkm([("K", G), ("V", G)])
         # ---- QK^T, half 0
         st.mfma(v(SA[(q, 0)], 16), v(KF[G % 4], 4), a(Q0 + 4 * g, 4), v(NEGM[0], 16) if g == 0 else v(SA[(q, 0)], 16))
-        if odd:      # scalar bookkeeping of the trip, a few per gap (state of trip t from that of trip t - 1)
+        if odd:      # scalar bookkeeping of the trip, two or three per gap (state of trip t from that of trip t - 1)
             if g == 0:
-                st.ins("s_add_u32 %s, %s, 0x4000" % (s(S_KD), s(S_KD)))
+                st.ins("s_add_u32 %s, %s, 0x%x" % (s(S_KD), s(S_KD), TILE))
                 st.ins("s_cmp_eq_u32 %s, %s" % (s(S_KD), s(S_KDEND)))
                 st.ins("s_cselect_b32 %s, %%[ldsk], %s" % (s(S_KD), s(S_KD)))
             elif g == 1:
-                st.ins("s_cmp_eq_u32 %s, %s" % (s(S_KD), s(S_KD2)))
-                st.ins("s_cselect_b32 %s, %s, %s" % (s(S_VSTEP), s(S_NEG), s(S_POS)))
-            elif g == 2:
-                st.ins("s_cmp_eq_u32 %s, %s" % (s(S_KD), s(S_KD1)))
-                st.ins("s_cselect_b32 %s, %s, %s" % (s(S_KSTEP), s(S_NEG), s(S_POS)))
-            elif g == 3:
-                st.ins("s_add_u32 %s, %s, 0x4000" % (s(S_VD), s(S_VD)))
+                st.ins("s_add_u32 %s, %s, 0x%x" % (s(S_VD), s(S_VD), TILE))
                 st.ins("s_cmp_eq_u32 %s, %s" % (s(S_VD), s(S_VDEND)))
                 st.ins("s_cselect_b32 %s, %%[ldsv], %s" % (s(S_VD), s(S_VD)))
-            elif g == 4:
-                st.ins("s_add_u32 %s, %s, 1" % (s(S_T3), s(S_T3)))
-                st.ins("s_cmp_lt_u32 %s, %%[nt]" % s(S_T3))
+            elif g == 2:
+                st.ins("s_add_u32 %s, %s, 1" % (s(S_TK), s(S_TK)))
+                st.ins("s_cmp_lt_u32 %s, %%[nt]" % s(S_TK))
                 st.ins("s_cselect_b32 %s, %%[kstride], 0" % s(S_TMP))
-            elif g == 5:
+            elif g == 3:
                 st.ins("s_add_u32 %s, %s, %s" % (s(S_KPTR), s(S_KPTR), s(S_TMP)))
                 st.ins("s_addc_u32 %s, %s, 0" % (s(S_KPTR + 1), s(S_KPTR + 1)))
-            elif g == 6:
-                st.ins("s_sub_u32 %s, %s, 1" % (s(S_TMP), s(S_T3)))
+            elif g == 4:
+                st.ins("s_sub_u32 %s, %s, 1" % (s(S_TMP), s(S_TK)))
                 st.ins("s_cmp_lt_u32 %s, %%[nt]" % s(S_TMP))
                 st.ins("s_cselect_b32 %s, 0x80, 0" % s(S_TMP))
-            else:
+            elif g == 5:
                 st.ins("s_add_u32 %s, %s, %s" % (s(S_VPTR), s(S_VPTR), s(S_TMP)))
                 st.ins("s_addc_u32 %s, %s, 0" % (s(S_VPTR + 1), s(S_VPTR + 1)))
-        else:        # LDS-DMA piece g of the tile boundary: K(t+3) pieces 0-3, V(t+2) pieces 0-3; M0 first, the load behind the exponentials
+        elif not cfg.nodma:        # LDS-DMA piece g of the tile boundary: K(t+N) pieces 0-3, V(t+N-1) pieces 0-3; M0 first, the load behind the exponentials
             if g < 4:
                 st.ins("s_add_u32 m0, %s, %d" % (s(S_KD), 1024 * g))
             else:
                 st.ins("s_add_u32 m0, %s, %d" % (s(S_VD), 1024 * (g - 4)))
         ev0 = sums_p[0] if g == 0 else E[0]
         od0 = sums_p[1] if g == 0 else E[1]
-        st.ins("v_exp_f32 %s, %s" % (v(ev0), v(SA[(p, 0)] + 2 * g)))
-        st.ins("v_exp_f32 %s, %s" % (v(od0), v(SA[(p, 0)] + 2 * g + 1)))
-        if not odd:
+        st.ins("%s %s, %s" % (EXP, v(ev0), v(SA[(p, 0)] + 2 * g)))
+        st.ins("%s %s, %s" % (EXP, v(od0), v(SA[(p, 0)] + 2 * g + 1)))
+        if not odd and not cfg.nodma:
             if g < 4:
                 st.ins("global_load_lds_dwordx4 %%[ko%d], %s" % (g, s(S_KPTR, 2)))
             else:
@@ -278,22 +301,18 @@ def gen_stage(st, G0, odd, stats):
         st.mfma(v(SA[(q, 1)], 16), v(KF[G % 4], 4), a(Q1 + 4 * g, 4), v(NEGM[1], 16) if g == 0 else v(SA[(q, 1)], 16))
         ev1 = sums_p[2] if g == 0 else E[2]
         od1 = sums_p[3] if g == 0 else E[3]
-        st.ins("v_exp_f32 %s, %s" % (v(ev1), v(SA[(p, 1)] + 2 * g)))
-        st.ins("v_exp_f32 %s, %s" % (v(od1), v(SA[(p, 1)] + 2 * g + 1)))
-        # K fragment of group G + 2
-        gg = g + 2
-        if odd:      # QK^T(2t+2) = (tile t+1, block 0); groups 6, 7 fetch fragments 0, 1 of (tile t+1, block 1) and step those addresses to tile t+2
-            if gg < 8:
-                st.ds_read(("K", G + 2), v(KF[(G + 2) % 4], 4), "%%[kx%d]" % gg, 0)
+        st.ins("%s %s, %s" % (EXP, v(ev1), v(SA[(p, 1)] + 2 * g)))
+        st.ins("%s %s, %s" % (EXP, v(od1), v(SA[(p, 1)] + 2 * g + 1)))
+        gt = g + A                 # the group AHEAD groups on, in this stage or the next
+        tgt_odd = odd if gt < 8 else (not odd)
+        k_read(st, cfg, ("K", G + A), (G + A) % 4, tgt_odd, gt % 8)
+        if not odd and g >= 6:     # the address steps of the NEXT trip, behind the last step of this one (even-stage targets are read through group 7 - AHEAD)
+            if g == 6:             # V^T read address wraps in trip t + 1 iff t % N == (N - 2) % N
+                st.ins("s_cmp_eq_u32 %s, %s" % (s(S_KD), s(S_KWV)))
+                st.ins("s_cselect_b32 %s, %s, %s" % (s(S_VSTEP), s(S_NEG), s(S_POS)))
             else:
-                st.ds_read(("K", G + 2), v(KF[(G + 2) % 4], 4), "%%[kx%d]" % (gg - 8), 8192)
-                st.ins("v_add_u32 %%[kx%d], %s, %%[kx%d]" % (gg - 8, s(S_KSTEP), gg - 8))
-        else:        # QK^T(2t+3) = (tile t+1, block 1): fragments 2..7 then step; groups 6, 7 fetch fragments 0, 1 of (tile t+2, block 0)
-            if gg < 8:
-                st.ds_read(("K", G + 2), v(KF[(G + 2) % 4], 4), "%%[kx%d]" % gg, 8192)
-                st.ins("v_add_u32 %%[kx%d], %s, %%[kx%d]" % (gg, s(S_KSTEP), gg))
-            else:
-                st.ds_read(("K", G + 2), v(KF[(G + 2) % 4], 4), "%%[kx%d]" % (gg - 8), 0)
+                st.ins("s_cmp_eq_u32 %s, %s" % (s(S_KD), s(S_KWK)))
+                st.ins("s_cselect_b32 %s, %s, %s" % (s(S_KSTEP), s(S_NEG), s(S_POS)))
         # ---- PV, half 0
         st.mfma("%%[o0%d]" % (g & 3), v(VF[G % 4], 4), v(PB[(q, 0)] + 4 * (g >> 2), 4), "%%[o0%d]" % (g & 3))
         if g == 0:   # the row sums of the previous stage's block are final: l += ps (block order), headroom record
@@ -303,29 +322,7 @@ def gen_stage(st, G0, odd, stats):
             st.ins("v_add_f32 %s, %s, %s" % (v(sums_p[0]), v(sums_p[0]), v(E[0])))
             st.ins("v_add_f32 %s, %s, %s" % (v(sums_p[1]), v(sums_p[1]), v(E[1])))
         st.ins("v_cvt_pk_bf16_f32 %s, %s, %s" % (v(PB[(p, 0)] + g), v(ev0), v(od0)))
-        # V^T fragment of group G + 2: (slab, db) of the stage it belongs to
-        if odd:      # PV(2t) = tile t slabs 0, 1; groups 6, 7: slab 2 of the next stage
-            if gg < 4:
-                st.ds_read(("V", G + 2), v(VF[(G + 2) % 4], 4), "%[vx0]", 4096 * gg)
-                if gg == 3:
-                    st.ins("v_add_u32 %%[vx0], %s, %%[vx0]" % s(S_VSTEP))
-            elif gg < 8:
-                st.ds_read(("V", G + 2), v(VF[(G + 2) % 4], 4), "%[vx1]", 4096 * (gg - 4))
-                if gg == 7:
-                    st.ins("v_add_u32 %%[vx1], %s, %%[vx1]" % s(S_VSTEP))
-            else:
-                st.ds_read(("V", G + 2), v(VF[(G + 2) % 4], 4), "%[vx2]", 4096 * (gg - 8))
-        else:        # PV(2t+1) = tile t slabs 2, 3; groups 6, 7: slab 0 of tile t+1
-            if gg < 4:
-                st.ds_read(("V", G + 2), v(VF[(G + 2) % 4], 4), "%[vx2]", 4096 * gg)
-                if gg == 3:
-                    st.ins("v_add_u32 %%[vx2], %s, %%[vx2]" % s(S_VSTEP))
-            elif gg < 8:
-                st.ds_read(("V", G + 2), v(VF[(G + 2) % 4], 4), "%[vx3]", 4096 * (gg - 4))
-                if gg == 7:
-                    st.ins("v_add_u32 %%[vx3], %s, %%[vx3]" % s(S_VSTEP))
-            else:
-                st.ds_read(("V", G + 2), v(VF[(G + 2) % 4], 4), "%[vx0]", 4096 * (gg - 8))
+        v_read(st, cfg, ("V", G + A), (G + A) % 4, tgt_odd, gt % 8)
         # ---- PV, half 1
         st.mfma("%%[o1%d]" % (g & 3), v(VF[G % 4], 4), v(PB[(q, 1)] + 4 * (g >> 2), 4), "%%[o1%d]" % (g & 3))
         if g == 0:
@@ -338,30 +335,33 @@ def gen_stage(st, G0, odd, stats):
         st.ins("v_cvt_pk_bf16_f32 %s, %s, %s" % (v(PB[(p, 1)] + g), v(ev1), v(od1)))
 
 
-def gen():
+def gen(cfg):
     st = Stream()
-    gen_prologue(st)
+    gen_prologue(st, cfg)
     entry = list(st.lgkm)
-    assert entry == [("K", 0), ("V", 0), ("K", 1), ("V", 1)]
+    assert entry == [(k, G) for G in range(cfg.ahead) for k in ("K", "V")], entry
     st.raw("AQ2_LOOP_%=:")
     n0 = len(st.lines)
     st.gap = None
-    gen_stage(st, 0, True, None)
-    st.comment("---- tile boundary: this wave's pieces of K(t+2) / V(t+1) have landed (requested one stage ago); behind the barrier they are visible and the slots of K(t) / V(t-1) are free")
-    st.ins("s_waitcnt vmcnt(0)")
-    st.ins("s_barrier")
-    gen_stage(st, 8, False, None)
+    gen_stage(st, cfg, 0, True)
+    st.comment("---- tile boundary: the DMA batch due now has landed (this wave's pieces: the counted vmcnt); behind the barrier it is visible and the slots of K(t) / V(t-1) are free")
+    if not cfg.novm:
+        st.ins("s_waitcnt vmcnt(%d)" % cfg.vm_at_barrier)
+    if not cfg.nobar:
+        st.ins("s_barrier")
+    gen_stage(st, cfg, 8, False)
     st.ins("s_sub_u32 %s, %s, 1" % (s(S_CNT), s(S_CNT)))
     st.ins("s_cmp_lg_u32 %s, 0" % s(S_CNT))
     st.ins("s_cbranch_scc1 AQ2_LOOP_%=")
     back = [(k, G - 16) for k, G in st.lgkm]
     assert back == entry, (back, entry)       # the LGKM queue at the back edge is the queue at the loop's entry: the counted waits hold on every trip
     loop_lines = [l for l in st.lines[n0:] if not l.startswith(";")]
+    gaps = list(st.gaps)
     st.comment("---- drain: the last PV MFMAs, the prefetched fragments and the clamped re-requests")
     st.ins("s_nop 15")
     st.ins("s_nop 15")
     st.ins("s_waitcnt vmcnt(0) lgkmcnt(0)")
-    return st, loop_lines
+    return st, loop_lines, gaps
 
 
 OPERANDS_OUT = [("o%d%d" % (h, d), "+a", "oacc%d[%d]" % (h, d)) for h in range(2) for d in range(4)] + \
@@ -372,32 +372,52 @@ OPERANDS_IN = [("ko%d" % i, "v", "ko[%d]" % i) for i in range(4)] + [("vo%d" % i
      ("kptr_lo", "s", "kptr_lo"), ("kptr_hi", "s", "kptr_hi"), ("vptr_lo", "s", "vptr_lo"), ("vptr_hi", "s", "vptr_hi"),
      ("kstride", "s", "kstride"), ("nt", "s", "nt"), ("ldsk", "s", "ldsk"), ("ldsv", "s", "ldsv"), ("kbv", "s", "kbv")]
 
+DEFAULT = Config("default")
+# A/B arms (UTX_ABLATION build; UTX_ATTN_VAR = index + 1 selects one).  Correct results unless named abl_*.
+VARIANTS = [Config("ring4", nslot=4), Config("ahead3", ahead=3), Config("ring4_ahead3", nslot=4, ahead=3),
+            Config("abl_novm", novm=True), Config("abl_nobar", novm=True, nobar=True), Config("abl_noexp", noexp=True), Config("abl_nodma", nodma=True, novm=True)]
 
-def main():
-    st, loop_lines = gen()
-    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "unitex_amd", "csrc", "attention_q64_asm.inc")
+
+def write_text(f, macro, st):
+    f.write("#define %s \\\n" % macro)
+    for l in st.lines:
+        f.write('    "%s\\n\\t" \\\n' % l.replace("\\", "\\\\").replace('"', '\\"'))
+    f.write('    ""\n')
+
+
+def census(cfg, loop_lines, gaps):
     n_mfma = sum(1 for l in loop_lines if l.startswith("v_mfma"))
     n_other = len(loop_lines) - n_mfma
-    gaps = st.gaps
-    with open(out, "w") as f:
+    loop_gaps = gaps[-n_mfma:]
+    return n_mfma, n_other, {k: loop_gaps.count(k) for k in sorted(set(loop_gaps))}
+
+
+def main():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = os.path.join(root, "unitex_amd", "csrc", "attention_q64_asm.inc")
+    st, loop_lines, gaps = gen(DEFAULT)
+    n_mfma, n_other, hist = census(DEFAULT, loop_lines, gaps)
+    with open(os.devnull if "--keep-default" in sys.argv else out, "w") as f:
         f.write("// GENERATED by tools/gen_attn_q64.py -- do not edit; the generator's header explains the stream.\n")
-        f.write("// loop trip (one 64-key tile, 64 queries per wave): %d MFMAs, %d other instructions (%.2f per MFMA gap)\n" % (n_mfma, n_other, n_other / n_mfma))
-        f.write("#define AQ2_ASM_TEXT \\\n")
-        for l in st.text():
-            f.write('    "%s\\n\\t" \\\n' % l.replace("\\", "\\\\").replace('"', '\\"'))
-        f.write('    ""\n')
+        f.write("// loop trip (one 64-key tile, 64 queries per wave): %d MFMAs, %d other instructions (%.2f per MFMA gap; histogram of gap sizes %s)\n" % (n_mfma, n_other, n_other / n_mfma, hist))
+        f.write("#define AQ2_NSLOT %d\n" % DEFAULT.nslot)
+        write_text(f, "AQ2_ASM_TEXT", st)
         f.write("#define AQ2_ASM_OUTPUTS " + ", ".join('[%s] "%s"(%s)' % o for o in OPERANDS_OUT) + "\n")
         f.write("#define AQ2_ASM_INPUTS " + ", ".join('[%s] "%s"(%s)' % o for o in OPERANDS_IN) + "\n")
         clob = ['"memory"', '"vcc"', '"scc"'] + ['"v%d"' % i for i in range(V_LO, V_HI + 1)] + ['"a%d"' % i for i in range(A_LO, A_HI + 1)] + ['"s%d"' % i for i in range(S_LO, S_HI + 1)]
         f.write("#define AQ2_ASM_CLOBBERS " + ", ".join(clob) + "\n")
-    # per-gap census of the loop (what the header of attention_q64.hip quotes)
-    st2 = Stream()
-    st2.lgkm = [("K", 0), ("V", 0), ("K", 1), ("V", 1)]
-    gen_stage(st2, 0, True, None)
-    st2.ins("s_waitcnt vmcnt(0)"); st2.ins("s_barrier")
-    gen_stage(st2, 8, False, None)
-    print("wrote %s: loop %d MFMAs + %d others = %.2f per gap; gap histogram %s" % (out, n_mfma, n_other, n_other / n_mfma,
-          {k: st2.gaps.count(k) for k in sorted(set(st2.gaps))}))
+    print("wrote %s: loop %d MFMAs + %d others = %.2f per gap; gap histogram %s" % (out, n_mfma, n_other, n_other / n_mfma, hist))
+    if "--variants" in sys.argv:
+        outv = os.path.join(root, "unitex_amd", "csrc", "attention_q64_asm_var.inc")
+        with open(outv, "w") as f:
+            f.write("// GENERATED by tools/gen_attn_q64.py --variants -- A/B arms of the 4 x 64 stream for the UTX_ABLATION build (git-ignored; never part of the product library).\n")
+            f.write("#define AQ2_NVAR %d\n" % len(VARIANTS))
+            for i, cfg in enumerate(VARIANTS):
+                stv, ll, gg = gen(cfg)
+                n_mfma, n_other, hist = census(cfg, ll, gg)
+                f.write("// arm %d = %s: %.2f per gap %s\n#define AQ2_NSLOT_V%d %d\n" % (i + 1, cfg.name, n_other / n_mfma, hist, i + 1, cfg.nslot))
+                write_text(f, "AQ2_ASM_TEXT_V%d" % (i + 1), stv)
+                print("  arm %d = %-14s %.2f per gap %s" % (i + 1, cfg.name, n_other / n_mfma, hist))
 
 
 if __name__ == "__main__":

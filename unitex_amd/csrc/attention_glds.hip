@@ -43,25 +43,14 @@ __device__ __forceinline__ float ag_mul_nofuse(float a, float b) {
     return a * b;
 }
 
-// VAR == 5 (ablation build only, WRONG results): every 32x32x16 MFMA replaced by two 16x16x32 MFMAs on the same operand registers --
-// same FLOPs and register / LDS traffic; measures what the more power-efficient instruction shape (tools/mfma_power_probe.py) would
-// buy this kernel before paying for the re-layout of the softmax.
-#define AG_MM(acc_, a_, b_, c_)                                                                              \
-    if constexpr (VAR == 5) {                                                                                \
-        f32x4 lo_ = {c_[0], c_[1], c_[2], c_[3]}, hi_ = {c_[4], c_[5], c_[6], c_[7]};                        \
-        lo_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_, b_, lo_, 0, 0, 0);                                 \
-        hi_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_, a_, hi_, 0, 0, 0);                                 \
-        acc_ = c_;                                                                                           \
-        acc_[0] = lo_[0]; acc_[1] = lo_[1]; acc_[2] = lo_[2]; acc_[3] = lo_[3];                              \
-        acc_[4] = hi_[0]; acc_[5] = hi_[1]; acc_[6] = hi_[2]; acc_[7] = hi_[3];                              \
-    } else acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b_, c_, 0, 0, 0);
+#define AG_MM(acc_, a_, b_, c_) acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b_, c_, 0, 0, 0);
 
 // BLK: Q rows, K rows and V^T columns arrive in BLOCKS of p.blk_rows tokens (a multiple of the 64-key tile) that lie p.q_bs / p.k_bs / p.vt_bs elements apart --
 // the receive buffer of the sequence-parallel Q / K / V exchange, [source rank][q | k | v][head][S_loc * 128] (flux/ulysses.py), read where the all-to-all put it
 // instead of behind a relayout pass.  Token j = block j / blk_rows, row j % blk_rows; inside a block rows are q_ss / k_ss apart and V^T rows vt_ds (= blk_rows for
 // the exchange buffer).  The staging cursor below walks tiles in order, so the block term is two scalar adds per tile; same tiles, same order, same arithmetic
 // as the contiguous form: bit-identical results.
-template <int PRESC, int TPB, int VAR, bool BLK = false, bool FAST = false, bool KBP = false>
+template <int PRESC, int TPB, bool BLK = false, bool FAST = false, bool KBP = false>
 __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const kring = smem;
@@ -97,15 +86,6 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
     const bf16_t* vbase = BLK ? p.vt + (long)head * p.vt_hs + (long)blk0 * p.vt_bs + loc0 * AG_KVB
                               : p.vt + (long)head * p.vt_hs + tb * AG_KVB;
 
-    // VAR 11 (ablation build, correct results): the workgroup's timeline -- wave 0 writes the 100 MHz wall clock at start / Q fragments loaded / ring filled (first
-    // barrier) / key loop done / output stores retired, plus where it ran (HW_ID, XCC_ID), 8 longs per workgroup into p.work (tools/attn_timeline.py): what a
-    // persistent workgroup that prefetches its next item's Q and drains its stores under the next item's first tiles could hide
-    long tl0 = 0, tl1 = 0, tl2 = 0, tl3 = 0;
-    // VAR 32 + bits (ablation build only, WRONG results; the FAST loop's cost account, tools/attn_fast_ablate.py): 1 v_exp -> move, 2 no K / V fragment reads in the loop (stale
-    // registers), 4 no DMA in the loop, 8 no barrier in the loop, 32 reads issued by asm into registers nothing waits for (MFMAs on stale registers).  READ THE ARMS' WALL TIMES AS ENERGY: the chip is power-limited,
-    // an arm whose MFMA operands stop changing clocks higher (tools/attn_pmc_arms.sh gives cycles and clock per arm)
-    constexpr int ABL = VAR >= 32 ? VAR - 32 : 0;
-    if constexpr (VAR == 11) tl0 = wall_clock64();
     const int q0 = qb * 256 + wave * 32;
     bf16x8 qf[8];
     {
@@ -174,32 +154,23 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
 #pragma unroll
     for (int i = 0; i < TPB; ++i)
         if (i < nt) AG_STAGE(i, i);
-    if constexpr (VAR == 11) { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); tl1 = wall_clock64(); }      // the Q loads are older than the first tile's four DMAs
     AG_BARRIER();
-    if constexpr (VAR == 11) tl2 = wall_clock64();
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) asm volatile("" : "+v"(qf[kk]));
 
-    // VAR 6 (ablation build, correct results): STATIC priority -- the second-dispatched half of the workgroup (waves 4-7) is the arbitration loser of
-    // every segment (MI355X_MICROARCH.md, "Two waves per SIMD", item 4): one s_setprio 1 for that half, no per-segment flips.  MEASURED AND NOT
-    // ADOPTED (profiles/r03_attn_variants_v0.log): 25.580 vs 25.380 ms at S = 50 240 (-0.8 %), equal at S = 13 376 -- that lever belongs to a loop whose
-    // halves alternate compute and load segments behind barriers; here all eight waves run the same interleaved stream and the per-tile flips
-    // (prio 1 while computing, 0 at the barrier) already are the better arbitration
-    if (VAR == 6 && wave >= 4) __builtin_amdgcn_s_setprio(1);
     // AG_TILE_BODY: the GENERAL tile (it may be the first tile, a ragged last tile, a key-multiplicity tile); AG_FAST_A / AG_FAST_B below: a tile that is none of these.
 #define AG_EXPB(sa_, p0_, p1_, ps_)                                                                  \
         {                                                                                            \
-            f32x2 acc2_ = {0.f, 0.f};                                                                \
             float sc0_ = 0.f, sc1_ = 0.f;                                                            \
             _Pragma("unroll") for (int r = 0; r < 16; r += 2) {                                      \
                 f32x2 pv_;                                                                           \
                 pv_[0] = __builtin_amdgcn_exp2f(PRESC ? sa_[r] : sa_[r] * c2);                       \
                 pv_[1] = __builtin_amdgcn_exp2f(PRESC ? sa_[r + 1] : sa_[r + 1] * c2);               \
-                if (VAR != 4) { sc0_ += pv_[0]; sc1_ += pv_[1]; } else acc2_ += pv_;                 \
+                sc0_ += pv_[0]; sc1_ += pv_[1];                                                      \
                 if (r < 8) { p0_[r] = (__bf16)pv_[0]; p0_[r + 1] = (__bf16)pv_[1]; }                 \
                 else { p1_[r - 8] = (__bf16)pv_[0]; p1_[r - 7] = (__bf16)pv_[1]; }                   \
             }                                                                                        \
-            ps_ = VAR != 4 ? sc0_ + sc1_ : acc2_[0] + acc2_[1];                                      \
+            ps_ = sc0_ + sc1_;                                                                       \
         }
 #define AG_SLOW(sa_, other_, fix_other_, kblk_, boff_, first_)                                       \
         {                                                                                            \
@@ -240,11 +211,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
         /* S0: QK(0); block-1 K fragments stream in behind the MFMAs */                              \
         _Pragma("unroll")                                                                            \
         for (int kk = 0; kk < 8; ++kk) kfa[kk] = *reinterpret_cast<const bf16x8*>(kb + kx[kk]);      \
-        if (VAR != 1 && VAR != 6) __builtin_amdgcn_s_setprio(1);                                     \
+        __builtin_amdgcn_s_setprio(1);                                                               \
         _Pragma("unroll")                                                                            \
         for (int kk = 0; kk < 8; ++kk) {                                                             \
-            if (VAR == 3) kfb[kk] = kfa[kk];   /* ablation: half of the K fragment reads removed (wrong results) */ \
-            else kfb[kk] = *reinterpret_cast<const bf16x8*>(kb + 8192 + kx[kk]);                     \
+            kfb[kk] = *reinterpret_cast<const bf16x8*>(kb + 8192 + kx[kk]);                          \
             if (kk == 0) { AG_MM(sa0, kfa[kk], qf[kk], negm) } else { AG_MM(sa0, kfa[kk], qf[kk], sa0) } \
         }                                                                                            \
         __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                                           \
@@ -265,12 +235,12 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
         }                                                                                            \
         AG_EXPB(sa0, pb[0], pb[1], ps0)                                                              \
         _Pragma("unroll")                                                                            \
-        for (int i_ = 0; i_ < (VAR == 2 ? 0 : 8); ++i_) {                                            \
+        for (int i_ = 0; i_ < 8; ++i_) {                                                             \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);                                       \
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);                                       \
             __builtin_amdgcn_sched_group_barrier(0x402, 4, 1);                                       \
         }                                                                                            \
-        if ((t == 0 && VAR != 10) || ragged || !__all(ps0 <= 8192.0f)) {      /* VAR 10 (ablation build, WRONG results): no first-tile max pass -- what the prologue's slow path costs */ \
+        if (t == 0 || ragged || !__all(ps0 <= 8192.0f)) {                                            \
             AG_SLOW(sa0, sa1, true, 0, 0, t == 0)                                           \
             AG_EXPB(sa0, pb[0], pb[1], ps0)                                                          \
         }                                                                                            \
@@ -278,8 +248,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
         /* S2: PV(0) || exp(1); V fragments of block 1 (s = 2, 3) stream in */                       \
         _Pragma("unroll")                                                                            \
         for (int i = 0; i < 8; ++i) {                                                                \
-            if (VAR == 3) vfb[i] = vfa[i];   /* ablation: half of the V fragment reads removed (wrong results) */ \
-            else vfb[i] = *reinterpret_cast<const bf16x8*>(vb + (i & 3) * 4096 + vx[2 + (i >> 2)]);  \
+            vfb[i] = *reinterpret_cast<const bf16x8*>(vb + (i & 3) * 4096 + vx[2 + (i >> 2)]);       \
             AG_MM(oacc[i & 3], vfa[i], pb[i >> 2], oacc[i & 3])                                      \
         }                                                                                            \
         if (kbias) {                                                                                 \
@@ -288,7 +257,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
         }                                                                                            \
         AG_EXPB(sa1, pb[2], pb[3], ps1)                                                              \
         _Pragma("unroll")                                                                            \
-        for (int i_ = 0; i_ < (VAR == 2 ? 0 : 8); ++i_) {                                            \
+        for (int i_ = 0; i_ < 8; ++i_) {                                                             \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 2);                                       \
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 2);                                       \
             __builtin_amdgcn_sched_group_barrier(0x402, 4, 2);                                       \
@@ -302,7 +271,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
         _Pragma("unroll")                                                                            \
         for (int i = 0; i < 8; ++i)                                                                  \
             AG_MM(oacc[i & 3], vfb[i], pb[2 + (i >> 2)], oacc[i & 3])                                \
-        if (VAR != 1 && VAR != 6) __builtin_amdgcn_s_setprio(0);                                     \
+        __builtin_amdgcn_s_setprio(0);                                                               \
         }
     // FAST (the default of the pre-scaled contiguous launch since round 5; UTX_ATTN_PEEL=0 selects the general loop for A/B): tile 0 and a ragged last tile run the general
     // body in front of / behind a loop whose tiles can be neither first, ragged nor key-multiplicity tiles.  In the general body `if (kbias)` and the first-tile test cut S1 / S2
@@ -315,22 +284,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
     // 23.96 ms at S = 50 240 (1199 -> 1294 TF/s), 1.851 -> 1.756 ms at 13 376.  The S1 / S2 sched_group_barrier hints are NOT used here: with them 23.99 ms (no gain), and on the
     // peeled loop with the barrier at the end they LOSE (25.27 vs 24.41 ms): they place exponentials between the QK^T(1) MFMAs, which chain on one accumulator.  Launches whose
     // key-multiplicity tiles recur (key_bias_period > 0: sequence parallelism) run the KBP instance: runs of ordinary tiles in an inner loop, the key-multiplicity tile between two runs through a copy of its own.
-#define AG_EXPF(sa_, p0_, p1_, ps_, qi_)                                                             \
-        if constexpr (ABL & 1) {                                                                \
-            float sc0_ = 0.f, sc1_ = 0.f;                                                            \
-            _Pragma("unroll") for (int r = 0; r < 16; r += 2) {                                      \
-                float e0_ = sa_[r], e1_ = sa_[r + 1];                                                \
-                asm volatile("v_mov_b32 %0, %0" : "+v"(e0_)); asm volatile("v_mov_b32 %0, %0" : "+v"(e1_)); \
-                sc0_ += e0_; sc1_ += e1_;                                                            \
-                if (r < 8) { p0_[r] = (__bf16)e0_; p0_[r + 1] = (__bf16)e1_; }                       \
-                else { p1_[r - 8] = (__bf16)e0_; p1_[r - 7] = (__bf16)e1_; }                         \
-            }                                                                                        \
-            ps_ = (sc0_ + sc1_) * 0.f;                                                               \
-        } else AG_EXPB(sa_, p0_, p1_, ps_)
-// ABL 32: the fragment reads are ISSUED (inline asm: hipcc neither counts nor waits for them) into registers that an empty asm "consumes" where the MFMA would -- the MFMAs
-// themselves run on stale registers: the reads' issue slots and LDS traffic without their s_waitcnt lgkmcnt stalls
-#define AG_RD_DUMMY(dst_, ptr_) asm volatile("ds_read_b128 %0, %1" : "=v"(dst_) : "v"((uint32_t)(uintptr_t)(ptr_)))
-#define AG_USE_DUMMY(x_) asm volatile("" :: "v"(x_))
+#define AG_EXPF(sa_, p0_, p1_, ps_, qi_) AG_EXPB(sa_, p0_, p1_, ps_)
 #define AG_LOAD_KFA(slot_)                                                                           \
         { _Pragma("unroll") for (int kk = 0; kk < 8; ++kk) kfa_n[kk] = *reinterpret_cast<const bf16x8*>(kring + (slot_) * AG_KTILE + kx[kk]); }
 #define AG_FAST_A(KB_)                                                                               \
@@ -341,22 +295,20 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
         const int lim = 0;                                                                           \
         const float kbv = PRESC ? p.key_bias_log2 : p.key_bias_log2 / c2;                            \
         f32x16 sa0, sa1;                                                                             \
-        bf16x8 kfb[8], vfa[8], dk[8], dv[8];                                                         \
+        bf16x8 kfb[8], vfa[8];                                                                       \
         float ps0 = 0.f, ps1 = 0.f;                                                                  \
         __builtin_amdgcn_s_setprio(1);                                                               \
         /* S0: QK(0) on the prefetched fragments; block-1 K fragments stream in behind the MFMAs */  \
         _Pragma("unroll")                                                                            \
         for (int kk = 0; kk < 8; ++kk) {                                                             \
-            if constexpr ((ABL & 32) != 0) { AG_RD_DUMMY(dk[kk], kb + 8192 + kx[kk]); kfb[kk] = kfa_n[kk]; } else \
-            if constexpr (ABL & 2) kfb[kk] = kfa_n[kk];                                              \
-            else kfb[kk] = *reinterpret_cast<const bf16x8*>(kb + 8192 + kx[kk]);                    \
+            kfb[kk] = *reinterpret_cast<const bf16x8*>(kb + 8192 + kx[kk]);                          \
             if (kk == 0) { AG_MM(sa0, kfa_n[kk], qf[kk], negm) } else { AG_MM(sa0, kfa_n[kk], qf[kk], sa0) } \
             __builtin_amdgcn_sched_barrier(0);                                                       \
         }                                                                                            \
         /* S1: QK(1) || exp(0); V fragments of block 0 stream in */                                  \
         _Pragma("unroll")                                                                            \
         for (int kk = 0; kk < 8; ++kk) {                                                             \
-            if constexpr ((ABL & 32) != 0) { AG_USE_DUMMY(dk[kk]); AG_RD_DUMMY(dv[kk], vb + (kk & 3) * 4096 + vx[kk >> 2]); vfa[kk] = kfa_n[kk]; } else if constexpr (ABL & 2) vfa[kk] = kfa_n[kk]; else vfa[kk] = *reinterpret_cast<const bf16x8*>(vb + (kk & 3) * 4096 + vx[kk >> 2]); \
+            vfa[kk] = *reinterpret_cast<const bf16x8*>(vb + (kk & 3) * 4096 + vx[kk >> 2]);          \
             if (kk == 0) { AG_MM(sa1, kfb[kk], qf[kk], negm) } else { AG_MM(sa1, kfb[kk], qf[kk], sa1) } \
         }                                                                                            \
         if (KB_) { _Pragma("unroll") for (int r = 0; r < 16; ++r) sa0[r] += kbv; }                    \
@@ -369,7 +321,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
         /* S2: PV(0) || exp(1); V fragments of block 1 stream in (they outlive this macro: S3 sits behind the barrier) */ \
         _Pragma("unroll")                                                                            \
         for (int i = 0; i < 8; ++i) {                                                                \
-            if constexpr ((ABL & 32) != 0) { AG_USE_DUMMY(dv[i]); AG_RD_DUMMY(dk[i], vb + (i & 3) * 4096 + vx[2 + (i >> 2)]); vfb_n[i] = kfa_n[i]; } else if constexpr (ABL & 2) vfb_n[i] = kfa_n[i]; else vfb_n[i] = *reinterpret_cast<const bf16x8*>(vb + (i & 3) * 4096 + vx[2 + (i >> 2)]); \
+            vfb_n[i] = *reinterpret_cast<const bf16x8*>(vb + (i & 3) * 4096 + vx[2 + (i >> 2)]);     \
             AG_MM(oacc[i & 3], vfa[i], pb[i >> 2], oacc[i & 3])                                      \
         }                                                                                            \
         if (KB_) { _Pragma("unroll") for (int r = 0; r < 16; ++r) sa1[r] += kbv; }                    \
@@ -379,15 +331,13 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
             AG_EXPF(sa1, pb[2], pb[3], ps1, 2)                                                          \
         }                                                                                            \
         l_run += ps1;                                                                                \
-        if constexpr ((ABL & 32) != 0) { _Pragma("unroll") for (int i = 0; i < 8; ++i) AG_USE_DUMMY(dk[i]); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } \
         }
     /* S3: PV(1); PF_ (literal): the next tile's first K fragments come in from ring slot gs ^ 1 behind the MFMAs */
 #define AG_FAST_B(PF_)                                                                               \
         {                                                                                            \
         _Pragma("unroll")                                                                            \
         for (int i = 0; i < 8; ++i) {                                                                \
-            if constexpr ((ABL & 32) != 0) { bf16x8 d_; AG_RD_DUMMY(d_, kring + (gs ^ 1) * AG_KTILE + kx[i]); AG_USE_DUMMY(d_); } \
-            else if ((PF_) && !(ABL & 2)) kfa_n[i] = *reinterpret_cast<const bf16x8*>(kring + (gs ^ 1) * AG_KTILE + kx[i]); \
+            if (PF_) kfa_n[i] = *reinterpret_cast<const bf16x8*>(kring + (gs ^ 1) * AG_KTILE + kx[i]); \
             AG_MM(oacc[i & 3], vfb_n[i], pb[2 + (i >> 2)], oacc[i & 3])                              \
             __builtin_amdgcn_sched_barrier(0);                                                       \
         }                                                                                            \
@@ -409,8 +359,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
         {                                                                                            \
             const int u = (u_), gs = (gs_);                                                          \
             AG_FAST_A(KB_)                                                                           \
-            if constexpr (!(ABL & 8)) AG_BARRIER();            /* tile u + 1 has landed (the vmcnt(0) this fence carries) and is visible; every wave is done with slot gs */ \
-            if (!(ABL & 4) && u + 2 < nt) AG_STAGE(u + 2, gs);                                       \
+            AG_BARRIER();                                      /* tile u + 1 has landed (the vmcnt(0) this fence carries) and is visible; every wave is done with slot gs */ \
+            if (u + 2 < nt) AG_STAGE(u + 2, gs);                                                     \
             AG_FAST_B(1)      /* always prefetches: behind the last fast tile the fragments are not used (slot gs ^ 1 then holds the ragged last tile or old data; nothing writes it) */ \
         }
         // two tiles per trip: the ring slots are literals, so every LDS address of the loop is a loop-invariant register + an immediate offset (the one-tile loop spent 20 v_add_u32 per
@@ -462,40 +412,21 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
     }
 
     // ---- epilogue: lane (q, h) holds O[q][32db + 8a + 4h + c], r = 4a + c -- 8 bytes of a row per (db, a), the other half-wave the neighbouring 8.
-    // Packed pairs of the groups a = 2j / 2j+1 are exchanged between the half-waves (v_permlane32_swap): lanes 0-31 then hold columns 16j .. 16j+7
-    // of the 32-column block, lanes 32-63 columns 16j+8 .. 16j+15 -> ONE 16-byte store instead of two 8-byte ones (MI355X_MICROARCH.md T21: the
-    // store tail of this layout is store-ISSUE-bound; the same exchange as the GEMM epilogue's).  MEASURED AND NOT ADOPTED (round 3,
-    // profiles/r03_attn_variants_v0.log, same process, interleaved): 25.380 vs 25.380 ms at S = 50 240, 1.889 vs 1.867 ms at S = 13 376 (-1.1 %) --
-    // with 785 key tiles per workgroup the epilogue is ~1 % of a workgroup's life and the 16 swaps cost what the 8 saved stores bought.  The
-    // default keeps the 8-byte stores; VAR 7 (ablation build) is the widened form, bit-identical.
-    if constexpr (VAR == 11) tl3 = wall_clock64();
+    // (16-byte stores through v_permlane32_swap, nontemporal stores and a static priority for waves 4-7 were measured in round 3 and not adopted -- profiles/r03_attn_variants_v0.log:
+    // with 785 key tiles per workgroup the epilogue is ~1 % of a workgroup's life; those arms, the per-workgroup timeline and the fast loop's cost-account arms lived in this file
+    // until round 6 and are in the history, commit 299008c.)
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
     const int qrow = q0 + lq;
-#define AG_STORE_ROW(dst_, wide_)                                                                            \
+#define AG_STORE_ROW(dst_)                                                                                   \
     do {                                                                                                     \
-        if (wide_) {                                                                                         \
-            bf16_t* const o16_ = (dst_) + 8 * lh;                                                            \
-            _Pragma("unroll") for (int db = 0; db < 4; ++db)                                                 \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                  \
-                const uint32_t w00_ = pack2bf(oacc[db][8 * j + 0] * inv, oacc[db][8 * j + 1] * inv), w01_ = pack2bf(oacc[db][8 * j + 2] * inv, oacc[db][8 * j + 3] * inv); \
-                const uint32_t w10_ = pack2bf(oacc[db][8 * j + 4] * inv, oacc[db][8 * j + 5] * inv), w11_ = pack2bf(oacc[db][8 * j + 6] * inv, oacc[db][8 * j + 7] * inv); \
-                auto s0_ = __builtin_amdgcn_permlane32_swap(w00_, w10_, false, false);                       \
-                auto s1_ = __builtin_amdgcn_permlane32_swap(w01_, w11_, false, false);                       \
-                if (qrow < Sq) *reinterpret_cast<uint4*>(o16_ + 32 * db + 16 * j) = make_uint4(s0_[0], s1_[0], s0_[1], s1_[1]); \
-            }                                                                                                \
-        } else if (qrow < Sq) {                                                                              \
+        if (qrow < Sq) {                                                                                     \
             bf16_t* const o8_ = (dst_) + 4 * lh;                                                             \
             _Pragma("unroll") for (int db = 0; db < 4; ++db)                                                 \
             _Pragma("unroll") for (int a = 0; a < 4; ++a) {                                                  \
                 uint2 v;                                                                                     \
                 v.x = pack2bf(oacc[db][4 * a + 0] * inv, oacc[db][4 * a + 1] * inv);                         \
                 v.y = pack2bf(oacc[db][4 * a + 2] * inv, oacc[db][4 * a + 3] * inv);                         \
-                if constexpr (VAR == 8) {   /* ablation build: NONTEMPORAL output stores -- O is read once, by the out-projection, long after; K / V should keep the L2 */ \
-                    typedef __attribute__((ext_vector_type(2))) unsigned int ag_u32x2;                       \
-                    const ag_u32x2 nv_ = {v.x, v.y};                                                         \
-                    __builtin_nontemporal_store(nv_, reinterpret_cast<ag_u32x2*>(o8_ + 32 * db + 8 * a));    \
-                } else                                                                                       \
                 *reinterpret_cast<uint2*>(o8_ + 32 * db + 8 * a) = v;                                        \
             }                                                                                                \
         }                                                                                                    \
@@ -503,32 +434,11 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_glds_kernel(AttnParams p) {
     if (nsp > 1) {
         // partial result of this key range: normalised rows (bf16) + log2-sum-exp; attn_merge_kernel combines the ranges
         const long prow = ((long)item * nsp + split) * 256 + wave * 32 + lq;
-        AG_STORE_ROW(p.part_o + prow * 128, VAR == 7);
+        AG_STORE_ROW(p.part_o + prow * 128);
         if (qrow < Sq && lh == 0) p.part_lse[prow] = (PRESC ? m_run : m_run * c2) + __builtin_amdgcn_logf(l_tot);
         return;
     }
-    const bool wide = VAR == 7 && ((p.o_ss & 7) == 0) && ((((uintptr_t)p.o) & 15) == 0);     // wave-uniform
-    if constexpr (VAR == 9) {      // ablation build, WRONG results: no output stores (one dword per lane keeps the accumulators alive) -- what the store tail costs
-        float keep_ = 0.f;
-#pragma unroll
-        for (int db = 0; db < 4; ++db)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) keep_ += oacc[db][r];
-        if (keep_ * inv == 123.456f) p.o[0] = (bf16_t)1u;
-        return;
-    }
-    AG_STORE_ROW(p.o + (long)(qrow < Sq ? qrow : 0) * p.o_ss + head * 128, wide);
-    if constexpr (VAR == 11) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const long tl4 = wall_clock64();
-        if (tid == 0 && p.work && (size_t)(blockIdx.x + 1) * 64 <= p.work_bytes) {
-            long* const tr = (long*)p.work + (size_t)blockIdx.x * 8;
-            unsigned hw = 0, xcc = 0;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            tr[0] = tl0; tr[1] = tl1; tr[2] = tl2; tr[3] = tl3; tr[4] = tl4; tr[5] = ((long)xcc << 32) | hw; tr[6] = wid; tr[7] = nt;
-        }
-    }
+    AG_STORE_ROW(p.o + (long)(qrow < Sq ? qrow : 0) * p.o_ss + head * 128);
 }
 
 // combine the key ranges of the tail items: out = sum_i 2^(lse_i - M) O_i / sum_i 2^(lse_i - M).  One thread per (query, 8 channels).
@@ -612,31 +522,31 @@ extern "C" int utx_launch_attn_merge(const AttnParams* t, int n_items, hipStream
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 
-template <int PRESC, int TPB, int VAR = 0, bool BLK = false, bool FAST = false, bool KBP = false>
+template <int PRESC, int TPB, bool BLK = false, bool FAST = false, bool KBP = false>
 static int launch_glds(AttnParams p, hipStream_t stream) {
     UTX_ONCE_PER_DEVICE(attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_glds_kernel<PRESC, TPB, VAR, BLK, FAST, KBP>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_glds_kernel<PRESC, TPB, BLK, FAST, KBP>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, AG_LDS(TPB)) != hipSuccess) return -3;
         UTX_ONCE_DONE(attr_set);
     }
     p.nqb = ((p.Sq > 0 ? p.Sq : p.S) + 255) / 256;
     p.w_base = 0; p.nsplit = 1; p.tiles_per_split = 0; p.part_o = nullptr; p.part_lse = nullptr;
     int pl[4] = {p.nqb * p.H, 0, 1, 0};
-    if (TPB == 1 && (VAR == 0 || VAR == 6 || VAR == 7 || VAR == 8 || VAR == 9 || VAR == 10) && !p.flags) utx_attn_split_plan_impl(p.H, p.Sq, p.S, utx_ncu(), pl);
+    if (TPB == 1 && !p.flags) utx_attn_split_plan_impl(p.H, p.Sq, p.S, utx_ncu(), pl);
     const int nwg = pl[0], nfull = pl[1], ns = pl[2], tps = pl[3], r = nwg - nfull;
     // the scratch of the split is CALLER-OWNED (utx_attn_fwd_bf16_ws; the legacy entry points pass the context's own buffer, grown outside of any
     // capture): nothing is allocated here, a launch whose scratch is missing or too small runs unsplit -- same result up to one bf16 rounding of the
     // tail rows, a fraction of a round slower
     const size_t rows = (size_t)r * ns * 256;
     if (ns <= 1 || !p.work || p.work_bytes < rows * (128 * sizeof(bf16_t) + sizeof(float))) {
-        hipLaunchKernelGGL((attn_fwd_glds_kernel<PRESC, TPB, VAR, BLK, FAST, KBP>), dim3(nwg), dim3(512), AG_LDS(TPB), stream, p);
+        hipLaunchKernelGGL((attn_fwd_glds_kernel<PRESC, TPB, BLK, FAST, KBP>), dim3(nwg), dim3(512), AG_LDS(TPB), stream, p);
         return hipGetLastError() == hipSuccess ? 0 : -4;
     }
-    hipLaunchKernelGGL((attn_fwd_glds_kernel<PRESC, TPB, VAR, BLK, FAST, KBP>), dim3(nfull), dim3(512), AG_LDS(TPB), stream, p);
+    hipLaunchKernelGGL((attn_fwd_glds_kernel<PRESC, TPB, BLK, FAST, KBP>), dim3(nfull), dim3(512), AG_LDS(TPB), stream, p);
     AttnParams t = p;
     t.w_base = nfull; t.nsplit = ns; t.tiles_per_split = tps;
     t.part_o = (bf16_t*)p.work; t.part_lse = (float*)((char*)p.work + rows * 128 * sizeof(bf16_t));
-    hipLaunchKernelGGL((attn_fwd_glds_kernel<PRESC, TPB, VAR, BLK, FAST, KBP>), dim3(r * ns), dim3(512), AG_LDS(TPB), stream, t);
+    hipLaunchKernelGGL((attn_fwd_glds_kernel<PRESC, TPB, BLK, FAST, KBP>), dim3(r * ns), dim3(512), AG_LDS(TPB), stream, t);
     const long mt = (long)r * 256 * 16;
     hipLaunchKernelGGL(attn_merge_kernel, dim3((unsigned)((mt + 255) / 256)), dim3(256), 0, stream, t, r);
     return hipGetLastError() == hipSuccess ? 0 : -4;
@@ -647,39 +557,13 @@ extern "C" int utx_launch_attn_fwd_glds(const AttnParams* p, int presc, hipStrea
     const int tpb = g_utx_opt.attn_tpb;
     if (p->blk_rows > 0) {      // block-strided operands (the sequence-parallel receive buffer): whole 64-key tiles per block, whole blocks per sequence
         if (tpb != 1 || p->flags || (p->blk_rows % AG_KVB) || (p->S % p->blk_rows) || ((p->q_bs | p->k_bs | p->vt_bs) & 7)) return -2;
-        return presc ? launch_glds<1, 1, 0, true>(*p, stream) : launch_glds<0, 1, 0, true>(*p, stream);
+        return presc ? launch_glds<1, 1, true>(*p, stream) : launch_glds<0, 1, true>(*p, stream);
     }
     if (tpb == 2) return presc ? launch_glds<1, 2>(*p, stream) : launch_glds<0, 2>(*p, stream);
-#ifdef UTX_ABLATION
-    { const int var = g_utx_opt.attn_var_abl;   // timing A/B only: 1 = no s_setprio, 2 = no interleave hints, 3 = half the fragment reads (WRONG results), 4 = row sums with v_pk_add_f32
-      if (var == 1 && presc) return launch_glds<1, 1, 1>(*p, stream);
-      if (var == 2 && presc) return launch_glds<1, 1, 2>(*p, stream);
-      if (var == 3 && presc) return launch_glds<1, 1, 3>(*p, stream);
-      if (var == 4 && presc) return launch_glds<1, 1, 4>(*p, stream);
-      if (var == 5 && presc) return launch_glds<1, 1, 5>(*p, stream);
-      if (var == 6 && presc) return launch_glds<1, 1, 6>(*p, stream);      // static priority for waves 4-7 (correct results)
-      if (var == 8 && presc) return launch_glds<1, 1, 8>(*p, stream);      // nontemporal output stores (correct results)
-      if (var == 9 && presc) return launch_glds<1, 1, 9>(*p, stream);      // no output stores (WRONG results): the store tail's share of a workgroup's fixed cost
-      if (var == 10 && presc) return launch_glds<1, 1, 10>(*p, stream);    // no first-tile max pass (WRONG results)
-      if (var >= 32 && presc) switch (var - 32) {      // the FAST loop's cost account (ABL bits above), WRONG results except 0
-          case 0: return launch_glds<1, 1, 32, false, true>(*p, stream);
-          case 1: return launch_glds<1, 1, 33, false, true>(*p, stream);
-          case 2: return launch_glds<1, 1, 34, false, true>(*p, stream);
-          case 4: return launch_glds<1, 1, 36, false, true>(*p, stream);
-          case 8: return launch_glds<1, 1, 40, false, true>(*p, stream);
-          case 14: return launch_glds<1, 1, 46, false, true>(*p, stream);
-          case 12: return launch_glds<1, 1, 44, false, true>(*p, stream);
-          case 32: return launch_glds<1, 1, 64, false, true>(*p, stream);
-
-          default: break;
-      }
-      if (var == 11 && presc) return launch_glds<1, 1, 11>(*p, stream);    // per-workgroup timeline into p.work (correct results; never split)
-      if (var == 7 && presc) return launch_glds<1, 1, 7>(*p, stream); }    // 16-byte epilogue stores through v_permlane32_swap (correct results)
-#endif
     // the pre-scaled form the DiT uses: the fast loop (FAST above); UTX_ATTN_PEEL=0: the general loop, the default until round 5 (A/B and the reference bits of the stress tests)
     // launches whose key-multiplicity tiles recur (key_bias_period > 0: sequence parallelism): the KBP instance (a loop nest: a second copy of the fast tile for those tiles INSIDE the
     // loop made hipcc spill in it -- 45 scratch accesses per trip with one tile per trip, 293 with two)
-    if (presc && g_utx_opt.attn_peel != 0 && (p->key_bias_period > 0 && p->key_bias_log2 != 0.f)) return launch_glds<1, 1, 0, false, true, true>(*p, stream);
-    if (presc && g_utx_opt.attn_peel != 0) return launch_glds<1, 1, 0, false, true>(*p, stream);
+    if (presc && g_utx_opt.attn_peel != 0 && (p->key_bias_period > 0 && p->key_bias_log2 != 0.f)) return launch_glds<1, 1, false, true, true>(*p, stream);
+    if (presc && g_utx_opt.attn_peel != 0) return launch_glds<1, 1, false, true>(*p, stream);
     return presc ? launch_glds<1, 1>(*p, stream) : launch_glds<0, 1>(*p, stream);
 }

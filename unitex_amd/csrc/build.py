@@ -61,7 +61,7 @@ def _newer(src, obj):
     if not os.path.exists(obj):
         return True
     t = os.path.getmtime(obj)
-    deps = [src] + [os.path.join(HERE, h) for h in os.listdir(HERE) if h.endswith(".h")]
+    deps = [src] + [os.path.join(HERE, h) for h in os.listdir(HERE) if h.endswith(".h") or h.endswith(".inc")]
     deps.append(os.path.normpath(os.path.join(HERE, "..", "..", "include", "unitex_hip.h")))
     return any(os.path.getmtime(d) > t for d in deps)
 
@@ -83,6 +83,11 @@ def build(verbose=True, ablate=False):
     """ablate=True builds libunitex_hip_ablate.so instead: the same sources with -DUTX_ABLATION, i.e. with the timing-ablation
     switches (UTX_ATTN_VAR / UTX_ATTN_DEBUG / UTX_GEMM_DEBUG -- wrong results by design) compiled in.  Only tools/ load it
     (unitex_amd._lib.use_ablation_library()); the product, the tests and bench.py never do."""
+    if ablate:      # the A/B arms of the generated 4 x 64 attention stream (attention_q64_asm_var.inc, git-ignored)
+        gen = os.path.normpath(os.path.join(HERE, "..", "..", "tools", "gen_attn_q64.py"))
+        r = subprocess.run([sys.executable, gen, "--variants", "--keep-default"], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("gen_attn_q64.py failed:\n" + r.stderr[-2000:])
     objdir = OBJDIR + ("_ablate" if ablate else "")
     defines = ["-DUTX_ABLATION"] if ablate else []
     os.makedirs(objdir, exist_ok=True)

@@ -220,28 +220,31 @@ __global__ __launch_bounds__(256) void bvh_trace_kernel(const int* info, const f
 // synchronisation) or, for the plain utx_bvh_build, one hipMalloc owned by the handle.  The tree depth -- which decides the traversal the launches use -- comes back
 // through a pinned host word behind an event and is read LAZILY, at the first launch that needs it (bvh_depth below).
 static size_t bvh_align(size_t x) { return (x + 255) & ~(size_t)255; }
-// pinned depth words: ONE hipHostMalloc per process (a pinned allocation costs far more than a build), slots handed out under a mutex
 namespace {
+// pinned words the builds copy their tree depth into.  Grows in chunks of 1024 words (a long-lived service may hold any number of meshes); chunks are never freed and the
+// pool itself is a leaked heap singleton: a utx_bvh_free that runs during static destruction still finds its mutex and vectors alive.
 struct DepthPool {
     std::mutex mu;
-    int* base = nullptr;
-    std::vector<int> free_slots;
+    std::vector<int*> chunks;
+    std::vector<int*> free_slots;
     int* take() {
         std::lock_guard<std::mutex> lock(mu);
-        if (!base) {
-            if (hipHostMalloc((void**)&base, 1024 * sizeof(int), hipHostMallocDefault) != hipSuccess) { base = nullptr; return nullptr; }
-            for (int i = 1023; i >= 0; --i) free_slots.push_back(i);
+        if (free_slots.empty()) {
+            int* c = nullptr;
+            if (hipHostMalloc((void**)&c, 1024 * sizeof(int), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+            chunks.push_back(c);
+            for (int i = 1023; i >= 0; --i) free_slots.push_back(c + i);
         }
-        if (free_slots.empty()) return nullptr;
-        const int i = free_slots.back(); free_slots.pop_back();
-        return base + i;
+        int* const p = free_slots.back(); free_slots.pop_back();
+        return p;
     }
     void give(int* p) {
         std::lock_guard<std::mutex> lock(mu);
-        if (base && p >= base && p < base + 1024) free_slots.push_back((int)(p - base));
+        for (int* c : chunks)
+            if (p >= c && p < c + 1024) { free_slots.push_back(p); return; }
     }
 };
-DepthPool g_depth_pool;
+static DepthPool& depth_pool() { static DepthPool* const pool = new DepthPool(); return *pool; }
 }
 static size_t bvh_sort_bytes(int F) {
     size_t n = 0;
@@ -259,9 +262,8 @@ extern "C" size_t utx_bvh_workspace_bytes_impl(int F) {
 extern "C" int utx_bvh_build_ws_impl(const float* verts, int V, const int* faces, int F, void* work, size_t work_bytes, utx_bvh** out, hipStream_t stream) {
     (void)V;
     if (F < 1 || !out || !work || ((uintptr_t)work & 255) || work_bytes < utx_bvh_workspace_bytes_impl(F)) return -2;
-    utx_bvh* b = new utx_bvh();
-    memset(b, 0, sizeof(*b));
-    b->F = F; b->verts = verts; b->faces = faces; b->depth = -1;
+    utx_bvh* b = new utx_bvh();      // value-initialised: every pointer null, the event null
+    b->F = F; b->verts = verts; b->faces = faces; b->depth.store(-1, std::memory_order_relaxed);
     const size_t nn = 2 * (size_t)F - 1;
     char* w = (char*)work;
     auto take = [&](size_t bytes) { void* p_ = w; w += bvh_align(bytes); return p_; };
@@ -279,7 +281,7 @@ extern "C" int utx_bvh_build_ws_impl(const float* verts, int V, const int* faces
     b->sort_tmp_bytes = bvh_sort_bytes(F);
     b->sort_tmp = take(b->sort_tmp_bytes);
 #define BCHK(e) do { if ((e) != hipSuccess) { utx_bvh_free_impl(b); return -7; } } while (0)
-    b->depth_host = g_depth_pool.take();      // more than 1024 live trees: none left
+    b->depth_host = depth_pool().take();      // a pinned word of the (growing) pool; nullptr only when pinned host memory itself is exhausted
     if (!b->depth_host) { utx_bvh_free_impl(b); return -7; }
     BCHK(hipEventCreateWithFlags(&b->depth_ready, hipEventDisableTiming));
     BCHK(hipMemsetAsync(b->depth_dev, 0, sizeof(int), stream));
@@ -295,7 +297,13 @@ extern "C" int utx_bvh_build_ws_impl(const float* verts, int V, const int* faces
     if (hipGetLastError() != hipSuccess) { utx_bvh_free_impl(b); return -4; }
     // the tree depth decides, once per mesh, which traversal the launches use: copied to the pinned word, read by bvh_depth() when a launch first asks (no wait here)
     BCHK(hipMemcpyAsync(b->depth_host, b->depth_dev, sizeof(int), hipMemcpyDeviceToHost, stream));
-    BCHK(hipEventRecord(b->depth_ready, stream));
+    if (hipEventRecord(b->depth_ready, stream) != hipSuccess) {
+        // cold path: the copy into the pinned word is enqueued but no event stands behind it -- drain the stream before the word goes back to the pool (utx_bvh_free's
+        // hipEventSynchronize on a never-recorded event would return at once and a later tree could read a stale or foreign depth from the slot)
+        (void)hipStreamSynchronize(stream);
+        utx_bvh_free_impl(b);
+        return -7;
+    }
 #undef BCHK
     *out = b;
     return 0;
@@ -318,9 +326,9 @@ extern "C" int utx_bvh_build_impl(const float* verts, int V, const int* faces, i
 
 extern "C" void utx_bvh_free_impl(utx_bvh* b) {
     if (!b) return;
-    if (b->depth_ready && b->depth < 0 && b->depth_host) (void)hipEventSynchronize(b->depth_ready);      // the copy into the pinned word must have landed before the word is handed on
+    if (b->depth_ready && b->depth.load(std::memory_order_relaxed) < 0 && b->depth_host) (void)hipEventSynchronize(b->depth_ready);      // the copy into the pinned word must have landed before the word is handed on
     if (b->depth_ready) (void)hipEventDestroy(b->depth_ready);
-    if (b->depth_host) g_depth_pool.give(b->depth_host);
+    if (b->depth_host) depth_pool().give(b->depth_host);
     if (b->owned) (void)hipFree(b->owned);      // the caller's workspace (utx_bvh_build_ws) is the caller's to release
     delete b;
 }
@@ -334,19 +342,25 @@ extern "C" int utx_bvh_arrays_impl(utx_bvh* b, int** info, float** aabb, unsigne
     return b->F;
 }
 
-// longest root-to-leaf path; the first call waits for the build's copy of it (an event behind the build's last kernel), later calls are a load.  -1: the wait failed
+// longest root-to-leaf path; the first call waits for the build's copy of it (an event behind the build's last kernel), later calls are a load.  -1: the wait failed.
+// The lazy write of b->depth is a relaxed atomic store of a value every thread computes identically: two threads launching on one fresh handle both wait on the event and
+// both store the same word (utx_bvh.depth is a std::atomic<int>).
 extern "C" int utx_bvh_depth_impl(utx_bvh* b) {
-    if (b->depth < 0) {
+    int d = b->depth.load(std::memory_order_relaxed);
+    if (d < 0) {
         if (hipEventSynchronize(b->depth_ready) != hipSuccess) return -1;
-        b->depth = *b->depth_host;
+        d = *b->depth_host;
+        b->depth.store(d, std::memory_order_relaxed);
     }
-    return b->depth;
+    return d;
 }
 
 extern "C" int utx_bvh_trace_impl(utx_bvh* b, const float* ro, const float* rd, long R, int* tid, unsigned long long* visited, int force_stack,
                                   hipStream_t stream) {
     if (!b || R <= 0) return -2;
-    if (utx_bvh_depth_impl(b) <= UTX_BVH_PACKED_MAX_DEPTH && !force_stack) {
+    const int depth = utx_bvh_depth_impl(b);
+    if (depth < 0) return -7;      // the build's depth never arrived (event wait failed): no traversal may be chosen on a guess -- as utx_launch_backproject
+    if (depth <= UTX_BVH_PACKED_MAX_DEPTH && !force_stack) {
         hipLaunchKernelGGL(bvh_trace_packed_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, stream, b->nodes, b->tris, ro, rd, R, tid, visited);
         return hipGetLastError() == hipSuccess ? 0 : -4;
     }

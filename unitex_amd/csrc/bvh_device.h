@@ -188,6 +188,7 @@ __device__ __forceinline__ int bvh_trace_packet(const float4* __restrict__ nodes
     return hit_tid;
 }
 
+#include <atomic>
 struct utx_bvh {
     int F;
     int* info;       // [2F-1][3]
@@ -204,7 +205,7 @@ struct utx_bvh {
     float4* nodes;   // [2F-1][2] packed tree (bvh_trace_packed)
     float4* tris;    // [F][3]
     int* depth_dev;  // max number of ancestors of a leaf
-    int depth;       // host copy (-1: not read back yet -- utx_bvh_depth_impl waits for depth_ready once); the packed traversal is used when depth <= UTX_BVH_PACKED_MAX_DEPTH
+    std::atomic<int> depth;   // host copy (-1: not read back yet -- utx_bvh_depth_impl waits for depth_ready once; atomic: a handle may see its first launches from two threads); the packed traversal is used when depth <= UTX_BVH_PACKED_MAX_DEPTH
     int* depth_host;           // pinned word the build copies depth_dev into
     hipEvent_t depth_ready;    // recorded behind that copy
     void* owned;               // the one hipMalloc of utx_bvh_build (null: the arrays live in the caller's workspace, utx_bvh_build_ws)

@@ -56,7 +56,8 @@ struct Attn8Params {
 struct UtxOptions {
     int attn_glds;        // 1 (default): LDS-DMA staged attention kernel; 0: register-staged variants
     int attn_fast;        // register-staged kernel only: 2 block-pipelined sum-checked softmax, 1 sum-checked, 0 per-tile max
-    int attn_q64;         // 1: the 4 x 64 kernel + repair pass
+    int attn_q64;         // 1 (default since round 6): launches the 4 x 64 kernel takes (attention_q64.hip: pre-scaled Q, whole 64-key tiles, contiguous operands, caller scratch) run it
+                          // + its repair pass; 0: the 8 x 32 kernel everywhere (A/B; bit-identical wherever the 8 x 32 kernel does not re-centre behind the first block)
     int attn_tpb;         // tiles per barrier of the LDS-DMA kernel (1 | 2)
     int attn_tailsplit;   // 1 (default): key-split tail round
     int gemm_group_m;     // 0 = built-in GROUP_M
@@ -72,6 +73,7 @@ struct UtxOptions {
                           // barrier between S2 and S3, next tile's first K fragments read under S3); 0: the general loop (the default until round 4).  Same bits either way.
     int attn8_peel;       // 1 (default since round 5): MX fp8 attention with tile 0 / a ragged last tile outside the loop and the loop's exponentials in quarters under the PV MFMAs
                           // (attn_fwd_fp8_kernel<1>, attention_fp8.hip); 0: the general loop.  Same bits either way.
+    int nn_grid;          // 0 (default): the NN fill's cell grid follows the atlas size; 64 | 128 | 256 force one (A/B and the grid-independence test; same results)
 };
 extern UtxOptions g_utx_opt;
 

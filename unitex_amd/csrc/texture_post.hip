@@ -63,9 +63,16 @@ extern "C" int utx_launch_seam_mask(const void* winner, const float* rast2d, int
 // dependent, scattered 12-byte load per candidate).  Now (a) 256^3 cells (a quarter of the candidates per ring volume on a surface), (b) the seen texels'
 // positions are GATHERED into cell order once ({x, y, z, texel index} as one 16-byte record), so a query streams each cell's candidates from
 // consecutive addresses.  Same exact search, same stopping rule, same tie rule: the result does not depend on the grid.
-// Round 5: the resolution follows the atlas -- 256 for T >= 1024^2 texels, 128 for T >= 256^2, 64 below: the cell table is 8 G^3 bytes (134 MB / 17 MB / 2 MB) and is
-// cleared on every call, which a small atlas should not pay for.  The result does not depend on the grid.
-static inline int nn_grid(long T) { return T >= (1L << 20) ? 256 : (T >= (1L << 16) ? 128 : 64); }
+// Round 5: the resolution follows the atlas: the cell table is 8 G^3 bytes (134 MB / 17 MB / 2 MB) and is cleared on every call, which a small atlas should not pay for.
+// Round 6: the steps sit where the candidate count per searched cell volume stays level -- 256 from 512^2 texels (a 1000^2 atlas, just under 2^20, used to drop to 128
+// and scan 8x the candidates per ring), 128 from 128^2, 64 below.  The result does not depend on the grid: UTX_NN_GRID (64 | 128 | 256) forces one, and
+// tests/test_geometry_gpu.py compares nn_index across all three on one input.  Positions outside [-1, 1] are clamped into edge cells; the stopping rule survives that: a
+// clamped point is at least as far from any query as its cell's inner face, and a clamped query only loses rings that hold no cells.
+static inline int nn_grid(long T) {
+    const int f = g_utx_opt.nn_grid;
+    if (f == 64 || f == 128 || f == 256) return f;
+    return T >= (1L << 18) ? 256 : (T >= (1L << 14) ? 128 : 64);
+}
 __device__ __forceinline__ int nn_cell1(float v, int G) {
     int c = (int)floorf((v + 1.0f) * ((float)G * 0.5f));
     return c < 0 ? 0 : (c > G - 1 ? G - 1 : c);

@@ -95,6 +95,8 @@ def time_backprojection(n_faces=50000, view_px=1024, atlas_px=2048, iters=3, war
     gbps = {k: bpt[k] * T / (stages[k] * 1e-3) / 1e9 for k in stages if k in bpt and stages[k] > 0}
     # total_ms brackets infer() with events on the launch stream: the stage chain + whatever the GPU idled waiting for the host.  kernel_sum_ms = the sum of the stage
     # brackets (each bracket holds its kernels and the gaps between them; the gaps BETWEEN stages -- torch allocations, the next stage's first launch -- are not in it);
-    # host_enqueue_ms = the host's wall time to enqueue the chain: when it approaches total_ms the chain is host-bound on that box.
+    # host_enqueue_ms = the host's wall time up to the chain's last enqueue.  The timed iterations reuse the mesh's cached tree, so it holds no device wait here; on a FRESH tree the
+    # first back-projection launch waits for the build's depth word (renderer_inverse.py), and the figure then includes that GPU time.  When it approaches total_ms with a cached tree the
+    # chain is host-bound on that box.
     return {"total_ms": float(np.mean(totals)), "kernel_sum_ms": float(sum(stages.values())), "host_enqueue_ms": float(np.mean(host_enq)), "stages_ms": stages, "stages_gbps": gbps, "faces": int(len(faces)),
             "texels": int(T), "covered_frac": covered, "view_px": view_px, "atlas_px": atlas_px, "nodes_per_ray": nodes_per_ray, "bvh_depth": depth}

@@ -102,7 +102,7 @@ class BVH:
         self.ctx = get_ctx(verts.device.index)
         self.verts, self.faces = _f(verts), _i(faces)   # kept alive: the handle borrows them
         h = C.c_void_p()
-        # every array of the tree in ONE torch allocation (caching allocator: no hipMalloc / hipFree on the path), the build enqueued without a host wait
+        # every array of the tree in ONE torch allocation (caching allocator: no hipMalloc / hipFree on the path), the build itself enqueued without a host wait (the wait moved one launch later: the first launch that needs the tree's depth blocks on the build's event once per tree)
         nbytes = int(self.ctx.lib.utx_bvh_workspace_bytes(faces.shape[0]))
         self.work = torch.empty(nbytes + 256, dtype=torch.uint8, device=verts.device)
         base = (self.work.data_ptr() + 255) & ~255

@@ -306,7 +306,9 @@ class NVDiffRendererInverse:
                 color_2d = torch.cat([ops.pull_push(baked[..., c:c + 3].contiguous(), mask_u8) for c in range(0, baked.shape[-1], 3)], dim=-1)
         with self._stage("to_u8"):
             tex = ops.to_u8(color_2d[..., :3].contiguous(), flip=True)  # tensor_to_image + FLIP_TOP_BOTTOM (link_pbr_to_mesh.py:17)
-        self.host_enqueue_ms = (time.perf_counter() - t_host0) * 1e3      # the host's time to ENQUEUE the whole chain (no device wait up to here); the copies below wait for the GPU
+        self.host_enqueue_ms = (time.perf_counter() - t_host0) * 1e3      # the host's wall time up to the last enqueue.  NOT free of device waits when the tree is fresh: the first utx_backproject behind utx_bvh_build_ws blocks in
+        # hipEventSynchronize(depth_ready) until the build -- and everything queued in front of it -- has run (the depth picks the traversal on the host), so on a new mesh this figure
+        # contains that GPU time; on a cached tree (DeviceMesh.optix, the benchmark's later iterations) it is enqueue time only.  The copies below wait for the GPU
         textured = TexturedMesh(m.vertices.cpu().numpy(), m.faces.cpu().numpy(), m.uvs01, tex.cpu().numpy())
         self.last = {"rast2d": rast2d, "winner": winner, "seam": seam, "atlas_prefill": baked, "view_mask": mv["mask_visiable"]}
         out = (textured, vis.bool()[..., None], (rast2d[..., 3] > 0)[None, ..., None], color_2d[None])
