@@ -77,13 +77,14 @@ __device__ __forceinline__ const char* w4_uniform(const char* p) {
     return (const char*)(((unsigned long)hi << 32) | lo);
 }
 
-// ABL (ablation build only, wrong results): 1 = no DMA in the loop, 2 = no fragment reads in the loop, 4 = no vmcnt wait / barrier, 8 = no epilogue,
-// 16 = epilogue without its C stores, 32 = the DMA cursor parked from the start (every DMA re-reads the same bytes)
+// (The timing arms of this kernel -- no DMA / no fragment reads / no barrier / no epilogue / parked cursor / the 16x16x32 MFMA-shape arm / the per-workgroup timeline / the
+// start stagger / plain C stores / the MX DMA placements -- lived here until round 6 and are in the history, commit 299008c; their measurements are quoted where they decided something.)
 // QKF: the fused q / k post-processing of utx_gemm_desc.qk_cols (plain kernel only)
 // MX: OCP MX fp8 operands with tile-packed E8M0 scales (utx_gemm_desc.mx8 == 2; "MX fp8" below): same staging, ring and epilogues, a K-tile is
 // 128 fp8 = the same 128-byte rows, 32 v_mfma_scale_f32_32x32x64_f8f6f4 per K-tile instead of 64 v_mfma_f32_32x32x16_bf16
-template <bool GATED, int ABL = 0, bool QKF = false, bool MX = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm256_w4_kernel(GemmParams p, int ntiles, int trace_wg, int sk_T, int sk_S) {
+template <bool GATED, bool QKF = false, bool MX = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm256_w4_kernel(GemmParams p, int ntiles, int reserved /* (the ablation arms' timeline workgroup until round 6; kept so that the kernel-argument layout -- and with it the register allocation of the five
+      instances -- is byte-for-byte what was measured: the listings before and after the arms left this file are instruction-identical) */, int sk_T, int sk_S) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -92,16 +93,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int l31 = lane & 31, lh = lane >> 5;
     const int G = gridDim.x;
     const int wid = xcd_remap(blockIdx.x, G);
-    // ABL 128 (ablation build): one workgroup's wave 0 writes a timeline into the buffer passed in the descriptor's (otherwise unused) zero_page field:
-    // per sub-stage the 100 MHz wall clock and the shader clock, a negative marker pair around every epilogue
-    long* const trace = ((ABL & 128) && blockIdx.x == (unsigned)trace_wg && tid == 0) ? (long*)p.zero_page : nullptr;
-    int trace_n = 0;
-    if constexpr ((ABL & 256) != 0) {      // ABL 256 (correct results): workgroups start up to 40 us apart, so tile boundaries (C store bursts) of different CUs stop coinciding
-        const long t0 = wall_clock64(), wait = (long)((blockIdx.x >> 3) & 15) * 4000 / 16;
-        while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(8);
-    }
-#define W4_TRACE(tag_) do { if ((ABL & 128) && trace && trace_n < 4000) { trace[3 * trace_n] = (tag_); trace[3 * trace_n + 1] = wall_clock64(); trace[3 * trace_n + 2] = __builtin_readcyclecounter(); ++trace_n; } } while (0)
-
     const int ntn = p.ntn & 0xffff, group_m = (p.ntn >> 16) & 0xff;
     const int ntm_ = (p.M + 255) / 256;
     const int per_group = group_m * ntn;
@@ -225,15 +216,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             W4_STAGE_AT(kk_, k1_, !ok_);                                                   \
         }                                                                                  \
     } while (0)
-    // ABL 32 only: parked from the start
-#define W4_PARK()                                                                          \
-    do {                                                                                   \
-        s_pA = (const char*)p.A; s_pB = (const char*)p.B;                                  \
-        voA0 = voA1 = voA2 = voA3 = voA4 = voA5 = voA6 = voA7 = dchunk;                    \
-        voB0 = voB1 = voB2 = voB3 = voB4 = voB5 = voB6 = voB7 = dchunk;                    \
-        s_ss = 0; s_seg_end = 0x7fffffff; s_seg = 2;                                       \
-    } while (0)
-
     // ---- compute cursor
     int c_tile = wid, c_ss = 0, c_nss = 0, c_m0 = 0, c_n0 = 0, c_slot = 0;
     int c_tj = -1;      // as s_tj; > 0 while the cursor is in a tail range (its c_tj-th)
@@ -255,19 +237,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     f32x16 acc[4][4];   // [jn][im], swapped MFMA: rows = n, cols = m
     typedef __attribute__((ext_vector_type(4))) float w4_f32x4;
     typedef __attribute__((ext_vector_type(4))) unsigned int w4_u32x4s;
-    w4_f32x4 acc4[4][4][2];   // ABL 64 only (timing experiment, wrong results): every 32x32x16 MFMA replaced by two 16x16x32 on the same operands
     // every use of the accumulators is an "a"-constrained asm operand (MFMA, zeroing, the epilogue's reads): the register class of the
     // tile is then AGPR by construction and the allocator has nothing to split
 #define W4_ZERO_ACC()                                                       \
     _Pragma("unroll") for (int a_ = 0; a_ < 4; ++a_)                        \
     _Pragma("unroll") for (int b_ = 0; b_ < 4; ++b_)                        \
     _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) {                     \
-        if constexpr ((ABL & 64) != 0) { if (r_ < 8) asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(acc4[a_][b_][r_ >> 2][r_ & 3])); } \
-        else if (W4_ZERO_BY_MFMA && r_ == 0) asm volatile("s_nop 2\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %1, 0" : "=a"(acc[a_][b_]) : "v"(zero8));   /* 0 x 0 + 0: one MFMA zeroes 16 registers (32 cycles; sixteen v_accvgpr_write take 80).  s_nop: hipcc may materialise the zero operand with a v_mov right in front of the asm and does not see the MFMA inside it (VALU write -> MFMA read needs wait states) */ \
+        if (W4_ZERO_BY_MFMA && r_ == 0) asm volatile("s_nop 2\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %1, 0" : "=a"(acc[a_][b_]) : "v"(zero8));   /* 0 x 0 + 0: one MFMA zeroes 16 registers (32 cycles; sixteen v_accvgpr_write take 80).  s_nop: hipcc may materialise the zero operand with a v_mov right in front of the asm and does not see the MFMA inside it (VALU write -> MFMA read needs wait states) */ \
         else if (!W4_ZERO_BY_MFMA) asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(acc[a_][b_][r_]));    \
     }
-#define W4_ACC(jn_, im_, r_) ({ float x_; if constexpr ((ABL & 64) != 0) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x_) : "a"(acc4[jn_][im_][((r_) >> 2) & 1][(r_) & 3])); \
-                                else asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x_) : "a"(acc[jn_][im_][r_])); x_; })
+#define W4_ACC(jn_, im_, r_) ({ float x_; asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x_) : "a"(acc[jn_][im_][r_])); x_; })
     W4_ZERO_ACC()
 
     // fragment read offsets inside a stage: row * 128 + ((2 kk + lh) ^ swz) * 16, swz = (row >> 1) & 7 = (l31 >> 1) & 7 (row blocks are multiples of 32)
@@ -292,18 +271,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define W4_MF(i_, FA_, FB_)                                                                                \
     do {                                                                                                   \
         constexpr int jn_ = ((i_) >> 2), im_ = ((i_) & 3);                                                 \
-        if constexpr ((ABL & 64) != 0)                                                                     \
-            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %2, %3, %0\n\tv_mfma_f32_16x16x32_bf16 %1, %3, %2, %1"      \
-                         : "+a"(acc4[jn_][im_][0]), "+a"(acc4[jn_][im_][1]) : "v"(FB_[jn_]), "v"(FA_[im_]));        \
-        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[jn_][im_]) : "v"(FB_[jn_]), "v"(FA_[im_])); \
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[jn_][im_]) : "v"(FB_[jn_]), "v"(FA_[im_])); \
     } while (0)
 #define W4_MF_M0(i_, FA_, FB_, m0_)                                                                        \
     do {                                                                                                   \
         constexpr int jn_ = ((i_) >> 2), im_ = ((i_) & 3);                                                 \
-        if constexpr ((ABL & 64) != 0)                                                                     \
-            asm volatile("s_mov_b32 m0, %4\n\tv_mfma_f32_16x16x32_bf16 %0, %2, %3, %0\n\tv_mfma_f32_16x16x32_bf16 %1, %3, %2, %1" \
-                         : "+a"(acc4[jn_][im_][0]), "+a"(acc4[jn_][im_][1]) : "v"(FB_[jn_]), "v"(FA_[im_]), "s"(m0_)); \
-        else asm volatile("s_mov_b32 m0, %3\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[jn_][im_]) : "v"(FB_[jn_]), "v"(FA_[im_]), "s"(m0_)); \
+        asm volatile("s_mov_b32 m0, %3\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[jn_][im_]) : "v"(FB_[jn_]), "v"(FA_[im_]), "s"(m0_)); \
     } while (0)
     // ---- MX fp8 (MX): fragments of 32 bytes per lane and MFMA -- lane (row, h) holds k = 16h .. 16h+15 of the MFMA's first 32-element scale block
     // in bytes 0-15 and k = 32 + 16h .. of its second block in bytes 16-31 (tools/mx_probe.hip), i.e. chunks 4 ks + h and 4 ks + 2 + h of the
@@ -446,23 +419,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // The C stores carry the NONTEMPORAL hint.  One round of tiles writes 4 MB of C per XCD -- the size of its L2 -- and write-allocated C lines
     // evicted the operand panels the next K-tiles stream: per tile of M = 50 688, N = 3072 (us; profiles/r02_gemm_w4_probe_nt.log)
     //   K = 1024: 37.3 -> 29.2 (no C stores at all: 27.7) | K = 3072: 82.7 -> 77.7 (75.1) | K = 6144: 150.0 -> 146.8 (145.0)
-    // i.e. the hint recovers 70-85 % of what the stores cost.  ABL 512 (ablation build, correct results) = plain stores, for the A/B.
-#define W4_STORE_U(im_, t_, O_) { if constexpr ((ABL & 512) == 0) { const uint4 o4_ = O_; const w4_u32x4 ov_ = {o4_.x, o4_.y, o4_.z, o4_.w};                  \
-                                      __builtin_nontemporal_store(ov_, reinterpret_cast<w4_u32x4*>(W4_CPTR(im_, t_))); }                       \
-                                  else *reinterpret_cast<uint4*>(W4_CPTR(im_, t_)) = O_; }
+    // i.e. the hint recovers 70-85 % of what the stores cost.
+#define W4_STORE_U(im_, t_, O_) { const uint4 o4_ = O_; const w4_u32x4 ov_ = {o4_.x, o4_.y, o4_.z, o4_.w};                                                  \
+                                  __builtin_nontemporal_store(ov_, reinterpret_cast<w4_u32x4*>(W4_CPTR(im_, t_))); }
 #define W4_STORE_M(im_, t_, O_) if (W4_ROW(im_, t_) < p.M) { W4_STORE_U(im_, t_, O_) }
 #define W4_PLAIN_BLOCK(im_, GELU_)                                                                                     \
         W4_EPI_WRITE(im_, GELU_)                                                                                       \
         {                                                                                                              \
             W4_EPI_READ8()                                                                                             \
-            if (!(ABL & 16)) {                                                                                         \
-                if (c_m0 + wm * 128 + 32 * (im_) + 32 <= p.M) {                                                        \
-                    W4_STORE_U(im_, 0, y0_) W4_STORE_U(im_, 1, y1_) W4_STORE_U(im_, 2, y2_) W4_STORE_U(im_, 3, y3_)    \
-                    W4_STORE_U(im_, 4, y4_) W4_STORE_U(im_, 5, y5_) W4_STORE_U(im_, 6, y6_) W4_STORE_U(im_, 7, y7_)    \
-                } else {                                                                                               \
-                    W4_STORE_M(im_, 0, y0_) W4_STORE_M(im_, 1, y1_) W4_STORE_M(im_, 2, y2_) W4_STORE_M(im_, 3, y3_)    \
-                    W4_STORE_M(im_, 4, y4_) W4_STORE_M(im_, 5, y5_) W4_STORE_M(im_, 6, y6_) W4_STORE_M(im_, 7, y7_)    \
-                }                                                                                                      \
+            if (c_m0 + wm * 128 + 32 * (im_) + 32 <= p.M) {                                                            \
+                W4_STORE_U(im_, 0, y0_) W4_STORE_U(im_, 1, y1_) W4_STORE_U(im_, 2, y2_) W4_STORE_U(im_, 3, y3_)        \
+                W4_STORE_U(im_, 4, y4_) W4_STORE_U(im_, 5, y5_) W4_STORE_U(im_, 6, y6_) W4_STORE_U(im_, 7, y7_)        \
+            } else {                                                                                                   \
+                W4_STORE_M(im_, 0, y0_) W4_STORE_M(im_, 1, y1_) W4_STORE_M(im_, 2, y2_) W4_STORE_M(im_, 3, y3_)        \
+                W4_STORE_M(im_, 4, y4_) W4_STORE_M(im_, 5, y5_) W4_STORE_M(im_, 6, y6_) W4_STORE_M(im_, 7, y7_)        \
             }                                                                                                          \
         }
     // ---- MX fp8 OUTPUT of the GELU tiles (MX kernel, utx_gemm_desc.q_out): after the LDS transpose a lane holds 8 consecutive columns of one row and 16
@@ -715,7 +685,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // ---- prologue: K-tile 0 complete and landed, operand A of K-tile 1 requested; F0 = fragments of K-step 0 of K-tile 0
 #define W4_STAGE_HALF(isb_) do { W4_DMA(isb_, 0); W4_DMA(isb_, 1); W4_DMA(isb_, 2); W4_DMA(isb_, 3); W4_DMA(isb_, 4); W4_DMA(isb_, 5); W4_DMA(isb_, 6); W4_DMA(isb_, 7); } while (0)
-    if constexpr ((ABL & 32) != 0) { W4_PARK(); } else { W4_STAGE_AT(0, -1, false); }      // ABL 32: every DMA re-reads the same 1 KB (issue + LDS write, no memory traffic)
+    W4_STAGE_AT(0, -1, false);
     // the sixteen fragment reads of an MX K-step, literal read numbers (W4_XREAD)
 #define W4_XREAD16(FA_, FB_, base_, xlo_, xhi_)                                                            \
     W4_XREAD(0, FA_, FB_, base_, xlo_, xhi_); W4_XREAD(1, FA_, FB_, base_, xlo_, xhi_); W4_XREAD(2, FA_, FB_, base_, xlo_, xhi_); W4_XREAD(3, FA_, FB_, base_, xlo_, xhi_);     \
@@ -728,14 +698,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         W4_XSCALE_LOAD(sa_nxt, s_pSA); W4_XSCALE_LOAD(sb_nxt, s_pSB);
         W4_STAGE_ADVANCE();
         W4_DMA(0, 0); W4_DMA(0, 1); W4_DMA(0, 2); W4_DMA(0, 3); W4_DMA(0, 4); W4_DMA(0, 5); W4_DMA(0, 6); W4_DMA(0, 7);
-        if constexpr ((ABL & 2048) != 0) { W4_WAIT_VM(8); }
-        else if constexpr ((ABL & 1024) != 0) {
-            W4_DMA(1, 0); W4_DMA(1, 1); W4_DMA(1, 2); W4_DMA(1, 3); W4_DMA(1, 4);
-            W4_WAIT_VM(13);
-        } else {
-            W4_DMA(1, 0); W4_DMA(1, 1); W4_DMA(1, 2);
-            W4_WAIT_VM(11);
-        }
+        W4_DMA(1, 0); W4_DMA(1, 1); W4_DMA(1, 2);
+        W4_WAIT_VM(11);
         W4_LANDED2(sa_nxt, sb_nxt);
         W4_FENCE();
         W4_XSCALE_TAKE();
@@ -762,7 +726,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // fragments of the K-step after this one) and / or one DMA; the LDS address of a DMA is put into M0 in front of the MFMA before it (the wait state
     // M0 needs).
     for (;;) {
-        W4_TRACE(c_ss);
         const int cb = c_slot * W4_STAGE, nb = (c_slot ^ 1) * W4_STAGE;
         // DMA schedule: piece p = 0..15 of the cursor's K-tile (p < 8: operand A piece p, else operand B piece p - 8), ONE DMA PER THREE MFMAs over
         // K-steps 3, 0, 1 (a burst of 1 KB requests backs the vector-memory path up into the issuing wave, which has no partner wave to hide behind;
@@ -773,11 +736,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                               : (ks_) == 1 ? ((((i_) % 3) == 1 && (i_) < 15) ? 11 + (i_) / 3 : -1) : -1)
 #define W4_KSTEP(i_, ks_, FA_, FB_, FAn_, FBn_, base_, xk_)                                                \
         {                                                                                                  \
-            constexpr int pc_ = (ABL & 1) ? -1 : W4_PIECE_OF(ks_, i_);                                     \
+            constexpr int pc_ = W4_PIECE_OF(ks_, i_);                                                      \
             constexpr int isb_ = pc_ >= 8 ? 1 : 0, d_ = pc_ < 0 ? 0 : (pc_ & 7);                           \
             if constexpr (pc_ >= 0) W4_MF_M0(i_, FA_, FB_, W4_DMA_LDS(isb_, d_)); else W4_MF(i_, FA_, FB_); \
             W4_FENCE();                                                                                    \
-            if ((i_) < 8 && !(ABL & 2)) W4_READ(i_, FAn_, FBn_, base_, xk_);                               \
+            if ((i_) < 8) W4_READ(i_, FAn_, FBn_, base_, xk_);                                             \
             if constexpr (pc_ >= 0) W4_DMA_M0(isb_, d_);                                                   \
             W4_FENCE();                                                                                    \
         }
@@ -797,13 +760,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         //             to land: the bf16 schedule's 18 x 32], s_barrier
         //   K-step 1: MFMAs on X1 | reads -> X0 (first half of the NEXT stage) | pieces 0..10 of K-tile + 2 into THIS stage (two per three slots:
         //             one DMA per 96 matrix-pipe cycles, the spacing the bf16 schedule settled on); scales next -> current
-        // (ablation build, correct results, tools/mx_dma_sweep.py: other placements of the same sixteen pieces -- ABL 1024: 3 in K-step 0 (slots 0, 2, 4) + 13 in
-        // K-step 1 (one per MFMA); ABL 2048: 8 + 8 (K-step 0 slots 0..7, K-step 1 every other slot); ABL 4096: the default placement with the two scale
-        // loads in slots 8, 9 instead of 0, 1.  Measured, profiles/r03_mx_dma_sweep_v0.log (taken while 8, 9 was the default): 3 + 13 equal (+-0.3 %), 8 + 8
-        // -2.3...-2.7 % on every shape (the last piece gets 8 instead of 9 MFMAs to land), scale loads in slots 0, 1 +0.4...+1.8 % -> adopted)
-#define W4_XPIECE_OF(ks_, i_) (((ABL) & 1024) ? ((ks_) == 1 ? ((i_) < 13 ? (i_) : -1) : (((i_) % 2 == 0 && (i_) < 6) ? 13 + (i_) / 2 : -1))                  \
-                               : ((ABL) & 2048) ? ((ks_) == 1 ? (((i_) % 2 == 0) ? (i_) / 2 : -1) : ((i_) < 8 ? 8 + (i_) : -1))                                \
-                               : ((ks_) == 1 ? ((((i_) % 3) != 2) ? ((i_) / 3) * 2 + ((i_) % 3) : -1) : (((((i_) % 3) != 2) && (i_) < 7) ? 11 + ((i_) / 3) * 2 + ((i_) % 3) : -1)))
+        // (other placements of the same sixteen pieces were measured in round 3, profiles/r03_mx_dma_sweep_v0.log: 3 in K-step 0 + 13 in K-step 1 equal (+-0.3 %), 8 + 8
+        // -2.3...-2.7 % on every shape (the last piece gets 8 instead of 9 MFMAs to land), the two scale loads in slots 0, 1 instead of 8, 9 +0.4...+1.8 % -> adopted)
+#define W4_XPIECE_OF(ks_, i_) ((ks_) == 1 ? ((((i_) % 3) != 2) ? ((i_) / 3) * 2 + ((i_) % 3) : -1) : (((((i_) % 3) != 2) && (i_) < 7) ? 11 + ((i_) / 3) * 2 + ((i_) % 3) : -1))
 #define W4_XKSTEP(i_, ks_, FA_, FB_, FAn_, FBn_, base_, xlo_, xhi_)                                        \
         {                                                                                                  \
             constexpr int pc_ = W4_XPIECE_OF(ks_, i_);                                                     \
@@ -812,8 +771,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             W4_FENCE();                                                                                    \
             W4_XREAD(i_, FAn_, FBn_, base_, xlo_, xhi_);                                                   \
             if constexpr (pc_ >= 0) W4_DMA_M0(isb_, d_);                                                   \
-            if constexpr ((ks_) == 0 && (i_) == (((ABL) & 4096) ? 8 : 0)) W4_XSCALE_LOAD(sa_nxt, s_pSA);   \
-            if constexpr ((ks_) == 0 && (i_) == (((ABL) & 4096) ? 9 : 1)) W4_XSCALE_LOAD(sb_nxt, s_pSB);   \
+            if constexpr ((ks_) == 0 && (i_) == 0) W4_XSCALE_LOAD(sa_nxt, s_pSA);                          \
+            if constexpr ((ks_) == 0 && (i_) == 1) W4_XSCALE_LOAD(sb_nxt, s_pSB);                          \
             W4_FENCE();                                                                                    \
         }
 #define W4_XKSTEP16(ks_, FA_, FB_, FAn_, FBn_, base_, xlo_, xhi_)                                          \
@@ -848,17 +807,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         W4_FENCE();
         // ---- K-step 1
         W4_KSTEP16(1, fa1, fb1, fa0, fb0, cb, xk2)
-        if (!(ABL & 1)) W4_STAGE_ADVANCE();
+        W4_STAGE_ADVANCE();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         W4_FENCE();
         // ---- K-step 2
         W4_KSTEP16(2, fa0, fb0, fa1, fb1, cb, xk3)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (!(ABL & 4)) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // K-tile + 1 landed (its last piece was requested 1.5 K-steps ago)
-            W4_FENCE();
-            __builtin_amdgcn_s_barrier();
-        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // K-tile + 1 landed (its last piece was requested 1.5 K-steps ago)
+        W4_FENCE();
+        __builtin_amdgcn_s_barrier();
         W4_FENCE();
         // ---- K-step 3
         W4_KSTEP16(3, fa1, fb1, fa0, fb0, nb, xk0)
@@ -871,11 +828,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // ---- tile boundary
         const bool full = (c_m0 + 256 <= p.M);
         W4_MFMA_DRAIN();
-        W4_TRACE(-1);
         if (c_tj > 0) { W4_DUMP(wid + (c_tj - 1) * G); }
-        else if (!(ABL & 8)) W4_EPILOGUE();
-        if (!(ABL & 8)) { W4_ZERO_ACC() }      // one zeroing behind both paths: the accumulator tile has a single definition at the join
-        W4_TRACE(-2);
+        else W4_EPILOGUE();
+        W4_ZERO_ACC()      // one zeroing behind both paths: the accumulator tile has a single definition at the join
         if constexpr (MX) {    // as QKF below: X0 (64 registers) is not kept alive across the epilogue, the stage is intact
             const int rb = c_slot * W4_STAGE;
             W4_XREAD16(xa0, xb0, rb, xk0, xk1)
@@ -1009,25 +964,8 @@ extern "C" int utx_launch_gemm_w4(GemmParams p, hipStream_t stream) {
     const int tiles = ntm * ntn;
     int grid = tiles < ncu ? tiles : ncu;
     if (g_utx_opt.gemm_pers_grid > 0 && g_utx_opt.gemm_pers_grid < grid) grid = g_utx_opt.gemm_pers_grid;
-    const int trace_wg = g_utx_opt.gemm_pers_sched >= 100 ? g_utx_opt.gemm_pers_sched - 100 : 0;   // ablation build: which workgroup writes the ABL 128 timeline
     int sk_T = 0, sk_S = 0;
     utx_gemm_w4_split_plan(&p, tiles, grid, (p.sk_work && p.sk_work_bytes >= (size_t)2 * grid * 262144) ? 1 : 0, &sk_T, &sk_S);     // a plan holds at most 2 grid partial tiles
-#ifdef UTX_ABLATION
-    if (p.mx8 == 2 && !p.gate) {      // DMA-placement variants of the MX kernel (correct results): UTX_GEMM_DEBUG = 32 * {1024, 2048, 4096}
-        const int xabl = (g_utx_opt.gemm_debug_abl >> 5) & (1024 | 2048 | 4096);
-#define W4_XABL_CASE(a_) if (xabl == (a_)) { hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_w4_kernel<false, (a_), false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
-                                            hipLaunchKernelGGL((gemm256_w4_kernel<false, (a_), false, true>), dim3(grid), dim3(256), LDS, stream, p, tiles, trace_wg, 0, 0); return hipGetLastError() == hipSuccess ? 0 : -4; }   /* never split: compare with UTX_GEMM_STREAMK=0 */
-        W4_XABL_CASE(1024) W4_XABL_CASE(2048) W4_XABL_CASE(4096)
-    }
-    {
-        const int abl = (g_utx_opt.gemm_debug_abl >> 5) & 1023;   // (ABL 256 = start-time stagger, 512 = plain instead of nontemporal C stores: results stay correct)     // UTX_GEMM_DEBUG bits 5..14
-        if (abl && !p.gate) {
-#define W4_ABL_CASE(a_) if (abl == (a_)) { hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_w4_kernel<false, (a_)>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
-                                           hipLaunchKernelGGL((gemm256_w4_kernel<false, (a_)>), dim3(grid), dim3(256), LDS, stream, p, tiles, trace_wg, 0, 0); return 0; }
-            W4_ABL_CASE(1) W4_ABL_CASE(2) W4_ABL_CASE(3) W4_ABL_CASE(4) W4_ABL_CASE(7) W4_ABL_CASE(8) W4_ABL_CASE(15) W4_ABL_CASE(16) W4_ABL_CASE(32) W4_ABL_CASE(64) W4_ABL_CASE(128) W4_ABL_CASE(144) W4_ABL_CASE(256) W4_ABL_CASE(512)
-        }
-    }
-#endif
     if (p.mx8 == 2) {
         // MX fp8 operands, tile-packed scales (K, lda, ldb arrive in bf16 units = halved, as for the 128^2 form: the staging code is byte-identical)
         if (p.K2 > 0 || p.qk_cols > 0 || (p.K % 64) || !p.a_scale || !p.b_scale || p.lds_a < (p.M + 127) / 128 || p.lds_b < p.N / 128 ||
@@ -1036,21 +974,21 @@ extern "C" int utx_launch_gemm_w4(GemmParams p, hipStream_t stream) {
         if (p.q_out && (p.gate || !p.qs_out || p.gelu_from >= p.N || (p.gelu_from % 128) || (p.ldq_out & 7) || p.ldq_out < p.N - p.gelu_from ||
                         p.qs_out_rb < (p.M + 127) / 128 || p.q_out_kt0 < 0 || ((uintptr_t)p.qs_out & 15) || ((uintptr_t)p.q_out & 7))) return -2;
         UTX_ONCE_PER_DEVICE(ax) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_w4_kernel<false, 0, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess ||
-                hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_w4_kernel<true, 0, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_w4_kernel<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_w4_kernel<true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
             UTX_ONCE_DONE(ax);
         }
-        if (p.gate) hipLaunchKernelGGL((gemm256_w4_kernel<true, 0, false, true>), dim3(grid), dim3(256), LDS, stream, p, tiles, trace_wg, sk_T, sk_S);
-        else hipLaunchKernelGGL((gemm256_w4_kernel<false, 0, false, true>), dim3(grid), dim3(256), LDS, stream, p, tiles, trace_wg, sk_T, sk_S);
+        if (p.gate) hipLaunchKernelGGL((gemm256_w4_kernel<true, false, true>), dim3(grid), dim3(256), LDS, stream, p, tiles, 0, sk_T, sk_S);
+        else hipLaunchKernelGGL((gemm256_w4_kernel<false, false, true>), dim3(grid), dim3(256), LDS, stream, p, tiles, 0, sk_T, sk_S);
     } else if (p.gate) {
         if (p.gelu_from < p.N || p.n_split < p.N) return -2;
-        hipLaunchKernelGGL((gemm256_w4_kernel<true>), dim3(grid), dim3(256), LDS, stream, p, tiles, trace_wg, sk_T, sk_S);
+        hipLaunchKernelGGL((gemm256_w4_kernel<true>), dim3(grid), dim3(256), LDS, stream, p, tiles, 0, sk_T, sk_S);
     } else {
         if (p.qk_cols > 0) {
-            UTX_ONCE_PER_DEVICE(aq) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_w4_kernel<false, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3; UTX_ONCE_DONE(aq); }
-            hipLaunchKernelGGL((gemm256_w4_kernel<false, 0, true>), dim3(grid), dim3(256), LDS, stream, p, tiles, trace_wg, sk_T, sk_S);
+            UTX_ONCE_PER_DEVICE(aq) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_w4_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3; UTX_ONCE_DONE(aq); }
+            hipLaunchKernelGGL((gemm256_w4_kernel<false, true>), dim3(grid), dim3(256), LDS, stream, p, tiles, 0, sk_T, sk_S);
         } else
-        hipLaunchKernelGGL((gemm256_w4_kernel<false>), dim3(grid), dim3(256), LDS, stream, p, tiles, trace_wg, sk_T, sk_S);
+        hipLaunchKernelGGL((gemm256_w4_kernel<false>), dim3(grid), dim3(256), LDS, stream, p, tiles, 0, sk_T, sk_S);
     }
     if (sk_T > 0) {
         if (p.gate) hipLaunchKernelGGL((gemm_w4_fixup_kernel<true>), dim3(sk_T * 16), dim3(256), 0, stream, p, tiles, sk_T, sk_S);
