@@ -57,6 +57,7 @@ class Machine:
         op["%[kptr_lo]"], op["%[kptr_hi]"] = KBASE & 0xffffffff, KBASE >> 32
         op["%[vptr_lo]"], op["%[vptr_hi]"] = VBASE & 0xffffffff, VBASE >> 32
         op["%[kstride]"], op["%[nt]"], op["%[kbv]"] = KSTRIDE, nt, kbv
+        op["%[trips]"], op["%[rem]"] = nt // 3, nt % 3
         op["%[ldsk]"], op["%[ldsv]"] = self.dma_off, self.vring + self.dma_off
         for i in range(8):
             op["%%[kx%d]" % i] = 32 * i                      # distinct per fragment, < 8192
@@ -217,7 +218,7 @@ class Machine:
             elif op == "global_load_lds_dwordx4":
                 if self.m0 is None or self.m0_age < 2:
                     self.err(i, "LDS-DMA directly behind (or without) its M0 write")
-                m = re.fullmatch(r"s\[(\d+):(\d+)\]", a[1])
+                m = re.fullmatch(r"s\[(\d+):(\d+)\]", a[1].split()[0])
                 ptr = self.reg["s" + m.group(1)] | (self.reg["s" + m.group(2)] << 32)
                 kind = "K" if a[0].startswith("%[ko") else "V"
                 j = int(a[0][4])
@@ -228,14 +229,16 @@ class Machine:
                 if rem or not (0 <= tile < self.nt):
                     self.err(i, "%s request through pointer 0x%x: not a tile of the sequence (nt = %d)" % (kind, ptr, self.nt))
                 base = 0 if kind == "K" else self.vring
-                off = self.m0 - base - self.dma_off - 1024 * j
+                mo = re.search(r"offset:(\d+)", rest)
+                dest = self.m0 + (int(mo.group(1)) if mo else 0)      # the instruction offset moves the LDS address too (tools/glds_offset_probe.hip, measured)
+                off = dest - base - self.dma_off - 1024 * j
                 if off % TILE or not (0 <= off // TILE < self.N):
-                    self.err(i, "%s piece %d lands at LDS 0x%x: not piece %d of this wave in a ring slot" % (kind, j, self.m0, j))
+                    self.err(i, "%s piece %d lands at LDS 0x%x: not piece %d of this wave in a ring slot" % (kind, j, dest, j))
                 d = dict(tile=tile, kind=kind, issue_epoch=self.epoch, issue_idx=i + steps * 0, retired_epoch=None, pub_epoch=None, step=steps)
                 d["issue_idx"] = steps
                 self.vm.append(d)
                 if j == 0:
-                    piece = self.m0
+                    piece = dest
                     # overwrite rule: every consumed read of this slot's previous content lies in an EARLIER barrier epoch (another wave may lag up to the last barrier)
                     for f in self.frag_history:
                         if f.get("piece") == piece and f["epoch"] >= self.epoch and f["dma"]["tile"] != tile:
@@ -359,30 +362,37 @@ def test_stream_ring_discipline_waits_and_register_choreography(cfg):
 
 
 def test_the_interpreter_catches_seeded_bugs():
-    """mutation check: the audit above must fail on streams with one wrong wait / slot / operand"""
-    base = _stream_lines(G.DEFAULT)
-    loop = [i for i, l in enumerate(base) if l.startswith("AQ2_LOOP")][0]
+    """mutation check: the audit above must fail on streams with one wrong wait / slot / operand -- on the product stream (three tiles per trip, literal slots) and on the
+    one-tile-per-trip arm (addresses stepped in registers)"""
+    tile1 = next(c for c in G.VARIANTS if c.name == "tile1")
 
-    def mutate(find, repl, after=loop, nth=0):
+    def mutate(cfg, find, repl, nth=0):
+        base = _stream_lines(cfg)
+        loop = [i for i, l in enumerate(base) if l.startswith("AQ2_LOOP")][0]
         lines = list(base)
-        hits = [i for i in range(after, len(lines)) if find in lines[i]]
+        hits = [i for i in range(loop, len(lines)) if find in lines[i]]
+        assert len(hits) > nth, "the stream has no `%s` (occurrence %d) to mutate: update this test" % (find, nth)
         lines[hits[nth]] = lines[hits[nth]].replace(find, repl)
-        m = Machine(lines, G.DEFAULT, 7)
+        m = Machine(lines, cfg, 7)
         m.frag_history = []
         try:
             m.run()
         except (AssertionError, KeyError):
             return ["crashed"]
         return m.errors
-    assert mutate("s_waitcnt lgkmcnt(2)", "s_waitcnt lgkmcnt(3)", nth=5), "a wait one read too lax"
-    assert mutate("s_waitcnt vmcnt(0)", "s_waitcnt vmcnt(4)"), "a DMA batch published before it was retired"
-    assert mutate("offset:8192", "offset:4096", nth=3), "wrong block of a K tile"
-    assert mutate("global_load_lds_dwordx4 %[ko0]", "global_load_lds_dwordx4 %[vo0]"), "K piece fetched through the V offsets"
-    assert mutate("v_exp_f32 v88, v226", "v_exp_f32 v88, v194"), "exponential of a score block that is still being accumulated"
-    assert mutate("v[128:131]", "v[132:135]", nth=0), "PV takes the other key slab's probabilities"
-    assert mutate("s_cselect_b32 s47, s52, s51", "s_cselect_b32 s47, s51, s51"), "K ring never wraps"
-    lines = [l for l in base if l != "s_barrier" or False]
-    m = Machine(lines, G.DEFAULT, 5)
-    m.frag_history = []
-    m.run()
-    assert m.errors, "no barrier at all"
+    for cfg in (G.DEFAULT, tile1):
+        assert mutate(cfg, "s_waitcnt lgkmcnt(2)", "s_waitcnt lgkmcnt(3)", nth=5), "a wait one read too lax"
+        assert mutate(cfg, "s_waitcnt vmcnt(0)", "s_waitcnt vmcnt(4)"), "a DMA batch published before it was retired"
+        assert mutate(cfg, "global_load_lds_dwordx4 %[ko0]", "global_load_lds_dwordx4 %[vo0]"), "K piece fetched through the V offsets"
+        assert mutate(cfg, "v_exp_f32 v88, v226", "v_exp_f32 v88, v194"), "exponential of a score block that is still being accumulated"
+        assert mutate(cfg, "v[128:131]", "v[132:135]", nth=0), "PV takes the other key slab's probabilities"
+        lines = [l for l in _stream_lines(cfg) if l != "s_barrier"]
+        m = Machine(lines, cfg, 5)
+        m.frag_history = []
+        m.run()
+        assert m.errors, "no barrier at all"
+    assert mutate(G.DEFAULT, "ds_read_b128 v[120:123], %[kx2] offset:16384", "ds_read_b128 v[120:123], %[kx2] offset:24576"), "wrong block of a K tile"
+    assert mutate(G.DEFAULT, "s_add_u32 m0, %[ldsk], 16384", "s_add_u32 m0, %[ldsk], 0"), "K tile requested into the slot that is being read"
+    assert mutate(G.DEFAULT, "%[vx0] offset:16384", "%[vx0] offset:0"), "V^T fragment from the previous trip's slot"
+    assert mutate(tile1, "offset:8192", "offset:4096", nth=3), "wrong block of a K tile"
+    assert mutate(tile1, "s_cselect_b32 s47, s52, s51", "s_cselect_b32 s47, s51, s51"), "K ring never wraps"

@@ -43,8 +43,17 @@ TILE = 16384
 
 
 class Config:
-    def __init__(self, name, nslot=3, ahead=2, novm=False, nobar=False, noexp=False, nodma=False):
+    def __init__(self, name, nslot=3, ahead=2, novm=False, nobar=False, noexp=False, nodma=False, unroll3=False, wait2=False, pkadd=False, m0once=False):
         self.name, self.nslot, self.ahead = name, nslot, ahead
+        # unroll3: three tiles per loop trip -- ring slots are literals, every LDS address is a loop-invariant register + an immediate, no address steps, no slot bookkeeping;
+        # nt % 3 tiles run through a second copy of the first two tile bodies behind the loop.  wait2: one counted lgkmcnt per TWO groups (needs read-ahead 3).
+        self.unroll3, self.wait2 = unroll3, wait2
+        # m0once: ONE M0 write per four pieces -- an LDS-DMA's instruction offset moves its LDS address AND its global address (tools/glds_offset_probe.hip on the
+        # hardware), so piece j carries offset:1024 j and the kernel hands over per-lane source offsets lowered by 1024 j (attention_q64.hip, AQ2_M0_ONCE)
+        self.m0once = m0once
+        self.pkadd = pkadd      # the two row-sum adds of a gap as ONE v_pk_add_f32 (same two IEEE additions, one instruction to fetch and issue)
+        assert not unroll3 or nslot == 3
+        assert not wait2 or ahead == 3
         self.novm, self.nobar, self.noexp, self.nodma = novm, nobar, noexp, nodma      # timing ablations (wrong results)
         assert nslot in (3, 4) and ahead in (2, 3)
         self.dk, self.dv = nslot, nslot - 1          # tile look-ahead of the DMA: K(t + dk), V(t + dv) are requested in trip t
@@ -81,6 +90,7 @@ class Stream:
             self.gap += 1
 
     def comment(self, text):
+        assert "%" not in text      # a percent sign is an operand escape in an asm string, also inside a comment
         self.lines.append("; " + text)
 
     def mfma(self, dst, a_, b_, c_):
@@ -109,8 +119,14 @@ class Stream:
         self.lgkm = []
 
 
-def dma(st, voff_op, sbase, m0_base, m0_imm):
+def dma(st, voff_op, sbase, m0_base, m0_imm, cfg=None, j=0):
     """one 1 KB piece: M0 = LDS destination of the wave-instruction, then global_load_lds (saddr + per-lane 32-bit offset)"""
+    if cfg is not None and cfg.m0once:
+        if j == 0:
+            st.ins("s_add_u32 m0, %s, %d" % (m0_base, m0_imm))
+            st.ins("s_nop 0")
+        st.ins("global_load_lds_dwordx4 %s, %s%s" % (voff_op, s(sbase, 2), (" offset:%d" % (1024 * j)) if j else ""))
+        return
     st.ins("s_add_u32 m0, %s, %d" % (m0_base, m0_imm))
     st.ins("s_nop 0")
     st.ins("global_load_lds_dwordx4 %s, %s" % (voff_op, s(sbase, 2)))
@@ -124,20 +140,25 @@ def advance_ptr(st, ptr, step, cond_lhs, cond_rhs):
     st.ins("s_addc_u32 %s, %s, 0" % (s(ptr + 1), s(ptr + 1)))
 
 
-def k_read(st, cfg, tag, buf, odd_target, gt):
+def k_read(st, cfg, tag, buf, odd_target, gt, jt=0):
     """K fragment gt of the block the TARGET stage's QK^T multiplies: odd stage 2t+1 -> (tile t+1, block 0); even stage 2t+2 -> (tile t+1, block 1), after which the
-    address steps to tile t+2"""
-    if odd_target:
+    address steps to tile t+2.  unroll3: t = 3 trip + jt, the slot of tile t+1 is the literal (jt + 1) % 3 and nothing steps"""
+    if cfg.unroll3:
+        st.ds_read(tag, v(KF[buf], 4), "%%[kx%d]" % gt, ((jt + 1) % 3) * TILE + (0 if odd_target else 8192))
+    elif odd_target:
         st.ds_read(tag, v(KF[buf], 4), "%%[kx%d]" % gt, 0)
     else:
         st.ds_read(tag, v(KF[buf], 4), "%%[kx%d]" % gt, 8192)
         st.ins("v_add_u32 %%[kx%d], %s, %%[kx%d]" % (gt, s(S_KSTEP), gt))
 
 
-def v_read(st, cfg, tag, buf, odd_target, gt):
+def v_read(st, cfg, tag, buf, odd_target, gt, jt=0):
     """V^T fragment (key slab, d-block gt & 3) of the block the TARGET stage's PV consumes: odd stage -> tile t slabs 0, 1; even stage -> tile t slabs 2, 3; an address steps
-    to tile t+1 behind its fourth d-block"""
+    to tile t+1 behind its fourth d-block (unroll3: the slot of tile t is the literal jt % 3)"""
     slab = (gt >> 2) + (0 if odd_target else 2)
+    if cfg.unroll3:
+        st.ds_read(tag, v(VF[buf], 4), "%%[vx%d]" % slab, (jt % 3) * TILE + 4096 * (gt & 3))
+        return
     st.ds_read(tag, v(VF[buf], 4), "%%[vx%d]" % slab, 4096 * (gt & 3))
     if (gt & 3) == 3:
         st.ins("v_add_u32 %%[vx%d], %s, %%[vx%d]" % (slab, s(S_VSTEP), slab))
@@ -171,10 +192,10 @@ def gen_prologue(st, cfg):
             if u < cfg.dv:
                 advance_ptr(st, S_VPTR, "0x80", s(S_TK), "%[nt]")
         for j in range(4):
-            dma(st, "%%[ko%d]" % j, S_KPTR, "%[ldsk]", u * TILE + 1024 * j)
+            dma(st, "%%[ko%d]" % j, S_KPTR, "%[ldsk]", u * TILE + (0 if cfg.m0once else 1024 * j), cfg, j)
         if u < cfg.dv:
             for j in range(4):
-                dma(st, "%%[vo%d]" % j, S_VPTR, "%[ldsv]", u * TILE + 1024 * j)
+                dma(st, "%%[vo%d]" % j, S_VPTR, "%[ldsv]", u * TILE + (0 if cfg.m0once else 1024 * j), cfg, j)
     st.comment("state of 'trip -1': K dest slot N-1, V dest slot N-2, K pointer at tile min(N-1, nt-1), V pointer at tile min(N-2, nt-1), TK = N - 1")
     st.ins("s_add_u32 %s, %%[ldsk], 0x%x" % (s(S_KD), (N - 1) * TILE))
     st.ins("s_add_u32 %s, %%[ldsv], 0x%x" % (s(S_VD), (N - 2) * TILE))
@@ -194,7 +215,8 @@ def gen_prologue(st, cfg):
                     st.mfma(v(SA[(blk, h)], 16), v(KF[i], 4), a(qb + 4 * g, 4), "0" if g == 0 else v(SA[(blk, h)], 16))
     st.gap = None
     for i in range(8):
-        st.ins("v_add_u32 %%[kx%d], %s, %%[kx%d]" % (i, s(S_POS), i))      # slot 0 -> slot 1: every K fragment address now points at tile 1
+        if not cfg.unroll3:
+            st.ins("v_add_u32 %%[kx%d], %s, %%[kx%d]" % (i, s(S_POS), i))      # slot 0 -> slot 1: every K fragment address now points at tile 1
     st.ins("s_nop 15")
     st.ins("s_nop 15")
     st.comment("---- key multiplicity of the first tile: scores += log2(multiplicity)")
@@ -242,13 +264,13 @@ def gen_prologue(st, cfg):
     st.ins("v_mov_b32 %[psmax], 0")
     st.comment("---- fragments of the first AHEAD groups of stage 1: K(tile 1, block 0), V(tile 0, slab 0)")
     for G in range(cfg.ahead):
-        k_read(st, cfg, ("K", G), G % 4, True, G)
-        v_read(st, cfg, ("V", G), G % 4, True, G)
-    st.ins("s_mov_b32 %s, %%[nt]" % s(S_CNT))
+        k_read(st, cfg, ("K", G), G % 4, True, G, 0)
+        v_read(st, cfg, ("V", G), G % 4, True, G, 0)
+    st.ins("s_mov_b32 %s, %s" % (s(S_CNT), "%[trips]" if cfg.unroll3 else "%[nt]"))
     st.ins("s_nop 3")
 
 
-def gen_stage(st, cfg, G0, odd):
+def gen_stage(st, cfg, G0, odd, j=0):
     """one stage of the loop; G0 = running index of its first group (read tags); odd: stage 2t+1 (softmax of a tile's block 1), else stage 2t+2"""
     p = 1 if odd else 0            # parity of the block whose softmax runs
     q = 1 - p                      # parity of the block QK^T writes / PV reads
@@ -257,11 +279,18 @@ def gen_stage(st, cfg, G0, odd):
     EXP = "v_mov_b32" if cfg.noexp else "v_exp_f32"
     for g in range(8):
         G = G0 + g
-        st.wait_lgkm([("K", G), ("V", G)])
+        if not cfg.wait2:
+            st.wait_lgkm([("K", G), ("V", G)])
+        elif g % 2 == 0:
+            st.wait_lgkm([("K", G), ("V", G), ("K", G + 1), ("V", G + 1)])
         # ---- QK^T, half 0
         st.mfma(v(SA[(q, 0)], 16), v(KF[G % 4], 4), a(Q0 + 4 * g, 4), v(NEGM[0], 16) if g == 0 else v(SA[(q, 0)], 16))
         if odd:      # scalar bookkeeping of the trip, two or three per gap (state of trip t from that of trip t - 1)
-            if g == 0:
+            if g == 0 and cfg.unroll3:
+                pass
+            elif g == 1 and cfg.unroll3:
+                pass
+            elif g == 0:
                 st.ins("s_add_u32 %s, %s, 0x%x" % (s(S_KD), s(S_KD), TILE))
                 st.ins("s_cmp_eq_u32 %s, %s" % (s(S_KD), s(S_KDEND)))
                 st.ins("s_cselect_b32 %s, %%[ldsk], %s" % (s(S_KD), s(S_KD)))
@@ -284,7 +313,14 @@ def gen_stage(st, cfg, G0, odd):
                 st.ins("s_add_u32 %s, %s, %s" % (s(S_VPTR), s(S_VPTR), s(S_TMP)))
                 st.ins("s_addc_u32 %s, %s, 0" % (s(S_VPTR + 1), s(S_VPTR + 1)))
         elif not cfg.nodma:        # LDS-DMA piece g of the tile boundary: K(t+N) pieces 0-3, V(t+N-1) pieces 0-3; M0 first, the load behind the exponentials
-            if g < 4:
+            if cfg.unroll3 and cfg.m0once:
+                if g == 0:
+                    st.ins("s_add_u32 m0, %%[ldsk], %d" % ((j % 3) * TILE))
+                elif g == 4:
+                    st.ins("s_add_u32 m0, %%[ldsv], %d" % (((j + 2) % 3) * TILE))
+            elif cfg.unroll3:      # K(t+3) -> slot t % 3 = j, V(t+2) -> slot (j + 2) % 3
+                st.ins("s_add_u32 m0, %s, %d" % (("%[ldsk]", (j % 3) * TILE + 1024 * g) if g < 4 else ("%[ldsv]", ((j + 2) % 3) * TILE + 1024 * (g - 4))))
+            elif g < 4:
                 st.ins("s_add_u32 m0, %s, %d" % (s(S_KD), 1024 * g))
             else:
                 st.ins("s_add_u32 m0, %s, %d" % (s(S_VD), 1024 * (g - 4)))
@@ -293,10 +329,11 @@ def gen_stage(st, cfg, G0, odd):
         st.ins("%s %s, %s" % (EXP, v(ev0), v(SA[(p, 0)] + 2 * g)))
         st.ins("%s %s, %s" % (EXP, v(od0), v(SA[(p, 0)] + 2 * g + 1)))
         if not odd and not cfg.nodma:
+            off = (" offset:%d" % (1024 * (g & 3))) if (cfg.m0once and (g & 3)) else ""
             if g < 4:
-                st.ins("global_load_lds_dwordx4 %%[ko%d], %s" % (g, s(S_KPTR, 2)))
+                st.ins("global_load_lds_dwordx4 %%[ko%d], %s%s" % (g, s(S_KPTR, 2), off))
             else:
-                st.ins("global_load_lds_dwordx4 %%[vo%d], %s" % (g - 4, s(S_VPTR, 2)))
+                st.ins("global_load_lds_dwordx4 %%[vo%d], %s%s" % (g - 4, s(S_VPTR, 2), off))
         # ---- QK^T, half 1
         st.mfma(v(SA[(q, 1)], 16), v(KF[G % 4], 4), a(Q1 + 4 * g, 4), v(NEGM[1], 16) if g == 0 else v(SA[(q, 1)], 16))
         ev1 = sums_p[2] if g == 0 else E[2]
@@ -305,8 +342,9 @@ def gen_stage(st, cfg, G0, odd):
         st.ins("%s %s, %s" % (EXP, v(od1), v(SA[(p, 1)] + 2 * g + 1)))
         gt = g + A                 # the group AHEAD groups on, in this stage or the next
         tgt_odd = odd if gt < 8 else (not odd)
-        k_read(st, cfg, ("K", G + A), (G + A) % 4, tgt_odd, gt % 8)
-        if not odd and g >= 6:     # the address steps of the NEXT trip, behind the last step of this one (even-stage targets are read through group 7 - AHEAD)
+        jt = j + 1 if (gt >= 8 and not odd) else j      # the trip-local tile index of the TARGET stage
+        k_read(st, cfg, ("K", G + A), (G + A) % 4, tgt_odd, gt % 8, jt)
+        if not odd and g >= 6 and not cfg.unroll3:     # the address steps of the NEXT trip, behind the last step of this one (even-stage targets are read through group 7 - AHEAD)
             if g == 6:             # V^T read address wraps in trip t + 1 iff t % N == (N - 2) % N
                 st.ins("s_cmp_eq_u32 %s, %s" % (s(S_KD), s(S_KWV)))
                 st.ins("s_cselect_b32 %s, %s, %s" % (s(S_VSTEP), s(S_NEG), s(S_POS)))
@@ -318,21 +356,36 @@ def gen_stage(st, cfg, G0, odd):
         if g == 0:   # the row sums of the previous stage's block are final: l += ps (block order), headroom record
             st.ins("v_add_f32 %s, %s, %s" % (v(PS0), v(sums_q[0]), v(sums_q[1])))
             st.ins("v_add_f32 %[l0], %[l0], " + v(PS0))
+        elif cfg.pkadd:
+            st.ins("v_pk_add_f32 %s, %s, %s" % (v(sums_p[0], 2), v(sums_p[0], 2), v(E[0], 2)))
         else:
             st.ins("v_add_f32 %s, %s, %s" % (v(sums_p[0]), v(sums_p[0]), v(E[0])))
             st.ins("v_add_f32 %s, %s, %s" % (v(sums_p[1]), v(sums_p[1]), v(E[1])))
         st.ins("v_cvt_pk_bf16_f32 %s, %s, %s" % (v(PB[(p, 0)] + g), v(ev0), v(od0)))
-        v_read(st, cfg, ("V", G + A), (G + A) % 4, tgt_odd, gt % 8)
+        v_read(st, cfg, ("V", G + A), (G + A) % 4, tgt_odd, gt % 8, jt)
         # ---- PV, half 1
         st.mfma("%%[o1%d]" % (g & 3), v(VF[G % 4], 4), v(PB[(q, 1)] + 4 * (g >> 2), 4), "%%[o1%d]" % (g & 3))
         if g == 0:
             st.ins("v_add_f32 %s, %s, %s" % (v(PS1), v(sums_q[2]), v(sums_q[3])))
             st.ins("v_add_f32 %[l1], %[l1], " + v(PS1))
             st.ins("v_max3_f32 %%[psmax], %%[psmax], %s, %s" % (v(PS0), v(PS1)))
+        elif cfg.pkadd:
+            st.ins("v_pk_add_f32 %s, %s, %s" % (v(sums_p[2], 2), v(sums_p[2], 2), v(E[2], 2)))
         else:
             st.ins("v_add_f32 %s, %s, %s" % (v(sums_p[2]), v(sums_p[2]), v(E[2])))
             st.ins("v_add_f32 %s, %s, %s" % (v(sums_p[3]), v(sums_p[3]), v(E[3])))
         st.ins("v_cvt_pk_bf16_f32 %s, %s, %s" % (v(PB[(p, 1)] + g), v(ev1), v(od1)))
+
+
+def gen_tile(st, cfg, G0, j):
+    """one tile: stage 2t+1, the boundary, stage 2t+2 (t = 3 trip + j under unroll3)"""
+    gen_stage(st, cfg, G0, True, j)
+    st.comment("---- tile boundary: the DMA batch due now has landed (this wave's pieces: the counted vmcnt); behind the barrier it is visible and the slots of K(t) / V(t-1) are free")
+    if not cfg.novm:
+        st.ins("s_waitcnt vmcnt(%d)" % cfg.vm_at_barrier)
+    if not cfg.nobar:
+        st.ins("s_barrier")
+    gen_stage(st, cfg, G0 + 8, False, j)
 
 
 def gen(cfg):
@@ -340,23 +393,35 @@ def gen(cfg):
     gen_prologue(st, cfg)
     entry = list(st.lgkm)
     assert entry == [(k, G) for G in range(cfg.ahead) for k in ("K", "V")], entry
+    ntile = 3 if cfg.unroll3 else 1
+    if cfg.unroll3:
+        st.ins("s_cmp_eq_u32 %[trips], 0")
+        st.ins("s_cbranch_scc1 AQ2_TAIL_%=")
     st.raw("AQ2_LOOP_%=:")
     n0 = len(st.lines)
     st.gap = None
-    gen_stage(st, cfg, 0, True)
-    st.comment("---- tile boundary: the DMA batch due now has landed (this wave's pieces: the counted vmcnt); behind the barrier it is visible and the slots of K(t) / V(t-1) are free")
-    if not cfg.novm:
-        st.ins("s_waitcnt vmcnt(%d)" % cfg.vm_at_barrier)
-    if not cfg.nobar:
-        st.ins("s_barrier")
-    gen_stage(st, cfg, 8, False)
+    for j in range(ntile):
+        gen_tile(st, cfg, 16 * j, j)
     st.ins("s_sub_u32 %s, %s, 1" % (s(S_CNT), s(S_CNT)))
     st.ins("s_cmp_lg_u32 %s, 0" % s(S_CNT))
     st.ins("s_cbranch_scc1 AQ2_LOOP_%=")
-    back = [(k, G - 16) for k, G in st.lgkm]
+    back = [(k, G - 16 * ntile) for k, G in st.lgkm]
     assert back == entry, (back, entry)       # the LGKM queue at the back edge is the queue at the loop's entry: the counted waits hold on every trip
     loop_lines = [l for l in st.lines[n0:] if not l.startswith(";")]
     gaps = list(st.gaps)
+    if cfg.unroll3:
+        st.comment("---- the nt mod 3 tiles behind the loop: the first two tile bodies once more (the loop always leaves the ring at slot phase 0)")
+        st.raw("AQ2_TAIL_%=:")
+        st.lgkm = list(entry)
+        st.ins("s_cmp_eq_u32 %[rem], 0")
+        st.ins("s_cbranch_scc1 AQ2_END_%=")
+        gen_tile(st, cfg, 0, 0)
+        assert [(k, G - 16) for k, G in st.lgkm] == entry
+        st.ins("s_cmp_eq_u32 %[rem], 1")
+        st.ins("s_cbranch_scc1 AQ2_END_%=")
+        gen_tile(st, cfg, 16, 1)
+        assert [(k, G - 32) for k, G in st.lgkm] == entry
+        st.raw("AQ2_END_%=:")
     st.comment("---- drain: the last PV MFMAs, the prefetched fragments and the clamped re-requests")
     st.ins("s_nop 15")
     st.ins("s_nop 15")
@@ -370,11 +435,16 @@ OPERANDS_OUT = [("o%d%d" % (h, d), "+a", "oacc%d[%d]" % (h, d)) for h in range(2
 OPERANDS_IN = [("ko%d" % i, "v", "ko[%d]" % i) for i in range(4)] + [("vo%d" % i, "v", "vo[%d]" % i) for i in range(4)] + \
     [("qp0", "v", "qp0"), ("qp1", "v", "qp1"), ("bperm", "v", "bperm"),
      ("kptr_lo", "s", "kptr_lo"), ("kptr_hi", "s", "kptr_hi"), ("vptr_lo", "s", "vptr_lo"), ("vptr_hi", "s", "vptr_hi"),
-     ("kstride", "s", "kstride"), ("nt", "s", "nt"), ("ldsk", "s", "ldsk"), ("ldsv", "s", "ldsv"), ("kbv", "s", "kbv")]
+     ("kstride", "s", "kstride"), ("nt", "s", "nt"), ("ldsk", "s", "ldsk"), ("ldsv", "s", "ldsv"), ("kbv", "s", "kbv"), ("trips", "s", "trips"), ("rem", "s", "rem")]
 
-DEFAULT = Config("default")
-# A/B arms (UTX_ABLATION build; UTX_ATTN_VAR = index + 1 selects one).  Correct results unless named abl_*.
-VARIANTS = [Config("ring4", nslot=4), Config("ahead3", ahead=3), Config("ring4_ahead3", nslot=4, ahead=3),
+DEFAULT = Config("default", unroll3=True, ahead=3, wait2=True)
+# A/B arms (UTX_ABLATION build; UTX_ATTN_VAR = index + 1 selects one).  Correct results unless named abl_*.  Measured, profiles/r06_attn_q64_arms_v*.log (TF/s at S = 13 376 / 50 240,
+# same process, interleaved; every correct arm bit-identical to the 8 x 32 kernel on the sweep):
+#   tile1 (the first stream of round 6: one tile per trip, addresses stepped in registers, read-ahead 2)   1380 / 1413      default (three tiles per trip, literal slots)  1417 / 1443
+#   ring4 / read-ahead 3 alone / no vmcnt / no barrier: equal to tile1 within 0.4 %  -- the loop is not waiting for anything; it is POWER-bound (time = energy / cap)
+#   m0 (one M0 write per four pieces: -6 SALU per tile) = default      pk (row sums as v_pk_add_f32: -32 instructions per tile) 1294 / 1321: packed fp32 beside MFMAs LOSES 10 %
+#   abl_noexp +5.7 %, abl_nodma +4.6 % over tile1: what the exponentials and the L2 -> LDS traffic cost
+VARIANTS = [Config("tile1"), Config("ring4", nslot=4), Config("m0", unroll3=True, ahead=3, wait2=True, m0once=True), Config("pk", unroll3=True, ahead=3, wait2=True, pkadd=True),
             Config("abl_novm", novm=True), Config("abl_nobar", novm=True, nobar=True), Config("abl_noexp", noexp=True), Config("abl_nodma", nodma=True, novm=True)]
 
 
@@ -389,6 +459,8 @@ def census(cfg, loop_lines, gaps):
     n_mfma = sum(1 for l in loop_lines if l.startswith("v_mfma"))
     n_other = len(loop_lines) - n_mfma
     loop_gaps = gaps[-n_mfma:]
+    if cfg.unroll3:      # per tile
+        n_mfma //= 3; n_other = round(n_other / 3.0, 1)
     return n_mfma, n_other, {k: loop_gaps.count(k) for k in sorted(set(loop_gaps))}
 
 
@@ -400,7 +472,7 @@ def main():
     with open(os.devnull if "--keep-default" in sys.argv else out, "w") as f:
         f.write("// GENERATED by tools/gen_attn_q64.py -- do not edit; the generator's header explains the stream.\n")
         f.write("// loop trip (one 64-key tile, 64 queries per wave): %d MFMAs, %d other instructions (%.2f per MFMA gap; histogram of gap sizes %s)\n" % (n_mfma, n_other, n_other / n_mfma, hist))
-        f.write("#define AQ2_NSLOT %d\n" % DEFAULT.nslot)
+        f.write("#define AQ2_NSLOT %d\n#define AQ2_M0_ONCE %d\n" % (DEFAULT.nslot, int(DEFAULT.m0once)))
         write_text(f, "AQ2_ASM_TEXT", st)
         f.write("#define AQ2_ASM_OUTPUTS " + ", ".join('[%s] "%s"(%s)' % o for o in OPERANDS_OUT) + "\n")
         f.write("#define AQ2_ASM_INPUTS " + ", ".join('[%s] "%s"(%s)' % o for o in OPERANDS_IN) + "\n")
@@ -415,7 +487,7 @@ def main():
             for i, cfg in enumerate(VARIANTS):
                 stv, ll, gg = gen(cfg)
                 n_mfma, n_other, hist = census(cfg, ll, gg)
-                f.write("// arm %d = %s: %.2f per gap %s\n#define AQ2_NSLOT_V%d %d\n" % (i + 1, cfg.name, n_other / n_mfma, hist, i + 1, cfg.nslot))
+                f.write("// arm %d = %s: %.2f per gap %s\n#define AQ2_NSLOT_V%d %d\n#define AQ2_M0_ONCE_V%d %d\n" % (i + 1, cfg.name, n_other / n_mfma, hist, i + 1, cfg.nslot, i + 1, int(cfg.m0once)))
                 write_text(f, "AQ2_ASM_TEXT_V%d" % (i + 1), stv)
                 print("  arm %d = %-14s %.2f per gap %s" % (i + 1, cfg.name, n_other / n_mfma, hist))
 
