@@ -112,6 +112,10 @@ size_t utx_attn_workspace_bytes(utx_ctx* ctx, int H, int S_q, int S_kv);
 int utx_quant_vt_mx8(utx_ctx* ctx, const void* vt, void* v8, void* vs, int H, int S_pad, utx_stream stream);
 int utx_attn_fwd_fp8(utx_ctx* ctx, const void* q8, const void* qs, const void* k8, const void* ks, const void* v8t, const void* vs, void* o, long o_ss,
                      int H, int S_q, int S_kv, int S_pad, float key_bias_log2, int key_bias_period, utx_stream stream);
+/* The same with CALLER-OWNED scratch for the key-split tail round (round 6: the bf16 kernel's plan, work items and merge): work >= utx_attn_workspace_bytes(ctx, H, S_q, S_kv)
+ * bytes, 16-byte aligned; null / too small: the launch stays unsplit.  utx_attn_fwd_fp8 uses the context's per-stream scratch (none while the stream is capturing). */
+int utx_attn_fwd_fp8_ws(utx_ctx* ctx, const void* q8, const void* qs, const void* k8, const void* ks, const void* v8t, const void* vs, void* o, long o_ss,
+                        int H, int S_q, int S_kv, int S_pad, float key_bias_log2, int key_bias_period, void* work, size_t work_bytes, utx_stream stream);
 int utx_attn_plan(int H, int S_q, int S_kv, int n_cus, int out[4]);
 /* The same on BLOCK-STRIDED operands: the S_kv tokens (queries and keys alike) come in blocks of blk_rows (a multiple of 64 that divides S_kv); block b of Q / K /
  * V^T of a head starts q_bs / k_bs / vt_bs elements (multiples of 8) behind block b - 1, rows inside a block are q_ss / k_ss apart, V^T rows vt_ds (each holding the
@@ -456,6 +460,8 @@ int utx_plan_add_add3(utx_plan* plan, const void* a, const void* b, const void* 
 int utx_plan_add_quant_vt_mx8(utx_plan* plan, const void* vt, void* v8, void* vs, int H, int S_pad);
 int utx_plan_add_attn_fp8(utx_plan* plan, const void* q8, const void* qs, const void* k8, const void* ks, const void* v8t, const void* vs, void* o, long o_ss,
                           int H, int S_q, int S_kv, int S_pad, float key_bias_log2, int key_bias_period);
+int utx_plan_add_attn_fp8_ws(utx_plan* plan, const void* q8, const void* qs, const void* k8, const void* ks, const void* v8t, const void* vs, void* o, long o_ss,
+                             int H, int S_q, int S_kv, int S_pad, float key_bias_log2, int key_bias_period, void* work, size_t work_bytes);
 int utx_plan_fork(utx_plan* plan);
 int utx_plan_main(utx_plan* plan);
 int utx_plan_join(utx_plan* plan);

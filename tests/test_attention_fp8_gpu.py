@@ -201,3 +201,62 @@ def test_fp8_attention_on_long_diffuse_rows_with_an_early_outlier_key(outlier):
         assert rel <= 0.08, rel
     else:
         assert rel <= 0.25, rel      # stated limit: numerator mass below 2^-10 of the running maximum is dropped, the denominator keeps it
+
+
+@pytest.mark.parametrize("H,S,S_q,kb", [(24, 3328, None, 3.0), (24, 6272, None, 0.0), (24, 13376, 4096, 3.0)])
+def test_fp8_attention_key_split_tail_round_matches_the_unsplit_launch(H, S, S_q, kb):
+    """round 6: the fp8 kernel cuts its last, partly filled round of workgroups along the keys like the bf16 kernel (same plan, work items, partial rows and
+    merge).  Against the same kernel with UTX_ATTN_TAILSPLIT=0 on the same operands: rows of the whole rounds are BIT-IDENTICAL.  Rows of the tail items are NOT a rounding apart as
+    in bf16: a key range re-centres on ITS first tile, and the e4m3 grid of P (3 mantissa bits) hangs on the running maximum -- the two launches quantise the same probabilities
+    differently.  Both are the fp8 kernel's contract: each within the P-rounding tolerance of the exact attention over the dequantised operands (<= 5 % of max|O|, mean <= 0.3 %:
+    the random-data test above), so at most twice that apart; key multiplicity stays on the SEQUENCE's tile 0 in whichever range holds it."""
+    from unitex_amd import _lib
+    ops = _ops()
+    lib = ops.get_ctx(0).lib
+    pl = (C.c_int * 4)()
+    nq = S if S_q is None else S_q
+    assert lib.utx_attn_plan(H, nq, S, torch.cuda.get_device_properties(0).multi_processor_count, pl) == 0
+    nwg, nfull, ns, tps = pl[0], pl[1], pl[2], pl[3]
+    assert ns > 1 and 0 < nfull < nwg, "shape does not exercise the split: %s" % list(pl)
+    g = torch.Generator(device="cuda").manual_seed(S)
+    qh = (torch.randn(H, S, 128, generator=g, device="cuda") * 0.19).to(BF)
+    kh = (torch.randn(H, S, 128, generator=g, device="cuda") * 1.5).to(BF)
+    vt = torch.randn(H, 128, S, generator=g, device="cuda").to(BF)
+    q8, qs = ops.quant_qk_mx8(qh); k8, ks = ops.quant_qk_mx8(kh); v8, vs = ops.quant_vt_mx8(vt)
+    outs = {}
+    try:
+        for split in (1, 0):
+            _lib.set_option("UTX_ATTN_TAILSPLIT", split)
+            outs[split] = ops.attention_fp8(q8, qs, k8, ks, v8, vs, S=S, S_q=nq, key_bias_log2=kb)
+            torch.cuda.synchronize()
+    finally:
+        _lib.set_option("UTX_ATTN_TAILSPLIT", 1)
+    a, b = outs[1].float().cpu(), outs[0].float().cpu()            # [nq, H * 128]
+    assert torch.isfinite(a).all()
+    # work item w = head * nqb + query block; items [nfull, nwg) are the tail
+    nqb = (nq + 255) // 256
+    tail = torch.zeros(nq, H, dtype=torch.bool)
+    for w in range(nfull, nwg):
+        h, qb = divmod(w, nqb)
+        tail[qb * 256: min(nq, qb * 256 + 256), h] = True
+    diff = (a != b).view(nq, H, 128).any(-1)
+    assert not bool((diff & ~tail).any()), "a row outside the tail round changed"
+    assert bool(diff.any()), "the split launch has the bits of the unsplit one everywhere: the tail round was not split"
+    mx = b.abs().max().item()
+    d = (a - b).abs()
+    print("\n[fp8 attention key split H=%d S=%d] tail rows %d of %d; split vs unsplit: max %.4g = %.2f %% of max|O| %.3g, mean over tail rows %.3f %%" % (
+        H, S, int(tail.sum()), tail.numel(), d.max().item(), 100 * d.max().item() / mx, mx, 100 * d.view(nq, H, 128)[tail].mean().item() / mx))
+    assert d.max().item() <= 0.10 * mx and d.view(nq, H, 128)[tail].mean().item() <= 0.006 * mx
+    # and the split rows hold the kernel's contract themselves: exact attention over the dequantised operands on sampled tail rows
+    rows = torch.nonzero(tail.any(1)).flatten()[::37][:64]
+    qd = mx8_ref.dequantize(q8.cpu().reshape(H * S, 128), qs.cpu().reshape(H * S, 4)).reshape(H, S, 128)[:, rows]
+    kd = mx8_ref.dequantize(k8.cpu().reshape(H * S, 128), ks.cpu().reshape(H * S, 4)).reshape(H, S, 128)
+    vd = mx8_ref.dequantize(v8.cpu().reshape(H * 128, S), vs.cpu().permute(0, 3, 2, 1).reshape(H * 128, S // 32)).reshape(H, 128, S).transpose(1, 2)
+    kbias = None
+    if kb:
+        kbias = torch.zeros(S); kbias[:64] = kb
+    ref = _dense(qd, kd, vd, S, kbias).permute(1, 0, 2)          # [rows, H, 128]
+    got = a.view(nq, H, 128)[rows]
+    sel = tail[rows]                                              # (row, head) pairs that went through the split
+    da = (got - ref).abs()[sel]
+    assert da.numel() > 0 and da.max().item() <= 0.05 * ref.abs().max().item() and da.mean().item() <= 0.003 * ref.abs().max().item(), (da.max().item(), da.mean().item())

@@ -127,6 +127,7 @@ SYMBOLS = {
     "utx_plan_add_add3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
     "utx_plan_add_quant_vt_mx8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int]),
     "utx_plan_add_attn_fp8": (c_int, [c_void_p] * 8 + [c_long, c_int, c_int, c_int, c_int, c_float, c_int]),
+    "utx_plan_add_attn_fp8_ws": (c_int, [c_void_p] * 8 + [c_long, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, C.c_size_t]),
     "utx_plan_fork": (c_int, [c_void_p]),
     "utx_plan_main": (c_int, [c_void_p]),
     "utx_plan_join": (c_int, [c_void_p]),
@@ -149,6 +150,7 @@ SYMBOLS = {
     "utx_attn_workspace_bytes": (C.c_size_t, [c_void_p, c_int, c_int, c_int]),
     "utx_quant_vt_mx8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "utx_attn_fwd_fp8": (c_int, [c_void_p] * 8 + [c_long, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "utx_attn_fwd_fp8_ws": (c_int, [c_void_p] * 8 + [c_long, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, C.c_size_t, c_void_p]),
     "utx_attn_plan": (c_int, [c_int, c_int, c_int, c_int, c_void_p]),
     "utx_gemm_bf16": (c_int, [c_void_p, C.POINTER(GemmDesc), c_void_p]),
     "utx_gemm_streamk_workspace_bytes": (C.c_size_t, [c_void_p]),

@@ -24,6 +24,7 @@
 // both conflict-free for the ds_read_b128 lane groups {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} with the row permutation above.
 #include "common.h"
 #include "kernels.h"
+#include <string.h>
 
 #define A8_KVB 64
 #define A8_KTILE 8192
@@ -63,14 +64,20 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_fp8_kernel(Attn8Params p) {
     const int lq = lane & 31, lh = lane >> 5;
 
     const int wid = xcd_remap(blockIdx.x, gridDim.x);
-    const int head = wid / p.nqb;
-    const int qb = wid - head * p.nqb;
-    const int S = p.S;
+    const int nsp = p.nsplit;                        // > 1: this launch covers the tail items, each cut along the keys (attention_glds.hip's plan and merge)
+    const int item = nsp > 1 ? wid / nsp : wid;
+    const int split = wid - item * nsp;
+    const int w = p.w_base + item;
+    const int head = w / p.nqb;
+    const int qb = w - head * p.nqb;
     const int Sq = p.Sq > 0 ? p.Sq : p.S;
-    const uint8_t* const kbase = p.k8 + (long)head * p.S_pad * 128;
-    const uint8_t* const vbase = p.v8t + (long)head * 128 * p.S_pad;
-    const uint32_t* const ksb = p.ks + (long)head * p.S_pad;
-    const uint32_t* const vsb = p.vs + (long)head * (p.S_pad / 32) * 32;
+    // keys of this workgroup: all of them, or tiles [tb, tb + tiles_per_split) of the sequence: base pointers advance, S counts from there, key multiplicity keeps the sequence's tile index
+    const int tb = nsp > 1 ? split * p.tiles_per_split : 0;
+    const int S = nsp > 1 ? ((p.S - tb * A8_KVB < p.tiles_per_split * A8_KVB) ? p.S - tb * A8_KVB : p.tiles_per_split * A8_KVB) : p.S;
+    const uint8_t* const kbase = p.k8 + ((long)head * p.S_pad + (long)tb * A8_KVB) * 128;
+    const uint8_t* const vbase = p.v8t + (long)head * 128 * p.S_pad + (long)tb * A8_KVB;
+    const uint32_t* const ksb = p.ks + (long)head * p.S_pad + (long)tb * A8_KVB;
+    const uint32_t* const vsb = p.vs + ((long)head * (p.S_pad / 32) + 2 * (long)tb) * 32;
 
     const int q0 = qb * 256 + wave * 32;
     a8_i32x8 qf[2];
@@ -170,7 +177,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_fp8_kernel(Attn8Params p) {
         const char* vb = vring + slot * A8_VTILE;                                                                      \
         const bool ragged = (SP_) && (t == nt - 1) && (S & (A8_KVB - 1));                                              \
         const int lim = S - t * A8_KVB - 16 * lh;   /* register r of block b is key 32 b + 16 lh + r of the tile */    \
-        const bool kbias = (SP_) && (p.key_bias_log2 != 0.f) && (p.key_bias_period > 0 ? (t % p.key_bias_period == 0) : (t == 0)); \
+        const bool kbias = (SP_) && (p.key_bias_log2 != 0.f) && (p.key_bias_period > 0 ? ((tb + t) % p.key_bias_period == 0) : (tb + t == 0)); \
         /* ---- QK^T: both 32-key blocks, scores come out as s - m_run (the accumulators start at -m) */               \
         f32x16 sa0, sa1;                                                                                               \
         {                                                                                                              \
@@ -349,7 +356,12 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_fp8_kernel(Attn8Params p) {
     const float inv = 1.0f / l_tot;
     const int qrow = q0 + lq;
     if (qrow < Sq) {
-        bf16_t* const o8 = p.o + (long)qrow * p.o_ss + head * 128 + 4 * lh;
+        bf16_t* o8 = p.o + (long)qrow * p.o_ss + head * 128 + 4 * lh;
+        if (nsp > 1) {      // partial result of this key range: normalised rows (bf16) + log2-sum-exp; attn_merge_kernel combines the ranges
+            const long prow = ((long)item * nsp + split) * 256 + wave * 32 + lq;
+            o8 = p.part_o + prow * 128 + 4 * lh;
+            if (lh == 0) p.part_lse[prow] = m_run + __builtin_amdgcn_logf(l_tot);
+        }
 #pragma unroll
         for (int db = 0; db < 4; ++db)
 #pragma unroll
@@ -416,13 +428,33 @@ extern "C" int utx_launch_quant_vt_mx8(const void* vt, void* v8, void* vs, int H
 }
 
 template <int VAR>
-static int a8_launch(const Attn8Params& p, hipStream_t stream) {
+static int a8_launch(const Attn8Params& p0, hipStream_t stream) {
     UTX_ONCE_PER_DEVICE(attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_fp8_kernel<VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, A8_LDS) != hipSuccess) return -3;
         UTX_ONCE_DONE(attr_set);
     }
-    hipLaunchKernelGGL((attn_fwd_fp8_kernel<VAR>), dim3(p.nqb * p.H), dim3(512), A8_LDS, stream, p);
-    return hipGetLastError() == hipSuccess ? 0 : -4;
+    Attn8Params p = p0;
+    p.w_base = 0; p.nsplit = 1; p.tiles_per_split = 0; p.part_o = nullptr; p.part_lse = nullptr;
+    // the key-split tail round of the bf16 kernel (attention_glds.hip: same 256-query work items, same plan, same partial rows, same merge): the last, partly filled round of
+    // workgroups is cut along the keys.  Scratch is the caller's (utx_attn_fwd_fp8_ws / the context's for utx_attn_fwd_fp8); without it the launch stays unsplit.
+    int pl[4] = {p.nqb * p.H, 0, 1, 0};
+    utx_attn_split_plan_impl(p.H, p.Sq, p.S, utx_ncu(), pl);
+    const int nwg = pl[0], nfull = pl[1], ns = pl[2], tps = pl[3], r = nwg - nfull;
+    const size_t rows = (size_t)r * ns * 256;
+    if (ns <= 1 || !p.work || p.work_bytes < rows * (128 * sizeof(bf16_t) + sizeof(float))) {
+        hipLaunchKernelGGL((attn_fwd_fp8_kernel<VAR>), dim3(nwg), dim3(512), A8_LDS, stream, p);
+        return hipGetLastError() == hipSuccess ? 0 : -4;
+    }
+    hipLaunchKernelGGL((attn_fwd_fp8_kernel<VAR>), dim3(nfull), dim3(512), A8_LDS, stream, p);
+    Attn8Params t = p;
+    t.w_base = nfull; t.nsplit = ns; t.tiles_per_split = tps;
+    t.part_o = (bf16_t*)p.work; t.part_lse = (float*)((char*)p.work + rows * 128 * sizeof(bf16_t));
+    hipLaunchKernelGGL((attn_fwd_fp8_kernel<VAR>), dim3(r * ns), dim3(512), A8_LDS, stream, t);
+    AttnParams m;      // what attn_merge_kernel reads: output, work-item geometry, the partial rows
+    memset(&m, 0, sizeof(m));
+    m.o = p.o; m.o_ss = p.o_ss; m.H = p.H; m.S = p.S; m.Sq = p.Sq; m.nqb = p.nqb;
+    m.w_base = nfull; m.nsplit = ns; m.tiles_per_split = tps; m.part_o = t.part_o; m.part_lse = t.part_lse;
+    return utx_launch_attn_merge(&m, r, stream);
 }
 
 extern "C" int utx_launch_attn_fwd_fp8(const Attn8Params* hp, hipStream_t stream) {

@@ -212,7 +212,22 @@ int utx_attn_fwd_fp8(utx_ctx* ctx, const void* q8, const void* qs, const void* k
     p.qs = (const uint32_t*)qs; p.ks = (const uint32_t*)ks; p.vs = (const uint32_t*)vs;
     p.o = (bf16_t*)o; p.o_ss = o_ss; p.H = H; p.S = S_kv; p.Sq = S_q; p.S_pad = S_pad; p.nqb = 0;
     p.key_bias_log2 = key_bias_log2; p.key_bias_period = key_bias_period;
+    // the key-split tail round runs on the context's per-stream scratch (none while the stream is capturing: the launch then stays unsplit); utx_attn_fwd_fp8_ws takes the caller's
+    p.work = (S_q > 0 && S_q <= S_kv) ? ctx_attn_ws(ctx, H, S_q, S_kv, (hipStream_t)stream, &p.work_bytes) : nullptr;
+    if (!p.work) p.work_bytes = 0;
     UTX_CALL(ctx, "utx_attn_fwd_fp8", utx_launch_attn_fwd_fp8(&p, (hipStream_t)stream));
+}
+
+int utx_attn_fwd_fp8_ws(utx_ctx* ctx, const void* q8, const void* qs, const void* k8, const void* ks, const void* v8t, const void* vs, void* o, long o_ss,
+                        int H, int S_q, int S_kv, int S_pad, float key_bias_log2, int key_bias_period, void* work, size_t work_bytes, utx_stream stream) {
+    if (!q8 || !qs || !k8 || !ks || !v8t || !vs || !o) return fail(ctx, -2, "utx_attn_fwd_fp8_ws");
+    Attn8Params p;
+    p.q8 = (const uint8_t*)q8; p.k8 = (const uint8_t*)k8; p.v8t = (const uint8_t*)v8t;
+    p.qs = (const uint32_t*)qs; p.ks = (const uint32_t*)ks; p.vs = (const uint32_t*)vs;
+    p.o = (bf16_t*)o; p.o_ss = o_ss; p.H = H; p.S = S_kv; p.Sq = S_q; p.S_pad = S_pad; p.nqb = 0;
+    p.key_bias_log2 = key_bias_log2; p.key_bias_period = key_bias_period;
+    p.work = work; p.work_bytes = work ? work_bytes : 0;
+    UTX_CALL(ctx, "utx_attn_fwd_fp8_ws", utx_launch_attn_fwd_fp8(&p, (hipStream_t)stream));
 }
 
 size_t utx_attn_workspace_bytes(utx_ctx* ctx, int H, int S_q, int S_kv) {

@@ -48,6 +48,12 @@ struct Attn8Params {
     int H, S, Sq, S_pad, nqb;
     float key_bias_log2;
     int key_bias_period;
+    // key-split tail round (round 6; the bf16 kernel's plan, work items and merge -- AttnParams above): filled by the launcher from `work`
+    int w_base, nsplit, tiles_per_split;
+    bf16_t* part_o;
+    float* part_lse;
+    void* work;            // caller-owned scratch (utx_attn_workspace_bytes); null / too small: the launch stays unsplit
+    size_t work_bytes;
 };
 // Launch options.  Every field is result-preserving (kernel selection / scheduling A/B): read ONCE from the environment by
 // the first utx_init (UTX_ATTN_*, UTX_GEMM_* variables of the same names), afterwards changed only through utx_set_option.

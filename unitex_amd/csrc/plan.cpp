@@ -99,6 +99,15 @@ int utx_plan_add_attn_fp8(utx_plan* p, const void* q8, const void* qs, const voi
     push(p, K_ATTN8).attn8 = a;
     return 0;
 }
+// the same with caller-owned scratch for the key-split tail round (utx_attn_workspace_bytes; the plan holds the pointer: the buffer must outlive the plan)
+int utx_plan_add_attn_fp8_ws(utx_plan* p, const void* q8, const void* qs, const void* k8, const void* ks, const void* v8t, const void* vs, void* o, long o_ss,
+                             int H, int S_q, int S_kv, int S_pad, float key_bias_log2, int key_bias_period, void* work, size_t work_bytes) {
+    const int rc = utx_plan_add_attn_fp8(p, q8, qs, k8, ks, v8t, vs, o, o_ss, H, S_q, S_kv, S_pad, key_bias_log2, key_bias_period);
+    if (rc) return rc;
+    p->entries.back().attn8.work = work;
+    p->entries.back().attn8.work_bytes = work ? work_bytes : 0;
+    return 0;
+}
 // two-stream section: fork; [side entries]; utx_plan_main; [main entries]; join
 int utx_plan_fork(utx_plan* p) {
     if (!p || p->cur_side || p->open_sections) return -2;

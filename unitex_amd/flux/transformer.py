@@ -460,7 +460,8 @@ class FluxDiT:
             plan.append(("quant_qk", (Qh, ws["Q8"], ws["Q8s"])))
             plan.append(("quant_qk", (Kh, ws["K8"], ws["K8s"])))
             plan.append(("quant_vt", (Vt, ws["V8"], ws["V8s"])))
-            plan.append(("attn8", (ws["Q8"][:, r0:], ws["Q8s"][:, r0:], ws["K8"], ws["K8s"], ws["V8"], ws["V8s"], out, r1 - r0, S, Qh.shape[1])))
+            wk8 = self._attn_work(ws, sh.num_heads, r1 - r0, S)      # scratch of the key-split tail round (round 6: the fp8 kernel splits its last round like the bf16 one)
+            plan.append(("attn8", (ws["Q8"][:, r0:], ws["Q8s"][:, r0:], ws["K8"], ws["K8s"], ws["V8"], ws["V8s"], out, r1 - r0, S, Qh.shape[1], wk8)))
             return
         Qs = Qh[:, r0:]
         wk = self._attn_work(ws, sh.num_heads, r1 - r0, S)
@@ -886,13 +887,13 @@ class FluxDiT:
             ops.quant_vt_mx8(d[0], out=(d[1], d[2]))
             return
         if fn == "attn8":
-            q8, qs, k8, ks, v8, vs, out, n_q, S_kv, S_pad = d
+            q8, qs, k8, ks, v8, vs, out, n_q, S_kv, S_pad, wk8 = d
             ev = getattr(self, "attn_events", None)
             if ev is not None:
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
-            rc = self.lib.utx_attn_fwd_fp8(self.ctx.handle, ptr(q8), ptr(qs), ptr(k8), ptr(ks), ptr(v8), ptr(vs), ptr(out), out.stride(0), self.shape.num_heads,
-                                           int(n_q), int(S_kv), int(S_pad), float(self.key_bias_log2), int(self.key_bias_period), st)
+            rc = self.lib.utx_attn_fwd_fp8_ws(self.ctx.handle, ptr(q8), ptr(qs), ptr(k8), ptr(ks), ptr(v8), ptr(vs), ptr(out), out.stride(0), self.shape.num_heads,
+                                              int(n_q), int(S_kv), int(S_pad), float(self.key_bias_log2), int(self.key_bias_period), ptr(wk8), 0 if wk8 is None else wk8.numel(), st)
             if ev is not None:
                 b.record()
                 ev.append((a, b))
@@ -1041,9 +1042,9 @@ class FluxDiT:
                 x_, q_, s_ = d
                 return lib.utx_plan_add_quant_vt_mx8(h, ptr(x_), ptr(q_), ptr(s_), x_.shape[0], x_.shape[2])
             if isinstance(fn, str) and fn == "attn8":
-                q8, qs, k8, ks, v8, vs, out, n_q, S_kv, S_pad = d
-                return lib.utx_plan_add_attn_fp8(h, ptr(q8), ptr(qs), ptr(k8), ptr(ks), ptr(v8), ptr(vs), ptr(out), out.stride(0), self.shape.num_heads,
-                                                 int(n_q), int(S_kv), int(S_pad), float(self.key_bias_log2), int(self.key_bias_period))
+                q8, qs, k8, ks, v8, vs, out, n_q, S_kv, S_pad, wk8 = d
+                return lib.utx_plan_add_attn_fp8_ws(h, ptr(q8), ptr(qs), ptr(k8), ptr(ks), ptr(v8), ptr(vs), ptr(out), out.stride(0), self.shape.num_heads,
+                                                    int(n_q), int(S_kv), int(S_pad), float(self.key_bias_log2), int(self.key_bias_period), ptr(wk8), 0 if wk8 is None else wk8.numel())
             if isinstance(fn, str) and fn == "temb_sum":
                 g = ws["e_g"] if self.shape.guidance_embeds else None
                 return lib.utx_plan_add_add3(h, ptr(ws["e_t"]), ptr(g), ptr(ws["e_p"]), ptr(ws["temb"]), ws["temb"].numel())
