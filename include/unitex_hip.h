@@ -45,7 +45,9 @@ const char* utx_last_error(utx_ctx* ctx);
  * they split -- the same result up to rounding, deterministic from launch to launch.  The first utx_init reads the environment
  * variables of the same names once; later changes go through utx_set_option only (no getenv on the launch path).  Names:
  * UTX_ATTN_GLDS, UTX_ATTN_FAST, UTX_ATTN_Q64, UTX_ATTN_TPB, UTX_ATTN_TAILSPLIT, UTX_GEMM_GROUP_M, UTX_GEMM_TILE, UTX_GEMM_TAILSPLIT,
- * UTX_GEMM_STREAMK, UTX_GEMM_PERS_GRID, UTX_GEMM_PERS_SCHED, UTX_BVH_STACK_WALK.  The timing-ablation switches that compute wrong
+ * UTX_GEMM_STREAMK, UTX_GEMM_PERS_GRID, UTX_GEMM_PERS_SCHED, UTX_BVH_STACK_WALK, UTX_BVH_PACKET, UTX_ATTN_PEEL, UTX_ATTN8_PEEL, UTX_NN_GRID.  UTX_ATTN_Q64 (default 1: the
+ * 4 x 64 attention kernel for the launches it takes) keeps the bits wherever the 8 x 32 kernel does not re-centre its running maximum behind the first 32 keys; where it does, the two
+ * kernels return two roundings of the same softmax.  The timing-ablation switches that compute wrong
  * results (UTX_ATTN_VAR, UTX_ATTN_DEBUG, UTX_GEMM_DEBUG) exist only in the separately built libunitex_hip_ablate.so (tools/ only): in
  * this library they return -7 and the environment variables are ignored.  Returns -2 for an unknown name. */
 int utx_set_option(const char* name, int value);
@@ -69,7 +71,9 @@ int utx_is_ablation_build(void);
  * o_ss multiple of 4.
  * softmax_scale > 0: the reference's scale (1/sqrt(128)); softmax_scale == 0: Q was pre-multiplied by
  * scale*log2(e) by utx_qkv_post (q_scale) and scores are used as base-2 exponents directly.
- * One call may issue up to three stream-ordered launches (full rounds of workgroups, the key-split tail round, its merge).
+ * One call may issue up to five stream-ordered operations (a memset of the flag bytes, full rounds of workgroups, the key-split tail round, its merge, the repair pass).
+ * Since round 6 the launches that qualify -- softmax_scale == 0, S a multiple of 64, contiguous operands, key_bias_period == 0, scratch present -- run the 4 x 64 kernel
+ * (attention_q64.hip: one wave per SIMD, generated instruction stream) followed by its repair pass; all others the 8 x 32 kernel (attention_glds.hip).
  * The tail round needs scratch.  utx_attn_fwd_bf16_ws takes it from the caller (utx_attn_workspace_bytes: nothing is allocated on the
  * launch path, re-entrant per stream / buffer).  The entry points without a workspace argument use a buffer owned by the CONTEXT, grown
  * with hipMalloc by the first call that needs more (never while the stream is being captured: such a launch stays unsplit -- same
@@ -93,7 +97,8 @@ int utx_attn_fwd_bf16_kbq(utx_ctx* ctx, const void* q, const void* k, const void
                           long q_hs, long q_ss, long k_hs, long k_ss, long vt_hs, long vt_ds, long o_ss,
                           int H, int S_q, int S_kv, float softmax_scale, float key_bias_log2, int key_bias_period, utx_stream stream);
 /* The same with CALLER-OWNED scratch for the key-split tail round: work >= utx_attn_workspace_bytes(ctx, H, S_q, S_kv) bytes, 16-byte aligned, used only
- * by the launches of this call (stream-ordered).  work == NULL or too small: the tail round is not split.  utx_attn_plan (pure host arithmetic,
+ * by the launches of this call (stream-ordered); layout [key-split scratch | one flag byte per 64-query group (the 4 x 64 kernel's headroom record)].  work == NULL or too small:
+ * the tail round is not split and the 8 x 32 kernel runs.  utx_attn_plan (pure host arithmetic,
  * no device): out = {workgroups, workgroups in full rounds of n_cus, key ranges per tail workgroup (1 = not split), 64-key tiles per range}. */
 int utx_attn_fwd_bf16_ws(utx_ctx* ctx, const void* q, const void* k, const void* vt, void* o,
                          long q_hs, long q_ss, long k_hs, long k_ss, long vt_hs, long vt_ds, long o_ss,

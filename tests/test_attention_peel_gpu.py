@@ -53,6 +53,17 @@ CASES = [
 ]
 
 
+@pytest.fixture(autouse=True)
+def _the_8x32_kernel():
+    """since round 6 the launches the 4 x 64 kernel takes would bypass BOTH loops compared here: this module is about the 8 x 32 kernel (the path of ragged / periodic-key-multiplicity /
+    block-strided launches and of the repair pass), so it runs with UTX_ATTN_Q64=0; tests/test_attention_q64_gpu.py holds the 4 x 64 kernel against this one"""
+    from unitex_amd import _lib
+    prev = _lib.get_options()["UTX_ATTN_Q64"]
+    _lib.set_option("UTX_ATTN_Q64", 0)
+    yield
+    _lib.set_option("UTX_ATTN_Q64", prev)
+
+
 @pytest.mark.parametrize("H,S,S_q,kb,period,spike", CASES)
 def test_fast_attention_loop_equals_the_general_loop_bit_for_bit(H, S, S_q, kb, period, spike):
     from unitex_amd import _lib

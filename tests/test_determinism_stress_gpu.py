@@ -215,6 +215,8 @@ def test_fast_attention_loop_320_launches_against_the_general_loops_bits():
     from unitex_amd import _lib
     from unitex_amd.flux import ops
     noise = _Perturb()
+    q64_prev = _lib.get_options()["UTX_ATTN_Q64"]
+    _lib.set_option("UTX_ATTN_Q64", 0)      # this test is about the 8 x 32 kernel's two loops (round 6: the 4 x 64 kernel would take the second shape in both arms)
     for H, S, S_q, kb, reps in ((24, 3000, None, 3.0, 200), (24, 4096, 2816, 0.0, 120)):
         g = torch.Generator(device="cuda").manual_seed(S)
         S_pad = (S + 63) // 64 * 64
@@ -237,4 +239,37 @@ def test_fast_attention_loop_320_launches_against_the_general_loops_bits():
             if not torch.equal(out.view(torch.int16), ref.view(torch.int16)):
                 bad.append((i, int((out.view(torch.int16) != ref.view(torch.int16)).sum())))
         assert not bad, "S = %d: %d of %d launches of the fast loop differ from the general loop: %s" % (S, len(bad), reps, bad[:5])
+    torch.cuda.synchronize()
+    _lib.set_option("UTX_ATTN_Q64", q64_prev)
+
+
+def test_q64_attention_stream_300_launches_against_the_8x32_kernels_bits():
+    """Round 6: the default attention kernel is a hand-placed instruction stream whose every wait is counted by its generator (one barrier per tile, K(t + 3) / V(t + 2)
+    requested behind it, fragments read three groups ahead) -- a missed wait or a slot reused too early would show as a RARE mismatch.  300 launches on two shapes (key
+    multiplicity + key-split tail round; pruned queries, nt mod 3 = 1) under the perturbing side stream / cache evictions, every one against the bits of the 8 x 32 kernel
+    (no outlier keys: the shapes on which the two kernels are bit-identical by construction)."""
+    from unitex_amd import _lib
+    from unitex_amd.flux import ops
+    assert _lib.get_options()["UTX_ATTN_Q64"] == 1
+    noise = _Perturb()
+    for H, S, S_q, kb, reps in ((24, 3328, None, 3.0, 180), (24, 4160, 2816, 0.0, 120)):
+        g = torch.Generator(device="cuda").manual_seed(S)
+        Qh = (torch.randn(H, S, 128, generator=g, device="cuda") * (1.4426950408889634 / math.sqrt(128.0))).to(BF)
+        Kh = torch.randn(H, S, 128, generator=g, device="cuda").to(BF)
+        Vt = torch.randn(H, 128, S, generator=g, device="cuda").to(BF)
+        try:
+            _lib.set_option("UTX_ATTN_Q64", 0)
+            ref = ops.attention(Qh, Kh, Vt, S=S, scale=0.0, key_bias_log2=kb, S_q=S_q).clone()
+            torch.cuda.synchronize()
+        finally:
+            _lib.set_option("UTX_ATTN_Q64", 1)
+        out = torch.empty_like(ref)
+        bad = []
+        for i in range(reps):
+            noise(i)
+            out.zero_()
+            ops.attention(Qh, Kh, Vt, S=S, scale=0.0, key_bias_log2=kb, S_q=S_q, out=out)
+            if not torch.equal(out.view(torch.int16), ref.view(torch.int16)):
+                bad.append((i, int((out.view(torch.int16) != ref.view(torch.int16)).sum())))
+        assert not bad, "S = %d: %d of %d launches of the 4 x 64 stream differ from the 8 x 32 kernel: %s" % (S, len(bad), reps, bad[:5])
     torch.cuda.synchronize()

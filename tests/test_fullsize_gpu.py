@@ -92,9 +92,18 @@ def _gemm_variants(fn):
             _set_tile(tile)
             outs[tile] = fn()
             torch.cuda.synchronize()
+        # round 6: the one-wave-per-SIMD kernel's steady-state K loop is a generated instruction stream (UTX_GEMM_FASTK=1, the default: what "2564" above ran);
+        # the same kernel on hipcc's own loop must give the same bits
+        assert _lib.get_options()["UTX_GEMM_FASTK"] == 1
+        _lib.set_option("UTX_GEMM_FASTK", 0)
+        _set_tile("2564")
+        slow = fn()
+        torch.cuda.synchronize()
+        assert _same_bits(slow, outs["2564"]), "gemm256_w4_kernel: generated K loop and hipcc's K loop disagree"
     finally:
         _set_tile(None)
         _lib.set_option("UTX_GEMM_STREAMK", 1)
+        _lib.set_option("UTX_GEMM_FASTK", 1)
     return outs
 
 

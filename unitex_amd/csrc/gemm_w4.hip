@@ -46,6 +46,7 @@
 // of a DMA is lane-linear) and on the fragment read address.
 #include "common.h"
 #include "kernels.h"
+#include "gemm_w4_loop_asm.inc"      // GENERATED (tools/gen_gemm_w4_loop.py): the steady-state K loop as one hand-placed stream, two K-tiles per trip
 
 #ifndef W4_ZERO_BY_MFMA
 #define W4_ZERO_BY_MFMA 1
@@ -82,7 +83,9 @@ __device__ __forceinline__ const char* w4_uniform(const char* p) {
 // QKF: the fused q / k post-processing of utx_gemm_desc.qk_cols (plain kernel only)
 // MX: OCP MX fp8 operands with tile-packed E8M0 scales (utx_gemm_desc.mx8 == 2; "MX fp8" below): same staging, ring and epilogues, a K-tile is
 // 128 fp8 = the same 128-byte rows, 32 v_mfma_scale_f32_32x32x64_f8f6f4 per K-tile instead of 64 v_mfma_f32_32x32x16_bf16
-template <bool GATED, bool QKF = false, bool MX = false>
+// FK (round 6; bf16 only): inside a K segment the K-tiles run through the generated stream (W4F_ASM_TEXT) -- same schedule, same MFMAs in the same order per accumulator, 74 instead of
+// 250 instructions beside a K-tile's 64 MFMAs; every boundary (tile, segment, LoRA switch, split-tail range, parking) stays with the loop below.  Bit-identical to FK = false.
+template <bool GATED, bool QKF = false, bool MX = false, bool FK = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm256_w4_kernel(GemmParams p, int ntiles, int reserved /* (the ablation arms' timeline workgroup until round 6; kept so that the kernel-argument layout -- and with it the register allocation of the five
       instances -- is byte-for-byte what was measured: the listings before and after the arms left this file are instruction-identical) */, int sk_T, int sk_S) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -725,7 +728,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // One K-tile = four K-steps of 16 MFMAs (schedule in the file header).  Slot i (behind MFMA i) of a K-step carries one fragment read (i < 8: the
     // fragments of the K-step after this one) and / or one DMA; the LDS address of a DMA is put into M0 in front of the MFMA before it (the wait state
     // M0 needs).
+    // fragment read addresses of the generated stream: absolute LDS byte address of (stage slot, k-chunk kk) for operand A / B; the stream adds 4096 x fragment index as an immediate
+    unsigned w4f_ra[2][4], w4f_rb[2][4];
+    if constexpr (FK && !MX) {
+        const int xk_[4] = {xk0, xk1, xk2, xk3};
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { w4f_ra[sl][k] = lds0 + (unsigned)(sl * W4_STAGE + arow + xk_[k]); w4f_rb[sl][k] = lds0 + (unsigned)(sl * W4_STAGE + brow + xk_[k]); }
+    }
     for (;;) {
+        if constexpr (FK && !MX) {
+            // W4_FAST_TRIPS: pairs of K-tiles during which neither cursor meets a boundary -- the compute cursor stays short of its segment's last K-tile (the tile boundary and its
+            // epilogue belong to the loop below), the staging cursor short of the K-tile whose advance re-places it (W4_STAGE_ADVANCE: s_ss == s_seg_end).  Stage slots: the
+            // stream's first K-tile computes on slot 0, so it is entered only with c_slot == 0 (s_slot == 1: the invariant s_slot == c_slot ^ 1 holds at every loop top).
+            if (c_slot == 0) {
+                int n_ = (s_seg_end - s_ss - 1) >> 1;
+                const int nc_ = (c_nss - c_ss - 1) >> 1;
+                if (nc_ < n_) n_ = nc_;
+                if (n_ > 0) {
+                    const unsigned long pa_ = (unsigned long)s_pA, pb_ = (unsigned long)s_pB;
+                    const unsigned w4f_pa_lo = __builtin_amdgcn_readfirstlane((unsigned)pa_), w4f_pa_hi = __builtin_amdgcn_readfirstlane((unsigned)(pa_ >> 32));
+                    const unsigned w4f_pb_lo = __builtin_amdgcn_readfirstlane((unsigned)pb_), w4f_pb_hi = __builtin_amdgcn_readfirstlane((unsigned)(pb_ >> 32));
+                    const unsigned w4f_trips = __builtin_amdgcn_readfirstlane((unsigned)n_);
+                    const unsigned w4f_ldsdma = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 1024u);
+                    asm volatile(W4F_ASM_TEXT : W4F_ASM_OUTPUTS : W4F_ASM_INPUTS : W4F_ASM_CLOBBERS);
+                    s_pA += 256L * n_; s_pB += 256L * n_;
+                    s_ss += 2 * n_; c_ss += 2 * n_;
+                }
+            }
+        }
         const int cb = c_slot * W4_STAGE, nb = (c_slot ^ 1) * W4_STAGE;
         // DMA schedule: piece p = 0..15 of the cursor's K-tile (p < 8: operand A piece p, else operand B piece p - 8), ONE DMA PER THREE MFMAs over
         // K-steps 3, 0, 1 (a burst of 1 KB requests backs the vector-memory path up into the issuing wave, which has no partner wave to hide behind;
@@ -980,6 +1012,19 @@ extern "C" int utx_launch_gemm_w4(GemmParams p, hipStream_t stream) {
         }
         if (p.gate) hipLaunchKernelGGL((gemm256_w4_kernel<true, false, true>), dim3(grid), dim3(256), LDS, stream, p, tiles, 0, sk_T, sk_S);
         else hipLaunchKernelGGL((gemm256_w4_kernel<false, false, true>), dim3(grid), dim3(256), LDS, stream, p, tiles, 0, sk_T, sk_S);
+    } else if (g_utx_opt.gemm_fastk != 0) {      // UTX_GEMM_FASTK (round 6): the instances whose steady-state K loop is the generated stream; same bits
+        UTX_ONCE_PER_DEVICE(af) {
+            const void* kf[3] = {reinterpret_cast<const void*>(gemm256_w4_kernel<false, false, false, true>), reinterpret_cast<const void*>(gemm256_w4_kernel<true, false, false, true>),
+                                 reinterpret_cast<const void*>(gemm256_w4_kernel<false, true, false, true>)};
+            for (const void* k : kf)
+                if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
+            UTX_ONCE_DONE(af);
+        }
+        if (p.gate) {
+            if (p.gelu_from < p.N || p.n_split < p.N) return -2;
+            hipLaunchKernelGGL((gemm256_w4_kernel<true, false, false, true>), dim3(grid), dim3(256), LDS, stream, p, tiles, 0, sk_T, sk_S);
+        } else if (p.qk_cols > 0) hipLaunchKernelGGL((gemm256_w4_kernel<false, true, false, true>), dim3(grid), dim3(256), LDS, stream, p, tiles, 0, sk_T, sk_S);
+        else hipLaunchKernelGGL((gemm256_w4_kernel<false, false, false, true>), dim3(grid), dim3(256), LDS, stream, p, tiles, 0, sk_T, sk_S);
     } else if (p.gate) {
         if (p.gelu_from < p.N || p.n_split < p.N) return -2;
         hipLaunchKernelGGL((gemm256_w4_kernel<true>), dim3(grid), dim3(256), LDS, stream, p, tiles, 0, sk_T, sk_S);

@@ -79,6 +79,7 @@ struct UtxOptions {
                           // barrier between S2 and S3, next tile's first K fragments read under S3); 0: the general loop (the default until round 4).  Same bits either way.
     int attn8_peel;       // 1 (default since round 5): MX fp8 attention with tile 0 / a ragged last tile outside the loop and the loop's exponentials in quarters under the PV MFMAs
                           // (attn_fwd_fp8_kernel<1>, attention_fp8.hip); 0: the general loop.  Same bits either way.
+    int gemm_fastk;       // one-wave-per-SIMD GEMM (bf16): 1 (default since round 6: +2.3 ... +3.7 % on the FLUX shapes, profiles/r06_gemm_fastk_check_v0.log) = the steady-state K loop runs the generated instruction stream (gemm_w4_loop_asm.inc), 0 = hipcc's loop (round 2-5).  Same bits.
     int nn_grid;          // 0 (default): the NN fill's cell grid follows the atlas size; 64 | 128 | 256 force one (A/B and the grid-independence test; same results)
 };
 extern UtxOptions g_utx_opt;
