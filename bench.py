@@ -534,13 +534,18 @@ def main():
         fl_nominal, _ = step_flops(S)
         attn_ms = [a.elapsed_time(b) for a, b in events]
         attn_avg_ms = sum(attn_ms) / max(len(attn_ms), 1)
-        attn_launch_flops = 4.0 * S_exec * S_exec * 128 * (model.ex.Hg if ulysses else HEADS)     # sequence parallel: one launch per head group of Hg heads
+        # sequence parallel with the ranks' identical text rows kept ONCE among the keys (FluxDiT.sp_kv_dedup, round 6): S_exec queries over ex.S_k keys
+        S_keys = model.ex.S_k if ulysses else S_exec
+        if S_keys != S_exec:
+            d_attn = 4.0 * S_exec * (S_exec - S_keys) * D * (N_DOUBLE + N_SINGLE)
+            fl -= d_attn; fl_attn -= d_attn
+        attn_launch_flops = 4.0 * S_exec * S_keys * 128 * (model.ex.Hg if ulysses else HEADS)     # sequence parallel: one launch per head group of Hg heads
         n_attn = 57 * (model.ex.G if ulysses else 1)
         if prune:
             # last-block pruning (FluxDiT.set_output_rows): the last of the 57 attention calls has n_noise queries instead of S_exec, and the
             # last block's q / MLP / output projections run on n_noise rows -- the FLOP figures are the EXECUTED ones
             dead = S_exec - n_noise
-            attn_last = 4.0 * n_noise * S_exec * 128 * HEADS
+            attn_last = 4.0 * n_noise * S_keys * 128 * HEADS
             fl -= (attn_launch_flops - attn_last) + 2.0 * dead * 3072 * (3072 + 4 * 3072) + 2.0 * dead * (5 * 3072) * 3072
             fl_attn -= (attn_launch_flops - attn_last)
             attn_launch_flops = (attn_launch_flops * (n_attn - 1) + attn_last) / n_attn      # mean over the step's calls, as attn_avg_ms is

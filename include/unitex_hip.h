@@ -89,7 +89,8 @@ int utx_attn_fwd_bf16(utx_ctx* ctx, const void* q, const void* k, const void* vt
 int utx_attn_fwd_bf16_kb(utx_ctx* ctx, const void* q, const void* k, const void* vt, void* o,
                          long q_hs, long q_ss, long k_hs, long k_ss, long vt_hs, long vt_ds, long o_ss,
                          int H, int S, float softmax_scale, float key_bias_log2, int key_bias_period, utx_stream stream);
-/* The same with FEWER QUERIES THAN KEYS: rows 0 .. S_q-1 of q are the queries (o gets S_q rows), keys / values are all S_kv tokens.  Used by
+/* The same with a QUERY COUNT OF ITS OWN: rows 0 .. S_q-1 of q are the queries (o gets S_q rows), keys / values are all S_kv tokens; q and k / vt are separate arrays and
+ * S_q may be smaller or (since round 6: the sequence-parallel launch over de-duplicated text keys, utx_sp_unpack_qkv_dedup) larger than S_kv.  S_q < S_kv is used by
  * the last transformer block: the pipeline discards the prediction of the condition tokens (flux_piplines/texturing/pipeline.py:645,660,684:
  * the condition tail of the latents is re-pinned before every transformer call and cut off at the end), so only the noise tokens need
  * a query in the block whose output nobody attends to any more (unitex_amd/flux/transformer.py, `set_output_rows`). */
@@ -272,10 +273,15 @@ int utx_qkv_post(utx_ctx* ctx, const utx_qkv_post_desc* d, utx_stream stream);
  * Both are pure 16-byte-vector copies (HBM-bound), one launch each; S = P * S_loc, S_loc % 64 == 0, E = S_loc * 128.
  *   utx_sp_unpack_qkv: recv [P src][3][Hp][E]  ->  q, k [Hp][S][128] (row = src*S_loc + tok),  vt [Hp][128][S]
  *                      (recv[src][0|1][hp] is [S_loc][128]; recv[src][2][hp] is [128][S_loc])
+ *   utx_sp_unpack_qkv_dedup: the same for q; k [Hp][S_k][128] and vt [Hp][128][S_k] with S_k = text_rows + P (S_loc - text_rows): the first text_rows tokens of
+ *                      EVERY source rank's block are the same rows (the caller's guarantee: the identical text tokens every rank carries, flux/transformer.py) and
+ *                      are kept ONCE, from source rank 0, followed by the other tokens of rank 0 .. P-1 -- the key order of the single-GPU sequence, so that a rank's
+ *                      attention launch (S_q = S queries over S_kv = S_k keys) is the single-GPU launch over H / P heads.  text_rows % 64 == 0, < S_loc
  *   utx_sp_unpack_o  : recv [P src][S_loc][Hp*128]  ->  out [S_loc][ld]: columns src*Hp*128 .. of row tok
  *   utx_sp_unpack_o_cols: the same for ONE head group of several (Hp = heads of the group): source rank src lands at column src * src_cols
  *                      of `out` (src_cols = all heads of a rank x 128; `out` points at the group's first column) */
 int utx_sp_unpack_qkv(utx_ctx* ctx, const void* recv, int P, int Hp, int S_loc, void* q, void* k, void* vt, utx_stream stream);
+int utx_sp_unpack_qkv_dedup(utx_ctx* ctx, const void* recv, int P, int Hp, int S_loc, int text_rows, void* q, void* k, void* vt, utx_stream stream);
 int utx_sp_unpack_o(utx_ctx* ctx, const void* recv, int P, int Hp, int S_loc, void* out, long ld, utx_stream stream);
 int utx_sp_unpack_o_cols(utx_ctx* ctx, const void* recv, int P, int Hp, int S_loc, void* out, long ld, long src_cols, utx_stream stream);
 

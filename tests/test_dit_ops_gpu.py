@@ -572,13 +572,22 @@ def _sp_worker(rank, world, port, q, zero_text=False, groups=1):
     lat = torch.randn(S_img, 64, generator=g).to(torch.bfloat16).cuda()
     enc = (0.5 * torch.randn(S_txt, 64, generator=g)).to(torch.bfloat16).cuda()
     pooled = (0.5 * torch.randn(1, 64, generator=g)).to(torch.bfloat16).cuda()
-    if zero_text:      # the reference's conditioning: identical text tokens -> every rank carries 64 of them, keys weighted 256 / 64-fold,
-        enc.zero_()    # one text tile at the start of every rank's chunk of the gathered key sequence (key_bias_period)
+    periodic = (zero_text == "periodic")      # UTX_SP_KV_DEDUP=0: every rank's text copy stays among the keys (round 2's form, what zero copy and fp8 attention run)
+    if periodic:
+        os.environ["UTX_SP_KV_DEDUP"] = "0"
+    if zero_text:      # the reference's conditioning: identical text tokens -> every rank carries 64 of them; round 6 default: the unpack keeps ONE copy among the keys
+        enc.zero_()    # (weight 256 world / 64); periodic / zero copy: one text tile at the start of every rank's chunk of the gathered key sequence (key_bias_period)
     txt_ids, img_ids = torch.zeros(S_txt, 3), R.latent_image_ids(8 * world, 24)
     m = FluxDiT(sd, shape, device="cuda:0", sequence_parallel=True)
     m.set_positions(txt_ids, img_ids)
     m.set_conditioning(enc, pooled, 3.5)
-    assert (m.text_rows == 64 and m.key_bias_period == (64 + 192) // 64 and abs(m.key_bias_log2 - 2.0) < 1e-6) if zero_text else (m.text_rows is None)
+    if not zero_text:
+        assert m.text_rows is None and not m.sp_kv_dedup and m.ex.S_k == m.ex.S
+    elif periodic or os.environ.get("UTX_SP_ZERO_COPY", "0") == "1":
+        assert m.text_rows == 64 and m.key_bias_period == (64 + 192) // 64 and abs(m.key_bias_log2 - 2.0) < 1e-6 and not m.sp_kv_dedup and m.ex.S_k == m.ex.S
+    else:
+        assert m.text_rows == 64 and m.sp_kv_dedup and m.key_bias_period == 0 and abs(m.key_bias_log2 - math.log2(4.0 * world)) < 1e-6
+        assert m.ex.kv_text_rows == 64 and m.ex.S == world * 256 and m.ex.S_k == 64 + world * 192 and m.ex.k.shape[1] == m.ex.S_k
     assert m.ex.G == groups and m.ex.Hg * groups * world == 4 and m.overlap_text      # two streams in the double blocks under sequence parallelism as well
     assert m.ex.zero_copy == (os.environ.get("UTX_SP_ZERO_COPY", "0") == "1")
     i0, i1 = m.local_image_range(S_img)
@@ -598,7 +607,8 @@ def _sp_worker(rank, world, port, q, zero_text=False, groups=1):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,zero_text,groups", [(2, False, 1), (2, True, 1), (2, False, 2), (2, True, 2), (4, True, 1), (4, False, 1), (2, True, -2), (4, True, -1)])
+@pytest.mark.parametrize("world,zero_text,groups", [(2, False, 1), (2, True, 1), (2, False, 2), (2, True, 2), (4, True, 1), (4, False, 1), (2, True, -2), (4, True, -1),
+                                                    (2, "periodic", 2), (4, "periodic", 1)])
 def test_sequence_parallel_two_ranks_match_unsharded_forward(world, zero_text, groups):
     """two processes share cuda:0 and exchange through gloo (host-staged all-to-all): the token-sharded /
     head-sharded FluxDiT plan -- real kernels, real slicing of ids / embeddings / latents -- against the plain forward.
@@ -619,6 +629,47 @@ def test_sequence_parallel_two_ranks_match_unsharded_forward(world, zero_text, g
         p.join(timeout=120)
         assert p.exitcode == 0
     assert err <= 0.02 * max(mx, 1.0), "sequence-parallel forward differs: %g (ref max %g, %.3f of elements differ)" % (err, mx, frac)
+
+
+@pytest.mark.parametrize("H,S_k,extra,kb", [(2, 1024, 64, 2.0), (3, 4096, 192, 3.0), (1, 640, 448, 0.0), (2, 1000, 88, 0.0)])
+def test_attention_more_queries_than_keys(H, S_k, extra, kb):
+    """S_q > S_kv (round 6: a sequence-parallel rank attends with ALL P x S_loc query rows over keys that carry the ranks' identical text rows once,
+    utx_sp_unpack_qkv_dedup): q and k / vt are separate arrays, nothing ties a query row to a key row.  Against the oracle softmax with the key weight on
+    tile 0, through both kernels (4 x 64 stream where it takes the shape, 8 x 32 loop), and row for row bit-identical to the S_q = S_kv launch."""
+    from unitex_amd import _lib
+    ops = _ops()
+    g = torch.Generator().manual_seed(S_k + extra)
+    S_q = S_k + extra
+    Sq_pad, Sk_pad = (S_q + 63) // 64 * 64, (S_k + 63) // 64 * 64
+    q = torch.randn(H, S_q, 128, generator=g).to(BF); k = torch.randn(H, S_k, 128, generator=g).to(BF); v = torch.randn(H, S_k, 128, generator=g).to(BF)
+    ref = torch.empty(H, S_q, 128)
+    for h in range(H):
+        sc = (q[h].float() @ k[h].float().t()) / math.sqrt(128.0)
+        sc[:, :64] += kb * math.log(2.0)
+        ref[h] = torch.softmax(sc, dim=-1) @ v[h].float()
+    Qh = torch.zeros(H, Sq_pad, 128, dtype=BF, device="cuda"); Qh[:, :S_q] = (q.float() * (1.4426950408889634 / math.sqrt(128.0))).to(BF).cuda()
+    Kh = torch.zeros(H, Sk_pad, 128, dtype=BF, device="cuda"); Kh[:, :S_k] = k.cuda()
+    Vt = torch.zeros(H, 128, Sk_pad, dtype=BF, device="cuda"); Vt[:, :, :S_k] = v.cuda().transpose(1, 2)
+    prev = _lib.get_options().get("UTX_ATTN_Q64", 1)
+    try:
+        for q64 in (1, 0):
+            _lib.set_option("UTX_ATTN_Q64", q64)
+            out = ops.attention(Qh, Kh, Vt, S=S_k, S_q=S_q, scale=0.0, key_bias_log2=kb)
+            same = ops.attention(Qh, Kh, Vt, S=S_k, S_q=S_k, scale=0.0, key_bias_log2=kb)
+            torch.cuda.synchronize()
+            assert out.shape == (S_q, H * 128) and torch.isfinite(out.float()).all()
+            err = (out.float().cpu().view(S_q, H, 128).permute(1, 0, 2) - ref).abs().max().item()
+            assert err < 3e-2, "S_q %d > S_kv %d: max-abs err %g (q64=%d)" % (S_q, S_k, err, q64)
+            assert torch.equal(out[:S_k].view(torch.int16), same.view(torch.int16)), "rows 0 .. S_kv-1 must not depend on the query count (q64=%d)" % q64
+    finally:
+        _lib.set_option("UTX_ATTN_Q64", prev)
+    # block-strided operands share their blocks between queries and keys: S_q > S_kv is refused there
+    ctx = ops.get_ctx(0)
+    import ctypes as C
+    rc = ctx.lib.utx_attn_fwd_bf16_blk(ctx.handle, C.c_void_p(Qh.data_ptr()), C.c_void_p(Kh.data_ptr()), C.c_void_p(Vt.data_ptr()), C.c_void_p(out.data_ptr()),
+                                       Qh.stride(0), 128, Kh.stride(0), 128, Vt.stride(0), Sk_pad, out.stride(0), H, Sk_pad + 64, Sk_pad, 0.0, 0.0, 0, None, 0,
+                                       64, 64 * 128, 64 * 128, 64, ctx.stream())
+    assert rc != 0
 
 
 def test_attention_running_max_keeps_growing():
@@ -956,6 +1007,19 @@ def test_sequence_parallel_relayout_kernels(P, Hp, S_loc):
     assert torch.equal(q.view(Hp, P, S_loc, 128), recv[:, 0].view(P, Hp, S_loc, 128).permute(1, 0, 2, 3))
     assert torch.equal(k.view(Hp, P, S_loc, 128), recv[:, 1].view(P, Hp, S_loc, 128).permute(1, 0, 2, 3))
     assert torch.equal(vt.view(Hp, 128, P, S_loc), recv[:, 2].view(P, Hp, 128, S_loc).permute(1, 2, 0, 3))
+    if S_loc > 64:      # round 6: the ranks' identical 64 leading rows kept ONCE among the keys (utx_sp_unpack_qkv_dedup): [text of src 0 | the other tokens of src 0 .. P-1]
+        T, I = 64, S_loc - 64
+        S_k = T + P * I
+        q2 = torch.full((Hp, S, 128), 7.0, dtype=BF, device="cuda"); k2 = torch.full((Hp, S_k, 128), 7.0, dtype=BF, device="cuda")
+        vt2 = torch.full((Hp, 128, S_k), 7.0, dtype=BF, device="cuda")
+        ctx.check(ctx.lib.utx_sp_unpack_qkv_dedup(ctx.handle, C.c_void_p(recv.data_ptr()), P, Hp, S_loc, T, C.c_void_p(q2.data_ptr()),
+                                                  C.c_void_p(k2.data_ptr()), C.c_void_p(vt2.data_ptr()), ctx.stream()))
+        rk, rv = recv[:, 1].view(P, Hp, S_loc, 128), recv[:, 2].view(P, Hp, 128, S_loc)
+        assert torch.equal(q2, q)
+        assert torch.equal(k2[:, :T], rk[0, :, :T]) and torch.equal(k2[:, T:].view(Hp, P, I, 128), rk[:, :, T:].permute(1, 0, 2, 3))
+        assert torch.equal(vt2[:, :, :T], rv[0, :, :, :T]) and torch.equal(vt2[:, :, T:].view(Hp, 128, P, I), rv[:, :, :, T:].permute(1, 2, 0, 3))
+        assert ctx.lib.utx_sp_unpack_qkv_dedup(ctx.handle, C.c_void_p(recv.data_ptr()), P, Hp, S_loc, 32, C.c_void_p(q2.data_ptr()),
+                                               C.c_void_p(k2.data_ptr()), C.c_void_p(vt2.data_ptr()), ctx.stream()) != 0, "text_rows must be whole 64-key tiles"
     W = Hp * 128
     orecv = torch.randn(P, S_loc, W, generator=g).to(BF).cuda()
     out = torch.zeros(S_loc, 5 * P * W, dtype=BF, device="cuda")                  # strided rows, like the single-block cat buffer

@@ -97,6 +97,39 @@ def _ulysses_worker(rank, world, port, q):
         out2 = torch.empty(own.numel(), H * 128)
         ex.tokens_out(out2)
         err = max(err, (out2 - ref).abs().max().item())
+    # round 6 -- every rank carries the SAME T text rows (the reference's identical text tokens, each key standing for w of them): the unpack keeps them once among the
+    # keys (kv_text_rows), a rank attends with S = P S_loc queries over S_k = T + P (S_loc - T) keys in the single-GPU key order, key weight on the first T keys only
+    import math
+    T, w = 64, 4.0
+
+    def sdpa_kw(qq, kk, vv):
+        o = torch.empty_like(qq)
+        for h in range(qq.shape[0]):
+            sc = (qq[h] @ kk[h].t()) / math.sqrt(128.0)
+            sc[:, :T] += math.log(w)
+            o[h] = torch.softmax(sc, dim=-1) @ vv[h]
+        return o
+    seq = torch.cat([torch.arange(0, T), S_txt + torch.arange(0, S_img)])             # the de-duplicated sequence: T text rows + every image row
+    ref_d = sdpa_kw(qf[:, seq], kf[:, seq], vf[:, seq])                                  # [H, T + S_img, 128]
+    own_d = torch.cat([torch.arange(0, T), S_txt + torch.arange(i0, i1)])              # this rank's tokens: the shared text rows + its image slice
+    ref_own = ref_d[:, torch.cat([torch.arange(0, T), T + torch.arange(i0, i1)])].permute(1, 0, 2).reshape(own_d.numel(), -1)
+    for G in [g for g in (1, 2, 3) if (H // world) % g == 0]:
+        ex = UlyssesExchange(H, own_d.numel(), device="cpu", dtype=torch.float32, head_groups=G, kv_text_rows=T)
+        assert ex.S == world * own_d.numel() and ex.S_k == T + S_img and ex.k.shape == (H // world, T + S_img, 128) and ex.vt.shape == (H // world, 128, T + S_img)
+        ex.pack(qf[:, own_d].contiguous(), kf[:, own_d].contiguous(), vf[:, own_d].transpose(1, 2).contiguous())
+        works = ex.start_heads_in()
+        out = torch.full((own_d.numel(), H * 128), float("nan"))
+        back = []
+        for g in range(G):
+            q_h, k_h, vt_h = ex.finish_heads_in_group(g, works[g])
+            # the keys ARE the single-GPU sequence, in its order
+            assert torch.equal(k_h, kf[rank * (H // world) + g * ex.Hg: rank * (H // world) + (g + 1) * ex.Hg][:, seq])
+            o = sdpa_kw(q_h, k_h, vt_h.transpose(1, 2))
+            ex.o[g].copy_(o.permute(1, 0, 2).reshape(ex.S, -1))
+            back.append(ex.start_tokens_out_group(g))
+        for g in range(G):
+            ex.finish_tokens_out_group(g, back[g], out)
+        err = max(err, (out - ref_own).abs().max().item())
     q.put((rank, err < 1e-5, err))
     dist.barrier()
     dist.destroy_process_group()

@@ -38,12 +38,13 @@ A_LO, A_HI = 128, 191
 S_KPTR, S_VPTR = 40, 42                                        # 64-bit: next K / V^T tile to request
 S_TK, S_KD, S_VD, S_KSTEP, S_VSTEP, S_TMP, S_CNT = 44, 45, 46, 47, 48, 49, 50
 S_POS, S_NEG, S_KWK, S_KWV, S_KDEND, S_VDEND = 51, 52, 53, 54, 55, 56
+S_ONES = S_KSTEP                                               # dot2 arm: the bf16 pair (1.0, 1.0); three tiles per trip step no address, so the register is free
 S_LO, S_HI = 40, 56
 TILE = 16384
 
 
 class Config:
-    def __init__(self, name, nslot=3, ahead=2, novm=False, nobar=False, noexp=False, nodma=False, unroll3=False, wait2=False, pkadd=False, m0once=False):
+    def __init__(self, name, nslot=3, ahead=2, novm=False, nobar=False, noexp=False, nodma=False, unroll3=False, wait2=False, pkadd=False, m0once=False, dot2=False, nosum=False, dot2c=False):
         self.name, self.nslot, self.ahead = name, nslot, ahead
         # unroll3: three tiles per loop trip -- ring slots are literals, every LDS address is a loop-invariant register + an immediate, no address steps, no slot bookkeeping;
         # nt % 3 tiles run through a second copy of the first two tile bodies behind the loop.  wait2: one counted lgkmcnt per TWO groups (needs read-ahead 3).
@@ -51,9 +52,15 @@ class Config:
         # m0once: ONE M0 write per four pieces -- an LDS-DMA's instruction offset moves its LDS address AND its global address (tools/glds_offset_probe.hip on the
         # hardware), so piece j carries offset:1024 j and the kernel hands over per-lane source offsets lowered by 1024 j (attention_q64.hip, AQ2_M0_ONCE)
         self.m0once = m0once
+        # dot2: the row sum of a lane's two keys of a group as ONE v_dot2_f32_bf16 over the packed pair PV consumes (P . (1, 1) + sum): one instruction instead of two adds per
+        # gap, one sum register per half, and l sums exactly the bf16 probabilities the PV MFMAs multiply.  NOT the 8 x 32 kernel's rounding (that one sums the fp32 P)
+        self.dot2 = dot2
+        self.dot2c = dot2c      # the dot2 arm with the 4-byte VOP2 form v_dot2c_f32_bf16 (sum zeroed by a v_mov at the head of the stage): encoding or execution unit?
+        self.nosum = nosum      # timing ablation: no row-sum instruction at all (wrong results): the bound of anything done about the row sums
         self.pkadd = pkadd      # the two row-sum adds of a gap as ONE v_pk_add_f32 (same two IEEE additions, one instruction to fetch and issue)
         assert not unroll3 or nslot == 3
         assert not wait2 or ahead == 3
+        assert not dot2 or unroll3
         self.novm, self.nobar, self.noexp, self.nodma = novm, nobar, noexp, nodma      # timing ablations (wrong results)
         assert nslot in (3, 4) and ahead in (2, 3)
         self.dk, self.dv = nslot, nslot - 1          # tile look-ahead of the DMA: K(t + dk), V(t + dv) are requested in trip t
@@ -180,6 +187,8 @@ def gen_prologue(st, cfg):
     st.ins("s_add_u32 %s, %%[ldsv], 0x%x" % (s(S_VDEND), N * TILE))
     st.ins("s_mov_b32 %s, %s" % (s(S_KSTEP), s(S_POS)))
     st.ins("s_mov_b32 %s, %s" % (s(S_VSTEP), s(S_POS)))
+    if cfg.dot2:
+        st.ins("s_mov_b32 %s, 0x3f803f80" % s(S_ONES))
     st.comment("---- Q fragments of both 32-query halves, straight into AGPRs (MFMA B operands only)")
     for h, (qp, base) in enumerate((("%[qp0]", Q0), ("%[qp1]", Q1))):
         for kk in range(8):
@@ -242,13 +251,17 @@ def gen_prologue(st, cfg):
         for r in range(16):
             st.ins("v_exp_f32 %s, %s" % (v(sa0 + r), v(sa0 + r)))
         ev, od = SUM[0][2 * h], SUM[0][2 * h + 1]
-        st.ins("v_mov_b32 %s, %s" % (v(ev), v(sa0)))
-        st.ins("v_mov_b32 %s, %s" % (v(od), v(sa0 + 1)))
-        for r in range(2, 16, 2):
-            st.ins("v_add_f32 %s, %s, %s" % (v(ev), v(ev), v(sa0 + r)))
-            st.ins("v_add_f32 %s, %s, %s" % (v(od), v(od), v(sa0 + r + 1)))
+        if not cfg.dot2:
+            st.ins("v_mov_b32 %s, %s" % (v(ev), v(sa0)))
+            st.ins("v_mov_b32 %s, %s" % (v(od), v(sa0 + 1)))
+            for r in range(2, 16, 2):
+                st.ins("v_add_f32 %s, %s, %s" % (v(ev), v(ev), v(sa0 + r)))
+                st.ins("v_add_f32 %s, %s, %s" % (v(od), v(od), v(sa0 + r + 1)))
         for i in range(8):
             st.ins("v_cvt_pk_bf16_f32 %s, %s, %s" % (v(PB[(0, h)] + i), v(sa0 + 2 * i), v(sa0 + 2 * i + 1)))
+        if cfg.dot2:
+            for i in range(8):
+                st.ins("v_dot2_f32_bf16 %s, %s, %s, %s" % (v(ev), v(PB[(0, h)] + i), s(S_ONES), "0" if i == 0 else v(ev)))
         for r in range(16):
             st.ins("v_xor_b32 %s, 0x80000000, %s" % (v(NEGM[h] + r), v(T0)))
         for r in range(16):
@@ -324,8 +337,11 @@ def gen_stage(st, cfg, G0, odd, j=0):
                 st.ins("s_add_u32 m0, %s, %d" % (s(S_KD), 1024 * g))
             else:
                 st.ins("s_add_u32 m0, %s, %d" % (s(S_VD), 1024 * (g - 4)))
-        ev0 = sums_p[0] if g == 0 else E[0]
-        od0 = sums_p[1] if g == 0 else E[1]
+        if cfg.dot2c and g == 0:
+            st.ins("v_mov_b32 %s, 0" % v(sums_p[0]))
+            st.ins("v_mov_b32 %s, 0" % v(sums_p[2]))
+        ev0 = sums_p[0] if (g == 0 and not cfg.dot2) else E[0]
+        od0 = sums_p[1] if (g == 0 and not cfg.dot2) else E[1]
         st.ins("%s %s, %s" % (EXP, v(ev0), v(SA[(p, 0)] + 2 * g)))
         st.ins("%s %s, %s" % (EXP, v(od0), v(SA[(p, 0)] + 2 * g + 1)))
         if not odd and not cfg.nodma:
@@ -336,8 +352,8 @@ def gen_stage(st, cfg, G0, odd, j=0):
                 st.ins("global_load_lds_dwordx4 %%[vo%d], %s%s" % (g - 4, s(S_VPTR, 2), off))
         # ---- QK^T, half 1
         st.mfma(v(SA[(q, 1)], 16), v(KF[G % 4], 4), a(Q1 + 4 * g, 4), v(NEGM[1], 16) if g == 0 else v(SA[(q, 1)], 16))
-        ev1 = sums_p[2] if g == 0 else E[2]
-        od1 = sums_p[3] if g == 0 else E[3]
+        ev1 = sums_p[2] if (g == 0 and not cfg.dot2) else E[2]
+        od1 = sums_p[3] if (g == 0 and not cfg.dot2) else E[3]
         st.ins("%s %s, %s" % (EXP, v(ev1), v(SA[(p, 1)] + 2 * g)))
         st.ins("%s %s, %s" % (EXP, v(od1), v(SA[(p, 1)] + 2 * g + 1)))
         gt = g + A                 # the group AHEAD groups on, in this stage or the next
@@ -353,9 +369,14 @@ def gen_stage(st, cfg, G0, odd, j=0):
                 st.ins("s_cselect_b32 %s, %s, %s" % (s(S_KSTEP), s(S_NEG), s(S_POS)))
         # ---- PV, half 0
         st.mfma("%%[o0%d]" % (g & 3), v(VF[G % 4], 4), v(PB[(q, 0)] + 4 * (g >> 2), 4), "%%[o0%d]" % (g & 3))
-        if g == 0:   # the row sums of the previous stage's block are final: l += ps (block order), headroom record
+        if cfg.dot2:
+            if g == 0:
+                st.ins("v_add_f32 %[l0], %[l0], " + v(sums_q[0]))
+        elif g == 0:   # the row sums of the previous stage's block are final: l += ps (block order), headroom record
             st.ins("v_add_f32 %s, %s, %s" % (v(PS0), v(sums_q[0]), v(sums_q[1])))
             st.ins("v_add_f32 %[l0], %[l0], " + v(PS0))
+        elif cfg.nosum:
+            pass
         elif cfg.pkadd:
             st.ins("v_pk_add_f32 %s, %s, %s" % (v(sums_p[0], 2), v(sums_p[0], 2), v(E[0], 2)))
         else:
@@ -363,18 +384,34 @@ def gen_stage(st, cfg, G0, odd, j=0):
             st.ins("v_add_f32 %s, %s, %s" % (v(sums_p[1]), v(sums_p[1]), v(E[1])))
         st.ins("v_cvt_pk_bf16_f32 %s, %s, %s" % (v(PB[(p, 0)] + g), v(ev0), v(od0)))
         v_read(st, cfg, ("V", G + A), (G + A) % 4, tgt_odd, gt % 8, jt)
+        if cfg.dot2:
+            if cfg.dot2c:
+                st.ins("v_dot2c_f32_bf16 %s, %s, %s" % (v(sums_p[0]), s(S_ONES), v(PB[(p, 0)] + g)))
+            else:
+                st.ins("v_dot2_f32_bf16 %s, %s, %s, %s" % (v(sums_p[0]), v(PB[(p, 0)] + g), s(S_ONES), "0" if g == 0 else v(sums_p[0])))
         # ---- PV, half 1
         st.mfma("%%[o1%d]" % (g & 3), v(VF[G % 4], 4), v(PB[(q, 1)] + 4 * (g >> 2), 4), "%%[o1%d]" % (g & 3))
-        if g == 0:
+        if cfg.dot2:
+            if g == 0:
+                st.ins("v_add_f32 %[l1], %[l1], " + v(sums_q[2]))
+                st.ins("v_max3_f32 %%[psmax], %%[psmax], %s, %s" % (v(sums_q[0]), v(sums_q[2])))
+        elif g == 0:
             st.ins("v_add_f32 %s, %s, %s" % (v(PS1), v(sums_q[2]), v(sums_q[3])))
             st.ins("v_add_f32 %[l1], %[l1], " + v(PS1))
             st.ins("v_max3_f32 %%[psmax], %%[psmax], %s, %s" % (v(PS0), v(PS1)))
+        elif cfg.nosum:
+            pass
         elif cfg.pkadd:
             st.ins("v_pk_add_f32 %s, %s, %s" % (v(sums_p[2], 2), v(sums_p[2], 2), v(E[2], 2)))
         else:
             st.ins("v_add_f32 %s, %s, %s" % (v(sums_p[2]), v(sums_p[2]), v(E[2])))
             st.ins("v_add_f32 %s, %s, %s" % (v(sums_p[3]), v(sums_p[3]), v(E[3])))
         st.ins("v_cvt_pk_bf16_f32 %s, %s, %s" % (v(PB[(p, 1)] + g), v(ev1), v(od1)))
+        if cfg.dot2:
+            if cfg.dot2c:
+                st.ins("v_dot2c_f32_bf16 %s, %s, %s" % (v(sums_p[2]), s(S_ONES), v(PB[(p, 1)] + g)))
+            else:
+                st.ins("v_dot2_f32_bf16 %s, %s, %s, %s" % (v(sums_p[2]), v(PB[(p, 1)] + g), s(S_ONES), "0" if g == 0 else v(sums_p[2])))
 
 
 def gen_tile(st, cfg, G0, j):
@@ -444,8 +481,14 @@ DEFAULT = Config("default", unroll3=True, ahead=3, wait2=True)
 #   ring4 / read-ahead 3 alone / no vmcnt / no barrier: equal to tile1 within 0.4 %  -- the loop is not waiting for anything; it is POWER-bound (time = energy / cap)
 #   m0 (one M0 write per four pieces: -6 SALU per tile) = default      pk (row sums as v_pk_add_f32: -32 instructions per tile) 1294 / 1321: packed fp32 beside MFMAs LOSES 10 %
 #   abl_noexp +5.7 %, abl_nodma +4.6 % over tile1: what the exponentials and the L2 -> LDS traffic cost
+#   dot2 / dot2c (row sums as ONE v_dot2_f32_bf16 / v_dot2c_f32_bf16 over the packed pair PV consumes: -32 instructions per tile, accuracy against fp64 equal or better)  1297 / 1332 and 1292 / 1320
+#   against 1391 / 1424 for the default in the same process: -7 %, and in CYCLES (3.25 -> 4.06e7 per CU, matrix pipe 89 -> 71 % busy at a clock that rises 1.51 -> 1.74 GHz): a VOP3P / dot
+#   instruction does not issue in an MFMA's shadow on gfx950 (~17 cycles each), like v_pk_add_f32.  abl_nosum (no row-sum instruction at all) +2.2 %: the bound of anything done about the sums
+#   (profiles/r06_attn_q64_arms_v5.log, r06_attn_pmc_arms_rowsum.log, r06_attn_q64_dot2_accuracy.log)
 VARIANTS = [Config("tile1"), Config("ring4", nslot=4), Config("m0", unroll3=True, ahead=3, wait2=True, m0once=True), Config("pk", unroll3=True, ahead=3, wait2=True, pkadd=True),
-            Config("abl_novm", novm=True), Config("abl_nobar", novm=True, nobar=True), Config("abl_noexp", noexp=True), Config("abl_nodma", nodma=True, novm=True)]
+            Config("abl_novm", novm=True), Config("abl_nobar", novm=True, nobar=True), Config("abl_noexp", noexp=True), Config("abl_nodma", nodma=True, novm=True),
+            Config("dot2", unroll3=True, ahead=3, wait2=True, dot2=True), Config("abl_nosum", unroll3=True, ahead=3, wait2=True, nosum=True),
+            Config("dot2c", unroll3=True, ahead=3, wait2=True, dot2=True, dot2c=True)]
 
 
 def write_text(f, macro, st):

@@ -164,6 +164,7 @@ SYMBOLS = {
     "utx_conv3x3_thin": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "utx_qkv_post": (c_int, [c_void_p, C.POINTER(QkvPostDesc), c_void_p]),
     "utx_sp_unpack_qkv": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "utx_sp_unpack_qkv_dedup": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "utx_sp_unpack_o": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_long, c_void_p]),
     "utx_sp_unpack_o_cols": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_long, c_long, c_void_p]),
     "utx_ln_mod": (c_int, [c_void_p, C.POINTER(LnModDesc), c_void_p]),

@@ -432,7 +432,9 @@ extern "C" int utx_launch_attn_fwd_blk(const void* q, const void* k, const void*
                                        long q_hs, long q_ss, long k_hs, long k_ss, long vt_hs, long vt_ds,
                                        long o_ss, int H, int S, int Sq, float scale, float key_bias_log2, int key_bias_period, void* work, size_t work_bytes,
                                        int blk_rows, long q_bs, long k_bs, long vt_bs, hipStream_t stream) {
-    if (S <= 0 || H <= 0 || scale < 0.f || key_bias_period < 0 || Sq < 0 || Sq > S || blk_rows < 0) return -1;
+    // Sq > S is a plain case (round 6): queries and keys are separate arrays and nothing ties a query row to a key row -- the sequence-parallel launch whose keys carry the
+    // ranks' identical text rows once (utx_sp_unpack_qkv_dedup) has P x 64 - 64 more queries than keys.  Block-strided operands share their blocks: Sq <= S there.
+    if (S <= 0 || H <= 0 || scale < 0.f || key_bias_period < 0 || Sq < 0 || (Sq > S && blk_rows > 0) || blk_rows < 0) return -1;
     if (Sq == S) Sq = 0;
     if ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)vt)) & 15) return -2;                       // 16-byte aligned bases (LDS-DMA / b128 loads)
     if ((vt_ds & 7) || (q_ss & 7) || (k_ss & 7) || (o_ss & 3) || (q_hs & 7) || (k_hs & 7) || (vt_hs & 7)) return -2;   // 16-byte rows

@@ -173,7 +173,7 @@ int utx_attn_fwd_bf16_kbq(utx_ctx* ctx, const void* q, const void* k, const void
                           long q_hs, long q_ss, long k_hs, long k_ss, long vt_hs, long vt_ds, long o_ss,
                           int H, int S_q, int S_kv, float softmax_scale, float key_bias_log2, int key_bias_period, utx_stream stream) {
     if (!q || !k || !vt || !o) return fail(ctx, -2, "utx_attn_fwd_bf16_kbq");
-    size_t wsb = 0; void* const ws = (S_q > 0 && S_q <= S_kv) ? ctx_attn_ws(ctx, H, S_q, S_kv, (hipStream_t)stream, &wsb) : nullptr;
+    size_t wsb = 0; void* const ws = (S_q > 0) ? ctx_attn_ws(ctx, H, S_q, S_kv, (hipStream_t)stream, &wsb) : nullptr;
     UTX_CALL(ctx, "utx_attn_fwd_bf16_kbq",
              utx_launch_attn_fwd(q, k, vt, o, q_hs, q_ss, k_hs, k_ss, vt_hs, vt_ds, o_ss, H, S_kv, S_q,
                                  softmax_scale, key_bias_log2, key_bias_period, ws, wsb, (hipStream_t)stream));
@@ -297,7 +297,12 @@ int utx_qkv_post(utx_ctx* ctx, const utx_qkv_post_desc* d, utx_stream stream) {
 
 int utx_sp_unpack_qkv(utx_ctx* ctx, const void* recv, int P, int Hp, int S_loc, void* q, void* k, void* vt, utx_stream stream) {
     if (!recv || !q || !k || !vt) return fail(ctx, -2, "utx_sp_unpack_qkv");
-    UTX_CALL(ctx, "utx_sp_unpack_qkv", utx_launch_sp_unpack_qkv(recv, P, Hp, S_loc, q, k, vt, (hipStream_t)stream));
+    UTX_CALL(ctx, "utx_sp_unpack_qkv", utx_launch_sp_unpack_qkv(recv, P, Hp, S_loc, 0, q, k, vt, (hipStream_t)stream));
+}
+
+int utx_sp_unpack_qkv_dedup(utx_ctx* ctx, const void* recv, int P, int Hp, int S_loc, int text_rows, void* q, void* k, void* vt, utx_stream stream) {
+    if (!recv || !q || !k || !vt) return fail(ctx, -2, "utx_sp_unpack_qkv_dedup");
+    UTX_CALL(ctx, "utx_sp_unpack_qkv_dedup", utx_launch_sp_unpack_qkv(recv, P, Hp, S_loc, text_rows, q, k, vt, (hipStream_t)stream));
 }
 
 int utx_sp_unpack_o(utx_ctx* ctx, const void* recv, int P, int Hp, int S_loc, void* out, long ld, utx_stream stream) {

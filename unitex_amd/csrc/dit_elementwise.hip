@@ -197,10 +197,16 @@ extern "C" int utx_launch_quant_mx8_packed(const void* x, long ldx, void* q, lon
 // Sequence-parallel exchange, receive side (unitex_hip.h: utx_sp_unpack_qkv / utx_sp_unpack_o): relayout of what the
 // all-to-all delivered into the attention kernel's / the out-projection's operand layouts.  Pure copies: one 16-byte vector
 // per thread and step, sources and destinations in runs of >= 128 B (S_loc % 64 == 0), grid-stride.
-__global__ __launch_bounds__(256) void sp_unpack_qkv_kernel(const uint4* __restrict__ recv, int P, int Hp, int S_loc, uint4* __restrict__ q,
+// text_rows > 0 ("key de-duplication across ranks", round 6): the caller guarantees that the first text_rows tokens of EVERY source rank's block are the same rows (the
+// identical text tokens every rank carries, flux/transformer.py) -- K and V^T keep them once, from source rank 0, followed by the image tokens of rank 0 .. P-1:
+// S_k = text_rows + P (S_loc - text_rows) keys in exactly the single-GPU order, so the rank's attention launch is the single-GPU launch (key multiplicity on tile 0
+// only: the 4 x 64 kernel takes it) over H / P heads.  Q keeps every row (each rank wants its own rows back).
+__global__ __launch_bounds__(256) void sp_unpack_qkv_kernel(const uint4* __restrict__ recv, int P, int Hp, int S_loc, int text_rows, uint4* __restrict__ q,
                                                             uint4* __restrict__ k, uint4* __restrict__ vt) {
     const long Ev = (long)S_loc * 16;                 // 16-byte vectors per (src, which, head) block: S_loc * 128 * 2 B / 16
     const long S = (long)P * S_loc;
+    const long I = S_loc - text_rows;                 // tokens of a rank behind the shared text rows
+    const long Sk = text_rows + (long)P * I;          // keys kept (== S when text_rows == 0)
     const long total = 3L * P * Hp * Ev;
     const long slv = S_loc / 8;                       // vectors per V^T row segment
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -209,13 +215,16 @@ __global__ __launch_bounds__(256) void sp_unpack_qkv_kernel(const uint4* __restr
         const int hp = (int)(b % Hp); b /= Hp;
         const int which = (int)(b % 3);
         const int src = (int)(b / 3);
-        const uint4 v = recv[i];
-        if (which < 2) {
-            uint4* dst = which ? k : q;
-            dst[((long)hp * S + (long)src * S_loc) * 16 + e] = v;          // [hp][src*S_loc + tok][128]
+        if (which == 0) {
+            q[((long)hp * S + (long)src * S_loc) * 16 + e] = recv[i];     // [hp][src*S_loc + tok][128]
+        } else if (which == 1) {
+            const long tok = e >> 4;
+            if (tok < text_rows) { if (src == 0) k[((long)hp * Sk + tok) * 16 + (e & 15)] = recv[i]; }
+            else k[((long)hp * Sk + text_rows + (long)src * I + (tok - text_rows)) * 16 + (e & 15)] = recv[i];      // [hp][text | img of src 0 | img of src 1 ...][128]
         } else {
-            const long d = e / slv, t8 = e - d * slv;
-            vt[((long)hp * 128 + d) * (S / 8) + (long)src * slv + t8] = v;  // [hp][d][src*S_loc + tok]
+            const long d = e / slv, t8 = e - d * slv;                       // eight tokens t8 * 8 .. of channel d
+            if (t8 * 8 < text_rows) { if (src == 0) vt[((long)hp * 128 + d) * (Sk / 8) + t8] = recv[i]; }
+            else vt[((long)hp * 128 + d) * (Sk / 8) + (text_rows + (long)src * I) / 8 + (t8 - text_rows / 8)] = recv[i];   // [hp][d][same key order]
         }
     }
 }
@@ -232,12 +241,12 @@ __global__ __launch_bounds__(256) void sp_unpack_o_kernel(const uint4* __restric
     }
 }
 
-extern "C" int utx_launch_sp_unpack_qkv(const void* recv, int P, int Hp, int S_loc, void* q, void* k, void* vt, hipStream_t stream) {
-    if (P <= 0 || Hp <= 0 || S_loc <= 0 || (S_loc & 63)) return -2;
+extern "C" int utx_launch_sp_unpack_qkv(const void* recv, int P, int Hp, int S_loc, int text_rows, void* q, void* k, void* vt, hipStream_t stream) {
+    if (P <= 0 || Hp <= 0 || S_loc <= 0 || (S_loc & 63) || text_rows < 0 || text_rows >= S_loc || (text_rows & 63)) return -2;
     if ((((uintptr_t)recv) | ((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)vt)) & 15) return -2;
     const long total = 3L * P * Hp * S_loc * 16;
     long blocks = (total + 255) / 256; if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(sp_unpack_qkv_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const uint4*)recv, P, Hp, S_loc, (uint4*)q, (uint4*)k, (uint4*)vt);
+    hipLaunchKernelGGL(sp_unpack_qkv_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const uint4*)recv, P, Hp, S_loc, text_rows, (uint4*)q, (uint4*)k, (uint4*)vt);
     return hipGetLastError() == hipSuccess ? 0 : -4;
 }
 

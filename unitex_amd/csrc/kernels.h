@@ -118,7 +118,7 @@ int utx_launch_gemv_bf16(const GemvParams* p, hipStream_t stream);
 int utx_launch_quant_mx8(const void* x, long ldx, void* q, long ldq, void* s, long lds, int M, int K, hipStream_t stream);
 int utx_launch_quant_mx8_packed(const void* x, long ldx, void* q, long ldq, void* s, long row_blocks, int M, int K, hipStream_t stream);
 int utx_launch_qkv_post(const QkvPostParams* p, hipStream_t stream);
-int utx_launch_sp_unpack_qkv(const void* recv, int P, int Hp, int S_loc, void* q, void* k, void* vt, hipStream_t stream);
+int utx_launch_sp_unpack_qkv(const void* recv, int P, int Hp, int S_loc, int text_rows, void* q, void* k, void* vt, hipStream_t stream);
 int utx_launch_sp_unpack_o(const void* recv, int P, int Hp, int S_loc, void* out, long ld, long src_cols, hipStream_t stream);
 size_t utx_group_norm_workspace_bytes_impl(void);
 int utx_launch_group_norm(const void* x, long npix, int C, const void* gamma, const void* beta, float eps, int silu, void* y, void* work, hipStream_t stream);

@@ -1,8 +1,8 @@
 """Arithmetic model of ONE denoise step under head-parallel sequence parallelism (flux/ulysses.py) on an xGMI node -- what the first
 multi-GPU SCALE run is to be compared with.  Pure host arithmetic, no device.
 
-Inputs that are MEASURED on one MI355X (bench.py; round 3: profiles/r03_bench_strip1024x6_v1.json.log, S = 50 688 tokens, 57 layers; the DEFAULTS are round 5's, MEASURED_1GPU below:
-step 1909.0 ms = 57 x 23.58 + 497 + the rest -> predicted 1.83 x / 3.53 x / 6.99 x, steps 1043 / 541 / 273 ms):
+Inputs that are MEASURED on one MI355X (bench.py; round 3: profiles/r03_bench_strip1024x6_v1.json.log, S = 50 688 tokens, 57 layers; the DEFAULTS are round 6's, MEASURED_1GPU below:
+step 1777.0 ms = 57 x 21.16 + 524.7 + the rest; `python -m unitex_amd.flux.sp_model` prints the predicted table):
     step 1998.9 ms = attention 57 x 25.47 ms (utx_attn_fwd_bf16) + large-M GEMMs 515.4 ms (roofline_gemm.sum_ms_per_step)
                      + 31.7 ms of everything else (LayerNorm-modulation, q/k post-processing, text-side GEMMs, GEMVs, launch gaps)
 Inputs that are ASSUMED (the fabric has never been measured by this repo -- no multi-GPU box in reach):
@@ -32,7 +32,12 @@ MEASURED_1GPU_R03 = dict(step_ms=1998.9, attn_ms_per_layer=25.47, gemm_ms_per_st
 # ROUND 5 (profiles/r05_bench_strip1024x6_v2.json.log, r05_attn_kbp_ab_v2.log): step 1909.0 ms = attention 57 x 23.58 ms (the fast loop, two tiles per trip) + GEMMs 497 ms + the rest.
 # Under sequence parallelism the launches carry periodic key multiplicity and run the fast loop's KBP instance (the same two-tile loop over the runs of ordinary tiles, key-multiplicity
 # tiles through a copy of their own): 1335 / 1337 TF/s at the 4- / 8-rank per-rank shapes against 1330 for the plain instance on the same box -> no extra factor.
-MEASURED_1GPU = MEASURED_1GPU_R05 = dict(step_ms=1909.0, attn_ms_per_layer=23.58, gemm_ms_per_step=497.0, replicated_ms=1.5, sp_unpack_ms_per_step=27.6, attn_corun_factor=1.013)
+MEASURED_1GPU_R05 = dict(step_ms=1909.0, attn_ms_per_layer=23.58, gemm_ms_per_step=497.0, replicated_ms=1.5, sp_unpack_ms_per_step=27.6, attn_corun_factor=1.013)
+# ROUND 6 (profiles/r06_bench_strip1024x6_v1.json.log): step 1777.0 ms = attention 57 x 21.16 ms (the 4 x 64 generated stream) + GEMMs 524.7 ms + the rest.  The sequence-parallel
+# launches run the SAME kernel since the receive-side unpack keeps the ranks' identical text rows once among the keys (ulysses.py kv_text_rows: S_q = P S_loc queries over the
+# single-GPU key sequence, key multiplicity on tile 0 only): 1406 / 1377 / 1413 TF/s for the head-group launches of 2 / 4 / 8 ranks against 1278 / 1253 / 1275 for the
+# periodic-multiplicity form on the 8 x 32 KBP loop, same process (profiles/r06_attn_sp_dedup_ab.log) -- queries grow with P, keys do not (kv_dedup below).
+MEASURED_1GPU = MEASURED_1GPU_R06 = dict(step_ms=1777.0, attn_ms_per_layer=21.16, gemm_ms_per_step=524.7, replicated_ms=1.5, sp_unpack_ms_per_step=27.6, attn_corun_factor=1.013)
 # the large-M GEMMs lose efficiency as M = S / P shrinks (fewer rounds of 256 x 256 tiles per launch, a larger share of fill / epilogue): bf16 TF/s at
 # M = 13 824 vs 50 688 on the FLUX shapes, same process (profiles/r03_perf_fp8_v0.log, bf16 column): 1224 / 1360, 1326 / 1292, 1241 / 1337 -> ~0.93 at a
 # quarter of the rows; 0.97 at half and 0.85 at an eighth are interpolated / extrapolated, not measured
@@ -60,9 +65,10 @@ def attention_round_factor(P, S, n_cus=256, groups=1, plan=None):
     return groups * rounds(Hg) / (rounds(HEADS) / P)
 
 
-def predict(P, S=50240, groups=None, measured=None, xgmi=None, plan=None, n_cus=256):
+def predict(P, S=50240, groups=None, measured=None, xgmi=None, plan=None, n_cus=256, kv_dedup=True):
     """predicted step time and speed-up on P ranks.  S = executed tokens of the single-GPU run (text de-duplication: 64 + 50 176); under P ranks every
-    rank carries its own 64 text rows.  groups: head groups per rank (None: ulysses.pick_head_groups).  Returns a dict with the breakdown."""
+    rank carries its own 64 text rows.  groups: head groups per rank (None: ulysses.pick_head_groups).  kv_dedup (the default since round 6): the ranks' text rows are kept once
+    among the keys -- the query count grows with P, the key count does not (False: round 2's periodic form, both grow).  Returns a dict with the breakdown."""
     from .ulysses import pick_head_groups
     m = dict(MEASURED_1GPU, **(measured or {}))
     x = dict(XGMI, **(xgmi or {}))
@@ -76,7 +82,7 @@ def predict(P, S=50240, groups=None, measured=None, xgmi=None, plan=None, n_cus=
     t_in = exchange_bytes_per_peer(S_loc, P) / link * 1e3            # ms; every peer pair on its own link, all at once
     t_out = t_in / 3.0
     grow = S_all / float(S)                                          # the extra text rows
-    t_attn = m["attn_ms_per_layer"] / P * grow * grow * attention_round_factor(P, S_all, n_cus, G, plan) * m["attn_corun_factor"]
+    t_attn = m["attn_ms_per_layer"] / P * grow * (1.0 if kv_dedup else grow) * attention_round_factor(P, S_all, n_cus, G, plan) * m["attn_corun_factor"]
     other_ms = m["step_ms"] - LAYERS * m["attn_ms_per_layer"] - m["gemm_ms_per_step"] - m["replicated_ms"]
     t_gemm_layer = m["gemm_ms_per_step"] / LAYERS / P * grow / GEMM_EFFICIENCY.get(P, 0.85)
     t_other_layer = (other_ms + m["sp_unpack_ms_per_step"]) / LAYERS / P * grow      # + the relayout kernels of the two exchanges

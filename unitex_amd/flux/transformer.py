@@ -132,6 +132,7 @@ class FluxDiT:
         self.fp8_attention = bool(fp8_attention)
         self.text_dedup = os.environ.get("UTX_TEXT_DEDUP", "1") != "0"
         self.key_bias_log2, self.key_bias_period, self.text_rows = 0.0, 0, None
+        self.sp_kv_dedup = False
         self._ids = None
         self._pack(state_dict)
 
@@ -527,7 +528,8 @@ class FluxDiT:
             if S_pad != S:
                 raise ValueError("sequence parallel: the local token count %d must be a multiple of 64" % S)
             self.ex = UlyssesExchange(H, S, group=self.sp[2], device=dev, dtype=BF16, ctx=self.ctx,
-                                      n_cus=torch.cuda.get_device_properties(dev).multi_processor_count)
+                                      n_cus=torch.cuda.get_device_properties(dev).multi_processor_count,
+                                      kv_text_rows=(S_txt if getattr(self, "sp_kv_dedup", False) else 0))
             if self.fp8_attention:      # MX operands of ONE head group (the groups' attentions are ordered on the stream): Hg heads x the full sequence
                 ex, u8 = self.ex, torch.uint8
                 if ex.zero_copy:
@@ -839,19 +841,23 @@ class FluxDiT:
         K = self.TEXT_KEEP
         identical = bool(self.text_dedup and S_txt > K * world and S_txt % (K * world) == 0 and
                          torch.equal(txt_ids, txt_ids[:1].expand_as(txt_ids)) and torch.equal(enc, enc[:1].expand_as(enc)))
+        # sequence parallel, identical text rows: every rank carries its own K copies.  Default (round 6): the receive-side unpack keeps ONE copy of them in K / V^T
+        # (ulysses.py kv_text_rows) -- a rank's attention launch is then the single-GPU launch (S_txt / K-fold keys in tile 0 only: the 4 x 64 kernel) over its heads.
+        # The zero-copy exchange and the fp8 attention read every rank's copy: a text tile at the start of every rank's block of the gathered key sequence
+        # (keys ordered (source rank, local token)), each key counting S_txt / (K world)-fold (key_bias_period).  UTX_SP_KV_DEDUP=0 forces that form (A/B, tests).
+        self.sp_kv_dedup = bool(identical and world > 1 and not self.fp8_attention and os.environ.get("UTX_SP_ZERO_COPY", "0") != "1" and
+                                os.environ.get("UTX_SP_KV_DEDUP", "1") != "0")
         if identical:
-            # every rank carries its own K copies; all keys of a text tile count S_txt / (K * world)-fold
             t0, t1 = 0, K
-            self.key_bias_log2 = math.log2(S_txt / float(K * world))
+            self.key_bias_log2 = math.log2(S_txt / float(K * (1 if self.sp_kv_dedup else world)))
             self.text_rows = K
         else:
             t0, t1 = self.local_text_range(S_txt)
             self.key_bias_log2, self.text_rows = 0.0, None
         i0, i1 = self.local_image_range(img_ids.shape[0])
         S_loc = (t1 - t0) + (i1 - i0)
-        # text tiles recur once per rank in the gathered key sequence (keys ordered (source rank, local token))
-        self.key_bias_period = (S_loc // 64) if (identical and world > 1) else 0
-        key = (t1 - t0, i1 - i0, self._lora_version, self.key_bias_log2, self.key_bias_period, self.out_rows)
+        self.key_bias_period = (S_loc // 64) if (identical and world > 1 and not self.sp_kv_dedup) else 0
+        key = (t1 - t0, i1 - i0, self._lora_version, self.key_bias_log2, self.key_bias_period, self.out_rows, self.sp_kv_dedup)
         if key not in self._plans:
             self._drop_plans()   # one live plan: workspaces are large
             self._plans[key] = self._build(t1 - t0, i1 - i0)
@@ -966,7 +972,7 @@ class FluxDiT:
             ex = self.ex
             works, self._sp_work = self._sp_work, None
             ev = getattr(self, "attn_events", None)
-            wk = self._attn_work(ws, ex.Hg, ex.S, ex.S)
+            wk = self._attn_work(ws, ex.Hg, ex.S, ex.S_k)      # S queries over S_k keys (S_k < S: the ranks' identical text rows kept once)
             back = []
             for g in range(ex.G):
                 hd = ex.finish_heads_in_group(g, None if works is None else works[g])
@@ -992,7 +998,7 @@ class FluxDiT:
                 else:
                     q, k, vt = hd
                     rc = lib.utx_attn_fwd_bf16_ws(h, ptr(q), ptr(k), ptr(vt), ptr(og), q.stride(0), q.stride(1), k.stride(0), k.stride(1),
-                                                  vt.stride(0), vt.stride(1), og.stride(0), ex.Hg, ex.S, ex.S, 0.0, float(self.key_bias_log2),
+                                                  vt.stride(0), vt.stride(1), og.stride(0), ex.Hg, ex.S, ex.S_k, 0.0, float(self.key_bias_log2),
                                                   int(self.key_bias_period), ptr(wk), 0 if wk is None else wk.numel(), st)
                 if ev is not None:
                     b.record()

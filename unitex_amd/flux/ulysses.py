@@ -34,6 +34,11 @@ Data movement per layer and rank (GPU path):
     all-to-all ONE HIP copy kernel (`utx_sp_unpack_o_cols`) interleaves the P column blocks into the consumer's rows.
 The gathered key order is (source rank, local token); attention is invariant to the key order and the query order is undone by
 the return exchange, so the result equals the unsharded computation up to fp32 summation order inside the kernel.
+Round 6 -- `kv_text_rows` = T > 0 (the transformer's default when every rank carries the same T identical text rows): the unpack keeps those
+rows ONCE in K / V^T (from source rank 0) followed by the ranks' other tokens in rank order: S_k = T + P (S_loc - T) keys in exactly the
+single-GPU key order, so a rank's attention launch is the single-GPU launch (key multiplicity on tile 0 only -- the 4 x 64 kernel takes it,
++10 % over the 8 x 32 loop the periodic-multiplicity launches ran) over H / P heads, S = P S_loc queries over S_k keys, and its rows are
+bit-identical to the single-GPU attention's.
 Per rank and layer 4 * S_loc * D * 2 B cross the fabric ((P-1)/P of it off-chip): 156 MB at S = 50 688, P = 8.
 Constraints: H % P == 0 and the local token count is a multiple of 64 (no padded keys inside the gathered sequence).
 
@@ -65,7 +70,7 @@ def pick_head_groups(Hp, S, n_cus=256, max_groups=4):
 
 
 class UlyssesExchange:
-    def __init__(self, H, S_loc, group=None, device="cpu", dtype=torch.bfloat16, ctx=None, head_groups=None, n_cus=256):
+    def __init__(self, H, S_loc, group=None, device="cpu", dtype=torch.bfloat16, ctx=None, head_groups=None, n_cus=256, kv_text_rows=0):
         self.group = group
         self.P = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -75,6 +80,11 @@ class UlyssesExchange:
         if S_loc % 64:
             raise ValueError("local token count %d must be a multiple of 64" % S_loc)
         self.H, self.Hp, self.S_loc, self.S = H, H // P, S_loc, S_loc * P
+        # keys kept by the unpack: all of them, or the ranks' identical leading text rows once + everything else (module docstring, round 6)
+        self.kv_text_rows = int(kv_text_rows)
+        if self.kv_text_rows and (self.kv_text_rows % 64 or not 0 < self.kv_text_rows < S_loc):
+            raise ValueError("kv_text_rows = %d must be a multiple of 64 below the local token count %d" % (self.kv_text_rows, S_loc))
+        self.S_k = self.kv_text_rows + P * (S_loc - self.kv_text_rows)
         self.G = int(head_groups) if head_groups else pick_head_groups(self.Hp, self.S, n_cus)
         if self.Hp % self.G:
             raise ValueError("%d head groups do not divide the %d heads of a rank" % (self.G, self.Hp))
@@ -103,6 +113,8 @@ class UlyssesExchange:
         # 2 / 4 / 8 blocks (+0.6 % with one block: the cursor arithmetic; the rest is the V^T rows lying S_loc instead of S columns apart), i.e. +0.16 ms per
         # layer at 4 ranks against 0.09 ms of relayout saved.  The default keeps the relayout into head-major tensors.
         self.zero_copy = bool(self.on_gpu and os.environ.get("UTX_SP_ZERO_COPY", "0") == "1")
+        if self.zero_copy and self.kv_text_rows:
+            raise ValueError("the zero-copy exchange reads the receive buffer as it lies: no key de-duplication (kv_text_rows) with UTX_SP_ZERO_COPY=1")
         self._z = z
         self._qkv = None                              # head-major copies (relayout form / CPU): allocated on first use
         self.o = z(G, self.S, Hg * 128)               # attention output of group g = [P][S_loc][Hg*128]: the send buffer of its exchange 2
@@ -115,7 +127,7 @@ class UlyssesExchange:
     def _heads(self):
         if self._qkv is None:
             z = self._z
-            self._qkv = (z(self.Hp, self.S, 128), z(self.Hp, self.S, 128), z(self.Hp, 128, self.S))     # heads of group g = rows [g*Hg, (g+1)*Hg)
+            self._qkv = (z(self.Hp, self.S, 128), z(self.Hp, self.S_k, 128), z(self.Hp, 128, self.S_k))     # heads of group g = rows [g*Hg, (g+1)*Hg)
         return self._qkv
 
     q = property(lambda self: self._heads()[0])
@@ -166,7 +178,8 @@ class UlyssesExchange:
         return [self._a2a(self.recv[g], self.send[g], async_op=True) for g in range(self.G)]
 
     def finish_heads_in_group(self, g, work=None, stream=None, unpack=None):
-        """wait for group g's exchange, then (unless zero copy) ONE relayout pass: recv[g] [P][3][Hg][E] -> q, k [Hg, S, 128], vt [Hg, 128, S] of the group.
+        """wait for group g's exchange, then (unless zero copy) ONE relayout pass: recv[g] [P][3][Hg][E] -> q [Hg, S, 128], k [Hg, S_k, 128], vt [Hg, 128, S_k] of the group
+        (S_k = S unless kv_text_rows).
         Zero copy: returns None -- the attention call takes heads_blocks(g)."""
         if work is not None:
             work.wait()                                   # the current stream waits for the collective; the host does not block
@@ -178,16 +191,28 @@ class UlyssesExchange:
         if self.on_gpu:
             lib, h = self.ctx.lib, self.ctx.handle
             st = self.ctx.stream() if stream is None else stream
-            self.ctx.check(lib.utx_sp_unpack_qkv(h, C.c_void_p(r.data_ptr()), P, Hg, S_loc, C.c_void_p(q.data_ptr()),
-                                                 C.c_void_p(k.data_ptr()), C.c_void_p(vt.data_ptr()), st))
+            if self.kv_text_rows:
+                self.ctx.check(lib.utx_sp_unpack_qkv_dedup(h, C.c_void_p(r.data_ptr()), P, Hg, S_loc, self.kv_text_rows, C.c_void_p(q.data_ptr()),
+                                                           C.c_void_p(k.data_ptr()), C.c_void_p(vt.data_ptr()), st))
+            else:
+                self.ctx.check(lib.utx_sp_unpack_qkv(h, C.c_void_p(r.data_ptr()), P, Hg, S_loc, C.c_void_p(q.data_ptr()),
+                                                     C.c_void_p(k.data_ptr()), C.c_void_p(vt.data_ptr()), st))
         else:
             q.view(Hg, P, S_loc, 128).copy_(r[:, 0].view(P, Hg, S_loc, 128).permute(1, 0, 2, 3))
-            k.view(Hg, P, S_loc, 128).copy_(r[:, 1].view(P, Hg, S_loc, 128).permute(1, 0, 2, 3))
-            vt.view(Hg, 128, P, S_loc).copy_(r[:, 2].view(P, Hg, 128, S_loc).permute(1, 2, 0, 3))
+            T = self.kv_text_rows
+            if T:
+                rk, rv = r[:, 1].view(P, Hg, S_loc, 128), r[:, 2].view(P, Hg, 128, S_loc)
+                k[:, :T].copy_(rk[0, :, :T])
+                k[:, T:].view(Hg, P, S_loc - T, 128).copy_(rk[:, :, T:].permute(1, 0, 2, 3))
+                vt[:, :, :T].copy_(rv[0, :, :, :T])
+                vt[:, :, T:].view(Hg, 128, P, S_loc - T).copy_(rv[:, :, :, T:].permute(1, 2, 0, 3))
+            else:
+                k.view(Hg, P, S_loc, 128).copy_(r[:, 1].view(P, Hg, S_loc, 128).permute(1, 0, 2, 3))
+                vt.view(Hg, 128, P, S_loc).copy_(r[:, 2].view(P, Hg, 128, S_loc).permute(1, 2, 0, 3))
         return q, k, vt
 
     def finish_heads_in(self, works=None, stream=None):
-        """all groups (blocking form): self.q, self.k [Hp, S, 128], self.vt [Hp, 128, S]."""
+        """all groups (blocking form): self.q [Hp, S, 128], self.k [Hp, S_k, 128], self.vt [Hp, 128, S_k]."""
         for g in range(self.G):
             self.finish_heads_in_group(g, None if works is None else works[g], stream, unpack=True)
         return self.q, self.k, self.vt
