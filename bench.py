@@ -565,7 +565,10 @@ def main():
                        "lora_rank": args.lora_rank, "guidance": 3.5, "launch": launch_path, "ms_per_step_hip_graph_replay": graph_ms, "parallelism": par,
                        "text_half_of_double_blocks": "second HIP stream beside the image half (opt-in: UTX_TXT_STREAM=1)" if model.overlap_text else
                        "on the caller's stream (default since round 5: the two-stream form's rare corruption has no established mechanism, DESIGN 9 b; costs 0.5 % here)",
-                       "tokens_computed": S_exec, "text_dedup": None if model.text_rows is None else "512 identical text tokens carried as %d rows per rank, key weight 2^%.2f (SURVEY 7 last bullet; UTX_TEXT_DEDUP=0 disables)" % (model.text_rows, model.key_bias_log2),
+                       "tokens_computed": S_exec, "attention_keys": S_keys,
+                       "sp_key_dedup": ("the ranks' identical text rows once among the keys (utx_sp_unpack_qkv_dedup): %d queries over %d keys per launch, key multiplicity on tile 0 only"
+                                        % (S_exec, S_keys)) if (ulysses and model.sp_kv_dedup) else None,
+                       "text_dedup": None if model.text_rows is None else "512 identical text tokens carried as %d rows per rank, key weight 2^%.2f (SURVEY 7 last bullet; UTX_TEXT_DEDUP=0 disables)" % (model.text_rows, model.key_bias_log2),
                        "last_block_pruning": ("last block: queries / MLP / out-projection for the %d noise tokens only (the prediction of the condition tail is never read: "
                                               "flux_piplines/texturing/pipeline.py:645,660,684; UTX_PRUNE_LAST=0 disables)" % n_noise) if prune else None,
                        "tflop_per_step": fl / 1e12, "tflop_per_step_reference_semantics": fl_nominal / 1e12,
@@ -575,7 +578,7 @@ def main():
                        # wrong-result ablations do not exist in this library) and every UTX_* variable of the environment
                        "launch_options": _lib.get_options(), "gemm_launches_per_step": _gemm_census(model), "ablation_build": bool(_lib.load_library().utx_is_ablation_build()),
                        "env_UTX": {k: v for k, v in sorted(os.environ.items()) if k.startswith("UTX_")}},
-            "roofline": {"bound": "mfma", "kernel": "attn_fwd_fp8_kernel (+ three MX quantiser passes, not in the launch time)" if args.fp8_attn else ("attn_fwd_q64_kernel (4 x 64, generated stream; + flag memset + repair-pass launch of attn_fwd_glds_kernel)" if _lib.get_options().get("UTX_ATTN_Q64") == 1 and not ulysses else "attn_fwd_glds_kernel"), "launches_per_call": "full rounds + key-split tail round (same kernel) + attn_merge_kernel; a 'launch' below is one utx_attn_fwd_bf16 call", "achieved": achieved, "peak": 5000.0 if args.fp8_attn else PEAK_BF16_TFLOPS,
+            "roofline": {"bound": "mfma", "kernel": "attn_fwd_fp8_kernel (+ three MX quantiser passes, not in the launch time)" if args.fp8_attn else ("attn_fwd_q64_kernel (4 x 64, generated stream; + flag memset + repair-pass launch of attn_fwd_glds_kernel)" if _lib.get_options().get("UTX_ATTN_Q64") == 1 and (not ulysses or model.sp_kv_dedup) else "attn_fwd_glds_kernel"), "launches_per_call": "full rounds + key-split tail round (same kernel) + attn_merge_kernel; a 'launch' below is one utx_attn_fwd_bf16 call", "achieved": achieved, "peak": 5000.0 if args.fp8_attn else PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / (5000.0 if args.fp8_attn else PEAK_BF16_TFLOPS), "traffic": None,
                          "launches_timed": len(attn_ms), "avg_launch_ms": attn_avg_ms,
                          "timed_in": "one extra step behind the timed region, HIP events on the launch stream around every attention call (the timed region itself carries no events: it is the product's launch path)",
