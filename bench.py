@@ -618,6 +618,13 @@ def main():
                     out["config"]["attn_clock_ghz"] = tr["attn_clock_ghz"]
                     out["config"]["attn_mfma_busy"] = tr["attn_mfma_busy"]
                     out["config"]["attn_busy_x_clock_over_2p4"] = tr["attn_mfma_busy"] * tr["attn_clock_ghz"] / 2.4
+                if "gemm" in tr and not args.fp8:      # the same two counters for the largest bf16 linear of the step (tools/gemm_one.py under tools/pmc_kernel.sh)
+                    out["config"]["gemm_clock_ghz"] = tr["gemm"]["gemm_clock_ghz"]
+                    out["config"]["gemm_mfma_busy"] = tr["gemm"]["gemm_mfma_busy"]
+                    out["config"]["gemm_busy_x_clock_over_2p4"] = tr["gemm"]["gemm_mfma_busy"] * tr["gemm"]["gemm_clock_ghz"] / 2.4
+                    if "roofline_gemm" in out:
+                        out["roofline_gemm"]["traffic"] = tr["gemm"]["traffic_bytes"]
+                        out["roofline_gemm"]["traffic_note"] = "bytes of ONE launch of the largest linear (M 50688, N 21504, K 3072; FETCH_SIZE x2 + WRITE_SIZE) against %d algorithmic: the re-reads are the 8 XCDs' separate L2s each streaming the operand panels of their 32 tiles (miss rate = the tile order's own at 1 ... 65 rounds, profiles/r06_gemm_l2_hit_vs_rounds.log)" % tr["gemm"]["algorithmic_bytes"]
         except OSError:
             pass
         if world == 1:

@@ -1,20 +1,16 @@
-# round 6, call 23: seconds per mesh texture end to end (1024^2 x 6 and the reference's 512^2 x 6), the fp8 bench lines, the 2-rank rehearsal of bench.py on one GPU over gloo (key de-dup path)
+# round 6, call 26: L2 hit rate of the bf16 GEMM against the number of tile rounds (is the 70 % of the full-size launch a lockstep drift of the persistent workgroups?)
 cd $GRAFT_REPO_ROOT
 exec < /dev/null
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 900 python tools/run_full_pipeline.py --view 1024 --reps 1 2>&1 | grep -v amdgpu | tail -25 > gpurun_out/r06_full_pipeline_e2e_1024.log; echo "e2e1024 rc=$?"; tail -6 gpurun_out/r06_full_pipeline_e2e_1024.log
-timeout 600 python tools/run_full_pipeline.py --view 512 --reps 2 2>&1 | grep -v amdgpu | tail -25 > gpurun_out/r06_full_pipeline_e2e_512.log; echo "e2e512 rc=$?"; tail -4 gpurun_out/r06_full_pipeline_e2e_512.log
-UTX_BENCH_EXPERIMENTS=0 UTX_BENCH_REF_POINT=0 timeout 600 python bench.py --gpus 1 --steps 10 --warmup 3 --fp8 > gpurun_out/r06_bench_strip1024x6_fp8.json.log 2> gpurun_out/r06_bench_fp8b.stderr.log; echo "fp8 rc=$?"
-UTX_BENCH_EXPERIMENTS=0 UTX_BENCH_REF_POINT=0 timeout 600 python bench.py --gpus 1 --steps 10 --warmup 3 --fp8 --fp8-attn > gpurun_out/r06_bench_strip1024x6_fp8_attn_v1.json.log 2> gpurun_out/r06_bench_fp8c.stderr.log; echo "fp8attn rc=$?"
-UTX_DIST_BACKEND=gloo timeout 900 python bench.py --gpus 2 --steps 2 --warmup 1 > gpurun_out/r06_bench_strip1024x6_2ranks_1gpu.json.log 2> gpurun_out/r06_bench_2ranks.stderr.log; echo "2ranks rc=$?"
-python - <<'PY'
-import json
-for f in ("r06_bench_strip1024x6_fp8", "r06_bench_strip1024x6_fp8_attn_v1", "r06_bench_strip1024x6_2ranks_1gpu"):
-    try:
-        d = json.loads([l for l in open("gpurun_out/%s.json.log" % f).read().strip().split("\n") if l.startswith("{")][-1])
-        print(f, d["n_gpus"], d["ms_per_step"], d["roofline"]["achieved"], d["config"].get("sequence_parallel", d["config"].get("parallelism")))
-    except Exception as e:
-        print(f, "ERR", e)
+for shape in "2048 8192 3072" "4096 8192 3072" "8192 8192 3072" "16384 8192 3072" "50688 8192 3072" "50688 21504 3072" "50688 3072 15360"; do
+  set -- $shape
+  echo "== M=$1 N=$2 K=$3 (tiles = $(( ($1/256) * ($2/256) )), rounds = $(python -c "print(round(($1/256)*($2/256)/256.0,2))"))"
+  PASSES="tcc1 tcc2" bash tools/pmc_kernel.sh gpurun_out/pmc_gemm_rounds gemm256_w4 python $GRAFT_REPO_ROOT/tools/gemm_one.py bf16 $1 $2 $3 2>&1 | grep -E "FETCH|TCC|WRITE|GRBM"
+  python - <<'PY'
+import csv, glob
+d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for f in glob.glob("gpurun_out/pmc_gemm_rounds/tcc1/*kernel_trace.csv") for r in csv.DictReader(open(f)) if "gemm256_w4" in r["Kernel_Name"]]
+print("kernel duration: n=%d avg %.4f ms" % (len(d), sum(d) / max(len(d), 1) / 1e6))
 PY
-tail -5 gpurun_out/r06_bench_2ranks.stderr.log | cut -c1-300
+  rm -rf gpurun_out/pmc_gemm_rounds
+done 2>&1 | tee gpurun_out/r06_gemm_l2_hit_vs_rounds.log
