@@ -161,7 +161,7 @@ def test_gemm_split_tail_round_matches_unsplit_launch_and_oracle_rows(M, N, K, K
     assert bool(diff.any()), "the split launch has the bits of the unsplit one everywhere: the tail round was not split"
     # tiles are numbered in groups of 4 row-tiles x all column tiles, column-major inside a group (gemm_w4.hip W4_TILE_ORIGIN); the tail tiles are the
     # last T of that order.  Everything else must be untouched.
-    ntm, gm = (M + 255) // 256, (2 if ntn >= 64 else 8 if ntn >= 32 else 4)      # the launcher's default UTX_GEMM_GROUP_M by output width
+    ntm, gm = (M + 255) // 256, (8 if ntn >= 32 else 2)      # the launcher's default UTX_GEMM_GROUP_M by output width (re-swept in round 6: gemm_w4.hip)
     tail = torch.zeros(ntm, ntn, dtype=torch.bool)
     for w in range(tiles - T, tiles):
         grp, rem = divmod(w, gm * ntn)

@@ -8,7 +8,7 @@ dev = "cuda"
 def t1(fn):
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record(); fn(); b.record(); torch.cuda.synchronize(); return a.elapsed_time(b)
-groups = [2, 4, 8, 16, 32]
+groups = [int(x) for x in os.environ.get("UTX_SWEEP_GROUPS", "2,4,8,16,32").split(",")]
 shapes = [(50240, 9216, 3072, "bias"), (50240, 12288, 3072, "gelu"), (50240, 21504, 3072, "bias"), (50240, 3072, 12288, "gate"), (50240, 3072, 15360, "gate"),
           (13376, 9216, 3072, "bias"), (13376, 12288, 3072, "gelu"), (13376, 21504, 3072, "bias"), (13376, 3072, 12288, "gate"), (13376, 3072, 15360, "gate")]
 for M, N, K, kind in shapes:
@@ -24,9 +24,9 @@ for M, N, K, kind in shapes:
         ops.gemm(A, B, out=C, **kw)
     ts = {g: [] for g in groups}
     for g in groups: run(g); run(g)
-    for r in range(7):
+    for r in range(int(os.environ.get("UTX_SWEEP_REPS", "7"))):
         for g in groups: ts[g].append(t1(lambda: run(g)))
-    med = {g: sorted(v)[3] for g, v in ts.items()}
+    med = {g: sorted(v)[len(v) // 2] for g, v in ts.items()}
     fl = 2.0 * M * N * K
     print("M=%6d N=%6d K=%6d %-4s | " % (M, N, K, kind) + "  ".join("gm%-2d %.3f ms %5.0f TF" % (g, med[g], fl / med[g] / 1e9) for g in groups), flush=True)
 _lib.set_option("UTX_GEMM_GROUP_M", 0)

@@ -988,9 +988,10 @@ extern "C" int utx_launch_gemm_w4(GemmParams p, hipStream_t stream) {
     }
     const int ncu = utx_ncu();
     const int ntm = (p.M + 255) / 256, ntn = p.N / 256;
-    // tile rows per L2 block of the tile order: wide outputs want narrow blocks (the B panel of a block is ntn tiles wide), mid-width ones taller
-    // blocks; +1...2 % against a fixed 4 (profiles/r02_gemm_group_m_sweep.log)
-    int group_m = g_utx_opt.gemm_group_m > 0 ? g_utx_opt.gemm_group_m : (ntn >= 64 ? 2 : ntn >= 32 ? 8 : 4);
+    // tile rows per L2 block of the tile order (an XCD's 32 consecutive tiles = group_m rows x 32 / group_m columns).  Re-swept in round 6 on the kernel as it is now
+    // (nontemporal C stores, generated K loop: profiles/r06_gemm_group_m_sweep.log, _fine.log): outputs of >= 32 tile columns want the 8 x 4 block (N = 21 504: 4.654 ms against
+    // 4.811 for round 2's choice of 2 -- with write-allocated C lines in the L2 the narrow block had won, r02_gemm_group_m_sweep.log), N = 3072 the narrow one (K = 15 360: 3.52 vs 3.56)
+    int group_m = g_utx_opt.gemm_group_m > 0 ? g_utx_opt.gemm_group_m : (ntn >= 32 ? 8 : 2);
     if (group_m > ntm) group_m = ntm;
     p.ntn = ntn | (group_m << 16);
     const int tiles = ntm * ntn;
