@@ -30,7 +30,8 @@ def _bf(t):
 def attention(q, k, vt, S=None, scale=None, out=None, o_ss=None, key_bias_log2=0.0, key_bias_period=0, S_q=None):
     """q,k [H,S_pad,128]; vt [H,128,S_pad] (S_pad multiple of 64, zero padded) -> o [S, H*128].
     key_bias_log2 / key_bias_period: key multiplicity of tile 0 (and every period-th tile), see utx_attn_fwd_bf16_kb.
-    S_q < S: only rows 0..S_q-1 of q are queries (o gets S_q rows), see utx_attn_fwd_bf16_kbq."""
+    S_q != S: rows 0..S_q-1 of q are the queries (o gets S_q rows) over the S keys of k / vt -- fewer (last-block pruning) or, since round 6, more than the keys (a
+    sequence-parallel rank's launch over de-duplicated text keys: q [H, >= S_q, 128], k [H, >= S, 128] are separate arrays), see utx_attn_fwd_bf16_kbq."""
     ctx = get_ctx(q.device.index)
     H, S_pad, D = q.shape
     assert D == 128 and vt.shape[1] == 128 and vt.shape[2] % 64 == 0
