@@ -1,6 +1,11 @@
-# round 6, call 30: tests/test_fullsize_gpu.py with the tile-order model of the re-chosen group_m
+# round 6, call 31: counter passes of the attention launch on the final stream (three tiles per trip) -> profiles/pmc_traffic.json
 cd $GRAFT_REPO_ROOT
 exec < /dev/null
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 1500 python -m pytest tests/test_fullsize_gpu.py -q -m gpu > gpurun_out/r06_fullsize_tests_gm.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/r06_fullsize_tests_gm.log
+PASSES="sq1 tcc1 tcc2" bash tools/pmc_kernel.sh gpurun_out/pmc_attn attn_fwd_q64 python $GRAFT_REPO_ROOT/tools/attn_one.py 50240 > gpurun_out/pmc_attn.log 2>&1
+cat gpurun_out/pmc_attn.log
+cp profiles/pmc_traffic.json gpurun_out/pmc_traffic.before.json
+python tools/pmc_traffic_update.py gpurun_out/pmc_attn gpurun_out/pmc_attn.log
+cp profiles/pmc_traffic.json gpurun_out/pmc_traffic.json
+rm -rf gpurun_out/pmc_attn/*/
