@@ -40,9 +40,10 @@ def lib():
     global _lib
     if _lib is None:
         src = os.path.join(_HERE, "geom_ref.c")
-        if (not os.path.exists(_SO)) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        so = os.environ.get("UTX_ORACLE_SO") or _SO      # UTX_ORACLE_SO: another build of the same source (the sanitizer build, tests/test_host_sanitizers_cpu.py)
+        if so == _SO and ((not os.path.exists(_SO)) or os.path.getmtime(_SO) < os.path.getmtime(src)):
             subprocess.run(["make", "-s", "-C", _HERE], check=True)
-        L = C.CDLL(_SO)
+        L = C.CDLL(so)
         L.utxref_rasterize.argtypes = [f32p, C.c_int, i32p, C.c_int, C.c_int, C.c_int, f32p]
         L.utxref_interpolate.argtypes = [f32p, C.c_int, f32p, i32p, C.c_long, f32p]
         L.utxref_bvh_build.argtypes = [f32p, C.c_int, i32p, C.c_int, i32p, f32p, u32p, i32p]
