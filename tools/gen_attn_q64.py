@@ -44,7 +44,7 @@ TILE = 16384
 
 
 class Config:
-    def __init__(self, name, nslot=3, ahead=2, novm=False, nobar=False, noexp=False, nodma=False, unroll3=False, wait2=False, pkadd=False, m0once=False, dot2=False, nosum=False, dot2c=False):
+    def __init__(self, name, nslot=3, ahead=2, novm=False, nobar=False, noexp=False, nodma=False, unroll3=False, wait2=False, pkadd=False, m0once=False, dot2=False, nosum=False, dot2c=False, mfma16qk=False):
         self.name, self.nslot, self.ahead = name, nslot, ahead
         # unroll3: three tiles per loop trip -- ring slots are literals, every LDS address is a loop-invariant register + an immediate, no address steps, no slot bookkeeping;
         # nt % 3 tiles run through a second copy of the first two tile bodies behind the loop.  wait2: one counted lgkmcnt per TWO groups (needs read-ahead 3).
@@ -56,6 +56,9 @@ class Config:
         # gap, one sum register per half, and l sums exactly the bf16 probabilities the PV MFMAs multiply.  NOT the 8 x 32 kernel's rounding (that one sums the fp32 P)
         self.dot2 = dot2
         self.dot2c = dot2c      # the dot2 arm with the 4-byte VOP2 form v_dot2c_f32_bf16 (sum zeroed by a v_mov at the head of the stage): encoding or execution unit?
+        # timing ablation (wrong results): every QK^T MFMA of the loop as TWO v_mfma_f32_16x16x32_bf16 on the same operand registers (same FLOPs, fragment reads, DMA and VALU work): the
+        # bound of what the vendor GEMM's MFMA shape could buy this kernel, for half of its MFMAs
+        self.mfma16qk = mfma16qk
         self.nosum = nosum      # timing ablation: no row-sum instruction at all (wrong results): the bound of anything done about the row sums
         self.pkadd = pkadd      # the two row-sum adds of a gap as ONE v_pk_add_f32 (same two IEEE additions, one instruction to fetch and issue)
         assert not unroll3 or nslot == 3
@@ -105,6 +108,14 @@ class Stream:
             self.gaps.append(self.gap)
         self.gap = 0
         self.lines.append("v_mfma_f32_32x32x16_bf16 %s, %s, %s, %s" % (dst, a_, b_, c_))
+
+    def mfma16x2(self, dst0, a_, b_, c0):
+        """two 16x16x32 MFMAs in place of one 32x32x16: 4-register accumulators dst0 .. dst0+3 and dst0+4 .. dst0+7 (VGPR numbers), the same A / B registers"""
+        if self.gap is not None:
+            self.gaps.append(self.gap)
+        self.gap = 0
+        for k in (0, 4):
+            self.lines.append("v_mfma_f32_16x16x32_bf16 v[%d:%d], %s, %s, v[%d:%d]" % (dst0 + k, dst0 + k + 3, a_, b_, c0 + k, c0 + k + 3))
 
     def ds_read(self, tag, dst, addr, off=0):
         self.ins("ds_read_b128 %s, %s%s" % (dst, addr, (" offset:%d" % off) if off else ""))
@@ -297,7 +308,10 @@ def gen_stage(st, cfg, G0, odd, j=0):
         elif g % 2 == 0:
             st.wait_lgkm([("K", G), ("V", G), ("K", G + 1), ("V", G + 1)])
         # ---- QK^T, half 0
-        st.mfma(v(SA[(q, 0)], 16), v(KF[G % 4], 4), a(Q0 + 4 * g, 4), v(NEGM[0], 16) if g == 0 else v(SA[(q, 0)], 16))
+        if cfg.mfma16qk:
+            st.mfma16x2(SA[(q, 0)], v(KF[G % 4], 4), a(Q0 + 4 * g, 4), NEGM[0] if g == 0 else SA[(q, 0)])
+        else:
+            st.mfma(v(SA[(q, 0)], 16), v(KF[G % 4], 4), a(Q0 + 4 * g, 4), v(NEGM[0], 16) if g == 0 else v(SA[(q, 0)], 16))
         if odd:      # scalar bookkeeping of the trip, two or three per gap (state of trip t from that of trip t - 1)
             if g == 0 and cfg.unroll3:
                 pass
@@ -351,7 +365,10 @@ def gen_stage(st, cfg, G0, odd, j=0):
             else:
                 st.ins("global_load_lds_dwordx4 %%[vo%d], %s%s" % (g - 4, s(S_VPTR, 2), off))
         # ---- QK^T, half 1
-        st.mfma(v(SA[(q, 1)], 16), v(KF[G % 4], 4), a(Q1 + 4 * g, 4), v(NEGM[1], 16) if g == 0 else v(SA[(q, 1)], 16))
+        if cfg.mfma16qk:
+            st.mfma16x2(SA[(q, 1)], v(KF[G % 4], 4), a(Q1 + 4 * g, 4), NEGM[1] if g == 0 else SA[(q, 1)])
+        else:
+            st.mfma(v(SA[(q, 1)], 16), v(KF[G % 4], 4), a(Q1 + 4 * g, 4), v(NEGM[1], 16) if g == 0 else v(SA[(q, 1)], 16))
         ev1 = sums_p[2] if (g == 0 and not cfg.dot2) else E[2]
         od1 = sums_p[3] if (g == 0 and not cfg.dot2) else E[3]
         st.ins("%s %s, %s" % (EXP, v(ev1), v(SA[(p, 1)] + 2 * g)))
@@ -485,10 +502,13 @@ DEFAULT = Config("default", unroll3=True, ahead=3, wait2=True)
 #   against 1391 / 1424 for the default in the same process: -7 %, and in CYCLES (3.25 -> 4.06e7 per CU, matrix pipe 89 -> 71 % busy at a clock that rises 1.51 -> 1.74 GHz): a VOP3P / dot
 #   instruction does not issue in an MFMA's shadow on gfx950 (~17 cycles each), like v_pk_add_f32.  abl_nosum (no row-sum instruction at all) +2.2 %: the bound of anything done about the sums
 #   (profiles/r06_attn_q64_arms_v5.log, r06_attn_pmc_arms_rowsum.log, r06_attn_q64_dot2_accuracy.log)
+#   abl_mfma16qk (every QK^T MFMA as two 16x16x32 on the same operand registers: the vendor GEMM's shape, the one the bare-MFMA probe sustains 10 % more of) 1398 / 1454 against 1406 / 1453:
+#   EQUAL in time -- 19 % more cycles (3.33 -> 3.97e7 per CU, matrix pipe 87 -> 73 % busy) at a clock 18 % higher (1.55 -> 1.83 GHz): the same energy for the same work, so the shape buys
+#   this kernel nothing (profiles/r06_attn_q64_arms_v6.log); a correct 16x16x32 stream was therefore not written
 VARIANTS = [Config("tile1"), Config("ring4", nslot=4), Config("m0", unroll3=True, ahead=3, wait2=True, m0once=True), Config("pk", unroll3=True, ahead=3, wait2=True, pkadd=True),
             Config("abl_novm", novm=True), Config("abl_nobar", novm=True, nobar=True), Config("abl_noexp", noexp=True), Config("abl_nodma", nodma=True, novm=True),
             Config("dot2", unroll3=True, ahead=3, wait2=True, dot2=True), Config("abl_nosum", unroll3=True, ahead=3, wait2=True, nosum=True),
-            Config("dot2c", unroll3=True, ahead=3, wait2=True, dot2=True, dot2c=True)]
+            Config("dot2c", unroll3=True, ahead=3, wait2=True, dot2=True, dot2c=True), Config("abl_mfma16qk", unroll3=True, ahead=3, wait2=True, mfma16qk=True)]
 
 
 def write_text(f, macro, st):
