@@ -38,7 +38,11 @@ Round 6 -- `kv_text_rows` = T > 0 (the transformer's default when every rank car
 rows ONCE in K / V^T (from source rank 0) followed by the ranks' other tokens in rank order: S_k = T + P (S_loc - T) keys in exactly the
 single-GPU key order, so a rank's attention launch is the single-GPU launch (key multiplicity on tile 0 only -- the 4 x 64 kernel takes it,
 +10 % over the 8 x 32 loop the periodic-multiplicity launches ran) over H / P heads, S = P S_loc queries over S_k keys, and its rows are
-bit-identical to the single-GPU attention's.
+bit-identical to the single-GPU attention's on the same operands.  "The same rows": the ranks compute their text rows from identical inputs with
+identical kernels; the one place where two ranks' copies can part by a bf16 ulp is the attention output of a text tile that falls into the
+key-split tail round of a launch while another rank's falls into a full round (same softmax, other summation order) -- rank 0's copy stands
+for all, a deviation of the size every other summation-order difference of the sharded run has (tests/test_dit_ops_gpu.py: two / four ranks
+against the unsharded forward).
 Per rank and layer 4 * S_loc * D * 2 B cross the fabric ((P-1)/P of it off-chip): 156 MB at S = 50 688, P = 8.
 Constraints: H % P == 0 and the local token count is a multiple of 64 (no padded keys inside the gathered sequence).
 
