@@ -202,7 +202,7 @@ int utx_gemm_bf16(utx_ctx* ctx, const utx_gemm_desc* d, utx_stream stream);
 size_t utx_gemm_streamk_workspace_bytes(utx_ctx* ctx);   /* size of utx_gemm_desc.sk_work for this device (2 partial tiles per CU) */
 /* What utx_gemm_bf16 would do with this descriptor on a device of n_cus compute units under the current launch options -- the library's own dispatch
  * arithmetic, no device needed (the host uses it to decide which projections can take the fused q / k epilogue, and bench.py to report the launch census):
- * out[0] = kernel (0 128x128 tiles, 1 one wave per SIMD, 2 persistent 8-wave, 3 per-tile 8-phase, 4 two-barrier 256^2, 5 one-pass streaming kernel for N <= 192 columns over >= 4096 rows: the LoRA-down products), out[1] = output tiles of that kernel (128^2 for kernel 0, 128-row blocks for kernel 5, else 256^2), out[2] = tiles
+ * out[0] = kernel (0 128x128 tiles, 1 one wave per SIMD, 2 persistent 8-wave, 3 per-tile 8-phase, 4 two-barrier 256^2), out[1] = output tiles of that kernel (128^2 for kernel 0, else 256^2), out[2] = tiles
  * of the last round that are cut along K (0: unsplit; needs d->sk_work != NULL), out[3] = K ranges per such tile. */
 int utx_gemm_plan(const utx_gemm_desc* d, int n_cus, int out[4]);
 

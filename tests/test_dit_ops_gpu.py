@@ -672,39 +672,6 @@ def test_attention_more_queries_than_keys(H, S_k, extra, kb):
     assert rc != 0
 
 
-@pytest.mark.parametrize("M,N,K,ldc,bias,alpha", [(4096, 64, 256, 64, False, 1.0), (50240, 192, 3072, 192, False, 1.0), (13001, 64, 12288, 192, False, 0.5),
-                                                 (5000, 160, 512, 256, True, 1.0), (4224, 96, 320, 128, True, 2.0), (50176, 64, 3072, 192, False, 1.0)])
-def test_skinny_gemm_matches_the_tile_kernel_bitwise(M, N, K, ldc, bias, alpha):
-    """gemm_skinny.hip (round 6): the LoRA-down products x . A^T -- N <= 192 columns over many rows -- in ONE pass over x (a workgroup owns 128 rows x all N columns, A straight into
-    registers three K-steps ahead, B through a two-slot LDS ring).  Same swapped MFMA, same K order, same epilogue expression as the 128 x 128 tile kernel it replaces
-    for these shapes: every output bit equal (UTX_GEMM_SKINNY=0 runs the tile kernel), ragged M, a strided output (the adapters' shared T buffer), bias, alpha; the
-    oracle's fp32 product as the outside reference."""
-    from unitex_amd import _lib
-    ops = _ops()
-    g = torch.Generator().manual_seed(M + N + K)
-    A = (torch.randn(M, K, generator=g) / math.sqrt(K)).to(BF).cuda()
-    B = torch.randn(N, K, generator=g).to(BF).cuda()
-    b = torch.randn(N, generator=g).to(BF).cuda() if bias else None
-    assert ops.gemm_plan(M, N, K=K)["kernel"] == "skinny"
-    outs = []
-    try:
-        for sk in (1, 0):
-            _lib.set_option("UTX_GEMM_SKINNY", sk)
-            buf = torch.full((M, ldc), 7.0, dtype=BF, device="cuda")
-            ops.gemm(A, B, bias=b, out=buf[:, :N], alpha=alpha)
-            torch.cuda.synchronize()
-            outs.append(buf)
-    finally:
-        _lib.set_option("UTX_GEMM_SKINNY", 1)
-    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16)), "the streaming kernel differs from the tile kernel (incl. the columns beyond N, which nobody may touch)"
-    rows = torch.randint(0, M, (512,), generator=g)
-    ref = alpha * (A[rows.cuda()].float() @ B.float().t()) + (b.float() if bias else 0.0)
-    err = (outs[0][rows.cuda(), :N].float() - ref).abs().max().item()
-    assert err <= 1.6e-2 * max(1.0, ref.abs().max().item()), "skinny GEMM vs fp32 product: %g" % err
-    # what the kernel does not take stays with the tile kernel: a LoRA segment, a gate, few rows
-    assert ops.gemm_plan(M, N, K=K, K2=64)["kernel"] != "skinny" and ops.gemm_plan(2048, N, K=K)["kernel"] != "skinny"
-
-
 def test_attention_running_max_keeps_growing():
     """pathological order for the sum-checked softmax: the scores of every query grow steadily along the key axis, so the
     running max has to be re-centred again and again (slow path on most tiles, in either 32-key block)."""

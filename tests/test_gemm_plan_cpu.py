@@ -40,10 +40,7 @@ def test_plan_of_the_flux_linears():
         (13376, 9216, 3072, 64): ("w4", 1908, 116, 2), (13376, 12288, 3072, 64): ("w4", 2544, 0, 0), (13376, 21504, 3072, 64): ("w4", 4452, 100, 2),
         (50240, 3072, 12288, 64): ("w4", 2364, 60, 4), (50240, 3072, 15360, 0): ("w4", 2364, 60, 4), (50240, 9216, 3072, 64): ("w4", 7092, 0, 0),
         (6144, 3072, 15360, 0): ("w4", 288, 32, 8), (13824, 3072, 12288, 64): ("w4", 648, 136, 3), (13824, 3072, 3072, 64): ("w4", 648, 0, 0),
-        (64, 9216, 3072, 64): ("128x128", 72, 0, 0),
-        # the LoRA-down products x . A^T (N = 64 / 192 columns over all rows): the one-pass streaming kernel, one workgroup per 128 rows (gemm_skinny.hip, round 6)
-        (13376, 192, 3072, 0): ("skinny", 105, 0, 0), (50240, 64, 12288, 0): ("skinny", 393, 0, 0), (50240, 320, 3072, 0): ("128x128", 1179, 0, 0),
-        (2048, 192, 3072, 0): ("128x128", 32, 0, 0),
+        (64, 9216, 3072, 64): ("128x128", 72, 0, 0), (13376, 192, 3072, 0): ("128x128", 210, 0, 0),
     }
     for (M, N, K, K2), want in expect.items():
         p = ops.gemm_plan(M, N, K=K, K2=K2)
@@ -59,9 +56,6 @@ def test_plan_of_the_flux_linears():
         _lib.set_option("UTX_GEMM_TILE", tile)
         assert ops.gemm_plan(13376, 3072, K=3072)["kernel"] == name
     _lib.set_option("UTX_GEMM_TILE", 0)
-    _lib.set_option("UTX_GEMM_SKINNY", 0)
-    assert ops.gemm_plan(13376, 192, K=3072)["kernel"] == "128x128"
-    _lib.set_option("UTX_GEMM_SKINNY", 1)
     assert ops.gemm_takes_w4(50240, 21504, n_split=9216, gelu_from=9216, K2=64, lora_seg_n=3072, lora_n_limit=9216)
     assert not ops.gemm_takes_w4(50240, 21504 + 128)          # a column boundary off the 256 grid
 

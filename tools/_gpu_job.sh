@@ -1,7 +1,6 @@
-# round 6, call 36: the one-pass streaming kernel for the LoRA-down products (gemm_skinny.hip): bit identity with the tile kernel, A/B
+# round 6, call 35: census of the step's GEMM launches by shape and kernel, each timed in isolation (where the 128 x 128 kernel's 2 % of the step goes)
 cd $GRAFT_REPO_ROOT
 exec < /dev/null
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_dit_ops_gpu.py -q -m gpu -k "skinny" -x 2>&1 | tail -15 | tee gpurun_out/r06_gemm_skinny_tests.log
-timeout 900 python tools/gemm_skinny_ab.py 2>&1 | grep -v amdgpu | tee gpurun_out/r06_gemm_skinny_ab.log
+timeout 900 python tools/small_gemm_census.py 2>&1 | grep -v amdgpu | tee gpurun_out/r06_small_gemm_census.log

@@ -240,7 +240,7 @@ def load_library():
 
 OPTION_NAMES = ["UTX_ATTN_GLDS", "UTX_ATTN_FAST", "UTX_ATTN_Q64", "UTX_ATTN_TPB", "UTX_ATTN_TAILSPLIT",
                 "UTX_GEMM_GROUP_M", "UTX_GEMM_TILE", "UTX_GEMM_TAILSPLIT", "UTX_GEMM_PERS_GRID", "UTX_GEMM_PERS_SCHED",
-                "UTX_GEMM_STREAMK", "UTX_BVH_STACK_WALK", "UTX_BVH_PACKET", "UTX_ATTN_PEEL", "UTX_ATTN8_PEEL", "UTX_NN_GRID", "UTX_GEMM_FASTK", "UTX_GEMM_SKINNY"]
+                "UTX_GEMM_STREAMK", "UTX_BVH_STACK_WALK", "UTX_BVH_PACKET", "UTX_ATTN_PEEL", "UTX_ATTN8_PEEL", "UTX_NN_GRID", "UTX_GEMM_FASTK"]
 
 
 def set_option(name, value):

@@ -32,7 +32,6 @@ SOURCES = [
     ("gemm.hip", []),
     ("gemm_pers.hip", []),
     ("gemm_w4.hip", []),
-    ("gemm_skinny.hip", []),
     ("dit_elementwise.hip", ["-ffp-contract=off"] + NO_PK),
     ("vae.hip", NO_PK),
     ("capi.cpp", []),

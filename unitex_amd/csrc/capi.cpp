@@ -12,7 +12,7 @@
 #include "kernels.h"
 #include "common.h"
 
-UtxOptions g_utx_opt = {1, 2, 1, 1, 1, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 1, 1, 1, 0, 1};      // (the last three: gemm_fastk, nn_grid, gemm_skinny)
+UtxOptions g_utx_opt = {1, 2, 1, 1, 1, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 1, 1, 1, 0};      // (the last two: gemm_fastk, nn_grid)
 
 struct OptName { const char* name; int UtxOptions::*field; bool ablation; };
 static const OptName kOptions[] = {
@@ -25,7 +25,6 @@ static const OptName kOptions[] = {
     {"UTX_BVH_STACK_WALK", &UtxOptions::bvh_stack_walk, false}, {"UTX_BVH_PACKET", &UtxOptions::bvh_packet, false},
     {"UTX_ATTN_PEEL", &UtxOptions::attn_peel, false},             {"UTX_ATTN8_PEEL", &UtxOptions::attn8_peel, false},
     {"UTX_NN_GRID", &UtxOptions::nn_grid, false},                 {"UTX_GEMM_FASTK", &UtxOptions::gemm_fastk, false},
-    {"UTX_GEMM_SKINNY", &UtxOptions::gemm_skinny, false},
     {"UTX_ATTN_VAR", &UtxOptions::attn_var_abl, true},      {"UTX_ATTN_DEBUG", &UtxOptions::attn_debug_abl, true},
     {"UTX_GEMM_DEBUG", &UtxOptions::gemm_debug_abl, true},
 };

@@ -783,13 +783,12 @@ static int launch_gemm8(GemmParams p, hipStream_t stream, int group_env, int dbg
 // Which kernel a descriptor goes to, and how the one-wave-per-SIMD kernel would cut its last round -- pure host arithmetic (no HIP call), shared by
 // the launcher below and by utx_gemm_plan (C ABI: the host side and the CPU tests read the decision instead of restating it).
 // kernel: 0 = 128^2 (incl. the implicit convolution / MX fp8 forms), 1 = one wave per SIMD (gemm_w4.hip), 2 = persistent 8-wave, 3 = per-tile 8-phase,
-// 4 = 2-barrier 256^2, 5 = the one-pass streaming kernel for skinny outputs over many rows (gemm_skinny.hip).  Shape validation stays in the launcher.
+// 4 = 2-barrier 256^2.  Shape validation stays in the launcher.
 extern "C" void utx_gemm_plan_impl(const GemmParams* pp, int ncu, int sk_has_work, int out[4]) {
     const GemmParams& p = *pp;
     const int dbg_env = g_utx_opt.gemm_debug_abl, tile_env = g_utx_opt.gemm_tile;
     out[0] = 0; out[1] = ((p.M + 127) / 128) * ((p.N + 127) / 128); out[2] = 0; out[3] = 0;
     if (p.conv_Wo > 0 || p.mx8 == 1) return;
-    if (g_utx_opt.gemm_skinny != 0 && utx_gemm_skinny_shape(&p)) { out[0] = 5; out[1] = (p.M + 127) / 128; return; }
     if (p.mx8 == 2) {     // MX fp8 with tile-packed scales: the one-wave-per-SIMD kernel only (gemm_w4.hip, MX); the launcher refuses other shapes
         out[0] = 1; out[1] = ((p.M + 255) / 256) * (p.N / 256);
         int grid = out[1] < ncu ? out[1] : ncu;
@@ -853,9 +852,6 @@ extern "C" int utx_launch_gemm_bf16(const GemmParams* hp, hipStream_t stream) {
         return utx_launch_gemm_w4(p, stream);
     }
     if (p.mx8) return launch_gemm<128, 128, 2, 2, false, true>(p, stream, group_env, 0);
-    // skinny outputs over many rows (the LoRA-down products x . A^T): one pass over A with all N columns in one workgroup (gemm_skinny.hip; bit-identical to the tile kernel
-    // below, UTX_GEMM_SKINNY=0 keeps that one for A/B)
-    if (g_utx_opt.gemm_skinny != 0 && utx_gemm_skinny_takes(&p)) return utx_launch_gemm_skinny(&p, stream);
     int plan[4];
     utx_gemm_plan_impl(&p, 256, 1, plan);      // the kernel choice does not depend on the CU count (only the split of the last round does)
     if (p.qk_cols > 0) {

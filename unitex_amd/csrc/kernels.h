@@ -81,8 +81,6 @@ struct UtxOptions {
                           // (attn_fwd_fp8_kernel<1>, attention_fp8.hip); 0: the general loop.  Same bits either way.
     int gemm_fastk;       // one-wave-per-SIMD GEMM (bf16): 1 (default since round 6: +2.3 ... +3.7 % on the FLUX shapes, profiles/r06_gemm_fastk_check_v0.log) = the steady-state K loop runs the generated instruction stream (gemm_w4_loop_asm.inc), 0 = hipcc's loop (round 2-5).  Same bits.
     int nn_grid;          // 0 (default): the NN fill's cell grid follows the atlas size; 64 | 128 | 256 force one (A/B and the grid-independence test; same results)
-    int gemm_skinny;      // 1 (default): plain bf16 products with N <= 192 columns over >= 4096 rows (the LoRA-down products) run gemm_skinny.hip's one-pass streaming kernel; 0: the 128 x 128
-                          // tile kernel (A/B).  Same bits either way.
 };
 extern UtxOptions g_utx_opt;
 
@@ -120,9 +118,6 @@ int utx_launch_gemv_bf16(const GemvParams* p, hipStream_t stream);
 int utx_launch_quant_mx8(const void* x, long ldx, void* q, long ldq, void* s, long lds, int M, int K, hipStream_t stream);
 int utx_launch_quant_mx8_packed(const void* x, long ldx, void* q, long ldq, void* s, long row_blocks, int M, int K, hipStream_t stream);
 int utx_launch_qkv_post(const QkvPostParams* p, hipStream_t stream);
-int utx_gemm_skinny_takes(const GemmParams* p);                           // gemm_skinny.hip: N <= 192 columns over many rows (the LoRA-down products), one pass over A
-int utx_gemm_skinny_shape(const GemmParams* p);
-int utx_launch_gemm_skinny(const GemmParams* p, hipStream_t stream);
 int utx_launch_sp_unpack_qkv(const void* recv, int P, int Hp, int S_loc, int text_rows, void* q, void* k, void* vt, hipStream_t stream);
 int utx_launch_sp_unpack_o(const void* recv, int P, int Hp, int S_loc, void* out, long ld, long src_cols, hipStream_t stream);
 size_t utx_group_norm_workspace_bytes_impl(void);

@@ -156,7 +156,7 @@ def streamk_workspace(device, stream=None, shared=True):
     return _SK_WS[key]
 
 
-GEMM_KERNELS = ("128x128", "w4", "pers8", "8phase", "2barrier", "skinny")
+GEMM_KERNELS = ("128x128", "w4", "pers8", "8phase", "2barrier")
 
 
 def gemm_plan(M, N, K=3072, K2=0, n_split=None, gelu_from=None, lora_seg_n=None, lora_n_limit=None, sk=True, n_cus=256):
