@@ -1,6 +1,7 @@
-# round 6, call 35: census of the step's GEMM launches by shape and kernel, each timed in isolation (where the 128 x 128 kernel's 2 % of the step goes)
+# round 6, call 38: smoke + a fast cross-section of the GPU suite on the final tree (after the streaming-GEMM experiment left the product)
 cd $GRAFT_REPO_ROOT
 exec < /dev/null
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 900 python tools/small_gemm_census.py 2>&1 | grep -v amdgpu | tee gpurun_out/r06_small_gemm_census.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke OK')" 2>&1 | tail -2
+timeout 1200 python -m pytest tests/test_dit_ops_gpu.py tests/test_attention_q64_gpu.py tests/test_fixtures_direct_gpu.py -q -m gpu 2>&1 | tail -3
