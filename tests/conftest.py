@@ -27,3 +27,29 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+_OPTION_DEFAULTS = None
+
+
+@pytest.fixture(autouse=True)
+def _launch_options_do_not_leak():
+    """The library's launch options (`utx_set_option`) are process-global.  A test that leaves one changed silently moves every LATER test onto another
+    kernel (round 6: a `finally` that reset UTX_ATTN_Q64 to its round-5 value 0 put the rest of an alphabetical run on the 8 x 32 attention loop).  So: the
+    options as the library first reports them are the defaults; a test that ends with any other value FAILS, and the defaults are put back for the next."""
+    global _OPTION_DEFAULTS
+    try:
+        from unitex_amd import _lib
+        now = _lib.get_options()
+    except Exception:
+        yield
+        return
+    if _OPTION_DEFAULTS is None:
+        _OPTION_DEFAULTS = dict(now)
+    yield
+    after = _lib.get_options()
+    leaked = {k: (after[k], v) for k, v in _OPTION_DEFAULTS.items() if after.get(k) != v}
+    for k, v in _OPTION_DEFAULTS.items():
+        if after.get(k) != v:
+            _lib.set_option(k, v)
+    assert not leaked, "test left launch options changed (now, default): %r" % leaked

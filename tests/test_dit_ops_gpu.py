@@ -709,6 +709,7 @@ def test_attention_q64_kernel_and_repair_pass(S, ramp_max):
     v = torch.randn(H, S, 128, generator=g).to(BF)
     ref = dit_ref.sdpa(q.float(), k.float(), v.float(), em=False)
     from unitex_amd import _lib
+    prev = _lib.get_options()["UTX_ATTN_Q64"]
     _lib.set_option("UTX_ATTN_Q64", 1)
     try:
         for prescaled in (False, True):
@@ -717,7 +718,7 @@ def test_attention_q64_kernel_and_repair_pass(S, ramp_max):
             err = (out - ref).abs().max().item()
             assert err < 4e-2, "4 x 64 attention err %g (S=%d ramp=%g prescaled=%s)" % (err, S, ramp_max, prescaled)
     finally:
-        _lib.set_option("UTX_ATTN_Q64", 0)
+        _lib.set_option("UTX_ATTN_Q64", prev)
 
 
 def test_hip_graph_replay_is_bit_identical_to_the_eager_plan():

@@ -1,7 +1,6 @@
-# round 6, call 38: smoke + a fast cross-section of the GPU suite on the final tree (after the streaming-GEMM experiment left the product)
+# round 6, call 40: the WHOLE GPU suite on the tree with the launch-option leak guard (tests/conftest.py) -- every later test now provably runs on the defaults
 cd $GRAFT_REPO_ROOT
 exec < /dev/null
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke OK')" 2>&1 | tail -2
-timeout 1200 python -m pytest tests/test_dit_ops_gpu.py tests/test_attention_q64_gpu.py tests/test_fixtures_direct_gpu.py -q -m gpu 2>&1 | tail -3
+timeout 2100 python -m pytest tests -q -m gpu --durations=15 > gpurun_out/r06_gpu_suite_guarded.log 2>&1; echo "pytest rc=$?"; grep -E "passed|failed" gpurun_out/r06_gpu_suite_guarded.log | tail -1; grep -E "^(FAILED|ERROR)" gpurun_out/r06_gpu_suite_guarded.log | head -20
