@@ -475,3 +475,126 @@ def test_projection_frames_bound_the_stretch():
         assert worst <= bound, (n, worst)
     assert 1.0 / (p @ meshes.projection_frames(26)[0].T).max(1).min() - 1.0 <= 1.0 / 6.0
 
+
+
+def _write_ply(path, v, polys, fmt, uv=None, extra_element=False):
+    """a PLY writer for the reader's test only: vertex (x y z [+ a skipped uchar property] [+ s t]), optionally an element in front that must be skipped, face lists
+    with a uchar count and int indices plus one scalar property behind the list"""
+    import struct as st
+    e = {"ascii": None, "binary_little_endian": "<", "binary_big_endian": ">"}[fmt]
+    h = ["ply", "format %s 1.0" % fmt, "comment written by the test"]
+    if extra_element:
+        h += ["element camera 2", "property float cx", "property short cid"]
+    h += ["element vertex %d" % len(v), "property float x", "property float y", "property float z", "property uchar red"]
+    if uv is not None:
+        h += ["property float s", "property float t"]
+    h += ["element face %d" % len(polys), "property list uchar int vertex_indices", "property float quality", "end_header"]
+    body = b""
+    if e is None:
+        rows = []
+        if extra_element:
+            rows += ["0.5 7", "1.5 -3"]
+        for i, p_ in enumerate(v):
+            rows.append(" ".join(repr(float(x)) for x in p_) + " %d" % (i % 256) + ("" if uv is None else " %r %r" % (float(uv[i, 0]), float(uv[i, 1]))))
+        for p_ in polys:
+            rows.append("%d " % len(p_) + " ".join(str(int(i)) for i in p_) + " 0.25")
+        body = ("\n".join(rows) + "\n").encode()
+    else:
+        if extra_element:
+            body += st.pack(e + "fh", 0.5, 7) + st.pack(e + "fh", 1.5, -3)
+        for i, p_ in enumerate(v):
+            body += st.pack(e + "fffB", float(p_[0]), float(p_[1]), float(p_[2]), i % 256)
+            if uv is not None:
+                body += st.pack(e + "ff", float(uv[i, 0]), float(uv[i, 1]))
+        for p_ in polys:
+            body += st.pack(e + "B%dif" % len(p_), len(p_), *[int(i) for i in p_], 0.25)
+    with open(path, "wb") as f:
+        f.write(("\n".join(h) + "\n").encode() + body)
+
+
+def test_interchange_mesh_formats_read_back_the_same_mesh(tmp_path):
+    """load_mesh on .ply (ascii / both binary byte orders; triangles, mixed polygons, skipped properties and elements, per-vertex s t), .stl (binary / ascii: corner
+    merge), .off and .gltf (data URIs and a side file) returns the mesh that was written -- the reference hands any of these to trimesh.load (io/mesh_loader.py:22-30)."""
+    import base64
+    import json
+    import struct as st
+    v, f, uv = meshes.sphere_with_faces(300)
+    v = v.astype(np.float32); f = f.astype(np.int32); uv = uv.astype(np.float32)
+    for fmt in ("ascii", "binary_little_endian", "binary_big_endian"):
+        p = str(tmp_path / ("tri_%s.ply" % fmt))
+        _write_ply(p, v, f, fmt, uv=uv, extra_element=(fmt != "ascii"))
+        v2, f2, uv2, tex = meshes.load_mesh(p)
+        assert tex is None and np.array_equal(v2, v) and np.array_equal(f2, f) and np.array_equal(uv2, uv), fmt
+        # quads + a pentagon + triangles in one file: the row-by-row path, fanned
+        polys = [[0, 1, 2, 3], [4, 5, 6], [7, 8, 9, 10, 11], [2, 1, 0]]
+        p = str(tmp_path / ("poly_%s.ply" % fmt))
+        _write_ply(p, v, polys, fmt)
+        v3, f3, uv3, _ = meshes.load_mesh(p)
+        assert uv3 is None and np.array_equal(v3, v)
+        assert f3.tolist() == [[0, 1, 2], [0, 2, 3], [4, 5, 6], [7, 8, 9], [7, 9, 10], [7, 10, 11], [2, 1, 0]], fmt
+    # all-quad binary file: the fixed-size fast path with lists of four
+    p = str(tmp_path / "quads.ply")
+    _write_ply(p, v, [[0, 1, 2, 3], [4, 5, 6, 7]], "binary_little_endian")
+    assert meshes.load_mesh(p)[1].tolist() == [[0, 1, 2], [0, 2, 3], [4, 5, 6], [4, 6, 7]]
+    # STL: a soup of the same triangles; corners merge back to the vertices the faces use, in first-use order
+    soup = v[f].reshape(-1, 3)
+    pb = str(tmp_path / "m.stl")
+    with open(pb, "wb") as fh:
+        fh.write(b"solid looks like ascii but is binary".ljust(80, b" ") + st.pack("<I", len(f)))
+        for t in v[f]:
+            fh.write(st.pack("<12fH", 0.0, 0.0, 0.0, *t.reshape(-1).tolist(), 0))
+    pa = str(tmp_path / "a.stl")
+    with open(pa, "w") as fh:
+        fh.write("solid s\n")
+        for t in v[f]:
+            fh.write("facet normal 0 0 0\n outer loop\n" + "".join("  vertex %r %r %r\n" % tuple(float(x) for x in c) for c in t) + " endloop\nendfacet\n")
+        fh.write("endsolid s\n")
+    for p in (pb, pa):
+        vs, fs, uvs, _ = meshes.load_mesh(p)
+        assert uvs is None and np.array_equal(vs[fs].reshape(-1, 3), soup), p
+        first_use = np.sort(np.unique(soup, axis=0, return_index=True)[1])      # the sphere's seam vertices share positions: they merge too
+        assert np.array_equal(vs, soup[first_use]), p
+    # OFF: counts on the header line / on the next line, a COFF with vertex colours, a face colour behind the indices, comments
+    po = str(tmp_path / "m.off")
+    with open(po, "w") as fh:
+        fh.write("OFF\n# a comment\n%d %d 0\n" % (len(v), len(f)) + "".join("%r %r %r\n" % tuple(float(x) for x in p_) for p_ in v)
+                 + "".join("3 %d %d %d 255 0 0\n" % tuple(t) for t in f))
+    vo, fo, _, _ = meshes.load_mesh(po)
+    assert np.array_equal(vo, v) and np.array_equal(fo, f)
+    pc = str(tmp_path / "c.off")
+    with open(pc, "w") as fh:
+        fh.write("COFF %d 2 0\n" % len(v) + "".join("%r %r %r 10 20 30 255\n" % tuple(float(x) for x in p_) for p_ in v) + "4 0 1 2 3\n3 4 5 6\n")
+    vc, fc, _, _ = meshes.load_mesh(pc)
+    assert np.array_equal(vc, v) and fc.tolist() == [[0, 1, 2], [0, 2, 3], [4, 5, 6]]
+    # glTF JSON: the GLB this package writes, re-containered -- buffer as a data URI, then as a side file with an external image
+    tex = (np.random.default_rng(1).random((16, 24, 3)) * 255).astype(np.uint8)
+    pg = str(tmp_path / "m.glb")
+    meshes.save_glb(pg, v, f, uv, tex)
+    ref = meshes.load_glb(pg)
+    blob = open(pg, "rb").read()
+    jl = st.unpack_from("<I", blob, 12)[0]
+    js = json.loads(blob[20:20 + jl].decode())
+    binc = blob[20 + jl + 8:]
+    js1 = json.loads(json.dumps(js))
+    js1["buffers"][0]["uri"] = "data:application/octet-stream;base64," + base64.b64encode(binc).decode()
+    p1 = str(tmp_path / "inline.gltf")
+    json.dump(js1, open(p1, "w"))
+    js2 = json.loads(json.dumps(js))
+    js2["buffers"][0]["uri"] = "side%20file.bin"
+    open(str(tmp_path / "side file.bin"), "wb").write(binc)
+    bv = js["bufferViews"][js["images"][0]["bufferView"]]
+    open(str(tmp_path / "albedo.png"), "wb").write(binc[bv["byteOffset"]:bv["byteOffset"] + bv["byteLength"]])
+    js2["images"][0] = {"uri": "albedo.png"}
+    p2 = str(tmp_path / "side.gltf")
+    json.dump(js2, open(p2, "w"))
+    for p in (p1, p2):
+        got = meshes.load_mesh(p)
+        for a, b in zip(got, ref):
+            assert np.array_equal(a, b), p
+    # refusals
+    import pytest
+    open(str(tmp_path / "cloud.ply"), "w").write("ply\nformat ascii 1.0\nelement vertex 1\nproperty float x\nproperty float y\nproperty float z\nend_header\n0 0 0\n")
+    with pytest.raises(ValueError):
+        meshes.load_mesh(str(tmp_path / "cloud.ply"))
+    with pytest.raises(NotImplementedError):
+        meshes.load_mesh(str(tmp_path / "m.fbx"))

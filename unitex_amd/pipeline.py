@@ -130,7 +130,7 @@ class RGBTextureFullPipelineBase:
     @CPUTimer("preprocess_blank_mesh")
     def preprocess_blank_mesh(self, save_dir, input_mesh_path, min_faces=20_000, max_faces=200_000, scale=0.95):
         """reference: open3d clean / decimate / subdivide / UVAtlas (geometry/uv/uv_atlas.py:131-194).  Here the
-        host-side equivalents of texturetools/meshes.py: .obj / .glb in, rescaled to bbox*scale; a mesh with UVs passes
+        host-side equivalents of texturetools/meshes.py: .obj / .glb / .gltf / .ply / .stl / .off in, rescaled to bbox*scale; a mesh with UVs passes
         through, one without is cleaned, brought into [min_faces, max_faces] and unwrapped (builder-defined atlas)."""
         from .texturetools import meshes
         # UV-less meshes get the chart unwrap: a handful of large charts at one texel density, as with the reference's UVAtlas charts

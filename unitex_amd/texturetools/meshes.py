@@ -224,7 +224,6 @@ _GLTF_NCOMP = {"SCALAR": 1, "VEC2": 2, "VEC3": 3, "VEC4": 4, "MAT4": 16}
 def load_glb(path):
     """glTF 2.0 binary reader: all triangle primitives of all meshes (node transforms applied), merged.
     Returns verts [V,3] f32, faces [F,3] i32, uvs [V,2] f32 in [0,1] with v bottom-up | None, texture u8 [H,W,3] | None."""
-    import io
     with open(path, "rb") as f:
         blob = f.read()
     magic, version, total = struct.unpack_from("<III", blob, 0)
@@ -239,6 +238,37 @@ def load_glb(path):
         elif ctype == 0x004E4942:
             binc = data
         off += 8 + clen + ((-clen) % 4)
+    return _gltf_scene_to_mesh(js, path, binc)
+
+
+def _gltf_uri_bytes(uri, path):
+    """a glTF `uri`: an RFC 2397 data URI (base64) or a file beside the .gltf"""
+    if uri.startswith("data:"):
+        import base64
+        return base64.b64decode(uri.split(",", 1)[1])
+    from urllib.parse import unquote
+    with open(os.path.join(os.path.dirname(os.path.abspath(path)), unquote(uri)), "rb") as f:
+        return f.read()
+
+
+def load_gltf(path):
+    """glTF 2.0 JSON form (the reference's header reader knows both containers: io/mesh_header_loader.py:49-55): buffers and images as data URIs or as files beside
+    the .gltf.  Same outputs as load_glb."""
+    with open(path, "r", encoding="utf-8") as f:
+        js = json.load(f)
+    return _gltf_scene_to_mesh(js, path, None)
+
+
+def _gltf_scene_to_mesh(js, path, glb_bin):
+    import io
+    bufs = []
+    for i, b in enumerate(js.get("buffers", [])):
+        if "uri" in b:
+            bufs.append(_gltf_uri_bytes(b["uri"], path))
+        elif i == 0 and glb_bin is not None:
+            bufs.append(glb_bin)       # the GLB's BIN chunk is buffer 0 when that buffer has no uri
+        else:
+            raise ValueError("%s: buffer %d has neither a uri nor a BIN chunk" % (path, i))
 
     def accessor(i):
         a = js["accessors"][i]
@@ -250,11 +280,11 @@ def load_glb(path):
         if stride and stride != item:
             # interleaved attributes: element i sits at start + i*stride; the last element ends `item` bytes in, NOT a full
             # stride -- reading count*stride bytes runs past the bufferView when accessor.byteOffset > 0
-            span = np.frombuffer(binc, dtype=np.uint8, count=stride * (a["count"] - 1) + item, offset=start)
+            span = np.frombuffer(bufs[bv.get("buffer", 0)], dtype=np.uint8, count=stride * (a["count"] - 1) + item, offset=start)
             raw = np.lib.stride_tricks.as_strided(span, shape=(a["count"], item), strides=(stride, 1))
             arr = np.frombuffer(np.ascontiguousarray(raw).tobytes(), dtype=dt).reshape(a["count"], nc)
         else:
-            arr = np.frombuffer(binc, dtype=dt, count=a["count"] * nc, offset=start).reshape(a["count"], nc)
+            arr = np.frombuffer(bufs[bv.get("buffer", 0)], dtype=dt, count=a["count"] * nc, offset=start).reshape(a["count"], nc)
         if a.get("normalized") and dt != np.float32:
             arr = arr.astype(np.float32) / float(np.iinfo(dt).max)
         return arr
@@ -301,10 +331,12 @@ def load_glb(path):
                     bct = js["materials"][mat].get("pbrMetallicRoughness", {}).get("baseColorTexture")
                     if bct is not None:
                         img = js["images"][js["textures"][bct["index"]]["source"]]
+                        from PIL import Image
                         if "bufferView" in img:
                             bv = js["bufferViews"][img["bufferView"]]
-                            from PIL import Image
-                            tex = np.asarray(Image.open(io.BytesIO(binc[bv.get("byteOffset", 0): bv.get("byteOffset", 0) + bv["byteLength"]])).convert("RGB"))
+                            tex = np.asarray(Image.open(io.BytesIO(bufs[bv.get("buffer", 0)][bv.get("byteOffset", 0): bv.get("byteOffset", 0) + bv["byteLength"]])).convert("RGB"))
+                        elif "uri" in img:
+                            tex = np.asarray(Image.open(io.BytesIO(_gltf_uri_bytes(img["uri"], path))).convert("RGB"))
         for c in n.get("children", []):
             visit(c, m)
 
@@ -318,8 +350,189 @@ def load_glb(path):
     return verts, faces, uvs, tex
 
 
+_PLY_TYPES = {"char": "i1", "int8": "i1", "uchar": "u1", "uint8": "u1", "short": "i2", "int16": "i2", "ushort": "u2", "uint16": "u2",
+              "int": "i4", "int32": "i4", "uint": "u4", "uint32": "u4", "float": "f4", "float32": "f4", "double": "f8", "float64": "f8"}
+
+
+def _fan(polys):
+    """polygons (lists of vertex indices) -> triangles by a fan around the first corner (what trimesh does with a convex polygon)"""
+    out = []
+    for p_ in polys:
+        for i in range(1, len(p_) - 1):
+            out.append((p_[0], p_[i], p_[i + 1]))
+    return np.asarray(out, dtype=np.int32).reshape(-1, 3)
+
+
+def load_ply(path):
+    """Stanford PLY, ascii / binary_little_endian / binary_big_endian: element `vertex` (x y z, optional s t | u v | texture_u texture_v; any other property is
+    skipped) and element `face` (a list property vertex_indices | vertex_index; other properties skipped; polygons fanned).  Other elements before / between are
+    skipped by their declared layout.  Returns (verts f32 [V,3], faces i32 [F,3], uvs f32 [V,2] | None)."""
+    with open(path, "rb") as f:
+        blob = f.read()
+    end = blob.find(b"end_header")
+    if not blob.startswith(b"ply") or end < 0:
+        raise ValueError("%s is not a PLY file" % path)
+    body = blob.index(b"\n", end) + 1
+    fmt, elements = None, []
+    for line in blob[:end].decode("ascii", "replace").splitlines():
+        t = line.split()
+        if not t or t[0] in ("ply", "comment", "obj_info"):
+            continue
+        if t[0] == "format":
+            fmt = t[1]
+        elif t[0] == "element":
+            elements.append([t[1], int(t[2]), []])
+        elif t[0] == "property":
+            if t[1] == "list":
+                elements[-1][2].append((t[4], _PLY_TYPES[t[2]], _PLY_TYPES[t[3]]))
+            else:
+                elements[-1][2].append((t[2], _PLY_TYPES[t[1]], None))
+    if fmt not in ("ascii", "binary_little_endian", "binary_big_endian"):
+        raise ValueError("%s: PLY format %r" % (path, fmt))
+    verts = uvs = None
+    polys = []
+    if fmt == "ascii":
+        tok = blob[body:].split()
+        pos = 0
+        for name, count, props in elements:
+            rows = []
+            for _ in range(count):
+                row = {}
+                for pn, pt, lt in props:
+                    if lt is None:
+                        row[pn] = float(tok[pos]); pos += 1
+                    else:
+                        n = int(tok[pos]); pos += 1
+                        row[pn] = [int(float(x)) for x in tok[pos:pos + n]]; pos += n
+                rows.append(row)
+            if name == "vertex":
+                verts, uvs = _ply_vertex_arrays(lambda k: np.asarray([r[k] for r in rows], dtype=np.float64), [p_[0] for p_ in props], count)
+            elif name == "face":
+                key = next((k for k in ("vertex_indices", "vertex_index") if rows and k in rows[0]), None)
+                polys = [r[key] for r in rows] if key else []
+    else:
+        e = "<" if fmt == "binary_little_endian" else ">"
+        pos = body
+        for name, count, props in elements:
+            if all(lt is None for _, _, lt in props):
+                dt = np.dtype([(pn, e + pt) for pn, pt, _ in props])
+                arr = np.frombuffer(blob, dtype=dt, count=count, offset=pos)
+                pos += dt.itemsize * count
+                if name == "vertex":
+                    verts, uvs = _ply_vertex_arrays(lambda k: arr[k].astype(np.float64), [p_[0] for p_ in props], count)
+                continue
+            # an element with list properties: fixed-size fast path when every list of the element has the same length (all-triangle / all-quad files), else row by row
+            got = None
+            if count:
+                lens = []
+                q = pos
+                for pn, pt, lt in props:
+                    if lt is None:
+                        q += np.dtype(pt).itemsize; lens.append(None)
+                    else:
+                        n = int(np.frombuffer(blob, dtype=e + pt, count=1, offset=q)[0]); lens.append(n)
+                        q += np.dtype(pt).itemsize + n * np.dtype(lt).itemsize
+                fields = []
+                for (pn, pt, lt), n in zip(props, lens):
+                    if lt is None:
+                        fields.append((pn, e + pt))
+                    else:
+                        fields.append((pn + "__n", e + pt)); fields.append((pn, e + lt, (n,)))
+                dt = np.dtype(fields)
+                if pos + dt.itemsize * count <= len(blob):
+                    arr = np.frombuffer(blob, dtype=dt, count=count, offset=pos)
+                    if all(n is None or np.all(arr[pn + "__n"] == n) for (pn, _, _), n in zip(props, lens)):
+                        got = arr
+                        pos += dt.itemsize * count
+            if got is not None:
+                if name == "face":
+                    key = next((k for k in ("vertex_indices", "vertex_index") if k in got.dtype.names), None)
+                    if key:
+                        polys = got[key].astype(np.int64)
+                continue
+            rows = []
+            for _ in range(count):
+                row = {}
+                for pn, pt, lt in props:
+                    if lt is None:
+                        row[pn] = np.frombuffer(blob, dtype=e + pt, count=1, offset=pos)[0]; pos += np.dtype(pt).itemsize
+                    else:
+                        n = int(np.frombuffer(blob, dtype=e + pt, count=1, offset=pos)[0]); pos += np.dtype(pt).itemsize
+                        row[pn] = np.frombuffer(blob, dtype=e + lt, count=n, offset=pos).astype(np.int64).tolist(); pos += n * np.dtype(lt).itemsize
+                rows.append(row)
+            if name == "face":
+                key = next((k for k in ("vertex_indices", "vertex_index") if rows and k in rows[0]), None)
+                polys = [r[key] for r in rows] if key else []
+    if verts is None:
+        raise ValueError("%s: no vertex element" % path)
+    if isinstance(polys, np.ndarray) and polys.ndim == 2 and polys.shape[1] == 3:
+        faces = polys.astype(np.int32)
+    else:
+        faces = _fan([list(p_) for p_ in polys])
+    if len(faces) == 0:
+        raise ValueError("%s holds no faces (a point cloud cannot be textured)" % path)
+    return verts, faces, uvs
+
+
+def _ply_vertex_arrays(col, names, count):
+    v = np.stack([col("x"), col("y"), col("z")], -1).astype(np.float32) if count else np.zeros((0, 3), np.float32)
+    for a, b in (("s", "t"), ("u", "v"), ("texture_u", "texture_v")):
+        if a in names and b in names:
+            return v, np.stack([col(a), col(b)], -1).astype(np.float32)
+    return v, None
+
+
+def load_stl(path):
+    """STL, binary or ascii: a triangle soup; bit-equal corners are merged into one vertex (first occurrence order), as trimesh's STL loader followed by
+    merge_vertices does (io/mesh_loader.py:17)."""
+    with open(path, "rb") as f:
+        blob = f.read()
+    tri = None
+    if len(blob) >= 84:
+        n = struct.unpack_from("<I", blob, 80)[0]
+        if 84 + 50 * n == len(blob):         # the binary form's length is exact; an ascii file that starts with 80 bytes of text never satisfies this
+            rec = np.frombuffer(blob, dtype=np.dtype([("n", "<f4", (3,)), ("v", "<f4", (9,)), ("a", "<u2")]), count=n, offset=84)
+            tri = rec["v"].reshape(-1, 3).astype(np.float32)
+    if tri is None:
+        pts = []
+        for line in blob.decode("ascii", "replace").splitlines():
+            t = line.split()
+            if len(t) == 4 and t[0] == "vertex":
+                pts.append((float(t[1]), float(t[2]), float(t[3])))
+        if not pts or len(pts) % 3:
+            raise ValueError("%s is not an STL file" % path)
+        tri = np.asarray(pts, dtype=np.float32)
+    uniq, first, inv = np.unique(tri.view(np.uint32).reshape(-1, 3), axis=0, return_index=True, return_inverse=True)
+    order = np.argsort(first)                 # keep the file's vertex order
+    rank = np.empty_like(order); rank[order] = np.arange(len(order))
+    return tri[first[order]], rank[inv.reshape(-1)].reshape(-1, 3).astype(np.int32)
+
+
+def load_off(path):
+    """Object File Format (OFF / COFF headers; the counts on the header line or on the next; polygons fanned; per-face colours behind the indices ignored)."""
+    with open(path, "r") as f:
+        lines = [t for t in (line.split("#", 1)[0].split() for line in f) if t]
+    if not lines or not lines[0][0].endswith("OFF"):
+        raise ValueError("%s is not an OFF file" % path)
+    head = lines[0][1:]
+    at = 1
+    if len(head) < 2:
+        head, at = lines[1], 2
+    nv, nf = int(head[0]), int(head[1])
+    if len(lines) < at + nv + nf:
+        raise ValueError("%s: OFF header promises %d vertices + %d faces, the file holds %d lines" % (path, nv, nf, len(lines) - at))
+    verts = np.asarray([t[:3] for t in lines[at:at + nv]], dtype=np.float64).astype(np.float32).reshape(nv, 3)      # COFF: colours behind x y z, cut
+    polys = []
+    for t in lines[at + nv:at + nv + nf]:
+        n = int(t[0])
+        polys.append([int(x) for x in t[1:1 + n]])
+    return verts, _fan(polys)
+
+
 def load_mesh(path):
-    """.obj / .glb -> (verts, faces, uvs | None [one per vertex], texture | None)."""
+    """.obj / .glb / .gltf / .ply / .stl / .off -> (verts, faces, uvs | None [one per vertex], texture | None).  The reference hands any path to trimesh.load
+    (io/mesh_loader.py:22-30); these are the formats its own tools name (mesh/structure.py:73-83, render/blender/render_blender.py:59) plus the
+    interchange formats mesh generators write."""
     ext = path.lower().rsplit(".", 1)[-1]
     if ext == "obj":
         v, f, uv, fuv = load_obj(path)
@@ -328,7 +541,18 @@ def load_mesh(path):
         return v, f, uv, None
     if ext == "glb":
         return load_glb(path)
-    raise NotImplementedError("mesh format .%s is not read natively (supported: .obj, .glb)" % ext)
+    if ext == "gltf":
+        return load_gltf(path)
+    if ext == "ply":
+        v, f, uv = load_ply(path)
+        return v, f, uv, None
+    if ext == "stl":
+        v, f = load_stl(path)
+        return v, f, None, None
+    if ext == "off":
+        v, f = load_off(path)
+        return v, f, None, None
+    raise NotImplementedError("mesh format .%s is not read natively (supported: .obj, .glb, .gltf, .ply, .stl, .off)" % ext)
 
 
 def clean_mesh(verts, faces, merge_eps=1e-8):

@@ -60,7 +60,7 @@ class DeviceMesh:
 
 
 def load_device_mesh(path, device):
-    verts, faces, uvs, _ = meshes.load_mesh(path)        # .obj / .glb
+    verts, faces, uvs, _ = meshes.load_mesh(path)        # .obj / .glb / .gltf / .ply / .stl / .off
     if uvs is None:
         raise ValueError("mesh %s has no UVs: run it through meshes.prepare_blank_mesh (pipeline.preprocess_blank_mesh) first" % path)
     return DeviceMesh(verts, faces, uvs, device)
