@@ -99,7 +99,7 @@ int utx_attn_fwd_bf16_kbq(utx_ctx* ctx, const void* q, const void* k, const void
                           int H, int S_q, int S_kv, float softmax_scale, float key_bias_log2, int key_bias_period, utx_stream stream);
 /* The same with CALLER-OWNED scratch for the key-split tail round: work >= utx_attn_workspace_bytes(ctx, H, S_q, S_kv) bytes, 16-byte aligned, used only
  * by the launches of this call (stream-ordered); layout [key-split scratch | one flag byte per 64-query group (the 4 x 64 kernel's headroom record)].  work == NULL or too small:
- * the tail round is not split and the 8 x 32 kernel runs.  utx_attn_plan (pure host arithmetic,
+ * the tail round is not split and the 8 x 32 kernel runs.  Both sizing calls follow the QUERY count and accept S_q > S_kv like the launch itself.  utx_attn_plan (pure host arithmetic,
  * no device): out = {workgroups, workgroups in full rounds of n_cus, key ranges per tail workgroup (1 = not split), 64-key tiles per range}. */
 int utx_attn_fwd_bf16_ws(utx_ctx* ctx, const void* q, const void* k, const void* vt, void* o,
                          long q_hs, long q_ss, long k_hs, long k_ss, long vt_hs, long vt_ds, long o_ss,

@@ -593,6 +593,11 @@ def _sp_worker(rank, world, port, q, zero_text=False, groups=1):
     i0, i1 = m.local_image_range(S_img)
     out_loc = m.forward(lat[i0:i1].contiguous(), 0.5).float().cpu()
     torch.cuda.synchronize()
+    if m.sp_kv_dedup:
+        # S queries over S_k < S keys: the launch must HAVE scratch (flag bytes of the 4 x 64 kernel at least), or it silently runs the 8 x 32 kernel unsplit --
+        # utx_attn_workspace_bytes refused S_q > S_kv until the last session of round 6 while the launcher accepted it
+        assert m.ex.S > m.ex.S_k and int(m.lib.utx_attn_workspace_bytes(m.ctx.handle, m.ex.Hg, m.ex.S, m.ex.S_k)) >= m.ex.Hg * (m.ex.S // 64)
+        assert all(pl["ws"].get("attn_ws") is not None for pl in m._plans.values())
     parts = [torch.empty_like(out_loc) for _ in range(world)]
     dist.all_gather(parts, out_loc)
     if rank == 0:

@@ -186,3 +186,13 @@ def test_sequence_parallel_model_bytes_overlap_window_and_predicted_scaling():
     # the attention launch of 3 heads at P = 8 is ONE launch whose third round is cut along the keys (utx_attn_plan), not 2.32 -> 3 whole rounds
     nwg, nfull, ns, tps = plan(3, 50688, 50688, 256)
     assert (nwg, nfull) == (594, 512) and ns == 3 and (nwg - nfull) * ns <= 256
+    # the de-duplicated sequence-parallel launch has MORE queries than keys (P x 64 text rows among the queries, 64 among the keys): the plan and the scratch size
+    # follow the query count -- a zero here would leave that launch without scratch, i.e. unsplit and on the 8 x 32 kernel
+    for P in (2, 4, 8):
+        S_q, S_k, Hg = P * 64 + 50176, 64 + 50176, 24 // P
+        pq = plan(Hg, S_q, S_k, 256)
+        assert pq[0] == Hg * ((S_q + 255) // 256) and pq[3] * pq[2] >= S_k // 64
+        need = int(lib.utx_attn_workspace_bytes(None, Hg, S_q, S_k))
+        flags = Hg * ((S_q + 255) // 256) * 4
+        split = (pq[0] - pq[1]) * pq[2] * 256 * (128 * 2 + 4) if pq[2] > 1 else 0
+        assert need >= split + flags > 0 and need - split - flags < 256

@@ -232,12 +232,14 @@ int utx_attn_fwd_fp8_ws(utx_ctx* ctx, const void* q8, const void* qs, const void
 
 size_t utx_attn_workspace_bytes(utx_ctx* ctx, int H, int S_q, int S_kv) {
     (void)ctx;
-    if (H <= 0 || S_kv <= 0 || S_q <= 0 || S_q > S_kv) return 0;
+    // S_q > S_kv is a plain case since round 6 (the sequence-parallel launch over de-duplicated text keys); refusing it here left exactly that launch without scratch -- unsplit
+    // and on the 8 x 32 kernel -- while the launcher itself accepted it
+    if (H <= 0 || S_kv <= 0 || S_q <= 0) return 0;
     return utx_attn_workspace_bytes_impl(H, S_q == S_kv ? 0 : S_q, S_kv, utx_ncu());
 }
 
 int utx_attn_plan(int H, int S_q, int S_kv, int n_cus, int out[4]) {
-    if (!out || H <= 0 || S_kv <= 0 || S_q <= 0 || S_q > S_kv || n_cus <= 0) return -2;
+    if (!out || H <= 0 || S_kv <= 0 || S_q <= 0 || n_cus <= 0) return -2;
     options_from_env_once();
     utx_attn_split_plan_impl(H, S_q == S_kv ? 0 : S_q, S_kv, n_cus, out);
     return 0;
