@@ -48,6 +48,11 @@ def test_product_library_has_no_wrong_result_switches():
     assert lib.utx_set_option(b"UTX_NO_SUCH", 1) == -2
     opts = _lib.get_options()
     assert set(opts) == set(_lib.OPTION_NAMES)
+    # the binding's list IS the library's table (capi.cpp kOptions minus the ablation-only names): the conftest guard that fails a test which leaves an option changed
+    # sees exactly the options it can read -- a name missing here would be a switch tests could leak unnoticed
+    import re
+    table = re.findall(r'\{"(UTX_[A-Z0-9_]+)",\s*&UtxOptions::\w+,\s*(true|false)\}', open(os.path.join(ROOT, "unitex_amd", "csrc", "capi.cpp")).read())
+    assert len(table) >= 20 and {n for n, abl in table if abl == "false"} == set(_lib.OPTION_NAMES), sorted({n for n, abl in table if abl == "false"} ^ set(_lib.OPTION_NAMES))
     _lib.set_option("UTX_GEMM_TILE", 128)
     assert _lib.get_options()["UTX_GEMM_TILE"] == 128
     _lib.set_option("UTX_GEMM_TILE", 0)
