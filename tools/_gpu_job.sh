@@ -1,6 +1,6 @@
-# round 6, call 43: epilogue arms of the 4 x 64 attention kernel (ablation library): product stores / no stores (bound) / O through LDS -- bit identity + interleaved timing
+# round 6, call 44: the WHOLE GPU suite on the tree with the S_q > S_kv scratch fix (library changed: capi.cpp)
 cd $GRAFT_REPO_ROOT
 exec < /dev/null
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 900 python tools/attn_q64_epi_ab.py > gpurun_out/r06_attn_q64_epi_ab.log 2>&1; echo "rc=$?"; grep -v amdgpu gpurun_out/r06_attn_q64_epi_ab.log | tail -24
+timeout 2100 python -m pytest tests -q -m gpu --durations=8 > gpurun_out/r06_gpu_suite_closing.log 2>&1; echo "pytest rc=$?"; grep -E "passed|failed" gpurun_out/r06_gpu_suite_closing.log | tail -1; grep -E "^(FAILED|ERROR)" gpurun_out/r06_gpu_suite_closing.log | head -20
