@@ -38,11 +38,14 @@ def _launch_options_do_not_leak():
     kernel (round 6: a `finally` that reset UTX_ATTN_Q64 to its round-5 value 0 put the rest of an alphabetical run on the 8 x 32 attention loop).  So: the
     options as the library first reports them are the defaults; a test that ends with any other value FAILS, and the defaults are put back for the next."""
     global _OPTION_DEFAULTS
+    import os
+    env_before = {k: v for k, v in os.environ.items() if k.startswith("UTX_")}      # the Python host reads its UTX_* switches at use: a variable left set is the same kind of leak
     try:
         from unitex_amd import _lib
         now = _lib.get_options()
     except Exception:
         yield
+        _check_env(env_before)
         return
     if _OPTION_DEFAULTS is None:
         _OPTION_DEFAULTS = dict(now)
@@ -52,4 +55,23 @@ def _launch_options_do_not_leak():
     for k, v in _OPTION_DEFAULTS.items():
         if after.get(k) != v:
             _lib.set_option(k, v)
+    env_leaked = _restore_env(env_before)
     assert not leaked, "test left launch options changed (now, default): %r" % leaked
+    assert not env_leaked, "test left UTX_* environment variables changed (now, before): %r" % env_leaked
+
+
+def _restore_env(before):
+    import os
+    now = {k: v for k, v in os.environ.items() if k.startswith("UTX_")}
+    changed = {k: (now.get(k), before.get(k)) for k in set(now) | set(before) if now.get(k) != before.get(k)}
+    for k, (_, was) in changed.items():
+        if was is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = was
+    return changed
+
+
+def _check_env(before):
+    changed = _restore_env(before)
+    assert not changed, "test left UTX_* environment variables changed (now, before): %r" % changed
