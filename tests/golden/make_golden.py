@@ -424,6 +424,22 @@ def g4_cameras(out):
     np.savez_compressed(os.path.join(out, "g4_cameras.npz"), **fix)
 
 
+def g12_camera_samplers(out):
+    """the camera generators beside the pipeline's own (camera/generator.py:129-151,187-200): seeded hemisphere / sphere / near-front samplers and the Euler grid of
+    export_orbit_video(enhance_mode='canonical') -- outputs only"""
+    gen = importlib.import_module("TextureTools.texturetools.camera.generator")
+    fix = {}
+    fix["canonical_888"] = gen.generate_canonical_views_c2ws(radius=2.8, steps=(8, 8, 8)).numpy()
+    fix["canonical_325"] = gen.generate_canonical_views_c2ws(radius=1.7, steps=(3, 2, 5)).numpy()
+    fix["hemisphere_semi_s7"] = gen.generate_hemisphere_views_c2ws(37, radius=2.8, seed=7, semi=True).numpy()
+    fix["hemisphere_full_s7"] = gen.generate_hemisphere_views_c2ws(37, radius=2.8, seed=7, semi=False).numpy()
+    fix["semisphere_s3"] = gen.generate_semisphere_views_c2ws(29, radius=2.0, seed=3, hemi=False).numpy()
+    fix["semisphere_hemi_s3"] = gen.generate_semisphere_views_c2ws(29, radius=2.0, seed=3, hemi=True).numpy()
+    fix["near_front_s5"] = gen.generate_near_front_views_c2ws(31, radius=2.8, scale_x=0.5, scale_y=0.25, seed=5).numpy()
+    fix["near_front_default_s11"] = gen.generate_near_front_views_c2ws(8, seed=11).numpy()
+    np.savez_compressed(os.path.join(out, "g12_camera_samplers.npz"), **fix)
+
+
 def _sphere():
     from unitex_amd.texturetools.meshes import sphere_with_faces
     return sphere_with_faces(1500)
@@ -681,7 +697,7 @@ def main():
     torch.set_num_threads(4)
     only = set(sys.argv[1:])
     for fn in (g1_pipeline, g2_attention, g3_infer_mv, g4_cameras, g5_image_ops, g67_backprojection, g8_bunny, g9_export_condition, g10_preprocess_image,
-               g11_kdtree_and_filter):
+               g11_kdtree_and_filter, g12_camera_samplers):
         if only and fn.__name__ not in only:
             continue
         fn(out)

@@ -1,7 +1,8 @@
 """Camera helpers with the reference's names and conventions (host-side torch, tiny matrices).
 
 Mirrors TextureTools/texturetools/camera/conversion.py:8-28,50-57 and camera/generator.py:93-114,153-185
-of the reference (pinned by tests/golden/g4_cameras.npz)."""
+of the reference (pinned by tests/golden/g4_cameras.npz); the generators off the pipeline's path (hemisphere / sphere / near-front samplers, the canonical Euler grid:
+camera/generator.py:42-90,129-151,187-200) are pinned by tests/golden/g12_camera_samplers.npz."""
 import math
 
 import torch
@@ -135,6 +136,99 @@ def generate_orbit_views_c2ws(num_views: int, radius: float = 1.0, height: float
     xyz = torch.stack([projected_radius * torch.cos(theta), projected_radius * torch.sin(theta),
                        torch.full((num_views,), fill_value=height, dtype=torch.float32)], dim=-1)
     return lookat_to_matrix(xyz)
+
+
+# ---- the other camera generators of camera/generator.py (not on the texture pipeline's path; export_orbit_video(enhance_mode='canonical') and the reference's data tools use
+# them).  Seeded samplers: the random draws are made in the reference's order so that a seed names the same cameras (tests/golden/g12_camera_samplers.npz).
+
+def _gen(seed):
+    return torch.Generator().manual_seed(seed) if seed is not None else None
+
+
+def _tangent_frame(n: torch.Tensor):
+    """an orthonormal pair (t, b) perpendicular to the unit vectors n [..., 3]: t along (1,1,1) x n, or along (-1,1,1) x n where n is parallel to (1,1,1)
+    (Blender Cycles' make_orthonormals, which camera/generator.py:42-52 follows)"""
+    nx, ny, nz = n[..., 0:1], n[..., 1:2], n[..., 2:3]
+    generic = torch.cat([nz - ny, nx - nz, ny - nx], dim=-1)
+    diagonal = torch.cat([nz - ny, nx + nz, -ny - nx], dim=-1)
+    t = torch.nn.functional.normalize(torch.where((nx != ny) | (nx != nz), generic, diagonal), dim=-1)
+    return t, torch.linalg.cross(n, t)
+
+
+def _concentric_disk(shape, generator=None):
+    """Shirley-Chiu concentric map of two uniform draws on [-1, 1]^2 to the unit disk (camera/generator.py:54-64): draw order a, then b"""
+    a = 2.0 * torch.rand(shape, dtype=torch.float32, generator=generator) - 1.0
+    b = 2.0 * torch.rand(shape, dtype=torch.float32, generator=generator) - 1.0
+    a_leads = a ** 2 > b ** 2
+    r = torch.where(a_leads, a, b)
+    phi = torch.where(a_leads, (torch.pi / 4) * (b / a), (torch.pi / 2) - (torch.pi / 4) * (a / b))
+    return r * torch.cos(phi), r * torch.sin(phi)
+
+
+def _about(n, x, y, z):
+    t, b = _tangent_frame(n)
+    return x * t + y * b + z * n
+
+
+def generate_hemisphere_views_c2ws(num_views: int, radius: float = 1.0, seed=None, semi: bool = True):
+    """cameras scattered over the upper half space about +z (semi) or over both by a coin (camera/generator.py:66-79,129-134).  Bug-compatible on purpose: the reference draws its
+    disk sample PER COMPONENT of the [num_views, 3] axis array (three samples blended through the tangent frame), so the positions are NOT on the sphere of `radius`; a seed
+    names the reference's cameras only if that is reproduced (tests/golden/g12_camera_samplers.npz)."""
+    up = torch.tensor([0.0, 0.0, 1.0]).unsqueeze(0).repeat(num_views, 1)
+    g = _gen(seed)
+    x, y = _concentric_disk(up.shape, generator=g)
+    z = 1 - (x ** 2 + y ** 2)
+    x, y = x * torch.sqrt(z + 1.0), y * torch.sqrt(z + 1.0)
+    if not semi:
+        z = z * torch.where(torch.randn(up.shape, generator=g) > 0.0, 1.0, -1.0)
+    return lookat_to_matrix(radius * _about(up, x, y, z))
+
+
+def generate_semisphere_views_c2ws(num_views: int, radius: float = 1.0, seed=None, hemi: bool = False):
+    """cameras at normalised Gaussian directions -- the whole sphere, or its upper half with hemi (camera/generator.py:136-144)"""
+    d = torch.nn.functional.normalize(torch.randn((num_views, 3), dtype=torch.float32, generator=_gen(seed)), dim=-1)
+    if hemi:
+        d[:, 2] = torch.abs(d[:, 2])
+    return lookat_to_matrix(radius * d)
+
+
+def generate_near_front_views_c2ws(num_views: int, radius: float = 1.0, scale_x: float = 1.0, scale_y: float = 1.0, seed=None):
+    """cameras scattered about the front view +x: a Gaussian offset (scale_x, scale_y) in the tangent plane, pulled back towards the sphere (camera/generator.py:81-90,146-151);
+    drawn per component of the axis array like the hemisphere sampler above (bug-compatible)"""
+    front = torch.tensor([1.0, 0.0, 0.0]).unsqueeze(0).repeat(num_views, 1)
+    g = _gen(seed)
+    x = torch.randn(front.shape, dtype=torch.float32, generator=g)
+    y = torch.randn(front.shape, dtype=torch.float32, generator=g)
+    r = torch.sqrt((scale_x ** 2) * (x ** 2) + (scale_y ** 2) * (y ** 2) + 1)
+    return lookat_to_matrix(radius * _about(front, scale_x * x / r, scale_y * y / r, 1 / r))
+
+
+def _axis_rotation(axis: int, angle: torch.Tensor) -> torch.Tensor:
+    """rotation matrices [..., 3, 3] about coordinate axis 0 / 1 / 2 (right-handed, column vectors)"""
+    c, s = torch.cos(angle), torch.sin(angle)
+    i, j = (axis + 1) % 3, (axis + 2) % 3
+    m = torch.zeros(angle.shape + (3, 3), dtype=angle.dtype)
+    m[..., axis, axis] = 1.0
+    m[..., i, i], m[..., i, j], m[..., j, i], m[..., j, j] = c, -s, s, c
+    return m
+
+
+def euler_xyz_to_matrix(angles: torch.Tensor) -> torch.Tensor:
+    """extrinsic-order product Rx(a0) Ry(a1) Rz(a2) of Euler angles [..., 3] in radians (camera/rotation.py:199-225 with convention 'XYZ')"""
+    rx, ry, rz = (_axis_rotation(k, angles[..., k]) for k in range(3))
+    return torch.matmul(torch.matmul(rx, ry), rz)
+
+
+def generate_canonical_views_c2ws(radius=2.8, steps=(8, 8, 8)):
+    """the Euler grid of export_orbit_video(enhance_mode='canonical'): yaw fastest, then pitch, then roll, each over [0, 360) degrees; the camera sits at R (0, 0, radius)
+    (camera/generator.py:187-200)"""
+    grid = lambda n: [360.0 * i / n for i in range(n)]
+    eulers = torch.tensor([[yaw, pitch, roll] for roll in grid(steps[2]) for pitch in grid(steps[1]) for yaw in grid(steps[0])], dtype=torch.float64).to(torch.float32)
+    rots = euler_xyz_to_matrix(torch.deg2rad(eulers))
+    c2ws = torch.eye(4).repeat(rots.shape[0], 1, 1)
+    c2ws[:, :3, :3] = rots
+    c2ws[:, :3, 3] = torch.matmul(torch.tensor([[0.0, 0.0, float(radius)]]), rots.transpose(1, 2))[:, 0]
+    return c2ws
 
 
 def parse_color(color):

@@ -145,6 +145,8 @@ class VideoExporter:
                               for h in (-2.425, -1.4, 0.0, 1.4, 2.425)])
         elif enhance_mode == "box":
             c2ws = camera.generate_box_views_c2ws(radius=2.8)
+        elif enhance_mode == "canonical":
+            c2ws = camera.generate_canonical_views_c2ws(radius=2.8, steps=(8, 8, 8))      # 512 frames over the Euler grid (export_nvdiffrast_video.py:204-205)
         else:
             raise NotImplementedError("enhance_mode %s is not supported" % enhance_mode)
         intrinsics = (camera.generate_intrinsics(49.1, 49.1, fov=True, degree=True) if perspective
