@@ -593,6 +593,11 @@ def test_interchange_mesh_formats_read_back_the_same_mesh(tmp_path):
             assert np.array_equal(a, b), p
     # refusals
     import pytest
+    js3 = json.loads(json.dumps(js))
+    js3["buffers"][0]["uri"] = "../escape.bin"
+    json.dump(js3, open(str(tmp_path / "escape.gltf"), "w"))
+    with pytest.raises(ValueError, match="outside"):
+        meshes.load_mesh(str(tmp_path / "escape.gltf"))
     open(str(tmp_path / "cloud.ply"), "w").write("ply\nformat ascii 1.0\nelement vertex 1\nproperty float x\nproperty float y\nproperty float z\nend_header\n0 0 0\n")
     with pytest.raises(ValueError):
         meshes.load_mesh(str(tmp_path / "cloud.ply"))

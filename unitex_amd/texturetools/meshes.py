@@ -247,7 +247,11 @@ def _gltf_uri_bytes(uri, path):
         import base64
         return base64.b64decode(uri.split(",", 1)[1])
     from urllib.parse import unquote
-    with open(os.path.join(os.path.dirname(os.path.abspath(path)), unquote(uri)), "rb") as f:
+    base = os.path.dirname(os.path.abspath(path))
+    full = os.path.normpath(os.path.join(base, unquote(uri)))
+    if os.path.commonpath([base, full]) != base:      # a mesh file names its side files; it does not get to name files outside its own directory
+        raise ValueError("%s: uri %r points outside the file's directory" % (path, uri))
+    with open(full, "rb") as f:
         return f.read()
 
 
