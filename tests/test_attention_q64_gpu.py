@@ -113,3 +113,26 @@ def test_launches_the_q64_kernel_does_not_take_run_the_8x32_kernel():
         torch.cuda.synchronize()
     _lib.set_option("UTX_ATTN_Q64", 1)
     assert torch.equal(outs[0], outs[1])
+
+
+def test_both_kernels_at_the_longest_joint_sequence_of_the_bench():
+    """maximum size: the joint strip of BASELINE configs[4]'s resolution in the reference's own semantics (bench.py workload strip2048x8: 8 views of 2048^2 = 131 072 noise +
+    131 072 control + 1024 dual tokens + 64 de-duplicated text rows = 263 232 executed tokens, 4113 key tiles, 1029 query blocks per head) on two heads: every address product
+    beyond the sizes the other tests reach (row offsets past 2^25 elements, V^T rows half a megabyte long), the key-split tail round (2058 work items on 256 CUs), key
+    multiplicity on tile 0.  The 4 x 64 stream and the 8 x 32 loop agree bit for bit, and sampled rows -- first, last, around block and tile edges -- match an fp64 softmax
+    over ALL keys of the bf16 operands."""
+    H, S, kb = 2, 64 + 131072 + 131072 + 1024, 3.0
+    Qh, Kh, Vt = _mk(H, S, 77)
+    ref = _run(False, Qh, Kh, Vt, S, kb)
+    got = _run(True, Qh, Kh, Vt, S, kb)
+    assert torch.isfinite(got.float()).all()
+    assert torch.equal(got.view(torch.int16), ref.view(torch.int16)), "%d of %d elements differ" % (int((got.view(torch.int16) != ref.view(torch.int16)).sum()), got.numel())
+    rows = torch.tensor([0, 63, 64, 255, 256, 65535, 65536, 131071, 131136, 200000, S - 257, S - 256, S - 65, S - 1], device="cuda")
+    for h in range(H):
+        s2 = Qh[h, rows].double() @ Kh[h].double().t()                    # base-2 exponents: Q carries scale * log2(e)
+        s2[:, :64] += kb
+        p = torch.exp2(s2 - s2.max(dim=-1, keepdim=True).values)
+        want = (p @ Vt[h].double().t()) / p.sum(dim=-1, keepdim=True)
+        err = (got[rows][:, h * 128:(h + 1) * 128].double() - want).abs().max().item()
+        # outputs are means over ~2.6e5 keys of unit-variance values: |o| ~ 1e-2; the bound is the small-S tests' bound scaled by that (P is bf16 in the PV product: 2^-9 relative per term)
+        assert err < 4e-4, "head %d: sampled rows differ from the fp64 softmax by %g (max |want| %g)" % (h, err, want.abs().max().item())
